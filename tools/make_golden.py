@@ -1,0 +1,204 @@
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (imported from /root/reference under
+tools/ref_shims).  Build-container only: the GPU box has no /root/reference and only reads the
+committed .npz files.  Fixtures hold inputs/seeds and expected outputs -- never reference source.
+
+    python -m tools.make_golden            # all
+    python -m tools.make_golden policy     # one group
+
+Weights are not stored: oracle/param_fill.fill_module regenerates them bit-identically from
+parameter NAMES on both sides; each fixture records a checksum of the weights it was made with.
+"""
+import sys
+import random
+import numpy as np
+import torch
+
+from tools.ref_build import build_ref_policy, build_ref_unet
+from oracle.param_fill import fill_module
+
+OUT = "tests/golden"
+torch.set_num_threads(8)
+
+
+def wsum(sd):
+    """Order-independent weight checksum (float64 sum of |w| over canonical float tensors)."""
+    return float(sum(v.double().abs().sum() for k, v in sorted(sd.items()) if torch.is_floating_point(v)))
+
+
+def sample_idx(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, n, (k,), generator=g).numpy()
+
+
+def g_tables():
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    d = GoalGaussianDiffusion(torch.nn.Identity(), image_size=(128, 128), channels=21, timesteps=100,
+                              sampling_timesteps=100, loss_type="l2", objective="pred_v", beta_schedule="cosine",
+                              min_snr_loss_weight=True, guidance_weight=0)
+    out = {k: v.numpy() for k, v in d.state_dict().items() if v.dim() == 1 and v.numel() == 100}
+    assert len(out) == 13
+    times = torch.linspace(-1, 99, steps=51)
+    times = list(reversed(times.int().tolist()))
+    out["ddim_pairs_100_50"] = np.array(list(zip(times[:-1], times[1:])), dtype=np.int64)
+    # third-party restated (diffusers, via tools/ref_shims): tagged, parity unpinned
+    from diffusers.schedulers.scheduling_ddpm import DDPMScheduler
+    from diffusers.schedulers.scheduling_ddim import DDIMScheduler
+    s = DDPMScheduler(num_train_timesteps=100, beta_schedule="squaredcos_cap_v2")
+    out["thirdparty_squaredcos_alphas_cumprod"] = s.alphas_cumprod.numpy()
+    s2 = DDIMScheduler(num_train_timesteps=100, beta_schedule="squaredcos_cap_v2")
+    s2.set_timesteps(8)
+    out["thirdparty_ddim8_timesteps"] = s2.timesteps.numpy()
+    np.savez_compressed(f"{OUT}/tables.npz", **out)
+    print("tables", {k: v.shape for k, v in out.items()})
+
+
+def g_unet_tiny():
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    torch.manual_seed(0)
+    m = build_ref_unet(tiny=True).eval()
+    sd = fill_module(m, seed=11)
+    out = {"weights_abs_sum": wsum(sd), "param_names": np.array(sorted(n for n, _ in m.named_parameters()))}
+    g = torch.Generator().manual_seed(100)
+    B, f, H, W = 2, 3, 32, 32
+    x = torch.randn(B, (f + 1) * 3, H, W, generator=g)
+    t = torch.tensor([7, 93])
+    te = torch.randn(B, 6, 512, generator=g)
+    with torch.no_grad():
+        y = m(x, t, te)
+    out.update(fwd_x=x.numpy(), fwd_t=t.numpy(), fwd_te=te.numpy(), fwd_y=y.numpy())
+    x_cond = torch.rand(B, 3, H, W, generator=g)
+    out["x_cond"] = x_cond.numpy()
+    for name, steps, gw in [("ddpm100", 100, 0.0), ("ddim50", 50, 0.0), ("ddim10_cfg", 10, 1.5)]:
+        d = GoalGaussianDiffusion(m, image_size=(H, W), channels=3 * f, timesteps=100, sampling_timesteps=steps,
+                                  loss_type="l2", objective="pred_v", beta_schedule="cosine",
+                                  min_snr_loss_weight=True, guidance_weight=gw).eval()
+        torch.manual_seed(1234)   # noise stream: randn(shape) then one randn_like per step (Appendix A item 7)
+        with torch.no_grad():
+            img = d.sample(x_cond, te, batch_size=B)
+        out[f"sample_{name}"] = img.numpy()
+    np.savez_compressed(f"{OUT}/unet_tiny.npz", **out)
+    print("unet_tiny ok", out["weights_abs_sum"])
+
+
+def g_unet_full():
+    torch.manual_seed(0)
+    m = build_ref_unet(tiny=False).eval()
+    sd = fill_module(m, seed=12)
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(1, 24, 128, 128, generator=g)
+    t = torch.tensor([41])
+    te = torch.randn(1, 10, 512, generator=g)
+    with torch.no_grad():
+        y = m(x, t, te)
+    idx = sample_idx(y.numel(), 4096, 5)
+    np.savez_compressed(f"{OUT}/unet_libero_full.npz", weights_abs_sum=wsum(sd), n_params=sum(p.numel() for p in m.parameters()),
+                        idx=idx, y_sampled=y.flatten()[idx].numpy(), y_sum=float(y.double().sum()),
+                        y_abs_sum=float(y.double().abs().sum()), n_state=len(sd))
+    print("unet_full ok", float(y.double().abs().sum()))
+
+
+def g_policy():
+    torch.manual_seed(0)
+    pol = build_ref_policy()
+    sd = fill_module(pol, seed=13)
+    names = [n for n, p in pol.named_parameters() if p.requires_grad and n not in ("_dummy_variable", "obs_encoder._dummy_variable")]
+    out = {"weights_abs_sum": wsum(sd), "param_names": np.array(names), "state_keys": np.array(list(sd.keys())),
+           "n_params": sum(p.numel() for p in pol.parameters())}
+    g = torch.Generator().manual_seed(102)
+    B = 2
+    batch = {"obs": {"img_obs_1": torch.rand(B, 1, 3, 128, 128, generator=g),
+                     "img_goal_1": torch.rand(B, 1, 3, 128, 128, generator=g)},
+             "action": torch.rand(B, 16, 7, generator=g) * 2 - 1}
+    out.update(img_obs=batch["obs"]["img_obs_1"].numpy(), img_goal=batch["obs"]["img_goal_1"].numpy(),
+               action=batch["action"].numpy())
+    # compute_loss RNG order in train mode: SpatialSoftmax draws randn_like(kp) per encoder (noise_std=0),
+    # then noise = randn(B,16,7), then t = randint(0,100,(B,))  (base_nets.py:262-264; policy :246-252)
+    pol.train()
+    torch.manual_seed(55)
+    loss = pol.compute_loss(batch)
+    loss.backward()
+    torch.manual_seed(55)
+    torch.randn(B, 32, 2); torch.randn(B, 32, 2)
+    noise = torch.randn(B, 16, 7)
+    ts = torch.randint(0, 100, (B,)).long()
+    out.update(loss=loss.item(), noise=noise.numpy(), timesteps=ts.numpy())
+    gn, gs = [], []
+    P = dict(pol.named_parameters())
+    for n in names:
+        gr = P[n].grad
+        gn.append(float(gr.double().norm()))
+        idx = sample_idx(gr.numel(), 8, 9)
+        gs.append(gr.flatten()[idx].numpy())
+    out.update(grad_norms=np.array(gn), grad_samples=np.stack(gs))
+    # 3 optimiser steps: clip 1.0 -> AdamW -> zero -> EMA(power .75) exactly as lb_online_trainer_v7.py:604-624
+    from ema_pytorch import EMA
+    opt = torch.optim.AdamW(pol.parameters(), lr=1e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6)
+    ema = EMA(pol, update_after_step=0, inv_gamma=1.0, power=0.75, min_value=0.0, update_every=1, include_online_model=False)
+    losses, norms = [], []
+    for it in range(3):
+        torch.manual_seed(60 + it)
+        l = pol.compute_loss(batch)
+        opt.zero_grad()
+        l.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(pol.parameters(), 1.0)))
+        opt.step(); opt.zero_grad(); ema.update()
+        losses.append(l.item())
+    out.update(train_losses=np.array(losses), train_gnorms=np.array(norms),
+               train_param_norms=np.array([float(P[n].double().norm()) for n in names]),
+               train_ema_norms=np.array([float(dict(ema.ema_model.named_parameters())[n].double().norm()) for n in names]),
+               thirdparty_note=np.array("AdamW/clip from torch (present); EMA via restated ema_pytorch 0.2.3; "
+                                        "resnet18 topology + diffusers schedulers restated: parity unpinned"))
+    # predict_action on the ORIGINAL weights
+    pol2 = build_ref_policy()
+    fill_module(pol2, seed=13)
+    pol2.eval()
+    torch.manual_seed(70)
+    o = pol2.predict_action(batch["obs"], use_ddim=True)
+    out.update(ddim_action=o["action"].numpy(), ddim_action_pred=o["action_pred"].numpy())
+    torch.manual_seed(71)
+    o = pol2.predict_action(batch["obs"], use_ddim=False)
+    out.update(ddpm_action_pred=o["action_pred"].numpy())
+    np.savez_compressed(f"{OUT}/policy.npz", **out)
+    print("policy ok loss", out["loss"], "train", losses, norms)
+
+
+def g_replay():
+    from diffuser.datasets.env_img_replay_buffer import Global_EnvReplayBuffer_Img
+
+    class _EnvList:
+        camera_list = ["agentview"]
+
+    out = {}
+    for seed in (0, 123, 9001):
+        rng = np.random.RandomState(seed + 1)
+        lens = rng.randint(121, 145, size=12)
+        buf = Global_EnvReplayBuffer_Img(task_list=["t"], max_num_unitBufs=1200, max_len_uB=700, min_len_uB=30,
+                                         env_list=_EnvList(), render_img_size=(4, 4),
+                                         env_buf_config={"sample_act_seq_len": 16})
+        for e, L in enumerate(lens):
+            # payload encodes (episode, frame) so the gather can be checked exactly: img[...] = e*1000 + i
+            imgs = [torch.full((3, 4, 4), float(e * 1000 + i)) for i in range(L)]
+            acts = [torch.full((7,), float(e * 1000 + i)) for i in range(L - 1)]
+            buf.add_one_episode("t", "agentview", e, imgs, acts)
+        np.random.seed(seed); random.seed(seed)
+        eps, starts = [], []
+        for _ in range(5):
+            s, gl, a, _, info = buf.sample_random_batch_seq(64)
+            ep = (s[:, 0, 0, 0] // 1000).long().numpy()
+            st = (s[:, 0, 0, 0] % 1000).long().numpy()
+            assert ((gl[:, 0, 0, 0] % 1000).long().numpy() == st + 16).all()
+            assert (a[:, 0, 0].long().numpy() == ep * 1000 + st).all() and a.shape == (64, 16, 7)
+            eps.append(ep); starts.append(st)
+        out[f"lens_{seed}"] = lens
+        out[f"episodes_{seed}"] = np.stack(eps)
+        out[f"starts_{seed}"] = np.stack(starts)
+    np.savez_compressed(f"{OUT}/replay.npz", **out)
+    print("replay ok", out["episodes_123"][0][:8], out["starts_123"][0][:8])
+
+
+GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(GROUPS)
+    for w in which:
+        GROUPS[w]()
