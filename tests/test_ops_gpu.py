@@ -1,0 +1,272 @@
+"""Per-kernel parity: every HIP op (through the C ABI) against a plain torch-CPU fp32 restatement of the same op.
+Tolerance: 1e-4 relative to the tensor's max magnitude (north_star's fp32 budget), typically met at ~1e-6."""
+import math
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, tol=1e-4, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def nhwc(x):  # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().to(dev())
+
+
+def nchw(y):
+    return y.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 16, 16, 64, 3, 1, 1),
+    (2, 64, 16, 16, 128, 3, 2, 1),
+    (3, 128, 9, 7, 96, 1, 1, 0),
+    (2, 3, 32, 32, 64, 7, 2, 3),       # scalar gather path (Cin % 16 != 0)
+    (1, 6, 12, 12, 32, 3, 1, 1),
+    (2, 256, 8, 8, 512, 3, 1, 1),
+    (4, 32, 64, 64, 3, 3, 1, 1),       # Cout = 3 (final video conv)
+    (1, 512, 4, 4, 512, 3, 1, 1),      # small M, large K -> split-K
+    (40, 48, 20, 20, 80, 3, 1, 1),     # M > 4096 -> 128-row tiles, ragged N
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_and_grads(case):
+    from v2a_hip import ops
+    N, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g)
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = ops.pack_weight(w.detach().to(dev()), 0)
+    yd = ops.conv2d(nhwc(x.detach()), wp, b.to(dev()), Cout, k, k, (s, s), (p, p))
+    close(nchw(yd), y, what="conv fwd")
+    # weight gradient
+    dw = ops.conv2d_wgrad(nhwc(x.detach()), nhwc(dy), tuple(w.shape), k, k, (s, s), (p, p))
+    close(dw, w.grad, what="conv wgrad")
+    # data gradient = same kernel, flipped/transposed pack, input dilation = stride
+    wd = ops.pack_weight(w.detach().to(dev()), 1)
+    dx = ops.conv2d(nhwc(dy), wd, None, Cin, k, k, (1, 1), (k - 1 - p, k - 1 - p), idil=s, out_hw=(H, W))
+    close(nchw(dx), x.grad, what="conv dgrad")
+
+
+def test_conv_epilogue_concat_upsample_split():
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(7)
+    N, C1, C2, H, W, Cout = 4, 32, 48, 6, 6, 64
+    x1 = torch.randn(N, C1, H, W, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 20
+    b = torch.randn(Cout, generator=g)
+    rv = torch.randn(2, Cout, generator=g)          # per-batch vector, 2 "batches" of 2 images
+    xin = torch.cat([x1, x2], 1)
+    up = F.interpolate(xin, scale_factor=2, mode="nearest")
+    res = torch.randn(N, Cout, 2 * H, 2 * W, generator=g)
+    ref = F.conv2d(up, w, b, padding=1) + rv.repeat_interleave(2, 0)[:, :, None, None] + res
+    wp = ops.pack_weight(w.to(dev()), 0)
+    y = ops.conv2d(nhwc(x1), wp, b.to(dev()), Cout, 3, 3, (1, 1), (1, 1), x2=nhwc(x2), rowvec=rv.to(dev()),
+                   rows_per_batch=2 * (2 * H) * (2 * W), residual=nhwc(res), ups=True)
+    close(nchw(y), ref, what="concat+upsample+epilogue")
+    # split output channels into two buffers
+    ya = torch.empty(N, 2 * H, 2 * W, 24, device=dev())
+    yb = torch.empty(N, 2 * H, 2 * W, Cout - 24, device=dev())
+    ops.conv2d(nhwc(x1), wp, b.to(dev()), Cout, 3, 3, (1, 1), (1, 1), x2=nhwc(x2), ups=True, y=ya, y2=yb, csplit=24)
+    ref2 = F.conv2d(up, w, b, padding=1)
+    close(nchw(ya), ref2[:, :24], what="csplit a")
+    close(nchw(yb), ref2[:, 24:], what="csplit b")
+
+
+def test_temporal_conv_as_3x1_view():
+    """Conv3d temporal part: Conv1d(k=3) over frames with zero pad 1+1 == (3x1) conv on [B, F, (H W), C]."""
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, Fr, H, W = 2, 32, 5, 4, 6
+    x = torch.randn(B, C, Fr, H, W, generator=g)
+    w = torch.randn(C, C, 3, generator=g) / 10
+    b = torch.randn(C, generator=g)
+    z = x.permute(0, 3, 4, 1, 2).reshape(B * H * W, C, Fr)
+    ref = F.conv1d(F.pad(z, (1, 1)), w, b).reshape(B, H, W, C, Fr).permute(0, 3, 4, 1, 2)
+    xcl = x.permute(0, 2, 3, 4, 1).contiguous().to(dev())            # [B,F,H,W,C]
+    wp = ops.pack_weight(w.to(dev()), 0)                              # [Cout][1][3][Cin] == [Cout][3][1][Cin]
+    y = ops.conv2d(xcl.view(B, Fr, H * W, C), wp, b.to(dev()), C, 3, 1, (1, 1), (1, 0))
+    y = y.view(B, Fr, H, W, C).permute(0, 4, 1, 2, 3).cpu()
+    close(y, ref, what="temporal conv")
+
+
+def test_conv1d_and_transposed():
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, T = 8, 64, 96, 16
+    x = torch.randn(B, Cin, T, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 5, generator=g) / 18).requires_grad_(True)
+    b = torch.randn(Cout, generator=g)
+    y = F.conv1d(x, w, b, padding=2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 1).contiguous().to(dev()).view(B, 1, T, Cin)
+    yd = ops.conv2d(xd, ops.pack_weight(w.detach().to(dev()), 0), b.to(dev()), Cout, 1, 5, (1, 1), (0, 2))
+    close(yd.view(B, T, Cout).permute(0, 2, 1), y, what="conv1d")
+    dyd = dy.permute(0, 2, 1).contiguous().to(dev()).view(B, 1, T, Cout)
+    dw = ops.conv2d_wgrad(xd, dyd, tuple(w.shape), 1, 5, (1, 1), (0, 2))
+    close(dw, w.grad, what="conv1d wgrad")
+    # ConvTranspose1d(k4, s2, p1): forward = dgrad-style conv (pack mode 1, idil 2, pad k-1-p)
+    wt = (torch.randn(Cin, Cout, 4, generator=g) / 16).requires_grad_(True)     # torch layout [Cin][Cout][K]
+    bt = torch.randn(Cout, generator=g)
+    x2 = torch.randn(B, Cin, 8, generator=g, requires_grad=True)
+    yt = F.conv_transpose1d(x2, wt, bt, stride=2, padding=1)
+    dyt = torch.randn(yt.shape, generator=g)
+    yt.backward(dyt)
+    x2d = x2.detach().permute(0, 2, 1).contiguous().to(dev()).view(B, 1, 8, Cin)
+    wtp = ops.pack_weight(wt.detach().to(dev()), 1)      # regular-conv view: [Cout'=Cin][Cin'=Cout][K] -> dgrad pack
+    ytd = ops.conv2d(x2d, wtp, bt.to(dev()), Cout, 1, 4, (1, 1), (0, 2), idil=2, out_hw=(1, 16))
+    close(ytd.view(B, 16, Cout).permute(0, 2, 1), yt, what="convtranspose1d fwd")
+    # its data gradient: regular stride-2 conv over dy with the forward pack of the same tensor
+    dytd = dyt.permute(0, 2, 1).contiguous().to(dev()).view(B, 1, 16, Cout)
+    dx2 = ops.conv2d(dytd, ops.pack_weight(wt.detach().to(dev()), 0), None, Cin, 1, 4, (1, 2), (0, 1))
+    close(dx2.view(B, 8, Cin).permute(0, 2, 1), x2.grad, what="convtranspose1d dgrad")
+    # its weight gradient: wgrad of the regular conv with roles swapped (input = dy, output-grad = x)
+    dwt = ops.conv2d_wgrad(dytd, x2d, tuple(wt.shape), 1, 4, (1, 2), (0, 1))
+    close(dwt, wt.grad, what="convtranspose1d wgrad")
+
+
+def test_linear_and_colsum():
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(64, 256, generator=g)
+    w = torch.randn(2048, 256, generator=g) / 16
+    b = torch.randn(2048, generator=g)
+    y = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()))
+    close(y, F.linear(x, w, b), what="linear")
+    close(ops.colsum(x.to(dev())), x.sum(0), what="colsum")
+
+
+GN_CASES = [
+    # N, S, C, G, act, residual, film
+    (2, 7 * 32 * 32, 128, 32, "silu", False, False),     # large path (video resblock)
+    (3, 64 * 64, 64, 4, "relu", True, False),            # large path + residual (resnet)
+    (4, 257, 384, 32, "silu", False, False),             # large path, ragged rows, L4 not dividing 256
+    (8, 16, 256, 8, "mish", False, True),                # small path + FiLM (conv1d block)
+    (8, 4, 1024, 8, "mish", False, False),
+    (6, 16, 512, 32, "relu", True, False),               # resnet layer4 small path + residual
+    (5, 64, 640, 32, "none", False, False),              # attention norm (per frame)
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+def test_groupnorm_fwd_bwd(case):
+    from v2a_hip import ops
+    N, S, C, G, act, use_res, use_film = case
+    g = torch.Generator().manual_seed(N * S + C)
+    x = (torch.randn(N, C, S, generator=g) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    res = torch.randn(N, C, S, generator=g).requires_grad_(True) if use_res else None
+    film = torch.randn(N, 2, C, generator=g).requires_grad_(True) if use_film else None
+    z = F.group_norm(x, G, gamma, beta, eps=1e-5)
+    if use_res:
+        z = z + res
+    a = {"silu": F.silu, "relu": F.relu, "mish": F.mish, "none": lambda v: v}[act](z)
+    if use_film:
+        a = film[:, 0, :, None] * a + film[:, 1, :, None]
+    dout = torch.randn(a.shape, generator=g)
+    a.backward(dout)
+    cl = lambda t: t.detach().permute(0, 2, 1).contiguous().to(dev())
+    xd = cl(x)
+    yd, mean, rstd = ops.groupnorm_fwd(xd, gamma.detach().to(dev()), beta.detach().to(dev()), G, act,
+                                       residual=cl(res) if use_res else None,
+                                       film=film.detach().to(dev()) if use_film else None)
+    close(yd.permute(0, 2, 1), a, what="gn fwd")
+    dx, dgam, dbet, dres, dfilm = ops.groupnorm_bwd(xd, gamma.detach().to(dev()), beta.detach().to(dev()), G, cl(dout), mean, rstd,
+                                                    act, residual=cl(res) if use_res else None,
+                                                    film=film.detach().to(dev()) if use_film else None,
+                                                    want_dres=use_res, want_dfilm=use_film)
+    close(dx.permute(0, 2, 1), x.grad, what="gn dx")
+    close(dgam, gamma.grad, what="gn dgamma")
+    close(dbet, beta.grad, what="gn dbeta")
+    if use_res:
+        close(dres.permute(0, 2, 1), res.grad, what="gn dres")
+    if use_film:
+        close(dfilm, film.grad, what="gn dfilm")
+
+
+@pytest.mark.parametrize("L,heads,ch,n", [(256, 4, 32, 3), (64, 5, 32, 7), (16, 2, 16, 2), (1024, 2, 32, 1)])
+def test_attention(L, heads, ch, n):
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(L + heads)
+    C = heads * ch
+    qkv = torch.randn(n, 3 * C, L, generator=g)          # reference layout [N, 3C, L]
+    q, k, v = qkv.reshape(n * heads, 3 * ch, L).split(ch, dim=1)
+    s = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", w, v).reshape(n, C, L)
+    out = ops.attention(qkv.permute(0, 2, 1).contiguous().to(dev()).view(n * L, 3 * C), n, L, heads, ch)
+    close(out.view(n, L, C).permute(0, 2, 1), ref, what="attention")
+
+
+def test_maxpool_and_spatial_softmax():
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 16, 20, 20, generator=g, requires_grad=True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yd, idx = ops.maxpool_fwd(nhwc(x.detach()))
+    close(nchw(yd), y, what="maxpool fwd")
+    dx = ops.maxpool_bwd(nhwc(dy), idx, (3, 20, 20, 16))
+    close(nchw(dx), x.grad, what="maxpool bwd")
+    import numpy as np
+    B, K, H, W = 4, 32, 4, 4
+    f = torch.randn(B, K, H, W, generator=g, requires_grad=True)
+    px, py = np.meshgrid(np.linspace(-1., 1., W), np.linspace(-1., 1., H))
+    px = torch.from_numpy(px.reshape(1, H * W)).float()
+    py = torch.from_numpy(py.reshape(1, H * W)).float()
+    att = F.softmax(f.reshape(-1, H * W), dim=-1)
+    kp = torch.cat([(px * att).sum(1, keepdim=True), (py * att).sum(1, keepdim=True)], 1).view(B, K * 2)
+    dkp = torch.randn(kp.shape, generator=g)
+    kp.backward(dkp)
+    kpd, attd = ops.spatial_softmax_fwd(nhwc(f.detach()))
+    close(kpd, kp, what="spatial softmax fwd")
+    df = ops.spatial_softmax_bwd(attd, kpd, dkp.to(dev()))
+    close(nchw(df), f.grad, what="spatial softmax bwd")
+
+
+def test_elementwise_bits():
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1000, generator=g) * 3
+    for act, fn in [("silu", F.silu), ("mish", F.mish), ("relu", F.relu), ("gelu", F.gelu)]:
+        close(ops.act_fwd(x.to(dev()), act), fn(x), what=act)
+    xr = x.clone().requires_grad_(True)
+    F.mish(xr).backward(torch.ones_like(xr))
+    close(ops.act_bwd(x.to(dev()), torch.ones(1000, device=dev()), "mish"), xr.grad, what="mish bwd")
+    t = torch.tensor([0, 7, 50, 99])
+    half = 64
+    e = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    ref = torch.cat(((t[:, None] * e[None]).sin(), (t[:, None] * e[None]).cos()), -1)
+    close(ops.sincos_embed(t.to(dev()), 128, 0), ref, what="SinusoidalPosEmb")
+    fr = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    a = t[:, None].float() * fr[None]
+    close(ops.sincos_embed(t.to(dev()), 128, 1), torch.cat([torch.cos(a), torch.sin(a)], -1), what="timestep_embedding")
+    img = torch.rand(2, 3, 8, 8, generator=g)
+    close(ops.nchw_to_nhwc(img.to(dev()), normalize=True).permute(0, 3, 1, 2), 2 * img - 1, what="nchw->nhwc")
+    u8 = (img * 255).to(torch.uint8)
+    close(ops.nchw_to_nhwc(u8.to(dev()), normalize=False).permute(0, 3, 1, 2), u8.float() / 255, what="u8 convert")
+    ln_x = torch.randn(10, 512, generator=g)
+    gg, bb = torch.randn(512, generator=g), torch.randn(512, generator=g)
+    close(ops.layernorm(ln_x.to(dev()), gg.to(dev()), bb.to(dev())), F.layer_norm(ln_x, (512,), gg, bb), what="layernorm")

@@ -1,0 +1,71 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of libv2a_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define V2A_OK 0
+#define V2A_ERR_ARG -1
+#define V2A_ERR_LAUNCH -2
+#define V2A_ERR_WORKSPACE -3
+
+#define V2A_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return V2A_ERR_LAUNCH;       \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// activation ids shared by norm/elementwise kernels and the C ABI
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_MISH = 3, ACT_GELU = 4 };
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case ACT_SILU: return x / (1.0f + expf(-x));
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_MISH: {
+            // x * tanh(softplus(x)), softplus with torch's threshold 20
+            float sp = x > 20.f ? x : log1pf(expf(x));
+            return x * tanhf(sp);
+        }
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        default: return x;
+    }
+}
+
+// d act(x) / dx
+__device__ __forceinline__ float act_bwd(float x, int act) {
+    switch (act) {
+        case ACT_SILU: {
+            float s = 1.0f / (1.0f + expf(-x));
+            return s * (1.0f + x * (1.0f - s));
+        }
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case ACT_MISH: {
+            float sp = x > 20.f ? x : log1pf(expf(x));
+            float t = tanhf(sp);
+            float sg = 1.0f / (1.0f + expf(-x));   // d softplus / dx
+            return t + x * (1.0f - t * t) * sg;
+        }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

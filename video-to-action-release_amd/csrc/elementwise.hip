@@ -1,0 +1,355 @@
+// HBM-bound elementwise / small-reduction kernels of the hot path (gfx950).  All fp32, channels-last.
+#include "common.h"
+
+#define GRID_FOR(total) dim3((unsigned)((((size_t)(total) + 255) / 256) > 8192 ? 8192 : (((size_t)(total) + 255) / 256)))
+
+// ----------------------------------------------------------------------------------------- activations / axpy
+__global__ void act_fwd_kernel(const float* x, float* y, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = act_fwd(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* x, const float* dy, float* dx, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = dy[i] * act_bwd(x[i], act);
+}
+// out = a + alpha * b
+__global__ void axpy_kernel(const float* a, const float* b, float* out, float alpha, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a[i] + alpha * b[i];
+}
+// strided 2-D copy: dst[r][dc0 + c] = src[r][sc0 + c]
+__global__ void copy2d_kernel(const float* src, float* dst, int rows, int cols, int lds_, int ldd, int accumulate) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const float v = src[(size_t)r * lds_ + c];
+        float* d = dst + (size_t)r * ldd + c;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+// out[c] = sum_r x[r][c]   (bias gradients); one wave per 64 columns, fp64 accumulate across row-chunks
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int rows, int cols, int accumulate) {
+    __shared__ double sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    double s = 0.0;
+    if (c < cols)
+        for (int r = w; r < rows; r += 4) s += (double)x[(size_t)r * cols + c];
+    sm[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) {
+        double t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
+}
+
+// ----------------------------------------------------------------------------------------- embeddings
+// kind 0: policy SinusoidalPosEmb (reference positional_embedding.py:10-17): [sin | cos], freq_i = exp(-ln(1e4)/(half-1) * i)
+// kind 1: video timestep_embedding (reference nn.py:171-189):               [cos | sin], freq_i = exp(-ln(1e4) * i / half)
+__global__ void sincos_embed_kernel(const int64_t* t, float* out, int B, int dim, int kind) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, k = i % half;
+    const float tv = (float)t[b];
+    float f;
+    if (kind == 0) f = expf((float)k * -(logf(10000.f) / (float)(half - 1)));
+    else f = expf(-logf(10000.f) * (float)k / (float)half);
+    const float a = tv * f;
+    if (kind == 0) { out[(size_t)b * dim + k] = sinf(a); out[(size_t)b * dim + half + k] = cosf(a); }
+    else { out[(size_t)b * dim + k] = cosf(a); out[(size_t)b * dim + half + k] = sinf(a); }
+}
+
+// ----------------------------------------------------------------------------------------- policy DDPM glue
+// noisy = sqrt(ac[t_b]) * act + sqrt(1 - ac[t_b]) * noise   (reference diffusion_unet_image_policy.py:255; normalise = identity for
+// the Libero action limits [-1, 1]: normalizer.py:139-146 gives 2*((a+1)/2)-1 which is evaluated literally here)
+__global__ void add_noise_kernel(const float* act, const float* noise, const int64_t* t, const float* ac, float* out, int B, int per) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * per) return;
+    const int b = i / per;
+    const float a = ac[t[b]];
+    const float na = 2.0f * ((act[i] - (-1.0f)) / (1.0f - (-1.0f))) - 1.0f;
+    out[i] = sqrtf(a) * na + sqrtf(1.0f - a) * noise[i];
+}
+// loss = mean((pred - target)^2) ; dpred = 2 (pred - target) / n      (single workgroup: n = B*16*7 is tiny)
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* pred, const float* target, float* loss, float* dpred, int n) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = pred[i] - target[i];
+        s += (double)d * d;
+        if (dpred) dpred[i] = 2.0f * d / (float)n;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (double)n);
+}
+// DDPM / DDIM scheduler step on the action trajectory (third-party diffusers algorithm, restated: see oracle/schedulers.py)
+// coef = {sqrt_b_t, sqrt_a_t, c0, ct, sigma} (DDPM) or {sqrt_b_t, sqrt_a_t, sqrt_a_prev, dir, 0} (DDIM, mode 1)
+__global__ void policy_sched_step_kernel(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb,
+                                         float c_sa, float c0, float c1, float sigma, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x0 = (sample[i] - c_sb * eps[i]) / c_sa;
+    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    float v;
+    if (mode == 0) {
+        v = c0 * x0 + c1 * sample[i];
+        if (noise) v += sigma * noise[i];
+    } else {
+        v = c0 * x0 + c1 * eps[i];
+    }
+    out[i] = v;
+}
+// unnormalize actions: clamp to [-1,1] only if ANY element is out of range (normalizer.py:152-157), then (x+1)/2*2-1.
+__global__ __launch_bounds__(256) void unnormalize_action_kernel(const float* x, float* out, int n) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    int f = 0;
+    for (int i = threadIdx.x; i < n; i += 256) f |= (x[i] > 1.f || x[i] < -1.f);
+    if (f) atomicOr(&any, 1);
+    __syncthreads();
+    const int clampit = any;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = x[i];
+        if (clampit) v = fminf(fmaxf(v, -1.f), 1.f);
+        v = (v + 1.f) / 2.0f;
+        out[i] = v * (1.0f - (-1.0f)) + (-1.0f);
+    }
+}
+
+// ----------------------------------------------------------------------------------------- layout converters
+// NCHW float (or uint8) image batch -> NHWC float, with the policy image normalisation 2*x-1 when `normalize`
+// (reference normalizer.py:139-146 with min 0 / max 1).  u8 sources are divided by 255 first (img_utils.py:27-37).
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const T* src, float* dst, int N, int C, int HW, int normalize, float scale) {
+    const size_t total = (size_t)N * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int hw = (int)(t % HW);
+        const int n = (int)(t / HW);
+        float v = (float)src[((size_t)n * C + c) * HW + hw] * scale;
+        if (normalize) v = 2.0f * ((v - 0.0f) / (1.0f - 0.0f)) - 1.0f;
+        dst[i] = v;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int N, int C, int HW) {
+    const size_t total = (size_t)N * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const size_t t = i / HW;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        dst[i] = src[((size_t)n * HW + hw) * C + c];
+    }
+}
+
+// ----------------------------------------------------------------------------------------- video sampler glue
+// Unet_Libero input pack (reference unet.py:217-220): img [B, 3f, H, W] ('b (f c) h w'), x_cond [B,3,H,W]
+//   -> xin [B, f, H, W, 6] channels-last (3 noisy + 3 cond, cond repeated over frames)
+__global__ void video_pack_kernel(const float* img, const float* cond, float* xin, int B, int f, int HW) {
+    const size_t total = (size_t)B * f * HW * 6;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % 6);
+        size_t t = i / 6;
+        const int hw = (int)(t % HW);
+        t /= HW;
+        const int fr = (int)(t % f);
+        const int b = (int)(t / f);
+        float v;
+        if (c < 3) v = img[(((size_t)b * f + fr) * 3 + c) * HW + hw];
+        else v = cond[((size_t)b * 3 + (c - 3)) * HW + hw];
+        xin[i] = v;
+    }
+}
+// One fused denoise step on the sampler state (reference goal_diffusion.py:484-497,549-580,617-634), v-prediction.
+//   v: UNet output [B, f, H, W, 3] channels-last (for CFG: v_u = unconditional half, gw > 0)
+//   img/out: [B, 3f, H, W]   noise: same layout or null
+// mode 0 (ancestral): x0 = clamp(sa*x - s1*v); out = c1*x0 + c2*x + sigma*noise
+// mode 1 (DDIM):      x0 = sa*x - s1*v; eps = (ra*x - x0)/rm; out = sqrt(a_next)*x0 + c*eps + sigma*noise
+// mode 2 (DDIM last): out = x0
+// final=1 additionally applies unnormalize + clamp: out = clamp((out+1)/2, 0, 1)   (:640, :650)
+struct DenoiseCoef { float sa, s1, ra, rm, c1, c2, sigma, gw; };
+__global__ void video_denoise_kernel(const float* v, const float* v_u, const float* img, const float* noise, float* out,
+                                     int B, int f, int HW, DenoiseCoef k, int mode, int final) {
+    const size_t total = (size_t)B * f * 3 * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        size_t t = i / HW;
+        const int c = (int)(t % 3);
+        t /= 3;
+        const int fr = (int)(t % f);
+        const int b = (int)(t / f);
+        const size_t vi = ((((size_t)b * f + fr) * HW) + hw) * 3 + c;
+        const float x = img[i];
+        float x0, eps;
+        if (k.gw > 0.f) {
+            const float x0c = k.sa * x - k.s1 * v[vi];
+            const float x0u = k.sa * x - k.s1 * v_u[vi];
+            const float nu = (k.ra * x - x0u) / k.rm;
+            const float nc = (k.ra * x - x0c) / k.rm;
+            eps = (1.f + k.gw) * nc - k.gw * nu;
+            x0 = k.ra * x - k.rm * eps;
+        } else {
+            x0 = k.sa * x - k.s1 * v[vi];
+            eps = (k.ra * x - x0) / k.rm;
+        }
+        float o;
+        if (mode == 0) {
+            x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            o = k.c1 * x0 + k.c2 * x;
+            if (noise) o += k.sigma * noise[i];
+        } else if (mode == 1) {
+            o = x0 * k.c1 + k.c2 * eps;
+            if (noise) o += k.sigma * noise[i];
+        } else {
+            o = x0;
+        }
+        if (final) o = fminf(fmaxf((o + 1.f) * 0.5f, 0.f), 1.f);
+        out[i] = o;
+    }
+}
+
+// ----------------------------------------------------------------------------------------- Philox4x32-10 normals
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+// out[i] ~ N(0,1); counter-based: (seed, offset + i/4) so a captured graph can be replayed with a device-side offset.
+__global__ void philox_normal_kernel(float* out, size_t n, uint64_t seed, const uint64_t* offset_ptr, uint64_t offset_imm) {
+    const uint64_t off = offset_ptr ? *offset_ptr : offset_imm;
+    const size_t n4 = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+        const uint64_t ctr = off + q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) philox_round(c, k);
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+            const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+            const float rr = sqrtf(-2.0f * logf(u1));
+            z[2 * h] = rr * cosf(6.283185307179586f * u2);
+            z[2 * h + 1] = rr * sinf(6.283185307179586f * u2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = z[j];
+    }
+}
+__global__ void philox_randint_kernel(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_ptr, uint64_t offset_imm) {
+    const uint64_t off = offset_ptr ? *offset_ptr : offset_imm;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ctr = off + (uint64_t)i;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    out[i] = (int64_t)(((uint64_t)c[0] * (uint64_t)high) >> 32);
+}
+__global__ void advance_counter_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
+
+extern "C" {
+
+int v2a_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(act_fwd_kernel, GRID_FOR(n), dim3(256), 0, s, x, y, n, act);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t s) {
+    hipLaunchKernelGGL(act_bwd_kernel, GRID_FOR(n), dim3(256), 0, s, x, dy, dx, n, act);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_axpy(const float* a, const float* b, float* out, float alpha, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_kernel, GRID_FOR(n), dim3(256), 0, s, a, b, out, alpha, n);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_copy2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(copy2d_kernel, GRID_FOR((size_t)rows * cols), dim3(256), 0, s, src, dst, rows, cols, ld_src, ld_dst, accumulate);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_colsum(const float* x, float* out, int rows, int cols, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, x, out, rows, cols, accumulate);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_sincos_embed(const int64_t* t, float* out, int B, int dim, int kind, hipStream_t s) {
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(sincos_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, B, dim, kind);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const float* alphas_cumprod, float* out, int B, int per, hipStream_t s) {
+    hipLaunchKernelGGL(add_noise_kernel, dim3((B * per + 255) / 256), dim3(256), 0, s, act, noise, t, alphas_cumprod, out, B, per);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int n, hipStream_t s) {
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, s, pred, target, loss, dpred, n);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_policy_sched_step(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb, float c_sa,
+                          float c0, float c1, float sigma, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(policy_sched_step_kernel, dim3((n + 255) / 256), dim3(256), 0, s, eps, sample, noise, out, n, c_sb, c_sa, c0, c1, sigma, mode);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_unnormalize_action(const float* x, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(unnormalize_action_kernel, dim3(1), dim3(256), 0, s, x, out, n);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int normalize, hipStream_t s) {
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), GRID_FOR((size_t)N * C * HW), dim3(256), 0, s, src, dst, N, C, HW, normalize, 1.0f);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, hipStream_t s) {
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint8_t>), GRID_FOR((size_t)N * C * HW), dim3(256), 0, s, src, dst, N, C, HW, normalize, 1.0f / 255.0f);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, GRID_FOR((size_t)N * C * HW), dim3(256), 0, s, src, dst, N, C, HW);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(video_pack_kernel, GRID_FOR((size_t)B * f * HW * 6), dim3(256), 0, s, img, cond, xin, B, f, HW);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
+                           float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
+                           hipStream_t s) {
+    DenoiseCoef k = {sa, s1, ra, rm, c1, c2, sigma, gw};
+    hipLaunchKernelGGL(video_denoise_kernel, GRID_FOR((size_t)B * f * 3 * HW), dim3(256), 0, s, v, v_uncond, img, noise, out, B, f, HW, k, mode, final);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, hipStream_t s) {
+    hipLaunchKernelGGL(philox_normal_kernel, GRID_FOR((n + 3) / 4), dim3(256), 0, s, out, n, seed, offset_dev, offset_imm);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, hipStream_t s) {
+    hipLaunchKernelGGL(philox_randint_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n, high, seed, offset_dev, offset_imm);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_advance_counter(uint64_t* ctr, uint64_t inc, hipStream_t s) {
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, s, ctr, inc);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// GroupNorm (+ fused activation / residual / FiLM) forward and backward on channels-last tensors [N, S, C].
+//
+// replaces: GroupNorm32 + SiLU of the video UNet (reference nn.py:26-28, unet.py:187-190,211-216,289,628-631),
+//           GroupNorm(C/16) + ReLU (+ residual) of the ResNet-18 encoders (multi_image_obs_encoder.py:66-74),
+//           GroupNorm(8) + Mish + FiLM of Conv1dBlock / ConditionalResidualBlock1D (conv1d_components.py:23-40,
+//           conditional_unet1d.py:46-66).
+// order of the fused tail:  z = gn(x) [+ residual];  a = act(z);  out = film ? scale * a + shift : a
+//
+// Two paths.  HBM-bound tensors: column-reduce (wave64 + LDS bins, fp64 combine) -> finalize -> float4 apply.
+// Small tensors (one (n, group) slab <= 8192 elements): one workgroup does stats + apply in one launch.
+// Statistics are combined in fp64 (sum / sum-of-squares of fp32 partials) so that mean / rstd carry < 1e-6
+// relative error -- the parity budget of the path is 1e-4.
+#include "common.h"
+
+struct GnDesc {
+    const float* x;         // [N][S][C]
+    const float* gamma;     // [C]
+    const float* beta;      // [C]
+    const float* residual;  // [N][S][C] or null (added before the activation)
+    const float* film;      // [N][2][C] (scale, shift) or null (applied after the activation)
+    const float* dout;      // backward only
+    float* y;               // forward output / backward dx
+    float* dres;            // backward: gradient w.r.t. residual (= dz) or null
+    float* dfilm;           // backward: [N][2][C] or null
+    float* mean;            // [N][G]
+    float* rstd;            // [N][G]
+    float* colsum;          // [N][2][C] (stats: sum x, sum x^2; backward: sum dz, sum dz*xhat)
+    double* partial;        // [N][nchunk][2][C]
+    int N, S, C, G, act, nchunk, rows_per_chunk;
+    float eps;
+};
+
+// -------------------------------------------------------------------------------------------- large path
+// MODE 0: (x, x^2).  MODE 1: (dz, dz * xhat) with dz = dout * act'(z), z = gn(x) [+ residual].
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
+    extern __shared__ __attribute__((aligned(16))) float bins[];   // [2][C]
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int C = p.C, L4 = C >> 2, cg = C / p.G;
+    for (int i = tid; i < 2 * C; i += 256) bins[i] = 0.f;
+    __syncthreads();
+    const int s0 = chunk * p.rows_per_chunk, s1 = min(p.S, s0 + p.rows_per_chunk);
+    const size_t base = ((size_t)n * p.S + s0) * C;
+    const int total4 = (s1 - s0) * L4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x + base);
+    const f32x4* d4 = MODE ? reinterpret_cast<const f32x4*>(p.dout + base) : nullptr;
+    const f32x4* r4 = (MODE && p.residual) ? reinterpret_cast<const f32x4*>(p.residual + base) : nullptr;
+    // a thread's channel advances by (256 % L4) float4 per step; accumulate a run locally while it stays put
+    int c4 = tid % L4;
+    const int step = 256 % L4;
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    auto flush = [&](int cc4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&bins[cc4 * 4 + j], a0[j]);
+            atomicAdd(&bins[C + cc4 * 4 + j], a1[j]);
+            a0[j] = 0.f;
+            a1[j] = 0.f;
+        }
+    };
+    for (int i = tid; i < total4; i += 256) {
+        f32x4 v = x4[i];
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[j] * v[j]; }
+        } else {
+            const int g = (c4 * 4) / cg;
+            const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
+            f32x4 d = d4[i];
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (r4) r = r4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c4 * 4 + j;
+                const float xh = (v[j] - mu) * rs;
+                const float z = xh * p.gamma[c] + p.beta[c] + r[j];
+                const float dz = d[j] * act_bwd(z, p.act);
+                a0[j] += dz;
+                a1[j] += dz * xh;
+            }
+        }
+        if (step != 0) {
+            flush(c4);
+            c4 += step;
+            if (c4 >= L4) c4 -= L4;
+        }
+    }
+    if (step == 0) flush(c4);
+    __syncthreads();
+    double* out = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) out[i] = (double)bins[i];
+}
+
+// one block per n: sums chunk partials in fp64.  MODE 0 -> mean/rstd.  MODE 1 -> colsum[n][2][C] (fp32).
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
+    const int n = blockIdx.x, tid = threadIdx.x, C = p.C, cg = C / p.G;
+    extern __shared__ __attribute__((aligned(16))) double dsum[];   // [2][C]
+    for (int i = tid; i < 2 * C; i += 256) {
+        double s = 0.0;
+        for (int k = 0; k < p.nchunk; ++k) s += p.partial[((size_t)n * p.nchunk + k) * 2 * C + i];
+        dsum[i] = s;
+        if (MODE == 1) p.colsum[(size_t)n * 2 * C + i] = (float)s;
+    }
+    __syncthreads();
+    if (MODE == 0) {
+        for (int g = tid; g < p.G; g += 256) {
+            double s = 0.0, q = 0.0;
+            for (int c = g * cg; c < (g + 1) * cg; ++c) { s += dsum[c]; q += dsum[C + c]; }
+            const double cnt = (double)p.S * cg;
+            const double mu = s / cnt;
+            double var = q / cnt - mu * mu;
+            if (var < 0.0) var = 0.0;
+            p.mean[n * p.G + g] = (float)mu;
+            p.rstd[n * p.G + g] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
+    const int C = p.C, L4 = C >> 2, cg = C / p.G;
+    const size_t per_n = (size_t)p.S * L4, total = per_n * p.N;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(p.residual);
+    f32x4* y4 = reinterpret_cast<f32x4*>(p.y);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / per_n);
+        const int c4 = (int)(i % L4);
+        const int g = (c4 * 4) / cg;
+        const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
+        f32x4 v = x4[i];
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (r4) r = r4[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4 * 4 + j;
+            float z = (v[j] - mu) * rs * p.gamma[c] + p.beta[c] + r[j];
+            float a = act_fwd(z, p.act);
+            if (p.film) a = p.film[(size_t)n * 2 * C + c] * a + p.film[(size_t)n * 2 * C + C + c];
+            o[j] = a;
+        }
+        y4[i] = o;
+    }
+}
+
+// dx = rstd * (gamma * dz - (A1 + xhat * A2) / cnt),  A1 = sum_{c in g} gamma_c * colsum0[n][c], A2 likewise with colsum1
+__global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
+    const int C = p.C, L4 = C >> 2, cg = C / p.G;
+    const size_t per_n = (size_t)p.S * L4, total = per_n * p.N;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(p.dout);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(p.residual);
+    f32x4* y4 = reinterpret_cast<f32x4*>(p.y);
+    f32x4* dr4 = reinterpret_cast<f32x4*>(p.dres);
+    const float inv_cnt = 1.0f / ((float)p.S * cg);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / per_n);
+        const int c4 = (int)(i % L4);
+        const int g = (c4 * 4) / cg;
+        const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
+        float A1 = 0.f, A2 = 0.f;
+        const float* cs = p.colsum + (size_t)n * 2 * C;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { A1 += p.gamma[c] * cs[c]; A2 += p.gamma[c] * cs[C + c]; }
+        f32x4 v = x4[i], d = d4[i];
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (r4) r = r4[i];
+        f32x4 o, dzv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4 * 4 + j;
+            const float xh = (v[j] - mu) * rs;
+            const float z = xh * p.gamma[c] + p.beta[c] + r[j];
+            const float dz = d[j] * act_bwd(z, p.act);
+            dzv[j] = dz;
+            o[j] = rs * (p.gamma[c] * dz - (A1 + xh * A2) * inv_cnt);
+        }
+        y4[i] = o;
+        if (dr4) dr4[i] = dzv;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- small path
+// one workgroup per (n, g): E = S * cg elements staged in LDS.  Forward: two-pass (centred) variance.
+__global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [E] + 8 scratch
+    const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
+    const int C = p.C, cg = C / p.G, E = p.S * cg;
+    float* red = sm + E;
+    const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
+    float s = 0.f;
+    for (int i = tid; i < E; i += 256) {
+        const int row = i / cg, cc = i - row * cg;
+        const float v = p.x[base + (size_t)row * C + cc];
+        sm[i] = v;
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)E;
+    __syncthreads();
+    float q = 0.f;
+    for (int i = tid; i < E; i += 256) { const float d = sm[i] - mu; q += d * d; }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)E;
+    const float rs = 1.0f / sqrtf(var + p.eps);
+    if (tid == 0) { p.mean[n * p.G + g] = mu; p.rstd[n * p.G + g] = rs; }
+    for (int i = tid; i < E; i += 256) {
+        const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
+        const size_t off = base + (size_t)row * C + cc;
+        float z = (sm[i] - mu) * rs * p.gamma[c] + p.beta[c];
+        if (p.residual) z += p.residual[off];
+        float a = act_fwd(z, p.act);
+        if (p.film) a = p.film[(size_t)n * 2 * C + c] * a + p.film[(size_t)n * 2 * C + C + c];
+        p.y[off] = a;
+    }
+}
+
+// backward of the small path.  Also emits per-(n, c) sums: colsum[n][0][c] = sum_s dz, colsum[n][1][c] = sum_s dz*xhat
+// (dgamma / dbeta = their sum over n) and dfilm[n][0][c] = sum_s dout * a, dfilm[n][1][c] = sum_s dout.
+__global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // xhat[E], dz[E], bins[4][cg], red[8]
+    const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
+    const int C = p.C, cg = C / p.G, E = p.S * cg;
+    float* xh = sm;
+    float* dzs = sm + E;
+    float* bins = sm + 2 * E;
+    float* red = bins + 4 * cg;
+    for (int i = tid; i < 4 * cg; i += 256) bins[i] = 0.f;
+    __syncthreads();
+    const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
+    const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
+    float A1 = 0.f, A2 = 0.f;
+    for (int i = tid; i < E; i += 256) {
+        const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
+        const size_t off = base + (size_t)row * C + cc;
+        const float h = (p.x[off] - mu) * rs;
+        float z = h * p.gamma[c] + p.beta[c];
+        if (p.residual) z += p.residual[off];
+        const float dout = p.dout[off];
+        float da = dout;
+        if (p.film) {
+            const float a = act_fwd(z, p.act);
+            da = dout * p.film[(size_t)n * 2 * C + c];
+            atomicAdd(&bins[2 * cg + cc], dout * a);
+            atomicAdd(&bins[3 * cg + cc], dout);
+        }
+        const float dz = da * act_bwd(z, p.act);
+        xh[i] = h;
+        dzs[i] = dz;
+        atomicAdd(&bins[cc], dz);
+        atomicAdd(&bins[cg + cc], dz * h);
+        A1 += dz * p.gamma[c];
+        A2 += dz * p.gamma[c] * h;
+    }
+    A1 = wave_sum(A1);
+    A2 = wave_sum(A2);
+    if ((tid & 63) == 0) { red[tid >> 6] = A1; red[4 + (tid >> 6)] = A2; }
+    __syncthreads();
+    A1 = red[0] + red[1] + red[2] + red[3];
+    A2 = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.0f / (float)E;
+    for (int i = tid; i < E; i += 256) {
+        const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
+        const size_t off = base + (size_t)row * C + cc;
+        p.y[off] = rs * (p.gamma[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
+        if (p.dres) p.dres[off] = dzs[i];
+    }
+    for (int cc = tid; cc < cg; cc += 256) {
+        const int c = g * cg + cc;
+        p.colsum[(size_t)n * 2 * C + c] = bins[cc];
+        p.colsum[(size_t)n * 2 * C + C + c] = bins[cg + cc];
+        if (p.dfilm) {
+            p.dfilm[(size_t)n * 2 * C + c] = bins[2 * cg + cc];
+            p.dfilm[(size_t)n * 2 * C + C + c] = bins[3 * cg + cc];
+        }
+    }
+}
+
+// dgamma[c] = sum_n colsum[n][1][c], dbeta[c] = sum_n colsum[n][0][c]
+__global__ void gn_param_grads(const float* colsum, float* dgamma, float* dbeta, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) { b += colsum[(size_t)n * 2 * C + c]; a += colsum[(size_t)n * 2 * C + C + c]; }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
+}
+
+#define GN_SMALL_MAX 8192
+
+static void gn_chunks(int N, int S, int C, int* nchunk, int* rows) {
+    // >= ~1024 workgroups overall, slabs of at least 16 KB
+    int min_rows = (16384 / (C * 4));
+    if (min_rows < 1) min_rows = 1;
+    int want = (1024 + N - 1) / N;
+    int r = (S + want - 1) / want;
+    if (r < min_rows) r = min_rows;
+    *rows = r;
+    *nchunk = (S + r - 1) / r;
+}
+
+extern "C" {
+
+size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
+    if ((long)S * (C / G) <= GN_SMALL_MAX) return 0;
+    int nchunk, rows;
+    gn_chunks(N, S, C, &nchunk, &rows);
+    return (size_t)N * nchunk * 2 * C * sizeof(double);
+}
+
+// y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
+int v2a_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
+                      float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
+                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
+    GnDesc p = {};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
+    p.N = N; p.S = S; p.C = C; p.G = G; p.act = act; p.eps = eps;
+    const int cg = C / G;
+    const long E = (long)S * cg;
+    if (E <= GN_SMALL_MAX) {
+        size_t lds = (E + 8) * sizeof(float);
+        hipLaunchKernelGGL(gn_small_fwd, dim3(N * G), dim3(256), lds, stream, p);
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
+    }
+    if (C % 4 != 0 || cg % 4 != 0) return V2A_ERR_ARG;
+    gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
+    if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    p.partial = (double*)workspace;
+    hipLaunchKernelGGL(gn_colreduce<0>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+    V2A_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize<0>, dim3(N), dim3(256), 2 * C * sizeof(double), stream, p);
+    V2A_CHECK_LAUNCH();
+    size_t total4 = (size_t)N * S * (C / 4);
+    int grid = (int)((total4 + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(gn_apply_fwd, dim3(grid), dim3(256), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+// Backward of v2a_groupnorm_fwd.  dx [N,S,C]; dres (optional) = gradient of the residual input;
+// dfilm (optional) [N][2][C]; colsum [N][2][C] scratch/output; dgamma/dbeta [C].
+int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
+                      const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm,
+                      float* colsum, float* dgamma, float* dbeta, int N, int S, int C, int G, int act, void* workspace,
+                      size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || !dout || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
+    GnDesc p = {};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
+    p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;
+    p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
+    const int cg = C / G;
+    const long E = (long)S * cg;
+    if (E <= GN_SMALL_MAX) {
+        size_t lds = (2 * E + 4 * cg + 8) * sizeof(float);
+        hipLaunchKernelGGL(gn_small_bwd, dim3(N * G), dim3(256), lds, stream, p);
+        V2A_CHECK_LAUNCH();
+    } else {
+        if (film || dfilm) return V2A_ERR_ARG;   // FiLM only occurs on the small (Conv1d) path
+        if (C % 4 != 0 || cg % 4 != 0) return V2A_ERR_ARG;
+        gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
+        if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
+        p.partial = (double*)workspace;
+        hipLaunchKernelGGL(gn_colreduce<1>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+        V2A_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_finalize<1>, dim3(N), dim3(256), 2 * C * sizeof(double), stream, p);
+        V2A_CHECK_LAUNCH();
+        size_t total4 = (size_t)N * S * (C / 4);
+        int grid = (int)((total4 + 255) / 256);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(gn_apply_bwd, dim3(grid), dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+    }
+    if (dgamma && dbeta) {
+        hipLaunchKernelGGL(gn_param_grads, dim3((C + 255) / 256), dim3(256), 0, stream, colsum, dgamma, dbeta, N, C);
+        V2A_CHECK_LAUNCH();
+    }
+    return V2A_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// Fused multi-tensor optimiser tail of the policy train step (HBM-bound, fp32 master weights):
+//   global grad L2 norm -> clip to max_norm -> AdamW -> zero grads -> EMA
+// replaces lb_online_trainer_v7.py:604-624 (accelerator.clip_grad_norm_, AdamW.step, zero_grad, ema.update) with
+// the arithmetic of torch.nn.utils.clip_grad_norm_, torch.optim.AdamW and ema_pytorch 0.2.3 (restated; see
+// oracle/optim.py).  All step-dependent scalars live in a device-side state block advanced by a 1-thread kernel,
+// so the whole tail is capturable in a hipGraph and replayed with no host involvement.
+//
+// Tensor table (device, int64): per tensor {p, g, m, v, ema, numel}; chunk map (int32): {tensor, start}.
+#include "common.h"
+
+#define MT_CHUNK 16384
+
+struct OptState {           // device resident
+    double lr, b1, b2, eps, wd, max_norm;
+    double ema_inv_gamma, ema_power, ema_min, ema_beta;
+    long long step;          // AdamW step (after increment)
+    long long ema_step;      // ema_pytorch `step` buffer
+    int ema_initted;
+    int ema_update_after, ema_update_every;
+    // derived per step
+    float clip_coef, grad_norm;
+    float step_size, inv_sqrt_bc2, decay_mul;   // decay_mul = 1 - lr*wd
+    float ema_decay;
+    int ema_mode;            // bit0 copy, bit1 lerp
+};
+
+__global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, const int* chunks, double* partial) {
+    __shared__ double sm[4];
+    const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
+    const float* g = reinterpret_cast<const float*>(table[t * 6 + 1]);
+    const long long n = table[t * 6 + 5];
+    const int cnt = (int)min((long long)MT_CHUNK, n - start);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += 256) { const float v = g[start + i]; s += v * v; }
+    double d = wave_sum_d((double)s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// one workgroup: finish the norm, advance step counters, derive this step's scalars
+__global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const double* partial, int nchunks) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nchunks; i += 256) s += partial[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double norm = sqrt(sm[0] + sm[1] + sm[2] + sm[3]);
+    st->grad_norm = (float)norm;
+    double coef = st->max_norm / ((double)(float)norm + 1e-6);
+    st->clip_coef = (float)(coef > 1.0 ? 1.0 : coef);
+    st->step += 1;
+    const double bc1 = 1.0 - pow(st->b1, (double)st->step), bc2 = 1.0 - pow(st->b2, (double)st->step);
+    st->step_size = (float)(st->lr / bc1);
+    st->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    st->decay_mul = (float)(1.0 - st->lr * st->wd);
+    // ema_pytorch.EMA.update()
+    const long long es = st->ema_step;
+    st->ema_step = es + 1;
+    int mode = 0;
+    if (es % st->ema_update_every == 0) {
+        if (es <= st->ema_update_after) mode = 1;
+        else {
+            if (!st->ema_initted) { mode |= 1; st->ema_initted = 1; }
+            mode |= 2;
+        }
+    }
+    double epoch = (double)(st->ema_step - st->ema_update_after - 1);
+    if (epoch < 0) epoch = 0;
+    double dec = 0.0;
+    if (epoch > 0) {
+        dec = 1.0 - pow(1.0 + epoch / st->ema_inv_gamma, -st->ema_power);
+        if (dec < st->ema_min) dec = st->ema_min;
+        if (dec > st->ema_beta) dec = st->ema_beta;
+    }
+    st->ema_decay = (float)dec;
+    st->ema_mode = mode;
+}
+
+__global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table, const int* chunks, const OptState* st, int zero_grad) {
+    const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
+    float* p = reinterpret_cast<float*>(table[t * 6 + 0]) + start;
+    float* g = reinterpret_cast<float*>(table[t * 6 + 1]) + start;
+    float* m = reinterpret_cast<float*>(table[t * 6 + 2]) + start;
+    float* v = reinterpret_cast<float*>(table[t * 6 + 3]) + start;
+    float* e = table[t * 6 + 4] ? reinterpret_cast<float*>(table[t * 6 + 4]) + start : nullptr;
+    const long long n = table[t * 6 + 5];
+    const int cnt = (int)min((long long)MT_CHUNK, n - start);
+    const float clip = st->clip_coef, b1 = (float)st->b1, b2 = (float)st->b2, eps = (float)st->eps;
+    const float step_size = st->step_size, isb2 = st->inv_sqrt_bc2, dmul = st->decay_mul, dec = st->ema_decay;
+    const int mode = st->ema_mode;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const float gr = g[i] * clip;
+        float pv = p[i] * dmul;
+        float mv = m[i];
+        mv = mv + (gr - mv) * (1.0f - b1);              // lerp_(g, 1-b1)
+        const float vv = v[i] * b2 + (1.0f - b2) * gr * gr;
+        const float denom = sqrtf(vv) * isb2 + eps;
+        pv = pv - step_size * (mv / denom);
+        p[i] = pv;
+        m[i] = mv;
+        v[i] = vv;
+        if (zero_grad) g[i] = 0.f;
+        if (e && mode) {
+            float ev = (mode & 1) ? pv : e[i];
+            if (mode & 2) { const float d = (ev - pv) * (1.0f - dec); ev = ev - d; }
+            e[i] = ev;
+        }
+    }
+}
+
+// grads *= 1/world (after an RCCL sum all-reduce) -- folded into the clip by scaling the table's grads in place
+__global__ void mt_scale_grads_kernel(const int64_t* table, const int* chunks, float scale) {
+    const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
+    float* g = reinterpret_cast<float*>(table[t * 6 + 1]) + start;
+    const long long n = table[t * 6 + 5];
+    const int cnt = (int)min((long long)MT_CHUNK, n - start);
+    for (int i = threadIdx.x; i < cnt; i += 256) g[i] *= scale;
+}
+
+extern "C" {
+
+int v2a_opt_chunk_elems(void) { return MT_CHUNK; }
+size_t v2a_opt_state_bytes(void) { return sizeof(OptState); }
+
+// Fill a HOST OptState image (caller copies it to the device once).
+int v2a_opt_state_init(void* host_state, double lr, double b1, double b2, double eps, double wd, double max_norm,
+                       double ema_inv_gamma, double ema_power, double ema_min, double ema_beta, int ema_update_after,
+                       int ema_update_every) {
+    if (!host_state) return V2A_ERR_ARG;
+    OptState s = {};
+    s.lr = lr; s.b1 = b1; s.b2 = b2; s.eps = eps; s.wd = wd; s.max_norm = max_norm;
+    s.ema_inv_gamma = ema_inv_gamma; s.ema_power = ema_power; s.ema_min = ema_min; s.ema_beta = ema_beta;
+    s.ema_update_after = ema_update_after; s.ema_update_every = ema_update_every < 1 ? 1 : ema_update_every;
+    *reinterpret_cast<OptState*>(host_state) = s;
+    return V2A_OK;
+}
+// read back {grad_norm, clip_coef, step, ema_decay} from a HOST copy of the state
+int v2a_opt_state_peek(const void* host_state, float* grad_norm, float* clip_coef, long long* step, float* ema_decay) {
+    const OptState* s = reinterpret_cast<const OptState*>(host_state);
+    if (grad_norm) *grad_norm = s->grad_norm;
+    if (clip_coef) *clip_coef = s->clip_coef;
+    if (step) *step = s->step;
+    if (ema_decay) *ema_decay = s->ema_decay;
+    return V2A_OK;
+}
+
+// One optimiser step over all tensors.  partial: nchunks doubles of scratch.
+int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
+                 int zero_grad, hipStream_t s) {
+    if (!table_dev || !chunks_dev || !state_dev || !partial_dev || nchunks <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, partial_dev);
+    V2A_CHECK_LAUNCH();
+    hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(256), 0, s, (OptState*)state_dev, partial_dev, nchunks);
+    V2A_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mt_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, (const OptState*)state_dev, zero_grad);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(mt_scale_grads_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, scale);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+}  // extern "C"

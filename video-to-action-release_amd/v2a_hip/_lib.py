@@ -1,0 +1,97 @@
+"""ctypes binding of libv2a_hip.so (the C ABI declared in include/v2a.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this
+module raises at import time, and every wrapper raises on a non-zero return code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libv2a_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+D = ctypes.c_double
+SZ = ctypes.c_size_t
+U64 = ctypes.c_uint64
+LL = ctypes.c_longlong
+
+# name -> (restype, argtypes).  Order/meaning mirrors include/v2a.h exactly.
+SIGNATURES = {
+    "v2a_conv2d_workspace_bytes": (SZ, [I, I, I]),
+    "v2a_conv2d_fwd": (I, [P] * 8 + [I] * 18 + [P, SZ, P]),
+    "v2a_conv2d_wgrad_workspace_bytes": (SZ, [I, I, I]),
+    "v2a_conv2d_wgrad": (I, [P, P, P, P] + [I] * 17 + [P, SZ, P]),
+    "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),
+    "v2a_groupnorm_workspace_bytes": (SZ, [I, I, I, I]),
+    "v2a_groupnorm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
+    "v2a_groupnorm_bwd": (I, [P] * 14 + [I, I, I, I, I, P, SZ, P]),
+    "v2a_act_fwd": (I, [P, P, SZ, I, P]),
+    "v2a_act_bwd": (I, [P, P, P, SZ, I, P]),
+    "v2a_axpy": (I, [P, P, P, F, SZ, P]),
+    "v2a_copy2d": (I, [P, P, I, I, I, I, I, P]),
+    "v2a_colsum": (I, [P, P, I, I, I, P]),
+    "v2a_sincos_embed": (I, [P, P, I, I, I, P]),
+    "v2a_add_noise": (I, [P, P, P, P, P, I, I, P]),
+    "v2a_mse_loss": (I, [P, P, P, P, I, P]),
+    "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
+    "v2a_unnormalize_action": (I, [P, P, I, P]),
+    "v2a_nchw_to_nhwc_f32": (I, [P, P, I, I, I, I, P]),
+    "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),
+    "v2a_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
+    "v2a_video_pack": (I, [P, P, P, I, I, I, P]),
+    "v2a_video_denoise_step": (I, [P, P, P, P, P, I, I, I, F, F, F, F, F, F, F, F, I, I, P]),
+    "v2a_philox_normal": (I, [P, SZ, U64, P, U64, P]),
+    "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
+    "v2a_advance_counter": (I, [P, U64, P]),
+    "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),
+    "v2a_perceiver_attention": (I, [P, P, P, P, P, I, I, I, I, I, F, P]),
+    "v2a_layernorm": (I, [P, P, P, P, I, I, F, P]),
+    "v2a_mean_rows": (I, [P, P, I, I, I, P]),
+    "v2a_maxpool3x3s2_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "v2a_maxpool3x3s2_bwd": (I, [P, P, P, I, I, I, I, P]),
+    "v2a_spatial_softmax_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "v2a_spatial_softmax_bwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "v2a_opt_chunk_elems": (I, []),
+    "v2a_opt_state_bytes": (SZ, []),
+    "v2a_opt_state_init": (I, [P, D, D, D, D, D, D, D, D, D, D, I, I]),
+    "v2a_opt_state_peek": (I, [P, P, P, P, P]),
+    "v2a_opt_step": (I, [P, P, I, P, P, I, P]),
+    "v2a_opt_scale_grads": (I, [P, P, I, F, P]),
+    "v2a_replay_sample_indices": (I, [P, P, P, I, I, I, P, P]),
+    "v2a_replay_count_uniform_below": (I, [P, I, D]),
+    "v2a_mt_seed_numpy": (I, [P, ctypes.c_uint32]),
+    "v2a_mt_seed_python": (I, [P, P, I]),
+    "v2a_replay_gather": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+}
+
+
+class V2AError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise V2AError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C video-to-action-release_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise V2AError(f"libv2a_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+_ERR = {-1: "bad argument", -2: "kernel launch failed", -3: "workspace too small", -4: "episode shorter than act_len + 1"}
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise V2AError(f"{what}: error {rc} ({_ERR.get(rc, 'unknown')})")

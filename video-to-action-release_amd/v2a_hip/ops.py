@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI (one function per exported entry point family).
+
+PyTorch is used for device memory and streams only; every arithmetic op below is a HIP kernel of
+libv2a_hip.so launched on torch's current stream with raw pointers.
+All activations are channels-last fp32: images [N,H,W,C], sequences [N,T,C], video [B,F,H,W,C].
+"""
+import torch
+from ._lib import lib, check
+
+ACT = {"none": 0, "silu": 1, "relu": 2, "mish": 3, "gelu": 4}
+
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def workspace(nbytes: int, device=None) -> torch.Tensor:
+    """Grow-only scratch buffer per device (not resized during graph capture: call reserve_workspace first)."""
+    device = torch.device(device if device is not None else torch.cuda.current_device())
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    cur = _ws.get(key)
+    if cur is None or cur.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("v2a workspace would grow during graph capture; call ops.reserve_workspace() first")
+        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{key}")
+        _ws[key] = cur
+    return cur
+
+
+def reserve_workspace(nbytes: int, device=None):
+    workspace(nbytes, device)
+
+
+def _chk(t, name="tensor"):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), f"{name}: need contiguous fp32 CUDA tensor"
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+    """torch layout [Cout,Cin,KH,KW] (or [Cout,Cin,K] / [Cout,Cin]) -> packed operand.
+    mode 0: [Cout][KH][KW][Cin] (forward);  mode 1: [Cin][KH'][KW'][Cout] flipped (data-gradient / transposed conv)."""
+    _chk(w, "weight")
+    if w.dim() == 2:
+        co, ci, kh, kw = w.shape[0], w.shape[1], 1, 1
+    elif w.dim() == 3:
+        co, ci, kh, kw = w.shape[0], w.shape[1], 1, w.shape[2]
+    else:
+        co, ci, kh, kw = w.shape
+    if out is None:
+        out = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    check(lib.v2a_pack_weight(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, mode, _stream()), "pack_weight")
+    return out
+
+
+def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
+           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0):
+    """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]."""
+    _chk(x, "x")
+    N, H, W, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "x2")
+        C2 = x2.shape[-1]
+    sh, sw = stride
+    ph, pw = pad
+    if out_hw is None:
+        HL = 2 * H if ups else ((H - 1) * idil + 1 if idil > 1 else H)
+        WL = 2 * W if ups else ((W - 1) * idil + 1 if idil > 1 else W)
+        OH = (HL + 2 * ph - KH) // sh + 1
+        OW = (WL + 2 * pw - KW) // sw + 1
+    else:
+        OH, OW = out_hw
+    M = N * OH * OW
+    K = KH * KW * (C1 + C2)
+    if y is None:
+        if y2 is not None or csplit:
+            raise ValueError("split output needs explicit y / y2")
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    wsb = lib.v2a_conv2d_workspace_bytes(M, Cout, K)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.v2a_conv2d_fwd(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
+                             _p(y2), csplit, N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, 1 if ups else 0,
+                             rows_per_batch, _p(ws), wsb, _stream()), "conv2d_fwd")
+    return y
+
+
+def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False):
+    """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout]."""
+    _chk(x, "x"); _chk(dy, "dy")
+    N, H, W, C1 = x.shape
+    C2 = x2.shape[-1] if x2 is not None else 0
+    _, OH, OW, Cout = dy.shape
+    if dw is None:
+        dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    M = N * OH * OW
+    K = KH * KW * (C1 + C2)
+    wsb = lib.v2a_conv2d_wgrad_workspace_bytes(M, Cout, K)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
+                               stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
+                               _p(ws), wsb, _stream()), "conv2d_wgrad")
+    return dw
+
+
+def linear(x2d, w, bias=None, residual=None):
+    """y = x @ w.T + b for x [M,K], torch weight [N,K] (already K-contiguous: no pack needed)."""
+    M, K = x2d.shape
+    y = conv2d(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=residual)
+    return y.view(M, w.shape[0])
+
+
+def colsum(x2d, out=None, accumulate=False):
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    check(lib.v2a_colsum(x2d.data_ptr(), out.data_ptr(), rows, cols, 1 if accumulate else 0, _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ group norm
+def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None):
+    """x [N,S,C] (any leading/spatial shape flattened by the caller).  Returns (y, mean, rstd)."""
+    _chk(x, "x")
+    N, S, C = x.shape
+    if y is None:
+        y = torch.empty_like(x)
+    mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
+    wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.v2a_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), y.data_ptr(),
+                                mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
+          "groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False):
+    """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None)."""
+    N, S, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dfilm = torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None
+    colsum_ = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.v2a_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), dout.data_ptr(),
+                                mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), _p(dfilm), colsum_.data_ptr(),
+                                dgamma.data_ptr(), dbeta.data_ptr(), N, S, C, G, ACT[act], _p(ws), wsb, _stream()),
+          "groupnorm_bwd")
+    return dx, dgamma, dbeta, dres, dfilm
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def act_fwd(x, act, y=None):
+    y = torch.empty_like(x) if y is None else y
+    check(lib.v2a_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), ACT[act], _stream()), "act_fwd")
+    return y
+
+
+def act_bwd(x, dy, act):
+    dx = torch.empty_like(x)
+    check(lib.v2a_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ACT[act], _stream()), "act_bwd")
+    return dx
+
+
+def axpy(a, b, alpha=1.0, out=None):
+    out = torch.empty_like(a) if out is None else out
+    check(lib.v2a_axpy(a.data_ptr(), b.data_ptr(), out.data_ptr(), float(alpha), a.numel(), _stream()), "axpy")
+    return out
+
+
+def copy2d(src, dst, rows, cols, ld_src, ld_dst, src_off=0, dst_off=0, accumulate=False):
+    check(lib.v2a_copy2d(src.data_ptr() + 4 * src_off, dst.data_ptr() + 4 * dst_off, rows, cols, ld_src, ld_dst,
+                         1 if accumulate else 0, _stream()), "copy2d")
+    return dst
+
+
+def sincos_embed(t_long, dim, kind):
+    B = t_long.numel()
+    out = torch.empty((B, dim), dtype=torch.float32, device=t_long.device)
+    check(lib.v2a_sincos_embed(t_long.data_ptr(), out.data_ptr(), B, dim, kind, _stream()), "sincos_embed")
+    return out
+
+
+def add_noise(act, noise, t_long, alphas_cumprod):
+    out = torch.empty_like(act)
+    B = act.shape[0]
+    check(lib.v2a_add_noise(act.data_ptr(), noise.data_ptr(), t_long.data_ptr(), alphas_cumprod.data_ptr(), out.data_ptr(), B,
+                            act.numel() // B, _stream()), "add_noise")
+    return out
+
+
+def mse_loss(pred, target, want_grad=True):
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    check(lib.v2a_mse_loss(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), _p(dpred), pred.numel(), _stream()), "mse_loss")
+    return loss, dpred
+
+
+def nchw_to_nhwc(src, normalize=False):
+    N, C, H, W = src.shape
+    dst = torch.empty((N, H, W, C), dtype=torch.float32, device=src.device)
+    assert src.is_contiguous()
+    if src.dtype == torch.uint8:
+        check(lib.v2a_nchw_to_nhwc_u8(src.data_ptr(), dst.data_ptr(), N, C, H * W, 1 if normalize else 0, _stream()), "nchw_to_nhwc")
+    else:
+        _chk(src)
+        check(lib.v2a_nchw_to_nhwc_f32(src.data_ptr(), dst.data_ptr(), N, C, H * W, 1 if normalize else 0, _stream()), "nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src):
+    N, H, W, C = src.shape
+    dst = torch.empty((N, C, H, W), dtype=torch.float32, device=src.device)
+    check(lib.v2a_nhwc_to_nchw_f32(src.data_ptr(), dst.data_ptr(), N, C, H * W, _stream()), "nhwc_to_nchw")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ attention etc.
+def attention(qkv, n_frames, L, heads, head_ch):
+    out = torch.empty((n_frames * L, heads * head_ch), dtype=torch.float32, device=qkv.device)
+    check(lib.v2a_attention_fwd(qkv.data_ptr(), out.data_ptr(), n_frames, L, heads, head_ch, _stream()), "attention_fwd")
+    return out
+
+
+def perceiver_attention(q, kv, q_scale, k_scale, B, Lq, Lk, H, D, sim_scale=8.0):
+    out = torch.empty((B, Lq, H * D), dtype=torch.float32, device=q.device)
+    check(lib.v2a_perceiver_attention(q.data_ptr(), kv.data_ptr(), q_scale.data_ptr(), k_scale.data_ptr(), out.data_ptr(), B, Lq,
+                                      Lk, H, D, sim_scale, _stream()), "perceiver_attention")
+    return out
+
+
+def layernorm(x2d, g, b=None, eps=1e-5):
+    rows, Dm = x2d.shape
+    y = torch.empty_like(x2d)
+    check(lib.v2a_layernorm(x2d.data_ptr(), g.data_ptr(), _p(b), y.data_ptr(), rows, Dm, eps, _stream()), "layernorm")
+    return y
+
+
+def mean_rows(x3d):
+    B, R, Dm = x3d.shape
+    out = torch.empty((B, Dm), dtype=torch.float32, device=x3d.device)
+    check(lib.v2a_mean_rows(x3d.data_ptr(), out.data_ptr(), B, R, Dm, _stream()), "mean_rows")
+    return out
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, OH, OW, C), dtype=torch.int8, device=x.device)
+    check(lib.v2a_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, C, _stream()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape):
+    N, H, W, C = in_shape
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    check(lib.v2a_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), N, H, W, C, _stream()), "maxpool_bwd")
+    return dx
+
+
+def spatial_softmax_fwd(feat):
+    B, H, W, K = feat.shape
+    kp = torch.empty((B, K * 2), dtype=torch.float32, device=feat.device)
+    att = torch.empty_like(feat)
+    check(lib.v2a_spatial_softmax_fwd(feat.data_ptr(), kp.data_ptr(), att.data_ptr(), B, H, W, K, _stream()), "spatial_softmax_fwd")
+    return kp, att
+
+
+def spatial_softmax_bwd(att, kp, dkp):
+    B, H, W, K = att.shape
+    dfeat = torch.empty_like(att)
+    check(lib.v2a_spatial_softmax_bwd(att.data_ptr(), kp.data_ptr(), dkp.data_ptr(), dfeat.data_ptr(), B, H, W, K, _stream()),
+          "spatial_softmax_bwd")
+    return dfeat
+
+
+def philox_normal(out, seed, offset_dev=None, offset_imm=0):
+    check(lib.v2a_philox_normal(out.data_ptr(), out.numel(), seed, _p(offset_dev), offset_imm, _stream()), "philox_normal")
+    return out
+
+
+def philox_randint(out, high, seed, offset_dev=None, offset_imm=0):
+    check(lib.v2a_philox_randint(out.data_ptr(), out.numel(), high, seed, _p(offset_dev), offset_imm, _stream()), "philox_randint")
+    return out
