@@ -14,6 +14,11 @@ __global__ void act_bwd_kernel(const float* x, const float* dy, float* dx, size_
 __global__ void axpy_kernel(const float* a, const float* b, float* out, float alpha, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a[i] + alpha * b[i];
 }
+// x *= *scalar (device scalar: the upstream gradient of the loss, e.g. a GradScaler factor)
+__global__ void scale_by_device_scalar_kernel(float* x, size_t n, const float* scalar) {
+    const float s = *scalar;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= s;
+}
 // strided 2-D copy: dst[r][dc0 + c] = src[r][sc0 + c]
 __global__ void copy2d_kernel(const float* src, float* dst, int rows, int cols, int lds_, int ldd, int accumulate) {
     const size_t total = (size_t)rows * cols;
@@ -268,6 +273,11 @@ int v2a_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, h
 }
 int v2a_axpy(const float* a, const float* b, float* out, float alpha, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(axpy_kernel, GRID_FOR(n), dim3(256), 0, s, a, b, out, alpha, n);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_scale_by_device_scalar(float* x, size_t n, const float* scalar, hipStream_t s) {
+    hipLaunchKernelGGL(scale_by_device_scalar_kernel, GRID_FOR(n), dim3(256), 0, s, x, n, scalar);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -30,6 +30,7 @@ SIGNATURES = {
     "v2a_act_fwd": (I, [P, P, SZ, I, P]),
     "v2a_act_bwd": (I, [P, P, P, SZ, I, P]),
     "v2a_axpy": (I, [P, P, P, F, SZ, P]),
+    "v2a_scale_by_device_scalar": (I, [P, SZ, P, P]),
     "v2a_copy2d": (I, [P, P, I, I, I, I, I, P]),
     "v2a_colsum": (I, [P, P, I, I, I, P]),
     "v2a_sincos_embed": (I, [P, P, I, I, I, P]),

@@ -141,15 +141,16 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     return y, mean, rstd
 
 
-def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False):
+def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
+                  dgamma=None, dbeta=None):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None)."""
     N, S, C = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     dfilm = torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None
     colsum_ = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.v2a_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), dout.data_ptr(),
@@ -293,3 +294,23 @@ def philox_normal(out, seed, offset_dev=None, offset_imm=0):
 def philox_randint(out, high, seed, offset_dev=None, offset_imm=0):
     check(lib.v2a_philox_randint(out.data_ptr(), out.numel(), high, seed, _p(offset_dev), offset_imm, _stream()), "philox_randint")
     return out
+
+
+def policy_sched_step(eps, sample, noise, coef, mode):
+    out = torch.empty_like(sample)
+    c_sb, c_sa, c0, c1, sigma = coef
+    check(lib.v2a_policy_sched_step(eps.data_ptr(), sample.data_ptr(), _p(noise), out.data_ptr(), sample.numel(), c_sb, c_sa, c0, c1,
+                                    sigma, mode, _stream()), "policy_sched_step")
+    return out
+
+
+def unnormalize_action(x):
+    out = torch.empty_like(x)
+    check(lib.v2a_unnormalize_action(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "unnormalize_action")
+    return out
+
+
+def scale_by_device_scalar(x, scalar):
+    """x *= scalar (a 0-dim / 1-element device tensor), in place, one kernel."""
+    check(lib.v2a_scale_by_device_scalar(x.data_ptr(), x.numel(), scalar.data_ptr(), _stream()), "scale_by_device_scalar")
+    return x

@@ -1,0 +1,491 @@
+"""Host-side executor of the goal-conditioned diffusion policy on the HIP kernels (forward, backward, sampling).
+
+Mirrors the reference's DiffusionUnetImagePolicy.compute_loss / predict_action
+(diffuser/diffusion_policy/diffusion_unet_image_policy.py:88-277) as an explicit launch sequence:
+  images NCHW -> NHWC + 2x-1 (normalizer.py:139-146)  -> 2 x ResNet18-GN + SpatialSoftmax + Linear
+  (model/multi_image_obs_encoder.py:144-196, common/vision_nets.py, common/base_nets.py:234-285)
+  -> add_noise -> ConditionalUnet1D (model/conditional_unet1d.py:178-246) -> MSE,
+then the hand-written backward of every op in reverse.  Parameters stay ordinary torch tensors with the
+reference's names; the engine only borrows their pointers and keeps packed copies of the conv weights.
+Everything is launched on torch's current stream and allocates only through torch's caching allocator, so a whole
+train step can be captured into one hipGraph (torch.cuda.graphs) and replayed.
+"""
+import math
+import numpy as np
+import torch
+from . import ops
+
+
+def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
+    """diffusers' squaredcos_cap_v2 betas -> alphas_cumprod (fp32 cumprod), restated from the published algorithm."""
+    ab = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    betas = torch.tensor([min(1 - ab((i + 1) / n) / ab(i / n), max_beta) for i in range(n)], dtype=torch.float32)
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+class _Conv:
+    """One conv / linear / transposed-conv parameter pair and its packed operands."""
+
+    def __init__(self, eng, wname, bname, transposed=False):
+        self.eng = eng
+        self.wname, self.bname = wname, bname
+        w = eng.P[wname]
+        self.shape = tuple(w.shape)
+        if w.dim() == 2:
+            self.kh, self.kw = 1, 1
+        elif w.dim() == 3:
+            self.kh, self.kw = 1, w.shape[2]
+        else:
+            self.kh, self.kw = w.shape[2], w.shape[3]
+        self.transposed = transposed
+        self.co, self.ci = w.shape[0], w.shape[1]     # torch dims 0 / 1 (for transposed: [Cin][Cout])
+        self._pf = None
+        self._pd = None
+        self._ver = (None, None)
+
+    @property
+    def w(self):
+        return self.eng.P[self.wname]
+
+    @property
+    def b(self):
+        return self.eng.P[self.bname] if self.bname is not None else None
+
+    def _fresh(self):
+        w = self.w
+        key = (w.data_ptr(), w._version)
+        if key != self._ver:
+            self.repack()
+
+    def repack(self):
+        w = self.w.detach()
+        if self.kh * self.kw == 1:
+            self._pf = w                         # [Cout][Cin] is already the K-contiguous forward operand
+        else:
+            if self._pf is None or self._pf is w:
+                self._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+            ops.pack_weight(w, 0, self._pf)
+        if self._pd is None:
+            self._pd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        ops.pack_weight(w, 1, self._pd)
+        self._ver = (self.w.data_ptr(), self.w._version)
+
+    def pf(self):
+        self._fresh()
+        return self._pf
+
+    def pd(self):
+        self._fresh()
+        return self._pd
+
+
+class PolicyEngine:
+    def __init__(self, cfg, params: dict):
+        """cfg: object with the PolicyCfg fields (see diffuser/diffusion_policy shell); params: name -> tensor (cuda fp32)."""
+        self.cfg = cfg
+        self.P = params
+        self.device = next(iter(params.values())).device
+        self.ac_host = squaredcos_alphas_cumprod(cfg.num_train_timesteps)
+        self.ac = self.ac_host.to(self.device)
+        self._convs = {}
+        self._build()
+
+    # ------------------------------------------------------------------ structure
+    def conv(self, wname, bname=None, transposed=False):
+        c = self._convs.get(wname)
+        if c is None:
+            c = _Conv(self, wname, bname, transposed)
+            self._convs[wname] = c
+        return c
+
+    def _build(self):
+        cfg = self.cfg
+        self.enc = {}
+        for key in cfg.rgb_keys:
+            pre = f"obs_encoder.key_model_map.{key}"
+            bb = pre + ".backbone.nets"
+            blocks = []
+            cin = cfg.widths[0]
+            for li, c in enumerate(cfg.widths):
+                for bi in range(2):
+                    stride = 2 if (li > 0 and bi == 0) else 1
+                    bp = f"{bb}.{4 + li}.{bi}"
+                    blk = dict(pre=bp, stride=stride, cin=cin, cout=c, conv1=self.conv(bp + ".conv1.weight"),
+                               conv2=self.conv(bp + ".conv2.weight"), down=None)
+                    if (bp + ".downsample.0.weight") in self.P:
+                        blk["down"] = self.conv(bp + ".downsample.0.weight")
+                    blocks.append(blk)
+                    cin = c
+            self.enc[key] = dict(pre=pre, bb=bb, conv1=self.conv(bb + ".0.weight"), blocks=blocks,
+                                 pool=self.conv(pre + ".pool.nets.weight", pre + ".pool.nets.bias"),
+                                 fc=self.conv(pre + ".nets.3.weight", pre + ".nets.3.bias"))
+        m = "model."
+        self.step1 = self.conv(m + "diffusion_step_encoder.1.weight", m + "diffusion_step_encoder.1.bias")
+        self.step3 = self.conv(m + "diffusion_step_encoder.3.weight", m + "diffusion_step_encoder.3.bias")
+        dims = [cfg.action_dim] + list(cfg.down_dims)
+        n = len(cfg.down_dims)
+
+        def rb(pre, cin, cout):
+            d = dict(pre=pre, cin=cin, cout=cout, c0=self.conv(pre + ".blocks.0.block.0.weight", pre + ".blocks.0.block.0.bias"),
+                     c1=self.conv(pre + ".blocks.1.block.0.weight", pre + ".blocks.1.block.0.bias"),
+                     ce=self.conv(pre + ".cond_encoder.1.weight", pre + ".cond_encoder.1.bias"), rc=None)
+            if cin != cout:
+                d["rc"] = self.conv(pre + ".residual_conv.weight", pre + ".residual_conv.bias")
+            return d
+
+        self.down = []
+        for i in range(n):
+            lvl = dict(r0=rb(f"{m}down_modules.{i}.0", dims[i], dims[i + 1]), r1=rb(f"{m}down_modules.{i}.1", dims[i + 1], dims[i + 1]),
+                       ds=None)
+            if i < n - 1:
+                lvl["ds"] = self.conv(f"{m}down_modules.{i}.2.conv.weight", f"{m}down_modules.{i}.2.conv.bias")
+            self.down.append(lvl)
+        mid = dims[-1]
+        self.mid = [rb(f"{m}mid_modules.{i}", mid, mid) for i in range(2)]
+        self.up = []
+        in_out = list(zip(dims[:-1], dims[1:]))
+        for i, (din, dout) in enumerate(reversed(in_out[1:])):
+            self.up.append(dict(r0=rb(f"{m}up_modules.{i}.0", dout * 2, din), r1=rb(f"{m}up_modules.{i}.1", din, din),
+                                us=self.conv(f"{m}up_modules.{i}.2.conv.weight", f"{m}up_modules.{i}.2.conv.bias", transposed=True)))
+        self.fin0 = self.conv(m + "final_conv.0.block.0.weight", m + "final_conv.0.block.0.bias")
+        self.fin1 = self.conv(m + "final_conv.1.weight", m + "final_conv.1.bias")
+
+    def refresh_packs(self):
+        """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable)."""
+        for c in self._convs.values():
+            c.repack()
+
+    # ------------------------------------------------------------------ encoder
+    def _gn(self, x4, pre, G, act, residual=None, film=None):
+        N = x4.shape[0]
+        C = x4.shape[-1]
+        x3 = x4.view(N, -1, C)
+        r3 = residual.view(N, -1, C) if residual is not None else None
+        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film)
+        return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
+
+    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False):
+        x3, mean, rstd, r3, film, pre, G, act = saved
+        d3 = dout4.view(x3.shape)
+        dx, dg, db, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
+                                                    residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
+                                                    dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"])
+        return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
+
+    def encode_fwd(self, key, img_nchw, save):
+        """img [B,3,H,W] in [0,1] (float or uint8) -> feature [B, feature_dim].  save: list collecting backward state (or None)."""
+        e = self.enc[key]
+        cfg = self.cfg
+        w0 = cfg.widths[0]
+        x0 = ops.nchw_to_nhwc(img_nchw, normalize=True)
+        c1 = ops.conv2d(x0, e["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3))
+        a1, s_gn1 = self._gn(c1, e["bb"] + ".1", w0 // 16, "relu")
+        h, pidx = ops.maxpool_fwd(a1)
+        st = dict(x0=x0, gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
+        for blk in e["blocks"]:
+            s, co = blk["stride"], blk["cout"]
+            g = co // 16
+            inp = h
+            o1 = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1))
+            a, s1 = self._gn(o1, blk["pre"] + ".bn1", g, "relu")
+            o2 = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1))
+            sd = None
+            if blk["down"] is not None:
+                idn = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0))
+                idn, sd = self._gn(idn, blk["pre"] + ".downsample.1", g, "none")
+            else:
+                idn = inp
+            h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn)
+            st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd))
+        feat = h
+        B, FH, FW, FC = feat.shape
+        kl = ops.conv2d(feat, e["pool"].pf(), e["pool"].b, cfg.num_kp, 1, 1)
+        kp, att = ops.spatial_softmax_fwd(kl)
+        f = ops.linear(kp, e["fc"].pf(), e["fc"].b)
+        st.update(feat=feat, kp=kp, att=att)
+        if save is not None:
+            save[key] = st
+        return f
+
+    def encode_bwd(self, key, df, st, grads):
+        e = self.enc[key]
+        cfg = self.cfg
+        B = df.shape[0]
+        fc, pool = e["fc"], e["pool"]
+        ops.conv2d_wgrad(st["kp"].view(1, 1, B, -1), df.view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname])
+        ops.colsum(df, out=grads[fc.bname])
+        dkp = ops.conv2d(df.view(1, 1, B, -1), fc.pd(), None, fc.ci, 1, 1).view(B, -1)
+        dkl = ops.spatial_softmax_bwd(st["att"], st["kp"], dkp)
+        feat = st["feat"]
+        ops.conv2d_wgrad(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname])
+        ops.colsum(dkl.view(-1, cfg.num_kp), out=grads[pool.bname])
+        dh = ops.conv2d(dkl, pool.pd(), None, pool.ci, 1, 1)
+        for blk, bs in zip(reversed(e["blocks"]), reversed(st["blocks"])):
+            s, co, ci = blk["stride"], blk["cout"], blk["cin"]
+            inp = bs["inp"]
+            do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True)
+            ops.conv2d_wgrad(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
+            da = ops.conv2d(do2, blk["conv2"].pd(), None, co, 3, 3, (1, 1), (1, 1))
+            do1, _, _ = self._gn_bwd(bs["s1"], da, grads)
+            ops.conv2d_wgrad(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname])
+            ih, iw = inp.shape[1], inp.shape[2]
+            if blk["down"] is not None:
+                didn_raw, _, _ = self._gn_bwd(bs["sd"], didn, grads)
+                ops.conv2d_wgrad(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname])
+                d1 = ops.conv2d(didn_raw, blk["down"].pd(), None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw))
+                dh = ops.conv2d(do1, blk["conv1"].pd(), None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1)
+            else:
+                dh = ops.conv2d(do1, blk["conv1"].pd(), None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn)
+        da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
+        dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
+        ops.conv2d_wgrad(st["x0"], dc1, e["conv1"].shape, 7, 7, (2, 2), (3, 3), dw=grads[e["conv1"].wname])
+
+    # ------------------------------------------------------------------ ConditionalUnet1D
+    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None):
+        """Conv1d on [B,T,C] (channels-last) via the (1 x k) view."""
+        B, T, C = x.shape
+        pad = k // 2 if pad is None else pad
+        y = ops.conv2d(x.view(B, 1, T, C), cv.pf(), cv.b, cv.co, 1, k, (1, stride), (0, pad),
+                       x2=None if x2 is None else x2.view(B, 1, T, -1),
+                       residual=None if residual is None else residual.view(B, 1, -1, cv.co))
+        return y.view(B, -1, cv.co)
+
+    def _res_fwd(self, r, x, mgf, save, x2=None):
+        cfg = self.cfg
+        k, G = cfg.kernel_size, cfg.n_groups
+        B, T, _ = x.shape
+        co = r["cout"]
+        c0 = self._c1d(x, r["c0"], k, x2=x2)
+        film = ops.linear(mgf, r["ce"].pf(), r["ce"].b)                       # [B, 2*co] == [B][2][co]
+        a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film)
+        a0 = a0.view(B, T, co)
+        c1 = self._c1d(a0, r["c1"], k)
+        a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish")
+        a1 = a1.view(B, T, co)
+        if r["rc"] is not None:
+            out = self._c1d(x, r["rc"], 1, x2=x2, residual=a1, pad=0)
+        else:
+            out = ops.axpy(a1, x)
+        if save is not None:
+            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1))
+        return out
+
+    def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True):
+        """Returns (dx, dx2, dmgf).  dx2 only for two-source (concat) inputs.  `extra` is added to dx."""
+        cfg = self.cfg
+        r, x, x2 = st["r"], st["x"], st["x2"]
+        k = cfg.kernel_size
+        B, T, _ = x.shape
+        co, ci = r["cout"], r["cin"]
+        C1 = x.shape[-1]
+        x4 = x.view(B, 1, T, C1)
+        x24 = None if x2 is None else x2.view(B, 1, T, -1)
+        d4 = dout.view(B, 1, T, co)
+        dc1, _, _ = self._gn_bwd(st["s1"], d4, grads)
+        c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
+        ops.conv2d_wgrad(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname])
+        ops.colsum(dc1.view(-1, co), out=grads[c1v.bname])
+        da0 = ops.conv2d(dc1, c1v.pd(), None, co, 1, k, (1, 1), (0, k // 2))
+        dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
+        df2 = dfilm.view(B, 2 * co)
+        ops.conv2d_wgrad(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname])
+        ops.colsum(df2, out=grads[cev.bname])
+        dmgf = ops.conv2d(df2.view(1, 1, B, -1), cev.pd(), None, cev.ci, 1, 1, residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
+        ops.conv2d_wgrad(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname])
+        ops.colsum(dc0.view(-1, co), out=grads[c0v.bname])
+        rc = r["rc"]
+        if rc is not None:
+            ops.conv2d_wgrad(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname])
+            ops.colsum(d4.view(-1, co), out=grads[rc.bname])
+        if not need_dx:
+            return None, None, dmgf
+        if rc is not None:
+            first = ops.conv2d(dc0, c0v.pd(), None, ci, 1, k, (1, 1), (0, k // 2),
+                               residual=None if extra is None else extra.view(B, 1, T, ci))
+            if x2 is None:
+                dx = ops.conv2d(d4, rc.pd(), None, ci, 1, 1, residual=first).view(B, T, ci)
+                return dx, None, dmgf
+            C2 = ci - C1
+            dxa = torch.empty((B, T, C1), dtype=torch.float32, device=x.device)
+            dxb = torch.empty((B, T, C2), dtype=torch.float32, device=x.device)
+            ops.conv2d(d4, rc.pd(), None, ci, 1, 1, residual=first, y=dxa.view(B, 1, T, C1), y2=dxb.view(B, 1, T, C2), csplit=C1)
+            return dxa, dxb, dmgf
+        res = dout if extra is None else ops.axpy(dout, extra)
+        dx = ops.conv2d(dc0, c0v.pd(), None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci)).view(B, T, ci)
+        return dx, None, dmgf
+
+    def unet_fwd(self, sample, t_long, global_cond, save=None):
+        """sample [B,T,Da] fp32, t_long [B] int64, global_cond [B,G] -> eps prediction [B,T,Da]."""
+        cfg = self.cfg
+        B, T, Da = sample.shape
+        temb = ops.sincos_embed(t_long, cfg.dsed, 0)
+        e1 = ops.linear(temb, self.step1.pf(), self.step1.b)
+        m1 = ops.act_fwd(e1, "mish")
+        e2 = ops.linear(m1, self.step3.pf(), self.step3.b)
+        Gd = global_cond.shape[1]
+        gf = torch.empty((B, cfg.dsed + Gd), dtype=torch.float32, device=sample.device)
+        ops.copy2d(e2, gf, B, cfg.dsed, cfg.dsed, cfg.dsed + Gd)
+        ops.copy2d(global_cond, gf, B, Gd, Gd, cfg.dsed + Gd, dst_off=cfg.dsed)
+        mgf = ops.act_fwd(gf, "mish")
+        self._mgf = mgf
+        tape = [] if save is not None else None
+        x = sample
+        hs = []
+        n = len(self.down)
+        for i, lvl in enumerate(self.down):
+            x = self._res_fwd(lvl["r0"], x, mgf, tape)
+            x = self._res_fwd(lvl["r1"], x, mgf, tape)
+            hs.append(x)
+            if lvl["ds"] is not None:
+                xin = x
+                x = self._c1d(x, lvl["ds"], 3, stride=2, pad=1)
+                if tape is not None:
+                    tape.append(dict(ds=lvl["ds"], x=xin))
+        for r in self.mid:
+            x = self._res_fwd(r, x, mgf, tape)
+        for lvl in self.up:
+            skip = hs.pop()
+            x = self._res_fwd(lvl["r0"], x, mgf, tape, x2=skip)
+            x = self._res_fwd(lvl["r1"], x, mgf, tape)
+            xin = x
+            us = lvl["us"]
+            Bx, Tx, Cx = x.shape
+            x = ops.conv2d(x.view(Bx, 1, Tx, Cx), us.pd(), us.b, us.ci, 1, 4, (1, 1), (0, 2), idil=2, out_hw=(1, 2 * Tx)).view(Bx, 2 * Tx, us.ci)
+            if tape is not None:
+                tape.append(dict(us=us, x=xin))
+        k = cfg.kernel_size
+        c = self._c1d(x, self.fin0, k)
+        a, sf = self._gn(c.view(B, 1, -1, self.fin0.co), "model.final_conv.0.block.1", 8, "mish")
+        a = a.view(B, -1, self.fin0.co)
+        pred = self._c1d(a, self.fin1, 1, pad=0)
+        if save is not None:
+            save.update(tape=tape, temb=temb, e1=e1, m1=m1, gf=gf, fin_x=x, fin_a=a, fin_s=sf, n_levels=n)
+        return pred
+
+    def unet_bwd(self, dpred, save, grads):
+        """Returns d(global_cond) [B,G]."""
+        cfg = self.cfg
+        k = cfg.kernel_size
+        B, T, Da = dpred.shape
+        f1, f0 = self.fin1, self.fin0
+        a, x = save["fin_a"], save["fin_x"]
+        d4 = dpred.view(B, 1, T, Da)
+        ops.conv2d_wgrad(a.view(B, 1, T, -1), d4, f1.shape, 1, 1, dw=grads[f1.wname])
+        ops.colsum(dpred.view(-1, Da), out=grads[f1.bname])
+        da = ops.conv2d(d4, f1.pd(), None, f1.ci, 1, 1)
+        dc, _, _ = self._gn_bwd(save["fin_s"], da, grads)
+        ops.conv2d_wgrad(x.view(B, 1, T, -1), dc, f0.shape, 1, k, (1, 1), (0, k // 2), dw=grads[f0.wname])
+        ops.colsum(dc.view(-1, f0.co), out=grads[f0.bname])
+        dx = ops.conv2d(dc, f0.pd(), None, f0.ci, 1, k, (1, 1), (0, k // 2)).view(B, T, f0.ci)
+        tape = save["tape"]
+        dmgf = None
+        pending_skip = []          # gradients flowing into hs entries from the up path (LIFO order of use)
+        # walk the tape backwards
+        i = len(tape) - 1
+        n_res_seen = 0
+        total_res = sum(1 for e in tape if "r" in e)
+        skip_for_level = {}
+        while i >= 0:
+            e = tape[i]
+            if "us" in e:
+                us, xin = e["us"], e["x"]
+                Bx, Tx, Cx = xin.shape
+                dy4 = dx.view(Bx, 1, 2 * Tx, us.ci)
+                x4 = xin.view(Bx, 1, Tx, Cx)
+                ops.conv2d_wgrad(dy4, x4, us.shape, 1, 4, (1, 2), (0, 1), dw=grads[us.wname])
+                ops.colsum(dx.view(-1, us.ci), out=grads[us.bname])
+                dx = ops.conv2d(dy4, us.pf(), None, Cx, 1, 4, (1, 2), (0, 1)).view(Bx, Tx, Cx)
+            elif "ds" in e:
+                ds, xin = e["ds"], e["x"]
+                Bx, Tx, Cx = xin.shape
+                dy4 = dx.view(Bx, 1, -1, ds.co)
+                x4 = xin.view(Bx, 1, Tx, Cx)
+                ops.conv2d_wgrad(x4, dy4, ds.shape, 1, 3, (1, 2), (0, 1), dw=grads[ds.wname])
+                ops.colsum(dx.view(-1, ds.co), out=grads[ds.bname])
+                skip = pending_skip.pop() if pending_skip else None
+                dx = ops.conv2d(dy4, ds.pd(), None, Cx, 1, 3, (1, 1), (0, 1), idil=2, out_hw=(1, Tx),
+                                residual=None if skip is None else skip.view(Bx, 1, Tx, Cx)).view(Bx, Tx, Cx)
+            else:
+                n_res_seen += 1
+                first_block = (n_res_seen == total_res)          # down_modules.0.0: its input is data -> no dx
+                extra = None
+                # the first mid block consumes hs[-1] directly (Identity downsample on the last level)
+                if e["r"] is self.mid[0]:
+                    extra = pending_skip.pop()
+                dx, dx2, dmgf = self._res_bwd(e, dx, grads, dmgf, extra=extra, need_dx=not first_block)
+                if dx2 is not None:
+                    pending_skip.append(dx2)
+            i -= 1
+        # pending_skip is pushed in up-path order (deepest level first) and popped by the matching consumers
+        # in reverse tape order: mid[0] pops the deepest, then each downsample pops the next shallower one.
+        # --- step encoder
+        gf = save["gf"]
+        dgf = ops.act_bwd(gf, dmgf, "mish")
+        Gd = gf.shape[1] - cfg.dsed
+        de2 = torch.empty((B, cfg.dsed), dtype=torch.float32, device=gf.device)
+        dgc = torch.empty((B, Gd), dtype=torch.float32, device=gf.device)
+        ops.copy2d(dgf, de2, B, cfg.dsed, gf.shape[1], cfg.dsed)
+        ops.copy2d(dgf, dgc, B, Gd, gf.shape[1], Gd, src_off=cfg.dsed)
+        s3, s1 = self.step3, self.step1
+        ops.conv2d_wgrad(save["m1"].view(1, 1, B, -1), de2.view(1, 1, B, -1), s3.shape, 1, 1, dw=grads[s3.wname])
+        ops.colsum(de2, out=grads[s3.bname])
+        dm1 = ops.conv2d(de2.view(1, 1, B, -1), s3.pd(), None, s3.ci, 1, 1).view(B, -1)
+        de1 = ops.act_bwd(save["e1"], dm1, "mish")
+        ops.conv2d_wgrad(save["temb"].view(1, 1, B, -1), de1.view(1, 1, B, -1), s1.shape, 1, 1, dw=grads[s1.wname])
+        ops.colsum(de1, out=grads[s1.bname])
+        return dgc
+
+    # ------------------------------------------------------------------ policy level
+    def global_cond(self, imgs: dict, save=None):
+        feats = [self.encode_fwd(k, imgs[k], save) for k in self.cfg.rgb_keys]
+        B = feats[0].shape[0]
+        fd = feats[0].shape[1]
+        gc = torch.empty((B, fd * len(feats)), dtype=torch.float32, device=feats[0].device)
+        for i, f in enumerate(feats):
+            ops.copy2d(f, gc, B, fd, fd, fd * len(feats), dst_off=i * fd)
+        return gc
+
+    def grad_layout(self, names):
+        """Flat-arena layout for the gradients of `names` (canonical parameter names, optimiser order)."""
+        offs, total = {}, 0
+        for n in names:
+            offs[n] = total
+            total += self.P[n].numel()
+        return offs, total
+
+    def grad_views(self, arena, names):
+        offs, total = self.grad_layout(names)
+        assert arena.numel() >= total
+        return {n: arena[offs[n]:offs[n] + self.P[n].numel()].view(self.P[n].shape) for n in names}
+
+    def loss_fwd_bwd(self, imgs: dict, action, noise, timesteps, need_grad=True, names=None, arena=None):
+        """compute_loss (+ backward).  imgs[key] [B,3,H,W]; action/noise [B,T,Da]; timesteps [B] int64.
+        Gradients (torch layout) are written into views of one flat fp32 arena (a fresh one unless given): the same
+        buffer feeds the RCCL all-reduce and the fused optimiser.  Returns (loss[1], {name: grad view}, arena)."""
+        save_enc = {} if need_grad else None
+        gc = self.global_cond(imgs, save_enc)
+        noisy = ops.add_noise(action, noise, timesteps, self.ac)
+        save = {} if need_grad else None
+        pred = self.unet_fwd(noisy, timesteps, gc, save)
+        loss, dpred = ops.mse_loss(pred, noise, want_grad=need_grad)
+        if not need_grad:
+            return loss, None, None
+        names = list(names) if names is not None else self.trainable_names()
+        if arena is None:
+            arena = torch.empty(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)
+        grads = self.grad_views(arena, names)
+        dgc = self.unet_bwd(dpred, save, grads)
+        B = dgc.shape[0]
+        fd = self.cfg.feature_dim
+        nk = len(self.cfg.rgb_keys)
+        for i, key in enumerate(self.cfg.rgb_keys):
+            df = torch.empty((B, fd), dtype=torch.float32, device=dgc.device)
+            ops.copy2d(dgc, df, B, fd, fd * nk, fd, src_off=i * fd)
+            self.encode_bwd(key, df, save_enc[key], grads)
+        return loss, grads, arena
+
+    def trainable_names(self):
+        """Every parameter the backward produces a gradient for (the reference trains all of these)."""
+        skip = ("_dummy_variable", "temperature")
+        return [n for n, p in self.P.items() if torch.is_floating_point(p) and p.dim() > 0 and p.numel() > 0
+                and not any(n.endswith(s) for s in skip) and not n.endswith("pos_x") and not n.endswith("pos_y")]
