@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Headline benchmark (driver contract: one JSON line on rank 0).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at N=1 = BASELINE.json configs[1]: Libero 8-task diffusion-policy train step, batch 64 per GPU, synthetic 128x128
+start/goal images (uint8 replay store, 8 tasks x 50 episodes x 121 frames) + 7-DoF action chunks (horizon 16), random-init weights
+of the reference architecture (87,219,143 parameters).  A "step" = SURVEY.md 8a rows R1..R9: bit-exact replay index draw + HBM
+gather -> noise / timesteps -> forward + backward (hand-written HIP) -> [RCCL grad all-reduce] -> fused clip + AdamW + zero + EMA.
+Compute dtype fp32 (exact-f32 MFMA): the parity configuration (north_star: outputs within 1e-4 of the fp32 CPU path).
+Multi-GPU: weak scaling, one process per GPU (torch.distributed 'nccl' = RCCL over xGMI), value = batch-64 steps of ALL ranks / time.
+Extra objects: `roofline` (dominant kernel, measured live with HIP events in an instrumented pass), `cpu_baseline` (the CPU oracle
+timed on this box's host cores on a bounded sample), `video` (sampler frames/s, when --video).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table (dense f32 matrix = vector peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_store(torch, device, batch, seed):
+    from v2a_hip.replay import ReplayStore
+    n_eps, ep_len = 8 * 50, 121
+    store = ReplayStore(1200, 700, 30, image_hw=(128, 128), capacity_frames=n_eps * ep_len, device=device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    # synthetic payload generated directly in HBM (uint8 frames like the HDF5 random-action file; actions U[-1,1))
+    store.frames.copy_(torch.randint(0, 256, store.frames.shape, dtype=torch.uint8, device=device, generator=g))
+    store.acts.copy_(torch.rand(store.acts.shape, device=device, generator=g) * 2 - 1)
+    for e in range(n_eps):
+        store.episodes.append((e * ep_len, ep_len, f"task{e % 8}", "agentview", e % 8))
+    return store
+
+
+def instrumented_pass(torch, trainer, steps):
+    """Eager pass with a HIP-event pair around every conv launch: per tile-variant totals of algorithmic FLOPs and time."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    recs = []
+    orig_fwd, orig_wg = ops.conv2d, ops.conv2d_wgrad
+
+    def timed(kind, fn, flops_of):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            recs.append((kind, flops_of(a, k, out), e0, e1))
+            return out
+        return wrapper
+
+    def f_fwd(a, k, out):
+        x, cout, kh, kw = a[0], a[3], a[4], a[5]
+        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
+        y = out if k.get("y") is None else k["y"]
+        m = y.shape[0] * y.shape[1] * y.shape[2]
+        K = kh * kw * (x.shape[-1] + c2)
+        bm = 128 if m >= 4096 else 64
+        bn = (128 if bm == 128 else 64) if cout > 64 else 64
+        return (f"conv_igemm_f32<{bm},{bn}>", 2.0 * m * cout * K)
+
+    def f_wg(a, k, out):
+        x, dy, kh, kw = a[0], a[1], a[3], a[4]
+        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
+        m = dy.shape[0] * dy.shape[1] * dy.shape[2]
+        cout = dy.shape[-1]
+        K = kh * kw * (x.shape[-1] + c2)
+        bm = 128 if cout > 64 else 64
+        bn = 128 if (K > 64 and bm == 128) else 64
+        return (f"conv_wgrad_f32<{bm},{bn}>", 2.0 * m * cout * K)
+
+    ops.conv2d = timed("fwd", orig_fwd, f_fwd)
+    ops.conv2d_wgrad = timed("wgrad", orig_wg, f_wg)
+    g_saved = trainer.use_graph
+    trainer.use_graph = False
+    try:
+        for _ in range(steps):
+            trainer.step()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d, ops.conv2d_wgrad = orig_fwd, orig_wg
+        trainer.use_graph = g_saved
+    agg = {}
+    for kind, (name, fl), e0, e1 in recs:
+        d = agg.setdefault(name, [0.0, 0.0, 0])
+        d[0] += fl
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    return agg
+
+
+def _cpu_baseline_worker(batch, threads, budget):
+    """Runs in a subprocess (bounded by a hard timeout): the CPU oracle train step on `threads` host threads."""
+    import torch
+    from oracle import policy as OP
+    from oracle import optim as OO
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    pol = build_policy(DEFAULT_CONF)
+    sd = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    names = [n for n, p in pol.named_parameters() if p.dim() > 0 and p.numel() > 0]
+    ps = [sd[n] for n in names]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    em = [p.clone() for p in ps]
+    st = OO.EmaState(power=0.75)
+    b = {"obs": {"img_obs_1": torch.rand(batch, 1, 3, 128, 128), "img_goal_1": torch.rand(batch, 1, 3, 128, 128)},
+         "action": torch.rand(batch, 16, 7) * 2 - 1}
+    n, t_used = 0, 0.0
+    while t_used < budget and n < 12:
+        t0 = time.time()
+        noise = torch.randn(batch, 16, 7)
+        ts = torch.randint(0, 100, (batch,))
+        _, g = OP.loss_and_grads(sd, b, noise, ts, names=names)
+        OO.train_tail(ps, [g[k] for k in names], ms, vs, em, n + 1, st)
+        dt = time.time() - t0
+        if n > 0:            # the first iteration warms the allocator / oneDNN primitives and is not counted
+            t_used += dt
+        n += 1
+        print(json.dumps({"done": max(n - 1, 0), "t": t_used}), flush=True)
+
+
+def cpu_baseline(batch, budget=20.0, hard_timeout=150.0):
+    """The CPU oracle (pinned bit-exact against the reference) timed on this box's host cores, in a subprocess with a hard
+    timeout so that a slow / oversubscribed host can never stall the benchmark.  Threads = min(usable cores, 32)."""
+    import subprocess
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = os.cpu_count() or 1
+    threads = max(1, min(usable, 32))
+    code = (f"import sys, json, time; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'video-to-action-release_amd')!r}); "
+            f"import bench; bench._cpu_baseline_worker({batch}, {threads}, {budget})")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    last = None
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=hard_timeout, env=env)
+        lines = p.stdout.strip().splitlines()
+    except subprocess.TimeoutExpired as e:
+        lines = (e.stdout or b"").decode().strip().splitlines() if isinstance(e.stdout, bytes) else (e.stdout or "").strip().splitlines()
+    for ln in lines:
+        try:
+            last = json.loads(ln)
+        except Exception:
+            pass
+    if not last or last["done"] < 1:
+        return {"value": None, "unit": "steps/s", "cores": threads, "kind": "port",
+                "sample": f"no B={batch} CPU step finished within the {hard_timeout:.0f} s cap on {threads} threads (host cores: {usable})"}
+    return {"value": last["done"] / last["t"], "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{last['done']} timed steps of the same B={batch} fp32 train step (CPU oracle fwd+bwd via torch-CPU autograd + "
+                      f"clip/AdamW/EMA; first step untimed), {last['t']:.1f} s on {threads} threads (usable host cores: {usable})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--video", action="store_true", help="also time the video sampler (C3-shaped, reduced step count)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import random
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        pg = dist.group.WORLD
+
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from v2a_hip.trainer import PolicyTrainer
+    torch.manual_seed(0)                       # identical replica init on every rank
+    pol = build_policy(DEFAULT_CONF).to(device)
+    np.random.seed(rank)
+    random.seed(rank)
+    store = build_store(torch, device, args.batch, seed=100 + rank)
+    tr = PolicyTrainer(pol, store, batch_size=args.batch, seed=rank, use_graph=not args.no_graph, process_group=pg,
+                       world_size=world, rank=rank)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):       # >= 3: two eager steps + the capture step
+        tr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(tr.loss.item())
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.steps / dt
+        P = 87219143
+        flops_step = 8.722e9 * args.batch                  # fwd+bwd algorithmic FLOPs per sample
+        out = {"metric": "policy_train_steps_per_sec", "value": value, "unit": "steps/s (batch-64 steps, all ranks)", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Libero 8-task diffusion-policy train step (BASELINE.json configs[1]): R1 replay gather -> "
+                                      "compute_loss fwd/bwd -> clip -> AdamW -> EMA", "batch_per_gpu": args.batch,
+                          "global_batch": args.batch * world, "image": "128x128x3 uint8 start+goal", "action": "16x7",
+                          "params": P, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+               "samples_per_sec": value * args.batch, "final_loss": loss,
+               "step_algorithmic_tflops": flops_step / (ms * 1e-3) / 1e12}
+    # ---- roofline of the dominant kernel (rank 0, N=1 only): instrumented eager pass
+    if rank == 0 and world == 1:
+        agg = instrumented_pass(torch, tr, 3)
+        tot = sum(v[1] for v in agg.values())
+        name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+        achieved = fl / sec / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(name)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": cnt,
+                           "avg_launch_us": sec / cnt * 1e6, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
+                           "share_of_conv_time": sec / tot,
+                           "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 3 * 1e3, "launches_per_step": v[2] // 3}
+                                                 for k, v in sorted(agg.items())}}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

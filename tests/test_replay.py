@@ -1,0 +1,102 @@
+"""Replay index stream: C oracle vs numpy/CPython (pinning), vs golden vectors from the reference's own buffer, and the product's
+native sampler vs both (host part runs without a GPU; the gather is covered under -m gpu)."""
+import ctypes
+import random
+import numpy as np
+import pytest
+import torch
+
+
+def test_oracle_pinned_against_numpy_and_cpython():
+    from oracle import replay as R
+    for seed in [0, 1, 123, 2 ** 31 + 5, 4294967295]:
+        nps, pys = R.np_seeded(seed), R.py_seeded(seed)
+        np.random.seed(seed); random.seed(seed)
+        for _ in range(50):
+            n_eps = random.randint(1, 1300)
+            assert R.lib().py_randint(ctypes.byref(pys), 1, 1300) == n_eps
+            lens = np.random.randint(17, 700, size=n_eps)
+            tmp = np.zeros(n_eps, dtype=np.int64)
+            R.lib().np_randint(ctypes.byref(nps), 17, 700, tmp.ctypes.data, n_eps)
+            assert (tmp == lens).all()
+            ref_ep = np.random.randint(0, n_eps, size=64)
+            ref_st = np.array([random.randint(0, lens[e] - 16 - 1) for e in ref_ep])
+            ep, st = R.sample_seq(nps, pys, lens, 64, 16)
+            assert (ep == ref_ep).all() and (st == ref_st).all()
+            u = np.random.uniform(low=0, high=1, size=(7,))
+            u2 = np.zeros(7)
+            R.lib().np_uniform(ctypes.byref(nps), 0.0, 1.0, u2.ctypes.data, 7)
+            assert (u == u2).all()
+
+
+def test_oracle_vs_reference_golden(golden_dir):
+    """golden replay.npz was produced by the reference's Global_EnvReplayBuffer_Img itself (tools/make_golden.py g_replay)."""
+    from oracle import replay as R
+    g = np.load(f"{golden_dir}/replay.npz")
+    for seed in (0, 123, 9001):
+        nps, pys = R.np_seeded(seed), R.py_seeded(seed)
+        lens = g[f"lens_{seed}"]
+        for it in range(5):
+            ep, st = R.sample_seq(nps, pys, lens, 64, 16)
+            assert (ep == g[f"episodes_{seed}"][it]).all() and (st == g[f"starts_{seed}"][it]).all()
+
+
+def test_product_sampler_consumes_live_generators_bit_exactly(golden_dir):
+    """v2a_hip.replay.sample_indices must (a) reproduce the golden stream and (b) leave np.random / random in exactly the state
+    the reference would have left them in."""
+    pytest.importorskip("v2a_hip")
+    from v2a_hip.replay import sample_indices, count_uniform_below
+    g = np.load(f"{golden_dir}/replay.npz")
+    for seed in (0, 123, 9001):
+        lens = g[f"lens_{seed}"]
+        np.random.seed(seed); random.seed(seed)
+        for it in range(5):
+            ep, st = sample_indices(lens, 64, 16)
+            assert (ep == g[f"episodes_{seed}"][it]).all() and (st == g[f"starts_{seed}"][it]).all()
+        after_np, after_py = np.random.randint(0, 10 ** 6), random.random()
+        np.random.seed(seed); random.seed(seed)
+        for it in range(5):
+            e = np.random.randint(0, len(lens), size=64)
+            [random.randint(0, lens[i] - 16 - 1) for i in e]
+        assert after_np == np.random.randint(0, 10 ** 6) and after_py == random.random()
+    np.random.seed(77)
+    probs = np.random.uniform(low=0, high=1, size=(64,))
+    np.random.seed(77)
+    assert count_uniform_below(64, 0.3) == int((probs < 0.3).sum())
+    # edge cases: a single episode draws nothing from numpy; too-short episode asserts like the reference
+    np.random.seed(1); random.seed(1)
+    s0 = np.random.get_state()[2]
+    ep, st = sample_indices(np.array([40]), 4, 16)
+    assert (ep == 0).all() and np.random.get_state()[2] == s0
+    with pytest.raises(AssertionError):
+        sample_indices(np.array([16]), 1, 16)
+
+
+@pytest.mark.gpu
+def test_store_gather_matches_reference_semantics(golden_dir):
+    from v2a_hip.replay import ReplayStore
+    g = np.load(f"{golden_dir}/replay.npz")
+    seed = 123
+    lens = g[f"lens_{seed}"]
+    store = ReplayStore(1200, 700, 30, image_hw=(4, 4), capacity_frames=int(lens.sum()) + 8, dtype=torch.float32)
+    for e, L in enumerate(lens):
+        imgs = [torch.full((3, 4, 4), float(e * 1000 + i)) for i in range(L)]
+        acts = [torch.full((7,), float(e * 1000 + i)) for i in range(L - 1)]
+        store.add_one_episode("t", "agentview", e, imgs, acts)
+    np.random.seed(seed); random.seed(seed)
+    for it in range(5):
+        s, gl, a, tasks, info = store.sample_random_batch_seq(64)
+        ep = (s[:, 0, 0, 0] // 1000).long().cpu().numpy()
+        st = (s[:, 0, 0, 0] % 1000).long().cpu().numpy()
+        assert (ep == g[f"episodes_{seed}"][it]).all() and (st == g[f"starts_{seed}"][it]).all()
+        assert ((gl[:, 0, 0, 0] % 1000).long().cpu().numpy() == st + 16).all()
+        assert s.shape == (64, 3, 4, 4) and a.shape == (64, 16, 7)
+        want = torch.from_numpy(ep * 1000 + st)[:, None] + torch.arange(16)[None]
+        assert torch.equal(a[:, :, 0].cpu().long(), want)
+    # uint8 store: /255 conversion and HWC->CHW
+    st8 = ReplayStore(4, 100, 2, image_hw=(4, 4), capacity_frames=64)
+    raw = torch.randint(0, 256, (20, 4, 4, 3), dtype=torch.uint8)
+    st8.add_one_episode("t", "c", 0, raw, torch.zeros(19, 7))
+    o0, o1, _ = st8.gather(np.array([0]), np.array([2]))
+    assert torch.equal(o0[0].cpu(), raw[2].permute(2, 0, 1).float() / 255.0)
+    assert torch.equal(o1[0].cpu(), raw[18].permute(2, 0, 1).float() / 255.0)

@@ -1,0 +1,83 @@
+"""Video path parity on the GPU: HIP UNet / sampler (through Unet_Libero / GoalGaussianDiffusion surfaces) vs golden vectors
+produced by the reference itself and vs the CPU oracle.  fp32, tolerance 1e-4 relative (sampler: per final frame)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _tiny():
+    from flowdiffusion.flowdiffusion.unet import Unet_Tiny
+    from oracle.param_fill import fill_module
+    from tools_wsum import wsum
+    torch.manual_seed(0)
+    m = Unet_Tiny()
+    sd = fill_module(m, seed=11)
+    return m.to("cuda:0").eval(), sd, wsum(sd)
+
+
+def test_tiny_unet_forward_vs_golden_and_oracle(golden_dir):
+    from oracle.video_unet import UNetCfg, unet_libero_forward
+    g = np.load(f"{golden_dir}/unet_tiny.npz", allow_pickle=True)
+    m, sd, ws = _tiny()
+    assert abs(ws - float(g["weights_abs_sum"])) < 1e-6 * ws
+    x, t, te = torch.from_numpy(g["fwd_x"]), torch.from_numpy(g["fwd_t"]), torch.from_numpy(g["fwd_te"])
+    y = m(x.cuda(), t.cuda(), te.cuda())
+    assert rel(y, g["fwd_y"]) <= TOL, rel(y, g["fwd_y"])
+    cfg = UNetCfg(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+                  num_head_channels=16)
+    with torch.no_grad():
+        yo = unet_libero_forward(sd, x, t, te, cfg)
+    assert rel(yo, g["fwd_y"]) < 1e-6          # oracle == reference
+    assert rel(y, yo) <= TOL
+
+
+@pytest.mark.parametrize("name,steps,gw", [("ddpm100", 100, 0.0), ("ddim50", 50, 0.0), ("ddim10_cfg", 10, 1.5)])
+def test_sampler_vs_golden(golden_dir, name, steps, gw):
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    g = np.load(f"{golden_dir}/unet_tiny.npz", allow_pickle=True)
+    m, _, _ = _tiny()
+    d = GoalGaussianDiffusion(m, image_size=(32, 32), channels=9, timesteps=100, sampling_timesteps=steps, loss_type="l2",
+                              objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=gw).to("cuda:0")
+    torch.manual_seed(1234)          # the reference's CPU stream: randn(shape) then one randn_like per step
+    d.__dict__["_noise_hook"] = lambda shape: torch.randn(shape)
+    out = d.sample(torch.from_numpy(g["x_cond"]).cuda(), torch.from_numpy(g["fwd_te"]).cuda(), batch_size=2)
+    ref = g[f"sample_{name}"]
+    assert out.shape == ref.shape and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    err = rel(out, ref)
+    assert err <= (5e-4 if steps == 100 else 2e-4), err     # 100 sequential fp32 UNet calls: budget 5e-4
+
+
+def test_full_unet_libero_forward_vs_golden(golden_dir):
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    from oracle.param_fill import fill_module
+    from tools_wsum import wsum
+    g = np.load(f"{golden_dir}/unet_libero_full.npz")
+    torch.manual_seed(0)
+    m = Unet_Libero()
+    sd = fill_module(m, seed=12)
+    assert abs(wsum(sd) - float(g["weights_abs_sum"])) < 1e-6 * float(g["weights_abs_sum"])
+    m = m.to("cuda:0").eval()
+    gen = torch.Generator().manual_seed(101)
+    x = torch.randn(1, 24, 128, 128, generator=gen)
+    t = torch.tensor([41])
+    te = torch.randn(1, 10, 512, generator=gen)
+    y = m(x.cuda(), t.cuda(), te.cuda())
+    yf = y.flatten().cpu()
+    got = yf[torch.from_numpy(g["idx"])]
+    scale = np.abs(g["y_sampled"]).max()
+    assert np.abs(got.numpy() - g["y_sampled"]).max() <= TOL * scale
+    assert abs(float(yf.double().abs().sum()) - float(g["y_abs_sum"])) <= 1e-5 * float(g["y_abs_sum"])
+
+
+def test_cpu_unet_raises():
+    from flowdiffusion.flowdiffusion.unet import Unet_Tiny
+    with pytest.raises(RuntimeError):
+        Unet_Tiny()(torch.zeros(1, 12, 32, 32), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 512))

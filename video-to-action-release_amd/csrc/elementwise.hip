@@ -151,7 +151,7 @@ __global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int N, int C, 
 // ----------------------------------------------------------------------------------------- video sampler glue
 // Unet_Libero input pack (reference unet.py:217-220): img [B, 3f, H, W] ('b (f c) h w'), x_cond [B,3,H,W]
 //   -> xin [B, f, H, W, 6] channels-last (3 noisy + 3 cond, cond repeated over frames)
-__global__ void video_pack_kernel(const float* img, const float* cond, float* xin, int B, int f, int HW) {
+__global__ void video_pack_kernel(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bs, size_t cond_bs) {
     const size_t total = (size_t)B * f * HW * 6;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % 6);
@@ -161,8 +161,8 @@ __global__ void video_pack_kernel(const float* img, const float* cond, float* xi
         const int fr = (int)(t % f);
         const int b = (int)(t / f);
         float v;
-        if (c < 3) v = img[(((size_t)b * f + fr) * 3 + c) * HW + hw];
-        else v = cond[((size_t)b * 3 + (c - 3)) * HW + hw];
+        if (c < 3) v = img[(size_t)b * img_bs + ((size_t)fr * 3 + c) * HW + hw];
+        else v = cond[(size_t)b * cond_bs + (size_t)(c - 3) * HW + hw];
         xin[i] = v;
     }
 }
@@ -333,8 +333,9 @@ int v2a_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int HW, hip
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
-int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(video_pack_kernel, GRID_FOR((size_t)B * f * HW * 6), dim3(256), 0, s, img, cond, xin, B, f, HW);
+// img_bstride / cond_bstride: elements between consecutive batch items (lets both be slices of one [B,(f+1)*3,H,W] tensor)
+int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride, hipStream_t s) {
+    hipLaunchKernelGGL(video_pack_kernel, GRID_FOR((size_t)B * f * HW * 6), dim3(256), 0, s, img, cond, xin, B, f, HW, img_bstride, cond_bstride);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

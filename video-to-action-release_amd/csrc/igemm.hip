@@ -459,14 +459,27 @@ static int pick_split(int tiles, int ktiles, int min_ktiles) {
     return s;
 }
 
+// one tile/split plan shared by the workspace query and the launcher (they must agree)
+static void conv_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int* s) {
+    *bm = M >= 4096 ? 128 : 64;
+    *bn = Cout > 64 ? (*bm == 128 ? 128 : 64) : 64;
+    if (*bm == 64) *bn = 64;
+    *tiles = cdiv(M, *bm) * cdiv(Cout, *bn);
+    *s = pick_split(*tiles, cdiv(K, BK), 8);
+}
+static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int* s) {
+    *bm = Cout > 64 ? 128 : 64;
+    *bn = (K > 64 && *bm == 128) ? 128 : 64;
+    *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
+    *s = pick_split(*tiles, cdiv(M, BK), 4);
+}
+
 extern "C" {
 
-// workspace (bytes) a conv forward may need for split-K slabs with the heuristic below
+// workspace (bytes) a conv forward may need for split-K slabs (same plan as the launcher)
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K) {
-    int bm = M >= 4096 ? 128 : 64, bn = Cout > 64 ? (bm == 128 ? 128 : 64) : 64;
-    if (bm == 64) bn = 64;
-    int tiles = cdiv(M, bm) * cdiv(Cout, bn);
-    int s = pick_split(tiles, cdiv(K, BK), 8);
+    int bm, bn, tiles, s;
+    conv_plan(M, Cout, K, &bm, &bn, &tiles, &s);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
@@ -491,12 +504,10 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     const bool vec = (Cin % 16 == 0) && (C1 % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!x2 || ((uintptr_t)x2 & 15) == 0) &&
                      (((uintptr_t)w_packed & 15) == 0);
-    int bm = p.M >= 4096 ? 128 : 64, bn = Cout > 64 ? (bm == 128 ? 128 : 64) : 64;
-    if (bm == 64) bn = 64;
-    const int tiles = cdiv(p.M, bm) * cdiv(Cout, bn);
+    int bm, bn, tiles, s;
+    conv_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     const int nkt = cdiv(p.K, BK);
-    int s = pick_split(tiles, nkt, 8);
-    if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) s = 1;
+    if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(nkt, s);
     dim3 grid(tiles, s), block(256);
@@ -521,8 +532,8 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
 }
 
 size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K) {
-    int tiles = cdiv(Cout, 64) * cdiv(K, 64);
-    int s = pick_split(tiles, cdiv(M, BK), 4);
+    int bm, bn, tiles, s;
+    wgrad_plan(M, Cout, K, &bm, &bn, &tiles, &s);
     return s > 1 ? (size_t)s * Cout * K * sizeof(float) : 0;
 }
 
@@ -544,11 +555,10 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     p.accumulate = accumulate;
     const bool veca = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     const bool vecb = (Cin % 4 == 0) && (C1 % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!x2 || ((uintptr_t)x2 & 15) == 0);
-    const int bm = Cout > 64 ? 128 : 64, bn = (p.K > 64 && bm == 128) ? 128 : 64;
-    const int tiles = cdiv(Cout, bm) * cdiv(p.K, bn);
+    int bm, bn, tiles, s;
+    wgrad_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     const int nrt = cdiv(p.M, BK);
-    int s = pick_split(tiles, nrt, 4);
-    if (s > 1 && (size_t)s * Cout * p.K * sizeof(float) > workspace_bytes) s = 1;
+    if (s > 1 && (size_t)s * Cout * p.K * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splits = s;
     p.rtiles_per_split = cdiv(nrt, s);
     dim3 grid(tiles, s), block(256);

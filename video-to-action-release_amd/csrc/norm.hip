@@ -13,7 +13,8 @@
 #include "common.h"
 
 struct GnDesc {
-    const float* x;         // [N][S][C]
+    const float* x;         // [N][S][C]   (or channels [0, C1) of a virtual concat when x2 != null: row stride C1)
+    const float* x2;        // channels [C1, C) of the virtual concat: [N][S][C - C1], forward large path only
     const float* gamma;     // [C]
     const float* beta;      // [C]
     const float* residual;  // [N][S][C] or null (added before the activation)
@@ -26,7 +27,7 @@ struct GnDesc {
     float* rstd;            // [N][G]
     float* colsum;          // [N][2][C] (stats: sum x, sum x^2; backward: sum dz, sum dz*xhat)
     double* partial;        // [N][nchunk][2][C]
-    int N, S, C, G, act, nchunk, rows_per_chunk;
+    int N, S, C, G, act, nchunk, rows_per_chunk, C1;
     float eps;
 };
 
@@ -43,6 +44,10 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
     const size_t base = ((size_t)n * p.S + s0) * C;
     const int total4 = (s1 - s0) * L4;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x + base);
+    const bool two = (MODE == 0) && p.x2 != nullptr;
+    const int C1 = p.C1, C2 = C - C1;
+    const float* xa = p.x + ((size_t)n * p.S + s0) * C1;
+    const float* xb = two ? p.x2 + ((size_t)n * p.S + s0) * C2 : nullptr;
     const f32x4* d4 = MODE ? reinterpret_cast<const f32x4*>(p.dout + base) : nullptr;
     const f32x4* r4 = (MODE && p.residual) ? reinterpret_cast<const f32x4*>(p.residual + base) : nullptr;
     // a thread's channel advances by (256 % L4) float4 per step; accumulate a run locally while it stays put
@@ -59,7 +64,14 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
         }
     };
     for (int i = tid; i < total4; i += 256) {
-        f32x4 v = x4[i];
+        f32x4 v;
+        if (two) {
+            const int row = i / L4, cc = (i - row * L4) * 4;
+            v = (cc < C1) ? *reinterpret_cast<const f32x4*>(xa + (size_t)row * C1 + cc)
+                          : *reinterpret_cast<const f32x4*>(xb + (size_t)row * C2 + (cc - C1));
+        } else {
+            v = x4[i];
+        }
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[j] * v[j]; }
@@ -128,7 +140,15 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
         const int c4 = (int)(i % L4);
         const int g = (c4 * 4) / cg;
         const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
-        f32x4 v = x4[i];
+        f32x4 v;
+        if (p.x2) {
+            const size_t row = i / L4;
+            const int cc = c4 * 4;
+            v = (cc < p.C1) ? *reinterpret_cast<const f32x4*>(p.x + row * p.C1 + cc)
+                            : *reinterpret_cast<const f32x4*>(p.x2 + row * (C - p.C1) + (cc - p.C1));
+        } else {
+            v = x4[i];
+        }
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (r4) r = r4[i];
         f32x4 o;
@@ -313,11 +333,14 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
 }
 
 // y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
-int v2a_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
-                      float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
+// x2 != null: the input is the channel concat [x | x2] (decoder skip, reference unet.py:681) read from both sources in place.
+int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                      const float* film, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
+    p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act; p.eps = eps;
     const int cg = C / G;

@@ -1,0 +1,52 @@
+"""Unet_Libero with the reference's surface (flowdiffusion/flowdiffusion/unet.py:195-222): no-arg constructor, `.unet`
+(UNetModel, 201,087,649 parameters), forward(x [B,24,H,W], t [B], task_embed [B,L,512]) -> [B,21,H,W].  Executed by
+v2a_hip.unet_engine on HIP kernels; inference only (the reference keeps this model frozen, lb_online_trainer_v7.py:83)."""
+import torch
+import torch.nn as nn
+from .guided_diffusion.guided_diffusion.unet import UNetModel
+
+
+class _HipUnetWrapper(nn.Module):
+    def _engine(self):
+        from v2a_hip.unet_engine import UNetEngine
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X-native video UNet runs on a HIP device only: call .to('cuda') first (no CPU fallback)")
+        eng = self.__dict__.get("_eng")
+        if eng is None or eng.device != dev:
+            eng = UNetEngine(self.unet.engine_cfg(), {n: p for n, p in self.named_parameters()}, prefix="unet.")
+            self.__dict__["_eng"] = eng
+        return eng
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_eng" else copy.deepcopy(v, memo)
+        return new
+
+    @torch.no_grad()
+    def forward(self, x, t, task_embed=None, **kwargs):
+        assert task_embed is not None, "must specify y if and only if the model is class-conditional"
+        label = kwargs.pop("_label_emb", None)
+        return self._engine().forward_libero(x, t, task_embed, label_emb=label)
+
+
+class Unet_Libero(_HipUnetWrapper):
+    def __init__(self):
+        super().__init__()
+        self.unet = UNetModel(image_size=(128, 128), in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2,
+                              attention_resolutions=(8, 16), dropout=0, channel_mult=(1, 2, 3, 4, 5), conv_resample=True, dims=3,
+                              num_classes=None, task_tokens=True, task_token_channels=512, use_checkpoint=False, use_fp16=False,
+                              num_head_channels=32)
+
+
+class Unet_Tiny(_HipUnetWrapper):
+    """Small same-architecture model used by the parity tests (matches tools/ref_build.build_ref_unet(tiny=True))."""
+
+    def __init__(self):
+        super().__init__()
+        self.unet = UNetModel(image_size=(32, 32), in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1,
+                              attention_resolutions=(2,), dropout=0, channel_mult=(1, 2), conv_resample=True, dims=3, num_classes=None,
+                              task_tokens=True, task_token_channels=512, use_checkpoint=False, use_fp16=False, num_head_channels=16)

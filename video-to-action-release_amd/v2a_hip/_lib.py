@@ -25,7 +25,7 @@ SIGNATURES = {
     "v2a_conv2d_wgrad": (I, [P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),
     "v2a_groupnorm_workspace_bytes": (SZ, [I, I, I, I]),
-    "v2a_groupnorm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
+    "v2a_groupnorm_fwd": (I, [P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
     "v2a_groupnorm_bwd": (I, [P] * 14 + [I, I, I, I, I, P, SZ, P]),
     "v2a_act_fwd": (I, [P, P, SZ, I, P]),
     "v2a_act_bwd": (I, [P, P, P, SZ, I, P]),
@@ -41,7 +41,7 @@ SIGNATURES = {
     "v2a_nchw_to_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),
     "v2a_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
-    "v2a_video_pack": (I, [P, P, P, I, I, I, P]),
+    "v2a_video_pack": (I, [P, P, P, I, I, I, SZ, SZ, P]),
     "v2a_video_denoise_step": (I, [P, P, P, P, P, I, I, I, F, F, F, F, F, F, F, F, I, I, P]),
     "v2a_philox_normal": (I, [P, SZ, U64, P, U64, P]),
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),

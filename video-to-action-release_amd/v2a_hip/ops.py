@@ -125,17 +125,19 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ group norm
-def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None):
-    """x [N,S,C] (any leading/spatial shape flattened by the caller).  Returns (y, mean, rstd)."""
+def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None):
+    """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
+    Returns (y [N,S,C(+C2)], mean, rstd)."""
     _chk(x, "x")
-    N, S, C = x.shape
+    N, S, C1 = x.shape
+    C = C1 + (x2.shape[-1] if x2 is not None else 0)
     if y is None:
-        y = torch.empty_like(x)
+        y = torch.empty((N, S, C), dtype=torch.float32, device=x.device)
     mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_groupnorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), y.data_ptr(),
+    check(lib.v2a_groupnorm_fwd(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), y.data_ptr(),
                                 mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
           "groupnorm_fwd")
     return y, mean, rstd
@@ -314,3 +316,32 @@ def scale_by_device_scalar(x, scalar):
     """x *= scalar (a 0-dim / 1-element device tensor), in place, one kernel."""
     check(lib.v2a_scale_by_device_scalar(x.data_ptr(), x.numel(), scalar.data_ptr(), _stream()), "scale_by_device_scalar")
     return x
+
+
+def video_pack(x_full, f, H, W):
+    """x_full [B,(f+1)*3,H,W] (noisy frames 'b (f c) h w' then the conditioning image) -> [B,f,H,W,6] channels-last."""
+    _chk(x_full, "x")
+    B = x_full.shape[0]
+    HW = H * W
+    out = torch.empty((B, f, H, W, 6), dtype=torch.float32, device=x_full.device)
+    bs = (f + 1) * 3 * HW
+    check(lib.v2a_video_pack(x_full.data_ptr(), x_full.data_ptr() + 4 * f * 3 * HW, out.data_ptr(), B, f, HW, bs, bs, _stream()), "video_pack")
+    return out
+
+
+def video_pack2(img, cond, f, H, W):
+    """img [B,3f,H,W], cond [B,3,H,W] (separate tensors) -> [B,f,H,W,6]."""
+    B = img.shape[0]
+    HW = H * W
+    out = torch.empty((B, f, H, W, 6), dtype=torch.float32, device=img.device)
+    check(lib.v2a_video_pack(img.data_ptr(), cond.data_ptr(), out.data_ptr(), B, f, HW, 3 * f * HW, 3 * HW, _stream()), "video_pack")
+    return out
+
+
+def video_denoise_step(v, v_uncond, img, noise, coef, mode, final, f, HW):
+    """coef = (sa, s1, ra, rm, c1, c2, sigma, gw); see csrc/elementwise.hip video_denoise_kernel."""
+    out = torch.empty_like(img)
+    B = img.shape[0]
+    check(lib.v2a_video_denoise_step(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, *[float(c) for c in coef],
+                                     mode, 1 if final else 0, _stream()), "video_denoise_step")
+    return out

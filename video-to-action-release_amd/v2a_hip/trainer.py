@@ -1,0 +1,138 @@
+"""One policy train step on the MI355X, end to end, as a replayable hipGraph:
+
+    replay indices (host, bit-exact stream)  ->  HIP gather from the HBM-resident store (R1-R3)
+    -> Philox noise / timesteps (R6)  ->  HIP forward + backward into one flat gradient arena (R4-R8)
+    -> [RCCL all-reduce of the arena over xGMI when world_size > 1]
+    -> fused clip + AdamW + zero + EMA (R9)  ->  weight re-pack for the next step
+
+Mirrors the order of lb_online_trainer_v7.py:558-624 (sample_from_bufs -> compute_loss -> backward -> clip_grad_norm_ ->
+opt.step -> zero_grad -> ema.update).  Data parallel = one process per GPU, every rank holds a full replica (parameters, Adam
+moments, EMA) and its own replay shard / RNG stream (seed + rank); the only collective is one sum all-reduce of the 87.2 M fp32
+gradients per step, averaged by folding 1/world into the optimiser's gradient scale.
+"""
+import copy
+import torch
+from . import ops
+from .optim import FusedAdamWEMA
+from .replay import ReplayStore, sample_indices
+from ._lib import lib, check
+
+
+class PolicyTrainer:
+    def __init__(self, policy, store: ReplayStore, batch_size=64, opt_params=None, ema_params=None, seed=0, use_graph=True,
+                 process_group=None, world_size=1, rank=0):
+        self.policy = policy
+        self.store = store
+        self.B = batch_size
+        self.eng = policy.engine
+        self.device = self.eng.device
+        self.world, self.rank, self.pg = world_size, rank, process_group
+        opt_params = dict(lr=1e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6) if opt_params is None else dict(opt_params)
+        ema_params = dict(update_after_step=0, inv_gamma=1.0, power=0.75, min_value=0.0, update_every=1) if ema_params is None else dict(ema_params)
+        ema_params.pop("include_online_model", None)
+        # EMA replica (ema_pytorch deep-copies the online model: lb_online_trainer_v7.py:135)
+        self.ema_policy = copy.deepcopy(policy)
+        self.ema_policy.requires_grad_(False)
+        self.names = policy.trainable_names()
+        P = dict(policy.named_parameters())
+        EP = dict(self.ema_policy.named_parameters())
+        total = sum(P[n].numel() for n in self.names)
+        self.arena = torch.zeros(total, dtype=torch.float32, device=self.device)
+        gviews = self.eng.grad_views(self.arena, self.names)
+        self.opt = FusedAdamWEMA([P[n].data for n in self.names], [gviews[n] for n in self.names], [EP[n].data for n in self.names],
+                                 lr=opt_params["lr"], betas=tuple(opt_params["betas"]), eps=opt_params["eps"],
+                                 weight_decay=opt_params["weight_decay"], max_norm=1.0, ema_inv_gamma=ema_params["inv_gamma"],
+                                 ema_power=ema_params["power"], ema_min_value=ema_params["min_value"],
+                                 ema_beta=ema_params.get("beta", 0.9999), ema_update_after_step=ema_params["update_after_step"],
+                                 ema_update_every=ema_params["update_every"])
+        self.seed = int(seed) + 7919 * rank
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)       # Philox offset, advanced on device
+        T, Da = policy.horizon, policy.action_dim
+        self.frame_start = torch.zeros(batch_size, dtype=torch.int64, device=self.device)
+        # ring of pinned staging buffers: the H2D copy of step k may still be queued when the host prepares step k+1
+        self._fs_ring = [torch.zeros(batch_size, dtype=torch.int64).pin_memory() for _ in range(8)]
+        self._fs_evt = [None] * 8
+        self.noise = torch.empty((batch_size, T, Da), dtype=torch.float32, device=self.device)
+        self.timesteps = torch.empty(batch_size, dtype=torch.int64, device=self.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.use_graph = use_graph
+        self._g_fb = None
+        self._g_opt = None
+        self._warm = 0
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ pieces
+    def _draw_indices(self):
+        ep, st = sample_indices(self.store.episode_lengths(), self.B, self.store.act_len)
+        offs = [self.store.episodes[int(e)][0] + int(s) for e, s in zip(ep, st)]
+        slot = self.step_count % len(self._fs_ring)
+        if self._fs_evt[slot] is not None:
+            self._fs_evt[slot].synchronize()
+        self._fs_ring[slot].copy_(torch.tensor(offs, dtype=torch.int64))
+        self.frame_start.copy_(self._fs_ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._fs_evt[slot] = ev
+        return ep, st
+
+    def _fwd_bwd(self):
+        st = self.store
+        B = self.B
+        o0 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
+        o1 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
+        oa = torch.empty((B, st.act_len, st.act_dim), dtype=torch.float32, device=self.device)
+        check(lib.v2a_replay_gather(st.frames.data_ptr(), 1 if st.dtype == torch.uint8 else 0, st.acts.data_ptr(),
+                                    self.frame_start.data_ptr(), o0.data_ptr(), o1.data_ptr(), oa.data_ptr(), B, st.H, st.W,
+                                    st.act_len, st.act_dim, 0, 1, ops._stream()), "replay_gather")
+        n_noise = self.noise.numel()
+        ops.philox_normal(self.noise, self.seed, offset_dev=self.counter)
+        ops.philox_randint(self.timesteps, self.policy.noise_scheduler.config.num_train_timesteps, self.seed ^ 0x5DEECE66D,
+                           offset_dev=self.counter)
+        check(lib.v2a_advance_counter(self.counter.data_ptr(), (n_noise + 3) // 4 + B, ops._stream()), "advance_counter")
+        imgs = {"img_obs_1": o0, "img_goal_1": o1}
+        loss, _, _ = self.eng.loss_fwd_bwd(imgs, oa, self.noise, self.timesteps, need_grad=True, names=self.names, arena=self.arena)
+        ops.copy2d(loss, self.loss, 1, 1, 1, 1)
+
+    def _all_reduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.pg)        # RCCL over xGMI
+            self.opt.scale_grads(1.0 / self.world)
+
+    def _opt(self):
+        self.opt.step(zero_grad=True)
+        self.eng.refresh_packs()
+
+    # ------------------------------------------------------------------ step
+    def step(self):
+        """One optimisation step.  Returns the device tensor holding the loss (read it with .item() only when needed)."""
+        self._draw_indices()
+        if not self.use_graph or self._warm < 2:
+            self._fwd_bwd()
+            self._all_reduce()
+            self._opt()
+            self._warm += 1
+        else:
+            if self._g_fb is None:
+                torch.cuda.synchronize()
+                self._g_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g_fb):
+                    self._fwd_bwd()
+                    if self.world == 1:
+                        self._opt()
+                if self.world > 1:
+                    self._g_opt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._g_opt):
+                        self._opt()
+                # capture does not execute: run the step for real
+            self._g_fb.replay()
+            if self.world > 1:
+                self._all_reduce()
+                self._g_opt.replay()
+        self.step_count += 1
+        return self.loss
+
+    def ema_for_inference(self):
+        """EMA weights are updated by the fused kernel behind torch's back: refresh its packed copies before use."""
+        self.ema_policy.engine.refresh_packs()
+        return self.ema_policy

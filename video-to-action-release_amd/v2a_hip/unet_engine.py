@@ -1,0 +1,260 @@
+"""Host-side executor of the AVDC pseudo-3D video UNet forward on the HIP kernels.
+
+Mirrors UNetModel.forward (reference guided_diffusion/guided_diffusion/unet.py:650-684) with the Libero wrapper
+(flowdiffusion/unet.py:216-222) as an explicit launch sequence over channels-last video tensors [B, F, H, W, C]:
+  * Conv3d = implicit-GEMM 3x3 on [(B F), H, W, C] + implicit-GEMM (3x1) over frames on [B, F, (H W), C]  (nn.py:53-87)
+    -- zero permute copies (the reference pays two full rearranges per Conv3d);
+  * GroupNorm32 + SiLU fused, fp32 statistics (nn.py:26-28); decoder skip concat read in place by two-source loaders
+    (unet.py:681), nearest x2 upsample folded into the conv loader (unet.py:105-115);
+  * timestep-embedding add folded into the temporal conv epilogue, residual add folded into the last conv of a ResBlock;
+  * per-frame spatial attention (unet.py:303-309, 341-358) by the fused HIP attention kernel;
+  * the text branch (PerceiverResampler + Linear + mean, imagen.py:254-372) does not depend on t: computed once per
+    sample() call and cached.
+Parameters are ordinary torch tensors under the reference's names (checkpoints load unchanged).
+"""
+import math
+import torch
+from . import ops
+
+GN_SMALL_MAX = 8192
+
+
+def build_program(cfg):
+    """Same flattening of UNetModel.__init__ as the oracle's (kept separate: the product never imports oracle/)."""
+    mc = cfg.model_channels
+    ch = int(cfg.channel_mult[0] * mc)
+    inp = [[("conv", "input_blocks.0.0", cfg.in_channels, ch)]]
+    chans = [ch]
+    ds = 1
+    idx = 1
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            blk = [("res", f"input_blocks.{idx}.0", ch, int(mult * mc))]
+            ch = int(mult * mc)
+            if ds in cfg.attention_resolutions:
+                blk.append(("attn", f"input_blocks.{idx}.1", ch))
+            inp.append(blk)
+            chans.append(ch)
+            idx += 1
+        if level != len(cfg.channel_mult) - 1:
+            inp.append([("down", f"input_blocks.{idx}.0", ch)])
+            chans.append(ch)
+            idx += 1
+            ds *= 2
+    mid = [("res", "middle_block.0", ch, ch), ("attn", "middle_block.1", ch), ("res", "middle_block.2", ch, ch)]
+    out = []
+    oidx = 0
+    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            ich = chans.pop()
+            blk = [("res", f"output_blocks.{oidx}.0", ch + ich, int(mc * mult))]
+            ch = int(mc * mult)
+            j = 1
+            if ds in cfg.attention_resolutions:
+                blk.append(("attn", f"output_blocks.{oidx}.{j}", ch))
+                j += 1
+            if level and i == cfg.num_res_blocks:
+                blk.append(("up", f"output_blocks.{oidx}.{j}", ch))
+                ds //= 2
+            out.append(blk)
+            oidx += 1
+    return inp, mid, out, ch
+
+
+class _Packs:
+    """Packed conv operands keyed by parameter name, refreshed when (data_ptr, _version) changes."""
+
+    def __init__(self, P):
+        self.P = P
+        self._c = {}
+
+    def get(self, name):
+        w = self.P[name]
+        key = (w.data_ptr(), w._version)
+        ent = self._c.get(name)
+        if ent is None or ent[0] != key:
+            wd = w.detach()
+            taps = 1
+            for s in wd.shape[2:]:
+                taps *= s
+            pk = wd if taps == 1 else ops.pack_weight(wd.contiguous(), 0, None if ent is None else ent[1])
+            ent = (key, pk)
+            self._c[name] = ent
+        return ent[1]
+
+
+class UNetEngine:
+    def __init__(self, cfg, params: dict, prefix="unet."):
+        self.cfg = cfg
+        self.P = params
+        self.pre = prefix
+        self.device = next(iter(params.values())).device
+        self.packs = _Packs(params)
+        self.inp, self.mid, self.out, self.final_ch = build_program(cfg)
+        self._label_cache = None
+
+    def w(self, name):
+        return self.packs.get(self.pre + name)
+
+    def p(self, name):
+        return self.P[self.pre + name]
+
+    def has(self, name):
+        return (self.pre + name) in self.P
+
+    # ------------------------------------------------------------------ primitives
+    def conv3d(self, x, name, cout, stride=1, ups=False, x2=None, rowvec=None, residual=None):
+        """x [B,F,H,W,C] (+x2) -> [B,F,OH,OW,cout].  rowvec [B,cout] / residual [B,F,OH,OW,cout] land in the LAST kernel."""
+        B, Fr, H, W, C = x.shape
+        wsp = self.w(name + ".spatial_conv.weight")
+        k = self.p(name + ".spatial_conv.weight").shape[-1]
+        has_t = self.has(name + ".temporal_conv.weight")
+        x4 = x.view(B * Fr, H, W, C)
+        x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
+        y = ops.conv2d(x4, wsp, self.p(name + ".spatial_conv.bias"), cout, k, k, (stride, stride), (k // 2, k // 2), x2=x24, ups=ups,
+                       rowvec=None if has_t else rowvec, rows_per_batch=1,
+                       residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout))
+        OH, OW = y.shape[1], y.shape[2]
+        if not has_t:
+            if rowvec is not None:
+                raise NotImplementedError("rowvec on a conv without temporal part")
+            return y.view(B, Fr, OH, OW, cout)
+        wt = self.w(name + ".temporal_conv.weight")
+        z = ops.conv2d(y.view(B, Fr, OH * OW, cout), wt, self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0),
+                       rowvec=rowvec, rows_per_batch=Fr * OH * OW,
+                       residual=None if residual is None else residual.view(B, Fr, OH * OW, cout))
+        return z.view(B, Fr, OH, OW, cout)
+
+    def gn_silu(self, x, name, act="silu", x2=None, frames_separate=False):
+        """GroupNorm32 over (C/32 x F x H x W) per sample (or per frame when frames_separate), fused activation."""
+        B, Fr, H, W, C1 = x.shape
+        C = C1 + (0 if x2 is None else x2.shape[-1])
+        N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
+        x3 = x.view(N, S, C1)
+        x23 = None if x2 is None else x2.view(N, S, -1)
+        if x23 is not None and S * (C // 32) <= GN_SMALL_MAX:
+            cat = torch.empty((N, S, C), dtype=torch.float32, device=x.device)      # tiny tensors: materialise the concat
+            ops.copy2d(x3, cat, N * S, C1, C1, C)
+            ops.copy2d(x23, cat, N * S, C - C1, C - C1, C, dst_off=C1)
+            x3, x23 = cat, None
+        y, _, _ = ops.groupnorm_fwd(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23)
+        return y.view(B, Fr, H, W, C)
+
+    def resblock(self, x, name, cin, cout, semb, x2=None):
+        B = x.shape[0]
+        a = self.gn_silu(x, name + ".in_layers.0", x2=x2)
+        eo = ops.linear(semb, self.p(name + ".emb_layers.1.weight"), self.p(name + ".emb_layers.1.bias"))      # [B,cout]
+        h = self.conv3d(a, name + ".in_layers.2", cout, rowvec=eo)
+        a2 = self.gn_silu(h, name + ".out_layers.0")
+        if self.has(name + ".skip_connection.spatial_conv.weight"):
+            xs = self.conv3d(x, name + ".skip_connection", cout, x2=x2)
+        else:
+            assert x2 is None
+            xs = x
+        return self.conv3d(a2, name + ".out_layers.3", cout, residual=xs)
+
+    def attention(self, x, name, C):
+        B, Fr, H, W, _ = x.shape
+        N, L = B * Fr, H * W
+        hc = self.cfg.num_head_channels
+        heads = C // hc
+        n = self.gn_silu(x, name + ".norm", act="none", frames_separate=True)
+        qkv = ops.linear(n.view(N * L, C), self.p(name + ".qkv.weight").view(3 * C, C), self.p(name + ".qkv.bias"))
+        a = ops.attention(qkv, N, L, heads, hc)
+        out = ops.linear(a, self.p(name + ".proj_out.weight").view(C, C), self.p(name + ".proj_out.bias"), residual=x.view(N * L, C))
+        return out.view(B, Fr, H, W, C)
+
+    # ------------------------------------------------------------------ embeddings
+    def _ln_g(self, x2d, gname):
+        return ops.layernorm(x2d, self.p(gname), None, 1e-5)
+
+    def label_embedding(self, y):
+        """task_attnpool(y).mean(1) -> [B, 4*mc]; y [B,L,512] (CLIP token features)."""
+        cfg = self.cfg
+        pre = "task_attnpool.0"
+        B, L, D = y.shape
+        y = y.float().contiguous()
+        pos = self.p(pre + ".pos_emb.weight")
+        xp = torch.empty_like(y)
+        for b in range(B):
+            ops.axpy(y[b], pos[:L], 1.0, out=xp[b])
+        n_lat, n_mp = cfg.pr_num_latents, cfg.pr_num_mean_pooled
+        NL = n_lat + n_mp
+        lat = torch.empty((B, NL, D), dtype=torch.float32, device=y.device)
+        lp = self.p(pre + ".latents")
+        for b in range(B):
+            ops.copy2d(lp, lat[b], n_lat, D, D, D, dst_off=n_mp * D)
+        if n_mp > 0:
+            mp = ops.mean_rows(y)
+            mp = self._ln_g(mp, pre + ".to_latents_from_mean_pooled_seq.0.g")
+            mp = ops.linear(mp, self.p(pre + ".to_latents_from_mean_pooled_seq.1.weight"), self.p(pre + ".to_latents_from_mean_pooled_seq.1.bias"))
+            ops.copy2d(mp, lat, B, n_mp * D, n_mp * D, NL * D)
+        H, dh = cfg.pr_heads, cfg.pr_dim_head
+        for li in range(cfg.pr_depth):
+            a = f"{pre}.layers.{li}.0"
+            xn = ops.layernorm(xp.view(B * L, D), self.p(a + ".norm.weight"), self.p(a + ".norm.bias"))
+            ln = ops.layernorm(lat.view(B * NL, D), self.p(a + ".norm_latents.weight"), self.p(a + ".norm_latents.bias"))
+            q = ops.linear(ln, self.p(a + ".to_q.weight"))
+            kvin = torch.empty((B, L + NL, D), dtype=torch.float32, device=y.device)
+            ops.copy2d(xn, kvin, B, L * D, L * D, (L + NL) * D)
+            ops.copy2d(ln, kvin, B, NL * D, NL * D, (L + NL) * D, dst_off=L * D)
+            kv = ops.linear(kvin.view(B * (L + NL), D), self.p(a + ".to_kv.weight"))
+            o = ops.perceiver_attention(q, kv, self.p(a + ".q_scale"), self.p(a + ".k_scale"), B, NL, L + NL, H, dh, 8.0)
+            o = ops.linear(o.view(B * NL, H * dh), self.p(a + ".to_out.0.weight"))
+            o = ops.layernorm(o, self.p(a + ".to_out.1.weight"), self.p(a + ".to_out.1.bias"))
+            lat = ops.axpy(o, lat.view(B * NL, D)).view(B, NL, D)
+            f = f"{pre}.layers.{li}.1"
+            h = ops.linear(self._ln_g(lat.view(B * NL, D), f + ".0.g"), self.p(f + ".1.weight"))
+            h = ops.act_fwd(h, "gelu")
+            h = ops.linear(self._ln_g(h, f + ".3.g"), self.p(f + ".4.weight"))
+            lat = ops.axpy(h, lat.view(B * NL, D)).view(B, NL, D)
+        z = ops.linear(lat.view(B * NL, D), self.p("task_attnpool.1.weight"), self.p("task_attnpool.1.bias"))
+        return ops.mean_rows(z.view(B, NL, -1))
+
+    def time_embedding(self, t_long):
+        e = ops.sincos_embed(t_long, self.cfg.model_channels, 1)
+        e = ops.linear(e, self.p("time_embed.0.weight"), self.p("time_embed.0.bias"))
+        e = ops.act_fwd(e, "silu")
+        return ops.linear(e, self.p("time_embed.2.weight"), self.p("time_embed.2.bias"))
+
+    # ------------------------------------------------------------------ forward
+    def _run(self, blk, h, semb, skip=None):
+        for op in blk:
+            kind, name = op[0], op[1]
+            if kind == "conv":
+                h = self.conv3d(h, name, op[3])
+            elif kind == "res":
+                h = self.resblock(h, name, op[2], op[3], semb, x2=skip)
+                skip = None
+            elif kind == "attn":
+                h = self.attention(h, name, op[2])
+            elif kind == "down":
+                h = self.conv3d(h, name + ".op", op[2], stride=2)
+            elif kind == "up":
+                h = self.conv3d(h, name + ".conv", op[2], ups=True)
+        return h
+
+    def forward_cl(self, xin, t_long, label_emb):
+        """xin [B,F,H,W,Cin] channels-last, t [B] int64, label_emb [B,4mc] -> [B,F,H,W,Cout] channels-last."""
+        emb = ops.axpy(self.time_embedding(t_long), label_emb)
+        semb = ops.act_fwd(emb, "silu")                     # every ResBlock's emb_layers starts with the same SiLU
+        hs = []
+        h = xin
+        for blk in self.inp:
+            h = self._run(blk, h, semb)
+            hs.append(h)
+        h = self._run(self.mid, h, semb)
+        for blk in self.out:
+            h = self._run(blk, h, semb, skip=hs.pop())
+        a = self.gn_silu(h, "out.0")
+        return self.conv3d(a, "out.2", self.cfg.out_channels)
+
+    def forward_libero(self, x, t, task_embed=None, label_emb=None):
+        """Unet_Libero.forward: x [B,(f+1)*3,H,W] -> [B,f*3,H,W] (reference layouts at the boundary)."""
+        B, C, H, W = x.shape
+        f = C // 3 - 1
+        xin = ops.video_pack(x.float().contiguous(), f, H, W)
+        if label_emb is None:
+            label_emb = self.label_embedding(task_embed)
+        v = self.forward_cl(xin, t.long().contiguous(), label_emb)                      # [B,f,H,W,3]
+        return ops.nhwc_to_nchw(v.view(B * f, H, W, self.cfg.out_channels)).view(B, f * self.cfg.out_channels, H, W)
