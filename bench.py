@@ -159,6 +159,75 @@ def cpu_baseline(batch, budget=20.0, hard_timeout=150.0):
                       f"clip/AdamW/EMA; first step untimed), {last['t']:.1f} s on {threads} threads (usable host cores: {usable})"}
 
 
+def video_leg(torch, device, batch=16, sampling_steps=50):
+    """BASELINE.json configs[2]: AVDC sampler, Unet_Libero (201 M params, random init), 8-frame 128x128 (1 cond + 7 predicted),
+    B=16, 50 sampling steps (sampling_timesteps=50 < 100 => the reference's DDIM path, goal_diffusion.py:405,647), CLIP-free
+    synthetic task tokens [B,10,512].  frames/s = B * 7 / wall time of one sample() with inputs resident in HBM."""
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    from v2a_hip import ops
+    torch.manual_seed(0)
+    unet = Unet_Libero().to(device).eval()
+    d = GoalGaussianDiffusion(unet, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=sampling_steps, loss_type="l2",
+                              objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to(device)
+    g = torch.Generator(device=device).manual_seed(1)
+    x_cond = torch.rand(batch, 3, 128, 128, device=device, generator=g)
+    te = torch.randn(batch, 10, 512, device=device, generator=g)
+    # warm-up: 2 steps (weight packs, workspace, allocator)
+    d.sampling_timesteps, d.is_ddim_sampling = 2, True
+    d.sample(x_cond, te, batch_size=batch)
+    d.sampling_timesteps = sampling_steps
+    d.is_ddim_sampling = sampling_steps < d.num_timesteps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = d.sample(x_cond, te, batch_size=batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops = 2.130e12 * batch * sampling_steps                       # SURVEY.md 8d: 2.130 TFLOP per sample per denoise step
+    # instrumented single UNet forward: per-variant conv timing with HIP events
+    recs = []
+    orig = ops.conv2d
+
+    def timed(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig(*a, **k)
+        e1.record()
+        x, cout, kh, kw = a[0], a[3], a[4], a[5]
+        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
+        m = y.shape[0] * y.shape[1] * y.shape[2]
+        bm = 128 if m >= 4096 else 64
+        bn = (128 if bm == 128 else 64) if cout > 64 else 64
+        recs.append((f"conv_igemm_f32<{bm},{bn}>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
+        return y
+
+    ops.conv2d = timed
+    try:
+        eng = unet._engine()
+        lab = eng.label_embedding(te)
+        xin = ops.video_pack2(torch.randn(batch, 21, 128, 128, device=device), x_cond, 7, 128, 128)
+        eng.forward_cl(xin, torch.full((batch,), 50, dtype=torch.long, device=device), lab)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+    agg = {}
+    for name, fl, e0, e1 in recs:
+        v = agg.setdefault(name, [0.0, 0.0, 0])
+        v[0] += fl; v[1] += e0.elapsed_time(e1) * 1e-3; v[2] += 1
+    name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+    ach = fl / sec / 1e12
+    return {"metric": "video_frames_per_sec", "value": batch * 7 / dt, "unit": "predicted frames/s (x8/7 incl. the conditioning frame)",
+            "seconds_per_sample_call": dt, "config": {"workload": "AVDC sampler Unet_Libero 128x128, 1+7 frames (BASELINE.json configs[2])",
+                                                       "batch": batch, "sampling_steps": sampling_steps, "sampler": "ddim" if sampling_steps < 100 else "ddpm",
+                                                       "guidance_weight": 0},
+            "dtype": "f32", "algorithmic_tflops": flops / dt / 1e12, "output_range": [float(out.min()), float(out.max())],
+            "roofline": {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                         "share_of_conv_time": sec / sum(v[1] for v in agg.values()),
+                         "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]}
+                                               for k, v in sorted(agg.items())}}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +236,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--video", action="store_true", help="also time the video sampler (C3-shaped, reduced step count)")
+    ap.add_argument("--no-video", action="store_true", help="skip the video-sampler leg (BASELINE.json configs[2])")
+    ap.add_argument("--video-batch", type=int, default=16)
+    ap.add_argument("--video-steps", type=int, default=50)
     args = ap.parse_args()
 
     import numpy as np
@@ -256,6 +327,10 @@ def main():
                                                  for k, v in sorted(agg.items())}}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
+        if not args.no_video:
+            del tr, pol, store
+            torch.cuda.empty_cache()
+            out["video"] = video_leg(torch, device, args.video_batch, args.video_steps)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

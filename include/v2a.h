@@ -1,0 +1,148 @@
+/* libv2a_hip.so -- C ABI of the MI355X-native (gfx950) hot path of video-to-action.
+ *
+ * The reference (video-to-action/video-to-action-release) is pure Python on PyTorch and has NO FFI; its plugin surface for this
+ * path is Python classes (GoalGaussianDiffusion / Unet_Libero, DiffusionUnetImagePolicy, Global_EnvReplayBuffer_Img).  The Python
+ * shells under video-to-action-release_amd/{flowdiffusion,diffuser}/ keep those surfaces and bind THIS library with ctypes
+ * (video-to-action-release_amd/v2a_hip/_lib.py; INTEGRATION.md shows the stub).  Each entry point below names the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers + sizes, no torch types; every pointer is DEVICE memory unless marked HOST; fp32; activations
+ * channels-last ([N,H,W,C]; sequences [N,1,T,C]; video [B,F,H,W,C]); asynchronous on `stream`, no device synchronisation, no
+ * allocation (scratch is passed in; query with the *_workspace_bytes functions); returns 0 or a negative error:
+ *   -1 bad argument, -2 kernel launch failed, -3 workspace too small, -4 replay episode shorter than act_len+1.
+ * Thread-safe for distinct streams.
+ */
+#ifndef V2A_H
+#define V2A_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* v2a_stream_t; /* hipStream_t */
+
+/* activation ids (norm / act kernels) */
+enum { V2A_ACT_NONE = 0, V2A_ACT_SILU = 1, V2A_ACT_RELU = 2, V2A_ACT_MISH = 3, V2A_ACT_GELU = 4 };
+
+/* ---------------------------------------------------------------------------------------------- contractions (csrc/igemm.hip)
+ * One implicit-GEMM kernel family (exact-f32 MFMA 32x32x2) replaces every torch conv / linear on the path:
+ *   Conv3d spatial + temporal parts   flowdiffusion/flowdiffusion/guided_diffusion/guided_diffusion/nn.py:30-87
+ *   nearest-x2 Upsample + conv        .../guided_diffusion/unet.py:86-115   (ups = 1: folded into the loader)
+ *   decoder skip concat               .../guided_diffusion/unet.py:681      (x2: second source, no cat tensor)
+ *   ResNet-18 convs                   diffuser/diffusion_policy/common/vision_nets.py:29-39 (torchvision resnet18)
+ *   Conv1d k5/k3/k1, ConvTranspose1d  diffuser/diffusion_policy/model/conv1d_components.py:7-40
+ *   nn.Linear                         conditional_unet1d.py:35-39,88-93; vision_nets.py:140; unet.py:204-210,482-486
+ * and their data gradients (same kernel: weight pack mode 1, idil = forward stride, pad = k-1-pad).
+ * w_packed: [Cout][KH][KW][C1+C2] (mode 0) -- a [Cout][Cin] Linear / 1x1 weight is already in that form.
+ * y (+y2 when csplit > 0: channels [csplit,Cout) go to y2) [N,OH,OW,Cout]; rowvec [batches][Cout] is added per
+ * (m / rows_per_batch, channel); residual [N,OH,OW,Cout]. */
+size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K);
+int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
+                   const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH, int OW,
+                   int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int rows_per_batch, void* workspace,
+                   size_t workspace_bytes, v2a_stream_t stream);
+/* weight gradient, written in the TORCH layout [Cout][Cin][KH][KW] (replaces autograd's conv backward-weight) */
+size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K);
+int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, int N, int H, int W, int C1, int C2, int OH,
+                     int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate,
+                     void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+/* torch weight [Cout][Cin][KH][KW] -> mode 0: [Cout][KH][KW][Cin]; mode 1: [Cin][KH'][KW'][Cout] flipped (dgrad / transposed) */
+int v2a_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int mode, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- GroupNorm (csrc/norm.hip)
+ * y = film(act(gn(x) + residual)) on [N,S,C]; x2 != NULL: x is channels [0,C1) and x2 channels [C1,C) of a concat.
+ * replaces GroupNorm32+SiLU (.../guided_diffusion/nn.py:26-28, unet.py:187-190,211-216,289,628-631), GroupNorm(C/16)+ReLU(+identity)
+ * (diffuser/diffusion_policy/model/multi_image_obs_encoder.py:66-74), GroupNorm(8)+Mish+FiLM (conv1d_components.py:23-40,
+ * conditional_unet1d.py:46-66).  film [N][2][C] = (scale, shift).  mean / rstd [N*G] are outputs (saved for backward). */
+size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G);
+int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                      const float* film, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
+                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
+                      const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm, float* colsum,
+                      float* dgamma, float* dbeta, int N, int S, int C, int G, int act, void* workspace, size_t workspace_bytes,
+                      v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- elementwise (csrc/elementwise.hip) */
+int v2a_act_fwd(const float* x, float* y, size_t n, int act, v2a_stream_t s);                 /* nn.Mish / nn.SiLU / nn.GELU */
+int v2a_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, v2a_stream_t s);
+int v2a_axpy(const float* a, const float* b, float* out, float alpha, size_t n, v2a_stream_t s);   /* out = a + alpha b */
+int v2a_scale_by_device_scalar(float* x, size_t n, const float* scalar, v2a_stream_t s);        /* x *= *scalar (loss scale) */
+int v2a_copy2d(const float* src, float* dst, int rows, int cols, int ld_src, int ld_dst, int accumulate, v2a_stream_t s); /* torch.cat / slicing */
+int v2a_colsum(const float* x, float* out, int rows, int cols, int accumulate, v2a_stream_t s);   /* bias gradients */
+/* kind 0: SinusoidalPosEmb (diffuser/diffusion_policy/model/positional_embedding.py:10-17); kind 1: timestep_embedding (.../nn.py:171-189) */
+int v2a_sincos_embed(const int64_t* t, float* out, int B, int dim, int kind, v2a_stream_t s);
+/* normalise actions + DDPMScheduler.add_noise (diffusion_unet_image_policy.py:255; normalizer.py:139-146) */
+int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const float* alphas_cumprod, float* out, int B, int per, v2a_stream_t s);
+/* F.mse_loss(...).mean() and its gradient (diffusion_unet_image_policy.py:273-276) */
+int v2a_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int n, v2a_stream_t s);
+/* DDPMScheduler.step (mode 0) / DDIMScheduler.step (mode 1) on the action trajectory (diffusion_unet_image_policy.py:121-128) */
+int v2a_policy_sched_step(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb, float c_sa,
+                          float c0, float c1, float sigma, int mode, v2a_stream_t s);
+/* LimitsConstNormalizer.unnormalize for the Libero action limits (normalizer.py:148-161) */
+int v2a_unnormalize_action(const float* x, float* out, int n, v2a_stream_t s);
+/* NCHW -> NHWC (+ 2x-1 image normalisation, normalizer.py:139-146; uint8 / 255, diffuser/datasets/img_utils.py:27-37) */
+int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);
+int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);
+int v2a_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int HW, v2a_stream_t s);
+/* Unet_Libero input pack 'b (f c) h w' + repeated cond image -> [B,f,H,W,6] (flowdiffusion/flowdiffusion/unet.py:217-220) */
+int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride, v2a_stream_t s);
+/* one fused sampler step: v-pred -> x0 (clamp) -> posterior mean + sigma*noise (mode 0, goal_diffusion.py:561-580), DDIM update (mode 1,
+ * :617-634), last DDIM pair (mode 2, :619-622); gw > 0 = classifier-free guidance mix (:536-547); final = unnormalize + clamp (:640,:650) */
+int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
+                           float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
+                           v2a_stream_t s);
+/* counter-based Philox4x32-10 generators (replace torch.randn / torch.randint of compute_loss :246-252 in perf runs) */
+int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
+int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
+int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------- attention (csrc/attention.hip) */
+/* QKVAttentionLegacy.forward (.../guided_diffusion/unet.py:341-358): qkv [n_frames*L][heads*3*ch] -> out [n_frames*L][heads*ch] */
+int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int heads, int head_ch, v2a_stream_t s);
+/* PerceiverAttention core (.../guided_diffusion/imagen.py:295-319): l2norm(q,k) * scales, sim * 8, softmax, @ v */
+int v2a_perceiver_attention(const float* q, const float* kv, const float* q_scale, const float* k_scale, float* out, int B, int Lq,
+                            int Lk, int H, int D, float sim_scale, v2a_stream_t s);
+int v2a_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, v2a_stream_t s); /* imagen.py:198-211 */
+int v2a_mean_rows(const float* x, float* out, int B, int R, int D, v2a_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------- pooling (csrc/pool.hip) */
+int v2a_maxpool3x3s2_fwd(const float* x, float* y, int8_t* idx, int N, int H, int W, int C, v2a_stream_t s);   /* resnet18.maxpool */
+int v2a_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int N, int H, int W, int C, v2a_stream_t s);
+/* SpatialSoftmax.forward (diffuser/diffusion_policy/common/base_nets.py:234-285): feat [B,H,W,K] -> kp [B,K,2]; att saved */
+int v2a_spatial_softmax_fwd(const float* feat, float* kp, float* att, int B, int H, int W, int K, v2a_stream_t s);
+int v2a_spatial_softmax_bwd(const float* att, const float* kp, const float* dkp, float* dfeat, int B, int H, int W, int K, v2a_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------- optimiser (csrc/optim.hip)
+ * clip_grad_norm_(1.0) -> AdamW.step -> zero_grad -> EMA.update  (diffuser/libero/lb_online_trainer_v7.py:604-624;
+ * hyper-parameters config/libero/lb_tk8_65to72.py:138-153).  table_dev: int64 [n_tensors][6] = {p, g, m, v, ema, numel};
+ * chunks_dev: int32 [nchunks][2] = {tensor, start} with chunks of v2a_opt_chunk_elems(); state_dev: v2a_opt_state_bytes() bytes
+ * initialised from the HOST image filled by v2a_opt_state_init; partial_dev: nchunks doubles. */
+int v2a_opt_chunk_elems(void);
+size_t v2a_opt_state_bytes(void);
+int v2a_opt_state_init(void* host_state, double lr, double b1, double b2, double eps, double wd, double max_norm, double ema_inv_gamma,
+                       double ema_power, double ema_min, double ema_beta, int ema_update_after, int ema_update_every);
+int v2a_opt_state_peek(const void* host_state, float* grad_norm, float* clip_coef, long long* step, float* ema_decay);
+int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad, v2a_stream_t s);
+int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, v2a_stream_t s);  /* 1/world after the RCCL sum */
+
+/* ---------------------------------------------------------------------------------------------- replay (csrc/replay.hip)
+ * Global_EnvReplayBuffer_Img.sample_random_batch_seq + EnvImg_UnitBuffer.sample_seq (diffuser/datasets/env_img_replay_buffer.py:
+ * 68-116, 278-302) and the 'rand_prob' split of sample_from_bufs (lb_online_trainer_v7.py:826-830).
+ * np_state / py_state: HOST uint32[625] = MT19937 key + position of numpy's legacy global RandomState / CPython's `random`;
+ * both are advanced in place exactly as np.random.randint / random.randint would have advanced them. */
+int v2a_replay_sample_indices(uint32_t* np_state, uint32_t* py_state, const int32_t* episode_len, int32_t n_episodes, int32_t batch,
+                              int32_t act_len, int64_t* out_episode, int64_t* out_start);          /* all HOST pointers */
+int v2a_replay_count_uniform_below(uint32_t* np_state, int32_t batch, double prob);              /* HOST; returns the count */
+int v2a_mt_seed_numpy(uint32_t* state, uint32_t seed);                                           /* HOST; np.random.seed(int) */
+int v2a_mt_seed_python(uint32_t* state, const uint32_t* key, int key_len);                       /* HOST; random.seed(int) */
+/* frames [n][H][W][3] (uint8 or fp32), acts [n][act_dim]; start/goal images + action chunk of every row in one gather */
+int v2a_replay_gather(const void* frames, int dtype_u8, const float* acts, const int64_t* frame_start, float* out_start, float* out_goal,
+                      float* out_acts, int B, int H, int W, int act_len, int act_dim, int normalize, int chw_out, v2a_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2A_H */

@@ -310,7 +310,7 @@ __global__ void gn_param_grads(const float* colsum, float* dgamma, float* dbeta,
     dbeta[c] = (float)b;
 }
 
-#define GN_SMALL_MAX 8192
+#define GN_SMALL_MAX 12288
 
 static void gn_chunks(int N, int S, int C, int* nchunk, int* rows) {
     // >= ~1024 workgroups overall, slabs of at least 16 KB
@@ -347,6 +347,7 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
     const long E = (long)S * cg;
     if (E <= GN_SMALL_MAX) {
         size_t lds = (E + 8) * sizeof(float);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gn_small_fwd, dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
         return V2A_OK;
@@ -382,6 +383,7 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
     const long E = (long)S * cg;
     if (E <= GN_SMALL_MAX) {
         size_t lds = (2 * E + 4 * cg + 8) * sizeof(float);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gn_small_bwd, dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
     } else {
