@@ -1,0 +1,16 @@
+"""Video-sampler leg only (for profiling): prints bench.video_leg's JSON object."""
+import argparse
+import json
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+import torch
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--batch", type=int, default=16)
+a = ap.parse_args()
+print(json.dumps(bench.video_leg(torch, "cuda:0", a.batch, a.steps)))
