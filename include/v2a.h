@@ -37,11 +37,12 @@ enum { V2A_ACT_NONE = 0, V2A_ACT_SILU = 1, V2A_ACT_RELU = 2, V2A_ACT_MISH = 3, V
  * and their data gradients (same kernel: weight pack mode 1, idil = forward stride, pad = k-1-pad).
  * w_packed: [Cout][KH][KW][C1+C2] (mode 0) -- a [Cout][Cin] Linear / 1x1 weight is already in that form.
  * y (+y2 when csplit > 0: channels [csplit,Cout) go to y2) [N,OH,OW,Cout]; rowvec [batches][Cout] is added per
- * (m / rows_per_batch, channel); residual [N,OH,OW,Cout]. */
+ * (m / rows_per_batch, channel); residual [N,OH,OW,Cout].  bmode = 1: data gradient computed straight from the FORWARD pack
+ * [Cred][KH][KW][Cout] of the layer (no second packed copy; needs Cred % 16 == 0 and Cout % 4 == 0). */
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                    const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH, int OW,
-                   int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int rows_per_batch, void* workspace,
+                   int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int rows_per_batch, int bmode, void* workspace,
                    size_t workspace_bytes, v2a_stream_t stream);
 /* weight gradient, written in the TORCH layout [Cout][Cin][KH][KW] (replaces autograd's conv backward-weight) */
 size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K);

@@ -270,3 +270,21 @@ def test_elementwise_bits():
     ln_x = torch.randn(10, 512, generator=g)
     gg, bb = torch.randn(512, generator=g), torch.randn(512, generator=g)
     close(ops.layernorm(ln_x.to(dev()), gg.to(dev()), bb.to(dev())), F.layer_norm(ln_x, (512,), gg, bb), what="layernorm")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 128, 3, 2, 1), (2, 256, 8, 8, 512, 3, 1, 1), (3, 128, 9, 7, 96, 1, 1, 0), (64, 32, 1, 16, 64, (1, 5), 1, (0, 2))])
+def test_dgrad_from_forward_pack(case):
+    """bmode=1: the data gradient read straight from the forward pack (N-major loader) equals autograd's."""
+    from v2a_hip import ops
+    N, Cin, H, W, Cout, k, s, p = case
+    kh, kw = (k, k) if isinstance(k, int) else k
+    ph, pw = (p, p) if isinstance(p, int) else p
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) / math.sqrt(Cin * kh * kw)).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=(ph, pw))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wp = ops.pack_weight(w.detach().to(dev()), 0)
+    dx = ops.conv2d(nhwc(dy), wp, None, Cin, kh, kw, (1, 1), (kh - 1 - ph, kw - 1 - pw), idil=s, out_hw=(H, W), bmode=1)
+    close(nchw(dx), x.grad, what="dgrad via forward pack")

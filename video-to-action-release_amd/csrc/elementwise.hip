@@ -125,14 +125,14 @@ __global__ __launch_bounds__(256) void unnormalize_action_kernel(const float* x,
 // NCHW float (or uint8) image batch -> NHWC float, with the policy image normalisation 2*x-1 when `normalize`
 // (reference normalizer.py:139-146 with min 0 / max 1).  u8 sources are divided by 255 first (img_utils.py:27-37).
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const T* src, float* dst, int N, int C, int HW, int normalize, float scale) {
+__global__ void nchw_to_nhwc_kernel(const T* src, float* dst, int N, int C, int HW, int normalize, float denom) {
     const size_t total = (size_t)N * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const size_t t = i / C;
         const int hw = (int)(t % HW);
         const int n = (int)(t / HW);
-        float v = (float)src[((size_t)n * C + c) * HW + hw] * scale;
+        float v = (float)src[((size_t)n * C + c) * HW + hw] / denom;
         if (normalize) v = 2.0f * ((v - 0.0f) / (1.0f - 0.0f)) - 1.0f;
         dst[i] = v;
     }
@@ -324,7 +324,7 @@ int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int
     return V2A_OK;
 }
 int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, hipStream_t s) {
-    hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint8_t>), GRID_FOR((size_t)N * C * HW), dim3(256), 0, s, src, dst, N, C, HW, normalize, 1.0f / 255.0f);
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint8_t>), GRID_FOR((size_t)N * C * HW), dim3(256), 0, s, src, dst, N, C, HW, normalize, 255.0f);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

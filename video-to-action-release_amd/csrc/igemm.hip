@@ -19,6 +19,7 @@
 
 #define BK 16
 #define LDS_PAD 4
+#define LDK 20
 
 struct ConvDesc {
     const float* x;         // source 1: [N, H, W, C1]
@@ -40,6 +41,7 @@ struct ConvDesc {
     int rows_per_batch;     // rowvec row = m / rows_per_batch
     int splitk, ktiles_per_split;
     int csplit;
+    int bmode;              // 0: w = [Cout][K] (K contiguous).  1: data-gradient straight from the FORWARD pack [Cred][taps][Cout]
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -51,12 +53,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + slot;
 }
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool BNMAJ>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int AL = BM / 64, BL = BN / 64;   // float4 loads per thread per tile
-    __shared__ float As[2][BK][BM + LDS_PAD];
-    __shared__ float Bs[2][BK][BN + LDS_PAD];
+    // row-major tiles [rows][16 k + 4 pad]: 80-B rows keep every float4 16-B aligned and make both the b128 store of a
+    // loaded float4 and the b128 operand read (16 lanes x 4 words = all 64 banks) conflict-free.
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    // BNMAJ (data gradient read from the forward pack): B rows are k, columns n contiguous -> k-major tile, b128 store, b32 reads
+    __shared__ __attribute__((aligned(16))) float Bs[2][BNMAJ ? BK * (BN + LDS_PAD) : BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.Cout + BN - 1) / BN;
@@ -118,12 +123,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
                 }
                 ra[i] = v;
             }
+            if (BNMAJ) {
+                // rows kk = tid / (BN/4) + i * (1024/BN): k = k0 + kk = (tap, cred = c0 + kk); 4 consecutive n per thread
+                const int taps = p.KH * p.KW;
+                const int cbase = k0 - tap * Cin;
 #pragma unroll
-            for (int i = 0; i < BL; ++i) {
-                int n = n0 + lrow + i * 64;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k0 + chunk * 4);
-                rb[i] = v;
+                for (int i = 0; i < BL; ++i) {
+                    const int kk = tid / (BN / 4) + i * (1024 / BN);
+                    const int n = n0 + (tid % (BN / 4)) * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n < p.Cout)
+                        v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)(cbase + kk) * taps + (taps - 1 - tap)) * p.Cout + n);
+                    rb[i] = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BL; ++i) {
+                    int n = n0 + lrow + i * 64;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k0 + chunk * 4);
+                    rb[i] = v;
+                }
             }
         } else {
 #pragma unroll
@@ -160,13 +180,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
 
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AL; ++i)
+        for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[buf][lrow + i * 64][chunk * 4]) = ra[i];
+        if (BNMAJ) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) As[buf][chunk * 4 + j][lrow + i * 64] = ra[i][j];
+            for (int i = 0; i < BL; ++i)
+                *reinterpret_cast<f32x4*>(&Bs[buf][(tid / (BN / 4) + i * (1024 / BN)) * (BN + LDS_PAD) + (tid % (BN / 4)) * 4]) = rb[i];
+        } else {
 #pragma unroll
-        for (int i = 0; i < BL; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Bs[buf][chunk * 4 + j][lrow + i * 64] = rb[i][j];
+            for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + i * 64) * LDK + chunk * 4]) = rb[i];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -189,18 +211,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
         if (more) load_tile(kt + 1);
+        // one ds_read_b128 per operand tile feeds FOUR MFMA k-steps: in step (h, s) the lanes with lk = 0 supply k = 8h + s and
+        // the lanes with lk = 1 supply k = 8h + 4 + s, for A and B alike (the k-order of an exact-f32 sum is free to choose).
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + lk][wm + i * 32 + lr];
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm + i * 32 + lr][8 * h + 4 * lk]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + lk][wn + j * 32 + lr];
+            for (int j = 0; j < TN; ++j) {
+                if (BNMAJ) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int q = 0; q < 4; ++q) b[j][q] = Bs[buf][(8 * h + 4 * lk + q) * (BN + LDS_PAD) + wn + j * 32 + lr];
+                } else {
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn + j * 32 + lr) * LDK + 8 * h + 4 * lk]);
+                }
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
@@ -488,7 +521,7 @@ size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K) {
 int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                    const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH,
                    int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups,
-                   int rows_per_batch, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                   int rows_per_batch, int bmode, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !w_packed || !y || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
     if (C2 > 0 && !x2) return V2A_ERR_ARG;
     ConvDesc p;
@@ -502,8 +535,11 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     const int Cin = C1 + C2;
     p.K = KH * KW * Cin;
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.bmode = bmode;
     const bool vec = (Cin % 16 == 0) && (C1 % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!x2 || ((uintptr_t)x2 & 15) == 0) &&
                      (((uintptr_t)w_packed & 15) == 0);
+    // the N-major (data-gradient) loader needs whole 16-wide k tiles inside one tap and float4 columns
+    if (bmode && !(vec && Cout % 4 == 0)) return V2A_ERR_ARG;
     int bm, bn, tiles, s;
     conv_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     const int nkt = cdiv(p.K, BK);
@@ -511,10 +547,11 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     p.splitk = s;
     p.ktiles_per_split = cdiv(nkt, s);
     dim3 grid(tiles, s), block(256);
-#define LAUNCH(BM_, BN_)                                                                          \
-    do {                                                                                          \
-        if (vec) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, true>), grid, block, 0, stream, p); \
-        else hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, false>), grid, block, 0, stream, p);    \
+#define LAUNCH(BM_, BN_)                                                                                        \
+    do {                                                                                                        \
+        if (p.bmode) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, true, true>), grid, block, 0, stream, p);      \
+        else if (vec) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, true, false>), grid, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, false, false>), grid, block, 0, stream, p);           \
     } while (0)
     if (bm == 128 && bn == 128) LAUNCH(128, 128);
     else if (bm == 128) LAUNCH(128, 64);

@@ -33,6 +33,9 @@ struct GnDesc {
 
 // -------------------------------------------------------------------------------------------- large path
 // MODE 0: (x, x^2).  MODE 1: (dz, dz * xhat) with dz = dout * act'(z), z = gn(x) [+ residual].
+// Thread -> fixed float4 column(s): with L4 = C/4 columns, rpi = max(1, 256 / L4) rows are processed in parallel and a
+// thread keeps its column's partial sums in registers for the whole slab (4 independent loads in flight per thread);
+// LDS float atomics are touched once per (thread, column) at the end.
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
     extern __shared__ __attribute__((aligned(16))) float bins[];   // [2][C]
@@ -41,90 +44,97 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
     for (int i = tid; i < 2 * C; i += 256) bins[i] = 0.f;
     __syncthreads();
     const int s0 = chunk * p.rows_per_chunk, s1 = min(p.S, s0 + p.rows_per_chunk);
-    const size_t base = ((size_t)n * p.S + s0) * C;
-    const int total4 = (s1 - s0) * L4;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(p.x + base);
+    const int nrows = s1 - s0;
     const bool two = (MODE == 0) && p.x2 != nullptr;
-    const int C1 = p.C1, C2 = C - C1;
+    const int C1 = two ? p.C1 : C, C2 = C - C1;
     const float* xa = p.x + ((size_t)n * p.S + s0) * C1;
-    const float* xb = two ? p.x2 + ((size_t)n * p.S + s0) * C2 : nullptr;
-    const f32x4* d4 = MODE ? reinterpret_cast<const f32x4*>(p.dout + base) : nullptr;
-    const f32x4* r4 = (MODE && p.residual) ? reinterpret_cast<const f32x4*>(p.residual + base) : nullptr;
-    // a thread's channel advances by (256 % L4) float4 per step; accumulate a run locally while it stays put
-    int c4 = tid % L4;
-    const int step = 256 % L4;
-    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-    auto flush = [&](int cc4) {
+    const float* xb = two ? p.x2 + ((size_t)n * p.S + s0) * C2 : xa;
+    const float* dptr = MODE ? p.dout + ((size_t)n * p.S + s0) * C : nullptr;
+    const float* rptr = (MODE && p.residual) ? p.residual + ((size_t)n * p.S + s0) * C : nullptr;
+    const int rpi = L4 >= 256 ? 1 : 256 / L4;                 // rows in flight per pass
+    const int row0 = L4 >= 256 ? 0 : tid / L4;
+    const bool active = L4 >= 256 ? true : (tid < rpi * L4);
+    const int c4_first = active ? (L4 >= 256 ? tid : tid % L4) : L4;
+    for (int c4 = c4_first; c4 < L4; c4 += 256) {
+        const int cc = c4 * 4;
+        const bool first = cc < C1;
+        const float* src = first ? xa : xb;
+        src += first ? cc : (cc - C1);
+        const int ld = first ? C1 : C2;
+        float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+        float mu = 0.f, rs = 0.f, gm[4] = {0, 0, 0, 0}, bt[4] = {0, 0, 0, 0};
+        if (MODE) {
+            const int g = cc / cg;
+            mu = p.mean[n * p.G + g];
+            rs = p.rstd[n * p.G + g];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            atomicAdd(&bins[cc4 * 4 + j], a0[j]);
-            atomicAdd(&bins[C + cc4 * 4 + j], a1[j]);
-            a0[j] = 0.f;
-            a1[j] = 0.f;
+            for (int j = 0; j < 4; ++j) { gm[j] = p.gamma[cc + j]; bt[j] = p.beta[cc + j]; }
         }
-    };
-    for (int i = tid; i < total4; i += 256) {
-        f32x4 v;
-        if (two) {
-            const int row = i / L4, cc = (i - row * L4) * 4;
-            v = (cc < C1) ? *reinterpret_cast<const f32x4*>(xa + (size_t)row * C1 + cc)
-                          : *reinterpret_cast<const f32x4*>(xb + (size_t)row * C2 + (cc - C1));
-        } else {
-            v = x4[i];
-        }
-        if (MODE == 0) {
+// (manual prefetch below)
+        for (int r = row0; r < nrows; r += rpi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * ld);
+            if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[j] * v[j]; }
-        } else {
-            const int g = (c4 * 4) / cg;
-            const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
-            f32x4 d = d4[i];
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (r4) r = r4[i];
+                for (int j = 0; j < 4; ++j) { a0[j] += v[j]; a1[j] += v[j] * v[j]; }
+            } else {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dptr + (size_t)r * C + cc);
+                f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+                if (rptr) rr = *reinterpret_cast<const f32x4*>(rptr + (size_t)r * C + cc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c4 * 4 + j;
-                const float xh = (v[j] - mu) * rs;
-                const float z = xh * p.gamma[c] + p.beta[c] + r[j];
-                const float dz = d[j] * act_bwd(z, p.act);
-                a0[j] += dz;
-                a1[j] += dz * xh;
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (v[j] - mu) * rs;
+                    const float z = xh * gm[j] + bt[j] + rr[j];
+                    const float dz = d[j] * act_bwd(z, p.act);
+                    a0[j] += dz;
+                    a1[j] += dz * xh;
+                }
             }
         }
-        if (step != 0) {
-            flush(c4);
-            c4 += step;
-            if (c4 >= L4) c4 -= L4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&bins[cc + j], a0[j]);
+            atomicAdd(&bins[C + cc + j], a1[j]);
         }
     }
-    if (step == 0) flush(c4);
     __syncthreads();
     double* out = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
     for (int i = tid; i < 2 * C; i += 256) out[i] = (double)bins[i];
 }
 
-// one block per n: sums chunk partials in fp64.  MODE 0 -> mean/rstd.  MODE 1 -> colsum[n][2][C] (fp32).
+// one block per (n, group): sums the chunk partials of the group's channels in fp64.
+// MODE 0 -> mean / rstd.  MODE 1 -> colsum[n][2][C] (fp32) for the group's channels.
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
-    const int n = blockIdx.x, tid = threadIdx.x, C = p.C, cg = C / p.G;
-    extern __shared__ __attribute__((aligned(16))) double dsum[];   // [2][C]
-    for (int i = tid; i < 2 * C; i += 256) {
-        double s = 0.0;
-        for (int k = 0; k < p.nchunk; ++k) s += p.partial[((size_t)n * p.nchunk + k) * 2 * C + i];
-        dsum[i] = s;
-        if (MODE == 1) p.colsum[(size_t)n * 2 * C + i] = (float)s;
-    }
-    __syncthreads();
+    __shared__ double red[2][4];
+    const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x, C = p.C, cg = C / p.G;
     if (MODE == 0) {
-        for (int g = tid; g < p.G; g += 256) {
-            double s = 0.0, q = 0.0;
-            for (int c = g * cg; c < (g + 1) * cg; ++c) { s += dsum[c]; q += dsum[C + c]; }
+        double s = 0.0, q = 0.0;
+        for (int i = tid; i < p.nchunk * cg; i += 256) {
+            const int k = i / cg, c = g * cg + i % cg;
+            const double* src = p.partial + ((size_t)n * p.nchunk + k) * 2 * C;
+            s += src[c];
+            q += src[C + c];
+        }
+        s = wave_sum_d(s);
+        q = wave_sum_d(q);
+        if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+        __syncthreads();
+        if (tid == 0) {
+            s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
             const double cnt = (double)p.S * cg;
             const double mu = s / cnt;
             double var = q / cnt - mu * mu;
             if (var < 0.0) var = 0.0;
             p.mean[n * p.G + g] = (float)mu;
             p.rstd[n * p.G + g] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+    } else {
+        for (int i = tid; i < 2 * cg; i += 256) {
+            const int which = i / cg, c = g * cg + i % cg;
+            double s = 0.0;
+            for (int k = 0; k < p.nchunk; ++k) s += p.partial[((size_t)n * p.nchunk + k) * 2 * C + which * C + c];
+            p.colsum[(size_t)n * 2 * C + which * C + c] = (float)s;
         }
     }
 }
@@ -301,13 +311,20 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
 }
 
 // dgamma[c] = sum_n colsum[n][1][c], dbeta[c] = sum_n colsum[n][0][c]
-__global__ void gn_param_grads(const float* colsum, float* dgamma, float* dbeta, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void gn_param_grads(const float* colsum, float* dgamma, float* dbeta, int N, int C) {
+    __shared__ double sm[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     double a = 0.0, b = 0.0;
-    for (int n = 0; n < N; ++n) { b += colsum[(size_t)n * 2 * C + c]; a += colsum[(size_t)n * 2 * C + C + c]; }
-    dgamma[c] = (float)a;
-    dbeta[c] = (float)b;
+    if (c < C)
+        for (int n = w; n < N; n += 4) { b += colsum[(size_t)n * 2 * C + c]; a += colsum[(size_t)n * 2 * C + C + c]; }
+    sm[0][w][threadIdx.x & 63] = a;
+    sm[1][w][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int l = threadIdx.x;
+        dgamma[c] = (float)(sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l]);
+        dbeta[c] = (float)(sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l]);
+    }
 }
 
 #define GN_SMALL_MAX 12288
@@ -358,7 +375,7 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
     p.partial = (double*)workspace;
     hipLaunchKernelGGL(gn_colreduce<0>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
     V2A_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize<0>, dim3(N), dim3(256), 2 * C * sizeof(double), stream, p);
+    hipLaunchKernelGGL(gn_finalize<0>, dim3(N * G), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     size_t total4 = (size_t)N * S * (C / 4);
     int grid = (int)((total4 + 255) / 256);
@@ -394,7 +411,7 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
         p.partial = (double*)workspace;
         hipLaunchKernelGGL(gn_colreduce<1>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
         V2A_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_finalize<1>, dim3(N), dim3(256), 2 * C * sizeof(double), stream, p);
+        hipLaunchKernelGGL(gn_finalize<1>, dim3(N * G), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
         size_t total4 = (size_t)N * S * (C / 4);
         int grid = (int)((total4 + 255) / 256);
@@ -403,7 +420,7 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
         V2A_CHECK_LAUNCH();
     }
     if (dgamma && dbeta) {
-        hipLaunchKernelGGL(gn_param_grads, dim3((C + 255) / 256), dim3(256), 0, stream, colsum, dgamma, dbeta, N, C);
+        hipLaunchKernelGGL(gn_param_grads, dim3((C + 63) / 64), dim3(256), 0, stream, colsum, dgamma, dbeta, N, C);
         V2A_CHECK_LAUNCH();
     }
     return V2A_OK;

@@ -14,13 +14,13 @@
 template <typename T>
 __global__ void replay_gather_kernel(const T* __restrict__ frames, const float* __restrict__ acts, const int64_t* __restrict__ frame_start,
                                      float* __restrict__ out_start, float* __restrict__ out_goal, float* __restrict__ out_acts,
-                                     int B, int frame_elems, int act_len, int act_dim, float scale, int normalize, int chw_out, int HW) {
+                                     int B, int frame_elems, int act_len, int act_dim, float denom, int normalize, int chw_out, int HW) {
     const int b = blockIdx.y;
     const int64_t f0 = frame_start[b];
     const T* s0 = frames + (size_t)f0 * frame_elems;
     const T* s1 = frames + (size_t)(f0 + act_len) * frame_elems;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < frame_elems; i += gridDim.x * 256) {
-        float a = (float)s0[i] * scale, g = (float)s1[i] * scale;
+        float a = (float)s0[i] / denom, g = (float)s1[i] / denom;      // true division, as images / 255.0 (img_utils.py:37)
         if (normalize) { a = 2.0f * a - 1.0f; g = 2.0f * g - 1.0f; }
         int o = i;
         if (chw_out) { const int c = i % 3, hw = i / 3; o = c * HW + hw; }   // store is HWC
@@ -142,7 +142,7 @@ int v2a_replay_gather(const void* frames, int dtype_u8, const float* acts, const
     dim3 grid((fe + 256 * 8 - 1) / (256 * 8), B);
     if (dtype_u8)
         hipLaunchKernelGGL((replay_gather_kernel<uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)frames, acts, frame_start, out_start,
-                           out_goal, out_acts, B, fe, act_len, act_dim, 1.0f / 255.0f, normalize, chw_out, H * W);
+                           out_goal, out_acts, B, fe, act_len, act_dim, 255.0f, normalize, chw_out, H * W);
     else
         hipLaunchKernelGGL((replay_gather_kernel<float>), grid, dim3(256), 0, s, (const float*)frames, acts, frame_start, out_start,
                            out_goal, out_acts, B, fe, act_len, act_dim, 1.0f, normalize, chw_out, H * W);

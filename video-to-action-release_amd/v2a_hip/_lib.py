@@ -20,7 +20,7 @@ LL = ctypes.c_longlong
 # name -> (restype, argtypes).  Order/meaning mirrors include/v2a.h exactly.
 SIGNATURES = {
     "v2a_conv2d_workspace_bytes": (SZ, [I, I, I]),
-    "v2a_conv2d_fwd": (I, [P] * 8 + [I] * 18 + [P, SZ, P]),
+    "v2a_conv2d_fwd": (I, [P] * 8 + [I] * 19 + [P, SZ, P]),
     "v2a_conv2d_wgrad_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_wgrad": (I, [P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),

@@ -60,7 +60,7 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
 
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
-           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0):
+           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]."""
     _chk(x, "x")
     N, H, W, C1 = x.shape
@@ -87,7 +87,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.v2a_conv2d_fwd(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
                              _p(y2), csplit, N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, 1 if ups else 0,
-                             rows_per_batch, _p(ws), wsb, _stream()), "conv2d_fwd")
+                             rows_per_batch, bmode, _p(ws), wsb, _stream()), "conv2d_fwd")
     return y
 
 

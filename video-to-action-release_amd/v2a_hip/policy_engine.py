@@ -16,6 +16,12 @@ import torch
 from . import ops
 
 
+def _dgrad(x, cv, bias, cout, kh, kw, stride=(1, 1), pad=(0, 0), **kw_):
+    """conv2d launch that uses cv's data-gradient operand (forward pack + N-major loader, or the flipped pack)."""
+    w, bmode = cv.dg()
+    return ops.conv2d(x, w, bias, cout, kh, kw, stride, pad, bmode=bmode, **kw_)
+
+
 def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
     """diffusers' squaredcos_cap_v2 betas -> alphas_cumprod (fp32 cumprod), restated from the published algorithm."""
     ab = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
@@ -39,6 +45,8 @@ class _Conv:
             self.kh, self.kw = w.shape[2], w.shape[3]
         self.transposed = transposed
         self.co, self.ci = w.shape[0], w.shape[1]     # torch dims 0 / 1 (for transposed: [Cin][Cout])
+        # data gradients read the forward pack directly (N-major loader) when the reduction channels are a multiple of 16
+        self.nmaj = (self.co % 16 == 0) and (self.ci % 4 == 0)
         self._pf = None
         self._pd = None
         self._ver = (None, None)
@@ -65,18 +73,20 @@ class _Conv:
             if self._pf is None or self._pf is w:
                 self._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
             ops.pack_weight(w, 0, self._pf)
-        if self._pd is None:
-            self._pd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
-        ops.pack_weight(w, 1, self._pd)
+        if not self.nmaj:            # data gradient cannot read the forward pack (odd channel counts): keep a flipped pack
+            if self._pd is None:
+                self._pd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+            ops.pack_weight(w, 1, self._pd)
         self._ver = (self.w.data_ptr(), self.w._version)
 
     def pf(self):
         self._fresh()
         return self._pf
 
-    def pd(self):
+    def dg(self):
+        """(operand, bmode) for the data-gradient / transposed-conv launch of this weight."""
         self._fresh()
-        return self._pd
+        return (self._pf, 1) if self.nmaj else (self._pd, 0)
 
 
 class PolicyEngine:
@@ -214,28 +224,28 @@ class PolicyEngine:
         fc, pool = e["fc"], e["pool"]
         ops.conv2d_wgrad(st["kp"].view(1, 1, B, -1), df.view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname])
         ops.colsum(df, out=grads[fc.bname])
-        dkp = ops.conv2d(df.view(1, 1, B, -1), fc.pd(), None, fc.ci, 1, 1).view(B, -1)
+        dkp = _dgrad(df.view(1, 1, B, -1), fc, None, fc.ci, 1, 1, (1, 1), (0, 0)).view(B, -1)
         dkl = ops.spatial_softmax_bwd(st["att"], st["kp"], dkp)
         feat = st["feat"]
         ops.conv2d_wgrad(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname])
         ops.colsum(dkl.view(-1, cfg.num_kp), out=grads[pool.bname])
-        dh = ops.conv2d(dkl, pool.pd(), None, pool.ci, 1, 1)
+        dh = _dgrad(dkl, pool, None, pool.ci, 1, 1)
         for blk, bs in zip(reversed(e["blocks"]), reversed(st["blocks"])):
             s, co, ci = blk["stride"], blk["cout"], blk["cin"]
             inp = bs["inp"]
             do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True)
             ops.conv2d_wgrad(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
-            da = ops.conv2d(do2, blk["conv2"].pd(), None, co, 3, 3, (1, 1), (1, 1))
+            da = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1))
             do1, _, _ = self._gn_bwd(bs["s1"], da, grads)
             ops.conv2d_wgrad(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname])
             ih, iw = inp.shape[1], inp.shape[2]
             if blk["down"] is not None:
                 didn_raw, _, _ = self._gn_bwd(bs["sd"], didn, grads)
                 ops.conv2d_wgrad(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname])
-                d1 = ops.conv2d(didn_raw, blk["down"].pd(), None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw))
-                dh = ops.conv2d(do1, blk["conv1"].pd(), None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1)
+                d1 = _dgrad(didn_raw, blk["down"], None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw))
+                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1)
             else:
-                dh = ops.conv2d(do1, blk["conv1"].pd(), None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn)
+                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn)
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
         ops.conv2d_wgrad(st["x0"], dc1, e["conv1"].shape, 7, 7, (2, 2), (3, 3), dw=grads[e["conv1"].wname])
@@ -285,12 +295,12 @@ class PolicyEngine:
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
         ops.conv2d_wgrad(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname])
         ops.colsum(dc1.view(-1, co), out=grads[c1v.bname])
-        da0 = ops.conv2d(dc1, c1v.pd(), None, co, 1, k, (1, 1), (0, k // 2))
+        da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2))
         dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
         df2 = dfilm.view(B, 2 * co)
         ops.conv2d_wgrad(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname])
         ops.colsum(df2, out=grads[cev.bname])
-        dmgf = ops.conv2d(df2.view(1, 1, B, -1), cev.pd(), None, cev.ci, 1, 1, residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
+        dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0), residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
         ops.conv2d_wgrad(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname])
         ops.colsum(dc0.view(-1, co), out=grads[c0v.bname])
         rc = r["rc"]
@@ -300,18 +310,18 @@ class PolicyEngine:
         if not need_dx:
             return None, None, dmgf
         if rc is not None:
-            first = ops.conv2d(dc0, c0v.pd(), None, ci, 1, k, (1, 1), (0, k // 2),
+            first = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2),
                                residual=None if extra is None else extra.view(B, 1, T, ci))
             if x2 is None:
-                dx = ops.conv2d(d4, rc.pd(), None, ci, 1, 1, residual=first).view(B, T, ci)
+                dx = _dgrad(d4, rc, None, ci, 1, 1, residual=first).view(B, T, ci)
                 return dx, None, dmgf
             C2 = ci - C1
             dxa = torch.empty((B, T, C1), dtype=torch.float32, device=x.device)
             dxb = torch.empty((B, T, C2), dtype=torch.float32, device=x.device)
-            ops.conv2d(d4, rc.pd(), None, ci, 1, 1, residual=first, y=dxa.view(B, 1, T, C1), y2=dxb.view(B, 1, T, C2), csplit=C1)
+            _dgrad(d4, rc, None, ci, 1, 1, residual=first, y=dxa.view(B, 1, T, C1), y2=dxb.view(B, 1, T, C2), csplit=C1)
             return dxa, dxb, dmgf
         res = dout if extra is None else ops.axpy(dout, extra)
-        dx = ops.conv2d(dc0, c0v.pd(), None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci)).view(B, T, ci)
+        dx = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci)).view(B, T, ci)
         return dx, None, dmgf
 
     def unet_fwd(self, sample, t_long, global_cond, save=None):
@@ -350,7 +360,7 @@ class PolicyEngine:
             xin = x
             us = lvl["us"]
             Bx, Tx, Cx = x.shape
-            x = ops.conv2d(x.view(Bx, 1, Tx, Cx), us.pd(), us.b, us.ci, 1, 4, (1, 1), (0, 2), idil=2, out_hw=(1, 2 * Tx)).view(Bx, 2 * Tx, us.ci)
+            x = _dgrad(x.view(Bx, 1, Tx, Cx), us, us.b, us.ci, 1, 4, (1, 1), (0, 2), idil=2, out_hw=(1, 2 * Tx)).view(Bx, 2 * Tx, us.ci)
             if tape is not None:
                 tape.append(dict(us=us, x=xin))
         k = cfg.kernel_size
@@ -372,11 +382,11 @@ class PolicyEngine:
         d4 = dpred.view(B, 1, T, Da)
         ops.conv2d_wgrad(a.view(B, 1, T, -1), d4, f1.shape, 1, 1, dw=grads[f1.wname])
         ops.colsum(dpred.view(-1, Da), out=grads[f1.bname])
-        da = ops.conv2d(d4, f1.pd(), None, f1.ci, 1, 1)
+        da = _dgrad(d4, f1, None, f1.ci, 1, 1)
         dc, _, _ = self._gn_bwd(save["fin_s"], da, grads)
         ops.conv2d_wgrad(x.view(B, 1, T, -1), dc, f0.shape, 1, k, (1, 1), (0, k // 2), dw=grads[f0.wname])
         ops.colsum(dc.view(-1, f0.co), out=grads[f0.bname])
-        dx = ops.conv2d(dc, f0.pd(), None, f0.ci, 1, k, (1, 1), (0, k // 2)).view(B, T, f0.ci)
+        dx = _dgrad(dc, f0, None, f0.ci, 1, k, (1, 1), (0, k // 2)).view(B, T, f0.ci)
         tape = save["tape"]
         dmgf = None
         pending_skip = []          # gradients flowing into hs entries from the up path (LIFO order of use)
@@ -403,7 +413,7 @@ class PolicyEngine:
                 ops.conv2d_wgrad(x4, dy4, ds.shape, 1, 3, (1, 2), (0, 1), dw=grads[ds.wname])
                 ops.colsum(dx.view(-1, ds.co), out=grads[ds.bname])
                 skip = pending_skip.pop() if pending_skip else None
-                dx = ops.conv2d(dy4, ds.pd(), None, Cx, 1, 3, (1, 1), (0, 1), idil=2, out_hw=(1, Tx),
+                dx = _dgrad(dy4, ds, None, Cx, 1, 3, (1, 1), (0, 1), idil=2, out_hw=(1, Tx),
                                 residual=None if skip is None else skip.view(Bx, 1, Tx, Cx)).view(Bx, Tx, Cx)
             else:
                 n_res_seen += 1
@@ -429,7 +439,7 @@ class PolicyEngine:
         s3, s1 = self.step3, self.step1
         ops.conv2d_wgrad(save["m1"].view(1, 1, B, -1), de2.view(1, 1, B, -1), s3.shape, 1, 1, dw=grads[s3.wname])
         ops.colsum(de2, out=grads[s3.bname])
-        dm1 = ops.conv2d(de2.view(1, 1, B, -1), s3.pd(), None, s3.ci, 1, 1).view(B, -1)
+        dm1 = _dgrad(de2.view(1, 1, B, -1), s3, None, s3.ci, 1, 1, (1, 1), (0, 0)).view(B, -1)
         de1 = ops.act_bwd(save["e1"], dm1, "mish")
         ops.conv2d_wgrad(save["temb"].view(1, 1, B, -1), de1.view(1, 1, B, -1), s1.shape, 1, 1, dw=grads[s1.wname])
         ops.colsum(de1, out=grads[s1.bname])
