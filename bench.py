@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table (dense f32 matrix = vector peak)
 HBM_PEAK_GBS = 8000.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA
 
 
 def build_store(torch, device, batch, seed):
@@ -198,7 +199,9 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
         m = y.shape[0] * y.shape[1] * y.shape[2]
         bm = 128 if m >= 4096 else 64
         bn = (128 if bm == 128 else 64) if cout > 64 else 64
-        recs.append((f"conv_igemm_f32<{bm},{bn}>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
+        import v2a_hip as _v
+        kn = "conv_igemm_bf16" if _v.get_precision() == "bf16" else "conv_igemm_f32"
+        recs.append((f"{kn}<{bm},{bn}>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
         return y
 
     ops.conv2d = timed
@@ -237,6 +240,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip the video-sampler leg (BASELINE.json configs[2])")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="MFMA precision of the contraction kernels: fp32 = exact-f32 (parity configuration, default); bf16 = bf16 inputs, "
+                         "fp32 accumulate/storage (performance configuration)")
+    ap.add_argument("--no-bf16-extra", action="store_true", help="skip the additional bf16-mode measurements appended to the fp32 run")
     ap.add_argument("--video-batch", type=int, default=16)
     ap.add_argument("--video-steps", type=int, default=50)
     args = ap.parse_args()
@@ -262,6 +269,8 @@ def main():
 
     from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
     from v2a_hip.trainer import PolicyTrainer
+    import v2a_hip
+    v2a_hip.set_precision(args.precision)
     torch.manual_seed(0)                       # identical replica init on every rank
     pol = build_policy(DEFAULT_CONF).to(device)
     np.random.seed(rank)
@@ -299,7 +308,7 @@ def main():
         flops_step = 8.722e9 * args.batch                  # fwd+bwd algorithmic FLOPs per sample
         out = {"metric": "policy_train_steps_per_sec", "value": value, "unit": "steps/s (batch-64 steps, all ranks)", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA inputs; f32 accumulate, f32 storage/optimizer)", "data": "synthetic",
                "config": {"workload": "Libero 8-task diffusion-policy train step (BASELINE.json configs[1]): R1 replay gather -> "
                                       "compute_loss fwd/bwd -> clip -> AdamW -> EMA", "batch_per_gpu": args.batch,
                           "global_batch": args.batch * world, "image": "128x128x3 uint8 start+goal", "action": "16x7",
@@ -327,10 +336,41 @@ def main():
                                                  for k, v in sorted(agg.items())}}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
+        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        out["roofline"]["peak"] = peak
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / peak
+        if args.precision == "fp32" and not args.no_bf16_extra:
+            # the same step in the bf16-MFMA performance configuration (fresh trainer: new hipGraph), reported beside the parity run
+            v2a_hip.set_precision("bf16")
+            torch.manual_seed(0)
+            pol2 = build_policy(DEFAULT_CONF).to(device)
+            tr2 = PolicyTrainer(pol2, store, batch_size=args.batch, seed=rank, use_graph=not args.no_graph)
+            for _ in range(max(args.warmup, 3)):
+                tr2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tr2.step()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            out["bf16"] = {"metric": "policy_train_steps_per_sec", "value": args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+                           "dtype": "bf16 MFMA inputs, f32 accumulate/storage/optimizer", "final_loss": float(tr2.loss.item()),
+                           "note": "performance configuration; parity (1e-4) is claimed for the fp32 run only"}
+            del tr2, pol2
+            v2a_hip.set_precision("fp32")
         if not args.no_video:
             del tr, pol, store
             torch.cuda.empty_cache()
             out["video"] = video_leg(torch, device, args.video_batch, args.video_steps)
+            if args.precision == "fp32" and not args.no_bf16_extra:
+                v2a_hip.set_precision("bf16")
+                torch.cuda.empty_cache()
+                vb = video_leg(torch, device, args.video_batch, args.video_steps)
+                vb["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
+                vb["roofline"]["frac"] = vb["roofline"]["achieved"] / BF16_MFMA_PEAK_TFLOPS
+                vb["dtype"] = "bf16 MFMA inputs, f32 accumulate/storage"
+                out["video_bf16"] = vb
+                v2a_hip.set_precision("fp32")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

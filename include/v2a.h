@@ -39,18 +39,26 @@ enum { V2A_ACT_NONE = 0, V2A_ACT_SILU = 1, V2A_ACT_RELU = 2, V2A_ACT_MISH = 3, V
  * y (+y2 when csplit > 0: channels [csplit,Cout) go to y2) [N,OH,OW,Cout]; rowvec [batches][Cout] is added per
  * (m / rows_per_batch, channel); residual [N,OH,OW,Cout].  bmode = 1: data gradient computed straight from the FORWARD pack
  * [Cred][KH][KW][Cout] of the layer (no second packed copy; needs Cred % 16 == 0 and Cout % 4 == 0). */
+/* process-wide MFMA precision of the contraction kernels: 0 = exact f32 (parity configuration, default), 1 = bf16 inputs with f32
+ * accumulation and fp32 HBM storage (performance configuration; the reference's GPU path is fp16 autocast). Returns the old mode. */
+int v2a_set_precision(int mode);
+int v2a_get_precision(void);
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                    const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH, int OW,
                    int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int rows_per_batch, int bmode, void* workspace,
                    size_t workspace_bytes, v2a_stream_t stream);
-/* weight gradient, written in the TORCH layout [Cout][Cin][KH][KW] (replaces autograd's conv backward-weight) */
+/* weight gradient, written in the TORCH layout [Cout][Cin][KH][KW] (replaces autograd's conv backward-weight);
+ * dbias != NULL: the bias gradient sum_rows dy is produced by the same launch */
 size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K);
-int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, int N, int H, int W, int C1, int C2, int OH,
+int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias, int N, int H, int W, int C1, int C2, int OH,
                      int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate,
                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 /* torch weight [Cout][Cin][KH][KW] -> mode 0: [Cout][KH][KW][Cin]; mode 1: [Cin][KH'][KW'][Cout] flipped (dgrad / transposed) */
 int v2a_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int mode, v2a_stream_t stream);
+/* every forward pack of a model in one launch: table_dev int64 [n][5] = {src, dst, Cout, Cin, taps}; chunks_dev int32 [nchunks][2] */
+int v2a_pack_chunk_elems(void);
+int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- GroupNorm (csrc/norm.hip)
  * y = film(act(gn(x) + residual)) on [N,S,C]; x2 != NULL: x is channels [0,C1) and x2 channels [C1,C) of a concat.
@@ -63,8 +71,8 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
                       void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
                       const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm, float* colsum,
-                      float* dgamma, float* dbeta, int N, int S, int C, int G, int act, void* workspace, size_t workspace_bytes,
-                      v2a_stream_t stream);
+                      float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act, void* workspace,
+                      size_t workspace_bytes, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- elementwise (csrc/elementwise.hip) */
 int v2a_act_fwd(const float* x, float* y, size_t n, int act, v2a_stream_t s);                 /* nn.Mish / nn.SiLU / nn.GELU */

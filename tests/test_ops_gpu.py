@@ -288,3 +288,46 @@ def test_dgrad_from_forward_pack(case):
     wp = ops.pack_weight(w.detach().to(dev()), 0)
     dx = ops.conv2d(nhwc(dy), wp, None, Cin, kh, kw, (1, 1), (kh - 1 - ph, kw - 1 - pw), idil=s, out_hw=(H, W), bmode=1)
     close(nchw(dx), x.grad, what="dgrad via forward pack")
+
+
+def test_bf16_mfma_mode_matches_bf16_rounded_reference():
+    """precision='bf16': operands rounded to bf16 (RNE), fp32 accumulation -> equals torch conv on bf16-rounded inputs to ~1e-5,
+    and stays within ~1e-2 of the fp32 result."""
+    import v2a_hip
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(77)
+    N, Cin, H, W, Cout = 4, 64, 24, 24, 96
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    old = v2a_hip.set_precision("bf16")
+    try:
+        y = ops.conv2d(nhwc(x), ops.pack_weight(w.to(dev()), 0), b.to(dev()), Cout, 3, 3, (1, 1), (1, 1))
+    finally:
+        v2a_hip.set_precision(old)
+    xr, wr = x.bfloat16().float(), w.bfloat16().float()
+    close(nchw(y), F.conv2d(xr, wr, b, padding=1), tol=2e-5, what="bf16 mode vs bf16-rounded reference")
+    close(nchw(y), F.conv2d(x, w, b, padding=1), tol=2e-2, what="bf16 mode vs fp32")
+    assert v2a_hip.get_precision() == "fp32"
+
+
+def test_bf16_wgrad_matches_bf16_rounded_reference():
+    import v2a_hip
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(78)
+    for (N, Cin, H, W, Cout, k, s_) in [(4, 64, 24, 24, 96, 3, 1), (64, 256, 1, 8, 128, (1, 5), 1), (3, 128, 16, 16, 128, 3, 2)]:
+        kh, kw = (k, k) if isinstance(k, int) else k
+        x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float().requires_grad_(False)
+        w = (torch.randn(Cout, Cin, kh, kw, generator=g) / math.sqrt(Cin * kh * kw)).requires_grad_(True)
+        b = torch.zeros(Cout, requires_grad=True)
+        y = F.conv2d(x, w, b, stride=s_, padding=(kh // 2, kw // 2))
+        dy = torch.randn(y.shape, generator=g).bfloat16().float()
+        y.backward(dy)
+        old = v2a_hip.set_precision("bf16")
+        try:
+            db = torch.empty(Cout, device=dev())
+            dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), tuple(w.shape), kh, kw, (s_, s_), (kh // 2, kw // 2), dbias=db)
+        finally:
+            v2a_hip.set_precision(old)
+        close(dw, w.grad, tol=2e-5, what="bf16 wgrad (inputs exactly representable in bf16)")
+        close(db, b.grad, tol=2e-5, what="fused bias grad")

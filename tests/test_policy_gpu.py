@@ -147,3 +147,30 @@ def test_trainer_graph_replay_matches_eager():
     tot = [float(np.sqrt(np.sum(np.square(r[1])))) for r in res]
     assert abs(tot[0] - tot[1]) <= 1e-5 * tot[0], tot
     assert all(np.isfinite(res[1][0]))
+
+
+def test_bf16_mode_policy_close_to_fp32(golden_dir):
+    """precision='bf16' (performance configuration): loss within 1e-2 of the fp32 golden loss, every gradient direction within
+    cos >= 0.99 of the oracle's (bf16 operand rounding, fp32 accumulation / storage).  The fp32 mode stays the parity mode."""
+    import v2a_hip
+    from oracle import policy as OP
+    g = np.load(f"{golden_dir}/policy.npz", allow_pickle=True)
+    pol, sd = _policy()
+    batch = _batch(g)
+    noise, ts = torch.from_numpy(g["noise"]), torch.from_numpy(g["timesteps"])
+    pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
+    old = v2a_hip.set_precision("bf16")
+    try:
+        loss = pol.compute_loss(batch)
+        loss.backward()
+    finally:
+        v2a_hip.set_precision(old)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-2 * abs(float(g["loss"]))
+    names = [str(n) for n in g["param_names"]]
+    P = dict(pol.named_parameters())
+    flat = torch.cat([P[n].grad.flatten().cpu() for n in names]).double()
+    _, og = OP.loss_and_grads(sd, batch, noise, ts, names=names)
+    ref = torch.cat([og[n].flatten() for n in names]).double()
+    cos = float((flat * ref).sum() / (flat.norm() * ref.norm()))
+    assert cos >= 0.995, cos
+    assert abs(float(flat.norm() / ref.norm()) - 1.0) <= 3e-2

@@ -7,6 +7,10 @@ import torch
 from v2a_hip import ops
 
 dev = "cuda:0"
+import v2a_hip
+if len(sys.argv) > 1:
+    v2a_hip.set_precision(sys.argv[1])
+print("precision:", v2a_hip.get_precision())
 FWD = [  # name, N, H, W, Cin, Cout, k, stride
     ("video 128^2 128->128 3x3 (B16)", 112, 128, 128, 128, 128, 3, 1),
     ("video 64^2 256->256 3x3", 112, 64, 64, 256, 256, 3, 1),

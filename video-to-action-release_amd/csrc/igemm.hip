@@ -21,6 +21,26 @@
 #define LDS_PAD 4
 #define LDK 20
 
+// division by a launch-invariant divisor without the ~40-instruction integer divide (libdivide branch-free form)
+struct FastDiv {
+    uint32_t d, m, s;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.m = 0; f.s = 0; return f; }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    if (f.d <= 1) return n;
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> 1)) >> (f.s - 1);
+}
+
 struct ConvDesc {
     const float* x;         // source 1: [N, H, W, C1]
     const float* x2;        // source 2 (concat along C): [N, H, W, C2] or null
@@ -53,15 +73,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + slot;
 }
 
-template <int BM, int BN, bool VEC, bool BNMAJ>
+template <int BM, int BN, int BKT, bool VEC, bool BNMAJ>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int AL = BM / 64, BL = BN / 64;   // float4 loads per thread per tile
-    // row-major tiles [rows][16 k + 4 pad]: 80-B rows keep every float4 16-B aligned and make both the b128 store of a
-    // loaded float4 and the b128 operand read (16 lanes x 4 words = all 64 banks) conflict-free.
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+    constexpr int KC = BKT / 4;                 // float4 chunks per tile row
+    constexpr int RPP = 256 / KC;               // tile rows loaded per pass of the 256 threads
+    constexpr int AL = BM / RPP, BL = BN / RPP; // float4 loads per thread per tile
+    constexpr int LDR = BKT + 4;                // LDS row stride (words): 16-B aligned, conflict-free b128 reads
+    constexpr int NB_ROWS = BKT * 4 / BN > 0 ? 1024 / BN : 1;   // BNMAJ: k-rows per pass = 256 / (BN/4)
+    constexpr int NBL = BKT / (1024 / BN);      // BNMAJ: float4 loads per thread per tile
+    // row-major tiles [rows][BKT k + 4 pad]: both the b128 store of a loaded float4 and the b128 operand read
+    // (16 lanes x 4 words = all 64 banks) are conflict-free; BKT = 32 makes every row segment a full 128-B line.
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDR];
     // BNMAJ (data gradient read from the forward pack): B rows are k, columns n contiguous -> k-major tile, b128 store, b32 reads
-    __shared__ __attribute__((aligned(16))) float Bs[2][BNMAJ ? BK * (BN + LDS_PAD) : BN * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BNMAJ ? BKT * (BN + LDS_PAD) : BN * LDR];
+    (void)NB_ROWS;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.Cout + BN - 1) / BN;
@@ -71,17 +97,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
     const int split = blockIdx.y;
     const int Cin = p.C1 + p.C2;
-    const int nkt = (p.K + BK - 1) / BK;
+    const int nkt = (p.K + BKT - 1) / BKT;
     const int kt_begin = split * p.ktiles_per_split;
     const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
 
     // ---- per-thread loader state
-    const int lrow = tid >> 2, chunk = tid & 3;
+    const int lrow = tid / KC, chunk = tid % KC;
     int a_ihb[AL], a_iwb[AL], a_img[AL];
     bool a_ok[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        int m = m0 + lrow + i * 64;
+        int m = m0 + lrow + i * RPP;
         a_ok[i] = m < p.M;
         int mm = a_ok[i] ? m : 0;
         int ow = mm % p.OW;
@@ -92,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
         a_iwb[i] = ow * p.sw - p.pw;
     }
 
-    f32x4 ra[AL], rb[BL];
+    f32x4 ra[AL], rb[BNMAJ ? NBL : BL];
 
     auto pix_of = [&](int i, int kh, int kw, bool& ok) -> size_t {
         int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
@@ -107,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     };
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
         if (VEC) {
             const int tap = k0 / Cin;
             const int c = k0 - tap * Cin + chunk * 4;
@@ -124,11 +150,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
                 ra[i] = v;
             }
             if (BNMAJ) {
-                // rows kk = tid / (BN/4) + i * (1024/BN): k = k0 + kk = (tap, cred = c0 + kk); 4 consecutive n per thread
+                // rows kk = tid / (BN/4) + i * (1024/BN): k = k0 + kk = (tap, cred = cbase + kk); 4 consecutive n per thread
                 const int taps = p.KH * p.KW;
                 const int cbase = k0 - tap * Cin;
 #pragma unroll
-                for (int i = 0; i < BL; ++i) {
+                for (int i = 0; i < NBL; ++i) {
                     const int kk = tid / (BN / 4) + i * (1024 / BN);
                     const int n = n0 + (tid % (BN / 4)) * 4;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
             } else {
 #pragma unroll
                 for (int i = 0; i < BL; ++i) {
-                    int n = n0 + lrow + i * 64;
+                    int n = n0 + lrow + i * RPP;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k0 + chunk * 4);
                     rb[i] = v;
@@ -164,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
             }
 #pragma unroll
             for (int i = 0; i < BL; ++i) {
-                int n = n0 + lrow + i * 64;
+                int n = n0 + lrow + i * RPP;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (n < p.Cout) {
 #pragma unroll
@@ -180,14 +206,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
 
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[buf][lrow + i * 64][chunk * 4]) = ra[i];
+        for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[buf][(lrow + i * RPP) * LDR + chunk * 4]) = ra[i];
         if (BNMAJ) {
 #pragma unroll
-            for (int i = 0; i < BL; ++i)
+            for (int i = 0; i < NBL; ++i)
                 *reinterpret_cast<f32x4*>(&Bs[buf][(tid / (BN / 4) + i * (1024 / BN)) * (BN + LDS_PAD) + (tid % (BN / 4)) * 4]) = rb[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + i * 64) * LDK + chunk * 4]) = rb[i];
+            for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + i * RPP) * LDR + chunk * 4]) = rb[i];
         }
     };
 
@@ -210,21 +236,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);
-        // one ds_read_b128 per operand tile feeds FOUR MFMA k-steps: in step (h, s) the lanes with lk = 0 supply k = 8h + s and
-        // the lanes with lk = 1 supply k = 8h + 4 + s, for A and B alike (the k-order of an exact-f32 sum is free to choose).
+        // one ds_read_b128 per operand tile feeds FOUR MFMA k-steps: in step (h, q) the lanes with lk = 0 supply k = 8h + q and
+        // the lanes with lk = 1 supply k = 8h + 4 + q, for A and B alike (the k-order of an exact-f32 sum is free to choose).
+        // The next tile's address arithmetic + global loads are issued after the first MFMA batch so that they execute under
+        // the matrix pipe instead of in front of it (right after the barrier every wave would otherwise do VALU work first).
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BKT / 8; ++h) {
+            if (h == 1 && more) load_tile(kt + 1);
             f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][wm + i * 32 + lr][8 * h + 4 * lk]);
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wm + i * 32 + lr) * LDR + 8 * h + 4 * lk]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (BNMAJ) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) b[j][q] = Bs[buf][(8 * h + 4 * lk + q) * (BN + LDS_PAD) + wn + j * 32 + lr];
                 } else {
-                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn + j * 32 + lr) * LDK + 8 * h + 4 * lk]);
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn + j * 32 + lr) * LDR + 8 * h + 4 * lk]);
                 }
             }
 #pragma unroll
@@ -241,6 +269,155 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 32 + lr;
+            if (n >= p.Cout) continue;
+            const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.splitk > 1) {
+                    p.partial[((size_t)split * p.M + m) * p.Cout + n] = v;
+                } else {
+                    v += bv;
+                    if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
+                    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                    if (p.y2 && n >= p.csplit) p.y2[(size_t)m * (p.Cout - p.csplit) + (n - p.csplit)] = v;
+                    else p.y[(size_t)m * (p.y2 ? p.csplit : p.Cout) + n] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ bf16-MFMA variant
+// Same implicit GEMM with v_mfma_f32_32x32x16_bf16 (16x the f32 matrix rate).  HBM storage stays fp32: operands are rounded
+// to bf16 (RNE) while being staged into LDS, accumulation is fp32.  This is the PERFORMANCE configuration (the reference's GPU
+// path runs fp16 autocast, lb_online_trainer_v7.py:72-76,593); the exact-f32 kernel above remains the parity configuration.
+// LDS rows hold 32 bf16 (+8 pad) = 80 B: b64 stores of 4 converted values, b128 operand reads (8 consecutive k per lane).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvDesc p) {
+    constexpr int BKT = 32, KC = 8, RPP = 32, LDH = 40;         // 40 halves = 80-B rows
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int AL = BM / RPP, BL = BN / RPP;
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * LDH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nkt = (p.K + BKT - 1) / BKT;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    const int lrow = tid / KC, chunk = tid % KC;
+    int a_ihb[AL], a_iwb[AL], a_img[AL];
+    bool a_ok[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        int m = m0 + lrow + i * RPP;
+        a_ok[i] = m < p.M;
+        int mm = a_ok[i] ? m : 0;
+        int ow = mm % p.OW;
+        int t = mm / p.OW;
+        int oh = t % p.OH;
+        a_img[i] = t / p.OH;
+        a_ihb[i] = oh * p.sh - p.ph;
+        a_iwb[i] = ow * p.sw - p.pw;
+    }
+    f32x4 ra[AL], rb[BL];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BKT;
+        const int tap = k0 / Cin;
+        const int c = k0 - tap * Cin + chunk * 4;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
+            bool ok = a_ok[i] && ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+            if (p.idil > 1) {
+                ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                ih /= p.idil;
+                iw /= p.idil;
+            }
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            const size_t pix = ((size_t)a_img[i] * p.H + ih) * p.W + iw;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float* src = (c < p.C1) ? p.x + pix * p.C1 + c : p.x2 + pix * p.C2 + (c - p.C1);
+                v = *reinterpret_cast<const f32x4*>(src);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            int n = n0 + lrow + i * RPP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k0 + chunk * 4);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            uint2 u = {pack_bf16x2(ra[i][0], ra[i][1]), pack_bf16x2(ra[i][2], ra[i][3])};
+            *reinterpret_cast<uint2*>(&As[buf][(lrow + i * RPP) * LDH + chunk * 4]) = u;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            uint2 u = {pack_bf16x2(rb[i][0], rb[i][1]), pack_bf16x2(rb[i][2], rb[i][3])};
+            *reinterpret_cast<uint2*>(&Bs[buf][(lrow + i * RPP) * LDH + chunk * 4]) = u;
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -288,10 +465,12 @@ struct WgradDesc {
     const float* x; const float* x2;   // conv input (two sources as in ConvDesc)
     const float* dy;                   // [M][Cout]
     float* dw;                         // torch layout [Cout][Cin][KH][KW]  (or [Cin][Cout][KH][KW]-free: see transposed)
-    float* partial;                    // [splits][Cout][K']
+    float* partial;                    // [splits][Cout][K'] followed by [splits][Cout] bias partials
+    float* dbias;                      // optional: [Cout] = sum_r dY[r][co] (fused bias gradient) or null
     int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, ups, HL, WL, M, K;
     int splits, rtiles_per_split;
     int accumulate;                    // 1: dw += result
+    FastDiv fd_ow, fd_oh;
 };
 
 __device__ __forceinline__ void wgrad_store(const WgradDesc& p, int co, int k, float v) {
@@ -335,6 +514,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradDesc p) {
         b_kw[j] = tap - b_kh[j] * p.KW;
     }
     f32x4 ra[AL], rb[BL];
+    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tile = [&](int rt) {
         const int r0 = rt * BK;
@@ -353,16 +534,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradDesc p) {
                 }
             }
             ra[i] = v;
+            if (do_bias) bsum += v;
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
             const int r = r0 + b_r + i * BROWS;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < p.M) {
-                const int ow = r % p.OW;
-                const int t = r / p.OW;
-                const int oh = t % p.OH;
-                const int img = t / p.OH;
+                const int t = (int)fdiv((uint32_t)r, p.fd_ow);
+                const int ow = r - t * p.OW;
+                const int img = (int)fdiv((uint32_t)t, p.fd_oh);
+                const int oh = t - img * p.OH;
                 const int ihb = oh * p.sh - p.ph, iwb = ow * p.sw - p.pw;
                 auto fetch = [&](int j) -> const float* {
                     int ih = ihb + b_kh[j], iw = iwb + b_kw[j];
@@ -449,6 +631,178 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradDesc p) {
                 else wgrad_store(p, co, k, acc[i][j][r]);
             }
         }
+    if (do_bias) {      // fused bias gradient: threads (a_r, a_c4) hold partial column sums of dY over their rows
+        __syncthreads();
+        float* red = &As[0][0][0];                       // [AROWS][BM] floats fit in the first buffer
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[a_r * BM + a_c4 * 4 + j] = bsum[j];
+        __syncthreads();
+        if (tid < BM) {
+            float t = 0.f;
+            for (int r = 0; r < AROWS; ++r) t += red[r * BM + tid];
+            const int co = m0 + tid;
+            if (co < p.Cout) {
+                if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = t;
+                else p.dbias[co] = p.accumulate ? p.dbias[co] + t : t;
+            }
+        }
+    }
+}
+
+// bf16-MFMA weight gradient.  The MFMA wants 8 consecutive reduction rows per lane while HBM is contiguous along the OTHER axis
+// (channels), so each loader thread owns a 8(rows) x 4(channels) register block: 8 coalesced float4 loads, then four b128 LDS
+// stores of 8 bf16 along the reduction axis ([channel][32 rows + pad] tiles).  Threads [0,BM) stage dY^T, [BM,BM+BN) the im2col.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
+    constexpr int BKT = 32, LDH = 40;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * LDH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nrt = (p.M + BKT - 1) / BKT;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    const bool isA = tid < BM;
+    const bool isB = !isA && tid < BM + BN;
+    const int t2 = isA ? tid : tid - BM;
+    const int c4 = isA ? t2 % (BM / 4) : t2 % (BN / 4);
+    const int rgrp = isA ? t2 / (BM / 4) : t2 / (BN / 4);
+    // B column (k') decode is loop invariant
+    int b_kh = 0, b_kw = 0, b_c = 0;
+    bool b_kok = false;
+    if (isB) {
+        const int k = n0 + c4 * 4;
+        b_kok = k < p.K;
+        const int kk = b_kok ? k : 0;
+        const int tap = kk / Cin;
+        b_c = kk - tap * Cin;
+        b_kh = tap / p.KW;
+        b_kw = tap - b_kh * p.KW;
+    }
+    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rv[8];
+    auto load_tile = [&](int rt) {
+        const int r0 = rt * BKT + rgrp * 8;
+        if (isA) {
+            const int co = m0 + c4 * 4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = r0 + e;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < p.M && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)r * p.Cout + co);
+                rv[e] = v;
+                if (do_bias) bsum += v;
+            }
+        } else if (isB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = r0 + e;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < p.M && b_kok) {
+                    const int t = (int)fdiv((uint32_t)r, p.fd_ow);
+                    const int ow = r - t * p.OW;
+                    const int img = (int)fdiv((uint32_t)t, p.fd_oh);
+                    const int oh = t - img * p.OH;
+                    int ih = oh * p.sh - p.ph + b_kh, iw = ow * p.sw - p.pw + b_kw;
+                    bool ok = ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+                    if (p.idil > 1) {
+                        ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                        ih /= p.idil;
+                        iw /= p.idil;
+                    }
+                    if (p.ups) { ih >>= 1; iw >>= 1; }
+                    if (ok) {
+                        const size_t pix = ((size_t)img * p.H + ih) * p.W + iw;
+                        const float* src = (b_c < p.C1) ? p.x + pix * p.C1 + b_c : p.x2 + pix * p.C2 + (b_c - p.C1);
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    }
+                }
+                rv[e] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (isA || isB) {
+            uint16_t* dst = (isA ? &As[buf][0] : &Bs[buf][0]) + (c4 * 4) * LDH + rgrp * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint4 u = {pack_bf16x2(rv[0][j], rv[1][j]), pack_bf16x2(rv[2][j], rv[3][j]), pack_bf16x2(rv[4][j], rv[5][j]),
+                           pack_bf16x2(rv[6][j], rv[7][j])};
+                *reinterpret_cast<uint4*>(dst + j * LDH) = u;
+            }
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    if (rt_begin < rt_end) {
+        load_tile(rt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        const bool more = (rt + 1) < rt_end;
+        if (more) load_tile(rt + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int k = n0 + wn + j * 32 + lr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co >= p.Cout) continue;
+                if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[i][j][r];
+                else wgrad_store(p, co, k, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&As[0][0]);        // [4][BM] floats
+        if (isA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[rgrp * BM + c4 * 4 + j] = bsum[j];
+        }
+        __syncthreads();
+        if (tid < BM) {
+            const float t = red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid];
+            const int co = m0 + tid;
+            if (co < p.Cout) {
+                if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = t;
+                else p.dbias[co] = p.accumulate ? p.dbias[co] + t : t;
+            }
+        }
+    }
 }
 
 __global__ void wgrad_splitk_reduce(const WgradDesc p) {
@@ -458,6 +812,14 @@ __global__ void wgrad_splitk_reduce(const WgradDesc p) {
         for (int s = 0; s < p.splits; ++s) v += p.partial[(size_t)s * total + idx];
         const int co = (int)(idx / p.K), k = (int)(idx - (size_t)co * p.K);
         wgrad_store(p, co, k, v);
+    }
+    if (p.dbias) {
+        const float* bp = p.partial + (size_t)p.splits * total;
+        for (int co = blockIdx.x * blockDim.x + threadIdx.x; co < p.Cout; co += gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < p.splits; ++s) v += bp[(size_t)s * p.Cout + co];
+            p.dbias[co] = p.accumulate ? p.dbias[co] + v : v;
+        }
     }
 }
 
@@ -484,6 +846,25 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
+// all forward packs of a model in ONE launch.  table (int64) per tensor: {src, dst, Cout, Cin, taps}; chunks (int32): {tensor, start}
+#define PACK_CHUNK 16384
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* table, const int* chunks) {
+    const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
+    const float* src = reinterpret_cast<const float*>(table[t * 5 + 0]);
+    float* dst = reinterpret_cast<float*>(table[t * 5 + 1]);
+    const int Cout = (int)table[t * 5 + 2], Cin = (int)table[t * 5 + 3], taps = (int)table[t * 5 + 4];
+    const long long total = (long long)Cout * Cin * taps;
+    const int cnt = (int)min((long long)PACK_CHUNK, total - start);
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const long long idx = (long long)start + i;
+        const int ci = (int)(idx % Cin);
+        const long long q = idx / Cin;
+        const int tap = (int)(q % taps);
+        const int co = (int)(q / taps);
+        dst[idx] = src[((size_t)co * Cin + ci) * taps + tap];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int pick_split(int tiles, int ktiles, int min_ktiles) {
     int s = 1;
@@ -498,16 +879,31 @@ static void conv_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int*
     *bn = Cout > 64 ? (*bm == 128 ? 128 : 64) : 64;
     if (*bm == 64) *bn = 64;
     *tiles = cdiv(M, *bm) * cdiv(Cout, *bn);
-    *s = pick_split(*tiles, cdiv(K, BK), 8);
+    *s = pick_split(*tiles, cdiv(K, 32), 4);      // split granularity in 32-deep k tiles (valid for both BKT)
 }
 static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int* s) {
+    // largest tile that still yields >= 192 workgroups; split the reduction only when even 64x64 tiles cannot fill the chip
     *bm = Cout > 64 ? 128 : 64;
     *bn = (K > 64 && *bm == 128) ? 128 : 64;
     *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
-    *s = pick_split(*tiles, cdiv(M, BK), 4);
+    if (M < 4096) {     // short reduction: get parallelism from smaller tiles; long reductions keep big tiles and split instead
+        if (*tiles < 192 && *bm == 128 && *bn == 128) { *bn = 64; *tiles = cdiv(Cout, *bm) * cdiv(K, *bn); }
+        if (*tiles < 192 && *bm == 128) { *bm = 64; *bn = 64; *tiles = cdiv(Cout, *bm) * cdiv(K, *bn); }
+    }
+    *s = (*tiles >= 192) ? 1 : pick_split(*tiles, cdiv(M, BK), 4);
 }
 
+static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
+
 extern "C" {
+
+// process-wide MFMA precision of the contraction kernels (0 = f32 exact, 1 = bf16 inputs / f32 accumulate); returns the old value
+int v2a_set_precision(int mode) {
+    int old = g_precision;
+    if (mode == 0 || mode == 1) g_precision = mode;
+    return old;
+}
+int v2a_get_precision(void) { return g_precision; }
 
 // workspace (bytes) a conv forward may need for split-K slabs (same plan as the launcher)
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K) {
@@ -542,16 +938,38 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     if (bmode && !(vec && Cout % 4 == 0)) return V2A_ERR_ARG;
     int bm, bn, tiles, s;
     conv_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
-    const int nkt = cdiv(p.K, BK);
+    // 32-deep tiles (full 128-B lines per row segment, half the barriers) pay off on the smaller tiles; the 128x128 tile keeps
+    // 16-deep tiles for occupancy (measured: tools/conv_bench.py)
+    const bool k32 = vec && (Cin % 32 == 0) && !(bm == 128 && bn == 128);
+    const int bkt = k32 ? 32 : 16;
+    const int nkt = cdiv(p.K, bkt);
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(nkt, s);
     dim3 grid(tiles, s), block(256);
-#define LAUNCH(BM_, BN_)                                                                                        \
-    do {                                                                                                        \
-        if (p.bmode) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, true, true>), grid, block, 0, stream, p);      \
-        else if (vec) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, true, false>), grid, block, 0, stream, p);   \
-        else hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, false, false>), grid, block, 0, stream, p);           \
+    if (g_precision == 1 && vec && Cin % 32 == 0 && !p.bmode) {     // bf16 MFMA (data gradients then use the flipped pack, bmode 0)
+        p.splitk = s;
+        p.ktiles_per_split = cdiv(cdiv(p.K, 32), s);
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 128>), grid, block, 0, stream, p);
+        else if (bm == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 64>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_bf16<64, 64>), grid, block, 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        if (s > 1) {
+            size_t total = (size_t)p.M * Cout;
+            int g = (int)((total + 255) / 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(conv_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            V2A_CHECK_LAUNCH();
+        }
+        return V2A_OK;
+    }
+#define LAUNCH(BM_, BN_)                                                                                              \
+    do {                                                                                                              \
+        if (p.bmode && k32) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 32, true, true>), grid, block, 0, stream, p);  \
+        else if (p.bmode) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, true, true>), grid, block, 0, stream, p);    \
+        else if (k32) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 32, true, false>), grid, block, 0, stream, p);       \
+        else if (vec) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, true, false>), grid, block, 0, stream, p);       \
+        else hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, false, false>), grid, block, 0, stream, p);               \
     } while (0)
     if (bm == 128 && bn == 128) LAUNCH(128, 128);
     else if (bm == 128) LAUNCH(128, 64);
@@ -571,17 +989,17 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
 size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K) {
     int bm, bn, tiles, s;
     wgrad_plan(M, Cout, K, &bm, &bn, &tiles, &s);
-    return s > 1 ? (size_t)s * Cout * K * sizeof(float) : 0;
+    return s > 1 ? ((size_t)s * Cout * K + (size_t)s * Cout) * sizeof(float) : 0;
 }
 
 // Weight gradient of the conv described by the same geometry arguments; dw is written in the TORCH layout
 // [Cout][Cin][KH][KW] so it can be handed to autograd / the optimiser unchanged.
-int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, int N, int H, int W, int C1, int C2,
+int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias, int N, int H, int W, int C1, int C2,
                      int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups,
                      int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !dy || !dw) return V2A_ERR_ARG;
     WgradDesc p;
-    p.x = x; p.x2 = x2; p.dy = dy; p.dw = dw; p.partial = (float*)workspace;
+    p.x = x; p.x2 = x2; p.dy = dy; p.dw = dw; p.dbias = dbias; p.partial = (float*)workspace;
     p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.idil = idil < 1 ? 1 : idil; p.ups = ups;
     p.HL = ups ? 2 * H : (p.idil > 1 ? (H - 1) * p.idil + 1 : H);
@@ -590,15 +1008,33 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     const int Cin = C1 + C2;
     p.K = KH * KW * Cin;
     p.accumulate = accumulate;
+    p.fd_ow = make_fastdiv((uint32_t)OW);
+    p.fd_oh = make_fastdiv((uint32_t)OH);
     const bool veca = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     const bool vecb = (Cin % 4 == 0) && (C1 % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!x2 || ((uintptr_t)x2 & 15) == 0);
     int bm, bn, tiles, s;
     wgrad_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     const int nrt = cdiv(p.M, BK);
-    if (s > 1 && (size_t)s * Cout * p.K * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    if (s > 1 && ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splits = s;
     p.rtiles_per_split = cdiv(nrt, s);
     dim3 grid(tiles, s), block(256);
+    if (g_precision == 1 && veca && vecb) {
+        p.splits = s;
+        p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128>), grid, block, 0, stream, p);
+        else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 64>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16<64, 64>), grid, block, 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        if (s > 1) {
+            size_t total = (size_t)Cout * p.K;
+            int g = (int)((total + 255) / 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            V2A_CHECK_LAUNCH();
+        }
+        return V2A_OK;
+    }
 #define LAUNCHW(BM_, BN_)                                                                                   \
     do {                                                                                                    \
         if (veca && vecb) hipLaunchKernelGGL((conv_wgrad_f32<BM_, BN_, true, true>), grid, block, 0, stream, p);   \
@@ -618,6 +1054,15 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
     }
+    return V2A_OK;
+}
+
+int v2a_pack_chunk_elems(void) { return PACK_CHUNK; }
+// forward packs (mode 0) of many tensors in one launch; see pack_weights_multi_kernel for the table layout
+int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, hipStream_t stream) {
+    if (!table_dev || !chunks_dev || nchunks <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev);
+    V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 

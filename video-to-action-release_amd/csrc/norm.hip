@@ -27,6 +27,8 @@ struct GnDesc {
     float* rstd;            // [N][G]
     float* colsum;          // [N][2][C] (stats: sum x, sum x^2; backward: sum dz, sum dz*xhat)
     double* partial;        // [N][nchunk][2][C]
+    float* dgamma_acc;      // small backward path: atomically accumulate dgamma / dbeta over n here (or null)
+    float* dbeta_acc;
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
     float eps;
 };
@@ -303,6 +305,10 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         const int c = g * cg + cc;
         p.colsum[(size_t)n * 2 * C + c] = bins[cc];
         p.colsum[(size_t)n * 2 * C + C + c] = bins[cg + cc];
+        if (p.dgamma_acc) {
+            atomicAdd(&p.dgamma_acc[c], bins[cg + cc]);
+            atomicAdd(&p.dbeta_acc[c], bins[cc]);
+        }
         if (p.dfilm) {
             p.dfilm[(size_t)n * 2 * C + c] = bins[2 * cg + cc];
             p.dfilm[(size_t)n * 2 * C + C + c] = bins[3 * cg + cc];
@@ -311,12 +317,13 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
 }
 
 // dgamma[c] = sum_n colsum[n][1][c], dbeta[c] = sum_n colsum[n][0][c]
-__global__ __launch_bounds__(256) void gn_param_grads(const float* colsum, float* dgamma, float* dbeta, int N, int C) {
+__global__ __launch_bounds__(256) void gn_param_grads(const float* colsum, float* dgamma, float* dbeta, int N, int C, int accumulate) {
     __shared__ double sm[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     double a = 0.0, b = 0.0;
     if (c < C)
         for (int n = w; n < N; n += 4) { b += colsum[(size_t)n * 2 * C + c]; a += colsum[(size_t)n * 2 * C + C + c]; }
+    if (accumulate && w == 0 && c < C) { a += dgamma[c]; b += dbeta[c]; }
     sm[0][w][threadIdx.x & 63] = a;
     sm[1][w][threadIdx.x & 63] = b;
     __syncthreads();
@@ -386,11 +393,12 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
 }
 
 // Backward of v2a_groupnorm_fwd.  dx [N,S,C]; dres (optional) = gradient of the residual input;
-// dfilm (optional) [N][2][C]; colsum [N][2][C] scratch/output; dgamma/dbeta [C].
+// dfilm (optional) [N][2][C]; colsum [N][2][C] scratch/output; dgamma/dbeta [C]: overwritten, or accumulated into when
+// accumulate_params = 1 (the gradient arena is zeroed by the fused optimiser; saves a reduction launch on the small path).
 int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
                       const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm,
-                      float* colsum, float* dgamma, float* dbeta, int N, int S, int C, int G, int act, void* workspace,
-                      size_t workspace_bytes, hipStream_t stream) {
+                      float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !dout || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
@@ -398,7 +406,9 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;
     const long E = (long)S * cg;
+    bool params_done = false;
     if (E <= GN_SMALL_MAX) {
+        if (accumulate_params && dgamma && dbeta) { p.dgamma_acc = dgamma; p.dbeta_acc = dbeta; params_done = true; }
         size_t lds = (2 * E + 4 * cg + 8) * sizeof(float);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gn_small_bwd, dim3(N * G), dim3(256), lds, stream, p);
@@ -419,8 +429,8 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
         hipLaunchKernelGGL(gn_apply_bwd, dim3(grid), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
     }
-    if (dgamma && dbeta) {
-        hipLaunchKernelGGL(gn_param_grads, dim3((C + 63) / 64), dim3(256), 0, stream, colsum, dgamma, dbeta, N, C);
+    if (dgamma && dbeta && !params_done) {
+        hipLaunchKernelGGL(gn_param_grads, dim3((C + 63) / 64), dim3(256), 0, stream, colsum, dgamma, dbeta, N, C, accumulate_params);
         V2A_CHECK_LAUNCH();
     }
     return V2A_OK;

@@ -19,14 +19,18 @@ LL = ctypes.c_longlong
 
 # name -> (restype, argtypes).  Order/meaning mirrors include/v2a.h exactly.
 SIGNATURES = {
+    "v2a_set_precision": (I, [I]),
+    "v2a_get_precision": (I, []),
     "v2a_conv2d_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_fwd": (I, [P] * 8 + [I] * 19 + [P, SZ, P]),
     "v2a_conv2d_wgrad_workspace_bytes": (SZ, [I, I, I]),
-    "v2a_conv2d_wgrad": (I, [P, P, P, P] + [I] * 17 + [P, SZ, P]),
+    "v2a_conv2d_wgrad": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),
+    "v2a_pack_chunk_elems": (I, []),
+    "v2a_pack_weights_multi": (I, [P, P, I, P]),
     "v2a_groupnorm_workspace_bytes": (SZ, [I, I, I, I]),
     "v2a_groupnorm_fwd": (I, [P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
-    "v2a_groupnorm_bwd": (I, [P] * 14 + [I, I, I, I, I, P, SZ, P]),
+    "v2a_groupnorm_bwd": (I, [P] * 14 + [I, I, I, I, I, I, P, SZ, P]),
     "v2a_act_fwd": (I, [P, P, SZ, I, P]),
     "v2a_act_bwd": (I, [P, P, P, SZ, I, P]),
     "v2a_axpy": (I, [P, P, P, F, SZ, P]),

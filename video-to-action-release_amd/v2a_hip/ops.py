@@ -91,7 +91,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     return y
 
 
-def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False):
+def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None):
     """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout]."""
     _chk(x, "x"); _chk(dy, "dy")
     N, H, W, C1 = x.shape
@@ -103,7 +103,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
     K = KH * KW * (C1 + C2)
     wsb = lib.v2a_conv2d_wgrad_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
+    check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
                                stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
                                _p(ws), wsb, _stream()), "conv2d_wgrad")
     return dw
@@ -144,7 +144,7 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
 
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
-                  dgamma=None, dbeta=None):
+                  dgamma=None, dbeta=None, accumulate_params=False):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None)."""
     N, S, C = x.shape
     dx = torch.empty_like(x)
@@ -157,7 +157,8 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.v2a_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), dout.data_ptr(),
                                 mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), _p(dfilm), colsum_.data_ptr(),
-                                dgamma.data_ptr(), dbeta.data_ptr(), N, S, C, G, ACT[act], _p(ws), wsb, _stream()),
+                                dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,
+                                _stream()),
           "groupnorm_bwd")
     return dx, dgamma, dbeta, dres, dfilm
 

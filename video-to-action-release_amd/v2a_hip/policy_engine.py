@@ -86,7 +86,13 @@ class _Conv:
     def dg(self):
         """(operand, bmode) for the data-gradient / transposed-conv launch of this weight."""
         self._fresh()
-        return (self._pf, 1) if self.nmaj else (self._pd, 0)
+        from ._lib import lib
+        if self.nmaj and lib.v2a_get_precision() == 0:
+            return self._pf, 1
+        if self._pd is None:                      # bf16 mode: the K-contiguous flipped pack keeps data gradients on the bf16 kernel
+            self._pd = torch.empty(self.w.numel(), dtype=torch.float32, device=self.w.device)
+            ops.pack_weight(self.w.detach(), 1, self._pd)
+        return self._pd, 0
 
 
 class PolicyEngine:
@@ -161,9 +167,36 @@ class PolicyEngine:
         self.fin1 = self.conv(m + "final_conv.1.weight", m + "final_conv.1.bias")
 
     def refresh_packs(self):
-        """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable)."""
+        """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable).
+        All forward packs go through ONE multi-tensor launch; only odd-channel layers keep a flipped data-gradient pack."""
+        from ._lib import lib, check
+        if getattr(self, "_mp", None) is None:
+            rows, chunks = [], []
+            ce = lib.v2a_pack_chunk_elems()
+            for c in self._convs.values():
+                w = c.w.detach()
+                if c.kh * c.kw == 1:
+                    c._pf = w
+                    continue
+                if c._pf is None or c._pf.data_ptr() == w.data_ptr():
+                    c._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+                rows.append([w.data_ptr(), c._pf.data_ptr(), c.co, c.ci, c.kh * c.kw])
+                for s0 in range(0, w.numel(), ce):
+                    chunks.append([len(rows) - 1, s0])
+            self._mp = (torch.tensor(rows, dtype=torch.int64).to(self.device), torch.tensor(chunks, dtype=torch.int32).to(self.device),
+                        len(chunks), [c.w.data_ptr() for c in self._convs.values()])
+        tab, ch, n, ptrs = self._mp
+        if ptrs != [c.w.data_ptr() for c in self._convs.values()]:      # parameters were re-allocated (.to(), load): rebuild
+            self._mp = None
+            return self.refresh_packs()
+        check(lib.v2a_pack_weights_multi(tab.data_ptr(), ch.data_ptr(), n, ops._stream()), "pack_weights_multi")
+        bf16 = lib.v2a_get_precision() == 1
         for c in self._convs.values():
-            c.repack()
+            if not c.nmaj or bf16:
+                if c._pd is None:
+                    c._pd = torch.empty(c.w.numel(), dtype=torch.float32, device=self.device)
+                ops.pack_weight(c.w.detach(), 1, c._pd)
+            c._ver = (c.w.data_ptr(), c.w._version)
 
     # ------------------------------------------------------------------ encoder
     def _gn(self, x4, pre, G, act, residual=None, film=None):
@@ -179,7 +212,7 @@ class PolicyEngine:
         d3 = dout4.view(x3.shape)
         dx, dg, db, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                     residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
-                                                    dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"])
+                                                    dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], accumulate_params=True)
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
     def encode_fwd(self, key, img_nchw, save):
@@ -222,13 +255,11 @@ class PolicyEngine:
         cfg = self.cfg
         B = df.shape[0]
         fc, pool = e["fc"], e["pool"]
-        ops.conv2d_wgrad(st["kp"].view(1, 1, B, -1), df.view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname])
-        ops.colsum(df, out=grads[fc.bname])
+        ops.conv2d_wgrad(st["kp"].view(1, 1, B, -1), df.view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname], dbias=grads[fc.bname])
         dkp = _dgrad(df.view(1, 1, B, -1), fc, None, fc.ci, 1, 1, (1, 1), (0, 0)).view(B, -1)
         dkl = ops.spatial_softmax_bwd(st["att"], st["kp"], dkp)
         feat = st["feat"]
-        ops.conv2d_wgrad(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname])
-        ops.colsum(dkl.view(-1, cfg.num_kp), out=grads[pool.bname])
+        ops.conv2d_wgrad(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
         dh = _dgrad(dkl, pool, None, pool.ci, 1, 1)
         for blk, bs in zip(reversed(e["blocks"]), reversed(st["blocks"])):
             s, co, ci = blk["stride"], blk["cout"], blk["cin"]
@@ -293,20 +324,16 @@ class PolicyEngine:
         d4 = dout.view(B, 1, T, co)
         dc1, _, _ = self._gn_bwd(st["s1"], d4, grads)
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
-        ops.conv2d_wgrad(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname])
-        ops.colsum(dc1.view(-1, co), out=grads[c1v.bname])
+        ops.conv2d_wgrad(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname])
         da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2))
         dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
         df2 = dfilm.view(B, 2 * co)
-        ops.conv2d_wgrad(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname])
-        ops.colsum(df2, out=grads[cev.bname])
+        ops.conv2d_wgrad(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
         dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0), residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
-        ops.conv2d_wgrad(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname])
-        ops.colsum(dc0.view(-1, co), out=grads[c0v.bname])
+        ops.conv2d_wgrad(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname])
         rc = r["rc"]
         if rc is not None:
-            ops.conv2d_wgrad(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname])
-            ops.colsum(d4.view(-1, co), out=grads[rc.bname])
+            ops.conv2d_wgrad(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname])
         if not need_dx:
             return None, None, dmgf
         if rc is not None:
@@ -380,12 +407,10 @@ class PolicyEngine:
         f1, f0 = self.fin1, self.fin0
         a, x = save["fin_a"], save["fin_x"]
         d4 = dpred.view(B, 1, T, Da)
-        ops.conv2d_wgrad(a.view(B, 1, T, -1), d4, f1.shape, 1, 1, dw=grads[f1.wname])
-        ops.colsum(dpred.view(-1, Da), out=grads[f1.bname])
+        ops.conv2d_wgrad(a.view(B, 1, T, -1), d4, f1.shape, 1, 1, dw=grads[f1.wname], dbias=grads[f1.bname])
         da = _dgrad(d4, f1, None, f1.ci, 1, 1)
         dc, _, _ = self._gn_bwd(save["fin_s"], da, grads)
-        ops.conv2d_wgrad(x.view(B, 1, T, -1), dc, f0.shape, 1, k, (1, 1), (0, k // 2), dw=grads[f0.wname])
-        ops.colsum(dc.view(-1, f0.co), out=grads[f0.bname])
+        ops.conv2d_wgrad(x.view(B, 1, T, -1), dc, f0.shape, 1, k, (1, 1), (0, k // 2), dw=grads[f0.wname], dbias=grads[f0.bname])
         dx = _dgrad(dc, f0, None, f0.ci, 1, k, (1, 1), (0, k // 2)).view(B, T, f0.ci)
         tape = save["tape"]
         dmgf = None
@@ -410,8 +435,7 @@ class PolicyEngine:
                 Bx, Tx, Cx = xin.shape
                 dy4 = dx.view(Bx, 1, -1, ds.co)
                 x4 = xin.view(Bx, 1, Tx, Cx)
-                ops.conv2d_wgrad(x4, dy4, ds.shape, 1, 3, (1, 2), (0, 1), dw=grads[ds.wname])
-                ops.colsum(dx.view(-1, ds.co), out=grads[ds.bname])
+                ops.conv2d_wgrad(x4, dy4, ds.shape, 1, 3, (1, 2), (0, 1), dw=grads[ds.wname], dbias=grads[ds.bname])
                 skip = pending_skip.pop() if pending_skip else None
                 dx = _dgrad(dy4, ds, None, Cx, 1, 3, (1, 1), (0, 1), idil=2, out_hw=(1, Tx),
                                 residual=None if skip is None else skip.view(Bx, 1, Tx, Cx)).view(Bx, Tx, Cx)
@@ -437,12 +461,10 @@ class PolicyEngine:
         ops.copy2d(dgf, de2, B, cfg.dsed, gf.shape[1], cfg.dsed)
         ops.copy2d(dgf, dgc, B, Gd, gf.shape[1], Gd, src_off=cfg.dsed)
         s3, s1 = self.step3, self.step1
-        ops.conv2d_wgrad(save["m1"].view(1, 1, B, -1), de2.view(1, 1, B, -1), s3.shape, 1, 1, dw=grads[s3.wname])
-        ops.colsum(de2, out=grads[s3.bname])
+        ops.conv2d_wgrad(save["m1"].view(1, 1, B, -1), de2.view(1, 1, B, -1), s3.shape, 1, 1, dw=grads[s3.wname], dbias=grads[s3.bname])
         dm1 = _dgrad(de2.view(1, 1, B, -1), s3, None, s3.ci, 1, 1, (1, 1), (0, 0)).view(B, -1)
         de1 = ops.act_bwd(save["e1"], dm1, "mish")
-        ops.conv2d_wgrad(save["temb"].view(1, 1, B, -1), de1.view(1, 1, B, -1), s1.shape, 1, 1, dw=grads[s1.wname])
-        ops.colsum(de1, out=grads[s1.bname])
+        ops.conv2d_wgrad(save["temb"].view(1, 1, B, -1), de1.view(1, 1, B, -1), s1.shape, 1, 1, dw=grads[s1.wname], dbias=grads[s1.bname])
         return dgc
 
     # ------------------------------------------------------------------ policy level
@@ -482,7 +504,7 @@ class PolicyEngine:
             return loss, None, None
         names = list(names) if names is not None else self.trainable_names()
         if arena is None:
-            arena = torch.empty(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)
+            arena = torch.zeros(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)   # GN param grads accumulate
         grads = self.grad_views(arena, names)
         dgc = self.unet_bwd(dpred, save, grads)
         B = dgc.shape[0]
