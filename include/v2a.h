@@ -97,12 +97,13 @@ int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int
 int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);
 int v2a_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int HW, v2a_stream_t s);
 /* Unet_Libero input pack 'b (f c) h w' + repeated cond image -> [B,f,H,W,6] (flowdiffusion/flowdiffusion/unet.py:217-220) */
-int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride, v2a_stream_t s);
+int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride,
+                   int frame_ch /* 3 RGB (Unet_Libero/MW/Thor/Bridge), 2 flow (UnetMWFlow) */, v2a_stream_t s);
 /* one fused sampler step: v-pred -> x0 (clamp) -> posterior mean + sigma*noise (mode 0, goal_diffusion.py:561-580), DDIM update (mode 1,
  * :617-634), last DDIM pair (mode 2, :619-622); gw > 0 = classifier-free guidance mix (:536-547); final = unnormalize + clamp (:640,:650) */
 int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                            float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
-                           v2a_stream_t s);
+                           int frame_ch, v2a_stream_t s);
 /* counter-based Philox4x32-10 generators (replace torch.randn / torch.randint of compute_loss :246-252 in perf runs) */
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);

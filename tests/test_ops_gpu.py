@@ -331,3 +331,23 @@ def test_bf16_wgrad_matches_bf16_rounded_reference():
             v2a_hip.set_precision(old)
         close(dw, w.grad, tol=2e-5, what="bf16 wgrad (inputs exactly representable in bf16)")
         close(db, b.grad, tol=2e-5, what="fused bias grad")
+
+
+def test_groupnorm_large_path_odd_group_width():
+    """cg % 4 != 0 on the HBM-bound path (UnetBridge: 160 channels / 32 groups = 5): float4 columns straddle groups."""
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(4)
+    N, S, C, G = 2, 9000, 160, 32
+    x = (torch.randn(N, C, S, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    a = F.silu(F.group_norm(x, G, gamma, beta, eps=1e-5))
+    dout = torch.randn(a.shape, generator=g)
+    a.backward(dout)
+    cl = lambda t: t.detach().permute(0, 2, 1).contiguous().to(dev())
+    y, mean, rstd = ops.groupnorm_fwd(cl(x), gamma.detach().to(dev()), beta.detach().to(dev()), G, "silu")
+    close(y.permute(0, 2, 1), a, what="gn fwd cg=5")
+    dx, dg, db, _, _ = ops.groupnorm_bwd(cl(x), gamma.detach().to(dev()), beta.detach().to(dev()), G, cl(dout), mean, rstd, "silu")
+    close(dx.permute(0, 2, 1), x.grad, what="gn dx cg=5")
+    close(dg, gamma.grad, what="gn dgamma cg=5")
+    close(db, beta.grad, what="gn dbeta cg=5")

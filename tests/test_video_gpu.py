@@ -81,3 +81,32 @@ def test_cpu_unet_raises():
     from flowdiffusion.flowdiffusion.unet import Unet_Tiny
     with pytest.raises(RuntimeError):
         Unet_Tiny()(torch.zeros(1, 12, 32, 32), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 512))
+
+
+@pytest.mark.parametrize("cls_name,ci,res,frames", [("UnetThor", 3, 16, 2), ("UnetMWFlow", 2, 32, 2), ("UnetBridge", 3, 16, 2)])
+def test_other_unet_wrappers_vs_oracle(cls_name, ci, res, frames):
+    """the other AVDC wrappers (same kernels, other hyper-parameters; UnetBridge has 160 base channels -> GroupNorm
+    groups of 5/10/20 channels, UnetMWFlow packs 2 flow channels per frame) against the CPU oracle with the same parameters."""
+    import flowdiffusion.flowdiffusion.unet as U
+    from oracle.param_fill import fill_module
+    from oracle.video_unet import UNetCfg, unet_forward
+    torch.manual_seed(0)
+    m = getattr(U, cls_name)()
+    sd = fill_module(m, seed=21)
+    cfgm = m.unet
+    cfg = UNetCfg(in_channels=cfgm.in_channels, model_channels=cfgm.model_channels, out_channels=cfgm.out_channels,
+                  num_res_blocks=cfgm.num_res_blocks, attention_resolutions=cfgm.attention_resolutions, channel_mult=cfgm.channel_mult,
+                  num_head_channels=32)
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 1, res, res
+    x = torch.randn(B, frames * ci + 3, H, W, generator=g)
+    t = torch.tensor([17])
+    te = torch.randn(B, 4, 512, generator=g)
+    y = m.to("cuda:0").eval()(x.cuda(), t.cuda(), te.cuda()).cpu()
+    # oracle: the reference's own pack (unet.py:28-35 / :87-92) then UNetModel.forward
+    cond = x[:, -3:, None].expand(B, 3, frames, H, W)
+    xx = x[:, :-3].reshape(B, frames, ci, H, W).permute(0, 2, 1, 3, 4)
+    with torch.no_grad():
+        yo = unet_forward(sd, torch.cat([xx, cond], 1), t, te, cfg, pre="unet.")
+    yo = yo.permute(0, 2, 1, 3, 4).reshape(B, frames * cfgm.out_channels, H, W)
+    assert rel(y, yo) <= TOL, rel(y, yo)

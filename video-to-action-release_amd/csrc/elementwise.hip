@@ -151,18 +151,19 @@ __global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int N, int C, 
 // ----------------------------------------------------------------------------------------- video sampler glue
 // Unet_Libero input pack (reference unet.py:217-220): img [B, 3f, H, W] ('b (f c) h w'), x_cond [B,3,H,W]
 //   -> xin [B, f, H, W, 6] channels-last (3 noisy + 3 cond, cond repeated over frames)
-__global__ void video_pack_kernel(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bs, size_t cond_bs) {
-    const size_t total = (size_t)B * f * HW * 6;
+__global__ void video_pack_kernel(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bs, size_t cond_bs, int ci) {
+    const int CT = ci + 3;                                  // ci channels per generated frame (3 RGB, 2 flow) + the RGB conditioning image
+    const size_t total = (size_t)B * f * HW * CT;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % 6);
-        size_t t = i / 6;
+        const int c = (int)(i % CT);
+        size_t t = i / CT;
         const int hw = (int)(t % HW);
         t /= HW;
         const int fr = (int)(t % f);
         const int b = (int)(t / f);
         float v;
-        if (c < 3) v = img[(size_t)b * img_bs + ((size_t)fr * 3 + c) * HW + hw];
-        else v = cond[(size_t)b * cond_bs + (size_t)(c - 3) * HW + hw];
+        if (c < ci) v = img[(size_t)b * img_bs + ((size_t)fr * ci + c) * HW + hw];
+        else v = cond[(size_t)b * cond_bs + (size_t)(c - ci) * HW + hw];
         xin[i] = v;
     }
 }
@@ -175,16 +176,16 @@ __global__ void video_pack_kernel(const float* img, const float* cond, float* xi
 // final=1 additionally applies unnormalize + clamp: out = clamp((out+1)/2, 0, 1)   (:640, :650)
 struct DenoiseCoef { float sa, s1, ra, rm, c1, c2, sigma, gw; };
 __global__ void video_denoise_kernel(const float* v, const float* v_u, const float* img, const float* noise, float* out,
-                                     int B, int f, int HW, DenoiseCoef k, int mode, int final) {
-    const size_t total = (size_t)B * f * 3 * HW;
+                                     int B, int f, int HW, DenoiseCoef k, int mode, int final, int ci) {
+    const size_t total = (size_t)B * f * ci * HW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int hw = (int)(i % HW);
         size_t t = i / HW;
-        const int c = (int)(t % 3);
-        t /= 3;
+        const int c = (int)(t % ci);
+        t /= ci;
         const int fr = (int)(t % f);
         const int b = (int)(t / f);
-        const size_t vi = ((((size_t)b * f + fr) * HW) + hw) * 3 + c;
+        const size_t vi = ((((size_t)b * f + fr) * HW) + hw) * ci + c;
         const float x = img[i];
         float x0, eps;
         if (k.gw > 0.f) {
@@ -334,16 +335,16 @@ int v2a_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int HW, hip
     return V2A_OK;
 }
 // img_bstride / cond_bstride: elements between consecutive batch items (lets both be slices of one [B,(f+1)*3,H,W] tensor)
-int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride, hipStream_t s) {
-    hipLaunchKernelGGL(video_pack_kernel, GRID_FOR((size_t)B * f * HW * 6), dim3(256), 0, s, img, cond, xin, B, f, HW, img_bstride, cond_bstride);
+int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride, int frame_ch, hipStream_t s) {
+    hipLaunchKernelGGL(video_pack_kernel, GRID_FOR((size_t)B * f * HW * (frame_ch + 3)), dim3(256), 0, s, img, cond, xin, B, f, HW, img_bstride, cond_bstride, frame_ch);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                            float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
-                           hipStream_t s) {
+                           int frame_ch, hipStream_t s) {
     DenoiseCoef k = {sa, s1, ra, rm, c1, c2, sigma, gw};
-    hipLaunchKernelGGL(video_denoise_kernel, GRID_FOR((size_t)B * f * 3 * HW), dim3(256), 0, s, v, v_uncond, img, noise, out, B, f, HW, k, mode, final);
+    hipLaunchKernelGGL(video_denoise_kernel, GRID_FOR((size_t)B * f * frame_ch * HW), dim3(256), 0, s, v, v_uncond, img, noise, out, B, f, HW, k, mode, final, frame_ch);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

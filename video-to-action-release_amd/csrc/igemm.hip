@@ -73,7 +73,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + slot;
 }
 
-template <int BM, int BN, int BKT, bool VEC, bool BNMAJ>
+template <int BM, int BN, int BKT, bool VEC, bool BNMAJ, int PF>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int KC = BKT / 4;                 // float4 chunks per tile row
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
         a_iwb[i] = ow * p.sw - p.pw;
     }
 
-    f32x4 ra[AL], rb[BNMAJ ? NBL : BL];
+    // PF register stages: tile t+1 .. t+PF are in flight while tile t is multiplied (weight-streaming layers with a handful of
+    // k-tiles per block are bound by the HBM latency of ONE outstanding tile otherwise)
+    f32x4 ra[PF][AL], rb[PF][BNMAJ ? NBL : BL];
 
     auto pix_of = [&](int i, int kh, int kw, bool& ok) -> size_t {
         int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
         return ((size_t)a_img[i] * p.H + ih) * p.W + iw;
     };
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, f32x4* ra, f32x4* rb) {
         const int k0 = kt * BKT;
         if (VEC) {
             const int tap = k0 / Cin;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4* ra, const f32x4* rb) {
 #pragma unroll
         for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[buf][(lrow + i * RPP) * LDR + chunk * 4]) = ra[i];
         if (BNMAJ) {
@@ -228,44 +230,52 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
     const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
     const int lr = lane & 31, lk = lane >> 5;
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
+    // prologue: tiles kt_begin .. kt_begin+PF-1 into the register stages, the first one on to LDS
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+        if (kt_begin + d < kt_end) load_tile(kt_begin + d, ra[d], rb[d]);
+    if (kt_begin < kt_end) store_tile(0, ra[0], rb[0]);
     __syncthreads();
     int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1) < kt_end;
-        // one ds_read_b128 per operand tile feeds FOUR MFMA k-steps: in step (h, q) the lanes with lk = 0 supply k = 8h + q and
-        // the lanes with lk = 1 supply k = 8h + 4 + q, for A and B alike (the k-order of an exact-f32 sum is free to choose).
-        // The next tile's address arithmetic + global loads are issued after the first MFMA batch so that they execute under
-        // the matrix pipe instead of in front of it (right after the barrier every wave would otherwise do VALU work first).
+    for (int kt0 = kt_begin; kt0 < kt_end; kt0 += PF) {
 #pragma unroll
-        for (int h = 0; h < BKT / 8; ++h) {
-            if (h == 1 && more) load_tile(kt + 1);
-            f32x4 a[TM], b[TN];
+        for (int d = 0; d < PF; ++d) {
+            const int kt = kt0 + d;
+            if (kt < kt_end) {
+                const bool more = (kt + 1) < kt_end;
+                const bool refill = (kt + PF) < kt_end;       // stage d is free again: fetch tile kt + PF into it
+                // one ds_read_b128 per operand tile feeds FOUR MFMA k-steps: in step (h, q) the lanes with lk = 0 supply k = 8h + q
+                // and the lanes with lk = 1 supply k = 8h + 4 + q, for A and B alike (the k-order of an exact-f32 sum is free).
+                // The refill's address arithmetic + global loads are issued after the first MFMA batch so they run under the
+                // matrix pipe instead of in front of it.
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wm + i * 32 + lr) * LDR + 8 * h + 4 * lk]);
+                for (int h = 0; h < BKT / 8; ++h) {
+                    if (h == 1 && refill) load_tile(kt + PF, ra[d], rb[d]);
+                    f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (BNMAJ) {
+                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wm + i * 32 + lr) * LDR + 8 * h + 4 * lk]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) b[j][q] = Bs[buf][(8 * h + 4 * lk + q) * (BN + LDS_PAD) + wn + j * 32 + lr];
-                } else {
-                    b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn + j * 32 + lr) * LDR + 8 * h + 4 * lk]);
+                    for (int j = 0; j < TN; ++j) {
+                        if (BNMAJ) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) b[j][q] = Bs[buf][(8 * h + 4 * lk + q) * (BN + LDS_PAD) + wn + j * 32 + lr];
+                        } else {
+                            b[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn + j * 32 + lr) * LDR + 8 * h + 4 * lk]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
                 }
+                if (more) store_tile(buf ^ 1, ra[(d + 1) % PF], rb[(d + 1) % PF]);
+                __syncthreads();
+                buf ^= 1;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -963,17 +973,17 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
         }
         return V2A_OK;
     }
-#define LAUNCH(BM_, BN_)                                                                                              \
-    do {                                                                                                              \
-        if (p.bmode && k32) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 32, true, true>), grid, block, 0, stream, p);  \
-        else if (p.bmode) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, true, true>), grid, block, 0, stream, p);    \
-        else if (k32) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 32, true, false>), grid, block, 0, stream, p);       \
-        else if (vec) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, true, false>), grid, block, 0, stream, p);       \
-        else hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, false, false>), grid, block, 0, stream, p);               \
+#define LAUNCH(BM_, BN_, PF_)                                                                                              \
+    do {                                                                                                                   \
+        if (p.bmode && k32) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 32, true, true, PF_>), grid, block, 0, stream, p);  \
+        else if (p.bmode) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, true, true, PF_>), grid, block, 0, stream, p);    \
+        else if (k32) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 32, true, false, PF_>), grid, block, 0, stream, p);       \
+        else if (vec) hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, true, false, PF_>), grid, block, 0, stream, p);       \
+        else hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 16, false, false, 1>), grid, block, 0, stream, p);                 \
     } while (0)
-    if (bm == 128 && bn == 128) LAUNCH(128, 128);
-    else if (bm == 128) LAUNCH(128, 64);
-    else LAUNCH(64, 64);
+    if (bm == 128 && bn == 128) LAUNCH(128, 128, 1);
+    else if (bm == 128) LAUNCH(128, 64, 2);
+    else LAUNCH(64, 64, 3);
 #undef LAUNCH
     V2A_CHECK_LAUNCH();
     if (s > 1) {

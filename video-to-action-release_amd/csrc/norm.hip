@@ -64,13 +64,16 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
         src += first ? cc : (cc - C1);
         const int ld = first ? C1 : C2;
         float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-        float mu = 0.f, rs = 0.f, gm[4] = {0, 0, 0, 0}, bt[4] = {0, 0, 0, 0};
+        float mu[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, gm[4] = {0, 0, 0, 0}, bt[4] = {0, 0, 0, 0};
         if (MODE) {
-            const int g = cc / cg;
-            mu = p.mean[n * p.G + g];
-            rs = p.rstd[n * p.G + g];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { gm[j] = p.gamma[cc + j]; bt[j] = p.beta[cc + j]; }
+            for (int j = 0; j < 4; ++j) {
+                const int g = (cc + j) / cg;          // per element: a float4 may straddle two groups when cg % 4 != 0
+                mu[j] = p.mean[n * p.G + g];
+                rs[j] = p.rstd[n * p.G + g];
+                gm[j] = p.gamma[cc + j];
+                bt[j] = p.beta[cc + j];
+            }
         }
 // (manual prefetch below)
         for (int r = row0; r < nrows; r += rpi) {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
                 if (rptr) rr = *reinterpret_cast<const f32x4*>(rptr + (size_t)r * C + cc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xh = (v[j] - mu) * rs;
+                    const float xh = (v[j] - mu[j]) * rs[j];
                     const float z = xh * gm[j] + bt[j] + rr[j];
                     const float dz = d[j] * act_bwd(z, p.act);
                     a0[j] += dz;
@@ -150,8 +153,6 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int n = (int)(i / per_n);
         const int c4 = (int)(i % L4);
-        const int g = (c4 * 4) / cg;
-        const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
         f32x4 v;
         if (p.x2) {
             const size_t row = i / L4;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c4 * 4 + j;
-            float z = (v[j] - mu) * rs * p.gamma[c] + p.beta[c] + r[j];
+            const int g = c / cg;
+            float z = (v[j] - p.mean[n * p.G + g]) * p.rstd[n * p.G + g] * p.gamma[c] + p.beta[c] + r[j];
             float a = act_fwd(z, p.act);
             if (p.film) a = p.film[(size_t)n * 2 * C + c] * a + p.film[(size_t)n * 2 * C + C + c];
             o[j] = a;
@@ -189,18 +191,25 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int n = (int)(i / per_n);
         const int c4 = (int)(i % L4);
-        const int g = (c4 * 4) / cg;
-        const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
-        float A1 = 0.f, A2 = 0.f;
         const float* cs = p.colsum + (size_t)n * 2 * C;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) { A1 += p.gamma[c] * cs[c]; A2 += p.gamma[c] * cs[C + c]; }
         f32x4 v = x4[i], d = d4[i];
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (r4) r = r4[i];
         f32x4 o, dzv;
+        int gprev = -1;
+        float A1 = 0.f, A2 = 0.f, mu = 0.f, rs = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c4 * 4 + j;
+            const int g = c / cg;
+            if (g != gprev) {            // (re)compute the group sums only when the float4 crosses into another group
+                gprev = g;
+                mu = p.mean[n * p.G + g];
+                rs = p.rstd[n * p.G + g];
+                A1 = 0.f;
+                A2 = 0.f;
+                for (int cc = g * cg; cc < (g + 1) * cg; ++cc) { A1 += p.gamma[cc] * cs[cc]; A2 += p.gamma[cc] * cs[C + cc]; }
+            }
             const float xh = (v[j] - mu) * rs;
             const float z = xh * p.gamma[c] + p.beta[c] + r[j];
             const float dz = d[j] * act_bwd(z, p.act);
@@ -376,7 +385,7 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
         V2A_CHECK_LAUNCH();
         return V2A_OK;
     }
-    if (C % 4 != 0 || cg % 4 != 0) return V2A_ERR_ARG;
+    if (C % 4 != 0) return V2A_ERR_ARG;
     gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
     if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.partial = (double*)workspace;
@@ -415,7 +424,7 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
         V2A_CHECK_LAUNCH();
     } else {
         if (film || dfilm) return V2A_ERR_ARG;   // FiLM only occurs on the small (Conv1d) path
-        if (C % 4 != 0 || cg % 4 != 0) return V2A_ERR_ARG;
+        if (C % 4 != 0) return V2A_ERR_ARG;
         gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
         if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
         p.partial = (double*)workspace;

@@ -142,7 +142,8 @@ class GoalGaussianDiffusion(nn.Module):
         if device.type != "cuda":
             raise RuntimeError("GoalGaussianDiffusion.sample runs on a HIP device only (no CPU fallback)")
         B, C, H, W = shape
-        f = C // 3
+        ci = getattr(self.model, "frame_channels", 3)
+        f = C // ci
         T = self._tables_host()
         eng = self.model._engine()
         x_cond = x_cond.to(device).float().contiguous()
@@ -154,7 +155,7 @@ class GoalGaussianDiffusion(nn.Module):
         imgs = [img]
 
         def unet(img_t, t_int, lab):
-            xin = ops.video_pack2(img_t, x_cond, f, H, W)
+            xin = ops.video_pack2(img_t, x_cond, f, H, W, ci)
             tt = torch.full((B,), t_int, dtype=torch.long, device=device)
             return eng.forward_cl(xin, tt, lab)
 
@@ -168,7 +169,7 @@ class GoalGaussianDiffusion(nn.Module):
                 coef = (T["sqrt_alphas_cumprod"][t], T["sqrt_one_minus_alphas_cumprod"][t], T["sqrt_recip_alphas_cumprod"][t],
                         T["sqrt_recipm1_alphas_cumprod"][t], T["posterior_mean_coef1"][t], T["posterior_mean_coef2"][t], sigma, gw)
                 last = (i == len(steps) - 1) and not return_all_timesteps
-                img = ops.video_denoise_step(v, vu, img, noise, coef, 0, last, f, H * W)
+                img = ops.video_denoise_step(v, vu, img, noise, coef, 0, last, f, H * W, ci)
                 imgs.append(img)
         else:
             times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)
@@ -182,14 +183,14 @@ class GoalGaussianDiffusion(nn.Module):
                         T["sqrt_recipm1_alphas_cumprod"][t])
                 last = (i == len(pairs) - 1) and not return_all_timesteps
                 if tn < 0:
-                    img = ops.video_denoise_step(v, vu, img, None, base + (0.0, 0.0, 0.0, gw), 2, last, f, H * W)
+                    img = ops.video_denoise_step(v, vu, img, None, base + (0.0, 0.0, 0.0, gw), 2, last, f, H * W, ci)
                 else:
                     a, an = T["alphas_cumprod"][t], T["alphas_cumprod"][tn]
                     sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
                     c = (1 - an - sigma ** 2).sqrt()
                     noise = self._noise(shape, device)                      # drawn even when eta = 0 (RNG stream parity)
                     img = ops.video_denoise_step(v, vu, img, noise if float(sigma) != 0.0 else None,
-                                                 base + (float(an.sqrt()), float(c), float(sigma), gw), 1, last, f, H * W)
+                                                 base + (float(an.sqrt()), float(c), float(sigma), gw), 1, last, f, H * W, ci)
                 imgs.append(img)
         if return_all_timesteps:
             ret = torch.stack(imgs, dim=1)

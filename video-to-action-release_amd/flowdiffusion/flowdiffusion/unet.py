@@ -26,11 +26,13 @@ class _HipUnetWrapper(nn.Module):
             new.__dict__[k] = None if k == "_eng" else copy.deepcopy(v, memo)
         return new
 
+    frame_channels = 3          # channels of one generated frame in the packed input/output (2 for optical-flow models)
+
     @torch.no_grad()
     def forward(self, x, t, task_embed=None, **kwargs):
         assert task_embed is not None, "must specify y if and only if the model is class-conditional"
         label = kwargs.pop("_label_emb", None)
-        return self._engine().forward_libero(x, t, task_embed, label_emb=label)
+        return self._engine().forward_libero(x, t, task_embed, label_emb=label, frame_ch=self.frame_channels)
 
 
 class Unet_Libero(_HipUnetWrapper):
@@ -40,6 +42,51 @@ class Unet_Libero(_HipUnetWrapper):
                               attention_resolutions=(8, 16), dropout=0, channel_mult=(1, 2, 3, 4, 5), conv_resample=True, dims=3,
                               num_classes=None, task_tokens=True, task_token_channels=512, use_checkpoint=False, use_fp16=False,
                               num_head_channels=32)
+
+
+def _avdc(image_size, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(8, 16),
+          channel_mult=(1, 2, 3, 4, 5)):
+    return UNetModel(image_size=image_size, in_channels=in_channels, model_channels=model_channels, out_channels=out_channels,
+                     num_res_blocks=num_res_blocks, attention_resolutions=attention_resolutions, dropout=0, channel_mult=channel_mult,
+                     conv_resample=True, dims=3, num_classes=None, task_tokens=True, task_token_channels=512, use_checkpoint=False,
+                     use_fp16=False, num_head_channels=32)
+
+
+class UnetMW(_HipUnetWrapper):
+    """MetaWorld checkpoint shape (reference unet.py:37-64): same hyper-parameters as Unet_Libero."""
+
+    def __init__(self):
+        super().__init__()
+        self.unet = _avdc((128, 128))
+
+
+class UnetThor_Luo(UnetMW):
+    """reference unet.py:163-192"""
+
+
+class UnetMWFlow(_HipUnetWrapper):
+    """Optical-flow variant (reference unet.py:66-93): 2 flow channels per frame + the RGB conditioning image."""
+    frame_channels = 2
+
+    def __init__(self):
+        super().__init__()
+        self.unet = _avdc((128, 128), in_channels=5, out_channels=2)
+
+
+class UnetThor(_HipUnetWrapper):
+    """iTHOR checkpoint shape (reference unet.py:122-152): 64x64, 3 res-blocks, channel_mult (1,2,4), attention at 4/8."""
+
+    def __init__(self):
+        super().__init__()
+        self.unet = _avdc((64, 64), num_res_blocks=3, attention_resolutions=(4, 8), channel_mult=(1, 2, 4))
+
+
+class UnetBridge(_HipUnetWrapper):
+    """Bridge checkpoint shape (reference unet.py:7-35): 48x64, 160 base channels, 3 res-blocks, channel_mult (1,2,4)."""
+
+    def __init__(self):
+        super().__init__()
+        self.unet = _avdc((48, 64), model_channels=160, num_res_blocks=3, attention_resolutions=(4, 8), channel_mult=(1, 2, 4))
 
 
 class Unet_Tiny(_HipUnetWrapper):

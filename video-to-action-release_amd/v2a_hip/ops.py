@@ -10,6 +10,21 @@ from ._lib import lib, check
 ACT = {"none": 0, "silu": 1, "relu": 2, "mish": 3, "gelu": 4}
 
 _ws = {}
+_lane = [0]
+
+
+class ws_lane:
+    """Context manager: kernels launched inside use scratch buffer `lane` (concurrent streams must not share split-K slabs)."""
+
+    def __init__(self, lane):
+        self.lane = lane
+
+    def __enter__(self):
+        self.prev = _lane[0]
+        _lane[0] = self.lane
+
+    def __exit__(self, *a):
+        _lane[0] = self.prev
 
 
 def _stream():
@@ -23,12 +38,13 @@ def _p(t):
 def workspace(nbytes: int, device=None) -> torch.Tensor:
     """Grow-only scratch buffer per device (not resized during graph capture: call reserve_workspace first)."""
     device = torch.device(device if device is not None else torch.cuda.current_device())
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _lane[0])          # one scratch buffer per (device, lane): a side-stream launch sequence sets lane 1 (see ws_lane)
     cur = _ws.get(key)
     if cur is None or cur.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("v2a workspace would grow during graph capture; call ops.reserve_workspace() first")
-        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{key}")
+            raise RuntimeError("v2a workspace would grow during graph capture; run one eager step first")
+        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{idx}")
         _ws[key] = cur
     return cur
 
@@ -319,30 +335,30 @@ def scale_by_device_scalar(x, scalar):
     return x
 
 
-def video_pack(x_full, f, H, W):
-    """x_full [B,(f+1)*3,H,W] (noisy frames 'b (f c) h w' then the conditioning image) -> [B,f,H,W,6] channels-last."""
+def video_pack(x_full, f, H, W, ci=3):
+    """x_full [B, f*ci + 3, H, W] (generated frames 'b (f c) h w' then the RGB conditioning image) -> [B,f,H,W,ci+3] channels-last."""
     _chk(x_full, "x")
     B = x_full.shape[0]
     HW = H * W
-    out = torch.empty((B, f, H, W, 6), dtype=torch.float32, device=x_full.device)
-    bs = (f + 1) * 3 * HW
-    check(lib.v2a_video_pack(x_full.data_ptr(), x_full.data_ptr() + 4 * f * 3 * HW, out.data_ptr(), B, f, HW, bs, bs, _stream()), "video_pack")
+    out = torch.empty((B, f, H, W, ci + 3), dtype=torch.float32, device=x_full.device)
+    bs = (f * ci + 3) * HW
+    check(lib.v2a_video_pack(x_full.data_ptr(), x_full.data_ptr() + 4 * f * ci * HW, out.data_ptr(), B, f, HW, bs, bs, ci, _stream()), "video_pack")
     return out
 
 
-def video_pack2(img, cond, f, H, W):
-    """img [B,3f,H,W], cond [B,3,H,W] (separate tensors) -> [B,f,H,W,6]."""
+def video_pack2(img, cond, f, H, W, ci=3):
+    """img [B,ci*f,H,W], cond [B,3,H,W] (separate tensors) -> [B,f,H,W,ci+3]."""
     B = img.shape[0]
     HW = H * W
-    out = torch.empty((B, f, H, W, 6), dtype=torch.float32, device=img.device)
-    check(lib.v2a_video_pack(img.data_ptr(), cond.data_ptr(), out.data_ptr(), B, f, HW, 3 * f * HW, 3 * HW, _stream()), "video_pack")
+    out = torch.empty((B, f, H, W, ci + 3), dtype=torch.float32, device=img.device)
+    check(lib.v2a_video_pack(img.data_ptr(), cond.data_ptr(), out.data_ptr(), B, f, HW, ci * f * HW, 3 * HW, ci, _stream()), "video_pack")
     return out
 
 
-def video_denoise_step(v, v_uncond, img, noise, coef, mode, final, f, HW):
+def video_denoise_step(v, v_uncond, img, noise, coef, mode, final, f, HW, ci=3):
     """coef = (sa, s1, ra, rm, c1, c2, sigma, gw); see csrc/elementwise.hip video_denoise_kernel."""
     out = torch.empty_like(img)
     B = img.shape[0]
     check(lib.v2a_video_denoise_step(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, *[float(c) for c in coef],
-                                     mode, 1 if final else 0, _stream()), "video_denoise_step")
+                                     mode, 1 if final else 0, ci, _stream()), "video_denoise_step")
     return out

@@ -104,6 +104,10 @@ class PolicyEngine:
         self.ac_host = squaredcos_alphas_cumprod(cfg.num_train_timesteps)
         self.ac = self.ac_host.to(self.device)
         self._convs = {}
+        import os as _os
+        self.async_wgrad = _os.environ.get("V2A_ASYNC_WGRAD", "1") != "0"
+        self._side = None
+        self._keep = []
         self._build()
 
     # ------------------------------------------------------------------ structure
@@ -165,6 +169,25 @@ class PolicyEngine:
                                 us=self.conv(f"{m}up_modules.{i}.2.conv.weight", f"{m}up_modules.{i}.2.conv.bias", transposed=True)))
         self.fin0 = self.conv(m + "final_conv.0.block.0.weight", m + "final_conv.0.block.0.bias")
         self.fin1 = self.conv(m + "final_conv.1.weight", m + "final_conv.1.bias")
+
+    # ------------------------------------------------------------------ weight gradients off the critical path
+    def _wg(self, *a, **k):
+        """Weight gradients feed nothing until the optimiser: launch them on a side stream so they fill the CUs the latency-bound
+        data-gradient chain leaves idle (captured as a parallel branch of the hipGraph).  Operands are kept alive until the join."""
+        if not self.async_wgrad:
+            return ops.conv2d_wgrad(*a, **k)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        self._keep.append((a, k))
+        with torch.cuda.stream(self._side), ops.ws_lane(1):
+            ops.conv2d_wgrad(*a, **k)
+
+    def _join_side(self):
+        if self._side is not None and self._keep:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._keep = []
 
     def refresh_packs(self):
         """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable).
@@ -255,31 +278,31 @@ class PolicyEngine:
         cfg = self.cfg
         B = df.shape[0]
         fc, pool = e["fc"], e["pool"]
-        ops.conv2d_wgrad(st["kp"].view(1, 1, B, -1), df.view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname], dbias=grads[fc.bname])
+        self._wg(st["kp"].view(1, 1, B, -1), df.view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname], dbias=grads[fc.bname])
         dkp = _dgrad(df.view(1, 1, B, -1), fc, None, fc.ci, 1, 1, (1, 1), (0, 0)).view(B, -1)
         dkl = ops.spatial_softmax_bwd(st["att"], st["kp"], dkp)
         feat = st["feat"]
-        ops.conv2d_wgrad(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
+        self._wg(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
         dh = _dgrad(dkl, pool, None, pool.ci, 1, 1)
         for blk, bs in zip(reversed(e["blocks"]), reversed(st["blocks"])):
             s, co, ci = blk["stride"], blk["cout"], blk["cin"]
             inp = bs["inp"]
             do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True)
-            ops.conv2d_wgrad(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
+            self._wg(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
             da = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1))
             do1, _, _ = self._gn_bwd(bs["s1"], da, grads)
-            ops.conv2d_wgrad(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname])
+            self._wg(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname])
             ih, iw = inp.shape[1], inp.shape[2]
             if blk["down"] is not None:
                 didn_raw, _, _ = self._gn_bwd(bs["sd"], didn, grads)
-                ops.conv2d_wgrad(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname])
+                self._wg(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname])
                 d1 = _dgrad(didn_raw, blk["down"], None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw))
                 dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1)
             else:
                 dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn)
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
-        ops.conv2d_wgrad(st["x0"], dc1, e["conv1"].shape, 7, 7, (2, 2), (3, 3), dw=grads[e["conv1"].wname])
+        self._wg(st["x0"], dc1, e["conv1"].shape, 7, 7, (2, 2), (3, 3), dw=grads[e["conv1"].wname])
 
     # ------------------------------------------------------------------ ConditionalUnet1D
     def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None):
@@ -324,16 +347,16 @@ class PolicyEngine:
         d4 = dout.view(B, 1, T, co)
         dc1, _, _ = self._gn_bwd(st["s1"], d4, grads)
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
-        ops.conv2d_wgrad(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname])
+        self._wg(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname])
         da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2))
         dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
         df2 = dfilm.view(B, 2 * co)
-        ops.conv2d_wgrad(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
+        self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
         dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0), residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
-        ops.conv2d_wgrad(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname])
+        self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname])
         rc = r["rc"]
         if rc is not None:
-            ops.conv2d_wgrad(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname])
+            self._wg(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname])
         if not need_dx:
             return None, None, dmgf
         if rc is not None:
@@ -407,10 +430,10 @@ class PolicyEngine:
         f1, f0 = self.fin1, self.fin0
         a, x = save["fin_a"], save["fin_x"]
         d4 = dpred.view(B, 1, T, Da)
-        ops.conv2d_wgrad(a.view(B, 1, T, -1), d4, f1.shape, 1, 1, dw=grads[f1.wname], dbias=grads[f1.bname])
+        self._wg(a.view(B, 1, T, -1), d4, f1.shape, 1, 1, dw=grads[f1.wname], dbias=grads[f1.bname])
         da = _dgrad(d4, f1, None, f1.ci, 1, 1)
         dc, _, _ = self._gn_bwd(save["fin_s"], da, grads)
-        ops.conv2d_wgrad(x.view(B, 1, T, -1), dc, f0.shape, 1, k, (1, 1), (0, k // 2), dw=grads[f0.wname], dbias=grads[f0.bname])
+        self._wg(x.view(B, 1, T, -1), dc, f0.shape, 1, k, (1, 1), (0, k // 2), dw=grads[f0.wname], dbias=grads[f0.bname])
         dx = _dgrad(dc, f0, None, f0.ci, 1, k, (1, 1), (0, k // 2)).view(B, T, f0.ci)
         tape = save["tape"]
         dmgf = None
@@ -427,7 +450,7 @@ class PolicyEngine:
                 Bx, Tx, Cx = xin.shape
                 dy4 = dx.view(Bx, 1, 2 * Tx, us.ci)
                 x4 = xin.view(Bx, 1, Tx, Cx)
-                ops.conv2d_wgrad(dy4, x4, us.shape, 1, 4, (1, 2), (0, 1), dw=grads[us.wname])
+                self._wg(dy4, x4, us.shape, 1, 4, (1, 2), (0, 1), dw=grads[us.wname])
                 ops.colsum(dx.view(-1, us.ci), out=grads[us.bname])
                 dx = ops.conv2d(dy4, us.pf(), None, Cx, 1, 4, (1, 2), (0, 1)).view(Bx, Tx, Cx)
             elif "ds" in e:
@@ -435,7 +458,7 @@ class PolicyEngine:
                 Bx, Tx, Cx = xin.shape
                 dy4 = dx.view(Bx, 1, -1, ds.co)
                 x4 = xin.view(Bx, 1, Tx, Cx)
-                ops.conv2d_wgrad(x4, dy4, ds.shape, 1, 3, (1, 2), (0, 1), dw=grads[ds.wname], dbias=grads[ds.bname])
+                self._wg(x4, dy4, ds.shape, 1, 3, (1, 2), (0, 1), dw=grads[ds.wname], dbias=grads[ds.bname])
                 skip = pending_skip.pop() if pending_skip else None
                 dx = _dgrad(dy4, ds, None, Cx, 1, 3, (1, 1), (0, 1), idil=2, out_hw=(1, Tx),
                                 residual=None if skip is None else skip.view(Bx, 1, Tx, Cx)).view(Bx, Tx, Cx)
@@ -461,10 +484,10 @@ class PolicyEngine:
         ops.copy2d(dgf, de2, B, cfg.dsed, gf.shape[1], cfg.dsed)
         ops.copy2d(dgf, dgc, B, Gd, gf.shape[1], Gd, src_off=cfg.dsed)
         s3, s1 = self.step3, self.step1
-        ops.conv2d_wgrad(save["m1"].view(1, 1, B, -1), de2.view(1, 1, B, -1), s3.shape, 1, 1, dw=grads[s3.wname], dbias=grads[s3.bname])
+        self._wg(save["m1"].view(1, 1, B, -1), de2.view(1, 1, B, -1), s3.shape, 1, 1, dw=grads[s3.wname], dbias=grads[s3.bname])
         dm1 = _dgrad(de2.view(1, 1, B, -1), s3, None, s3.ci, 1, 1, (1, 1), (0, 0)).view(B, -1)
         de1 = ops.act_bwd(save["e1"], dm1, "mish")
-        ops.conv2d_wgrad(save["temb"].view(1, 1, B, -1), de1.view(1, 1, B, -1), s1.shape, 1, 1, dw=grads[s1.wname], dbias=grads[s1.bname])
+        self._wg(save["temb"].view(1, 1, B, -1), de1.view(1, 1, B, -1), s1.shape, 1, 1, dw=grads[s1.wname], dbias=grads[s1.bname])
         return dgc
 
     # ------------------------------------------------------------------ policy level
@@ -514,6 +537,7 @@ class PolicyEngine:
             df = torch.empty((B, fd), dtype=torch.float32, device=dgc.device)
             ops.copy2d(dgc, df, B, fd, fd * nk, fd, src_off=i * fd)
             self.encode_bwd(key, df, save_enc[key], grads)
+        self._join_side()
         return loss, grads, arena
 
     def trainable_names(self):

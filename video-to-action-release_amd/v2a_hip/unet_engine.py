@@ -249,11 +249,12 @@ class UNetEngine:
         a = self.gn_silu(h, "out.0")
         return self.conv3d(a, "out.2", self.cfg.out_channels)
 
-    def forward_libero(self, x, t, task_embed=None, label_emb=None):
-        """Unet_Libero.forward: x [B,(f+1)*3,H,W] -> [B,f*3,H,W] (reference layouts at the boundary)."""
+    def forward_libero(self, x, t, task_embed=None, label_emb=None, frame_ch=3):
+        """Unet_Libero / UnetMW / UnetThor / UnetBridge (frame_ch 3) and UnetMWFlow (frame_ch 2) forward:
+        x [B, f*frame_ch + 3, H, W] -> [B, f*out_channels, H, W] (reference layouts at the boundary)."""
         B, C, H, W = x.shape
-        f = C // 3 - 1
-        xin = ops.video_pack(x.float().contiguous(), f, H, W)
+        f = (C - 3) // frame_ch
+        xin = ops.video_pack(x.float().contiguous(), f, H, W, frame_ch)
         if label_emb is None:
             label_emb = self.label_embedding(task_embed)
         v = self.forward_cl(xin, t.long().contiguous(), label_emb)                      # [B,f,H,W,3]
