@@ -1,5 +1,6 @@
 """Policy parity on the GPU: HIP path (through the reference's plugin surface) vs golden vectors generated from the
 reference itself (tests/golden/policy.npz) and vs the CPU oracle on the same seeded inputs.  Tolerance 1e-4 relative."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -174,3 +175,49 @@ def test_bf16_mode_policy_close_to_fp32(golden_dir):
     cos = float((flat * ref).sum() / (flat.norm() * ref.norm()))
     assert cos >= 0.995, cos
     assert abs(float(flat.norm() / ref.norm()) - 1.0) <= 3e-2
+
+
+def _dp_worker(rank, world, port, q):
+    import os, sys, random
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "video-to-action-release_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)        # CPU box / one GPU: gloo stands in for RCCL
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from v2a_hip.replay import ReplayStore
+    from v2a_hip.trainer import PolicyTrainer
+    torch.manual_seed(1)
+    pol = build_policy(DEFAULT_CONF).to("cuda:0")
+    store = ReplayStore(64, 200, 30, capacity_frames=40 * 12)
+    gen = torch.Generator().manual_seed(3 + rank)
+    for e in range(12):
+        n = 30 + e
+        store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
+                              torch.rand(n - 1, 7, generator=gen) * 2 - 1)
+    np.random.seed(5 + rank); random.seed(5 + rank)
+    tr = PolicyTrainer(pol, store, batch_size=4, seed=11, use_graph=True, process_group=dist.group.WORLD, world_size=world, rank=rank)
+    losses = [tr.step().item() for _ in range(5)]          # 2 eager steps, capture, 2 replays of the two-graph step
+    flat = torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu()
+    q.put((rank, losses, float(flat.double().norm()), flat[::9973].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_on_one_gpu():
+    """The world_size > 1 branch of PolicyTrainer for real on the GPU: flat-arena all-reduce (gloo here, RCCL on a node) between
+    the captured fwd+bwd graph and the captured optimiser graph; replicas must stay identical, per-rank batches must differ."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.allclose(res[0][3], res[1][3], rtol=0, atol=0), "replicas diverged"
+    assert res[0][2] == res[1][2]
+    assert res[0][1] != res[1][1] and all(np.isfinite(res[0][1] + res[1][1]))
