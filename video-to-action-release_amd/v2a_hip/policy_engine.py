@@ -515,30 +515,58 @@ class PolicyEngine:
 
     def loss_fwd_bwd(self, imgs: dict, action, noise, timesteps, need_grad=True, names=None, arena=None):
         """compute_loss (+ backward).  imgs[key] [B,3,H,W]; action/noise [B,T,Da]; timesteps [B] int64.
-        Gradients (torch layout) are written into views of one flat fp32 arena (a fresh one unless given): the same
+        Gradients (torch layout) are written into views of one flat fp32 arena (a fresh zeroed one unless given): the same
         buffer feeds the RCCL all-reduce and the fused optimiser.  Returns (loss[1], {name: grad view}, arena)."""
-        save_enc = {} if need_grad else None
+        if not need_grad:
+            gc = self.global_cond(imgs, None)
+            noisy = ops.add_noise(action, noise, timesteps, self.ac)
+            pred = self.unet_fwd(noisy, timesteps, gc, None)
+            loss, _ = ops.mse_loss(pred, noise, want_grad=False)
+            return loss, None, None
+        st = self.backward_phase1(imgs, action, noise, timesteps, names=names, arena=arena)
+        self.backward_phase2(st)
+        return st["loss"], st["grads"], st["arena"]
+
+    def backward_phase1(self, imgs, action, noise, timesteps, names=None, arena=None):
+        """forward + loss + ConditionalUnet1D backward: afterwards the `model.*` slice of the arena is final (its all-reduce can
+        start while phase 2 runs).  Returns the state phase 2 needs."""
+        save_enc = {}
         gc = self.global_cond(imgs, save_enc)
         noisy = ops.add_noise(action, noise, timesteps, self.ac)
-        save = {} if need_grad else None
+        save = {}
         pred = self.unet_fwd(noisy, timesteps, gc, save)
-        loss, dpred = ops.mse_loss(pred, noise, want_grad=need_grad)
-        if not need_grad:
-            return loss, None, None
+        loss, dpred = ops.mse_loss(pred, noise, want_grad=True)
         names = list(names) if names is not None else self.trainable_names()
         if arena is None:
             arena = torch.zeros(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)   # GN param grads accumulate
         grads = self.grad_views(arena, names)
         dgc = self.unet_bwd(dpred, save, grads)
+        self._join_side()
+        return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc)
+
+    def backward_phase2(self, st):
+        """image-encoder backward (the `obs_encoder.*` slice of the arena)."""
+        dgc, grads = st["dgc"], st["grads"]
         B = dgc.shape[0]
         fd = self.cfg.feature_dim
         nk = len(self.cfg.rgb_keys)
         for i, key in enumerate(self.cfg.rgb_keys):
             df = torch.empty((B, fd), dtype=torch.float32, device=dgc.device)
             ops.copy2d(dgc, df, B, fd, fd * nk, fd, src_off=i * fd)
-            self.encode_bwd(key, df, save_enc[key], grads)
+            self.encode_bwd(key, df, st["save_enc"][key], grads)
         self._join_side()
-        return loss, grads, arena
+
+    def arena_slices(self, names):
+        """(start, end) element ranges of the `model.*` (ConditionalUnet1D) and the remaining (encoder) gradients in the arena."""
+        offs, total = self.grad_layout(names)
+        m = [n for n in names if n.startswith("model.")]
+        if not m:
+            return (0, 0), (0, total)
+        lo = offs[m[0]]
+        hi = offs[m[-1]] + self.P[m[-1]].numel()
+        assert hi - lo == sum(self.P[n].numel() for n in m), "model.* gradients must be contiguous in the arena"
+        assert lo == 0 or hi == total
+        return (lo, hi), ((0, lo) if hi == total else (hi, total))
 
     def trainable_names(self):
         """Every parameter the backward produces a gradient for (the reference trains all of these)."""

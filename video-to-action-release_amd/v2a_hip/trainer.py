@@ -8,7 +8,8 @@
 Mirrors the order of lb_online_trainer_v7.py:558-624 (sample_from_bufs -> compute_loss -> backward -> clip_grad_norm_ ->
 opt.step -> zero_grad -> ema.update).  Data parallel = one process per GPU, every rank holds a full replica (parameters, Adam
 moments, EMA) and its own replay shard / RNG stream (seed + rank); the only collective is one sum all-reduce of the 87.2 M fp32
-gradients per step, averaged by folding 1/world into the optimiser's gradient scale.
+gradients per step (issued as two asynchronous slice all-reduces: the ConditionalUnet1D slice travels under the image-encoder
+backward), averaged by folding 1/world into the optimiser's gradient scale.
 """
 import copy
 import torch
@@ -57,7 +58,11 @@ class PolicyTrainer:
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.use_graph = use_graph
         self._g_fb = None
+        self._g_enc = None
         self._g_opt = None
+        self._works = []
+        self._slices = self.eng.arena_slices(self.names)
+        self._st = None
         self._warm = 0
         self.step_count = 0
 
@@ -90,14 +95,25 @@ class PolicyTrainer:
                            offset_dev=self.counter)
         check(lib.v2a_advance_counter(self.counter.data_ptr(), (n_noise + 3) // 4 + B, ops._stream()), "advance_counter")
         imgs = {"img_obs_1": o0, "img_goal_1": o1}
-        loss, _, _ = self.eng.loss_fwd_bwd(imgs, oa, self.noise, self.timesteps, need_grad=True, names=self.names, arena=self.arena)
-        ops.copy2d(loss, self.loss, 1, 1, 1, 1)
+        self._st = self.eng.backward_phase1(imgs, oa, self.noise, self.timesteps, names=self.names, arena=self.arena)
+        ops.copy2d(self._st["loss"], self.loss, 1, 1, 1, 1)
 
-    def _all_reduce(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.pg)        # RCCL over xGMI
-            self.opt.scale_grads(1.0 / self.world)
+    def _bwd_encoders(self):
+        self.eng.backward_phase2(self._st)
+
+    def _reduce_async(self, which):
+        """Sum all-reduce of one arena slice (RCCL over xGMI), asynchronous: the ConditionalUnet1D slice (74 % of the bytes) is
+        final before the image-encoder backward starts and travels underneath it."""
+        import torch.distributed as dist
+        lo, hi = self._slices[which]
+        if hi > lo:
+            self._works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _reduce_wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self.opt.scale_grads(1.0 / self.world)
 
     def _opt(self):
         self.opt.step(zero_grad=True)
@@ -109,25 +125,39 @@ class PolicyTrainer:
         self._draw_indices()
         if not self.use_graph or self._warm < 2:
             self._fwd_bwd()
-            self._all_reduce()
+            if self.world > 1:
+                self._reduce_async(0)
+            self._bwd_encoders()
+            if self.world > 1:
+                self._reduce_async(1)
+                self._reduce_wait()
             self._opt()
             self._warm += 1
         else:
             if self._g_fb is None:
                 torch.cuda.synchronize()
                 self._g_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._g_fb):
-                    self._fwd_bwd()
-                    if self.world == 1:
+                if self.world == 1:                       # one graph: gather -> fwd -> bwd -> optimiser -> re-pack
+                    with torch.cuda.graph(self._g_fb):
+                        self._fwd_bwd()
+                        self._bwd_encoders()
                         self._opt()
-                if self.world > 1:
+                else:                                     # three graphs with the two slice all-reduces launched between them
+                    with torch.cuda.graph(self._g_fb):
+                        self._fwd_bwd()
+                    self._g_enc = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._g_enc, pool=self._g_fb.pool()):
+                        self._bwd_encoders()
                     self._g_opt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._g_opt):
+                    with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
                         self._opt()
                 # capture does not execute: run the step for real
             self._g_fb.replay()
             if self.world > 1:
-                self._all_reduce()
+                self._reduce_async(0)
+                self._g_enc.replay()
+                self._reduce_async(1)
+                self._reduce_wait()
                 self._g_opt.replay()
         self.step_count += 1
         return self.loss
