@@ -27,6 +27,16 @@ HBM_PEAK_GBS = 8000.0
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA
 
 
+def _traffic(leg, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    FETCH doubled per MI355X_MICROARCH.md section HBM; tools/profile_round.sh + tools/summarize_pmc.py), or None."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        return json.load(open(tpath)).get(leg, {}).get(kernel)
+    except Exception:
+        return None
+
+
 def build_store(torch, device, batch, seed):
     from v2a_hip.replay import ReplayStore
     n_eps, ep_len = 8 * 50, 121
@@ -225,7 +235,7 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
                                                        "guidance_weight": 0},
             "dtype": "f32", "algorithmic_tflops": flops / dt / 1e12, "output_range": [float(out.min()), float(out.max())],
             "roofline": {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic("video", name), "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
                          "share_of_conv_time": sec / sum(v[1] for v in agg.values()),
                          "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]}
                                                for k, v in sorted(agg.items())}}}
@@ -325,7 +335,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(name)
+                traffic = json.load(open(tpath)).get("policy", {}).get(name)
             except Exception:
                 traffic = None
         out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

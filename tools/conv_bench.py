@@ -48,15 +48,20 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-for name, N, H, W, Ci, Co, k, s in FWD:
-    kh, kw = (k, k) if isinstance(k, int) else k
-    x = torch.randn(N, H, W, Ci, device=dev)
-    w = torch.randn(Co, kh * kw * Ci, device=dev) * 0.02
-    b = torch.randn(Co, device=dev)
-    y = ops.conv2d(x, w, b, Co, kh, kw, (s, s), (kh // 2, kw // 2))
-    M = y.shape[0] * y.shape[1] * y.shape[2]
-    fl = 2.0 * M * Co * kh * kw * Ci
-    t = timeit(lambda: ops.conv2d(x, w, b, Co, kh, kw, (s, s), (kh // 2, kw // 2)))
-    dy = torch.randn_like(y)
-    tw = timeit(lambda: ops.conv2d_wgrad(x, dy, (Co, Ci, kh, kw), kh, kw, (s, s), (kh // 2, kw // 2)))
-    print(f"{name:36s} M={M:8d} K={kh*kw*Ci:6d} N={Co:5d}  fwd {t*1e6:9.1f} us {fl/t/1e12:7.1f} TF | wgrad {tw*1e6:9.1f} us {fl/tw/1e12:7.1f} TF")
+def main():
+  for name, N, H, W, Ci, Co, k, s in FWD:
+      kh, kw = (k, k) if isinstance(k, int) else k
+      x = torch.randn(N, H, W, Ci, device=dev)
+      w = torch.randn(Co, kh * kw * Ci, device=dev) * 0.02
+      b = torch.randn(Co, device=dev)
+      y = ops.conv2d(x, w, b, Co, kh, kw, (s, s), (kh // 2, kw // 2))
+      M = y.shape[0] * y.shape[1] * y.shape[2]
+      fl = 2.0 * M * Co * kh * kw * Ci
+      t = timeit(lambda: ops.conv2d(x, w, b, Co, kh, kw, (s, s), (kh // 2, kw // 2)))
+      dy = torch.randn_like(y)
+      tw = timeit(lambda: ops.conv2d_wgrad(x, dy, (Co, Ci, kh, kw), kh, kw, (s, s), (kh // 2, kw // 2)))
+      print(f"{name:36s} M={M:8d} K={kh*kw*Ci:6d} N={Co:5d}  fwd {t*1e6:9.1f} us {fl/t/1e12:7.1f} TF | wgrad {tw*1e6:9.1f} us {fl/tw/1e12:7.1f} TF")
+
+
+if __name__ == "__main__":
+    main()

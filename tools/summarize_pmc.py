@@ -31,4 +31,18 @@ for leg in ("policy", "video"):
         v["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
         v["hbm_bytes_per_launch_raw"] = (f + w) * 1024.0
     out[leg] = dict(sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0) * kv[1]["n"])[:40])
+# bench.py reads profiles/roofline_traffic.json: {"policy"|"video": {"<kernel><BM,BN>": corrected HBM bytes per launch}}
+import re
+rt = {}
+for leg_name in ("policy", "video"):
+    traffic = {}
+    for k, v in out[leg_name].items():
+        m = re.match(r"(conv_(?:igemm|wgrad)_(?:f32|bf16))<(\d+), (\d+)", k)
+        if m:
+            key = f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+            a = traffic.setdefault(key, [0.0, 0])     # template variants sharing a tile: launch-count weighted mean
+            a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
+            a[1] += v["n"]
+    rt[leg_name] = {k: a[0] / max(a[1], 1) for k, a in traffic.items()}
+out["roofline_traffic"] = rt
 print(json.dumps(out, indent=1))
