@@ -61,6 +61,7 @@ class PolicyTrainer:
         self._g_enc = None
         self._g_opt = None
         self._works = []
+        self._blocking_reduce = False
         self._slices = self.eng.arena_slices(self.names)
         self._st = None
         self._warm = 0
@@ -106,10 +107,20 @@ class PolicyTrainer:
         final before the image-encoder backward starts and travels underneath it."""
         import torch.distributed as dist
         lo, hi = self._slices[which]
-        if hi > lo:
+        if hi <= lo or self._blocking_reduce:
+            return
+        try:
             self._works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        except Exception as e:      # a backend without async slices: one blocking all-reduce of the whole arena in _reduce_wait
+            if self._works or self.step_count > 0:
+                raise
+            print(f"[v2a] async slice all-reduce unavailable ({type(e).__name__}: {e}); using one blocking all-reduce per step")
+            self._blocking_reduce = True
 
     def _reduce_wait(self):
+        import torch.distributed as dist
+        if self._blocking_reduce:
+            dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.pg)
         for w in self._works:
             w.wait()
         self._works = []
