@@ -80,6 +80,8 @@ def instrumented_pass(torch, trainer, steps):
         K = kh * kw * (x.shape[-1] + c2)
         bm = 128 if m >= 4096 else 64
         bn = (128 if bm == 128 else 64) if cout > 64 else 64
+        if bm == 128 and -(-m // 128) * -(-cout // bn) < 600:      # mirrors conv_plan() in csrc/igemm.hip
+            bm = bn = 64
         import v2a_hip as _v
         kn = "conv_igemm_bf16" if _v.get_precision() == "bf16" else "conv_igemm_f32"
         return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K)
@@ -228,6 +230,8 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
         m = y.shape[0] * y.shape[1] * y.shape[2]
         bm = 128 if m >= 4096 else 64
         bn = (128 if bm == 128 else 64) if cout > 64 else 64
+        if bm == 128 and -(-m // 128) * -(-cout // bn) < 600:
+            bm = bn = 64
         import v2a_hip as _v
         kn = "conv_igemm_bf16" if _v.get_precision() == "bf16" else "conv_igemm_f32"
         recs.append((f"{kn}<{bm},{bn}>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))

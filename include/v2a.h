@@ -43,6 +43,7 @@ enum { V2A_ACT_NONE = 0, V2A_ACT_SILU = 1, V2A_ACT_RELU = 2, V2A_ACT_MISH = 3, V
  * accumulation and fp32 HBM storage (performance configuration; the reference's GPU path is fp16 autocast). Returns the old mode. */
 int v2a_set_precision(int mode);
 int v2a_get_precision(void);
+int v2a_debug_force_tile(int bm, int bn);   /* tuning aid: force the forward tile (128x128 | 128x64 | 64x64), 0,0 = heuristic */
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                    const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH, int OW,

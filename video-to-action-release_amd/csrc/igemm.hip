@@ -884,10 +884,14 @@ static int pick_split(int tiles, int ktiles, int min_ktiles) {
 }
 
 // one tile/split plan shared by the workspace query and the launcher (they must agree)
+static int g_force_bm = 0, g_force_bn = 0;     // experiments only (v2a_debug_force_tile)
 static void conv_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int* s) {
     *bm = M >= 4096 ? 128 : 64;
     *bn = Cout > 64 ? (*bm == 128 ? 128 : 64) : 64;
     if (*bm == 64) *bn = 64;
+    // few-hundred-tile problems (ResNet layers at B=64) run better on 64x64 tiles: more workgroups per CU (tools/tile_sweep.py)
+    if (*bm == 128 && cdiv(M, 128) * cdiv(Cout, *bn) < 600) { *bm = 64; *bn = 64; }
+    if (g_force_bm) { *bm = g_force_bm; *bn = g_force_bn; }
     *tiles = cdiv(M, *bm) * cdiv(Cout, *bn);
     *s = pick_split(*tiles, cdiv(K, 32), 4);      // split granularity in 32-deep k tiles (valid for both BKT)
 }
@@ -914,6 +918,13 @@ int v2a_set_precision(int mode) {
     return old;
 }
 int v2a_get_precision(void) { return g_precision; }
+// tuning aid: force the forward tile (128x128, 128x64, 64x64) or 0,0 to restore the heuristic
+int v2a_debug_force_tile(int bm, int bn) {
+    if (!((bm == 0 && bn == 0) || (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))) return V2A_ERR_ARG;
+    g_force_bm = bm;
+    g_force_bn = bn;
+    return V2A_OK;
+}
 
 // workspace (bytes) a conv forward may need for split-K slabs (same plan as the launcher)
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K) {

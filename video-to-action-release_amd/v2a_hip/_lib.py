@@ -21,6 +21,7 @@ LL = ctypes.c_longlong
 SIGNATURES = {
     "v2a_set_precision": (I, [I]),
     "v2a_get_precision": (I, []),
+    "v2a_debug_force_tile": (I, [I, I]),
     "v2a_conv2d_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_fwd": (I, [P] * 8 + [I] * 19 + [P, SZ, P]),
     "v2a_conv2d_wgrad_workspace_bytes": (SZ, [I, I, I]),
