@@ -1,17 +1,15 @@
-import torch.nn as nn
+"""nn.Module base that exposes `.device` / `.dtype` (surface of the reference's common/module_attr_mixin.py:3-14).
+
+The reference answers both from its first registered parameter, an empty placeholder called `_dummy_variable`; the same
+placeholder is registered here first (it is part of the checkpoint key layout) and queried directly."""
+import torch
+from torch import nn
 
 
 class ModuleAttrMixin(nn.Module):
-    """Same surface as the reference mixin (common/module_attr_mixin.py:3-14): a dummy parameter gives .device/.dtype."""
-
     def __init__(self):
         super().__init__()
-        self._dummy_variable = nn.Parameter()
+        self.register_parameter("_dummy_variable", nn.Parameter(torch.empty(0)))
 
-    @property
-    def device(self):
-        return next(iter(self.parameters())).device
-
-    @property
-    def dtype(self):
-        return next(iter(self.parameters())).dtype
+    device = property(lambda self: self._dummy_variable.device)
+    dtype = property(lambda self: self._dummy_variable.dtype)
