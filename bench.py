@@ -391,6 +391,24 @@ def main():
                            "note": "performance configuration; parity (1e-4) is claimed for the fp32 run only"}
             del tr2, pol2
             v2a_hip.set_precision("fp32")
+        # predict_action latency (B=1, DDIM-8, EMA-style replica) under hipGraph replay
+        try:
+            from v2a_hip.inference import GraphedPredictAction
+            polq = tr.ema_for_inference()
+            gp = GraphedPredictAction(polq, batch_size=1, use_ddim=True)
+            obs1 = {k: torch.rand(1, 1, 3, 128, 128, device=device) for k in ("img_obs_1", "img_goal_1")}
+            for _ in range(3):
+                gp(obs1)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(50):
+                gp(obs1)
+            torch.cuda.synchronize()
+            out["predict_action"] = {"latency_ms": (time.perf_counter() - t2) / 50 * 1e3, "batch": 1, "sampler": "ddim-8",
+                                     "note": "encoders + 8 ConditionalUnet1D steps + unnormalise, one hipGraph replay per call; "
+                                             "reference CPU path 110 ms (SURVEY section 6)"}
+        except Exception as e:                      # never let the secondary leg break the headline line
+            out["predict_action"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_video:
             del tr, pol, store
             torch.cuda.empty_cache()

@@ -221,3 +221,21 @@ def test_data_parallel_two_ranks_on_one_gpu():
     assert np.allclose(res[0][3], res[1][3], rtol=0, atol=0), "replicas diverged"
     assert res[0][2] == res[1][2]
     assert res[0][1] != res[1][1] and all(np.isfinite(res[0][1] + res[1][1]))
+
+
+def test_graphed_predict_action_matches_eager(golden_dir):
+    """The hipGraph-replayed predict_action (v2a_hip.inference) against the golden DDIM-8 output (same injected noise)."""
+    from v2a_hip.inference import GraphedPredictAction
+    g = np.load(f"{golden_dir}/policy.npz", allow_pickle=True)
+    pol, _ = _policy()
+    pol.eval()
+    obs = {k: v.cuda() for k, v in _batch(g)["obs"].items()}
+    gp = GraphedPredictAction(pol, batch_size=2, use_ddim=True)
+    torch.manual_seed(70)
+    init = torch.randn(2, 16, 7)
+    for _ in range(3):                                   # first call captures, the others replay
+        out = gp(obs, init_noise=init.cuda())
+    assert rel(out["action_pred"], g["ddim_action_pred"]) <= TOL
+    assert rel(out["action"], g["ddim_action"]) <= TOL
+    out2 = gp(obs)                                       # device Philox noise: different sample, finite, in range
+    assert torch.isfinite(out2["action_pred"]).all() and float(out2["action_pred"].abs().max()) <= 1.0

@@ -43,7 +43,6 @@ class _Conv:
             self.kh, self.kw = 1, w.shape[2]
         else:
             self.kh, self.kw = w.shape[2], w.shape[3]
-        self.transposed = transposed
         self.co, self.ci = w.shape[0], w.shape[1]     # torch dims 0 / 1 (for transposed: [Cin][Cout])
         # data gradients read the forward pack directly (N-major loader) when the reduction channels are a multiple of 16
         self.nmaj = (self.co % 16 == 0) and (self.ci % 4 == 0)

@@ -86,8 +86,7 @@ class ReplayStore:
             self._head = 0
         lo, hi = self._head, self._head + n
         # evict (FIFO) anything overlapping the region we are about to overwrite
-        while self.episodes and not (self.episodes[0][0] + self.episodes[0][1] <= lo or self.episodes[0][0] >= hi) \
-                and len(self.episodes) > 0:
+        while self.episodes and self.episodes[0][0] < hi and self.episodes[0][0] + self.episodes[0][1] > lo:
             self.episodes.popleft()
         self._head = hi
         return lo

@@ -15,7 +15,7 @@ import copy
 import torch
 from . import ops
 from .optim import FusedAdamWEMA
-from .replay import ReplayStore, sample_indices
+from .replay import ReplayStore, sample_indices  # noqa: F401  (ReplayStore: the type of `store`)
 from ._lib import lib, check
 
 

@@ -91,7 +91,6 @@ class UNetEngine:
         self.device = next(iter(params.values())).device
         self.packs = _Packs(params)
         self.inp, self.mid, self.out, self.final_ch = build_program(cfg)
-        self._label_cache = None
 
     def w(self, name):
         return self.packs.get(self.pre + name)
