@@ -84,7 +84,7 @@ def instrumented_pass(torch, trainer, steps):
             bm = bn = 64
         import v2a_hip as _v
         kn = "conv_igemm_bf16" if _v.get_precision() == "bf16" else "conv_igemm_f32"
-        return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K)
+        return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K, (m, cout, K, kh, kw, int(k.get("bmode", 0) or 0)))
 
     def f_wg(a, k, out):
         x, dy, kh, kw = a[0], a[1], a[3], a[4]
@@ -103,7 +103,7 @@ def instrumented_pass(torch, trainer, steps):
                 bm = bn = 64
         import v2a_hip as _v
         kn = "conv_wgrad_bf16" if _v.get_precision() == "bf16" else "conv_wgrad_f32"
-        return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K)
+        return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K, (m, cout, K, kh, kw, -1))
 
     orig_axpy = ops.axpy
     ops.conv2d = timed("fwd", orig_fwd, f_fwd)
@@ -119,12 +119,20 @@ def instrumented_pass(torch, trainer, steps):
         ops.conv2d, ops.conv2d_wgrad = orig_fwd, orig_wg
         trainer.use_graph = g_saved
         trainer.eng.async_wgrad = a_saved
-    agg = {}
-    for kind, (name, fl), e0, e1 in recs:
-        d = agg.setdefault(name, [0.0, 0.0, 0])
-        d[0] += fl
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += 1
+    agg, shapes = {}, {}
+    for kind, (name, fl, shape), e0, e1 in recs:
+        dt = e0.elapsed_time(e1) * 1e-3
+        for tab, key in ((agg, name), (shapes, (name,) + shape)):
+            d = tab.setdefault(key, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += dt
+            d[2] += 1
+    if os.environ.get("V2A_BENCH_SHAPES"):       # per-shape table for kernel tuning: (kernel, M, Cout, K, kh, kw, bmode|-1 = wgrad)
+        rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
+        with open(os.environ["V2A_BENCH_SHAPES"], "w") as f:
+            for key, (fl, t, n) in rows:
+                f.write(f"{key[0]:28s} M={key[1]:7d} Cout={key[2]:5d} K={key[3]:6d} k={key[4]}x{key[5]} mode={key[6]:2d} n/step={n / steps:5.1f} "
+                        f"us={t / n * 1e6:8.1f} TF={fl / t / 1e12:6.1f} ms/step={t / steps * 1e3:6.3f}\n")
     return agg
 
 

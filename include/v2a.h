@@ -136,6 +136,9 @@ size_t v2a_opt_state_bytes(void);
 int v2a_opt_state_init(void* host_state, double lr, double b1, double b2, double eps, double wd, double max_norm, double ema_inv_gamma,
                        double ema_power, double ema_min, double ema_beta, int ema_update_after, int ema_update_every);
 int v2a_opt_state_peek(const void* host_state, float* grad_norm, float* clip_coef, long long* step, float* ema_decay);
+/* step counters of a HOST copy of the state, for `trainer.save/load` (lb_online_trainer_v7.py:367-408); lr <= 0 keeps the rate */
+int v2a_opt_state_counters(const void* host_state, long long* step, long long* ema_step, int* ema_initted);
+int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_step, int ema_initted, double lr);
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad, v2a_stream_t s);
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, v2a_stream_t s);  /* 1/world after the RCCL sum */
 

@@ -196,7 +196,22 @@ def g_replay():
     print("replay ok", out["episodes_123"][0][:8], out["starts_123"][0][:8])
 
 
-GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay}
+from tests.tools_schedule import _schedule_trace, schedule_stub, SCHEDULE_CFGS  # noqa: E402  (shared with tests/test_joint_loop.py)
+
+
+def g_schedule():
+    from diffuser.libero.lb_online_trainer_v7 import LB_Online_Trainer_V7 as Ref
+    assert "/root/reference" in sys.modules[Ref.__module__].__file__
+    out = {}
+    for name, cfg in SCHEDULE_CFGS.items():
+        n = 30000 if name == "released" else 4000
+        out[name] = np.packbits(_schedule_trace(Ref, lambda: schedule_stub(cfg), n), axis=0)
+        out[name + "_n"] = np.array(n)
+    np.savez_compressed(f"{OUT}/schedule.npz", **out)
+    print("schedule ok", {k: v.shape for k, v in out.items()})
+
+
+GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "schedule": g_schedule}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

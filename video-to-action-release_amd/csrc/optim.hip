@@ -147,6 +147,25 @@ int v2a_opt_state_peek(const void* host_state, float* grad_norm, float* clip_coe
     return V2A_OK;
 }
 
+// checkpoint support (lb_online_trainer_v7.py:367-408 saves opt / ema state): read / patch the step counters of a HOST copy
+int v2a_opt_state_counters(const void* host_state, long long* step, long long* ema_step, int* ema_initted) {
+    const OptState* s = reinterpret_cast<const OptState*>(host_state);
+    if (!s) return V2A_ERR_ARG;
+    if (step) *step = s->step;
+    if (ema_step) *ema_step = s->ema_step;
+    if (ema_initted) *ema_initted = s->ema_initted;
+    return V2A_OK;
+}
+int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_step, int ema_initted, double lr) {
+    OptState* s = reinterpret_cast<OptState*>(host_state);
+    if (!s || step < 0 || ema_step < 0) return V2A_ERR_ARG;
+    s->step = step;
+    s->ema_step = ema_step;
+    s->ema_initted = ema_initted ? 1 : 0;
+    if (lr > 0) s->lr = lr;
+    return V2A_OK;
+}
+
 // One optimiser step over all tensors.  partial: nchunks doubles of scratch.
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
                  int zero_grad, hipStream_t s) {

@@ -1,0 +1,689 @@
+"""LB_Online_Trainer_V7 -- the joint loop of the reference (diffuser/libero/lb_online_trainer_v7.py:29-1347) on the MI355X path:
+
+    every `video_explo_freq` steps:   for each (task, cam, env) of this rank:
+                                          video model samples 7 goal frames from the current render        (HIP UNet sampler)
+                                          EMA policy follows them, `n_preds` x 8 actions per frame         (HIP predict_action)
+                                          grasp heuristic on the wrist depth; episode -> envBuf_vid        (uint8, HBM resident)
+    every `rand_explo_freq` steps:    more random-action episodes from the HDF5 file -> envBuf_rand
+    every step:                       sample_from_bufs -> compute_loss -> backward -> clip -> AdamW -> zero -> EMA
+                                      = one hipGraph replay of v2a_hip.trainer.PolicyTrainer (+ RCCL all-reduce when world > 1)
+
+Same constructor keywords, attributes (`.opt .ema .accelerator .results_folder .step .gcp_model .video_model .envBuf_rand
+.envBuf_vid ...`), schedule state machines (`update_iter_type`, `update_explo_type`), RNG call order and checkpoint keys as the
+reference, so `scripts/train_libero_dp.py` and `LB_DP_Eval` drive it unchanged.  Differences, all on purpose:
+  * the replay buffers are `v2a_hip.replay.ReplayStore`s over one HBM pool (uint8 frames) instead of deques of fp32 CPU tensors;
+  * clip / AdamW / zero_grad / EMA run fused on the device: `.opt` and `.ema` are handles over that state which keep the
+    `zero_grad / state_dict / load_state_dict / ema_model / update` surface (torch.optim.AdamW / ema_pytorch key layouts);
+  * `accelerate` is not required: `.accelerator` is a small object with the attributes the scripts read; one process per GPU, rank r
+    explores the (task, cam, env) combinations r, r+N, ... and trains on its own buffers;
+  * figure / gif / wandb side effects of the reference's debug mode are not produced (metrics go to `metrics.jsonl`).
+"""
+import contextlib
+import json
+import os
+import os.path as osp
+import random
+from copy import deepcopy
+from functools import partial
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Subset
+
+from v2a_hip.replay import ReplayStore, sample_mixed
+from v2a_hip.trainer import PolicyTrainer
+from . import _host_utils as utils
+from ._host_utils import imgs_preproc_simple_noCrop_v1
+from .lb_randsam_io import open_randsam
+
+__version__ = "v2a-mi355x-0.1"
+
+
+def exists(x):
+    return x is not None
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+class _Accelerator:
+    """The attributes of accelerate.Accelerator that train_libero_dp.py / plan_lb.py / LB_DP_Eval touch."""
+
+    def __init__(self):
+        self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
+        self.process_index = int(os.environ.get("RANK", "0"))
+        self.local_process_index = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise RuntimeError("LB_Online_Trainer_V7 needs a GPU: the policy / video hot path has no CPU fallback")
+        self.device = torch.device("cuda", self.local_process_index)
+        torch.cuda.set_device(self.device)
+        self.process_group = None
+        if self.num_processes > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", device_id=self.device)        # RCCL over xGMI
+            self.process_group = dist.group.WORLD
+        self.scaler = None
+        self.native_amp = False
+        self.is_main_process = self.process_index == 0
+        self.is_local_main_process = self.local_process_index == 0
+
+    def prepare(self, *objs):
+        return objs[0] if len(objs) == 1 else objs
+
+    def unwrap_model(self, m):
+        return m
+
+    def get_state_dict(self, m):
+        return m.state_dict()
+
+    def autocast(self):
+        return contextlib.nullcontext()           # the HIP path picks its own precision (v2a_hip.set_precision)
+
+    def wait_for_everyone(self):
+        if self.num_processes > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.process_group)
+
+    def print(self, *a, **k):
+        if self.is_main_process:
+            print(*a, **k)
+
+
+class _OptHandle:
+    """`trainer.opt`: torch.optim.AdamW's surface over the fused device optimiser."""
+
+    def __init__(self, ptrainer: PolicyTrainer):
+        self._t = ptrainer
+        named = list(ptrainer.policy.named_parameters())
+        fused_index = {n: i for i, n in enumerate(ptrainer.names)}
+        self._ckpt_names = [n for n, _ in named]                                # .parameters() order, as AdamW(params) saw it
+        self._order = [fused_index.get(n, -1) for n in self._ckpt_names]        # -1: never receives a gradient (no state)
+
+    @property
+    def param_groups(self):
+        return [dict(self._t.opt.hyper, params=[dict(self._t.policy.named_parameters())[n] for n in self._ckpt_names])]
+
+    def zero_grad(self, set_to_none=True):
+        self._t.arena.zero_()
+        for p in self._t.policy.parameters():
+            p.grad = None
+
+    def state_dict(self):
+        return self._t.opt.state_dict(order=self._order)
+
+    def load_state_dict(self, sd):
+        self._t.opt.load_state_dict(sd, order=self._order)
+
+    def step(self):
+        raise RuntimeError("the optimiser step is fused into PolicyTrainer.step(); call trainer.train() / trainer.train_step()")
+
+
+class _EMAHandle:
+    """`trainer.ema`: ema_pytorch.EMA's surface (`.ema_model`, `.update()`, state_dict with online_model./ema_model./initted/step)."""
+
+    def __init__(self, ptrainer: PolicyTrainer):
+        self._t = ptrainer
+        self._fresh = -1
+
+    @property
+    def online_model(self):
+        return self._t.policy
+
+    @property
+    def ema_model(self):
+        if self._fresh != self._t.step_count:           # the fused kernel updates the EMA weights behind torch's back
+            self._t.ema_for_inference()
+            self._fresh = self._t.step_count
+        return self._t.ema_policy
+
+    def update(self):
+        pass                                            # done by the fused optimiser kernel of the same step
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        self._t.ema_policy.eval()
+        return self
+
+    def state_dict(self):
+        _, ema_step, initted = self._t.opt.counters()
+        sd = {f"online_model.{k}": v for k, v in self._t.policy.state_dict().items()}
+        sd.update({f"ema_model.{k}": v for k, v in self._t.ema_policy.state_dict().items()})
+        sd["initted"] = torch.tensor([initted])
+        sd["step"] = torch.tensor([ema_step])
+        return sd
+
+    def load_state_dict(self, sd):
+        self._t.ema_policy.load_state_dict({k[len("ema_model."):]: v for k, v in sd.items() if k.startswith("ema_model.")})
+        step, _, _ = self._t.opt.counters()
+        self._t.opt.set_counters(step, int(sd["step"].item()), bool(sd["initted"].item()))
+        self._fresh = -1
+
+
+class LB_Online_Trainer_V7(object):
+    def __init__(self, init_diff_policy, video_model, tokenizer, text_encoder, train_set, valid_set, channels=3, *,
+                 train_batch_size=1, video_batch_size=1, valid_batch_size=1, gradient_accumulate_every=1,
+                 augment_horizontal_flip=True, train_num_steps=100000, opt_params, ema_params, render_img_size=(320, 240),
+                 input_img_size=(128, 128), sample_freq=1000, save_freq=1000, label_freq=50000, log_freq=100, num_samples=3,
+                 results_folder='./results', amp=True, fp16=True, split_batches=False, trainer_dict, **kwargs):
+        super().__init__()
+        self.tokenizer = tokenizer
+        self.text_encoder = text_encoder
+        self.accelerator = _Accelerator()
+        acc = self.accelerator
+
+        self.gcp_model = init_diff_policy.diffusion_policy
+        self.video_model = video_model.to(self.device)
+        assert tuple(video_model.ema.ema_model.image_size) == tuple(input_img_size)
+        self.video_model.requires_grad_(False)
+        self.video_model.eval()
+
+        self.channels = channels
+        self.num_samples = num_samples
+        self.sample_freq, self.save_freq, self.label_freq, self.log_freq = sample_freq, save_freq, label_freq, log_freq
+        self.render_img_size = render_img_size
+        self.input_img_size = tuple(input_img_size)
+        self.batch_size_rand = train_batch_size
+        self.valid_batch_size = valid_batch_size
+        if gradient_accumulate_every != 1:
+            raise NotImplementedError("the fused train step takes one minibatch per optimiser step (config: gradient_accumulate_every=1)")
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.train_num_steps = int(train_num_steps)
+
+        self.env_list = train_set.env_list
+        self.task_list = self.env_list.task_list
+        self.train_set = train_set
+        self.train_set_len = len(train_set)
+
+        dl = DataLoader(self.train_set, batch_size=train_batch_size, shuffle=True, num_workers=0)
+        self.dl = cycle(dl)
+        assert video_batch_size == 1
+        mine = list(range(acc.process_index, len(self.train_set), acc.num_processes))     # this rank's rollout combinations
+        self.dl_vid = DataLoader(Subset(self.train_set, mine), batch_size=video_batch_size, shuffle=True, num_workers=0)
+
+        self.gcp_model.to(self.device)
+        if hasattr(self.text_encoder, "to"):
+            self.text_encoder.to(self.device)
+        assert not getattr(self.text_encoder, "training", False)
+
+        self.results_folder = Path(results_folder)
+        self.results_folder.mkdir(exist_ok=True, parents=True)
+        self.step = 0
+        self.num_steps_in_env = 0
+
+        self.act_min_np, self.act_max_np = self.train_set.act_min_max
+        assert (np.abs(self.act_min_np) == self.act_max_np).all(), 'necessary for our sampling'
+        self.act_min, self.act_max = torch.tensor(self.act_min_np), torch.tensor(self.act_max_np)
+        self.act_dim = len(self.act_max)
+
+        self.trainer_dict = trainer_dict
+        self.lr_warmupDecay = trainer_dict.get('lr_warmupDecay', False)
+        if self.lr_warmupDecay:
+            raise NotImplementedError("lr_warmupDecay (unused by the released configs)")
+        self.cur_mode = trainer_dict.get('cur_mode', 'train')
+        self._opt_params, self._ema_params = dict(opt_params), dict(ema_params)
+        self.init_helpers()
+        self.control_mode = 'delta'
+        self.debug = False
+
+    # ------------------------------------------------------------------------------------------------------------ set-up
+    def init_helpers(self):
+        td = self.trainer_dict
+        self.num_envs_per_tk = self.env_list.num_seed_per_task
+        assert self.num_envs_per_tk == 1
+        self.num_envs_all_tks = self.num_envs_per_tk * self.env_list.num_tasks
+        assert self.train_set_len == self.num_envs_all_tks
+
+        self.envBuf_max_num_uB_rand = td['envBuf_max_num_uB_rand']
+        self.envBuf_max_num_uB_vid = td['envBuf_max_num_uB_vid']
+        self.max_len_uB, self.min_len_uB = td['max_len_uB'], td['min_len_uB']
+        if not td.get('allow_small_buffers', False):                       # the reference's sanity floor (:198-199)
+            assert self.envBuf_max_num_uB_rand >= 1000
+            assert self.envBuf_max_num_uB_vid >= 500
+        self.model_act_horizon = td['model_act_horizon']
+
+        # both buffers in one HBM pool: a mixed minibatch is one gather launch (v2a_hip.replay.ReplayStore.pair)
+        self.envBuf_rand, self.envBuf_vid = ReplayStore.pair(
+            self.envBuf_max_num_uB_rand, self.envBuf_max_num_uB_vid, self.max_len_uB, self.min_len_uB,
+            capacity_a=td.get('pool_frames_rand'), capacity_b=td.get('pool_frames_vid'), image_hw=self.input_img_size,
+            act_dim=self.act_dim, act_len=self.model_act_horizon, device=self.device)
+
+        self.num_init_rand_episodes_per_tk = td['num_init_rand_Ep_per_tk']
+        self.buf_sample_method = td.get('buf_sample_method', 'iter_bias_fix')
+        assert self.buf_sample_method in ['iter_bias_fix', 'rand_prob', 'iter_bias_rand']
+        if self.buf_sample_method != 'rand_prob':
+            raise NotImplementedError("only buf_sample_method='rand_prob' (the released configs) is fused into the train step")
+        self.buf_sample_randBuf_prob = td['buf_sample_randBuf_prob']
+
+        rs_fname = td['randsam_filename']
+        if rs_fname.startswith('synthetic') or osp.isabs(rs_fname):
+            self.randsam_file_path = rs_fname
+        else:
+            self.randsam_file_path = osp.join('./data_dir/scratch/libero/env_rand_samples/', rs_fname)
+        assert self.cur_mode in ['train', 'eval']
+        self.randsam = open_randsam(self.randsam_file_path, env_list=self.env_list)
+        self.h5_total_num_ep_per_task = self.randsam.num_episodes(self.task_list[0])
+        if self.cur_mode == 'train':
+            assert self.h5_total_num_ep_per_task >= self.num_init_rand_episodes_per_tk
+
+        self.task_env_states = deepcopy(self.env_list.env_init_states)
+        self.rendered_imgs_preproc_fn = imgs_preproc_simple_noCrop_v1
+
+        self.iter_type = 'rand-bias'
+        self.init_rand_steps = td['init_rand_steps']
+        self.rand_cycle_steps, self.vid_cycle_steps = td['rand_cycle_steps'], td['vid_cycle_steps']
+        self.use_env_rand_reset = td['use_env_rand_reset']
+        self.video_explo_freq, self.rand_explo_freq = td['video_explo_freq'], td['rand_explo_freq']
+        self.rand_explo_type = td['rand_explo_type']
+        assert self.rand_explo_type == 'from_h5'
+        self.rand_explo_num_episodes_per_tk = td['rand_explo_num_Ep_per_tk']
+
+        self.explo_type_rand = 'explo'
+        self.explo_type_vid = 'explo'
+        self.enable_noExp = td.get('enable_noExp', False)
+        self.noExp_start_buf_len_rand = td.get('noExp_start_buf_len_rand')
+        self.noExp_start_buf_len_vid = td.get('noExp_start_buf_len_vid')
+        self.Exp_noExp_rand = td.get('Exp_noExp_rand')
+        self.Exp_noExp_vid = td.get('Exp_noExp_vid')
+        self.cnt_no_exp_rand = self.cnt_exp_rand = self.cnt_no_exp_vid = self.cnt_exp_vid = 0
+        if self.init_rand_steps != -1:
+            assert self.init_rand_steps % self.rand_cycle_steps == 0
+        self.rand_iter_cnt = self.vid_iter_cnt = 0
+
+        self.cnt_explore_suc = 0
+        self.cnt_vid_rollouts = 0
+        self.cnt_explo_suc_per_tk = {tk: 0 for tk in self.task_list}
+        self.cnt_vid_rout_per_tk = {tk: 0 for tk in self.task_list}
+
+        self.n_acts_per_pred = td['n_acts_per_pred']
+        self.n_preds_betw_vframes = td['n_preds_betw_vframes']
+        self.max_acts_betw_vframes = self.n_acts_per_pred * self.n_preds_betw_vframes[1]
+        total_rollout_acts = self.max_acts_betw_vframes * self.video_model.video_future_horizon
+        assert self.max_len_uB > total_rollout_acts, 'must store all rollout'
+
+        self.buf_sample_batch_size = td['buf_sample_batch_size']
+        bsr_rand, bsr_vid = td['buf_sample_ratio_rand'], td['buf_sample_ratio_vid']
+        self.nums_buf_sample_rand = utils.number_by_ratio(self.buf_sample_batch_size, bsr_rand)
+        self.nums_buf_sample_vid_bias = utils.number_by_ratio(self.buf_sample_batch_size, bsr_vid)
+        self.r_prob_rand, self.r_prob_vid = bsr_rand[0], bsr_vid[0]
+
+        self.n_acts_down_range = td['n_acts_down_range']
+        self.n_acts_close_grp = td['n_acts_close_grp']
+        self.act_down_val = td['act_down_val']
+        if 'act_down_val_range_per_tk' in td:
+            self.act_down_val_range_per_tk = td['act_down_val_range_per_tk']
+            assert self.act_down_val is None
+        else:
+            assert self.act_down_val <= -0.5
+        self.close_grp_force = td['close_grp_force']
+        self.close_grp_act_down_val = td['close_grp_act_down_val']
+        assert self.close_grp_act_down_val <= 0
+        self.grasp_z_diff_limit = td['grasp_z_diff_limit']
+        self.grasp_abs_z_limit = td['grasp_abs_z_limit']
+        self.grp_cam_name = 'gripper'
+        self.is_all_randsam_visited = False
+        self.is_stop_at_suc = td['is_stop_at_suc']
+
+        # ---- the fused device train step + the handles the scripts expect
+        acc = self.accelerator
+        self.ptrainer = PolicyTrainer(self.gcp_model, self.envBuf_rand, batch_size=self.buf_sample_batch_size,
+                                      opt_params=self._opt_params, ema_params=self._ema_params,
+                                      seed=td.get('seed', 0), use_graph=td.get('use_graph', True), process_group=acc.process_group,
+                                      world_size=acc.num_processes, rank=acc.process_index, store_vid=self.envBuf_vid,
+                                      rand_prob=self.buf_sample_randBuf_prob)
+        self.opt = _OptHandle(self.ptrainer)
+        self.ema = _EMAHandle(self.ptrainer)
+        self.ema.ema_model.normalizer.to_device(self.device)
+        self._graphed_predict = None
+
+    @property
+    def device(self):
+        return self.accelerator.device
+
+    # ------------------------------------------------------------------------------------------------------ checkpoints
+    def save(self, milestone):
+        if not self.accelerator.is_local_main_process:
+            return
+        data = {
+            'step': self.step,
+            'num_steps_in_env': self.num_steps_in_env,
+            'gcp_model': self.accelerator.get_state_dict(self.gcp_model),
+            'opt': self.opt.state_dict(),
+            'ema': self.ema.state_dict(),
+            'scaler': None,
+            'version': __version__,
+            'cnt_vid_rollouts': self.cnt_vid_rollouts,
+            'cnt_vid_rout_per_tk': self.cnt_vid_rout_per_tk,
+        }
+        savepath = str(self.results_folder / f'model-{milestone}.pt')
+        torch.save(data, savepath)
+        utils.print_color(f'[ utils/training ] Saved model to {savepath}', c='y')
+
+    def load(self, milestone):
+        data = torch.load(str(self.results_folder / f'model-{milestone}.pt'), map_location=self.device, weights_only=False)
+        self.gcp_model.load_state_dict(data['gcp_model'])
+        self.step = data['step']
+        self.num_steps_in_env = data['num_steps_in_env']
+        self.opt.load_state_dict(data['opt'])
+        self.ema.load_state_dict(data['ema'])
+        self.gcp_model.engine.refresh_packs()            # parameters changed behind the packed copies
+        if 'version' in data:
+            print(f"loading from version {data['version']}")
+
+    def encode_batch_text(self, batch_text):
+        ids = self.tokenizer(batch_text, return_tensors='pt', padding=True, truncation=True, max_length=128).to(self.device)
+        return self.text_encoder(**ids).last_hidden_state
+
+    # ---------------------------------------------------------------------------------------------------- env utilities
+    def reset_all_envs(self):
+        self.env_list.check_no_envs_exist()
+
+    def reset_given_envs(self, tasks_str, env_idxs):
+        self.env_list.recreate_given_envs(tasks_str, env_idxs, is_rand=True)
+        for i_sam, tk in enumerate(tasks_str):
+            e_idx = env_idxs[i_sam]
+            assert e_idx in self.task_env_states[tk].keys()
+            self.task_env_states[tk][e_idx] = self.env_list.env_init_states[tk][e_idx]
+
+    def env_get_preproc_imgs(self, tasks_str, cams_str, env_idxs):
+        assert len(tasks_str) == 1
+        imgs = []
+        for i_sam, tk in enumerate(tasks_str):
+            img = self.env_list.render_an_env(tk, cams_str[i_sam], env_idxs[i_sam])
+            assert img.shape[:2] == self.input_img_size
+            imgs.append(img)
+        return self.rendered_imgs_preproc_fn(np.array(imgs))
+
+    def env_get_preproc_img(self, tk, cam_name, env_idx):
+        tmp_img = self.env_list.render_an_env_with_preproc(tk, cam_name, env_idx, imgs_preproc_fn=partial(self.rendered_imgs_preproc_fn))
+        assert tmp_img.shape[1:3] == self.input_img_size
+        return tmp_img
+
+    def get_is_envs_exception(self, tasks_str, env_idxs):
+        return [False for _ in tasks_str]
+
+    def get_new_env_buffer(self, max_num_unitBufs):
+        return ReplayStore(max_num_unitBufs, self.max_len_uB, self.min_len_uB, image_hw=self.input_img_size, act_dim=self.act_dim,
+                           act_len=self.model_act_horizon, device=self.device)
+
+    # --------------------------------------------------------------------------------------------------- schedule logic
+    def update_explo_type(self):
+        """Alternate `explo` / `no-explo` phases per buffer once it holds enough episodes (reference :432-468)."""
+        if not self.enable_noExp:
+            return
+        if len(self.envBuf_rand) >= self.noExp_start_buf_len_rand:
+            if self.explo_type_rand == 'no-explo':
+                self.cnt_no_exp_rand += 1
+            elif self.explo_type_rand == 'explo':
+                self.cnt_exp_rand += 1
+            else:
+                assert False
+        if self.cnt_exp_rand == self.Exp_noExp_rand[0]:
+            self.cnt_exp_rand = 0
+            self.explo_type_rand = 'no-explo'
+        if self.cnt_no_exp_rand == self.Exp_noExp_rand[1]:
+            self.cnt_no_exp_rand = 0
+            self.explo_type_rand = 'explo'
+        if len(self.envBuf_vid) >= self.noExp_start_buf_len_vid:
+            if self.explo_type_vid == 'no-explo':
+                self.cnt_no_exp_vid += 1
+            elif self.explo_type_vid == 'explo':
+                self.cnt_exp_vid += 1
+            else:
+                assert False
+            if self.cnt_exp_vid == self.Exp_noExp_vid[0]:
+                self.cnt_exp_vid = 0
+                self.explo_type_vid = 'no-explo'
+            if self.cnt_no_exp_vid == self.Exp_noExp_vid[1]:
+                self.cnt_no_exp_vid = 0
+                self.explo_type_vid = 'explo'
+
+    def update_iter_type(self):
+        """rand-bias for the first `init_rand_steps`, then cycles of rand_cycle_steps / vid_cycle_steps (reference :942-970)."""
+        if self.step < self.init_rand_steps:
+            self.iter_type = 'rand-bias'
+        elif self.step == self.init_rand_steps:
+            self.rand_iter_cnt = 0
+        elif self.rand_iter_cnt == self.rand_cycle_steps:
+            self.rand_iter_cnt = 0
+            self.iter_type = 'vid-bias'
+        elif self.vid_iter_cnt == self.vid_cycle_steps:
+            self.vid_iter_cnt = 0
+            self.iter_type = 'rand-bias'
+        if self.vid_cycle_steps == 0:
+            self.iter_type = 'rand-bias'
+        elif self.rand_cycle_steps == 0:
+            self.iter_type = 'vid-bias'
+        assert self.iter_type in ['rand-bias', 'vid-bias']
+
+    # -------------------------------------------------------------------------------------------------------- train loop
+    def train_step(self):
+        """Steps 6-7 + the optimiser segment of the reference loop (:558-624) as one device-side step."""
+        loss = self.ptrainer.step()
+        self.step += 1
+        return loss
+
+    def train(self):
+        acc = self.accelerator
+        timer = utils.Timer()
+        self.gcp_model.train()
+        if len(self.envBuf_rand) == 0:                 # (a second train() call in the same process keeps its buffers)
+            print('Start training, fill init rand buf')
+            self.h5_add_rand_act_episodes_to_Buf(0, self.num_init_rand_episodes_per_tk)
+            assert len(self.envBuf_rand) == self.env_list.num_tasks * self.num_init_rand_episodes_per_tk
+            self.h5_randsam_start_idx = self.num_init_rand_episodes_per_tk
+        metrics_path = self.results_folder / 'metrics.jsonl'
+
+        while self.step < self.train_num_steps:
+            self.update_iter_type()
+            self.update_explo_type()
+            if self.step > self.init_rand_steps and self.step % self.video_explo_freq == 0 and self.explo_type_vid == 'explo':
+                self.video_guided_explore()
+            if self.step > self.init_rand_steps and self.step % self.rand_explo_freq == 0 and self.explo_type_rand == 'explo':
+                st_idx = self.h5_randsam_start_idx % self.h5_total_num_ep_per_task
+                n_add = min(self.h5_total_num_ep_per_task - st_idx, self.rand_explo_num_episodes_per_tk)
+                self.h5_add_rand_act_episodes_to_Buf(st_idx, st_idx + n_add)
+                self.h5_randsam_start_idx += n_add
+                if self.h5_randsam_start_idx >= self.h5_total_num_ep_per_task:
+                    self.is_all_randsam_visited = True
+            if self.iter_type == 'rand-bias':
+                self.rand_iter_cnt += 1
+            elif self.iter_type == 'vid-bias':
+                assert len(self.envBuf_rand) > 0 or self.init_rand_steps == -1
+                self.vid_iter_cnt += 1
+            else:
+                raise NotImplementedError()
+
+            loss = self.train_step()
+
+            if acc.is_main_process:
+                if self.step % self.save_freq == 0 or self.step == 1:
+                    self.save(self.step // self.label_freq * self.label_freq)
+                if self.step % self.log_freq == 0 or self.step == 1:
+                    lv = float(loss.item())
+                    print(f'{self.step}: {lv:8.4f} | t: {timer():8.4f}', flush=True)
+                    m = {'train/it': self.step, 'train/loss': lv, 'train/lr': self.ptrainer.opt.hyper['lr'],
+                         'train/num_steps_in_env': self.num_steps_in_env, 'train/cnt_explore_suc': self.cnt_explore_suc,
+                         'buf/len_envBuf_rand': len(self.envBuf_rand), 'buf/len_envBuf_vid': len(self.envBuf_vid),
+                         'explo/cnt_vid_rollouts': self.cnt_vid_rollouts}
+                    m.update(self.make_wandb_dict_per_tk())
+                    with open(metrics_path, 'a') as f:
+                        f.write(json.dumps(m) + '\n')
+                if self.sample_freq and self.step % self.sample_freq == 0:
+                    self.ema.ema_model.eval()
+        acc.print('training complete')
+
+    # ------------------------------------------------------------------------------------------------------ buffer input
+    def h5_add_rand_act_episodes_to_Buf(self, start_ep_idx, end_ep_idx):
+        """Random-action episodes [start, end) of every task -> envBuf_rand (reference :718-780): range check (+-0.012 slack),
+        clip to the action limits, uint8 frames go to HBM as they are."""
+        len_before = len(self.envBuf_rand)
+        for i_t, tk in enumerate(self.task_list):
+            for i_ep in range(start_ep_idx, end_ep_idx):
+                if i_ep >= self.h5_total_num_ep_per_task:
+                    assert not self.randsam.has(tk, i_ep)
+                    break
+                imgs_ep, acts_ep = self.randsam.episode(tk, i_ep)
+                assert (acts_ep > self.act_min_np[None] - 0.012).all()
+                assert (acts_ep < self.act_max_np[None] + 0.012).all()
+                acts_ep = np.clip(acts_ep, a_min=self.act_min_np[None], a_max=self.act_max_np[None]).astype(np.float32)
+                assert len(imgs_ep) - 1 == len(acts_ep)
+                if not self.is_all_randsam_visited:
+                    self.num_steps_in_env += len(acts_ep)
+                tmp_e_idx = self.env_list.seed_sets[tk][0]
+                self.envBuf_rand.add_one_episode(tk, self.env_list.camera_list[0], tmp_e_idx, torch.from_numpy(np.ascontiguousarray(imgs_ep)),
+                                                 torch.from_numpy(acts_ep))
+        utils.print_color(f'[Rand Buf Size Before Load] ep {len_before}', c='y')
+        utils.print_color(f'[Rand Buf Size After Load] ep {len(self.envBuf_rand)}', c='y')
+
+    def sample_from_bufs(self):
+        """(imgs_start, imgs_goal, acts, tasks_str, info) with the reference's mixing rule (:787-851); tensors are on the GPU."""
+        return sample_mixed(self.envBuf_rand, self.envBuf_vid, self.buf_sample_batch_size, self.buf_sample_randBuf_prob)
+
+    # ------------------------------------------------------------------------------------------- video-guided exploration
+    def video_guided_explore(self):
+        """For every (task, cam, env) of this rank: predict a goal video, follow it, store the episode (reference :859-938)."""
+        self.reset_all_envs()
+        buf_len_0 = len(self.envBuf_vid)
+        utils.print_color(f'[Vid Exp] self.step {self.step}', c='y')
+        for _, batch in enumerate(self.dl_vid):
+            tasks_str, cams_str, env_idxs = batch
+            tasks_str, cams_str = list(tasks_str), list(cams_str)
+            env_idxs = env_idxs.cpu().numpy()
+            assert len(tasks_str) == 1
+            self.env_list.init_1_given_env(tk_name=tasks_str[0], env_idx=env_idxs[0], is_rand=True)
+            imgs_start = self.env_get_preproc_imgs(tasks_str, cams_str, env_idxs)
+            with torch.no_grad():
+                preds_video = self.video_model.forward(imgs_start.to(self.device), tasks_str)
+            batch_imgs, batch_acts = self.envs_video_guided_execute(tasks_str, cams_str, env_idxs, imgs_start, preds_video)
+            is_except = self.get_is_envs_exception(tasks_str, env_idxs)
+            self.env_list.close_1_given_env(tk_name=tasks_str[0], env_idx=env_idxs[0])
+            for i_sam, tk in enumerate(tasks_str):
+                if is_except[i_sam]:
+                    continue
+                self.envBuf_vid.add_one_episode(tk, cams_str[i_sam], env_idxs[i_sam], batch_imgs[i_sam], batch_acts[i_sam])
+        utils.print_color(f'Finish Vid Explore, vid buf before: {buf_len_0}, after: {len(self.envBuf_vid)}')
+        self.reset_all_envs()
+
+    def _predict(self, img_st, img_goal):
+        """EMA policy, DDIM-8: `[1,3,H,W]` start / goal -> clamped actions [n_acts_per_pred, 7] on the host."""
+        batch = self.to_batch_dict(img_st, img_goal, None)
+        if self.trainer_dict.get('graphed_rollout', False):
+            from v2a_hip.inference import GraphedPredictAction
+            ema = self.ema.ema_model                                   # refreshes the packed EMA weights if stale
+            if self._graphed_predict is None:
+                self._graphed_predict = GraphedPredictAction(ema, batch_size=1, use_ddim=True, seed=self.trainer_dict.get('seed', 0))
+            act = self._graphed_predict(batch['obs'])['action'].cpu()
+        else:
+            act = self.ema.ema_model.predict_action(batch['obs'], use_ddim=True)['action'].cpu()
+        act = act[0]
+        assert len(act) == self.n_acts_per_pred
+        return act.clamp(min=self.act_min, max=self.act_max)
+
+    def envs_video_guided_execute(self, tasks_str, cams_str, env_idxs, imgs_start, preds_video, vis_rollout=False):
+        """Follow each predicted frame for n_preds policy calls of n_acts_per_pred actions; close the gripper and descend when the
+        wrist depth says an object is under the fingers (reference :995-1291).  Returns per sample a uint8 [T+1,H,W,3] frame
+        array and a float [T,7] action tensor."""
+        preds_video = preds_video.detach().to(self.device)
+        assert imgs_start.shape[2:4] == self.input_img_size
+        v_hzn = len(preds_video[0])
+        assert v_hzn == self.video_model.video_future_horizon
+        batch_imgs_out_dense, batch_acts_out = [], []
+        for i_sam, tk in enumerate(tasks_str):
+            pred_v = preds_video[i_sam]
+            img_st = imgs_start[i_sam:i_sam + 1]
+            env_idx, cam = env_idxs[i_sam], cams_str[i_sam]
+            is_suc = False
+            frames = [self.env_list.render_an_env(tk, cam, env_idx)]            # uint8 HWC: what the store keeps
+            acts_out = []
+            do_grasp = False
+            num_acc_acts = 0
+
+            def step_and_record(a):
+                _, _, done, _ = self.env_list.step_an_env(tk, env_idx, a.numpy())
+                frames.append(self.env_list.render_an_env(tk, cam, env_idx))
+                return done
+
+            for g_idx in range(v_hzn):
+                img_goal = pred_v[None, g_idx]
+                n_preds = random.randint(*self.n_preds_betw_vframes)
+                for i_p in range(n_preds):
+                    with torch.no_grad():
+                        act = self._predict(img_st.to(self.device), img_goal)
+                    act[:, -1] = self.close_grp_force if do_grasp else -self.close_grp_force
+                    e_done = False
+                    for i_a in range(self.n_acts_per_pred):
+                        e_done = step_and_record(act[i_a])
+                        self.num_steps_in_env += 1
+                    is_suc = e_done or is_suc
+                    img_st = self.rendered_imgs_preproc_fn(frames[-1][None])
+                    acts_out.append(act)
+                    num_acc_acts += len(act)
+
+                    # ---- grasp heuristic on the wrist depth
+                    grp_depth = self.env_list.render_an_env_with_depth(tk, self.grp_cam_name, env_idx)[1]
+                    assert grp_depth.shape[:2] == (128, 128)
+                    assert (grp_depth >= 0).all(), 'sanity check'
+                    h, w = grp_depth.shape[:2]
+                    h_st, h_e = round(h * 0.75), round(h * 0.82)
+                    w_st, w_e = round(w * 0.35), round(w * 0.65)
+                    d_m = np.mean(grp_depth[h_st:h_e, w_st:w_e])
+                    ee_pos = self.env_list.get_an_env_obs(tk, env_idx)['robot0_eef_pos']
+                    assert ee_pos.shape == (3,)
+                    z_diff = np.abs(ee_pos[2] - d_m).item()
+                    if z_diff > self.grasp_z_diff_limit and ee_pos[2] < self.grasp_abs_z_limit and not do_grasp:
+                        do_grasp = True
+                        assert self.control_mode == 'delta'
+                        n_acts_down = random.randint(self.n_acts_down_range[0], self.n_acts_down_range[1])
+                        if self.act_down_val is None:
+                            actd_rg = self.act_down_val_range_per_tk[self.env_list.task_to_task_idx[tk]]
+                            down_val = np.random.uniform(low=actd_rg[0], high=actd_rg[1], size=1).item()
+                        else:
+                            down_val = self.act_down_val
+                        assert down_val <= 0
+                        act_down = torch.tensor([[0, 0, down_val, 0, 0, 0, 0]] * n_acts_down)
+                        for i_a in range(len(act_down)):
+                            step_and_record(act_down[i_a])
+                        acts_out.append(act_down)
+                        act_grasp = torch.tensor([[0, 0, self.close_grp_act_down_val, 0, 0, 0, self.close_grp_force]] * self.n_acts_close_grp)
+                        for i_a in range(len(act_grasp)):
+                            step_and_record(act_grasp[i_a])
+                        acts_out.append(act_grasp)
+                        img_st = self.rendered_imgs_preproc_fn(frames[-1][None])
+                        num_acc_acts += len(act_down) + len(act_grasp)
+                if is_suc and self.is_stop_at_suc:
+                    break
+
+            acts_cat = torch.cat(acts_out).float()
+            assert len(frames) == len(acts_cat) + 1
+            assert num_acc_acts == len(acts_cat)
+            batch_imgs_out_dense.append(torch.from_numpy(np.stack(frames)))
+            batch_acts_out.append(acts_cat)
+            if is_suc:
+                self.cnt_explore_suc += 1
+                self.cnt_explo_suc_per_tk[tk] += 1
+            self.cnt_vid_rollouts += 1
+            self.cnt_vid_rout_per_tk[tk] += 1
+        return batch_imgs_out_dense, batch_acts_out
+
+    # ------------------------------------------------------------------------------------------------------------ misc
+    def to_batch_dict(self, imgs_start, imgs_goal, acts_gt, goal_embed=None):
+        assert imgs_start.ndim == 4
+        batch = dict(obs={'img_obs_1': imgs_start[:, None, ...], 'img_goal_1': imgs_goal[:, None, ...]})
+        if acts_gt is not None:
+            assert acts_gt.ndim == 3 and acts_gt.shape[-1] == 7
+            batch['action'] = acts_gt
+        return batch
+
+    def make_wandb_dict_per_tk(self):
+        m = {}
+        for tk in self.cnt_vid_rout_per_tk:
+            m[f'explo/{tk}-cnt_vid_rollouts'] = self.cnt_vid_rout_per_tk[tk]
+            m[f'explo/{tk}-cnt_explore_suc_vsR'] = self.cnt_explo_suc_per_tk[tk]
+        return m

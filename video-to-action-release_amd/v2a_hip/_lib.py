@@ -63,6 +63,8 @@ SIGNATURES = {
     "v2a_opt_state_bytes": (SZ, []),
     "v2a_opt_state_init": (I, [P, D, D, D, D, D, D, D, D, D, D, I, I]),
     "v2a_opt_state_peek": (I, [P, P, P, P, P]),
+    "v2a_opt_state_counters": (I, [P, P, P, P]),
+    "v2a_opt_state_set_counters": (I, [P, LL, LL, I, D]),
     "v2a_opt_step": (I, [P, P, I, P, P, I, P]),
     "v2a_opt_scale_grads": (I, [P, P, I, F, P]),
     "v2a_replay_sample_indices": (I, [P, P, P, I, I, I, P, P]),

@@ -36,6 +36,10 @@ class FusedAdamWEMA:
                                      ema_power, ema_min_value, ema_beta, ema_update_after_step, ema_update_every), "opt_state_init")
         self.state = torch.frombuffer(bytearray(host), dtype=torch.uint8).clone().to(self.device)
         self._nb = nb
+        self.hyper = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        self._offsets = [0]
+        for p in params:
+            self._offsets.append(self._offsets[-1] + p.numel())
 
     def step(self, zero_grad=True):
         check(lib.v2a_opt_step(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
@@ -53,3 +57,59 @@ class FusedAdamWEMA:
         st = ctypes.c_longlong()
         lib.v2a_opt_state_peek(ctypes.addressof(buf), ctypes.byref(gn), ctypes.byref(cc), ctypes.byref(st), ctypes.byref(dec))
         return gn.value, cc.value, st.value, dec.value
+
+    # ------------------------------------------------------------------ checkpointing (lb_online_trainer_v7.py:367-408)
+    def counters(self):
+        """(AdamW step, EMA step, EMA initted) -- synchronises."""
+        host = self.state.cpu().numpy().tobytes()
+        buf = ctypes.create_string_buffer(host, len(host))
+        st, es, ini = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
+        check(lib.v2a_opt_state_counters(ctypes.addressof(buf), ctypes.byref(st), ctypes.byref(es), ctypes.byref(ini)), "opt_state_counters")
+        return st.value, es.value, bool(ini.value)
+
+    def set_counters(self, step, ema_step, ema_initted, lr=0.0):
+        host = self.state.cpu().numpy().tobytes()
+        buf = ctypes.create_string_buffer(host, len(host))
+        check(lib.v2a_opt_state_set_counters(ctypes.addressof(buf), int(step), int(ema_step), 1 if ema_initted else 0, float(lr)),
+              "opt_state_set_counters")
+        self.state.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+
+    def state_dict(self, order=None):
+        """torch.optim.AdamW's layout ({'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}).  `order[i]` = index
+        into this optimiser's tensor list of the i-th entry of the checkpoint's parameter list, or -1 for a parameter the optimiser
+        was given but never updates (no gradient: torch keeps no state for those either).  Default: identity."""
+        step = self.counters()[0]
+        order = list(range(len(self.params))) if order is None else list(order)
+        state = {}
+        if step > 0:
+            for i, j in enumerate(order):
+                if j < 0:
+                    continue
+                lo, hi = self._offsets[j], self._offsets[j + 1]
+                shp = self.params[j].shape
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.m[lo:hi].view(shp).clone(),
+                            "exp_avg_sq": self.v[lo:hi].view(shp).clone()}
+        group = dict(lr=self.hyper["lr"], betas=self.hyper["betas"], eps=self.hyper["eps"], weight_decay=self.hyper["weight_decay"],
+                     amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(order))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd, order=None, ema_step=None, ema_initted=None):
+        order = list(range(len(self.params))) if order is None else list(order)
+        step = 0
+        for i, j in enumerate(order):
+            if j < 0:
+                continue
+            ent = sd["state"].get(i)
+            lo, hi = self._offsets[j], self._offsets[j + 1]
+            if ent is None:
+                self.m[lo:hi].zero_()
+                self.v[lo:hi].zero_()
+                continue
+            self.m[lo:hi].copy_(ent["exp_avg"].reshape(-1))
+            self.v[lo:hi].copy_(ent["exp_avg_sq"].reshape(-1))
+            step = int(float(ent["step"]))
+        _, es, ini = self.counters()
+        lr = float(sd["param_groups"][0]["lr"])
+        self.hyper["lr"] = lr
+        self.set_counters(step, es if ema_step is None else ema_step, ini if ema_initted is None else ema_initted, lr=lr)

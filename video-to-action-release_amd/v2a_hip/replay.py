@@ -62,21 +62,50 @@ def count_uniform_below(batch: int, prob: float) -> int:
 
 class ReplayStore:
     def __init__(self, max_episodes, max_len, min_len, image_hw=(128, 128), act_dim=7, act_len=16, device="cuda:0",
-                 capacity_frames=None, dtype=torch.uint8):
+                 capacity_frames=None, dtype=torch.uint8, pool=None, pool_offset=0):
+        """`pool` = (frames, acts) root tensors shared by several stores (see `ReplayStore.pair`): this store then owns rows
+        [pool_offset, pool_offset + capacity_frames) of them, and one gather launch can read rows of every store in the pool."""
         self.max_episodes, self.max_len, self.min_len = max_episodes, max_len, min_len
         self.H, self.W = image_hw
         self.act_dim, self.act_len = act_dim, act_len
         self.device = torch.device(device)
         self.dtype = dtype
         cap = capacity_frames or max_episodes * 160
-        self.frames = torch.empty((cap, self.H, self.W, 3), dtype=dtype, device=self.device)
-        self.acts = torch.zeros((cap, act_dim), dtype=torch.float32, device=self.device)
+        if pool is None:
+            self.root_frames = torch.empty((cap, self.H, self.W, 3), dtype=dtype, device=self.device)
+            self.root_acts = torch.zeros((cap, act_dim), dtype=torch.float32, device=self.device)
+            pool_offset = 0
+        else:
+            self.root_frames, self.root_acts = pool
+            assert self.root_frames.dtype == dtype and pool_offset + cap <= self.root_frames.shape[0]
+        self.base = int(pool_offset)                 # first pool row of this store
+        self.frames = self.root_frames[self.base:self.base + cap]
+        self.acts = self.root_acts[self.base:self.base + cap]
         self.episodes = deque()          # (offset, length, task, cam, env_idx) in insertion order, FIFO eviction
         self._head = 0                   # ring allocation pointer
         self.cnt_all_history_episodes = 0
 
+    @classmethod
+    def pair(cls, max_episodes_a, max_episodes_b, max_len, min_len, capacity_a=None, capacity_b=None, **kw):
+        """Two stores over one HBM pool -- the reference's envBuf_rand / envBuf_vid (lb_online_trainer_v7.py:211-215) -- so that a
+        mixed minibatch (sample_from_bufs, :787-851) is one gather launch over pool-absolute frame rows."""
+        ca = capacity_a or max_episodes_a * 160
+        cb = capacity_b or max_episodes_b * 320
+        H, W = kw.get("image_hw", (128, 128))
+        dev = torch.device(kw.get("device", "cuda:0"))
+        dtype = kw.get("dtype", torch.uint8)
+        frames = torch.empty((ca + cb, H, W, 3), dtype=dtype, device=dev)
+        acts = torch.zeros((ca + cb, kw.get("act_dim", 7)), dtype=torch.float32, device=dev)
+        a = cls(max_episodes_a, max_len, min_len, capacity_frames=ca, pool=(frames, acts), pool_offset=0, **kw)
+        b = cls(max_episodes_b, max_len, min_len, capacity_frames=cb, pool=(frames, acts), pool_offset=ca, **kw)
+        return a, b
+
     def __len__(self):
         return len(self.episodes)
+
+    def pool_rows(self, ep, start):
+        """Pool-absolute first-frame rows of the drawn (episode, start) pairs."""
+        return np.array([self.episodes[int(e)][0] for e in ep], dtype=np.int64) + np.asarray(start, dtype=np.int64) + self.base
 
     def _alloc(self, n):
         cap = self.frames.shape[0]

@@ -12,18 +12,26 @@ gradients per step (issued as two asynchronous slice all-reduces: the Conditiona
 backward), averaged by folding 1/world into the optimiser's gradient scale.
 """
 import copy
+import numpy as np
 import torch
 from . import ops
 from .optim import FusedAdamWEMA
-from .replay import ReplayStore, sample_indices  # noqa: F401  (ReplayStore: the type of `store`)
+from .replay import ReplayStore, sample_indices, count_uniform_below
 from ._lib import lib, check
 
 
 class PolicyTrainer:
     def __init__(self, policy, store: ReplayStore, batch_size=64, opt_params=None, ema_params=None, seed=0, use_graph=True,
-                 process_group=None, world_size=1, rank=0):
+                 process_group=None, world_size=1, rank=0, store_vid: ReplayStore = None, rand_prob=0.3):
+        """`store_vid` (optional, same HBM pool as `store`: ReplayStore.pair) is the video-guided-rollout buffer; minibatches
+        then follow sample_from_bufs' 'rand_prob' rule (lb_online_trainer_v7.py:787-851): all rows from `store` while `store_vid` is
+        empty, otherwise n_rand = #(U[0,1) < rand_prob) rows from `store` first and the rest from `store_vid`."""
         self.policy = policy
         self.store = store
+        self.store_vid = store_vid
+        self.rand_prob = rand_prob
+        if store_vid is not None:
+            assert store_vid.root_frames.data_ptr() == store.root_frames.data_ptr(), "build the two stores with ReplayStore.pair"
         self.B = batch_size
         self.eng = policy.engine
         self.device = self.eng.device
@@ -69,12 +77,25 @@ class PolicyTrainer:
 
     # ------------------------------------------------------------------ pieces
     def _draw_indices(self):
-        ep, st = sample_indices(self.store.episode_lengths(), self.B, self.store.act_len)
-        offs = [self.store.episodes[int(e)][0] + int(s) for e, s in zip(ep, st)]
+        sv = self.store_vid
+        if sv is None or len(sv) == 0:
+            ep, st = sample_indices(self.store.episode_lengths(), self.B, self.store.act_len)
+            offs = self.store.pool_rows(ep, st)
+        elif len(self.store) == 0:
+            ep, st = sample_indices(sv.episode_lengths(), self.B, sv.act_len)
+            offs = sv.pool_rows(ep, st)
+        else:
+            n_rand = count_uniform_below(self.B, self.rand_prob)
+            if n_rand == 0 or n_rand == self.B:
+                raise RuntimeError("stack expects a non-empty TensorList")     # the reference's torch.stack([]) on an empty draw
+            e0, s0 = sample_indices(self.store.episode_lengths(), n_rand, self.store.act_len)
+            e1, s1 = sample_indices(sv.episode_lengths(), self.B - n_rand, sv.act_len)
+            offs = np.concatenate([self.store.pool_rows(e0, s0), sv.pool_rows(e1, s1)])
+            ep, st = (e0, e1), (s0, s1)
         slot = self.step_count % len(self._fs_ring)
         if self._fs_evt[slot] is not None:
             self._fs_evt[slot].synchronize()
-        self._fs_ring[slot].copy_(torch.tensor(offs, dtype=torch.int64))
+        self._fs_ring[slot].copy_(torch.from_numpy(np.asarray(offs, dtype=np.int64)))
         self.frame_start.copy_(self._fs_ring[slot], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -87,7 +108,7 @@ class PolicyTrainer:
         o0 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
         o1 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
         oa = torch.empty((B, st.act_len, st.act_dim), dtype=torch.float32, device=self.device)
-        check(lib.v2a_replay_gather(st.frames.data_ptr(), 1 if st.dtype == torch.uint8 else 0, st.acts.data_ptr(),
+        check(lib.v2a_replay_gather(st.root_frames.data_ptr(), 1 if st.dtype == torch.uint8 else 0, st.root_acts.data_ptr(),
                                     self.frame_start.data_ptr(), o0.data_ptr(), o1.data_ptr(), oa.data_ptr(), B, st.H, st.W,
                                     st.act_len, st.act_dim, 0, 1, ops._stream()), "replay_gather")
         n_noise = self.noise.numel()
