@@ -126,6 +126,21 @@ int v2a_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int N, i
 int v2a_spatial_softmax_fwd(const float* feat, float* kp, float* att, int B, int H, int W, int K, v2a_stream_t s);
 int v2a_spatial_softmax_bwd(const float* att, const float* kp, const float* dkp, float* dfeat, int B, int H, int W, int K, v2a_stream_t s);
 
+/* ------------------------------------------------------------------------------------- bf16-storage convolution (csrc/igemm_h.hip)
+ * The reference's GPU path runs the video UNet under fp16 autocast (diffuser/libero/lb_online_trainer_v7.py:889,
+ * guided_diffusion/guided_diffusion/nn.py:53-87 Conv3d); this is that configuration on gfx950: activations and packed weights are
+ * bf16 in HBM, accumulation fp32, epilogue (bias + embedding row vector + residual) in fp32 registers.
+ * x / x2 / residual / y: bf16 channels-last; w_packed: bf16 [Cout][KH][KW][C1+C2] (v2a_pack_weight_h); bias / rowvec: fp32;
+ * exactly one of y (bf16) / y_f32 non-null; zeros: >= 128 zero bytes (padding taps read it).  C1 % 64 == C2 % 64 == 0. */
+size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K);
+int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
+                     void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh,
+                     int sw, int ph, int pw, int ups, int OH, int OW, int rows_per_batch, void* workspace, size_t workspace_bytes,
+                     v2a_stream_t s);
+int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, v2a_stream_t s);   /* [Cout][Cin][taps] f32 -> [Cout][taps][Cin] bf16 */
+int v2a_cast_f32_bf16(const float* x, void* y, size_t n, v2a_stream_t s);
+int v2a_cast_bf16_f32(const void* x, float* y, size_t n, v2a_stream_t s);
+
 /* ---------------------------------------------------------------------------------------------- optimiser (csrc/optim.hip)
  * clip_grad_norm_(1.0) -> AdamW.step -> zero_grad -> EMA.update  (diffuser/libero/lb_online_trainer_v7.py:604-624;
  * hyper-parameters config/libero/lb_tk8_65to72.py:138-153).  table_dev: int64 [n_tensors][6] = {p, g, m, v, ema, numel};

@@ -351,3 +351,68 @@ def test_groupnorm_large_path_odd_group_width():
     close(dx.permute(0, 2, 1), x.grad, what="gn dx cg=5")
     close(dg, gamma.grad, what="gn dgamma cg=5")
     close(db, beta.grad, what="gn dbeta cg=5")
+
+
+# ------------------------------------------------------------------------------------------------ bf16-storage family
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    dict(N=3, H=20, W=24, C1=128, C2=0, Co=192, k=3, s=1, ups=False),          # ragged M (1440 rows), Cout not a tile multiple
+    dict(N=2, H=16, W=16, C1=64, C2=128, Co=128, k=3, s=1, ups=False),         # two-source concat
+    dict(N=2, H=17, W=19, C1=64, C2=0, Co=64, k=3, s=2, ups=False),            # stride 2, odd extents
+    dict(N=2, H=8, W=8, C1=128, C2=0, Co=128, k=3, s=1, ups=True),             # folded nearest x2 upsample
+    dict(N=1, H=1, W=300, C1=256, C2=0, Co=3, k=1, s=1, ups=False, f32=True),   # 1x1 / linear, tiny Cout, fp32 output
+    dict(N=4, H=8, W=8, C1=1280, C2=0, Co=640, k=3, s=1, ups=False),           # deep K -> split-K path
+    dict(N=2, H=7, W=256, C1=128, C2=0, Co=128, k=(3, 1), s=1, ups=False),     # temporal (3x1) view
+])
+def test_conv2d_h_matches_fp32_reference_on_bf16_inputs(case):
+    from v2a_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, H, W, C1, C2, Co = case["N"], case["H"], case["W"], case["C1"], case["C2"], case["Co"]
+    kh, kw = (case["k"], case["k"]) if isinstance(case["k"], int) else case["k"]
+    s, ups = case["s"], case["ups"]
+    x = _bf(torch.randn(N, H, W, C1, generator=g)).to(dev)
+    x2 = _bf(torch.randn(N, H, W, C2, generator=g)).to(dev) if C2 else None
+    w = (torch.randn(Co, C1 + C2, kh, kw, generator=g) * 0.05).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    wp = ops.pack_weight_h(w)
+    # fp32 reference on exactly the bf16-rounded operands
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+    wq = w.to(torch.bfloat16).float()
+    ref = torch.nn.functional.conv2d(xin.double(), wq.double(), b.double(), stride=s, padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1)
+    OH, OW = ref.shape[1], ref.shape[2]
+    rowvec = torch.randn(N, Co, generator=g).to(dev)
+    res = _bf(torch.randn(N, OH, OW, Co, generator=g)).to(dev)
+    ref = ref + rowvec.double()[:, None, None, :] + res.double()
+    y = ops.conv2d_h(x, wp, b, Co, kh, kw, (s, s), (kh // 2, kw // 2), x2=x2, rowvec=rowvec, rows_per_batch=OH * OW, residual=res,
+                     ups=ups, out_f32=case.get("f32", False))
+    assert y.shape == (N, OH, OW, Co)
+    scale = ref.abs().max().item()
+    if case.get("f32", False):
+        assert y.dtype == torch.float32
+        assert (y.double() - ref).abs().max().item() <= 2e-5 * scale            # fp32 accumulation order only
+    else:
+        assert y.dtype == torch.bfloat16
+        # one bf16 rounding of the exact result: |err| <= 2^-9 |ref| (+ accumulation noise)
+        err = (y.double() - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * scale).all()
+
+
+@pytest.mark.gpu
+def test_cast_roundtrip_and_pack_weight_h():
+    from v2a_hip import ops
+    dev = "cuda:0"
+    x = torch.randn(4099 * 4, device=dev)
+    h = ops.cast_h(x)
+    assert torch.equal(h, x.to(torch.bfloat16))                                   # round-to-nearest-even like torch
+    assert torch.equal(ops.cast_f(h), h.float())
+    w = torch.randn(5, 64, 3, 3, device=dev)
+    p = ops.pack_weight_h(w).view(5, 3, 3, 64)
+    assert torch.equal(p, w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16))

@@ -1,0 +1,351 @@
+// Implicit-GEMM convolution over bf16 activations / bf16 weights with fp32 accumulation: the "bf16 storage" configuration of the
+// video UNet (the reference's GPU path runs these layers under fp16 autocast: flowdiffusion/flowdiffusion/goal_diffusion.py +
+// diffuser/libero/lb_online_trainer_v7.py:889 `accelerator.autocast()`; guided_diffusion/guided_diffusion/nn.py:53-87 Conv3d).
+//
+//   y[m][n] = sum_k A[m][k] * W[n][k] + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]
+//   A[m][k] = x[img, oh*s - p + kh, ow*s - p + kw, ci]   (k = (kh, kw, ci); optional second source = channel concat; optional
+//             nearest x2 upsample folded into the gather), x channels-last bf16, W = [Cout][KH][KW][Cin] bf16.
+//
+// Data movement (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
+//   * 128 x 128 output tile per 256-thread workgroup, k tile = 64 bf16 = one full 128-B line per tile row, which by the layer
+//     shapes (Cin % 64 == 0) always lies inside ONE filter tap -> every row segment is one contiguous 128-B global read;
+//   * both operands go HBM/L2 -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane, no staging VGPRs, no ds_write pass);
+//     the LDS image of a DMA is lane-linear, so the bank swizzle is applied on the SOURCE side: LDS slot (row r, position p)
+//     receives the row's 16-B chunk p ^ ((r >> 1) & 7).  The ds_read_b128 operand fetches of the 32x32x16 MFMA are then
+//     conflict-free in every one of the instruction's four 16-lane groups;
+//   * out-of-image taps (zero padding) and rows past M read a 128-B zero line in global memory instead of branching;
+//   * two LDS buffers (64 KB -> two workgroups per CU): the DMA of tile t+1 is in flight while tile t is multiplied; one
+//     barrier per k tile;
+//   * epilogue in registers: bias, per-(batch, channel) embedding vector, residual, then bf16 (or fp32) stores; split-K writes
+//     fp32 slabs and a second kernel finishes (only the small 8x8 / 16x16 levels need it).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct FastDivH {
+    uint32_t d, m, s;
+};
+static inline FastDivH make_fastdiv_h(uint32_t d) {
+    FastDivH f;
+    f.d = d;
+    if (d <= 1) { f.m = 0; f.s = 0; return f; }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdivh(uint32_t n, const FastDivH& f) {
+    if (f.d <= 1) return n;
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> 1)) >> (f.s - 1);
+}
+
+struct ConvDescH {
+    const uint16_t* x;        // source 1: [N, H, W, C1] bf16
+    const uint16_t* x2;       // source 2 (concat along C) or null
+    const uint16_t* w;        // [Cout][KH*KW*(C1+C2)] bf16
+    const float* bias;        // [Cout] or null
+    const float* rowvec;      // [M / rows_per_batch][Cout] or null
+    const uint16_t* residual; // [M][Cout] bf16 or null
+    uint16_t* y;              // [M][Cout] bf16 (null when yf is used)
+    float* yf;                // [M][Cout] fp32 output instead of bf16
+    float* partial;           // split-K slabs [splitk][M][Cout]
+    const uint16_t* zeros;    // >= 128 B of zeros
+    int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, ups, HL, WL, M, K;
+    int rows_per_batch, splitk, ktiles_per_split;
+    FastDivH fd_ow, fd_oh;
+};
+
+__device__ __forceinline__ int xcd_remap_h(int bid, int nblk) {
+    int q = nblk >> 3, r = nblk & 7;
+    int xcd = bid & 7, slot = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
+    constexpr int ROWB = 128;                       // bytes per tile row (64 bf16)
+    constexpr int AL = BM / 32, BL = BN / 32;       // DMA pieces per thread per tile (32 rows x 8 chunks per 256-thread pass)
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int BUF = (BM + BN) * ROWB;
+    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * BUF];      // ONE LDS object (A0 B0 A1 B1)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nkt = p.K >> 6;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+
+    // ---- DMA source state.  Pass j of the 256 threads fills rows j*32 .. j*32+31; this thread's slot is (row j*32 + tid/8,
+    // position tid%8) and carries the row's chunk (tid%8) ^ swz with swz = ((row >> 1) & 7) = ((tid >> 4) & 7) for every j.
+    const int lrow = tid >> 3;
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    int a_ihb[AL], a_iwb[AL], a_img[AL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int m = m0 + j * 32 + lrow;
+        const bool ok = m < p.M;
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t t = fdivh(mm, p.fd_ow);
+        const int ow = (int)(mm - t * p.OW);
+        const uint32_t img = fdivh(t, p.fd_oh);
+        const int oh = (int)(t - img * p.OH);
+        a_img[j] = (int)img;
+        a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);       // rows past M fail the bounds test below
+        a_iwb[j] = ow * p.sw - p.pw;
+    }
+    const uint16_t* b_src[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        b_src[j] = (n < p.Cout) ? p.w + (size_t)n * p.K + chunk * 8 : nullptr;
+    }
+    const uint16_t* zsrc = p.zeros + chunk * 8;
+
+    // running (tap, channel) position of the next k tile to issue
+    int ik0 = kt_begin * 64;
+    int itap = ik0 / Cin;
+    int ic0 = ik0 - itap * Cin;
+    int ikh = itap / p.KW, ikw = itap - ikh * p.KW;
+
+    auto issue = [&](int buf) {
+        unsigned char* abase = smem + buf * BUF;
+        unsigned char* bbase = abase + BM * ROWB;
+        const bool first = ic0 < p.C1;
+        const uint16_t* src = first ? p.x : p.x2;
+        const int Cs = first ? p.C1 : p.C2;
+        const int cc = (first ? ic0 : ic0 - p.C1) + chunk * 8;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
+            const bool ok = ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            const uint16_t* g = ok ? src + (((size_t)a_img[j] * p.H + ih) * p.W + iw) * Cs + cc : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const uint16_t* g = b_src[j] ? b_src[j] + ik0 : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+        ik0 += 64;
+        ic0 += 64;
+        if (ic0 >= Cin) {
+            ic0 = 0;
+            if (++ikw == p.KW) { ikw = 0; ++ikh; }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int rswz = (lr >> 1) & 7;                 // (row >> 1) & 7 of every operand row this lane reads (wm, i*32 are multiples of 16)
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = (wm + i * 32 + lr) * ROWB;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j] = BM * ROWB + (wn + j * 32 + lr) * ROWB;
+
+    if (kt_begin < kt_end) issue(0);
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                            // tile kt landed everywhere; everyone is done reading the other buffer
+        if (kt + 1 < kt_end) issue(buf ^ 1);
+        const unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int pos = (((h << 1) | lk) ^ rswz) << 4;
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + pos);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + b_off[j] + pos);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // ---- epilogue (C layout of the 32x32 MFMA: lane -> column lr, rows (r & 3) + 8 * (r >> 2) + 4 * lk)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 32 + lr;
+            if (n >= p.Cout) continue;
+            const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                const size_t o = (size_t)m * p.Cout + n;
+                if (p.splitk > 1) {
+                    p.partial[(size_t)split * p.M * p.Cout + o] = v;
+                } else {
+                    v += bv;
+                    if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
+                    if (p.residual) v += bf2f(p.residual[o]);
+                    if (p.yf) p.yf[o] = v;
+                    else p.y[o] = f2bf(v);
+                }
+            }
+        }
+}
+
+__global__ void conv_splitk_reduce_h(const ConvDescH p) {
+    const size_t total = (size_t)p.M * p.Cout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / p.Cout), n = (int)(idx - (size_t)m * p.Cout);
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; ++s) v += p.partial[(size_t)s * total + idx];
+        if (p.bias) v += p.bias[n];
+        if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
+        if (p.residual) v += bf2f(p.residual[idx]);
+        if (p.yf) p.yf[idx] = v;
+        else p.y[idx] = f2bf(v);
+    }
+}
+
+// torch [Cout][Cin][taps] fp32 -> [Cout][taps][Cin] bf16 (round to nearest even); taps == 1 is a plain cast
+__global__ void pack_weight_h_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int taps) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Cin);
+        const size_t t = idx / Cin;
+        const int tap = (int)(t % taps);
+        const int co = (int)(t / taps);
+        out[idx] = f2bf(w[((size_t)co * Cin + ci) * taps + tap]);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        uint2 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        reinterpret_cast<uint2*>(y)[i] = o;
+    }
+}
+__global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint2 u = reinterpret_cast<const uint2*>(x)[i];
+        f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+static void conv_plan_h(int M, int Cout, int K, int* tiles, int* s) {
+    *tiles = cdiv(M, 128) * cdiv(Cout, 128);
+    int sp = 1;
+    const int nkt = K / 64;
+    while (*tiles * sp < 448 && nkt / (sp * 2) >= 6 && sp < 16) sp *= 2;      // >= ~2 workgroups per CU, >= 6 k tiles per slice
+    *s = sp;
+}
+
+extern "C" {
+
+size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
+    int tiles, s;
+    conv_plan_h(M, Cout, K, &tiles, &s);
+    return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
+}
+
+// bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
+// exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned x / x2 / w; zeros: >= 128 zero bytes.
+int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
+                     void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh,
+                     int sw, int ph, int pw, int ups, int OH, int OW, int rows_per_batch, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream) {
+    if (!x || !w_packed || !zeros || (!y == !y_f32) || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
+    if (C1 <= 0 || C1 % 64 || C2 < 0 || C2 % 64 || (C2 > 0 && !x2)) return V2A_ERR_ARG;
+    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)w_packed | (uintptr_t)zeros) & 15) != 0) return V2A_ERR_ARG;
+    ConvDescH p;
+    p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.w = (const uint16_t*)w_packed;
+    p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual;
+    p.y = (uint16_t*)y; p.yf = y_f32; p.partial = (float*)workspace; p.zeros = (const uint16_t*)zeros;
+    p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.ups = ups ? 1 : 0;
+    p.HL = ups ? 2 * H : H; p.WL = ups ? 2 * W : W;
+    p.M = N * OH * OW;
+    p.K = KH * KW * (C1 + C2);
+    p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.fd_ow = make_fastdiv_h((uint32_t)OW);
+    p.fd_oh = make_fastdiv_h((uint32_t)OH);
+    int tiles, s;
+    conv_plan_h(p.M, Cout, p.K, &tiles, &s);
+    if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    p.splitk = s;
+    p.ktiles_per_split = cdiv(p.K / 64, s);
+    hipLaunchKernelGGL((conv_igemm_h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    if (s > 1) {
+        const size_t total = (size_t)p.M * Cout;
+        int g = (int)((total + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce_h, dim3(g), dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+    }
+    return V2A_OK;
+}
+
+// torch-layout fp32 weight [Cout][Cin][taps] -> bf16 [Cout][taps][Cin]
+int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, hipStream_t stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || taps <= 0) return V2A_ERR_ARG;
+    const size_t total = (size_t)Cout * Cin * taps;
+    int g = (int)((total + 255) / 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(pack_weight_h_kernel, dim3(g), dim3(256), 0, stream, w, (uint16_t*)out, Cout, Cin, taps);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+// elementwise casts between the two storage types (n % 4 == 0, 16-B / 8-B aligned)
+int v2a_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
+    if (!x || !y || n % 4) return V2A_ERR_ARG;
+    if (n == 0) return V2A_OK;
+    int g = (int)((n / 4 + 255) / 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_cast_bf16_f32(const void* x, float* y, size_t n, hipStream_t stream) {
+    if (!x || !y || n % 4) return V2A_ERR_ARG;
+    if (n == 0) return V2A_OK;
+    int g = (int)((n / 4 + 255) / 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+}  // extern "C"

@@ -62,6 +62,11 @@ SIGNATURES = {
     "v2a_opt_chunk_elems": (I, []),
     "v2a_opt_state_bytes": (SZ, []),
     "v2a_opt_state_init": (I, [P, D, D, D, D, D, D, D, D, D, D, I, I]),
+    "v2a_conv2d_h_workspace_bytes": (SZ, [I, I, I]),
+    "v2a_conv2d_fwd_h": (I, [P, P, P, P, P, P, P, P, P] + [I] * 16 + [P, SZ, P]),
+    "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),
+    "v2a_cast_f32_bf16": (I, [P, P, SZ, P]),
+    "v2a_cast_bf16_f32": (I, [P, P, SZ, P]),
     "v2a_opt_state_peek": (I, [P, P, P, P, P]),
     "v2a_opt_state_counters": (I, [P, P, P, P]),
     "v2a_opt_state_set_counters": (I, [P, LL, LL, I, D]),

@@ -125,6 +125,79 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
     return dw
 
 
+# ---- bf16-storage family (csrc/igemm_h.hip): activations / packed weights are torch.bfloat16 tensors, accumulation fp32
+_zeros_h = {}
+
+
+def _zero_line(device):
+    idx = torch.device(device).index
+    z = _zeros_h.get(idx)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.bfloat16, device=device)
+        _zeros_h[idx] = z
+    return z
+
+
+def _chk_h(t, name="tensor"):
+    assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), f"{name}: need contiguous bf16 CUDA tensor"
+    return t
+
+
+def pack_weight_h(w: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """torch fp32 weight [Cout,Cin,*taps] -> bf16 [Cout][taps][Cin] (the K order of conv2d_h)."""
+    _chk(w, "weight")
+    co, ci = w.shape[0], w.shape[1]
+    taps = w.numel() // (co * ci)
+    if out is None:
+        out = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+    check(lib.v2a_pack_weight_h(w.data_ptr(), out.data_ptr(), co, ci, taps, _stream()), "pack_weight_h")
+    return out
+
+
+def cast_h(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 (round to nearest even), same shape."""
+    _chk(x, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.v2a_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_f32_bf16")
+    return y
+
+
+def cast_f(x: torch.Tensor) -> torch.Tensor:
+    """bf16 -> fp32, same shape."""
+    _chk_h(x, "x")
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.v2a_cast_bf16_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_bf16_f32")
+    return y
+
+
+def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1, residual=None,
+             ups=False, out_f32=False):
+    """bf16-storage conv: x [N,H,W,C1] (+x2) bf16, w_packed bf16 [Cout][KH][KW][C1+C2], bias / rowvec fp32, residual bf16.
+    Returns bf16 [N,OH,OW,Cout] (fp32 when out_f32).  Needs C1 % 64 == 0 and C2 % 64 == 0."""
+    _chk_h(x, "x")
+    N, H, W, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        _chk_h(x2, "x2")
+        C2 = x2.shape[-1]
+    if residual is not None:
+        _chk_h(residual, "residual")
+    sh, sw = stride
+    ph, pw = pad
+    HL, WL = (2 * H, 2 * W) if ups else (H, W)
+    OH = (HL + 2 * ph - KH) // sh + 1
+    OW = (WL + 2 * pw - KW) // sw + 1
+    M, K = N * OH * OW, KH * KW * (C1 + C2)
+    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    wsb = lib.v2a_conv2d_h_workspace_bytes(M, Cout, K)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.v2a_conv2d_fwd_h(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual),
+                               None if out_f32 else y.data_ptr(), y.data_ptr() if out_f32 else None, _zero_line(x.device).data_ptr(),
+                               N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, OH, OW, rows_per_batch, _p(ws), wsb,
+                               _stream()), "conv2d_fwd_h")
+    return y
+
+
 def linear(x2d, w, bias=None, residual=None):
     """y = x @ w.T + b for x [M,K], torch weight [N,K] (already K-contiguous: no pack needed)."""
     M, K = x2d.shape
