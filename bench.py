@@ -245,7 +245,21 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
         recs.append((f"{kn}<{bm},{bn}>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
         return y
 
+    orig_h = ops.conv2d_h
+
+    def timed_h(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_h(*a, **k)
+        e1.record()
+        x, cout, kh, kw = a[0], a[3], a[4], a[5]
+        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
+        m = y.shape[0] * y.shape[1] * y.shape[2]
+        recs.append(("conv_igemm_h<128,128>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
+        return y
+
     ops.conv2d = timed
+    ops.conv2d_h = timed_h
     try:
         eng = unet._engine()
         lab = eng.label_embedding(te)
@@ -254,6 +268,7 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
         torch.cuda.synchronize()
     finally:
         ops.conv2d = orig
+        ops.conv2d_h = orig_h
     agg = {}
     for name, fl, e0, e1 in recs:
         v = agg.setdefault(name, [0.0, 0.0, 0])
@@ -422,14 +437,16 @@ def main():
             torch.cuda.empty_cache()
             out["video"] = video_leg(torch, device, args.video_batch, args.video_steps)
             if args.precision == "fp32" and not args.no_bf16_extra:
-                v2a_hip.set_precision("bf16")
+                v2a_hip.set_video_storage("bf16")
                 torch.cuda.empty_cache()
                 vb = video_leg(torch, device, args.video_batch, args.video_steps)
                 vb["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
                 vb["roofline"]["frac"] = vb["roofline"]["achieved"] / BF16_MFMA_PEAK_TFLOPS
-                vb["dtype"] = "bf16 MFMA inputs, f32 accumulate/storage"
+                vb["dtype"] = "bf16 activations / weights in HBM, bf16 MFMA, f32 accumulate / norm statistics / softmax"
+                vb["note"] = ("performance configuration (counterpart of the reference's fp16-autocast GPU path); 0.8 % relative L2 "
+                              "deviation from the fp32 parity path per UNet forward (tests/test_video_gpu.py)")
                 out["video_bf16"] = vb
-                v2a_hip.set_precision("fp32")
+                v2a_hip.set_video_storage("f32")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -13,7 +13,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--precision", default="fp32")
+ap.add_argument("--storage", default="f32", choices=["f32", "bf16"])
 a = ap.parse_args()
 import v2a_hip
 v2a_hip.set_precision(a.precision)
+v2a_hip.set_video_storage(a.storage)
 print(json.dumps(bench.video_leg(torch, "cuda:0", a.batch, a.steps)))

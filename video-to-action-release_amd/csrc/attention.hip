@@ -7,15 +7,33 @@
 // 0.25 % of the sampler FLOPs -> a VALU kernel; the heavy projections around it run on MFMA.
 #include "common.h"
 
-template <int CH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int heads) {
+// T = float (fp32 storage) or uint16_t (bf16 storage: loads widen to fp32, the output is rounded to nearest even)
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const uint16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(uint16_t* p, f32x4 v) {
+    uint32_t u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i] = __float_as_uint(v[i]); u[i] += 0x7fffu + ((u[i] >> 16) & 1u); }
+    uint2 o = {(u[0] >> 16) | (u[1] & 0xffff0000u), (u[2] >> 16) | (u[3] & 0xffff0000u)};
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+template <int CH, typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads) {
     constexpr int KT = 256;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // K[KT][CH], V[KT][CH]
     float* Ks = sm;
     float* Vs = sm + KT * CH;
     const int n = blockIdx.x / heads, h = blockIdx.x % heads;
     const int C3 = heads * 3 * CH, C = heads * CH;
-    const float* base = qkv + (size_t)n * L * C3 + (size_t)h * 3 * CH;
+    const T* base = qkv + (size_t)n * L * C3 + (size_t)h * 3 * CH;
     const float s = 1.0f / sqrtf(sqrtf((float)CH));
     for (int q0 = 0; q0 < L; q0 += blockDim.x) {
         const int qi = q0 + threadIdx.x;
@@ -23,15 +41,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         float q[CH], o[CH];
         float m = -INFINITY, l = 0.f;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { q[c] = active ? base[(size_t)qi * C3 + c] * s : 0.f; o[c] = 0.f; }
+        for (int c = 0; c < CH; ++c) { q[c] = active ? ld1(base + (size_t)qi * C3 + c) * s : 0.f; o[c] = 0.f; }
         for (int k0 = 0; k0 < L; k0 += KT) {
             const int kn = min(KT, L - k0);
             __syncthreads();
             for (int i = threadIdx.x; i < kn * (CH / 4); i += blockDim.x) {
                 const int r = i / (CH / 4), c4 = i % (CH / 4);
-                const float* src = base + (size_t)(k0 + r) * C3 + CH + c4 * 4;
-                f32x4 kv = *reinterpret_cast<const f32x4*>(src);
-                f32x4 vv = *reinterpret_cast<const f32x4*>(src + CH);
+                const T* src = base + (size_t)(k0 + r) * C3 + CH + c4 * 4;
+                f32x4 kv = ld4(src);
+                f32x4 vv = ld4(src + CH);
                 kv *= s;
                 *reinterpret_cast<f32x4*>(&Ks[r * CH + c4 * 4]) = kv;
                 *reinterpret_cast<f32x4*>(&Vs[r * CH + c4 * 4]) = vv;
@@ -72,11 +90,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         if (active) {
             const float inv = 1.0f / l;
-            float* dst = out + ((size_t)n * L + qi) * C + (size_t)h * CH;
+            T* dst = out + ((size_t)n * L + qi) * C + (size_t)h * CH;
 #pragma unroll
             for (int c = 0; c < CH; c += 4) {
                 f32x4 v = {o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
-                *reinterpret_cast<f32x4*>(dst + c) = v;
+                st4(dst + c, v);
             }
         }
     }
@@ -181,12 +199,33 @@ int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int hea
     const size_t lds = (size_t)2 * 256 * head_ch * sizeof(float);
     dim3 grid(n_frames * heads);
     if (lds > 64 * 1024) {
-        if (head_ch == 64) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (head_ch == 64) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     switch (head_ch) {
-        case 16: hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
-        case 32: hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
-        case 64: hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
+        case 16: hipLaunchKernelGGL((attn_fwd_kernel<16, float>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
+        case 32: hipLaunchKernelGGL((attn_fwd_kernel<32, float>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
+        case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, float>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
+        default: return V2A_ERR_ARG;
+    }
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+// bf16-storage variant: qkv / out are bf16 ([n_frames*L][3*C] -> [n_frames*L][C]); softmax state and accumulation stay fp32
+int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int heads, int head_ch, hipStream_t s) {
+    if (!qkv || !out) return V2A_ERR_ARG;
+    const int threads = L >= 256 ? 256 : ((L + 63) / 64) * 64;
+    const size_t lds = (size_t)2 * 256 * head_ch * sizeof(float);
+    dim3 grid(n_frames * heads);
+    const uint16_t* q = (const uint16_t*)qkv;
+    uint16_t* o = (uint16_t*)out;
+    if (lds > 64 * 1024) {
+        if (head_ch == 64) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    switch (head_ch) {
+        case 16: hipLaunchKernelGGL((attn_fwd_kernel<16, uint16_t>), grid, dim3(threads), lds, s, q, o, L, heads); break;
+        case 32: hipLaunchKernelGGL((attn_fwd_kernel<32, uint16_t>), grid, dim3(threads), lds, s, q, o, L, heads); break;
+        case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, uint16_t>), grid, dim3(threads), lds, s, q, o, L, heads); break;
         default: return V2A_ERR_ARG;
     }
     V2A_CHECK_LAUNCH();

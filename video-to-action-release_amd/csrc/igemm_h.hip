@@ -110,13 +110,15 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
         a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);       // rows past M fail the bounds test below
         a_iwb[j] = ow * p.sw - p.pw;
     }
+    const uint16_t* zsrc = p.zeros + chunk * 8;
     const uint16_t* b_src[BL];
+    bool b_ok[BL];
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
         const int n = n0 + j * 32 + lrow;
-        b_src[j] = (n < p.Cout) ? p.w + (size_t)n * p.K + chunk * 8 : nullptr;
+        b_ok[j] = n < p.Cout;
+        b_src[j] = b_ok[j] ? p.w + (size_t)n * p.K + chunk * 8 : zsrc;
     }
-    const uint16_t* zsrc = p.zeros + chunk * 8;
 
     // running (tap, channel) position of the next k tile to issue
     int ik0 = kt_begin * 64;
@@ -129,19 +131,21 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
         unsigned char* bbase = abase + BM * ROWB;
         const bool first = ic0 < p.C1;
         const uint16_t* src = first ? p.x : p.x2;
-        const int Cs = first ? p.C1 : p.C2;
-        const int cc = (first ? ic0 : ic0 - p.C1) + chunk * 8;
+        const uint32_t Cs = (uint32_t)(first ? p.C1 : p.C2);
+        const uint32_t cc = (uint32_t)((first ? ic0 : ic0 - p.C1) + chunk * 8);
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
-            const bool ok = ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+            const bool ok = (unsigned)ih < (unsigned)p.HL && (unsigned)iw < (unsigned)p.WL;
             if (p.ups) { ih >>= 1; iw >>= 1; }
-            const uint16_t* g = ok ? src + (((size_t)a_img[j] * p.H + ih) * p.W + iw) * Cs + cc : zsrc;
+            // offset computed unconditionally in 32 bits (the host checks the tensor has < 2^32 elements); select, do not branch
+            const uint32_t off = ((uint32_t)(a_img[j] * p.H + ih) * (uint32_t)p.W + (uint32_t)iw) * Cs + cc;
+            const uint16_t* g = ok ? src + off : zsrc;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + (j * 256 + wid * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < BL; ++j) {
-            const uint16_t* g = b_src[j] ? b_src[j] + ik0 : zsrc;
+            const uint16_t* g = b_src[j] + (b_ok[j] ? ik0 : 0);
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbase + (j * 256 + wid * 64) * 16), 16, 0, 0);
         }
         ik0 += 64;
@@ -193,31 +197,90 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
         buf ^= 1;
     }
 
-    // ---- epilogue (C layout of the 32x32 MFMA: lane -> column lr, rows (r & 3) + 8 * (r >> 2) + 4 * lk)
+    // ---- epilogue.  C layout of the 32x32 MFMA: lane -> column lr, rows (r & 3) + 8 * (r >> 2) + 4 * lk.  Each wave parks its
+    // 64x64 fp32 sub-tile in its own 16 KB + pad of the (now free) LDS, then every lane owns 8 consecutive channels of a row:
+    // bias / embedding vector / residual are applied on 8-wide vectors and the result leaves as one 16-B bf16 store (a full
+    // 128-B line per row and wave) instead of 2-byte scatters.
+    __syncthreads();
+    constexpr int LDC = WN;                                       // floats per parked row; columns XOR-ed with 4 * (row & 1) so that
+    static_assert(4 * WM * LDC * 4 <= 2 * BUF, "epilogue staging exceeds the operand buffers");   // the b128 read-back is conflict-free
+    float* cw = reinterpret_cast<float*>(smem) + wid * WM * LDC;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn + j * 32 + lr;
-            if (n >= p.Cout) continue;
-            const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                const size_t o = (size_t)m * p.Cout + n;
-                if (p.splitk > 1) {
-                    p.partial[(size_t)split * p.M * p.Cout + o] = v;
-                } else {
-                    v += bv;
-                    if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
-                    if (p.residual) v += bf2f(p.residual[o]);
-                    if (p.yf) p.yf[o] = v;
-                    else p.y[o] = f2bf(v);
-                }
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                cw[row * LDC + ((j * 32 + lr) ^ ((row & 1) << 2))] = acc[i][j][r];
+            }
+    // wave-private region: no workgroup barrier needed, only the LDS writes of this wave must have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int V = WN / 8;                                     // 8-channel vectors per row
+    const int vrow = lane / V, vcol = (lane % V) * 8;
+    const int n = n0 + wn + vcol;
+    const bool vec_ok = (p.Cout % 8 == 0) && (n + 8 <= p.Cout);
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && p.splitk == 1 && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < WM; rr += 64 / V) {
+        const int ml = rr + vrow;
+        const int m = m0 + wm + ml;
+        if (m >= p.M || n >= p.Cout) continue;
+        const int sx = (ml & 1) << 2;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const size_t o = (size_t)m * p.Cout + n;
+        if (p.splitk > 1) {
+            float* dst = p.partial + (size_t)split * p.M * p.Cout + o;
+            if (vec_ok) {
+                *reinterpret_cast<f32x4*>(dst) = c0;
+                *reinterpret_cast<f32x4*>(dst + 4) = c1;
+            } else {
+                for (int e = 0; e < 8 && n + e < p.Cout; ++e) dst[e] = v[e];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        if (vec_ok) {
+            if (p.rowvec) {
+                const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.Cout + n;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+            }
+            if (p.residual) {
+                const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
+                v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+            }
+            if (p.yf) {
+                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(p.yf + o) = o0;
+                *reinterpret_cast<f32x4*>(p.yf + o + 4) = o1;
+            } else {
+                uint4 u;
+                u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+                u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+                *reinterpret_cast<uint4*>(p.y + o) = u;
+            }
+        } else {                                                  // ragged channel count (e.g. the 3-channel output head)
+            for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
+                float t = v[e];
+                if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
+                if (p.residual) t += bf2f(p.residual[o + e]);
+                if (p.yf) p.yf[o + e] = t;
+                else p.y[o + e] = f2bf(t);
             }
         }
+    }
 }
 
 __global__ void conv_splitk_reduce_h(const ConvDescH p) {
@@ -288,6 +351,7 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
     if (!x || !w_packed || !zeros || (!y == !y_f32) || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
     if (C1 <= 0 || C1 % 64 || C2 < 0 || C2 % 64 || (C2 > 0 && !x2)) return V2A_ERR_ARG;
     if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)w_packed | (uintptr_t)zeros) & 15) != 0) return V2A_ERR_ARG;
+    if ((double)N * H * W * (C1 > C2 ? C1 : C2) >= 4294967296.0) return V2A_ERR_ARG;      // the gather uses 32-bit element offsets
     ConvDescH p;
     p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.w = (const uint16_t*)w_packed;
     p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual;

@@ -1,0 +1,196 @@
+// GroupNorm (+ fused activation) forward over bf16 channels-last tensors [N, S, C]: the bf16-storage configuration of the video
+// UNet's GroupNorm32 + SiLU (reference guided_diffusion/guided_diffusion/nn.py:26-28 computes the normalisation in fp32 on the
+// autocast-half input and returns the input dtype: same contract here).  Optional second source = channel concat
+// (decoder ResBlocks normalise cat[h, skip] without materialising it).
+//
+// HBM-bound, three launches:  column sums (16-B bf16x8 loads, fp32 registers -> LDS bins -> fp32 partial per row chunk)
+//                             -> per (n, group) fp64 combine -> per (n, channel) scale / shift
+//                             -> apply: y = act(x * a[n][c] + b[n][c]), 16-B loads and stores.
+// 6 bytes per element of traffic (2 reads + 1 write of bf16) against 12 for the fp32 tensors.
+#include "common.h"
+
+struct GnDescH {
+    const uint16_t* x;      // [N][S][C1]
+    const uint16_t* x2;     // [N][S][C - C1] or null
+    const float* gamma;     // [C]
+    const float* beta;      // [C]
+    uint16_t* y;            // [N][S][C]
+    float* partial;         // [N][nchunk][2][C]
+    float* ab;              // [N][2][C]  (scale, shift)
+    float* mean;            // [N][G] or null
+    float* rstd;            // [N][G] or null
+    int N, S, C, C1, G, act, nchunk, rows_per_chunk;
+    float eps;
+};
+
+__device__ __forceinline__ void unpack8(const uint4 u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
+    extern __shared__ __attribute__((aligned(16))) float bins[];   // [2][C]
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int C = p.C, L8 = C >> 3;
+    for (int i = tid; i < 2 * C; i += 256) bins[i] = 0.f;
+    __syncthreads();
+    const int s0 = chunk * p.rows_per_chunk, s1 = min(p.S, s0 + p.rows_per_chunk);
+    const int nrows = s1 - s0;
+    const int C1 = p.x2 ? p.C1 : C, C2 = C - C1;
+    const uint16_t* xa = p.x + ((size_t)n * p.S + s0) * C1;
+    const uint16_t* xb = p.x2 ? p.x2 + ((size_t)n * p.S + s0) * C2 : nullptr;
+    const int rpi = L8 >= 256 ? 1 : 256 / L8;                 // rows in flight per pass
+    const int row0 = L8 >= 256 ? 0 : tid / L8;
+    const bool active = L8 >= 256 ? true : (tid < rpi * L8);
+    for (int c8 = active ? (L8 >= 256 ? tid : tid % L8) : L8; c8 < L8; c8 += 256) {
+        const int c = c8 * 8;
+        const bool first = c < C1;
+        const uint16_t* src = first ? xa + c : xb + (c - C1);
+        const int stride = first ? C1 : C2;
+        float s[8], q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+        int r = row0;
+        for (; r + 3 * rpi < nrows; r += 4 * rpi) {           // four independent 16-B loads in flight
+            uint4 u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = *reinterpret_cast<const uint4*>(src + (size_t)(r + k * rpi) * stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float f[8];
+                unpack8(u[k], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+        }
+        for (; r < nrows; r += rpi) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(src + (size_t)r * stride), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(&bins[c + e], s[e]);
+            atomicAdd(&bins[C + c + e], q[e]);
+        }
+    }
+    __syncthreads();
+    float* dst = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) dst[i] = bins[i];
+}
+
+// one wave per (n, group): fp64 combine over chunks and the group's channels, then the per-channel affine of the apply pass
+__global__ __launch_bounds__(64) void gn_finalize_h(const GnDescH p) {
+    const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, lane = threadIdx.x;
+    const int cg = p.C / p.G;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < p.nchunk * cg; i += 64) {
+        const int ch = i / cg, c = g * cg + i % cg;
+        const float* src = p.partial + ((size_t)n * p.nchunk + ch) * 2 * p.C;
+        s += (double)src[c];
+        q += (double)src[p.C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    const double cnt = (double)p.S * cg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float mu = (float)mean;
+    if (lane == 0) {
+        if (p.mean) p.mean[n * p.G + g] = mu;
+        if (p.rstd) p.rstd[n * p.G + g] = rstd;
+    }
+    for (int i = lane; i < cg; i += 64) {
+        const int c = g * cg + i;
+        const float a = p.gamma[c] * rstd;
+        p.ab[(size_t)n * 2 * p.C + c] = a;
+        p.ab[(size_t)n * 2 * p.C + p.C + c] = p.beta[c] - mu * a;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
+    const int L8 = p.C >> 3;
+    const size_t per_n = (size_t)p.S * L8;
+    const size_t total = per_n * p.N;
+    const int C1 = p.x2 ? p.C1 : p.C, C2 = p.C - C1;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int n = (int)(idx / per_n);
+        const size_t rem = idx - (size_t)n * per_n;
+        const size_t row = rem / L8;
+        const int c = (int)(rem - row * L8) * 8;
+        const size_t grow = (size_t)n * p.S + row;
+        const uint16_t* src = (c < C1) ? p.x + grow * C1 + c : p.x2 + grow * C2 + (c - C1);
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(src), f);
+        const float* a = p.ab + (size_t)n * 2 * p.C + c;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a + p.C), b1 = *reinterpret_cast<const f32x4*>(a + p.C + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = act_fwd(f[e] * a0[e] + b0[e], p.act);
+            o[e + 4] = act_fwd(f[e + 4] * a1[e] + b1[e], p.act);
+        }
+        uint4 u = {pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        *reinterpret_cast<uint4*>(p.y + grow * p.C + c) = u;
+    }
+}
+
+static void gn_chunks_h(int N, int S, int* nchunk, int* rows) {
+    // ~2048 workgroups over the whole tensor, at least 64 rows per chunk
+    int want = 2048 / (N > 0 ? N : 1);
+    if (want < 1) want = 1;
+    int r = cdiv(S, want);
+    if (r < 64) r = 64;
+    *rows = r;
+    *nchunk = cdiv(S, r);
+}
+
+extern "C" {
+
+size_t v2a_groupnorm_h_workspace_bytes(int N, int S, int C) {
+    int nchunk, rows;
+    gn_chunks_h(N, S, &nchunk, &rows);
+    return ((size_t)N * nchunk * 2 * C + (size_t)N * 2 * C) * sizeof(float);
+}
+
+// y = act(GroupNorm_G(cat[x, x2]) * gamma + beta), all activations bf16 [N][S][C]; mean / rstd ([N][G], fp32) optional outputs.
+// C % 8 == 0, C1 % 8 == 0, C % G == 0.
+int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        int N, int S, int C, int G, float eps, int act, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || N <= 0 || S <= 0 || C <= 0 || G <= 0 || C % G || C % 8) return V2A_ERR_ARG;
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % 8)) return V2A_ERR_ARG;
+    if (2 * C * sizeof(float) > 64 * 1024) return V2A_ERR_ARG;
+    GnDescH p;
+    p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.gamma = gamma; p.beta = beta; p.y = (uint16_t*)y;
+    p.mean = mean; p.rstd = rstd;
+    p.N = N; p.S = S; p.C = C; p.C1 = x2 ? C1 : C; p.G = G; p.act = act; p.eps = eps;
+    gn_chunks_h(N, S, &p.nchunk, &p.rows_per_chunk);
+    const size_t need = ((size_t)N * p.nchunk * 2 * C + (size_t)N * 2 * C) * sizeof(float);
+    if (!workspace || workspace_bytes < need) return V2A_ERR_WORKSPACE;
+    p.partial = (float*)workspace;
+    p.ab = p.partial + (size_t)N * p.nchunk * 2 * C;
+    hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+    V2A_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize_h, dim3(N * G), dim3(64), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    const size_t vecs = (size_t)N * S * (C / 8);
+    int g = (int)((vecs + 255) / 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(gn_apply_h, dim3(g), dim3(256), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+}  // extern "C"

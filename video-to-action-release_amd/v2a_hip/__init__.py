@@ -14,3 +14,21 @@ def set_precision(mode: str) -> str:
 
 def get_precision() -> str:
     return "bf16" if lib.v2a_get_precision() == 1 else "fp32"
+
+
+_video_storage = ["f32"]
+
+
+def set_video_storage(mode: str) -> str:
+    """HBM storage type of the video UNet's activations / weight packs: 'f32' (parity configuration, default) or 'bf16' (bf16
+    tensors, fp32 accumulation and statistics: the counterpart of the reference's fp16-autocast GPU path).  Applies to every
+    video UNet whose channel widths allow it (multiples of 64) and that has no `.storage` attribute of its own."""
+    if mode not in ("f32", "bf16"):
+        raise ValueError(mode)
+    old = _video_storage[0]
+    _video_storage[0] = mode
+    return old
+
+
+def get_video_storage() -> str:
+    return _video_storage[0]

@@ -199,8 +199,10 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
 
 
 def linear(x2d, w, bias=None, residual=None):
-    """y = x @ w.T + b for x [M,K], torch weight [N,K] (already K-contiguous: no pack needed)."""
+    """y = x @ w.T + b for x [M,K], torch weight [N,K] (already K-contiguous: no pack needed).  bf16 x takes a bf16 weight."""
     M, K = x2d.shape
+    if x2d.dtype == torch.bfloat16:
+        return conv2d_h(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=residual).view(M, w.shape[0])
     y = conv2d(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=residual)
     return y.view(M, w.shape[0])
 
@@ -230,6 +232,21 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
                                 mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
           "groupnorm_fwd")
     return y, mean, rstd
+
+
+def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None):
+    """bf16-storage GroupNorm + activation: x [N,S,C1] (+ x2 [N,S,C2] virtual concat) bf16 -> y [N,S,C] bf16."""
+    _chk_h(x, "x")
+    N, S, C1 = x.shape
+    C = C1 + (x2.shape[-1] if x2 is not None else 0)
+    if x2 is not None:
+        _chk_h(x2, "x2")
+    y = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
+    wsb = lib.v2a_groupnorm_h_workspace_bytes(N, S, C)
+    ws = workspace(wsb, x.device)
+    check(lib.v2a_groupnorm_fwd_h(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, None, N, S, C, G,
+                                  eps, ACT[act], ws.data_ptr(), wsb, _stream()), "groupnorm_fwd_h")
+    return y
 
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
@@ -320,6 +337,10 @@ def nhwc_to_nchw(src):
 
 # ------------------------------------------------------------------------------------------------ attention etc.
 def attention(qkv, n_frames, L, heads, head_ch):
+    if qkv.dtype == torch.bfloat16:
+        out = torch.empty((n_frames * L, heads * head_ch), dtype=torch.bfloat16, device=qkv.device)
+        check(lib.v2a_attention_fwd_h(qkv.data_ptr(), out.data_ptr(), n_frames, L, heads, head_ch, _stream()), "attention_fwd_h")
+        return out
     out = torch.empty((n_frames * L, heads * head_ch), dtype=torch.float32, device=qkv.device)
     check(lib.v2a_attention_fwd(qkv.data_ptr(), out.data_ptr(), n_frames, L, heads, head_ch, _stream()), "attention_fwd")
     return out

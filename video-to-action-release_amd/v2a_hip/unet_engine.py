@@ -62,24 +62,29 @@ def build_program(cfg):
 
 
 class _Packs:
-    """Packed conv operands keyed by parameter name, refreshed when (data_ptr, _version) changes."""
+    """Packed conv operands keyed by parameter name, refreshed when (data_ptr, _version) changes.  `half`: bf16 packs for the
+    bf16-storage kernels (csrc/igemm_h.hip) instead of fp32 ones."""
 
     def __init__(self, P):
         self.P = P
         self._c = {}
 
-    def get(self, name):
+    def get(self, name, half=False):
         w = self.P[name]
         key = (w.data_ptr(), w._version)
-        ent = self._c.get(name)
+        ck = (name, half)
+        ent = self._c.get(ck)
         if ent is None or ent[0] != key:
             wd = w.detach()
             taps = 1
             for s in wd.shape[2:]:
                 taps *= s
-            pk = wd if taps == 1 else ops.pack_weight(wd.contiguous(), 0, None if ent is None else ent[1])
+            if half:
+                pk = ops.pack_weight_h(wd.contiguous(), None if ent is None else ent[1])
+            else:
+                pk = wd if taps == 1 else ops.pack_weight(wd.contiguous(), 0, None if ent is None else ent[1])
             ent = (key, pk)
-            self._c[name] = ent
+            self._c[ck] = ent
         return ent[1]
 
 
@@ -91,9 +96,23 @@ class UNetEngine:
         self.device = next(iter(params.values())).device
         self.packs = _Packs(params)
         self.inp, self.mid, self.out, self.final_ch = build_program(cfg)
+        # "f32": fp32 tensors in HBM (parity configuration; the MFMA input type follows v2a_hip.set_precision).
+        # "bf16": bf16 activations + bf16 weight packs, fp32 accumulation / normalisation statistics / softmax -- the counterpart of
+        # the reference's fp16-autocast GPU path (lb_online_trainer_v7.py:889); needs every inner width to be a multiple of 64.
+        self.storage = "f32"
 
-    def w(self, name):
-        return self.packs.get(self.pre + name)
+    def set_storage(self, mode):
+        if mode not in ("f32", "bf16"):
+            raise ValueError(mode)
+        if mode == "bf16":
+            c = self.cfg
+            widths = [c.model_channels * m for m in c.channel_mult]
+            if any(w % 64 for w in widths):
+                raise ValueError(f"bf16 storage needs channel widths that are multiples of 64, got {widths}")
+        self.storage = mode
+
+    def w(self, name, half=False):
+        return self.packs.get(self.pre + name, half)
 
     def p(self, name):
         return self.P[self.pre + name]
@@ -102,9 +121,40 @@ class UNetEngine:
         return (self.pre + name) in self.P
 
     # ------------------------------------------------------------------ primitives
-    def conv3d(self, x, name, cout, stride=1, ups=False, x2=None, rowvec=None, residual=None):
+    def _conv3d_h(self, x, name, cout, stride, ups, x2, rowvec, residual, out_f32):
+        """bf16-storage Conv3d: spatial conv then (k > 1) temporal conv, both on the LDS-DMA kernel.  A cout that the temporal
+        kernel cannot take (the 3-channel output head) leaves the spatial result in fp32 and finishes on the fp32 kernels."""
+        B, Fr, H, W, C = x.shape
+        k = self.p(name + ".spatial_conv.weight").shape[-1]
+        has_t = self.has(name + ".temporal_conv.weight")
+        t_half = has_t and cout % 64 == 0
+        x4 = x.view(B * Fr, H, W, C)
+        x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
+        y = ops.conv2d_h(x4, self.w(name + ".spatial_conv.weight", half=True), self.p(name + ".spatial_conv.bias"), cout, k, k,
+                         (stride, stride), (k // 2, k // 2), x2=x24, ups=ups, rowvec=None if has_t else rowvec, rows_per_batch=1,
+                         residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout),
+                         out_f32=(has_t and not t_half) or (out_f32 and not has_t))
+        OH, OW = y.shape[1], y.shape[2]
+        if not has_t:
+            if rowvec is not None:
+                raise NotImplementedError("rowvec on a conv without temporal part")
+            return y.view(B, Fr, OH, OW, cout)
+        if t_half:
+            z = ops.conv2d_h(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
+                             self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
+                             rows_per_batch=Fr * OH * OW, residual=None if residual is None else residual.view(B, Fr, OH * OW, cout),
+                             out_f32=out_f32)
+        else:
+            assert residual is None and out_f32
+            z = ops.conv2d(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight"), self.p(name + ".temporal_conv.bias"),
+                           cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW)
+        return z.view(B, Fr, OH, OW, cout)
+
+    def conv3d(self, x, name, cout, stride=1, ups=False, x2=None, rowvec=None, residual=None, out_f32=False):
         """x [B,F,H,W,C] (+x2) -> [B,F,OH,OW,cout].  rowvec [B,cout] / residual [B,F,OH,OW,cout] land in the LAST kernel."""
         B, Fr, H, W, C = x.shape
+        if x.dtype == torch.bfloat16:
+            return self._conv3d_h(x, name, cout, stride, ups, x2, rowvec, residual, out_f32)
         wsp = self.w(name + ".spatial_conv.weight")
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
@@ -118,6 +168,11 @@ class UNetEngine:
             if rowvec is not None:
                 raise NotImplementedError("rowvec on a conv without temporal part")
             return y.view(B, Fr, OH, OW, cout)
+        if self.storage == "bf16" and cout % 64 == 0:      # stem: fp32 spatial conv (Cin = 6), the 128-wide temporal conv on the bf16 kernel
+            z = ops.conv2d_h(ops.cast_h(y).view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
+                             self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW,
+                             residual=None if residual is None else residual.view(B, Fr, OH * OW, cout))
+            return z.view(B, Fr, OH, OW, cout)
         wt = self.w(name + ".temporal_conv.weight")
         z = ops.conv2d(y.view(B, Fr, OH * OW, cout), wt, self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0),
                        rowvec=rowvec, rows_per_batch=Fr * OH * OW,
@@ -131,6 +186,8 @@ class UNetEngine:
         N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
         x3 = x.view(N, S, C1)
         x23 = None if x2 is None else x2.view(N, S, -1)
+        if x.dtype == torch.bfloat16:
+            return ops.groupnorm_fwd_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23).view(B, Fr, H, W, C)
         if x23 is not None and S * (C // 32) <= GN_SMALL_MAX:
             cat = torch.empty((N, S, C), dtype=torch.float32, device=x.device)      # tiny tensors: materialise the concat
             ops.copy2d(x3, cat, N * S, C1, C1, C)
@@ -158,9 +215,12 @@ class UNetEngine:
         hc = self.cfg.num_head_channels
         heads = C // hc
         n = self.gn_silu(x, name + ".norm", act="none", frames_separate=True)
-        qkv = ops.linear(n.view(N * L, C), self.p(name + ".qkv.weight").view(3 * C, C), self.p(name + ".qkv.bias"))
+        half = x.dtype == torch.bfloat16
+        wq = self.w(name + ".qkv.weight", True).view(3 * C, C) if half else self.p(name + ".qkv.weight").view(3 * C, C)
+        wo = self.w(name + ".proj_out.weight", True).view(C, C) if half else self.p(name + ".proj_out.weight").view(C, C)
+        qkv = ops.linear(n.view(N * L, C), wq, self.p(name + ".qkv.bias"))
         a = ops.attention(qkv, N, L, heads, hc)
-        out = ops.linear(a, self.p(name + ".proj_out.weight").view(C, C), self.p(name + ".proj_out.bias"), residual=x.view(N * L, C))
+        out = ops.linear(a, wo, self.p(name + ".proj_out.bias"), residual=x.view(N * L, C))
         return out.view(B, Fr, H, W, C)
 
     # ------------------------------------------------------------------ embeddings
@@ -239,14 +299,16 @@ class UNetEngine:
         semb = ops.act_fwd(emb, "silu")                     # every ResBlock's emb_layers starts with the same SiLU
         hs = []
         h = xin
-        for blk in self.inp:
+        for i, blk in enumerate(self.inp):
             h = self._run(blk, h, semb)
+            if i == 0 and self.storage == "bf16" and h.dtype != torch.bfloat16:
+                h = ops.cast_h(h)          # the stem (Cin = 6) runs on the fp32 kernels; everything after it is bf16 in HBM
             hs.append(h)
         h = self._run(self.mid, h, semb)
         for blk in self.out:
             h = self._run(blk, h, semb, skip=hs.pop())
         a = self.gn_silu(h, "out.0")
-        return self.conv3d(a, "out.2", self.cfg.out_channels)
+        return self.conv3d(a, "out.2", self.cfg.out_channels, out_f32=True)
 
     def forward_libero(self, x, t, task_embed=None, label_emb=None, frame_ch=3):
         """Unet_Libero / UnetMW / UnetThor / UnetBridge (frame_ch 3) and UnetMWFlow (frame_ch 2) forward:
