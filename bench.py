@@ -168,6 +168,59 @@ def _cpu_baseline_worker(batch, threads, budget):
         print(json.dumps({"done": max(n - 1, 0), "t": t_used}), flush=True)
 
 
+def _cpu_video_worker(threads, budget):
+    """Subprocess body: full-size Unet_Libero forward of the CPU oracle at B=1 (one denoise step of one sample)."""
+    import torch
+    from oracle.video_unet import unet_libero_forward, LIBERO_CFG
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    sd = {k: v.detach() for k, v in Unet_Libero().state_dict().items()}
+    x, t, te = torch.randn(1, 24, 128, 128), torch.tensor([50]), torch.randn(1, 10, 512)
+    n, t_used = 0, 0.0
+    with torch.no_grad():
+        while t_used < budget and n < 4:
+            t0 = time.time()
+            unet_libero_forward(sd, x, t, te, LIBERO_CFG)
+            dt = time.time() - t0
+            if n > 0:
+                t_used += dt
+            n += 1
+            print(json.dumps({"done": max(n - 1, 0), "t": t_used}), flush=True)
+
+
+def cpu_baseline_video(batch, sampling_steps, budget=12.0, hard_timeout=90.0):
+    """CPU oracle of the sampler's unit of work (time single UNet forwards and extrapolate linearly to B x steps)."""
+    import subprocess
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = os.cpu_count() or 1
+    threads = max(1, min(usable, 32))
+    code = (f"import sys, json, time; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'video-to-action-release_amd')!r}); "
+            f"import bench; bench._cpu_video_worker({threads}, {budget})")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    last = None
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=hard_timeout, env=env)
+        lines = p.stdout.strip().splitlines()
+    except subprocess.TimeoutExpired as e:
+        lines = (e.stdout or b"").decode().strip().splitlines() if isinstance(e.stdout, bytes) else (e.stdout or "").strip().splitlines()
+    for ln in lines:
+        try:
+            last = json.loads(ln)
+        except Exception:
+            pass
+    if not last or last["done"] < 1:
+        return {"value": None, "unit": "predicted frames/s", "cores": threads, "kind": "port",
+                "sample": f"no B=1 UNet forward finished within the {hard_timeout:.0f} s cap on {threads} threads"}
+    per_fwd = last["t"] / last["done"]
+    return {"value": 7.0 / (per_fwd * sampling_steps), "unit": "predicted frames/s", "cores": threads, "kind": "port",
+            "sample": f"{last['done']} timed full-size Unet_Libero forwards of the CPU oracle at B=1 ({per_fwd:.2f} s each on {threads} threads, "
+                      f"first untimed), extrapolated linearly to {sampling_steps} denoise steps per sample (the sampler's cost is B x steps "
+                      f"UNet forwards; elementwise DDIM update ignored)"}
+
+
 def cpu_baseline(batch, budget=20.0, hard_timeout=150.0):
     """The CPU oracle (pinned bit-exact against the reference) timed on this box's host cores, in a subprocess with a hard
     timeout so that a slow / oversubscribed host can never stall the benchmark.  Threads = min(usable cores, 32)."""
@@ -436,6 +489,8 @@ def main():
             del tr, pol, store
             torch.cuda.empty_cache()
             out["video"] = video_leg(torch, device, args.video_batch, args.video_steps)
+            if not args.no_cpu_baseline:
+                out["video"]["cpu_baseline"] = cpu_baseline_video(args.video_batch, args.video_steps)
             if args.precision == "fp32" and not args.no_bf16_extra:
                 v2a_hip.set_video_storage("bf16")
                 torch.cuda.empty_cache()
