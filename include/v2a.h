@@ -57,9 +57,11 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 /* torch weight [Cout][Cin][KH][KW] -> mode 0: [Cout][KH][KW][Cin]; mode 1: [Cin][KH'][KW'][Cout] flipped (dgrad / transposed) */
 int v2a_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int mode, v2a_stream_t stream);
-/* every forward pack of a model in one launch: table_dev int64 [n][5] = {src, dst, Cout, Cin, taps}; chunks_dev int32 [nchunks][2] */
+/* every pack of a model in two launches: table_dev int64 [n][7] = {src, dst fp32 or 0, Cout, Cin, taps, mode, dst bf16 or 0};
+ * transposed 0: mode-0 rows, chunks_dev int32 {operand, start} of v2a_pack_chunk_elems() elements; transposed 1: mode-1 rows
+ * (data-gradient operand = tap-reversed transpose), chunks_dev {operand, 64x64 tile index over [Cout x Cin*taps]} */
 int v2a_pack_chunk_elems(void);
-int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, v2a_stream_t stream);
+int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, int transposed, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- GroupNorm (csrc/norm.hip)
  * y = film(act(gn(x) + residual)) on [N,S,C]; x2 != NULL: x is channels [0,C1) and x2 channels [C1,C) of a concat.
@@ -134,9 +136,9 @@ int v2a_spatial_softmax_bwd(const float* att, const float* kp, const float* dkp,
  * exactly one of y (bf16) / y_f32 non-null; zeros: >= 128 zero bytes (padding taps read it).  C1 % 64 == C2 % 64 == 0. */
 size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
-                     void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh,
-                     int sw, int ph, int pw, int ups, int OH, int OW, int rows_per_batch, void* workspace, size_t workspace_bytes,
-                     v2a_stream_t s);
+                     const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
+                     int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
+                     void* workspace, size_t workspace_bytes, v2a_stream_t s);   /* residual (bf16) xor residual_f32; idil 1 | 2 */
 /* GroupNorm + activation and QKV attention over bf16 tensors (csrc/norm_h.hip, csrc/attention.hip): same math as v2a_groupnorm_fwd /
  * v2a_attention_fwd (reference nn.py:26-28 GroupNorm32 computes in fp32 and returns the input dtype; unet.py:341-358), bf16 I/O. */
 size_t v2a_groupnorm_h_workspace_bytes(int N, int S, int C);

@@ -162,6 +162,7 @@ def test_bf16_mode_policy_close_to_fp32(golden_dir):
     pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
     old = v2a_hip.set_precision("bf16")
     try:
+        pol.engine.refresh_packs()          # registers the bf16 operand twins: eligible layers run on the LDS-DMA bf16 kernel
         loss = pol.compute_loss(batch)
         loss.backward()
     finally:

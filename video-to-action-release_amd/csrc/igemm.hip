@@ -856,13 +856,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
-// all forward packs of a model in ONE launch.  table (int64) per tensor: {src, dst, Cout, Cin, taps}; chunks (int32): {tensor, start}
+// all packs of a model in TWO launches.  table (int64) per operand: {src, dst, Cout, Cin, taps, mode, dst_bf16 or 0}.
+// mode 0 (forward pack [Cout][taps][Cin]): chunks (int32) {operand, start element}, PACK_CHUNK elements per workgroup.
+// mode 1 (data-gradient pack [Cin][taps reversed][Cout] = a [Cout x Cin*taps] -> [Cin*taps x Cout] transpose with the taps of
+// each input channel reversed): chunks {operand, 64x64 tile index}; the tile goes through LDS so that both the global reads
+// (contiguous along Cin*taps) and the global writes (contiguous along Cout) are full lines.
+// A non-zero 7th column also writes the bf16 twin of the operand (the LDS-DMA kernels' weight operand).
 #define PACK_CHUNK 16384
+__device__ __forceinline__ uint16_t f2bf_pack(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* table, const int* chunks) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
-    const float* src = reinterpret_cast<const float*>(table[t * 5 + 0]);
-    float* dst = reinterpret_cast<float*>(table[t * 5 + 1]);
-    const int Cout = (int)table[t * 5 + 2], Cin = (int)table[t * 5 + 3], taps = (int)table[t * 5 + 4];
+    const float* src = reinterpret_cast<const float*>(table[t * 7 + 0]);
+    float* dst = reinterpret_cast<float*>(table[t * 7 + 1]);
+    uint16_t* dsth = reinterpret_cast<uint16_t*>(table[t * 7 + 6]);
+    const int Cout = (int)table[t * 7 + 2], Cin = (int)table[t * 7 + 3], taps = (int)table[t * 7 + 4];
     const long long total = (long long)Cout * Cin * taps;
     const int cnt = (int)min((long long)PACK_CHUNK, total - start);
     for (int i = threadIdx.x; i < cnt; i += 256) {
@@ -871,7 +882,35 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
         const long long q = idx / Cin;
         const int tap = (int)(q % taps);
         const int co = (int)(q / taps);
-        dst[idx] = src[((size_t)co * Cin + ci) * taps + tap];
+        const float v = src[((size_t)co * Cin + ci) * taps + tap];
+        if (dst) dst[idx] = v;
+        if (dsth) dsth[idx] = f2bf_pack(v);
+    }
+}
+__global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t* table, const int* chunks) {
+    __shared__ float tile[64][65];
+    const int t = chunks[2 * blockIdx.x], tl = chunks[2 * blockIdx.x + 1];
+    const float* src = reinterpret_cast<const float*>(table[t * 7 + 0]);
+    float* dst = reinterpret_cast<float*>(table[t * 7 + 1]);
+    uint16_t* dsth = reinterpret_cast<uint16_t*>(table[t * 7 + 6]);
+    const int Cout = (int)table[t * 7 + 2], Cin = (int)table[t * 7 + 3], taps = (int)table[t * 7 + 4];
+    const int J = Cin * taps, tj = (J + 63) >> 6;
+    const int c0 = (tl / tj) << 6, j0 = (tl % tj) << 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {                       // read: row = co, 64 contiguous j
+        const int co = c0 + r, j = j0 + tx;
+        tile[r][tx] = (co < Cout && j < J) ? src[(size_t)co * J + j] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {                       // write: row = j (tap reversed inside its channel), 64 contiguous co
+        const int j = j0 + r, co = c0 + tx;
+        if (j < J && co < Cout) {
+            const int ci = j / taps, tap = j - ci * taps;
+            const size_t o = ((size_t)ci * taps + (taps - 1 - tap)) * Cout + co;
+            const float v = tile[tx][r];
+            if (dst) dst[o] = v;
+            if (dsth) dsth[o] = f2bf_pack(v);
+        }
     }
 }
 
@@ -1079,10 +1118,12 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
 }
 
 int v2a_pack_chunk_elems(void) { return PACK_CHUNK; }
-// forward packs (mode 0) of many tensors in one launch; see pack_weights_multi_kernel for the table layout
-int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, hipStream_t stream) {
+// packs of many tensors per launch; see pack_weights_multi_kernel for the table layout ({src, dst, Cout, Cin, taps, mode, dst_bf16}).
+// transposed = 0: the mode-0 rows (chunks = {operand, start}); transposed = 1: the mode-1 rows (chunks = {operand, 64x64 tile}).
+int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, int transposed, hipStream_t stream) {
     if (!table_dev || !chunks_dev || nchunks <= 0) return V2A_ERR_ARG;
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev);
+    if (transposed) hipLaunchKernelGGL(pack_weights_multi_t_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev);
+    else hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -50,12 +50,14 @@ struct ConvDescH {
     const float* bias;        // [Cout] or null
     const float* rowvec;      // [M / rows_per_batch][Cout] or null
     const uint16_t* residual; // [M][Cout] bf16 or null
+    const float* residual_f;  // [M][Cout] fp32 residual (alternative to `residual`) or null
     uint16_t* y;              // [M][Cout] bf16 (null when yf is used)
     float* yf;                // [M][Cout] fp32 output instead of bf16
     float* partial;           // split-K slabs [splitk][M][Cout]
     const uint16_t* zeros;    // >= 128 B of zeros
     int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, ups, HL, WL, M, K;
     int rows_per_batch, splitk, ktiles_per_split;
+    int idil;                 // input dilation 1 | 2 (strided data gradient / transposed conv): logical input = zero-interleaved x
     FastDivH fd_ow, fd_oh;
 };
 
@@ -136,8 +138,9 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
-            const bool ok = (unsigned)ih < (unsigned)p.HL && (unsigned)iw < (unsigned)p.WL;
+            bool ok = (unsigned)ih < (unsigned)p.HL && (unsigned)iw < (unsigned)p.WL;
             if (p.ups) { ih >>= 1; iw >>= 1; }
+            if (p.idil == 2) { ok = ok && !((ih | iw) & 1); ih >>= 1; iw >>= 1; }
             // offset computed unconditionally in 32 bits (the host checks the tensor has < 2^32 elements); select, do not branch
             const uint32_t off = ((uint32_t)(a_img[j] * p.H + ih) * (uint32_t)p.W + (uint32_t)iw) * Cs + cc;
             const uint16_t* g = ok ? src + off : zsrc;
@@ -252,6 +255,11 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
             }
+            if (p.residual_f) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.residual_f + o), r1 = *reinterpret_cast<const f32x4*>(p.residual_f + o + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+            }
             if (p.residual) {
                 const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
                 v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
                 float t = v[e];
                 if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
                 if (p.residual) t += bf2f(p.residual[o + e]);
+                if (p.residual_f) t += p.residual_f[o + e];
                 if (p.yf) p.yf[o + e] = t;
                 else p.y[o + e] = f2bf(t);
             }
@@ -292,6 +301,7 @@ __global__ void conv_splitk_reduce_h(const ConvDescH p) {
         if (p.bias) v += p.bias[n];
         if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
         if (p.residual) v += bf2f(p.residual[idx]);
+        if (p.residual_f) v += p.residual_f[idx];
         if (p.yf) p.yf[idx] = v;
         else p.y[idx] = f2bf(v);
     }
@@ -326,8 +336,9 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
-static void conv_plan_h(int M, int Cout, int K, int* tiles, int* s) {
-    *tiles = cdiv(M, 128) * cdiv(Cout, 128);
+static void conv_plan_h(int M, int Cout, int K, int* bn, int* tiles, int* s) {
+    *bn = Cout <= 64 ? 64 : 128;                   // 64-wide layers (ResNet layer1) would waste half of a 128-column tile
+    *tiles = cdiv(M, 128) * cdiv(Cout, *bn);
     int sp = 1;
     const int nkt = K / 64;
     while (*tiles * sp < 448 && nkt / (sp * 2) >= 6 && sp < 16) sp *= 2;      // >= ~2 workgroups per CU, >= 6 k tiles per slice
@@ -337,39 +348,42 @@ static void conv_plan_h(int M, int Cout, int K, int* tiles, int* s) {
 extern "C" {
 
 size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
-    int tiles, s;
-    conv_plan_h(M, Cout, K, &tiles, &s);
+    int bn, tiles, s;
+    conv_plan_h(M, Cout, K, &bn, &tiles, &s);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
 // bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
 // exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned x / x2 / w; zeros: >= 128 zero bytes.
 int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
-                     void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh,
-                     int sw, int ph, int pw, int ups, int OH, int OW, int rows_per_batch, void* workspace, size_t workspace_bytes,
-                     hipStream_t stream) {
+                     const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
+                     int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !w_packed || !zeros || (!y == !y_f32) || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
     if (C1 <= 0 || C1 % 64 || C2 < 0 || C2 % 64 || (C2 > 0 && !x2)) return V2A_ERR_ARG;
+    if ((idil != 1 && idil != 2) || (idil == 2 && ups) || (residual && residual_f32)) return V2A_ERR_ARG;
     if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)w_packed | (uintptr_t)zeros) & 15) != 0) return V2A_ERR_ARG;
     if ((double)N * H * W * (C1 > C2 ? C1 : C2) >= 4294967296.0) return V2A_ERR_ARG;      // the gather uses 32-bit element offsets
     ConvDescH p;
     p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.w = (const uint16_t*)w_packed;
-    p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual;
+    p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual; p.residual_f = residual_f32; p.idil = idil;
     p.y = (uint16_t*)y; p.yf = y_f32; p.partial = (float*)workspace; p.zeros = (const uint16_t*)zeros;
     p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.ups = ups ? 1 : 0;
-    p.HL = ups ? 2 * H : H; p.WL = ups ? 2 * W : W;
+    p.HL = ups ? 2 * H : (idil == 2 ? 2 * H - 1 : H);
+    p.WL = ups ? 2 * W : (idil == 2 ? 2 * W - 1 : W);
     p.M = N * OH * OW;
     p.K = KH * KW * (C1 + C2);
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.fd_ow = make_fastdiv_h((uint32_t)OW);
     p.fd_oh = make_fastdiv_h((uint32_t)OH);
-    int tiles, s;
-    conv_plan_h(p.M, Cout, p.K, &tiles, &s);
+    int bn, tiles, s;
+    conv_plan_h(p.M, Cout, p.K, &bn, &tiles, &s);
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(p.K / 64, s);
-    hipLaunchKernelGGL((conv_igemm_h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+    if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64>), dim3(tiles, s), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     if (s > 1) {
         const size_t total = (size_t)p.M * Cout;

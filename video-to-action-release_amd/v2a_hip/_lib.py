@@ -28,7 +28,7 @@ SIGNATURES = {
     "v2a_conv2d_wgrad": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),
     "v2a_pack_chunk_elems": (I, []),
-    "v2a_pack_weights_multi": (I, [P, P, I, P]),
+    "v2a_pack_weights_multi": (I, [P, P, I, I, P]),
     "v2a_groupnorm_workspace_bytes": (SZ, [I, I, I, I]),
     "v2a_groupnorm_fwd": (I, [P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
     "v2a_groupnorm_bwd": (I, [P] * 14 + [I, I, I, I, I, I, P, SZ, P]),
@@ -63,7 +63,7 @@ SIGNATURES = {
     "v2a_opt_state_bytes": (SZ, []),
     "v2a_opt_state_init": (I, [P, D, D, D, D, D, D, D, D, D, D, I, I]),
     "v2a_conv2d_h_workspace_bytes": (SZ, [I, I, I]),
-    "v2a_conv2d_fwd_h": (I, [P, P, P, P, P, P, P, P, P] + [I] * 16 + [P, SZ, P]),
+    "v2a_conv2d_fwd_h": (I, [P, P, P, P, P, P, P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_groupnorm_h_workspace_bytes": (SZ, [I, I, I]),
     "v2a_groupnorm_fwd_h": (I, [P, P, I, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
     "v2a_attention_fwd_h": (I, [P, P, I, I, I, I, P]),

@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only; every arithmetic op below is
 libv2a_hip.so launched on torch's current stream with raw pointers.
 All activations are channels-last fp32: images [N,H,W,C], sequences [N,T,C], video [B,F,H,W,C].
 """
+import weakref
 import torch
 from ._lib import lib, check
 
@@ -75,6 +76,27 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
     return out
 
 
+_H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '4096'))]
+_h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
+
+
+def register_h_twin(w_f32: torch.Tensor, w_h: torch.Tensor):
+    """Declare `w_h` (bf16) to hold the same packed operand as `w_f32`: in the bf16 precision mode conv2d then runs eligible
+    layers on the LDS-DMA bf16 kernel (csrc/igemm_h.hip) -- the fp32 activations are rounded to bf16 by a cast launch first."""
+    _h_twin[w_f32.data_ptr()] = (weakref.ref(w_f32), w_h)      # validated by identity: a recycled address never matches
+
+
+def _twin_of(w_packed):
+    ent = _h_twin.get(w_packed.data_ptr())
+    if ent is None:
+        return None
+    if ent[0]() is not w_packed:
+        if ent[0]() is None:
+            del _h_twin[w_packed.data_ptr()]
+        return None
+    return ent[1]
+
+
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
            residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]."""
@@ -84,6 +106,12 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     if x2 is not None:
         _chk(x2, "x2")
         C2 = x2.shape[-1]
+    if (_h_twin and bmode == 0 and y2 is None and not csplit and C1 % 64 == 0 and C2 % 64 == 0 and idil in (1, 2)
+            and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
+        wh = _twin_of(w_packed)
+        if wh is not None:
+            return conv2d_h(cast_h(x), wh, bias, Cout, KH, KW, stride, pad, x2=None if x2 is None else cast_h(x2), rowvec=rowvec,
+                            rows_per_batch=rows_per_batch, residual=residual, ups=ups, out_f32=True, idil=idil, out_hw=out_hw, y=y)
     sh, sw = stride
     ph, pw = pad
     if out_hw is None:
@@ -171,7 +199,7 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1, residual=None,
-             ups=False, out_f32=False):
+             ups=False, out_f32=False, idil=1, out_hw=None, y=None):
     """bf16-storage conv: x [N,H,W,C1] (+x2) bf16, w_packed bf16 [Cout][KH][KW][C1+C2], bias / rowvec fp32, residual bf16.
     Returns bf16 [N,OH,OW,Cout] (fp32 when out_f32).  Needs C1 % 64 == 0 and C2 % 64 == 0."""
     _chk_h(x, "x")
@@ -180,20 +208,26 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
     if x2 is not None:
         _chk_h(x2, "x2")
         C2 = x2.shape[-1]
-    if residual is not None:
-        _chk_h(residual, "residual")
+    res_h = residual if (residual is not None and residual.dtype == torch.bfloat16) else None
+    res_f = residual if (residual is not None and residual.dtype == torch.float32) else None
     sh, sw = stride
     ph, pw = pad
-    HL, WL = (2 * H, 2 * W) if ups else (H, W)
-    OH = (HL + 2 * ph - KH) // sh + 1
-    OW = (WL + 2 * pw - KW) // sw + 1
+    if out_hw is None:
+        HL, WL = (2 * H, 2 * W) if ups else (((H - 1) * idil + 1, (W - 1) * idil + 1) if idil > 1 else (H, W))
+        OH = (HL + 2 * ph - KH) // sh + 1
+        OW = (WL + 2 * pw - KW) // sw + 1
+    else:
+        OH, OW = out_hw
     M, K = N * OH * OW, KH * KW * (C1 + C2)
-    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    if y is None:
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    else:
+        out_f32 = y.dtype == torch.float32
     wsb = lib.v2a_conv2d_h_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_conv2d_fwd_h(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual),
+    check(lib.v2a_conv2d_fwd_h(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(res_h), _p(res_f),
                                None if out_f32 else y.data_ptr(), y.data_ptr() if out_f32 else None, _zero_line(x.device).data_ptr(),
-                               N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, OH, OW, rows_per_batch, _p(ws), wsb,
+                               N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil, OH, OW, rows_per_batch, _p(ws), wsb,
                                _stream()), "conv2d_fwd_h")
     return y
 

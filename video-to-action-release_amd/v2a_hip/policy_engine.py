@@ -48,6 +48,8 @@ class _Conv:
         self.nmaj = (self.co % 16 == 0) and (self.ci % 4 == 0)
         self._pf = None
         self._pd = None
+        self._pf_h = None          # bf16 twins of the two operands (bf16 precision mode, see PolicyEngine.refresh_packs)
+        self._pd_h = None
         self._ver = (None, None)
 
     @property
@@ -72,10 +74,18 @@ class _Conv:
             if self._pf is None or self._pf is w:
                 self._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
             ops.pack_weight(w, 0, self._pf)
-        if not self.nmaj:            # data gradient cannot read the forward pack (odd channel counts): keep a flipped pack
+        if not self.nmaj or self._pd is not None:     # flipped pack: odd channel counts always, every layer once the bf16 mode used it
             if self._pd is None:
                 self._pd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
             ops.pack_weight(w, 1, self._pd)
+        if self._pf_h is not None:                    # keep the bf16 twins in step with the fp32 operands
+            from ._lib import lib, check
+            for src, dst in ((self._pf, self._pf_h), (self._pd, self._pd_h)):
+                check(lib.v2a_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel() - src.numel() % 4, ops._stream()), "cast_f32_bf16")
+                if src.numel() % 4:
+                    dst[-(src.numel() % 4):] = src.reshape(-1)[-(src.numel() % 4):].to(torch.bfloat16)
+            ops.register_h_twin(self._pf, self._pf_h)
+            ops.register_h_twin(self._pd, self._pd_h)
         self._ver = (self.w.data_ptr(), self.w._version)
 
     def pf(self):
@@ -190,34 +200,52 @@ class PolicyEngine:
 
     def refresh_packs(self):
         """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable).
-        All forward packs go through ONE multi-tensor launch; only odd-channel layers keep a flipped data-gradient pack."""
+        Two multi-tensor launches write everything: the forward packs (gather within a filter) and the flipped data-gradient
+        packs (tap-reversed transposes through LDS; odd-channel layers always, every layer in the bf16 precision mode).  In that
+        mode both launches also write the bf16 twin of each operand, which ops.conv2d picks up for the layers the LDS-DMA
+        bf16 kernel can take."""
         from ._lib import lib, check
+        bf16 = lib.v2a_get_precision() == 1
+        if getattr(self, "_mp", None) is not None and self._mp["bf16"] != bf16:
+            self._mp = None
         if getattr(self, "_mp", None) is None:
-            rows, chunks = [], []
+            rows, ch0, ch1 = [], [], []
             ce = lib.v2a_pack_chunk_elems()
             for c in self._convs.values():
                 w = c.w.detach()
-                if c.kh * c.kw == 1:
+                taps = c.kh * c.kw
+                if bf16 and c._pf_h is None:
+                    c._pf_h = torch.empty(w.numel(), dtype=torch.bfloat16, device=self.device)
+                    c._pd_h = torch.empty(w.numel(), dtype=torch.bfloat16, device=self.device)
+                if taps == 1:
                     c._pf = w
-                    continue
-                if c._pf is None or c._pf.data_ptr() == w.data_ptr():
+                elif c._pf is None or c._pf.data_ptr() == w.data_ptr():
                     c._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
-                rows.append([w.data_ptr(), c._pf.data_ptr(), c.co, c.ci, c.kh * c.kw])
-                for s0 in range(0, w.numel(), ce):
-                    chunks.append([len(rows) - 1, s0])
-            self._mp = (torch.tensor(rows, dtype=torch.int64).to(self.device), torch.tensor(chunks, dtype=torch.int32).to(self.device),
-                        len(chunks), [c.w.data_ptr() for c in self._convs.values()])
-        tab, ch, n, ptrs = self._mp
-        if ptrs != [c.w.data_ptr() for c in self._convs.values()]:      # parameters were re-allocated (.to(), load): rebuild
+                if taps > 1 or bf16:                   # forward operand (1x1 weights are their own fp32 operand: twin only)
+                    rows.append([w.data_ptr(), c._pf.data_ptr() if taps > 1 else 0, c.co, c.ci, taps, 0, c._pf_h.data_ptr() if bf16 else 0])
+                    ch0 += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
+                if not c.nmaj or bf16:
+                    if c._pd is None:
+                        c._pd = torch.empty(w.numel(), dtype=torch.float32, device=self.device)
+                    rows.append([w.data_ptr(), c._pd.data_ptr(), c.co, c.ci, taps, 1, c._pd_h.data_ptr() if bf16 else 0])
+                    ntile = -(-c.co // 64) * -(-(c.ci * taps) // 64)
+                    ch1 += [[len(rows) - 1, t] for t in range(ntile)]
+                if bf16:
+                    ops.register_h_twin(c._pf, c._pf_h)
+                    ops.register_h_twin(c._pd, c._pd_h)
+            dev = self.device
+            t = lambda a, dt: torch.tensor(a, dtype=dt).to(dev) if a else None
+            self._mp = dict(tab=t(rows, torch.int64), ch0=t(ch0, torch.int32), n0=len(ch0), ch1=t(ch1, torch.int32), n1=len(ch1),
+                            ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16)
+        mp = self._mp
+        if mp["ptrs"] != [c.w.data_ptr() for c in self._convs.values()]:      # parameters were re-allocated (.to(), load): rebuild
             self._mp = None
             return self.refresh_packs()
-        check(lib.v2a_pack_weights_multi(tab.data_ptr(), ch.data_ptr(), n, ops._stream()), "pack_weights_multi")
-        bf16 = lib.v2a_get_precision() == 1
+        if mp["n0"]:
+            check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch0"].data_ptr(), mp["n0"], 0, ops._stream()), "pack_weights_multi")
+        if mp["n1"]:
+            check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"].data_ptr(), mp["n1"], 1, ops._stream()), "pack_weights_multi_t")
         for c in self._convs.values():
-            if not c.nmaj or bf16:
-                if c._pd is None:
-                    c._pd = torch.empty(c.w.numel(), dtype=torch.float32, device=self.device)
-                ops.pack_weight(c.w.detach(), 1, c._pd)
             c._ver = (c.w.data_ptr(), c.w._version)
 
     # ------------------------------------------------------------------ encoder
