@@ -108,9 +108,11 @@ def instrumented_pass(torch, trainer, steps):
     orig_axpy = ops.axpy
     ops.conv2d = timed("fwd", orig_fwd, f_fwd)
     ops.conv2d_wgrad = timed("wgrad", orig_wg, f_wg)
-    g_saved, a_saved = trainer.use_graph, trainer.eng.async_wgrad
+    g_saved, a_saved, e_saved, m_saved = trainer.use_graph, trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode
     trainer.use_graph = False
-    trainer.eng.async_wgrad = False          # measure every kernel alone on the main stream (the timed step overlaps them)
+    trainer.eng.async_wgrad = False          # measure every kernel alone on the main stream (the timed step overlaps the two
+    trainer.eng.enc_streams = False          # camera encoders as parallel graph branches)
+    trainer.eng._wg_mode = "0"
     try:
         for _ in range(steps):
             trainer.step()
@@ -118,7 +120,7 @@ def instrumented_pass(torch, trainer, steps):
     finally:
         ops.conv2d, ops.conv2d_wgrad = orig_fwd, orig_wg
         trainer.use_graph = g_saved
-        trainer.eng.async_wgrad = a_saved
+        trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode = a_saved, e_saved, m_saved
     agg, shapes = {}, {}
     for kind, (name, fl, shape), e0, e1 in recs:
         dt = e0.elapsed_time(e1) * 1e-3

@@ -114,7 +114,15 @@ class PolicyEngine:
         self.ac = self.ac_host.to(self.device)
         self._convs = {}
         import os as _os
-        self.async_wgrad = _os.environ.get("V2A_ASYNC_WGRAD", "1") != "0"
+        # the two camera encoders (separate weights, no shared state) run as parallel branches of the step graph: +17 % steps/s
+        # at B=64 (their small-grid kernels fill each other's idle CUs).  Weight gradients on a third stream used to give ~1 %
+        # alone and cost 10 % on top of the encoder branches, so they stay on their chain's stream by default
+        # ("unet": side stream for the ConditionalUnet1D weight gradients only).
+        self.enc_streams = _os.environ.get("V2A_ENC_STREAMS", "1") != "0"
+        self._enc_side = []
+        self._wg_mode = _os.environ.get("V2A_ASYNC_WGRAD", "0")
+        self.async_wgrad = self._wg_mode == "1"
+        self._in_enc = False
         self._side = None
         self._keep = []
         self._build()
@@ -183,7 +191,7 @@ class PolicyEngine:
     def _wg(self, *a, **k):
         """Weight gradients feed nothing until the optimiser: launch them on a side stream so they fill the CUs the latency-bound
         data-gradient chain leaves idle (captured as a parallel branch of the hipGraph).  Operands are kept alive until the join."""
-        if not self.async_wgrad:
+        if not (self.async_wgrad or (self._wg_mode == "unet" and not self._in_enc)):
             return ops.conv2d_wgrad(*a, **k)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -518,8 +526,27 @@ class PolicyEngine:
         return dgc
 
     # ------------------------------------------------------------------ policy level
+    def _enc_parallel(self, fns):
+        """Run the per-camera encoder chains (independent: separate weights, no shared state) as parallel branches: the first on
+        the current stream, the others on side streams with their own scratch lanes; joined before returning."""
+        if not self.enc_streams or len(fns) < 2:
+            return [f() for f in fns]
+        main = torch.cuda.current_stream()
+        while len(self._enc_side) < len(fns) - 1:
+            self._enc_side.append(torch.cuda.Stream(device=self.device))
+        out = [None] * len(fns)
+        for i, f in enumerate(fns[1:], 1):
+            st = self._enc_side[i - 1]
+            st.wait_stream(main)
+            with torch.cuda.stream(st), ops.ws_lane(1 + i):
+                out[i] = f()
+        out[0] = fns[0]()
+        for st in self._enc_side[:len(fns) - 1]:
+            main.wait_stream(st)
+        return out
+
     def global_cond(self, imgs: dict, save=None):
-        feats = [self.encode_fwd(k, imgs[k], save) for k in self.cfg.rgb_keys]
+        feats = self._enc_parallel([(lambda k=k: self.encode_fwd(k, imgs[k], save)) for k in self.cfg.rgb_keys])
         B = feats[0].shape[0]
         fd = feats[0].shape[1]
         gc = torch.empty((B, fd * len(feats)), dtype=torch.float32, device=feats[0].device)
@@ -577,10 +604,17 @@ class PolicyEngine:
         B = dgc.shape[0]
         fd = self.cfg.feature_dim
         nk = len(self.cfg.rgb_keys)
-        for i, key in enumerate(self.cfg.rgb_keys):
+        def one(i, key):
             df = torch.empty((B, fd), dtype=torch.float32, device=dgc.device)
             ops.copy2d(dgc, df, B, fd, fd * nk, fd, src_off=i * fd)
             self.encode_bwd(key, df, st["save_enc"][key], grads)
+            return df
+
+        self._in_enc = True
+        try:
+            self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
+        finally:
+            self._in_enc = False
         self._join_side()
 
     def arena_slices(self, names):
