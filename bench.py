@@ -113,6 +113,7 @@ def instrumented_pass(torch, trainer, steps):
     trainer.eng.async_wgrad = False          # measure every kernel alone on the main stream (the timed step overlaps the two
     trainer.eng.enc_streams = False          # camera encoders as parallel graph branches)
     trainer.eng._wg_mode = "0"
+    d_saved, trainer.eng.defer_unet_wgrad = trainer.eng.defer_unet_wgrad, False
     try:
         for _ in range(steps):
             trainer.step()
@@ -121,6 +122,7 @@ def instrumented_pass(torch, trainer, steps):
         ops.conv2d, ops.conv2d_wgrad = orig_fwd, orig_wg
         trainer.use_graph = g_saved
         trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode = a_saved, e_saved, m_saved
+        trainer.eng.defer_unet_wgrad = d_saved
     agg, shapes = {}, {}
     for kind, (name, fl, shape), e0, e1 in recs:
         dt = e0.elapsed_time(e1) * 1e-3
@@ -351,6 +353,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip the video-sampler leg (BASELINE.json configs[2])")
+    ap.add_argument("--no-predict", action="store_true", help="skip the predict_action latency leg")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented eager pass (profiling runs)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="MFMA precision of the contraction kernels: fp32 = exact-f32 (parity configuration, default); bf16 = bf16 inputs, "
                          "fp32 accumulate/storage (performance configuration)")
@@ -427,7 +431,7 @@ def main():
                "samples_per_sec": value * args.batch, "final_loss": loss,
                "step_algorithmic_tflops": flops_step / (ms * 1e-3) / 1e12}
     # ---- roofline of the dominant kernel (rank 0, N=1 only): instrumented eager pass
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_roofline_pass:
         agg = instrumented_pass(torch, tr, 3)
         tot = sum(v[1] for v in agg.values())
         name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
@@ -471,6 +475,8 @@ def main():
             v2a_hip.set_precision("fp32")
         # predict_action latency (B=1, DDIM-8, EMA-style replica) under hipGraph replay
         try:
+            if args.no_predict:
+                raise KeyboardInterrupt
             from v2a_hip.inference import GraphedPredictAction
             polq = tr.ema_for_inference()
             gp = GraphedPredictAction(polq, batch_size=1, use_ddim=True)
@@ -485,6 +491,8 @@ def main():
             out["predict_action"] = {"latency_ms": (time.perf_counter() - t2) / 50 * 1e3, "batch": 1, "sampler": "ddim-8",
                                      "note": "encoders + 8 ConditionalUnet1D steps + unnormalise, one hipGraph replay per call; "
                                              "reference CPU path 110 ms (SURVEY section 6)"}
+        except KeyboardInterrupt:
+            pass
         except Exception as e:                      # never let the secondary leg break the headline line
             out["predict_action"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_video:

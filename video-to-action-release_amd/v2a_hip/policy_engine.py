@@ -123,6 +123,14 @@ class PolicyEngine:
         self._wg_mode = _os.environ.get("V2A_ASYNC_WGRAD", "0")
         self.async_wgrad = self._wg_mode == "1"
         self._in_enc = False
+        # ConditionalUnet1D weight gradients feed nothing until the optimiser: with defer_unet_wgrad they are collected during the
+        # data-gradient chain and launched as ONE extra branch next to the two encoder backward chains (one fork / one join).
+        # The data-parallel trainer turns this off: there the `model.*` arena slice must be final after phase 1 so that its
+        # all-reduce can travel under the encoder backward.
+        self.defer_unet_wgrad = _os.environ.get("V2A_DEFER_UNET_WGRAD", "1") != "0"
+        self._deferred = []
+        self._collect_wg = False
+        self._wg_stream = None
         self._side = None
         self._keep = []
         self._build()
@@ -191,6 +199,9 @@ class PolicyEngine:
     def _wg(self, *a, **k):
         """Weight gradients feed nothing until the optimiser: launch them on a side stream so they fill the CUs the latency-bound
         data-gradient chain leaves idle (captured as a parallel branch of the hipGraph).  Operands are kept alive until the join."""
+        if self.defer_unet_wgrad and self._collect_wg:
+            self._deferred.append((a, k))
+            return None
         if not (self.async_wgrad or (self._wg_mode == "unet" and not self._in_enc)):
             return ops.conv2d_wgrad(*a, **k)
         if self._side is None:
@@ -594,9 +605,13 @@ class PolicyEngine:
         if arena is None:
             arena = torch.zeros(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)   # GN param grads accumulate
         grads = self.grad_views(arena, names)
-        dgc = self.unet_bwd(dpred, save, grads)
+        self._collect_wg = True
+        try:
+            dgc = self.unet_bwd(dpred, save, grads)
+        finally:
+            self._collect_wg = False
         self._join_side()
-        return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc)
+        return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc, keep=save)
 
     def backward_phase2(self, st):
         """image-encoder backward (the `obs_encoder.*` slice of the arena)."""
@@ -610,11 +625,22 @@ class PolicyEngine:
             self.encode_bwd(key, df, st["save_enc"][key], grads)
             return df
 
+        main = torch.cuda.current_stream()
+        deferred, self._deferred = self._deferred, []
+        if deferred:                                   # third branch: every ConditionalUnet1D weight gradient
+            if self._wg_stream is None:
+                self._wg_stream = torch.cuda.Stream(device=self.device)
+            self._wg_stream.wait_stream(main)
+            with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
+                for a, k in deferred:
+                    ops.conv2d_wgrad(*a, **k)
         self._in_enc = True
         try:
             self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
         finally:
             self._in_enc = False
+        if deferred:
+            main.wait_stream(self._wg_stream)
         self._join_side()
 
     def arena_slices(self, names):

@@ -36,6 +36,8 @@ class PolicyTrainer:
         self.eng = policy.engine
         self.device = self.eng.device
         self.world, self.rank, self.pg = world_size, rank, process_group
+        if world_size > 1:
+            self.eng.defer_unet_wgrad = False      # the model.* gradient slice must be final after phase 1 (its all-reduce starts there)
         opt_params = dict(lr=1e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6) if opt_params is None else dict(opt_params)
         ema_params = dict(update_after_step=0, inv_gamma=1.0, power=0.75, min_value=0.0, update_every=1) if ema_params is None else dict(ema_params)
         ema_params.pop("include_online_model", None)
