@@ -307,13 +307,14 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
     def timed_h(*a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = orig_h(*a, **k)
+        ret = orig_h(*a, **k)
         e1.record()
+        y = ret[0] if isinstance(ret, tuple) else ret
         x, cout, kh, kw = a[0], a[3], a[4], a[5]
         c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
         m = y.shape[0] * y.shape[1] * y.shape[2]
         recs.append(("conv_igemm_h<128,128>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
-        return y
+        return ret
 
     ops.conv2d = timed
     ops.conv2d_h = timed_h

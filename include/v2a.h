@@ -138,12 +138,15 @@ size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                      const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
                      int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
-                     void* workspace, size_t workspace_bytes, v2a_stream_t s);   /* residual (bf16) xor residual_f32; idil 1 | 2 */
+                     float* stats, void* workspace, size_t workspace_bytes, v2a_stream_t s);
+/* residual (bf16) xor residual_f32; idil 1 | 2; stats (optional, only when v2a_conv2d_h_workspace_bytes() == 0 and y is bf16):
+ * [ceil(M/64)][2][Cout] per-64-row sum / sum of squares of the rounded outputs, consumed by v2a_groupnorm_fwd_h */
 /* GroupNorm + activation and QKV attention over bf16 tensors (csrc/norm_h.hip, csrc/attention.hip): same math as v2a_groupnorm_fwd /
  * v2a_attention_fwd (reference nn.py:26-28 GroupNorm32 computes in fp32 and returns the input dtype; unet.py:341-358), bf16 I/O. */
 size_t v2a_groupnorm_h_workspace_bytes(int N, int S, int C);
 int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                        int N, int S, int C, int G, float eps, int act, void* workspace, size_t workspace_bytes, v2a_stream_t s);
+                        const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, int act, void* workspace,
+                        size_t workspace_bytes, v2a_stream_t s);
 int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int heads, int head_ch, v2a_stream_t s);
 int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, v2a_stream_t s);   /* [Cout][Cin][taps] f32 -> [Cout][taps][Cin] bf16 */
 int v2a_cast_f32_bf16(const float* x, void* y, size_t n, v2a_stream_t s);

@@ -416,3 +416,50 @@ def test_cast_roundtrip_and_pack_weight_h():
     w = torch.randn(5, 64, 3, 3, device=dev)
     p = ops.pack_weight_h(w).view(5, 3, 3, 64)
     assert torch.equal(p, w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,S,C1,C2,act", [(3, 1000, 128, 0, "silu"), (2, 777, 256, 128, "silu"), (4, 64, 640, 640, "silu"),
+                                            (5, 256, 512, 0, "none"), (2, 4099, 384, 0, "silu")])
+def test_groupnorm_fwd_h_matches_fp32_groupnorm_on_bf16_inputs(N, S, C1, C2, act):
+    from v2a_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(N * 1000 + S)
+    x = (torch.randn(N, S, C1, generator=g) * 2 + 0.5).to(torch.bfloat16).to(dev)
+    x2 = (torch.randn(N, S, C2, generator=g) - 0.3).to(torch.bfloat16).to(dev) if C2 else None
+    C = C1 + C2
+    gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    y = ops.groupnorm_fwd_h(x, gamma, beta, 32, act, x2=x2)
+    full = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    ref = torch.nn.functional.group_norm(full.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), eps=1e-5).permute(0, 2, 1)
+    if act == "silu":
+        ref = ref * torch.sigmoid(ref)
+    assert y.dtype == torch.bfloat16 and y.shape == (N, S, C)
+    err = (y.double() - ref).abs()
+    assert (err <= ref.abs() * 2.0 ** -8 + 1e-4 * ref.abs().max()).all(), float(err.max())
+
+
+@pytest.mark.gpu
+def test_conv_epilogue_statistics_feed_groupnorm():
+    """conv2d_h(want_stats=True) returns per-64-row sum / sum-of-squares slabs of its rounded outputs; GroupNorm consuming them
+    (two-source concat, ragged last tile) equals GroupNorm that computes its own statistics."""
+    from v2a_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(2)
+    N, H, W = 3, 24, 24                       # 576 rows per sample = 9 blocks of 64; M = 1728 = 13.5 tiles of 128
+    xa = torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).to(dev)       # K = 576: 9 k tiles, below the split-K threshold
+    xb = torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).to(dev)
+    wa = ops.pack_weight_h((torch.randn(192, 64, 3, 3, generator=g) * 0.05).to(dev))
+    wb = ops.pack_weight_h((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev))        # 64-wide: the BN=64 tile variant
+    ya, sa = ops.conv2d_h(xa, wa, None, 192, 3, 3, (1, 1), (1, 1), want_stats=True)
+    yb, sb = ops.conv2d_h(xb, wb, None, 64, 3, 3, (1, 1), (1, 1), want_stats=True)
+    assert sa is not None and sb is not None and sa.shape == (27, 2, 192) and sb.shape == (27, 2, 64)
+    rows = ya.float().view(27, 64, 192)
+    assert torch.allclose(sa[:, 0], rows.sum(1), rtol=1e-4, atol=1e-3) and torch.allclose(sa[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=1e-3)
+    C = 256
+    gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    own = ops.groupnorm_fwd_h(ya.view(N, H * W, 192), gamma, beta, 32, "silu", x2=yb.view(N, H * W, 64))
+    fused = ops.groupnorm_fwd_h(ya.view(N, H * W, 192), gamma, beta, 32, "silu", x2=yb.view(N, H * W, 64), stats=sa, stats2=sb)
+    d = (own.float() - fused.float()).abs()
+    assert (d <= own.float().abs() * 2.0 ** -7 + 1e-5).all(), float(d.max())            # at most one bf16 ulp apart
+    assert (d > 0).float().mean().item() < 0.01

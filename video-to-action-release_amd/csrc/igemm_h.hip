@@ -55,6 +55,7 @@ struct ConvDescH {
     float* yf;                // [M][Cout] fp32 output instead of bf16
     float* partial;           // split-K slabs [splitk][M][Cout]
     const uint16_t* zeros;    // >= 128 B of zeros
+    float* stats;             // optional [ceil(M/64)][2][Cout]: per 64-row block sum / sum of squares of the bf16 outputs (GroupNorm)
     int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, ups, HL, WL, M, K;
     int rows_per_batch, splitk, ktiles_per_split;
     int idil;                 // input dilation 1 | 2 (strided data gradient / transposed conv): logical input = zero-interleaved x
@@ -223,9 +224,13 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
     const int vrow = lane / V, vcol = (lane % V) * 8;
     const int n = n0 + wn + vcol;
     const bool vec_ok = (p.Cout % 8 == 0) && (n + 8 <= p.Cout);
-    float bv[8];
+    float bv[8], ssum[8], ssq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && p.splitk == 1 && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+        bv[e] = (p.bias && p.splitk == 1 && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+        ssum[e] = 0.f;
+        ssq[e] = 0.f;
+    }
 #pragma unroll
     for (int rr = 0; rr < WM; rr += 64 / V) {
         const int ml = rr + vrow;
@@ -272,11 +277,19 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
                 *reinterpret_cast<f32x4*>(p.yf + o) = o0;
                 *reinterpret_cast<f32x4*>(p.yf + o + 4) = o1;
             } else {
+                uint16_t h[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h[e] = f2bf(v[e]);
+                    const float r = bf2f(h[e]);                   // statistics of what the consumer will read
+                    ssum[e] += r;
+                    ssq[e] += r * r;
+                }
                 uint4 u;
-                u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-                u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+                u.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                u.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                u.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16);
+                u.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
                 *reinterpret_cast<uint4*>(p.y + o) = u;
             }
         } else {                                                  // ragged channel count (e.g. the 3-channel output head)
@@ -288,6 +301,27 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
                 if (p.yf) p.yf[o + e] = t;
                 else p.y[o + e] = f2bf(t);
             }
+        }
+    }
+    if (p.stats && p.splitk == 1 && vec_ok) {
+        // this wave's 64 rows x 64 channels: lanes with equal lane % V hold the same 8 channels for different rows
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = V; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
+        }
+        const int blk = (m0 + wm) >> 6;                                // 64-row block index of this wave's rows
+        if (lane < V && (m0 + wm) < p.M) {
+            float* dst = p.stats + (size_t)blk * 2 * p.Cout + n;
+            f32x4 a0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, a1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
+            f32x4 q0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, q1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
+            *reinterpret_cast<f32x4*>(dst) = a0;
+            *reinterpret_cast<f32x4*>(dst + 4) = a1;
+            *reinterpret_cast<f32x4*>(dst + p.Cout) = q0;
+            *reinterpret_cast<f32x4*>(dst + p.Cout + 4) = q1;
         }
     }
 }
@@ -358,7 +392,7 @@ size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
 int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                      const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
                      int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !w_packed || !zeros || (!y == !y_f32) || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
     if (C1 <= 0 || C1 % 64 || C2 < 0 || C2 % 64 || (C2 > 0 && !x2)) return V2A_ERR_ARG;
     if ((idil != 1 && idil != 2) || (idil == 2 && ups) || (residual && residual_f32)) return V2A_ERR_ARG;
@@ -370,6 +404,7 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
     p.y = (uint16_t*)y; p.yf = y_f32; p.partial = (float*)workspace; p.zeros = (const uint16_t*)zeros;
     p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.ups = ups ? 1 : 0;
+    p.stats = nullptr;
     p.HL = ups ? 2 * H : (idil == 2 ? 2 * H - 1 : H);
     p.WL = ups ? 2 * W : (idil == 2 ? 2 * W - 1 : W);
     p.M = N * OH * OW;
@@ -382,6 +417,11 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(p.K / 64, s);
+    // fused GroupNorm statistics need the single-pass epilogue, bf16 output and whole 8-channel vectors
+    if (stats) {
+        if (s > 1 || !y || Cout % 8) return V2A_ERR_ARG;
+        p.stats = stats;
+    }
     if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64>), dim3(tiles, s), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_igemm_h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();

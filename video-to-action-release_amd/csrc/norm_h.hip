@@ -17,9 +17,12 @@ struct GnDescH {
     uint16_t* y;            // [N][S][C]
     float* partial;         // [N][nchunk][2][C]
     float* ab;              // [N][2][C]  (scale, shift)
+    const float* st1;       // optional precomputed statistics of x : [N * S/64][2][C1] (conv epilogue, csrc/igemm_h.hip)
+    const float* st2;       // ... and of x2: [N * S/64][2][C - C1]
     float* mean;            // [N][G] or null
     float* rstd;            // [N][G] or null
     int N, S, C, C1, G, act, nchunk, rows_per_chunk;
+    uint32_t l8_magic, l8_shift;   // idx / (C/8) == umulhi(idx, l8_magic) >> l8_shift for idx < 2^31
     float eps;
 };
 
@@ -88,6 +91,34 @@ __global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
     for (int i = tid; i < 2 * C; i += 256) dst[i] = bins[i];
 }
 
+// statistics that came with the tensors (per-64-row [2][C_src] slabs from the conv epilogue, csrc/igemm_h.hip) -> the same
+// [N][nchunk][2][C] partial layout gn_stats_h writes: grid (nchunk, N), thread = one column of the virtual [2][C] slab, coalesced
+// across threads, `rows_per_chunk` here counts 64-row slabs per chunk.
+__global__ __launch_bounds__(256) void gn_reduce_blocks_h(const GnDescH p) {
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int nb = p.S >> 6;
+    const int b0 = chunk * p.rows_per_chunk, b1 = min(nb, b0 + p.rows_per_chunk);
+    const int C = p.C, C1 = p.x2 ? p.C1 : C, C2 = C - C1;
+    float* dst = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
+    for (int col = threadIdx.x; col < 2 * C; col += 256) {
+        const int half = col >= C, c = half ? col - C : col;
+        const bool first = c < C1;
+        const float* src = first ? p.st1 + (size_t)half * C1 + c : p.st2 + (size_t)half * C2 + (c - C1);
+        const size_t stride = first ? 2 * (size_t)C1 : 2 * (size_t)C2;
+        const float* q = src + ((size_t)n * nb + b0) * stride;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = b0;
+        for (; b + 3 < b1; b += 4, q += 4 * stride) {             // four independent loads in flight
+            a0 += q[0];
+            a1 += q[stride];
+            a2 += q[2 * stride];
+            a3 += q[3 * stride];
+        }
+        for (; b < b1; ++b, q += stride) a0 += q[0];
+        dst[col] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 // one wave per (n, group): fp64 combine over chunks and the group's channels, then the per-channel affine of the apply pass
 __global__ __launch_bounds__(64) void gn_finalize_h(const GnDescH p) {
     const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, lane = threadIdx.x;
@@ -119,31 +150,50 @@ __global__ __launch_bounds__(64) void gn_finalize_h(const GnDescH p) {
     }
 }
 
+// grid (chunks, N): 32-bit indexing inside one sample, row / column split by a launch-invariant reciprocal (no 64-bit divides),
+// four independent 16-B loads in flight per thread.
 __global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
     const int L8 = p.C >> 3;
-    const size_t per_n = (size_t)p.S * L8;
-    const size_t total = per_n * p.N;
+    const uint32_t per_n = (uint32_t)p.S * (uint32_t)L8;
+    const int n = blockIdx.y;
     const int C1 = p.x2 ? p.C1 : p.C, C2 = p.C - C1;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int n = (int)(idx / per_n);
-        const size_t rem = idx - (size_t)n * per_n;
-        const size_t row = rem / L8;
-        const int c = (int)(rem - row * L8) * 8;
-        const size_t grow = (size_t)n * p.S + row;
-        const uint16_t* src = (c < C1) ? p.x + grow * C1 + c : p.x2 + grow * C2 + (c - C1);
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(src), f);
-        const float* a = p.ab + (size_t)n * 2 * p.C + c;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a + p.C), b1 = *reinterpret_cast<const f32x4*>(a + p.C + 4);
-        float o[8];
+    const uint16_t* xa = p.x + (size_t)n * p.S * C1;
+    const uint16_t* xb = p.x2 ? p.x2 + (size_t)n * p.S * C2 : nullptr;
+    uint16_t* yo = p.y + (size_t)n * p.S * p.C;
+    const float* ab = p.ab + (size_t)n * 2 * p.C;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < per_n; i0 += 4 * stride) {
+        uint4 u[4];
+        uint32_t row[4];
+        int c[4];
+        bool ok[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[e] = act_fwd(f[e] * a0[e] + b0[e], p.act);
-            o[e + 4] = act_fwd(f[e + 4] * a1[e] + b1[e], p.act);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t idx = i0 + k * stride;
+            ok[k] = idx < per_n;
+            const uint32_t id = ok[k] ? idx : 0u;
+            row[k] = (L8 == 1) ? id : (__umulhi(id, p.l8_magic) >> p.l8_shift);   // id / L8 (exact for id < 2^31: host-side magic)
+            c[k] = (int)(id - row[k] * (uint32_t)L8) * 8;
+            const uint16_t* src = (c[k] < C1) ? xa + (size_t)row[k] * C1 + c[k] : xb + (size_t)row[k] * C2 + (c[k] - C1);
+            u[k] = ok[k] ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
         }
-        uint4 u = {pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
-        *reinterpret_cast<uint4*>(p.y + grow * p.C + c) = u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            float f[8];
+            unpack8(u[k], f);
+            const float* a = ab + c[k];
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a + p.C), b1 = *reinterpret_cast<const f32x4*>(a + p.C + 4);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = act_fwd(f[e] * a0[e] + b0[e], p.act);
+                o[e + 4] = act_fwd(f[e + 4] * a1[e] + b1[e], p.act);
+            }
+            uint4 v = {pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            *reinterpret_cast<uint4*>(yo + (size_t)row[k] * p.C + c[k]) = v;
+        }
     }
 }
 
@@ -166,29 +216,56 @@ size_t v2a_groupnorm_h_workspace_bytes(int N, int S, int C) {
 }
 
 // y = act(GroupNorm_G(cat[x, x2]) * gamma + beta), all activations bf16 [N][S][C]; mean / rstd ([N][G], fp32) optional outputs.
-// C % 8 == 0, C1 % 8 == 0, C % G == 0.
+// C % 8 == 0, C1 % 8 == 0, C % G == 0.  stats1 / stats2 (optional): per-64-row [2][C_src] sum / sum-of-squares slabs written by
+// v2a_conv2d_fwd_h for x / x2 -- the statistics pass is skipped (S % 64 == 0 required).
 int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                        int N, int S, int C, int G, float eps, int act, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                        const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, int act, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || N <= 0 || S <= 0 || C <= 0 || G <= 0 || C % G || C % 8) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 8)) return V2A_ERR_ARG;
     if (2 * C * sizeof(float) > 64 * 1024) return V2A_ERR_ARG;
     GnDescH p;
     p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.gamma = gamma; p.beta = beta; p.y = (uint16_t*)y;
     p.mean = mean; p.rstd = rstd;
+    p.st1 = stats1; p.st2 = stats2;
+    if (stats1 && ((S & 63) || (x2 && !stats2))) return V2A_ERR_ARG;      // 64-row statistic blocks must tile every sample
     p.N = N; p.S = S; p.C = C; p.C1 = x2 ? C1 : C; p.G = G; p.act = act; p.eps = eps;
     gn_chunks_h(N, S, &p.nchunk, &p.rows_per_chunk);
     const size_t need = ((size_t)N * p.nchunk * 2 * C + (size_t)N * 2 * C) * sizeof(float);
     if (!workspace || workspace_bytes < need) return V2A_ERR_WORKSPACE;
     p.partial = (float*)workspace;
     p.ab = p.partial + (size_t)N * p.nchunk * 2 * C;
-    hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
-    V2A_CHECK_LAUNCH();
+    if (!stats1) {
+        hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+        V2A_CHECK_LAUNCH();
+    } else {
+        const int nb = S >> 6;
+        int nch = cdiv(nb, 8);                                    // ~8 slabs per workgroup: thousands of short workgroups
+        if (nch > p.nchunk) nch = p.nchunk;                       // stay inside the workspace sized for the statistics pass
+        p.nchunk = nch;
+        p.rows_per_chunk = cdiv(nb, nch);                         // 64-row slabs per chunk
+        p.ab = p.partial + (size_t)N * p.nchunk * 2 * C;
+        hipLaunchKernelGGL(gn_reduce_blocks_h, dim3(p.nchunk, N), dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(gn_finalize_h, dim3(N * G), dim3(64), 0, stream, p);
     V2A_CHECK_LAUNCH();
-    const size_t vecs = (size_t)N * S * (C / 8);
-    int g = (int)((vecs + 255) / 256);
-    if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(gn_apply_h, dim3(g), dim3(256), 0, stream, p);
+    {   // round-up reciprocal of L8: exact quotient for every idx < 2^31 (Granlund-Montgomery with a 32+s bit magic, s = ceil(log2 d))
+        const uint32_t d = (uint32_t)(C / 8);
+        uint32_t sft = 0;
+        while ((1u << sft) < d) ++sft;
+        const uint64_t m = ((1ull << (31 + sft)) + d - 1) / d;      // < 2^32 because 2^sft < 2 d
+        p.l8_magic = (uint32_t)m;
+        p.l8_shift = sft - 1 + 0;                                    // umulhi gives >> 32; total shift 31 + sft
+        if (d == 1) { p.l8_magic = 0; p.l8_shift = 0; }              // the kernel special-cases L8 == 1
+    }
+    if ((double)S * (C / 8) >= 2147483648.0) return V2A_ERR_ARG;
+    const size_t vecs = (size_t)S * (C / 8);
+    int g = (int)((vecs + 1023) / 1024);
+    int cap = 8192 / N;
+    if (cap < 32) cap = 32;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL(gn_apply_h, dim3(g, N), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

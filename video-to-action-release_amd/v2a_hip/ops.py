@@ -155,6 +155,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
 
 # ---- bf16-storage family (csrc/igemm_h.hip): activations / packed weights are torch.bfloat16 tensors, accumulation fp32
 _zeros_h = {}
+_FUSED_STATS = __import__('os').environ.get('V2A_GN_FUSED_STATS', '1') != '0'
 
 
 def _zero_line(device):
@@ -199,7 +200,7 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1, residual=None,
-             ups=False, out_f32=False, idil=1, out_hw=None, y=None):
+             ups=False, out_f32=False, idil=1, out_hw=None, y=None, want_stats=False):
     """bf16-storage conv: x [N,H,W,C1] (+x2) bf16, w_packed bf16 [Cout][KH][KW][C1+C2], bias / rowvec fp32, residual bf16.
     Returns bf16 [N,OH,OW,Cout] (fp32 when out_f32).  Needs C1 % 64 == 0 and C2 % 64 == 0."""
     _chk_h(x, "x")
@@ -225,18 +226,25 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         out_f32 = y.dtype == torch.float32
     wsb = lib.v2a_conv2d_h_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
+    stats = None
+    if want_stats and _FUSED_STATS and wsb == 0 and not out_f32 and Cout % 8 == 0:      # single-pass epilogue: GroupNorm statistics ride along
+        stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device)
     check(lib.v2a_conv2d_fwd_h(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(res_h), _p(res_f),
                                None if out_f32 else y.data_ptr(), y.data_ptr() if out_f32 else None, _zero_line(x.device).data_ptr(),
-                               N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil, OH, OW, rows_per_batch, _p(ws), wsb,
-                               _stream()), "conv2d_fwd_h")
+                               N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil, OH, OW, rows_per_batch, _p(stats),
+                               _p(ws), wsb, _stream()), "conv2d_fwd_h")
+    if want_stats:
+        return y, stats
     return y
 
 
-def linear(x2d, w, bias=None, residual=None):
+def linear(x2d, w, bias=None, residual=None, want_stats=False):
     """y = x @ w.T + b for x [M,K], torch weight [N,K] (already K-contiguous: no pack needed).  bf16 x takes a bf16 weight."""
     M, K = x2d.shape
     if x2d.dtype == torch.bfloat16:
-        return conv2d_h(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=residual).view(M, w.shape[0])
+        r = conv2d_h(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=None if residual is None else residual.view(1, 1, M, -1),
+                     want_stats=want_stats)
+        return (r[0].view(M, w.shape[0]), r[1]) if want_stats else r.view(M, w.shape[0])
     y = conv2d(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=residual)
     return y.view(M, w.shape[0])
 
@@ -268,8 +276,9 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     return y, mean, rstd
 
 
-def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None):
-    """bf16-storage GroupNorm + activation: x [N,S,C1] (+ x2 [N,S,C2] virtual concat) bf16 -> y [N,S,C] bf16."""
+def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None, stats2=None):
+    """bf16-storage GroupNorm + activation: x [N,S,C1] (+ x2 [N,S,C2] virtual concat) bf16 -> y [N,S,C] bf16.
+    stats / stats2: the per-64-row statistic slabs conv2d_h(want_stats=True) returned with x / x2 (skips the statistics pass)."""
     _chk_h(x, "x")
     N, S, C1 = x.shape
     C = C1 + (x2.shape[-1] if x2 is not None else 0)
@@ -278,8 +287,10 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None):
     y = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
     wsb = lib.v2a_groupnorm_h_workspace_bytes(N, S, C)
     ws = workspace(wsb, x.device)
-    check(lib.v2a_groupnorm_fwd_h(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, None, N, S, C, G,
-                                  eps, ACT[act], ws.data_ptr(), wsb, _stream()), "groupnorm_fwd_h")
+    if stats is None or S % 64 or (x2 is not None and stats2 is None):
+        stats = stats2 = None
+    check(lib.v2a_groupnorm_fwd_h(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), None, None, _p(stats),
+                                  _p(stats2), N, S, C, G, eps, ACT[act], ws.data_ptr(), wsb, _stream()), "groupnorm_fwd_h")
     return y
 
 

@@ -130,25 +130,35 @@ class UNetEngine:
         t_half = has_t and cout % 64 == 0
         x4 = x.view(B * Fr, H, W, C)
         x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
+        sp_f32 = (has_t and not t_half) or (out_f32 and not has_t)
         y = ops.conv2d_h(x4, self.w(name + ".spatial_conv.weight", half=True), self.p(name + ".spatial_conv.bias"), cout, k, k,
                          (stride, stride), (k // 2, k // 2), x2=x24, ups=ups, rowvec=None if has_t else rowvec, rows_per_batch=1,
                          residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout),
-                         out_f32=(has_t and not t_half) or (out_f32 and not has_t))
+                         out_f32=sp_f32, want_stats=not has_t and not sp_f32)
+        stats = None
+        if not has_t and not sp_f32:
+            y, stats = y
         OH, OW = y.shape[1], y.shape[2]
         if not has_t:
             if rowvec is not None:
                 raise NotImplementedError("rowvec on a conv without temporal part")
-            return y.view(B, Fr, OH, OW, cout)
+            out = y.view(B, Fr, OH, OW, cout)
+            out._gn_stats = stats        # per-64-row sum / sum-of-squares slabs: the next GroupNorm skips its statistics pass
+            return out
         if t_half:
             z = ops.conv2d_h(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
                              self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
                              rows_per_batch=Fr * OH * OW, residual=None if residual is None else residual.view(B, Fr, OH * OW, cout),
-                             out_f32=out_f32)
+                             out_f32=out_f32, want_stats=not out_f32)
+            if not out_f32:
+                z, stats = z
         else:
             assert residual is None and out_f32
             z = ops.conv2d(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight"), self.p(name + ".temporal_conv.bias"),
                            cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW)
-        return z.view(B, Fr, OH, OW, cout)
+        out = z.view(B, Fr, OH, OW, cout)
+        out._gn_stats = stats
+        return out
 
     def conv3d(self, x, name, cout, stride=1, ups=False, x2=None, rowvec=None, residual=None, out_f32=False):
         """x [B,F,H,W,C] (+x2) -> [B,F,OH,OW,cout].  rowvec [B,cout] / residual [B,F,OH,OW,cout] land in the LAST kernel."""
@@ -169,10 +179,13 @@ class UNetEngine:
                 raise NotImplementedError("rowvec on a conv without temporal part")
             return y.view(B, Fr, OH, OW, cout)
         if self.storage == "bf16" and cout % 64 == 0:      # stem: fp32 spatial conv (Cin = 6), the 128-wide temporal conv on the bf16 kernel
-            z = ops.conv2d_h(ops.cast_h(y).view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
-                             self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW,
-                             residual=None if residual is None else residual.view(B, Fr, OH * OW, cout))
-            return z.view(B, Fr, OH, OW, cout)
+            z, stats = ops.conv2d_h(ops.cast_h(y).view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
+                                    self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
+                                    rows_per_batch=Fr * OH * OW, residual=None if residual is None else residual.view(B, Fr, OH * OW, cout),
+                                    want_stats=True)
+            out = z.view(B, Fr, OH, OW, cout)
+            out._gn_stats = stats
+            return out
         wt = self.w(name + ".temporal_conv.weight")
         z = ops.conv2d(y.view(B, Fr, OH * OW, cout), wt, self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0),
                        rowvec=rowvec, rows_per_batch=Fr * OH * OW,
@@ -187,7 +200,9 @@ class UNetEngine:
         x3 = x.view(N, S, C1)
         x23 = None if x2 is None else x2.view(N, S, -1)
         if x.dtype == torch.bfloat16:
-            return ops.groupnorm_fwd_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23).view(B, Fr, H, W, C)
+            return ops.groupnorm_fwd_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
+                                       stats=getattr(x, "_gn_stats", None),
+                                       stats2=None if x2 is None else getattr(x2, "_gn_stats", None)).view(B, Fr, H, W, C)
         if x23 is not None and S * (C // 32) <= GN_SMALL_MAX:
             cat = torch.empty((N, S, C), dtype=torch.float32, device=x.device)      # tiny tensors: materialise the concat
             ops.copy2d(x3, cat, N * S, C1, C1, C)
@@ -220,6 +235,11 @@ class UNetEngine:
         wo = self.w(name + ".proj_out.weight", True).view(C, C) if half else self.p(name + ".proj_out.weight").view(C, C)
         qkv = ops.linear(n.view(N * L, C), wq, self.p(name + ".qkv.bias"))
         a = ops.attention(qkv, N, L, heads, hc)
+        if half:
+            out, stats = ops.linear(a, wo, self.p(name + ".proj_out.bias"), residual=x.view(N * L, C), want_stats=True)
+            out = out.view(B, Fr, H, W, C)
+            out._gn_stats = stats
+            return out
         out = ops.linear(a, wo, self.p(name + ".proj_out.bias"), residual=x.view(N * L, C))
         return out.view(B, Fr, H, W, C)
 
