@@ -139,6 +139,13 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
                      const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
                      int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
                      float* stats, void* workspace, size_t workspace_bytes, v2a_stream_t s);
+/* the same LDS-DMA kernel over fp32 tensors with the exact-f32 MFMA: parity-configuration conv for channel counts that are multiples of
+ * 32 (replaces v2a_conv2d_fwd for those layers; w_packed = the fp32 forward pack [Cout][KH][KW][C1+C2]) */
+size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K);
+int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
+                           const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
+                           int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, float* stats,
+                           void* workspace, size_t workspace_bytes, v2a_stream_t s);
 /* residual (bf16) xor residual_f32; idil 1 | 2; stats (optional, only when v2a_conv2d_h_workspace_bytes() == 0 and y is bf16):
  * [ceil(M/64)][2][Cout] per-64-row sum / sum of squares of the rounded outputs, consumed by v2a_groupnorm_fwd_h */
 /* GroupNorm + activation and QKV attention over bf16 tensors (csrc/norm_h.hip, csrc/attention.hip): same math as v2a_groupnorm_fwd /

@@ -44,17 +44,18 @@ __device__ __forceinline__ uint32_t fdivh(uint32_t n, const FastDivH& f) {
 }
 
 struct ConvDescH {
-    const uint16_t* x;        // source 1: [N, H, W, C1] bf16
-    const uint16_t* x2;       // source 2 (concat along C) or null
-    const uint16_t* w;        // [Cout][KH*KW*(C1+C2)] bf16
+    // T = storage type of the kernel instance: bf16 (uint16_t) or fp32 (float, exact-f32 MFMA: the parity configuration's kernels)
+    const void* x;            // source 1: [N, H, W, C1] T
+    const void* x2;           // source 2 (concat along C) or null
+    const void* w;            // [Cout][KH*KW*(C1+C2)] T
     const float* bias;        // [Cout] or null
     const float* rowvec;      // [M / rows_per_batch][Cout] or null
-    const uint16_t* residual; // [M][Cout] bf16 or null
-    const float* residual_f;  // [M][Cout] fp32 residual (alternative to `residual`) or null
-    uint16_t* y;              // [M][Cout] bf16 (null when yf is used)
-    float* yf;                // [M][Cout] fp32 output instead of bf16
+    const void* residual;     // [M][Cout] T or null
+    const float* residual_f;  // bf16 instances: [M][Cout] fp32 residual (alternative to `residual`) or null
+    void* y;                  // [M][Cout] T (null when yf is used)
+    float* yf;                // bf16 instances: [M][Cout] fp32 output instead of bf16
     float* partial;           // split-K slabs [splitk][M][Cout]
-    const uint16_t* zeros;    // >= 128 B of zeros
+    const void* zeros;        // >= 128 B of zeros
     float* stats;             // optional [ceil(M/64)][2][Cout]: per 64-row block sum / sum of squares of the bf16 outputs (GroupNorm)
     int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, ups, HL, WL, M, K;
     int rows_per_batch, splitk, ktiles_per_split;
@@ -76,9 +77,14 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
-template <int BM, int BN>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, typename T>
 __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
-    constexpr int ROWB = 128;                       // bytes per tile row (64 bf16)
+    constexpr int ROWB = 128;                       // bytes per tile row (64 bf16 / 32 fp32)
+    constexpr int EPT = ROWB / (int)sizeof(T);      // elements per k tile
+    constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-B chunk
+    constexpr bool HALF = sizeof(T) == 2;
     constexpr int AL = BM / 32, BL = BN / 32;       // DMA pieces per thread per tile (32 rows x 8 chunks per 256-thread pass)
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int BUF = (BM + BN) * ROWB;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
     const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
     const int split = blockIdx.y;
     const int Cin = p.C1 + p.C2;
-    const int nkt = p.K >> 6;
+    const int nkt = p.K / EPT;
     const int kt_begin = split * p.ktiles_per_split;
     const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
 
@@ -113,18 +119,18 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
         a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);       // rows past M fail the bounds test below
         a_iwb[j] = ow * p.sw - p.pw;
     }
-    const uint16_t* zsrc = p.zeros + chunk * 8;
-    const uint16_t* b_src[BL];
+    const T* zsrc = reinterpret_cast<const T*>(p.zeros) + chunk * EPC;
+    const T* b_src[BL];
     bool b_ok[BL];
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
         const int n = n0 + j * 32 + lrow;
         b_ok[j] = n < p.Cout;
-        b_src[j] = b_ok[j] ? p.w + (size_t)n * p.K + chunk * 8 : zsrc;
+        b_src[j] = b_ok[j] ? reinterpret_cast<const T*>(p.w) + (size_t)n * p.K + chunk * EPC : zsrc;
     }
 
     // running (tap, channel) position of the next k tile to issue
-    int ik0 = kt_begin * 64;
+    int ik0 = kt_begin * EPT;
     int itap = ik0 / Cin;
     int ic0 = ik0 - itap * Cin;
     int ikh = itap / p.KW, ikw = itap - ikh * p.KW;
@@ -133,9 +139,9 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
         unsigned char* abase = smem + buf * BUF;
         unsigned char* bbase = abase + BM * ROWB;
         const bool first = ic0 < p.C1;
-        const uint16_t* src = first ? p.x : p.x2;
+        const T* src = reinterpret_cast<const T*>(first ? p.x : p.x2);
         const uint32_t Cs = (uint32_t)(first ? p.C1 : p.C2);
-        const uint32_t cc = (uint32_t)((first ? ic0 : ic0 - p.C1) + chunk * 8);
+        const uint32_t cc = (uint32_t)((first ? ic0 : ic0 - p.C1) + chunk * EPC);
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
@@ -144,16 +150,16 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
             if (p.idil == 2) { ok = ok && !((ih | iw) & 1); ih >>= 1; iw >>= 1; }
             // offset computed unconditionally in 32 bits (the host checks the tensor has < 2^32 elements); select, do not branch
             const uint32_t off = ((uint32_t)(a_img[j] * p.H + ih) * (uint32_t)p.W + (uint32_t)iw) * Cs + cc;
-            const uint16_t* g = ok ? src + off : zsrc;
+            const T* g = ok ? src + off : zsrc;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + (j * 256 + wid * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < BL; ++j) {
-            const uint16_t* g = b_src[j] + (b_ok[j] ? ik0 : 0);
+            const T* g = b_src[j] + (b_ok[j] ? ik0 : 0);
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbase + (j * 256 + wid * 64) * 16), 16, 0, 0);
         }
-        ik0 += 64;
-        ic0 += 64;
+        ik0 += EPT;
+        ic0 += EPT;
         if (ic0 >= Cin) {
             ic0 = 0;
             if (++ikw == p.KW) { ikw = 0; ++ikh; }
@@ -187,16 +193,33 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int pos = (((h << 1) | lk) ^ rswz) << 4;
-            bf16x8 a[TM], b[TN];
+            if constexpr (HALF) {
+                bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + pos);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + pos);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + b_off[j] + pos);
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + b_off[j] + pos);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                // one b128 fetch per operand row feeds FOUR exact-f32 MFMA k-steps: lanes with lk = 0 supply k = 8h + e, the others
+                // k = 8h + 4 + e, for A and B alike (the order of an exact fp32 sum is free)
+                f32x4_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(base + a_off[i] + pos);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(base + b_off[j] + pos);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
         }
         buf ^= 1;
     }
@@ -266,16 +289,28 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
                 for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
             }
             if (p.residual) {
-                const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
-                v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                if constexpr (HALF) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
+                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                    v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                    v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                } else {
+                    const float* rp = reinterpret_cast<const float*>(p.residual) + o;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                }
             }
-            if (p.yf) {
+            if (!HALF || p.yf) {
+                float* yo = HALF ? p.yf : reinterpret_cast<float*>(p.y);
                 f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                *reinterpret_cast<f32x4*>(p.yf + o) = o0;
-                *reinterpret_cast<f32x4*>(p.yf + o + 4) = o1;
+                *reinterpret_cast<f32x4*>(yo + o) = o0;
+                *reinterpret_cast<f32x4*>(yo + o + 4) = o1;
+                if (!HALF) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                }
             } else {
                 uint16_t h[8];
 #pragma unroll
@@ -290,16 +325,17 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
                 u.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
                 u.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16);
                 u.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
-                *reinterpret_cast<uint4*>(p.y + o) = u;
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + o) = u;
             }
         } else {                                                  // ragged channel count (e.g. the 3-channel output head)
             for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                 float t = v[e];
                 if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
-                if (p.residual) t += bf2f(p.residual[o + e]);
+                if (p.residual) t += HALF ? bf2f(reinterpret_cast<const uint16_t*>(p.residual)[o + e]) : reinterpret_cast<const float*>(p.residual)[o + e];
                 if (p.residual_f) t += p.residual_f[o + e];
-                if (p.yf) p.yf[o + e] = t;
-                else p.y[o + e] = f2bf(t);
+                if (!HALF) reinterpret_cast<float*>(p.y)[o + e] = t;
+                else if (p.yf) p.yf[o + e] = t;
+                else reinterpret_cast<uint16_t*>(p.y)[o + e] = f2bf(t);
             }
         }
     }
@@ -326,7 +362,9 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
     }
 }
 
+template <typename T>
 __global__ void conv_splitk_reduce_h(const ConvDescH p) {
+    constexpr bool HALF = sizeof(T) == 2;
     const size_t total = (size_t)p.M * p.Cout;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / p.Cout), n = (int)(idx - (size_t)m * p.Cout);
@@ -334,10 +372,11 @@ __global__ void conv_splitk_reduce_h(const ConvDescH p) {
         for (int s = 0; s < p.splitk; ++s) v += p.partial[(size_t)s * total + idx];
         if (p.bias) v += p.bias[n];
         if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
-        if (p.residual) v += bf2f(p.residual[idx]);
+        if (p.residual) v += HALF ? bf2f(reinterpret_cast<const uint16_t*>(p.residual)[idx]) : reinterpret_cast<const float*>(p.residual)[idx];
         if (p.residual_f) v += p.residual_f[idx];
-        if (p.yf) p.yf[idx] = v;
-        else p.y[idx] = f2bf(v);
+        if (!HALF) reinterpret_cast<float*>(p.y)[idx] = v;
+        else if (p.yf) p.yf[idx] = v;
+        else reinterpret_cast<uint16_t*>(p.y)[idx] = f2bf(v);
     }
 }
 
@@ -370,11 +409,11 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
-static void conv_plan_h(int M, int Cout, int K, int* bn, int* tiles, int* s) {
+static void conv_plan_h(int M, int Cout, int K, int ept, int* bn, int* tiles, int* s) {
     *bn = Cout <= 64 ? 64 : 128;                   // 64-wide layers (ResNet layer1) would waste half of a 128-column tile
     *tiles = cdiv(M, 128) * cdiv(Cout, *bn);
     int sp = 1;
-    const int nkt = K / 64;
+    const int nkt = K / ept;                       // k tiles of 128 B: 64 bf16 or 32 fp32
     while (*tiles * sp < 448 && nkt / (sp * 2) >= 6 && sp < 16) sp *= 2;      // >= ~2 workgroups per CU, >= 6 k tiles per slice
     *s = sp;
 }
@@ -383,25 +422,34 @@ extern "C" {
 
 size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
     int bn, tiles, s;
-    conv_plan_h(M, Cout, K, &bn, &tiles, &s);
+    conv_plan_h(M, Cout, K, 64, &bn, &tiles, &s);
+    return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
+}
+size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K) {
+    int bn, tiles, s;
+    conv_plan_h(M, Cout, K, 32, &bn, &tiles, &s);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
-// bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
-// exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned x / x2 / w; zeros: >= 128 zero bytes.
-int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
-                     const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
-                     int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
-                     float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !w_packed || !zeros || (!y == !y_f32) || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
-    if (C1 <= 0 || C1 % 64 || C2 < 0 || C2 % 64 || (C2 > 0 && !x2)) return V2A_ERR_ARG;
+}  // extern "C"
+
+// shared launcher of the two storage types (ept = elements per 128-B k tile: 64 bf16 / 32 fp32)
+template <typename T>
+static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
+                           const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2,
+                           int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
+                           float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr int ept = 128 / (int)sizeof(T);
+    if (!x || !w_packed || !zeros || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
+    if (C1 <= 0 || C1 % ept || C2 < 0 || C2 % ept || (C2 > 0 && !x2)) return V2A_ERR_ARG;
     if ((idil != 1 && idil != 2) || (idil == 2 && ups) || (residual && residual_f32)) return V2A_ERR_ARG;
-    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)w_packed | (uintptr_t)zeros) & 15) != 0) return V2A_ERR_ARG;
+    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)w_packed | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)y_f32 | (uintptr_t)residual) & 15) != 0)
+        return V2A_ERR_ARG;
     if ((double)N * H * W * (C1 > C2 ? C1 : C2) >= 4294967296.0) return V2A_ERR_ARG;      // the gather uses 32-bit element offsets
     ConvDescH p;
-    p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.w = (const uint16_t*)w_packed;
-    p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual; p.residual_f = residual_f32; p.idil = idil;
-    p.y = (uint16_t*)y; p.yf = y_f32; p.partial = (float*)workspace; p.zeros = (const uint16_t*)zeros;
+    p.x = x; p.x2 = x2; p.w = w_packed;
+    p.bias = bias; p.rowvec = rowvec; p.residual = residual; p.residual_f = residual_f32; p.idil = idil;
+    p.y = y; p.yf = y_f32; p.partial = (float*)workspace; p.zeros = zeros;
     p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.ups = ups ? 1 : 0;
     p.stats = nullptr;
@@ -413,26 +461,51 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
     p.fd_ow = make_fastdiv_h((uint32_t)OW);
     p.fd_oh = make_fastdiv_h((uint32_t)OH);
     int bn, tiles, s;
-    conv_plan_h(p.M, Cout, p.K, &bn, &tiles, &s);
+    conv_plan_h(p.M, Cout, p.K, ept, &bn, &tiles, &s);
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
-    p.ktiles_per_split = cdiv(p.K / 64, s);
-    // fused GroupNorm statistics need the single-pass epilogue, bf16 output and whole 8-channel vectors
+    p.ktiles_per_split = cdiv(p.K / ept, s);
+    // fused GroupNorm statistics need the single-pass epilogue, an output in the storage type and whole 8-channel vectors
     if (stats) {
         if (s > 1 || !y || Cout % 8) return V2A_ERR_ARG;
         p.stats = stats;
     }
-    if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64>), dim3(tiles, s), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+    if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T>), dim3(tiles, s), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_h<128, 128, T>), dim3(tiles, s), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     if (s > 1) {
         const size_t total = (size_t)p.M * Cout;
         int g = (int)((total + 255) / 256);
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(conv_splitk_reduce_h, dim3(g), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(conv_splitk_reduce_h<T>, dim3(g), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
     }
     return V2A_OK;
+}
+
+extern "C" {
+
+// bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
+// exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned pointers; zeros: >= 128 zero bytes.
+int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
+                     const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
+                     int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
+                     float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!y == !y_f32) return V2A_ERR_ARG;
+    return conv_dma_launch<uint16_t>(x, x2, w_packed, bias, rowvec, residual, residual_f32, y, y_f32, zeros, N, H, W, C1, C2, Cout, KH, KW,
+                                     sh, sw, ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
+}
+
+// The same LDS-DMA kernel over fp32 tensors with the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the parity configuration's
+// convolution for layers whose channel counts are multiples of 32 (k tile = 32 floats = one 128-B line).  x / x2 / residual / y /
+// w_packed ([Cout][KH][KW][C1+C2]) fp32.
+int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
+                           const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
+                           int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, float* stats,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!y) return V2A_ERR_ARG;
+    return conv_dma_launch<float>(x, x2, w_packed, bias, rowvec, residual, nullptr, y, nullptr, zeros, N, H, W, C1, C2, Cout, KH, KW, sh, sw,
+                                  ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
 }
 
 // torch-layout fp32 weight [Cout][Cin][taps] -> bf16 [Cout][taps][Cin]

@@ -77,6 +77,8 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
 
 
 _H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '4096'))]
+# fp32 convs whose im2col matrix (rows x K) has at least this many elements run on the LDS-DMA kernel (tools/conv_dma_f32_bench.py)
+_DMA_F32_MIN_ROWS = [int(__import__('os').environ.get('V2A_DMA_F32_MIN_WORK', '4000000'))]
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
 
@@ -97,6 +99,30 @@ def _twin_of(w_packed):
     return ent[1]
 
 
+def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y):
+    """fp32 conv on the LDS-DMA kernel (exact-f32 MFMA): same results as the register-staged kernel up to summation order."""
+    N, H, W, C1 = x.shape
+    C2 = x2.shape[-1] if x2 is not None else 0
+    sh, sw = stride
+    ph, pw = pad
+    if out_hw is None:
+        HL = 2 * H if ups else ((H - 1) * idil + 1 if idil > 1 else H)
+        WL = 2 * W if ups else ((W - 1) * idil + 1 if idil > 1 else W)
+        OH = (HL + 2 * ph - KH) // sh + 1
+        OW = (WL + 2 * pw - KW) // sw + 1
+    else:
+        OH, OW = out_hw
+    M, K = N * OH * OW, KH * KW * (C1 + C2)
+    if y is None:
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    wsb = lib.v2a_conv2d_dma_f32_workspace_bytes(M, Cout, K)
+    ws = workspace(wsb, x.device) if wsb else None
+    check(lib.v2a_conv2d_fwd_dma_f32(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
+                                     _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil,
+                                     OH, OW, rows_per_batch, None, _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32")
+    return y
+
+
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
            residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]."""
@@ -106,6 +132,9 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     if x2 is not None:
         _chk(x2, "x2")
         C2 = x2.shape[-1]
+    if (bmode == 0 and y2 is None and not csplit and C1 % 32 == 0 and C2 % 32 == 0 and idil in (1, 2) and not (ups and idil > 1)
+            and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_ROWS[0] and lib.v2a_get_precision() == 0):
+        return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y)
     if (_h_twin and bmode == 0 and y2 is None and not csplit and C1 % 64 == 0 and C2 % 64 == 0 and idil in (1, 2)
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)

@@ -96,7 +96,7 @@ class _Conv:
         """(operand, bmode) for the data-gradient / transposed-conv launch of this weight."""
         self._fresh()
         from ._lib import lib
-        if self.nmaj and lib.v2a_get_precision() == 0:
+        if self.nmaj and lib.v2a_get_precision() == 0 and not self.eng.flip_dgrad:
             return self._pf, 1
         if self._pd is None:                      # bf16 mode: the K-contiguous flipped pack keeps data gradients on the bf16 kernel
             self._pd = torch.empty(self.w.numel(), dtype=torch.float32, device=self.w.device)
@@ -128,6 +128,9 @@ class PolicyEngine:
         # The data-parallel trainer turns this off: there the `model.*` arena slice must be final after phase 1 so that its
         # all-reduce can travel under the encoder backward.
         self.defer_unet_wgrad = _os.environ.get("V2A_DEFER_UNET_WGRAD", "1") != "0"
+        # data gradients as ordinary convs over a flipped, K-contiguous pack (written by the transposing multi-pack launch) instead
+        # of the N-major loader over the forward pack: the K-contiguous form is what the LDS-DMA kernels take
+        self.flip_dgrad = _os.environ.get("V2A_FLIP_DGRAD", "1") != "0"
         self._deferred = []
         self._collect_wg = False
         self._wg_stream = None
@@ -243,7 +246,7 @@ class PolicyEngine:
                 if taps > 1 or bf16:                   # forward operand (1x1 weights are their own fp32 operand: twin only)
                     rows.append([w.data_ptr(), c._pf.data_ptr() if taps > 1 else 0, c.co, c.ci, taps, 0, c._pf_h.data_ptr() if bf16 else 0])
                     ch0 += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
-                if not c.nmaj or bf16:
+                if not c.nmaj or bf16 or self.flip_dgrad:
                     if c._pd is None:
                         c._pd = torch.empty(w.numel(), dtype=torch.float32, device=self.device)
                     rows.append([w.data_ptr(), c._pd.data_ptr(), c.co, c.ci, taps, 1, c._pd_h.data_ptr() if bf16 else 0])
