@@ -78,13 +78,7 @@ def instrumented_pass(torch, trainer, steps):
         y = out if k.get("y") is None else k["y"]
         m = y.shape[0] * y.shape[1] * y.shape[2]
         K = kh * kw * (x.shape[-1] + c2)
-        bm = 128 if m >= 4096 else 64
-        bn = (128 if bm == 128 else 64) if cout > 64 else 64
-        if bm == 128 and -(-m // 128) * -(-cout // bn) < 600:      # mirrors conv_plan() in csrc/igemm.hip
-            bm = bn = 64
-        import v2a_hip as _v
-        kn = "conv_igemm_bf16" if _v.get_precision() == "bf16" else "conv_igemm_f32"
-        return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K, (m, cout, K, kh, kw, int(k.get("bmode", 0) or 0)))
+        return (ops.last_kernel[0], 2.0 * m * cout * K, (m, cout, K, kh, kw, int(k.get("bmode", 0) or 0)))     # name: the launcher's plan
 
     def f_wg(a, k, out):
         x, dy, kh, kw = a[0], a[1], a[3], a[4]
@@ -92,18 +86,7 @@ def instrumented_pass(torch, trainer, steps):
         m = dy.shape[0] * dy.shape[1] * dy.shape[2]
         cout = dy.shape[-1]
         K = kh * kw * (x.shape[-1] + c2)
-        bm = 128 if cout > 64 else 64
-        bn = 128 if (K > 64 and bm == 128) else 64
-        tiles = -(-cout // bm) * -(-K // bn)
-        if m < 4096:                      # mirrors wgrad_plan() in csrc/igemm.hip
-            if tiles < 192 and bm == 128 and bn == 128:
-                bn = 64
-                tiles = -(-cout // bm) * -(-K // bn)
-            if tiles < 192 and bm == 128:
-                bm = bn = 64
-        import v2a_hip as _v
-        kn = "conv_wgrad_bf16" if _v.get_precision() == "bf16" else "conv_wgrad_f32"
-        return (f"{kn}<{bm},{bn}>", 2.0 * m * cout * K, (m, cout, K, kh, kw, -1))
+        return (ops.last_kernel[0], 2.0 * m * cout * K, (m, cout, K, kh, kw, -1))
 
     orig_axpy = ops.axpy
     ops.conv2d = timed("fwd", orig_fwd, f_fwd)
@@ -256,7 +239,7 @@ def cpu_baseline(batch, budget=20.0, hard_timeout=150.0):
                       f"clip/AdamW/EMA; first step untimed), {last['t']:.1f} s on {threads} threads (usable host cores: {usable})"}
 
 
-def video_leg(torch, device, batch=16, sampling_steps=50):
+def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video"):
     """BASELINE.json configs[2]: AVDC sampler, Unet_Libero (201 M params, random init), 8-frame 128x128 (1 cond + 7 predicted),
     B=16, 50 sampling steps (sampling_timesteps=50 < 100 => the reference's DDIM path, goal_diffusion.py:405,647), CLIP-free
     synthetic task tokens [B,10,512].  frames/s = B * 7 / wall time of one sample() with inputs resident in HBM."""
@@ -285,37 +268,22 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
     recs = []
     orig = ops.conv2d
 
-    def timed(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = orig(*a, **k)
-        e1.record()
-        x, cout, kh, kw = a[0], a[3], a[4], a[5]
-        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
-        m = y.shape[0] * y.shape[1] * y.shape[2]
-        bm = 128 if m >= 4096 else 64
-        bn = (128 if bm == 128 else 64) if cout > 64 else 64
-        if bm == 128 and -(-m // 128) * -(-cout // bn) < 600:
-            bm = bn = 64
-        import v2a_hip as _v
-        kn = "conv_igemm_bf16" if _v.get_precision() == "bf16" else "conv_igemm_f32"
-        recs.append((f"{kn}<{bm},{bn}>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
-        return y
+    def wrap(orig_fn):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ret = orig_fn(*a, **k)
+            e1.record()
+            y = ret[0] if isinstance(ret, tuple) else ret
+            x, cout, kh, kw = a[0], a[3], a[4], a[5]
+            c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
+            m = y.shape[0] * y.shape[1] * y.shape[2]
+            recs.append((ops.last_kernel[0], 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
+            return ret
+        return timed
 
     orig_h = ops.conv2d_h
-
-    def timed_h(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ret = orig_h(*a, **k)
-        e1.record()
-        y = ret[0] if isinstance(ret, tuple) else ret
-        x, cout, kh, kw = a[0], a[3], a[4], a[5]
-        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
-        m = y.shape[0] * y.shape[1] * y.shape[2]
-        recs.append(("conv_igemm_h<128,128>", 2.0 * m * cout * kh * kw * (x.shape[-1] + c2), e0, e1))
-        return ret
-
+    timed, timed_h = wrap(orig), wrap(orig_h)
     ops.conv2d = timed
     ops.conv2d_h = timed_h
     try:
@@ -339,7 +307,7 @@ def video_leg(torch, device, batch=16, sampling_steps=50):
                                                        "guidance_weight": 0},
             "dtype": "f32", "algorithmic_tflops": flops / dt / 1e12, "output_range": [float(out.min()), float(out.max())],
             "roofline": {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic("video", name), "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(traffic_leg, name), "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
                          "share_of_conv_time": sec / sum(v[1] for v in agg.values()),
                          "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]}
                                                for k, v in sorted(agg.items())}}}
@@ -505,7 +473,7 @@ def main():
             if args.precision == "fp32" and not args.no_bf16_extra:
                 v2a_hip.set_video_storage("bf16")
                 torch.cuda.empty_cache()
-                vb = video_leg(torch, device, args.video_batch, args.video_steps)
+                vb = video_leg(torch, device, args.video_batch, args.video_steps, traffic_leg="video_bf16")
                 vb["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
                 vb["roofline"]["frac"] = vb["roofline"]["achieved"] / BF16_MFMA_PEAK_TFLOPS
                 vb["dtype"] = "bf16 activations / weights in HBM, bf16 MFMA, f32 accumulate / norm statistics / softmax"

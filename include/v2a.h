@@ -55,6 +55,9 @@ size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw, float* dbias, int N, int H, int W, int C1, int C2, int OH,
                      int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate,
                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+/* tile / split-K plan the two launchers above will use for a problem size (benchmark labelling) */
+int v2a_conv2d_plan(int M, int Cout, int K, int* bm, int* bn, int* split);
+int v2a_conv2d_wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* split);
 /* torch weight [Cout][Cin][KH][KW] -> mode 0: [Cout][KH][KW][Cin]; mode 1: [Cin][KH'][KW'][Cout] flipped (dgrad / transposed) */
 int v2a_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int mode, v2a_stream_t stream);
 /* every pack of a model in two launches: table_dev int64 [n][7] = {src, dst fp32 or 0, Cout, Cin, taps, mode, dst bf16 or 0};

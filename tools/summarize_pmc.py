@@ -10,7 +10,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 out = {}
-for leg in ("policy", "video"):
+for leg in ("policy", "video", "video_bf16"):
     res = defaultdict(lambda: {"n": 0})
     for ctr in ("fetch", "write"):
         files = glob.glob(os.path.join(root, f"pmc_{ctr}_{leg}", "**", "*counter_collection.csv"), recursive=True)
@@ -34,12 +34,14 @@ for leg in ("policy", "video"):
 # bench.py reads profiles/roofline_traffic.json: {"policy"|"video": {"<kernel><BM,BN>": corrected HBM bytes per launch}}
 import re
 rt = {}
-for leg_name in ("policy", "video"):
+for leg_name in ("policy", "video", "video_bf16"):
     traffic = {}
     for k, v in out[leg_name].items():
         m = re.match(r"(conv_(?:igemm|wgrad)_(?:f32|bf16))<(\d+), (\d+)", k)
-        if m:
-            key = f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+        mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)>", k)
+        if m or mh:
+            key = (f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else
+                   f"conv_igemm_h<{mh.group(1)},{mh.group(2)},{'float' if mh.group(3) == 'float' else 'bf16'}>")
             a = traffic.setdefault(key, [0.0, 0])     # template variants sharing a tile: launch-count weighted mean
             a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
             a[1] += v["n"]

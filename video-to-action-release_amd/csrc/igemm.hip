@@ -965,6 +965,18 @@ int v2a_debug_force_tile(int bm, int bn) {
     return V2A_OK;
 }
 
+// the tile / split plan the launchers will use (for benchmarks that label kernels: bench.py)
+int v2a_conv2d_plan(int M, int Cout, int K, int* bm, int* bn, int* split) {
+    int tiles;
+    conv_plan(M, Cout, K, bm, bn, &tiles, split);
+    return V2A_OK;
+}
+int v2a_conv2d_wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* split) {
+    int tiles;
+    wgrad_plan(M, Cout, K, bm, bn, &tiles, split);
+    return V2A_OK;
+}
+
 // workspace (bytes) a conv forward may need for split-K slabs (same plan as the launcher)
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K) {
     int bm, bn, tiles, s;

@@ -79,6 +79,16 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
 _H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '4096'))]
 # fp32 convs whose im2col matrix (rows x K) has at least this many elements run on the LDS-DMA kernel (tools/conv_dma_f32_bench.py)
 _DMA_F32_MIN_ROWS = [int(__import__('os').environ.get('V2A_DMA_F32_MIN_WORK', '4000000'))]
+last_kernel = [None]    # rocprof-style name of the contraction kernel the most recent conv2d / conv2d_wgrad / conv2d_h call launched
+
+
+def _plan_name(fn, prefix, M, Cout, K):
+    import ctypes
+    bm, bn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    fn(M, Cout, K, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(sp))
+    return f"{prefix}<{bm.value},{bn.value}>"
+
+
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
 
@@ -120,6 +130,7 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
     check(lib.v2a_conv2d_fwd_dma_f32(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
                                      _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil,
                                      OH, OW, rows_per_batch, None, _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32")
+    last_kernel[0] = f"conv_igemm_h<128,{64 if Cout <= 64 else 128},float>"
     return y
 
 
@@ -161,6 +172,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     check(lib.v2a_conv2d_fwd(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
                              _p(y2), csplit, N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, 1 if ups else 0,
                              rows_per_batch, bmode, _p(ws), wsb, _stream()), "conv2d_fwd")
+    last_kernel[0] = _plan_name(lib.v2a_conv2d_plan, "conv_igemm_bf16" if lib.v2a_get_precision() == 1 else "conv_igemm_f32", M, Cout, K)
     return y
 
 
@@ -179,6 +191,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
     check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
                                stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
                                _p(ws), wsb, _stream()), "conv2d_wgrad")
+    last_kernel[0] = _plan_name(lib.v2a_conv2d_wgrad_plan, "conv_wgrad_bf16" if lib.v2a_get_precision() == 1 else "conv_wgrad_f32", M, Cout, K)
     return dw
 
 
@@ -262,6 +275,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
                                None if out_f32 else y.data_ptr(), y.data_ptr() if out_f32 else None, _zero_line(x.device).data_ptr(),
                                N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil, OH, OW, rows_per_batch, _p(stats),
                                _p(ws), wsb, _stream()), "conv2d_fwd_h")
+    last_kernel[0] = f"conv_igemm_h<128,{64 if Cout <= 64 else 128},bf16>"
     if want_stats:
         return y, stats
     return y
