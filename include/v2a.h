@@ -57,6 +57,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 /* tile / split-K plan the two launchers above will use for a problem size (benchmark labelling) */
 int v2a_conv2d_plan(int M, int Cout, int K, int* bm, int* bn, int* split);
+int v2a_debug_wgrad_dma(int on);   /* tuning aid: fp32 weight gradients on the LDS-DMA kernel (default on); returns the old value */
 int v2a_conv2d_wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* split);
 /* torch weight [Cout][Cin][KH][KW] -> mode 0: [Cout][KH][KW][Cin]; mode 1: [Cin][KH'][KW'][Cout] flipped (dgrad / transposed) */
 int v2a_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int mode, v2a_stream_t stream);

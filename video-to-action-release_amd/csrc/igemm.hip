@@ -16,6 +16,7 @@
 // are k-major ([16][BM+4]) so that the MFMA operand read (lane -> row, k = lane>>5) is bank-conflict free;
 // global loads are float4 along the contiguous channel axis; register-staged double buffering.
 #include "common.h"
+#include <stdlib.h>
 
 #define BK 16
 #define LDS_PAD 4
@@ -659,6 +660,147 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradDesc p) {
     }
 }
 
+// Weight gradient with LDS-DMA staging (exact-f32 MFMA).  Both operands are k-major here -- tile rows are reduction rows r, the
+// 128 columns are contiguous in HBM (output channels of dY; the channels of one or two filter taps of the gathered input) -- so a
+// tile is 32 rows x 512 B, moved by `global_load_lds_dwordx4` (16 B per lane, no staging VGPRs), and the 32x32x2 MFMA operand
+// fetch (one float per lane: row kk + lk, column lr) is a conflict-free `ds_read_b32` on the plain lane-linear image.  The
+// column of every DMA piece (-> filter tap, input channel) is fixed per thread for the whole reduction; per k tile only the
+// reduction row is decoded (two reciprocal multiplies).  Rows past M, padding taps and columns past the edge read a zero line.
+// Needs Cout % 4 == 0, K % 4 == 0, Cin % 4 == 0 (whole 16-B pieces).  Epilogue / split layout identical to conv_wgrad_f32.
+__device__ __attribute__((aligned(128))) float g_zero_line[64];
+
+typedef const __attribute__((address_space(1))) void* gptr_w_t;
+typedef __attribute__((address_space(3))) void* lptr_w_t;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
+    constexpr int BKR = 32;                                     // reduction rows per tile
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int ACH = BM / 4, BCH = BN / 4;                   // 16-B pieces per tile row
+    constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;         // tile rows covered by one pass of the 256 threads
+    constexpr int AL = BKR / AROWS, BL = BKR / BROWS;           // DMA pieces per thread per tile
+    constexpr int ABYTES = BKR * BM * 4, BBYTES = BKR * BN * 4, BUF = ABYTES + BBYTES;
+    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nrt = (p.M + BKR - 1) / BKR;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    const float* zline = g_zero_line;
+
+    // A (dY^T): piece column fixed per thread
+    const int a_col = tid % ACH, a_row = tid / ACH;
+    const int a_co = m0 + a_col * 4;
+    const bool a_cok = a_co < p.Cout;
+    // B (gathered input): piece column -> (tap, channel) fixed per thread
+    const int b_col = tid % BCH, b_row = tid / BCH;
+    const int bk = n0 + b_col * 4;
+    const bool b_kok = bk < p.K;
+    const int btap = (b_kok ? bk : 0) / Cin;
+    const int bci = (b_kok ? bk : 0) - btap * Cin;
+    const int bkh = btap / p.KW, bkw = btap - bkh * p.KW;
+    const bool bfirst = bci < p.C1;
+    const float* bsrc = bfirst ? p.x : p.x2;
+    const uint32_t bCs = (uint32_t)(bfirst ? p.C1 : p.C2);
+    const uint32_t bcc = (uint32_t)(bfirst ? bci : bci - p.C1);
+
+    auto issue = [&](int rt, int buf) {
+        unsigned char* abase = smem + buf * BUF;
+        unsigned char* bbase = abase + ABYTES;
+        const int r0 = rt * BKR;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const int r = r0 + a_row + j * AROWS;
+            const float* g = (a_cok && r < p.M) ? p.dy + (size_t)r * p.Cout + a_co : zline;
+            __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(abase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const int r = r0 + b_row + j * BROWS;
+            const uint32_t rr = r < p.M ? (uint32_t)r : 0u;
+            const uint32_t t = fdiv(rr, p.fd_ow);
+            const int ow = (int)(rr - t * p.OW);
+            const uint32_t img = fdiv(t, p.fd_oh);
+            const int oh = (int)(t - img * p.OH);
+            int ih = oh * p.sh - p.ph + bkh, iw = ow * p.sw - p.pw + bkw;
+            bool ok = b_kok && r < p.M && (unsigned)ih < (unsigned)p.HL && (unsigned)iw < (unsigned)p.WL;
+            if (p.idil > 1) {
+                ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                ih /= p.idil;
+                iw /= p.idil;
+            }
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            const uint32_t off = ((uint32_t)((int)img * p.H + ih) * (uint32_t)p.W + (uint32_t)iw) * bCs + bcc;
+            const float* g = ok ? bsrc + off : zline;
+            __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(bbase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    float bsum = 0.f;                                           // thread tid < BM: column sum of dY over this block's rows
+
+    if (rt_begin < rt_end) issue(rt_begin, 0);
+    int buf = 0;
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rt + 1 < rt_end) issue(rt + 1, buf ^ 1);
+        const float* As = reinterpret_cast<const float*>(smem + buf * BUF);
+        const float* Bs = As + BKR * BM;
+#pragma unroll
+        for (int kk = 0; kk < BKR; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(kk + lk) * BM + wm + i * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lk) * BN + wn + j * 32 + lr];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_bias && tid < BM) {
+#pragma unroll 8
+            for (int r = 0; r < BKR; ++r) bsum += As[r * BM + tid];
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int k = n0 + wn + j * 32 + lr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co >= p.Cout) continue;
+                if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[i][j][r];
+                else wgrad_store(p, co, k, acc[i][j][r]);
+            }
+        }
+    if (do_bias && tid < BM) {
+        const int co = m0 + tid;
+        if (co < p.Cout) {
+            if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = bsum;
+            else p.dbias[co] = p.accumulate ? p.dbias[co] + bsum : bsum;
+        }
+    }
+}
+
 // bf16-MFMA weight gradient.  The MFMA wants 8 consecutive reduction rows per lane while HBM is contiguous along the OTHER axis
 // (channels), so each loader thread owns a 8(rows) x 4(channels) register block: 8 coalesced float4 loads, then four b128 LDS
 // stores of 8 bf16 along the reduction axis ([channel][32 rows + pad] tiles).  Threads [0,BM) stage dY^T, [BM,BM+BN) the im2col.
@@ -916,10 +1058,14 @@ __global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t
 
 // ------------------------------------------------------------------------------------------------ host side
 static int pick_split(int tiles, int ktiles, int min_ktiles) {
-    int s = 1;
-    // aim for >= 512 workgroups (2 per CU) while keeping every split >= min_ktiles deep
-    while (tiles * s < 512 && ktiles / (s * 2) >= min_ktiles && s < 64) s *= 2;
-    return s;
+    // fill the 512 workgroup slots (2 per CU) in ONE round: the largest split with tiles * s <= 512 that keeps every slice
+    // >= min_ktiles deep (a power-of-two split overshoots into a second, mostly empty round: 9 tiles x 64 = 576 workgroups)
+    if (tiles >= 512) return 1;
+    int smax = ktiles / min_ktiles;
+    if (smax > 64) smax = 64;
+    int s = 512 / tiles;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
 }
 
 // one tile/split plan shared by the workspace query and the launcher (they must agree)
@@ -946,6 +1092,7 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
     *s = (*tiles >= 192) ? 1 : pick_split(*tiles, cdiv(M, BK), 4);
 }
 
+static int g_wgrad_dma = -1;  // fp32 weight gradients with 128-row output tiles on the LDS-DMA kernel (V2A_WGRAD_DMA=0 / v2a_debug_wgrad_dma)
 static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
 
 extern "C" {
@@ -957,6 +1104,14 @@ int v2a_set_precision(int mode) {
     return old;
 }
 int v2a_get_precision(void) { return g_precision; }
+static int wgrad_dma_on() {
+    if (g_wgrad_dma < 0) {
+        const char* e = getenv("V2A_WGRAD_DMA");
+        g_wgrad_dma = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_wgrad_dma;
+}
+int v2a_debug_wgrad_dma(int on) { int old = wgrad_dma_on(); g_wgrad_dma = on ? 1 : 0; return old; }
 // tuning aid: force the forward tile (128x128, 128x64, 64x64) or 0,0 to restore the heuristic
 int v2a_debug_force_tile(int bm, int bn) {
     if (!((bm == 0 && bn == 0) || (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))) return V2A_ERR_ARG;
@@ -1097,6 +1252,22 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128>), grid, block, 0, stream, p);
         else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 64>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_wgrad_bf16<64, 64>), grid, block, 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        if (s > 1) {
+            size_t total = (size_t)Cout * p.K;
+            int g = (int)((total + 255) / 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            V2A_CHECK_LAUNCH();
+        }
+        return V2A_OK;
+    }
+    // long reductions over whole 16-B pieces: the LDS-DMA kernel (32-row tiles; the split plan is in tiles of BK = 16 rows)
+    if (wgrad_dma_on() && veca && vecb && bm == 128 && Cout % 4 == 0 && p.K % 4 == 0 && (C1 + C2) % 4 == 0 && C1 % 4 == 0 &&
+        (double)N * H * W * (C1 > C2 ? C1 : C2) < 4294967296.0) {
+        p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
+        if (bn == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 128>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 64>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
             size_t total = (size_t)Cout * p.K;

@@ -414,7 +414,12 @@ static void conv_plan_h(int M, int Cout, int K, int ept, int* bn, int* tiles, in
     *tiles = cdiv(M, 128) * cdiv(Cout, *bn);
     int sp = 1;
     const int nkt = K / ept;                       // k tiles of 128 B: 64 bf16 or 32 fp32
-    while (*tiles * sp < 448 && nkt / (sp * 2) >= 6 && sp < 16) sp *= 2;      // >= ~2 workgroups per CU, >= 6 k tiles per slice
+    if (*tiles < 448) {                            // one round over the 512 workgroup slots, >= 6 k tiles per slice, <= 16 slices
+        sp = 512 / *tiles;
+        const int smax = nkt / 6 < 16 ? nkt / 6 : 16;
+        if (sp > smax) sp = smax;
+        if (sp < 1) sp = 1;
+    }
     *s = sp;
 }
 
