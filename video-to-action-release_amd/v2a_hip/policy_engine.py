@@ -123,6 +123,7 @@ class PolicyEngine:
         self._wg_mode = _os.environ.get("V2A_ASYNC_WGRAD", "0")
         self.async_wgrad = self._wg_mode == "1"
         self._in_enc = False
+        self._cur_batch = 0
         # ConditionalUnet1D weight gradients feed nothing until the optimiser: with defer_unet_wgrad they are collected during the
         # data-gradient chain and launched as ONE extra branch next to the two encoder backward chains (one fork / one join).
         # The data-parallel trainer turns this off: there the `model.*` arena slice must be final after phase 1 so that its
@@ -543,7 +544,7 @@ class PolicyEngine:
     def _enc_parallel(self, fns):
         """Run the per-camera encoder chains (independent: separate weights, no shared state) as parallel branches: the first on
         the current stream, the others on side streams with their own scratch lanes; joined before returning."""
-        if not self.enc_streams or len(fns) < 2:
+        if not self.enc_streams or len(fns) < 2 or self._cur_batch < 8:      # B = 1 rollouts: fork / join costs more than it hides
             return [f() for f in fns]
         main = torch.cuda.current_stream()
         while len(self._enc_side) < len(fns) - 1:
@@ -560,6 +561,7 @@ class PolicyEngine:
         return out
 
     def global_cond(self, imgs: dict, save=None):
+        self._cur_batch = next(iter(imgs.values())).shape[0]
         feats = self._enc_parallel([(lambda k=k: self.encode_fwd(k, imgs[k], save)) for k in self.cfg.rgb_keys])
         B = feats[0].shape[0]
         fd = feats[0].shape[1]
