@@ -146,6 +146,7 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
 /* the same LDS-DMA kernel over fp32 tensors with the exact-f32 MFMA: parity-configuration conv for channel counts that are multiples of
  * 32 (replaces v2a_conv2d_fwd for those layers; w_packed = the fp32 forward pack [Cout][KH][KW][C1+C2]) */
 size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K);
+int v2a_conv2d_h_can_emit_stats(int M, int Cout, int K);   /* 1: v2a_conv2d_fwd_h takes a stats buffer for this problem size */
 int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                            const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
                            int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, float* stats,

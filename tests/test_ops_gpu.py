@@ -446,15 +446,15 @@ def test_conv_epilogue_statistics_feed_groupnorm():
     from v2a_hip import ops
     dev = "cuda:0"
     g = torch.Generator().manual_seed(2)
-    N, H, W = 3, 24, 24                       # 576 rows per sample = 9 blocks of 64; M = 1728 = 13.5 tiles of 128
+    N, H, W = 3, 96, 98                       # 9408 rows per sample = 147 blocks of 64; M = 28224 = 220.5 tiles of 128 (ragged)
     xa = torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).to(dev)       # K = 576: 9 k tiles, below the split-K threshold
     xb = torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).to(dev)
     wa = ops.pack_weight_h((torch.randn(192, 64, 3, 3, generator=g) * 0.05).to(dev))
     wb = ops.pack_weight_h((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev))        # 64-wide: the BN=64 tile variant
     ya, sa = ops.conv2d_h(xa, wa, None, 192, 3, 3, (1, 1), (1, 1), want_stats=True)
     yb, sb = ops.conv2d_h(xb, wb, None, 64, 3, 3, (1, 1), (1, 1), want_stats=True)
-    assert sa is not None and sb is not None and sa.shape == (27, 2, 192) and sb.shape == (27, 2, 64)
-    rows = ya.float().view(27, 64, 192)
+    assert sa is not None and sb is not None and sa.shape == (441, 2, 192) and sb.shape == (441, 2, 64)
+    rows = ya.float().view(441, 64, 192)
     assert torch.allclose(sa[:, 0], rows.sum(1), rtol=1e-4, atol=1e-3) and torch.allclose(sa[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=1e-3)
     C = 256
     gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)

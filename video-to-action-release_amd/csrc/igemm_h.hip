@@ -19,6 +19,7 @@
 //   * epilogue in registers: bias, per-(batch, channel) embedding vector, residual, then bf16 (or fp32) stores; split-K writes
 //     fp32 slabs and a second kernel finishes (only the small 8x8 / 16x16 levels need it).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -409,9 +410,20 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
-static void conv_plan_h(int M, int Cout, int K, int ept, int* bn, int* tiles, int* s) {
+static int g_small_tile_h = -1;   // 64x64 tiles for problems that 128-row tiles cannot spread over the chip (V2A_DMA_SMALL_TILE=0 disables)
+static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* tiles, int* s) {
+    if (g_small_tile_h < 0) {
+        const char* e = getenv("V2A_DMA_SMALL_TILE");
+        g_small_tile_h = (e && e[0] == '0') ? 0 : 1;
+    }
+    *bm = 128;
     *bn = Cout <= 64 ? 64 : 128;                   // 64-wide layers (ResNet layer1) would waste half of a 128-column tile
     *tiles = cdiv(M, 128) * cdiv(Cout, *bn);
+    if (g_small_tile_h && *tiles < 128) {          // few big tiles: quarter them (more workgroups, shallower split-K)
+        *bm = 64;
+        *bn = 64;
+        *tiles = cdiv(M, 64) * cdiv(Cout, 64);
+    }
     int sp = 1;
     const int nkt = K / ept;                       // k tiles of 128 B: 64 bf16 or 32 fp32
     if (*tiles < 448) {                            // one round over the 512 workgroup slots, >= 6 k tiles per slice, <= 16 slices
@@ -426,13 +438,19 @@ static void conv_plan_h(int M, int Cout, int K, int ept, int* bn, int* tiles, in
 extern "C" {
 
 size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
-    int bn, tiles, s;
-    conv_plan_h(M, Cout, K, 64, &bn, &tiles, &s);
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 64, &bm, &bn, &tiles, &s);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
+// 1 when v2a_conv2d_fwd_h accepts a `stats` buffer for this problem (single-pass epilogue on 128-row tiles)
+int v2a_conv2d_h_can_emit_stats(int M, int Cout, int K) {
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 64, &bm, &bn, &tiles, &s);
+    return (s == 1 && bm == 128 && Cout % 8 == 0) ? 1 : 0;
+}
 size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K) {
-    int bn, tiles, s;
-    conv_plan_h(M, Cout, K, 32, &bn, &tiles, &s);
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
@@ -465,17 +483,18 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.fd_ow = make_fastdiv_h((uint32_t)OW);
     p.fd_oh = make_fastdiv_h((uint32_t)OH);
-    int bn, tiles, s;
-    conv_plan_h(p.M, Cout, p.K, ept, &bn, &tiles, &s);
+    int bm, bn, tiles, s;
+    conv_plan_h(p.M, Cout, p.K, ept, &bm, &bn, &tiles, &s);
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(p.K / ept, s);
     // fused GroupNorm statistics need the single-pass epilogue, an output in the storage type and whole 8-channel vectors
     if (stats) {
-        if (s > 1 || !y || Cout % 8) return V2A_ERR_ARG;
+        if (s > 1 || !y || Cout % 8 || bm != 128) return V2A_ERR_ARG;
         p.stats = stats;
     }
-    if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T>), dim3(tiles, s), dim3(256), 0, stream, p);
+    if (bm == 64) hipLaunchKernelGGL((conv_igemm_h<64, 64, T>), dim3(tiles, s), dim3(256), 0, stream, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T>), dim3(tiles, s), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_igemm_h<128, 128, T>), dim3(tiles, s), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     if (s > 1) {

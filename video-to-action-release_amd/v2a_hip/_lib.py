@@ -71,6 +71,7 @@ SIGNATURES = {
     "v2a_groupnorm_fwd_h": (I, [P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
     "v2a_attention_fwd_h": (I, [P, P, I, I, I, I, P]),
     "v2a_conv2d_dma_f32_workspace_bytes": (SZ, [I, I, I]),
+    "v2a_conv2d_h_can_emit_stats": (I, [I, I, I]),
     "v2a_conv2d_fwd_dma_f32": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),
     "v2a_cast_f32_bf16": (I, [P, P, SZ, P]),

@@ -78,7 +78,7 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
 
 _H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '4096'))]
 # fp32 convs whose im2col matrix (rows x K) has at least this many elements run on the LDS-DMA kernel (tools/conv_dma_f32_bench.py)
-_DMA_F32_MIN_ROWS = [int(__import__('os').environ.get('V2A_DMA_F32_MIN_WORK', '4000000'))]
+_DMA_F32_MIN_ROWS = [int(__import__('os').environ.get('V2A_DMA_F32_MIN_WORK', '300000'))]
 last_kernel = [None]    # rocprof-style name of the contraction kernel the most recent conv2d / conv2d_wgrad / conv2d_h call launched
 
 
@@ -89,6 +89,14 @@ def _plan_name(fn, prefix, M, Cout, K):
     return f"{prefix}<{bm.value},{bn.value}>"
 
 
+def _plan_name_h(M, Cout, K, ept, tname):
+    tiles128 = -(-M // 128) * -(-Cout // (64 if Cout <= 64 else 128))
+    if tiles128 < 128 and _SMALL_TILE_H:          # mirrors conv_plan_h (csrc/igemm_h.hip)
+        return f"conv_igemm_h<64,64,{tname}>"
+    return f"conv_igemm_h<128,{64 if Cout <= 64 else 128},{tname}>"
+
+
+_SMALL_TILE_H = __import__('os').environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
 
@@ -130,7 +138,7 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
     check(lib.v2a_conv2d_fwd_dma_f32(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
                                      _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil,
                                      OH, OW, rows_per_batch, None, _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32")
-    last_kernel[0] = f"conv_igemm_h<128,{64 if Cout <= 64 else 128},float>"
+    last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
     return y
 
 
@@ -269,13 +277,13 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
     wsb = lib.v2a_conv2d_h_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
     stats = None
-    if want_stats and _FUSED_STATS and wsb == 0 and not out_f32 and Cout % 8 == 0:      # single-pass epilogue: GroupNorm statistics ride along
+    if want_stats and _FUSED_STATS and not out_f32 and lib.v2a_conv2d_h_can_emit_stats(M, Cout, K):      # GroupNorm statistics ride along
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device)
     check(lib.v2a_conv2d_fwd_h(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(res_h), _p(res_f),
                                None if out_f32 else y.data_ptr(), y.data_ptr() if out_f32 else None, _zero_line(x.device).data_ptr(),
                                N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil, OH, OW, rows_per_batch, _p(stats),
                                _p(ws), wsb, _stream()), "conv2d_fwd_h")
-    last_kernel[0] = f"conv_igemm_h<128,{64 if Cout <= 64 else 128},bf16>"
+    last_kernel[0] = _plan_name_h(M, Cout, K, 64, "bf16")
     if want_stats:
         return y, stats
     return y
