@@ -1263,11 +1263,12 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         return V2A_OK;
     }
     // long reductions over whole 16-B pieces: the LDS-DMA kernel (32-row tiles; the split plan is in tiles of BK = 16 rows)
-    if (wgrad_dma_on() && veca && vecb && bm == 128 && Cout % 4 == 0 && p.K % 4 == 0 && (C1 + C2) % 4 == 0 && C1 % 4 == 0 &&
+    if (wgrad_dma_on() && veca && vecb && Cout % 4 == 0 && p.K % 4 == 0 && (C1 + C2) % 4 == 0 && C1 % 4 == 0 &&
         (double)N * H * W * (C1 > C2 ? C1 : C2) < 4294967296.0) {
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
-        if (bn == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 128>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 64>), grid, block, 0, stream, p);
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 128>), grid, block, 0, stream, p);
+        else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 64>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
             size_t total = (size_t)Cout * p.K;
