@@ -124,6 +124,7 @@ class PolicyEngine:
         self.async_wgrad = self._wg_mode == "1"
         self._in_enc = False
         self._cur_batch = 0
+        self._stem_pad = {}
         # ConditionalUnet1D weight gradients feed nothing until the optimiser: with defer_unet_wgrad they are collected during the
         # data-gradient chain and launched as ONE extra branch next to the two encoder backward chains (one fork / one join).
         # The data-parallel trainer turns this off: there the `model.*` arena slice must be final after phase 1 so that its
@@ -352,7 +353,23 @@ class PolicyEngine:
                 dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn)
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
-        self._wg(st["x0"], dc1, e["conv1"].shape, 7, 7, (2, 2), (3, 3), dw=grads[e["conv1"].wname])
+        # RGB stem: 3 input channels make every 16-B piece of the gathered operand straddle pixels (scalar-gather kernel, 0.4 ms
+        # per encoder).  Pad the saved input to 4 channels once (zeros in the 4th), take the gradient of the 4-channel filter on
+        # the vector / LDS-DMA kernel and keep its first three input channels.
+        x0 = st["x0"]
+        c1 = e["conv1"]
+        if x0.shape[-1] == 3:
+            N0, H0, W0, _ = x0.shape
+            xp = self._stem_pad.get(key)
+            if xp is None or xp.shape[:3] != x0.shape[:3]:
+                xp = torch.zeros((N0, H0, W0, 4), dtype=torch.float32, device=x0.device)
+                self._stem_pad[key] = xp
+            ops.copy2d(x0, xp, N0 * H0 * W0, 3, 3, 4)
+            dw4 = torch.empty((c1.co, 4, 7, 7), dtype=torch.float32, device=x0.device)
+            self._wg(xp, dc1, (c1.co, 4, 7, 7), 7, 7, (2, 2), (3, 3), dw=dw4)
+            ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
+        else:
+            self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
 
     # ------------------------------------------------------------------ ConditionalUnet1D
     def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None):
