@@ -37,7 +37,7 @@ rt = {}
 for leg_name in ("policy", "video", "video_bf16"):
     traffic = {}
     for k, v in out[leg_name].items():
-        m = re.match(r"(conv_(?:igemm|wgrad)_(?:f32|bf16))<(\d+), (\d+)", k)
+        m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
         mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)>", k)
         if m or mh:
             key = (f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else

@@ -97,6 +97,7 @@ def _plan_name_h(M, Cout, K, ept, tname):
 
 
 _SMALL_TILE_H = __import__('os').environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
+_WGRAD_DMA = __import__('os').environ.get('V2A_WGRAD_DMA', '1') != '0'
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
 
@@ -199,7 +200,12 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
     check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
                                stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
                                _p(ws), wsb, _stream()), "conv2d_wgrad")
-    last_kernel[0] = _plan_name(lib.v2a_conv2d_wgrad_plan, "conv_wgrad_bf16" if lib.v2a_get_precision() == 1 else "conv_wgrad_f32", M, Cout, K)
+    if lib.v2a_get_precision() == 1:
+        kn = "conv_wgrad_bf16"
+    else:       # mirrors the dispatch in v2a_conv2d_wgrad: whole 16-B pieces -> the LDS-DMA kernel
+        dma = _WGRAD_DMA and Cout % 4 == 0 and K % 4 == 0 and C1 % 4 == 0 and (C1 + C2) % 4 == 0
+        kn = "conv_wgrad_dma_f32" if dma else "conv_wgrad_f32"
+    last_kernel[0] = _plan_name(lib.v2a_conv2d_wgrad_plan, kn, M, Cout, K)
     return dw
 
 
