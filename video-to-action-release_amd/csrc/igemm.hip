@@ -1246,7 +1246,10 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     p.splits = s;
     p.rtiles_per_split = cdiv(nrt, s);
     dim3 grid(tiles, s), block(256);
-    if (g_precision == 1 && veca && vecb) {
+    // bf16 mode: the 64x64 problems run faster on the exact-f32 LDS-DMA kernel below than on the register-staged bf16 one
+    const bool dma_ok = wgrad_dma_on() && veca && vecb && Cout % 4 == 0 && p.K % 4 == 0 && (C1 + C2) % 4 == 0 && C1 % 4 == 0 &&
+                        (double)N * H * W * (C1 > C2 ? C1 : C2) < 4294967296.0;
+    if (g_precision == 1 && veca && vecb && !(bm == 64 && dma_ok)) {
         p.splits = s;
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128>), grid, block, 0, stream, p);
@@ -1263,8 +1266,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         return V2A_OK;
     }
     // long reductions over whole 16-B pieces: the LDS-DMA kernel (32-row tiles; the split plan is in tiles of BK = 16 rows)
-    if (wgrad_dma_on() && veca && vecb && Cout % 4 == 0 && p.K % 4 == 0 && (C1 + C2) % 4 == 0 && C1 % 4 == 0 &&
-        (double)N * H * W * (C1 > C2 ? C1 : C2) < 4294967296.0) {
+    if (dma_ok) {
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 128>), grid, block, 0, stream, p);
         else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 64>), grid, block, 0, stream, p);
