@@ -1,0 +1,53 @@
+"""Per-shape conv time of one bf16-storage (or fp32) Unet_Libero forward at B=16 (GPU box)."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+sys.path.insert(0, ROOT)
+import torch
+import v2a_hip
+from v2a_hip import ops
+from flowdiffusion.flowdiffusion.unet import Unet_Libero
+
+storage = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+v2a_hip.set_video_storage(storage)
+dev = "cuda:0"
+torch.manual_seed(0)
+m = Unet_Libero().to(dev).eval()
+B = 16
+x = torch.randn(B, 24, 128, 128, device=dev)
+t = torch.full((B,), 50, device=dev)
+te = torch.randn(B, 10, 512, device=dev)
+m(x, t, task_embed=te)
+recs = []
+
+
+def wrap(fn):
+    def f(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        y = r[0] if isinstance(r, tuple) else r
+        xx, cout, kh, kw = a[0], a[3], a[4], a[5]
+        c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
+        M = y.shape[0] * y.shape[1] * y.shape[2]
+        recs.append(((M, xx.shape[-1] + c2, cout, kh, kw, ops.last_kernel[0]), 2.0 * M * cout * kh * kw * (xx.shape[-1] + c2), e0, e1))
+        return r
+    return f
+
+
+o1, o2 = ops.conv2d, ops.conv2d_h
+ops.conv2d, ops.conv2d_h = wrap(o1), wrap(o2)
+m(x, t, task_embed=te)
+torch.cuda.synchronize()
+ops.conv2d, ops.conv2d_h = o1, o2
+agg = {}
+for key, fl, e0, e1 in recs:
+    a = agg.setdefault(key, [0.0, 0.0, 0])
+    a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+tot = sum(a[1] for a in agg.values())
+print(f"total conv time {tot*1e3:.1f} ms over {sum(a[2] for a in agg.values())} launches, {sum(a[0] for a in agg.values())/tot/1e12:.0f} TFLOP/s")
+for key, (fl, tt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    M, Cin, Cout, kh, kw, name = key
+    print(f"M={M:8d} Cin={Cin:5d} Cout={Cout:5d} k={kh}x{kw} {name:30s} n={n:3d} avg {tt/n*1e6:8.1f} us  {fl/tt/1e12:6.0f} TF  {tt*1e3:6.2f} ms ({100*tt/tot:4.1f} %)")
