@@ -80,8 +80,12 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, typename T>
-__global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
+// STAGES = 2: two LDS buffers per workgroup (64 KB at 128x128 -> 2 workgroups / CU), the DMA of tile t+1 flies under the MFMAs of
+// tile t.  STAGES = 1: one buffer (32 KB, <= 128 VGPRs -> 4 workgroups / CU): nothing overlaps inside a workgroup, but twice as
+// many tiles are in flight per CU -- these kernels wait ~1.4 us for a k tile against ~0.2 us of MFMA work on it, so bytes in
+// flight per CU (not per workgroup) is what buys throughput.
+template <int BM, int BN, typename T, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const ConvDescH p) {
     constexpr int ROWB = 128;                       // bytes per tile row (64 bf16 / 32 fp32)
     constexpr int EPT = ROWB / (int)sizeof(T);      // elements per k tile
     constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-B chunk
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
     constexpr int AL = BM / 32, BL = BN / 32;       // DMA pieces per thread per tile (32 rows x 8 chunks per 256-thread pass)
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int BUF = (BM + BN) * ROWB;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * BUF];      // ONE LDS object (A0 B0 A1 B1)
+    __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * BUF];      // ONE LDS object (A0 B0 [A1 B1])
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.Cout + BN - 1) / BN;
@@ -184,45 +188,57 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) b_off[j] = BM * ROWB + (wn + j * 32 + lr) * ROWB;
 
-    if (kt_begin < kt_end) issue(0);
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                            // tile kt landed everywhere; everyone is done reading the other buffer
-        if (kt + 1 < kt_end) issue(buf ^ 1);
-        const unsigned char* base = smem + buf * BUF;
+    auto compute = [&](const unsigned char* base) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int pos = (((h << 1) | lk) ^ rswz) << 4;
-            if constexpr (HALF) {
-                bf16x8 a[TM], b[TN];
+    for (int h = 0; h < 4; ++h) {
+        const int pos = (((h << 1) | lk) ^ rswz) << 4;
+        if constexpr (HALF) {
+            bf16x8 a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + pos);
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + pos);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + b_off[j] + pos);
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + b_off[j] + pos);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+            // one b128 fetch per operand row feeds FOUR exact-f32 MFMA k-steps: lanes with lk = 0 supply k = 8h + e, the others
+            // k = 8h + 4 + e, for A and B alike (the order of an exact fp32 sum is free)
+            f32x4_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(base + a_off[i] + pos);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(base + b_off[j] + pos);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            } else {
-                // one b128 fetch per operand row feeds FOUR exact-f32 MFMA k-steps: lanes with lk = 0 supply k = 8h + e, the others
-                // k = 8h + 4 + e, for A and B alike (the order of an exact fp32 sum is free)
-                f32x4_t a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(base + a_off[i] + pos);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(base + b_off[j] + pos);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-        buf ^= 1;
+    }
+    };
+    if constexpr (STAGES == 2) {
+        if (kt_begin < kt_end) issue(0);
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                        // tile kt landed everywhere; everyone is done reading the other buffer
+            if (kt + 1 < kt_end) issue(buf ^ 1);
+            compute(smem + buf * BUF);
+            buf ^= 1;
+        }
+    } else {
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                        // tile kt landed everywhere
+            compute(smem);
+            __syncthreads();                        // everyone is done reading before the next tile overwrites the buffer
+        }
     }
 
     // ---- epilogue.  C layout of the 32x32 MFMA: lane -> column lr, rows (r & 3) + 8 * (r >> 2) + 4 * lk.  Each wave parks its
@@ -231,19 +247,8 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
     // 128-B line per row and wave) instead of 2-byte scatters.
     __syncthreads();
     constexpr int LDC = WN;                                       // floats per parked row; columns XOR-ed with 4 * (row & 1) so that
-    static_assert(4 * WM * LDC * 4 <= 2 * BUF, "epilogue staging exceeds the operand buffers");   // the b128 read-back is conflict-free
-    float* cw = reinterpret_cast<float*>(smem) + wid * WM * LDC;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                cw[row * LDC + ((j * 32 + lr) ^ ((row & 1) << 2))] = acc[i][j][r];
-            }
-    // wave-private region: no workgroup barrier needed, only the LDS writes of this wave must have landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_assert(4 * 32 * LDC * 4 <= STAGES * BUF, "epilogue staging exceeds the operand buffers");   // the b128 read-back is conflict-free
+    float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;  // one 32-row sub-tile of this wave at a time (wave-private region)
     constexpr int V = WN / 8;                                     // 8-channel vectors per row
     const int vrow = lane / V, vcol = (lane % V) * 8;
     const int n = n0 + wn + vcol;
@@ -256,87 +261,100 @@ __global__ __launch_bounds__(256) void conv_igemm_h(const ConvDescH p) {
         ssq[e] = 0.f;
     }
 #pragma unroll
-    for (int rr = 0; rr < WM; rr += 64 / V) {
-        const int ml = rr + vrow;
-        const int m = m0 + wm + ml;
-        if (m >= p.M || n >= p.Cout) continue;
-        const int sx = (ml & 1) << 2;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
-        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const size_t o = (size_t)m * p.Cout + n;
-        if (p.splitk > 1) {
-            float* dst = p.partial + (size_t)split * p.M * p.Cout + o;
-            if (vec_ok) {
-                *reinterpret_cast<f32x4*>(dst) = c0;
-                *reinterpret_cast<f32x4*>(dst + 4) = c1;
-            } else {
-                for (int e = 0; e < 8 && n + e < p.Cout; ++e) dst[e] = v[e];
-            }
-            continue;
-        }
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        if (vec_ok) {
-            if (p.rowvec) {
-                const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.Cout + n;
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                cw[row * LDC + ((j * 32 + lr) ^ ((row & 1) << 2))] = acc[i][j][r];
             }
-            if (p.residual_f) {
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.residual_f + o), r1 = *reinterpret_cast<const f32x4*>(p.residual_f + o + 4);
+        // LDS operations of one wave complete in order: only this wave's writes must have landed before its reads (and its reads
+        // of sub-tile i are issued before the writes of sub-tile i + 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
-            }
-            if (p.residual) {
-                if constexpr (HALF) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
-                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                    v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                    v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+        for (int rr = 0; rr < 32; rr += 64 / V) {
+            const int ml = rr + vrow;                                  // row inside the parked 32-row sub-tile
+            const int m = m0 + wm + i * 32 + ml;
+            if (m >= p.M || n >= p.Cout) continue;
+            const int sx = (ml & 1) << 2;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
+            float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            const size_t o = (size_t)m * p.Cout + n;
+            if (p.splitk > 1) {
+                float* dst = p.partial + (size_t)split * p.M * p.Cout + o;
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(dst) = c0;
+                    *reinterpret_cast<f32x4*>(dst + 4) = c1;
                 } else {
-                    const float* rp = reinterpret_cast<const float*>(p.residual) + o;
-                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+                    for (int e = 0; e < 8 && n + e < p.Cout; ++e) dst[e] = v[e];
+                }
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            if (vec_ok) {
+                if (p.rowvec) {
+                    const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.Cout + n;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
                 }
-            }
-            if (!HALF || p.yf) {
-                float* yo = HALF ? p.yf : reinterpret_cast<float*>(p.y);
-                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                *reinterpret_cast<f32x4*>(yo + o) = o0;
-                *reinterpret_cast<f32x4*>(yo + o + 4) = o1;
-                if (!HALF) {
+                if (p.residual_f) {
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.residual_f + o), r1 = *reinterpret_cast<const f32x4*>(p.residual_f + o + 4);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
                 }
-            } else {
-                uint16_t h[8];
+                if (p.residual) {
+                    if constexpr (HALF) {
+                        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
+                        v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                        v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                        v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                        v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                    } else {
+                        const float* rp = reinterpret_cast<const float*>(p.residual) + o;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    h[e] = f2bf(v[e]);
-                    const float r = bf2f(h[e]);                   // statistics of what the consumer will read
-                    ssum[e] += r;
-                    ssq[e] += r * r;
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                    }
                 }
-                uint4 u;
-                u.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-                u.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-                u.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16);
-                u.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
-                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + o) = u;
-            }
-        } else {                                                  // ragged channel count (e.g. the 3-channel output head)
-            for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
-                float t = v[e];
-                if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
-                if (p.residual) t += HALF ? bf2f(reinterpret_cast<const uint16_t*>(p.residual)[o + e]) : reinterpret_cast<const float*>(p.residual)[o + e];
-                if (p.residual_f) t += p.residual_f[o + e];
-                if (!HALF) reinterpret_cast<float*>(p.y)[o + e] = t;
-                else if (p.yf) p.yf[o + e] = t;
-                else reinterpret_cast<uint16_t*>(p.y)[o + e] = f2bf(t);
+                if (!HALF || p.yf) {
+                    float* yo = HALF ? p.yf : reinterpret_cast<float*>(p.y);
+                    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(yo + o) = o0;
+                    *reinterpret_cast<f32x4*>(yo + o + 4) = o1;
+                    if (!HALF) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+                    }
+                } else {
+                    uint16_t h[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        h[e] = f2bf(v[e]);
+                        const float r = bf2f(h[e]);                   // statistics of what the consumer will read
+                        ssum[e] += r;
+                        ssq[e] += r * r;
+                    }
+                    uint4 u;
+                    u.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                    u.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                    u.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16);
+                    u.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + o) = u;
+                }
+            } else {                                                  // ragged channel count (e.g. the 3-channel output head)
+                for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
+                    float t = v[e];
+                    if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
+                    if (p.residual) t += HALF ? bf2f(reinterpret_cast<const uint16_t*>(p.residual)[o + e]) : reinterpret_cast<const float*>(p.residual)[o + e];
+                    if (p.residual_f) t += p.residual_f[o + e];
+                    if (!HALF) reinterpret_cast<float*>(p.y)[o + e] = t;
+                    else if (p.yf) p.yf[o + e] = t;
+                    else reinterpret_cast<uint16_t*>(p.y)[o + e] = f2bf(t);
+                }
             }
         }
     }
@@ -410,6 +428,7 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
+static int g_stages_h = -1;       // 128x128 kernel on launches of >= 768 workgroups: 1 LDS buffer, 4 workgroups per CU (V2A_DMA_STAGES=2: always two buffers)
 static int g_small_tile_h = -1;   // 64x64 tiles for problems that 128-row tiles cannot spread over the chip (V2A_DMA_SMALL_TILE=0 disables)
 static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* tiles, int* s) {
     if (g_small_tile_h < 0) {
@@ -493,9 +512,14 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         if (s > 1 || !y || Cout % 8 || bm != 128) return V2A_ERR_ARG;
         p.stats = stats;
     }
-    if (bm == 64) hipLaunchKernelGGL((conv_igemm_h<64, 64, T>), dim3(tiles, s), dim3(256), 0, stream, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T>), dim3(tiles, s), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_h<128, 128, T>), dim3(tiles, s), dim3(256), 0, stream, p);
+    if (g_stages_h < 0) {
+        const char* e = getenv("V2A_DMA_STAGES");
+        g_stages_h = (e && e[0] == '2') ? 2 : 1;
+    }
+    if (bm == 64) hipLaunchKernelGGL((conv_igemm_h<64, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
+    else if (g_stages_h == 1 && tiles * s >= 768) hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 1>), dim3(tiles, s), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     if (s > 1) {
         const size_t total = (size_t)p.M * Cout;
