@@ -38,7 +38,7 @@ for leg_name in ("policy", "video", "video_bf16"):
     traffic = {}
     for k, v in out[leg_name].items():
         m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
-        mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)>", k)
+        mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)(?:, \d+)?>", k)
         if m or mh:
             key = (f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else
                    f"conv_igemm_h<{mh.group(1)},{mh.group(2)},{'float' if mh.group(3) == 'float' else 'bf16'}>")
