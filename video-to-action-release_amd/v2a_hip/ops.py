@@ -76,7 +76,7 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
     return out
 
 
-_H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '4096'))]
+_H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '256'))]
 # fp32 convs whose im2col matrix (rows x K) has at least this many elements run on the LDS-DMA kernel (tools/conv_dma_f32_bench.py)
 _DMA_F32_MIN_ROWS = [int(__import__('os').environ.get('V2A_DMA_F32_MIN_WORK', '300000'))]
 last_kernel = [None]    # rocprof-style name of the contraction kernel the most recent conv2d / conv2d_wgrad / conv2d_h call launched
