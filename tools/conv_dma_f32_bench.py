@@ -18,7 +18,7 @@ for name, N, H, W, Ci, Co, k, s in FWD:
     b = torch.randn(Co, device=dev)
     res = {}
     for mode, rows in (("staged", 1 << 60), ("dma", 0)):
-        ops._DMA_F32_MIN_ROWS[0] = rows
+        ops._DMA_F32_MIN_WORK[0] = rows
         f = lambda: ops.conv2d(x, w, b, Co, kh, kw, (s, s), (kh // 2, kw // 2))
         y = f()
         res[mode] = (timeit(f), y)

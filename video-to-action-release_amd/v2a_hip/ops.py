@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only; every arithmetic op below is
 libv2a_hip.so launched on torch's current stream with raw pointers.
 All activations are channels-last fp32: images [N,H,W,C], sequences [N,T,C], video [B,F,H,W,C].
 """
+import os
 import weakref
 import torch
 from ._lib import lib, check
@@ -76,9 +77,9 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
     return out
 
 
-_H_ROUTE_MIN_ROWS = [int(__import__('os').environ.get('V2A_H_ROUTE_MIN_ROWS', '256'))]
+_H_ROUTE_MIN_ROWS = [int(os.environ.get('V2A_H_ROUTE_MIN_ROWS', '256'))]
 # fp32 convs whose im2col matrix (rows x K) has at least this many elements run on the LDS-DMA kernel (tools/conv_dma_f32_bench.py)
-_DMA_F32_MIN_ROWS = [int(__import__('os').environ.get('V2A_DMA_F32_MIN_WORK', '300000'))]
+_DMA_F32_MIN_WORK = [int(os.environ.get('V2A_DMA_F32_MIN_WORK', '300000'))]
 last_kernel = [None]    # rocprof-style name of the contraction kernel the most recent conv2d / conv2d_wgrad / conv2d_h call launched
 
 
@@ -96,8 +97,8 @@ def _plan_name_h(M, Cout, K, ept, tname):
     return f"conv_igemm_h<128,{64 if Cout <= 64 else 128},{tname}>"
 
 
-_SMALL_TILE_H = __import__('os').environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
-_WGRAD_DMA = __import__('os').environ.get('V2A_WGRAD_DMA', '1') != '0'
+_SMALL_TILE_H = os.environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
+_WGRAD_DMA = os.environ.get('V2A_WGRAD_DMA', '1') != '0'
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
 
@@ -153,7 +154,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
         _chk(x2, "x2")
         C2 = x2.shape[-1]
     if (bmode == 0 and y2 is None and not csplit and C1 % 32 == 0 and C2 % 32 == 0 and idil in (1, 2) and not (ups and idil > 1)
-            and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_ROWS[0] and lib.v2a_get_precision() == 0):
+            and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] and lib.v2a_get_precision() == 0):
         return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y)
     if (_h_twin and bmode == 0 and y2 is None and not csplit and C1 % 64 == 0 and C2 % 64 == 0 and idil in (1, 2)
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
@@ -211,7 +212,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
 
 # ---- bf16-storage family (csrc/igemm_h.hip): activations / packed weights are torch.bfloat16 tensors, accumulation fp32
 _zeros_h = {}
-_FUSED_STATS = __import__('os').environ.get('V2A_GN_FUSED_STATS', '1') != '0'
+_FUSED_STATS = os.environ.get('V2A_GN_FUSED_STATS', '1') != '0'
 
 
 def _zero_line(device):
