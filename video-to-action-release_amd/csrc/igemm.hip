@@ -1085,6 +1085,18 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
     *bm = Cout > 64 ? 128 : 64;
     *bn = (K > 64 && *bm == 128) ? 128 : 64;
     *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
+    // very few big tiles mean a very deep split (9 tiles -> 56 slices): the fp32 slabs (write + re-read) then cost as much as the
+    // contraction.  Quartering the tiles quarters the split depth at nearly the same MFMA efficiency (V2A_WGRAD_SMALL_TILES=0: off)
+    static int small_mode = -1;
+    if (small_mode < 0) {
+        const char* e = getenv("V2A_WGRAD_SMALL_TILES");
+        small_mode = e ? atoi(e) : 96;
+    }
+    if (small_mode > 0 && *tiles < small_mode && *bm == 128) {
+        *bm = 64;
+        *bn = 64;
+        *tiles = cdiv(Cout, 64) * cdiv(K, 64);
+    }
     if (M < 4096) {     // short reduction: get parallelism from smaller tiles; long reductions keep big tiles and split instead
         if (*tiles < 192 && *bm == 128 && *bn == 128) { *bn = 64; *tiles = cdiv(Cout, *bm) * cdiv(K, *bn); }
         if (*tiles < 192 && *bm == 128) { *bm = 64; *bn = 64; *tiles = cdiv(Cout, *bm) * cdiv(K, *bn); }
