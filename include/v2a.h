@@ -74,9 +74,9 @@ int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int 
  * conditional_unet1d.py:46-66).  film [N][2][C] = (scale, shift).  mean / rstd [N*G] are outputs (saved for backward). */
 size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G);
 int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
-                      const float* film, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
-                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);
-int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
+                      const float* film, int film_ld, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
+                      void* workspace, size_t workspace_bytes, v2a_stream_t stream);   /* film_ld: floats between samples' FiLM rows (0 = 2*C) */
+int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
                       const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm, float* colsum,
                       float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act, void* workspace,
                       size_t workspace_bytes, v2a_stream_t stream);

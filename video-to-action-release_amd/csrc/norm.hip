@@ -30,6 +30,7 @@ struct GnDesc {
     float* dgamma_acc;      // small backward path: atomically accumulate dgamma / dbeta over n here (or null)
     float* dbeta_acc;
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
+    int film_ld;            // elements between the FiLM rows of consecutive samples (2*C when the [N][2][C] tensor is dense)
     float eps;
 };
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
             const int g = c / cg;
             float z = (v[j] - p.mean[n * p.G + g]) * p.rstd[n * p.G + g] * p.gamma[c] + p.beta[c] + r[j];
             float a = act_fwd(z, p.act);
-            if (p.film) a = p.film[(size_t)n * 2 * C + c] * a + p.film[(size_t)n * 2 * C + C + c];
+            if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
             o[j] = a;
         }
         y4[i] = o;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
         float z = (sm[i] - mu) * rs * p.gamma[c] + p.beta[c];
         if (p.residual) z += p.residual[off];
         float a = act_fwd(z, p.act);
-        if (p.film) a = p.film[(size_t)n * 2 * C + c] * a + p.film[(size_t)n * 2 * C + C + c];
+        if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
         p.y[off] = a;
     }
 }
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         float da = dout;
         if (p.film) {
             const float a = act_fwd(z, p.act);
-            da = dout * p.film[(size_t)n * 2 * C + c];
+            da = dout * p.film[(size_t)n * p.film_ld + c];
             atomicAdd(&bins[2 * cg + cc], dout * a);
             atomicAdd(&bins[3 * cg + cc], dout);
         }
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
             atomicAdd(&p.dbeta_acc[c], bins[cc]);
         }
         if (p.dfilm) {
-            p.dfilm[(size_t)n * 2 * C + c] = bins[2 * cg + cc];
-            p.dfilm[(size_t)n * 2 * C + C + c] = bins[3 * cg + cc];
+            p.dfilm[(size_t)n * p.film_ld + c] = bins[2 * cg + cc];
+            p.dfilm[(size_t)n * p.film_ld + C + c] = bins[3 * cg + cc];
         }
     }
 }
@@ -368,13 +369,14 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
 // y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
 // x2 != null: the input is the channel concat [x | x2] (decoder skip, reference unet.py:681) read from both sources in place.
 int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
-                      const float* film, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
+                      const float* film, int film_ld, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
+    p.film_ld = film_ld > 0 ? film_ld : 2 * C;
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act; p.eps = eps;
     const int cg = C / G;
     const long E = (long)S * cg;
@@ -405,12 +407,13 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
 // dfilm (optional) [N][2][C]; colsum [N][2][C] scratch/output; dgamma/dbeta [C]: overwritten, or accumulated into when
 // accumulate_params = 1 (the gradient arena is zeroed by the fused optimiser; saves a reduction launch on the small path).
 int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
-                      const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm,
+                      int film_ld, const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm,
                       float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !dout || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
+    p.film_ld = film_ld > 0 ? film_ld : 2 * C;
     p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;

@@ -328,7 +328,9 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_groupnorm_fwd(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), y.data_ptr(),
+    # film: [N, 2*C] rows (scale | shift); may be a column slice of a wider [N, NF] matrix (batched FiLM projections): row stride
+    film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
+    check(lib.v2a_groupnorm_fwd(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
                                 mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
           "groupnorm_fwd")
     return y, mean, rstd
@@ -353,18 +355,22 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
-                  dgamma=None, dbeta=None, accumulate_params=False):
-    """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None)."""
+                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None):
+    """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
+    as `film` (a column slice of the batched [N, NF] gradient matrix)."""
     N, S, C = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    dfilm = torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None
+    dfilm = dfilm_out if dfilm_out is not None else (torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None)
+    film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
+    if dfilm_out is not None:
+        assert film is not None and dfilm_out.stride(0) == film_ld
     colsum_ = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), dout.data_ptr(),
+    check(lib.v2a_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
                                 mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), _p(dfilm), colsum_.data_ptr(),
                                 dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,
                                 _stream()),

@@ -199,6 +199,25 @@ class PolicyEngine:
                                 us=self.conv(f"{m}up_modules.{i}.2.conv.weight", f"{m}up_modules.{i}.2.conv.bias", transposed=True)))
         self.fin0 = self.conv(m + "final_conv.0.block.0.weight", m + "final_conv.0.block.0.bias")
         self.fin1 = self.conv(m + "final_conv.1.weight", m + "final_conv.1.bias")
+        # the 16 FiLM projections (cond_encoder = Mish -> Linear(G, 2*C), one per residual block) all read the same Mish(cond):
+        # they run as ONE GEMM over concatenated weights (forward, weight gradient, data gradient), see unet_fwd / unet_bwd
+        self.film = []
+        for lvl in self.down:
+            self.film += [lvl["r0"], lvl["r1"]]
+        self.film += list(self.mid)
+        for lvl in self.up:
+            self.film += [lvl["r0"], lvl["r1"]]
+        off = 0
+        for r in self.film:
+            r["film_off"] = off
+            off += 2 * r["cout"]
+        self.film_nf = off
+        self.film_gd = self.film[0]["ce"].ci
+        self._film_w = self._film_b = self._film_wd = None
+        self._film_ver = None
+        self._dfilm_all = None
+        import os as _os2
+        self.batch_film = _os2.environ.get("V2A_BATCH_FILM", "1") != "0"
 
     # ------------------------------------------------------------------ weight gradients off the critical path
     def _wg(self, *a, **k):
@@ -221,6 +240,43 @@ class PolicyEngine:
         if self._side is not None and self._keep:
             torch.cuda.current_stream().wait_stream(self._side)
         self._keep = []
+
+    def _film_key(self):
+        return tuple((r["ce"].w.data_ptr(), r["ce"].w._version, r["ce"].b._version) for r in self.film)
+
+    def _film_rows(self):
+        """Multi-pack table rows that (re)build the concatenated FiLM operands: W_cat [NF][G] and b_cat [NF] by plain copies
+        (mode 0, one tap), W_cat^T [G][NF] (the data-gradient operand) by the transposing launch."""
+        dev = self.device
+        if self._film_w is None:
+            self._film_w = torch.empty((self.film_nf, self.film_gd), dtype=torch.float32, device=dev)
+            self._film_b = torch.empty(self.film_nf, dtype=torch.float32, device=dev)
+            self._film_wd = torch.empty(self.film_nf * self.film_gd, dtype=torch.float32, device=dev)
+        rows0, rows1 = [], []
+        for r in self.film:
+            w, b = r["ce"].w.detach(), r["ce"].b.detach()
+            o, n2 = r["film_off"], 2 * r["cout"]
+            rows0.append([w.data_ptr(), self._film_w.data_ptr() + 4 * o * self.film_gd, n2, self.film_gd, 1, 0, 0])
+            rows0.append([b.data_ptr(), self._film_b.data_ptr() + 4 * o, 1, n2, 1, 0, 0])
+        rows1.append([self._film_w.data_ptr(), self._film_wd.data_ptr(), self.film_nf, self.film_gd, 1, 1, 0])
+        return rows0, rows1
+
+    def _refresh_film(self):
+        """Standalone rebuild (parameters changed outside refresh_packs, e.g. the autograd / compute_loss path)."""
+        from ._lib import lib, check
+        rows0, rows1 = self._film_rows()
+        ce = lib.v2a_pack_chunk_elems()
+        ch0 = [[i, s0] for i, r in enumerate(rows0) for s0 in range(0, r[2] * r[3], ce)]
+        ntile = -(-self.film_nf // 64) * -(-self.film_gd // 64)
+        ch1 = [[0, t] for t in range(ntile)]
+        t0 = torch.tensor(rows0, dtype=torch.int64).to(self.device)
+        t1 = torch.tensor(rows1, dtype=torch.int64).to(self.device)
+        c0 = torch.tensor(ch0, dtype=torch.int32).to(self.device)
+        c1 = torch.tensor(ch1, dtype=torch.int32).to(self.device)
+        check(lib.v2a_pack_weights_multi(t0.data_ptr(), c0.data_ptr(), len(ch0), 0, ops._stream()), "pack_weights_multi")
+        check(lib.v2a_pack_weights_multi(t1.data_ptr(), c1.data_ptr(), len(ch1), 1, ops._stream()), "pack_weights_multi_t")
+        self._film_keep = (t0, t1, c0, c1)              # keep the tables alive until the launches ran
+        self._film_ver = self._film_key()
 
     def refresh_packs(self):
         """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable).
@@ -257,6 +313,14 @@ class PolicyEngine:
                 if bf16:
                     ops.register_h_twin(c._pf, c._pf_h)
                     ops.register_h_twin(c._pd, c._pd_h)
+            if self.batch_film:
+                f0, f1 = self._film_rows()
+                for row in f0:
+                    rows.append(row)
+                    ch0 += [[len(rows) - 1, s0] for s0 in range(0, row[2] * row[3], ce)]
+                for row in f1:
+                    rows.append(row)
+                    ch1 += [[len(rows) - 1, t_] for t_ in range(-(-row[2] // 64) * -(-row[3] // 64))]
             dev = self.device
             t = lambda a, dt: torch.tensor(a, dtype=dt).to(dev) if a else None
             self._mp = dict(tab=t(rows, torch.int64), ch0=t(ch0, torch.int32), n0=len(ch0), ch1=t(ch1, torch.int32), n1=len(ch1),
@@ -271,6 +335,8 @@ class PolicyEngine:
             check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"].data_ptr(), mp["n1"], 1, ops._stream()), "pack_weights_multi_t")
         for c in self._convs.values():
             c._ver = (c.w.data_ptr(), c.w._version)
+        if self.batch_film:
+            self._film_ver = self._film_key()
 
     # ------------------------------------------------------------------ encoder
     def _gn(self, x4, pre, G, act, residual=None, film=None):
@@ -281,12 +347,13 @@ class PolicyEngine:
         y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film)
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
-    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False):
+    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None):
         x3, mean, rstd, r3, film, pre, G, act = saved
         d3 = dout4.view(x3.shape)
         dx, dg, db, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                     residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
-                                                    dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], accumulate_params=True)
+                                                    dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], accumulate_params=True,
+                                                    dfilm_out=dfilm_out)
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
     def encode_fwd(self, key, img_nchw, save):
@@ -387,7 +454,10 @@ class PolicyEngine:
         B, T, _ = x.shape
         co = r["cout"]
         c0 = self._c1d(x, r["c0"], k, x2=x2)
-        film = ops.linear(mgf, r["ce"].pf(), r["ce"].b)                       # [B, 2*co] == [B][2][co]
+        if self._film_all is not None:
+            film = self._film_all[:, r["film_off"]:r["film_off"] + 2 * co]         # column slice of the batched projection
+        else:
+            film = ops.linear(mgf, r["ce"].pf(), r["ce"].b)                       # [B, 2*co] == [B][2][co]
         a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film)
         a0 = a0.view(B, T, co)
         c1 = self._c1d(a0, r["c1"], k)
@@ -416,10 +486,15 @@ class PolicyEngine:
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
         self._wg(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname])
         da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2))
-        dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
-        df2 = dfilm.view(B, 2 * co)
-        self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
-        dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0), residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
+        if self._dfilm_all is not None:          # batched FiLM: the gradient rows go into this block's columns of [B, NF]
+            o = r["film_off"]
+            dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co])
+        else:
+            dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
+            df2 = dfilm.view(B, 2 * co)
+            self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
+            dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0),
+                          residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
         self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname])
         rc = r["rc"]
         if rc is not None:
@@ -455,6 +530,11 @@ class PolicyEngine:
         ops.copy2d(global_cond, gf, B, Gd, Gd, cfg.dsed + Gd, dst_off=cfg.dsed)
         mgf = ops.act_fwd(gf, "mish")
         self._mgf = mgf
+        self._film_all = None
+        if self.batch_film:
+            if self._film_ver != self._film_key():
+                self._refresh_film()
+            self._film_all = ops.linear(mgf, self._film_w, self._film_b)          # [B, NF]: every block's (scale | shift) rows
         tape = [] if save is not None else None
         x = sample
         hs = []
@@ -504,6 +584,9 @@ class PolicyEngine:
         dx = _dgrad(dc, f0, None, f0.ci, 1, k, (1, 1), (0, k // 2)).view(B, T, f0.ci)
         tape = save["tape"]
         dmgf = None
+        self._dfilm_all = None
+        if self._film_all is not None and self._film_grads_contiguous(grads):
+            self._dfilm_all = torch.empty((B, self.film_nf), dtype=torch.float32, device=dpred.device)
         pending_skip = []          # gradients flowing into hs entries from the up path (LIFO order of use)
         # walk the tape backwards
         i = len(tape) - 1
@@ -542,6 +625,14 @@ class PolicyEngine:
             i -= 1
         # pending_skip is pushed in up-path order (deepest level first) and popped by the matching consumers
         # in reverse tape order: mid[0] pops the deepest, then each downsample pops the next shallower one.
+        if self._dfilm_all is not None:
+            # the 16 FiLM projections' gradients as two GEMMs over the concatenated operands: dW_cat / db_cat land directly in the
+            # arena (their 32 slices are contiguous in film order: trainable_names), d Mish(cond) = dFiLM_all @ W_cat
+            df4 = self._dfilm_all.view(1, 1, B, self.film_nf)
+            w0, b0 = self.film[0]["ce"].wname, self.film[0]["ce"].bname
+            self._wg(self._mgf.view(1, 1, B, -1), df4, (self.film_nf, self.film_gd), 1, 1, dw=grads[w0], dbias=grads[b0])
+            dmgf = ops.conv2d(df4, self._film_wd, None, self.film_gd, 1, 1).view(B, -1)
+            self._dfilm_all = None
         # --- step encoder
         gf = save["gf"]
         dgf = ops.act_bwd(gf, dmgf, "mish")
@@ -677,8 +768,30 @@ class PolicyEngine:
         assert lo == 0 or hi == total
         return (lo, hi), ((0, lo) if hi == total else (hi, total))
 
+    def _film_grads_contiguous(self, grads):
+        """True when the gradient views of the 16 FiLM weights (then the 16 biases) are adjacent in film order (trainable_names)."""
+        ws = [grads.get(r["ce"].wname) for r in self.film]
+        bs = [grads.get(r["ce"].bname) for r in self.film]
+        if any(t is None for t in ws + bs):
+            return False
+        for seq in (ws, bs):
+            for a, b in zip(seq[:-1], seq[1:]):
+                if a.data_ptr() + 4 * a.numel() != b.data_ptr():
+                    return False
+        return True
+
     def trainable_names(self):
-        """Every parameter the backward produces a gradient for (the reference trains all of these)."""
+        """Every parameter the backward produces a gradient for (the reference trains all of these), in arena order: the
+        `model.*` group first with its 16 FiLM weights, then its 16 FiLM biases, at the end of the group in film order (their
+        gradients are written by ONE batched GEMM), then the encoders."""
         skip = ("_dummy_variable", "temperature")
-        return [n for n, p in self.P.items() if torch.is_floating_point(p) and p.dim() > 0 and p.numel() > 0
-                and not any(n.endswith(s) for s in skip) and not n.endswith("pos_x") and not n.endswith("pos_y")]
+        names = [n for n, p in self.P.items() if torch.is_floating_point(p) and p.dim() > 0 and p.numel() > 0
+                 and not any(n.endswith(s) for s in skip) and not n.endswith("pos_x") and not n.endswith("pos_y")]
+        fw = [r["ce"].wname for r in self.film]
+        fb = [r["ce"].bname for r in self.film]
+        film = set(fw + fb)
+        model = [n for n in names if n.startswith("model.") and n not in film]
+        rest = [n for n in names if not n.startswith("model.")]
+        first_is_model = bool(names) and names[0].startswith("model.")
+        grp = model + [n for n in fw if n in names] + [n for n in fb if n in names]
+        return grp + rest if first_is_model else rest + grp
