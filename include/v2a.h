@@ -153,6 +153,12 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
                            void* workspace, size_t workspace_bytes, v2a_stream_t s);
 /* residual (bf16) xor residual_f32; idil 1 | 2; stats (optional, only when v2a_conv2d_h_workspace_bytes() == 0 and y is bf16):
  * [ceil(M/64)][2][Cout] per-64-row sum / sum of squares of the rounded outputs, consumed by v2a_groupnorm_fwd_h */
+/* multi-stage 256-row variant of v2a_conv2d_fwd_h for the large layers (csrc/igemm_h2.hip: 8 waves, 4-5 LDS stages, counted vmcnt):
+ * bf16 in / bf16 out, optional bf16 residual and statistics, no split-K; v2a_conv2d_h2_eligible says whether a problem qualifies */
+int v2a_conv2d_h2_eligible(int M, int Cout, int K, int C1, int C2);
+int v2a_conv2d_fwd_h2(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
+                      void* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh, int sw, int ph,
+                      int pw, int ups, int OH, int OW, int rows_per_batch, float* stats, v2a_stream_t s);
 /* GroupNorm + activation and QKV attention over bf16 tensors (csrc/norm_h.hip, csrc/attention.hip): same math as v2a_groupnorm_fwd /
  * v2a_attention_fwd (reference nn.py:26-28 GroupNorm32 computes in fp32 and returns the input dtype; unet.py:341-358), bf16 I/O. */
 size_t v2a_groupnorm_h_workspace_bytes(int N, int S, int C);

@@ -485,3 +485,43 @@ def test_attention_h_mfma_matches_fp32_attention_on_bf16_inputs(N, L, heads):
     assert err <= 2e-2 * ref.abs().max().item(), err
     # and it agrees with the VALU bf16 kernel's contract on a transposition-sensitive input (distinct q / k / v statistics per channel)
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_conv2d_h2_multistage_kernel_matches_fp64_reference():
+    """The 8-wave, 4-stage 256x256 kernel (csrc/igemm_h2.hip; counted-vmcnt pipeline) on a problem large enough to be routed to it:
+    two-source concat, bias + per-sample row vector + residual, ragged last tile, statistics; result within one bf16 ulp of an
+    fp64 conv of the same rounded operands -- and equal to the 128x128 kernel's result up to summation order."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C1, C2, Co = 5, 168, 168, 64, 64, 256                  # M = 141120 = 551.25 tiles of 256 rows
+    assert lib.v2a_conv2d_h2_eligible(N * H * W, Co, 9 * (C1 + C2), C1, C2) == 1
+    x = torch.randn(N, H, W, C1, generator=g).to(torch.bfloat16).to(dev)
+    x2 = torch.randn(N, H, W, C2, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    rowvec = torch.randn(N, Co, generator=g).to(dev)
+    res = torch.randn(N, H, W, Co, generator=g).to(torch.bfloat16).to(dev)
+    wp = ops.pack_weight_h(w)
+    y, st = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), x2=x2, rowvec=rowvec, rows_per_batch=H * W, residual=res, want_stats=True)
+    assert ops.last_kernel[0].startswith("conv_igemm_h2") and st is not None
+    old = ops._H2
+    ops._H2 = False
+    try:
+        y1 = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), x2=x2, rowvec=rowvec, rows_per_batch=H * W, residual=res)
+    finally:
+        ops._H2 = old
+    d = (y.float() - y1.float()).abs()
+    assert (d <= y1.float().abs() * 2.0 ** -7 + 1e-5).all() and (d > 0).float().mean().item() < 0.01
+    # fp64 reference on a slab of rows (full conv on the host would take minutes): samples 0 and 4, all channels
+    xin = torch.cat([x.float(), x2.float()], -1).permute(0, 3, 1, 2).cpu().double()
+    wq = w.to(torch.bfloat16).float().cpu().double()
+    for n in (0, 4):
+        ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=1).permute(0, 2, 3, 1)[0]
+        ref = ref + rowvec[n].cpu().double() + res[n].cpu().double()
+        err = (y[n].cpu().double() - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
+    rows = y.float().view(-1, 64, Co)
+    assert torch.allclose(st[:, 0], rows.sum(1), rtol=1e-4, atol=2e-3) and torch.allclose(st[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=2e-3)

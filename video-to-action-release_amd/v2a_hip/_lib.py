@@ -73,6 +73,8 @@ SIGNATURES = {
     "v2a_conv2d_dma_f32_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_h_can_emit_stats": (I, [I, I, I]),
     "v2a_conv2d_fwd_dma_f32": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
+    "v2a_conv2d_h2_eligible": (I, [I, I, I, I, I]),
+    "v2a_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P] + [I] * 16 + [P, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),
     "v2a_cast_f32_bf16": (I, [P, P, SZ, P]),
     "v2a_cast_bf16_f32": (I, [P, P, SZ, P]),

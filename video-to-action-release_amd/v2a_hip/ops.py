@@ -213,6 +213,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
 # ---- bf16-storage family (csrc/igemm_h.hip): activations / packed weights are torch.bfloat16 tensors, accumulation fp32
 _zeros_h = {}
 _FUSED_STATS = os.environ.get('V2A_GN_FUSED_STATS', '1') != '0'
+_H2 = os.environ.get('V2A_CONV_H2', '1') != '0'
 
 
 def _zero_line(device):
@@ -281,6 +282,15 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     else:
         out_f32 = y.dtype == torch.float32
+    if (_H2 and idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16
+            and lib.v2a_conv2d_h2_eligible(M, Cout, K, C1, C2)):
+        # large layer: the multi-stage 256-row kernel (csrc/igemm_h2.hip)
+        stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
+        check(lib.v2a_conv2d_fwd_h2(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(res_h), y.data_ptr(),
+                                    _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0,
+                                    OH, OW, rows_per_batch, _p(stats), _stream()), "conv2d_fwd_h2")
+        last_kernel[0] = f"conv_igemm_h2<{'256x256' if Cout % 256 == 0 else '256x128'}>"
+        return (y, stats) if want_stats else y
     wsb = lib.v2a_conv2d_h_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
     stats = None
