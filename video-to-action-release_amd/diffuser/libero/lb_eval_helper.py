@@ -65,57 +65,68 @@ class LB_DP_Eval(object):
                     suc_rate_per_tk=suc_rate_per_tk, is_sucs_per_tk=is_sucs_per_tk, is_sucs_all=is_sucs_all,
                     run_times_all=run_times_all, run_times_per_tk=run_times_per_tk, seeds=self.valid_seeds)
 
+    # ------------------------------------------------------------------------------------------------ one episode
+    def _observe(self, env, cam_name):
+        """Current camera frame as the model input: [1,3,H,W] float in [0,1] on the host."""
+        frame = self.env_list.render_a_given_env(env, cam_name=cam_name)
+        if type(frame) is not np.ndarray:
+            raise TypeError("the environment must render numpy frames")
+        obs = self.rendered_imgs_preproc_fn(frame[None])
+        assert obs.ndim == 4 and obs.shape[:2] == (1, 3) and tuple(obs.shape[2:4]) == tuple(self.input_img_size)
+        return obs
+
+    def _plan_video(self, obs, task):
+        """One call of the video model from the current observation -> predicted frames [T,3,H,W] (device tensor)."""
+        self.pre_vid_gen_fn(**self.pvG_fn_args)
+        with torch.no_grad():
+            video = self.video_model.forward(obs.to(self.device), [task])
+        self.after_vid_gen_fn(**self.avG_fn_args)
+        assert len(video) == 1
+        return video.detach()[0]
+
+    def _act_towards(self, env, cam_name, obs, goal, frames_out):
+        """One policy call towards `goal` and the execution of its n_acts_per_pred actions.  Returns (new observation, success)."""
+        with torch.no_grad():
+            query = self.trainer.to_batch_dict(obs.to(self.device), goal, None)
+            acts = self.ema.ema_model.predict_action(query['obs'], use_ddim=self.is_dp_ddim)['action'].cpu()[0]
+        assert len(acts) == self.n_acts_per_pred and acts.shape[-1] == 7
+        acts = acts.clamp(min=self.trainer.act_min, max=self.trainer.act_max)
+        success = False
+        for a in acts:
+            _, _, done, _ = env.step(a.numpy())
+            frames_out.append(self._observe(env, cam_name))
+            success = success or bool(done)
+        return torch.clone(frames_out[-1]), success
+
     def eval_1_env(self, env, tk, cam_name):
+        """Closed-loop episode (reference :168-373).  The goal video is re-planned `num_vid_pred_per_ep` times: after the first
+        `use_vid_first_n_frames` frames of a plan were followed, a new plan starts from the current observation; every frame is
+        pursued with `eval_n_preds_betw_vframes` policy calls.  Returns (is_suc, observed frames as HWC float arrays, seconds,
+        [start frame + predicted video per plan], None)."""
         self.ema.ema_model.eval()
         self.video_model.ema.ema_model.eval()
-        timer = utils.Timer()
-        img_r = self.env_list.render_a_given_env(env, cam_name)
-        assert type(img_r) == np.ndarray
-        img_st = self.rendered_imgs_preproc_fn(img_r[None])
-        assert img_st.ndim == 4 and img_st.shape[1] == 3 and img_st.shape[2:4] == self.input_img_size
-        tasks_str = [tk]
-        v_hzn = self.video_model.video_future_horizon
-        is_suc = False
-        imgs_out_dense = [img_st]
-        all_full_pred_v = []
-        cnt_vid_pred = 0
-        num_vid_ppp = 1 if tk in LB_1_VIDEO_PRED else self.num_vid_pred_per_ep
-        num_total_frames = (num_vid_ppp - 1) * self.use_vid_first_n_frames + v_hzn
-        g_idx, pred_v = 0, None
-        for fr_idx in range(num_total_frames):
-            if cnt_vid_pred < num_vid_ppp and (fr_idx == 0 or g_idx == self.use_vid_first_n_frames - 1):
-                self.pre_vid_gen_fn(**self.pvG_fn_args)
-                with torch.no_grad():
-                    preds_video = self.video_model.forward(img_st.to(self.device), tasks_str)
-                self.after_vid_gen_fn(**self.avG_fn_args)
-                assert len(preds_video) == 1
-                pred_v = preds_video.detach()[0]
-                all_full_pred_v.append(torch.cat([img_st.cpu(), pred_v.cpu()], dim=0))
-                cnt_vid_pred += 1
-                g_idx = 0
+        clock = utils.Timer()
+        obs = self._observe(env, cam_name)
+        horizon = self.video_model.video_future_horizon
+        plans_allowed = 1 if tk in LB_1_VIDEO_PRED else self.num_vid_pred_per_ep
+        total_goals = (plans_allowed - 1) * self.use_vid_first_n_frames + horizon
+        n_calls = self.eval_n_preds_betw_vframes
+        assert type(n_calls) == int
+        observed, plans = [obs], []
+        video, goal_idx, solved = None, 0, False
+        for step in range(total_goals):
+            replan = len(plans) < plans_allowed and (step == 0 or goal_idx == self.use_vid_first_n_frames - 1)
+            if replan:
+                video = self._plan_video(obs, tk)
+                plans.append(torch.cat([obs.cpu(), video.cpu()], dim=0))
+                goal_idx = 0
             else:
-                g_idx += 1
-            img_goal = pred_v[None, g_idx]
-            n_preds = self.eval_n_preds_betw_vframes
-            assert type(n_preds) == int
-            for i_p in range(n_preds):
-                img_st = img_st.to(self.device)
-                with torch.no_grad():
-                    batch = self.trainer.to_batch_dict(img_st, img_goal, None)
-                    act = self.ema.ema_model.predict_action(batch['obs'], use_ddim=self.is_dp_ddim)['action'].cpu()
-                act = act[0]
-                assert len(act) == self.n_acts_per_pred
-                act = act.clamp(min=self.trainer.act_min, max=self.trainer.act_max)
-                assert act.shape[-1] == 7
-                for i_a in range(self.n_acts_per_pred):
-                    _, _, e_done, info = env.step(act[i_a].numpy())
-                    img_cur = self.rendered_imgs_preproc_fn(self.env_list.render_a_given_env(env, cam_name=cam_name)[None])
-                    imgs_out_dense.append(img_cur)
-                    is_suc = bool(e_done) or is_suc
-                img_st = torch.clone(imgs_out_dense[-1])
-                assert img_st.ndim == 4 and img_st.shape[0] == 1
-            if is_suc and self.is_stop_at_suc:
+                goal_idx += 1
+            goal = video[None, goal_idx]
+            for _ in range(n_calls):
+                obs, ok = self._act_towards(env, cam_name, obs, goal, observed)
+                solved = solved or ok
+            if solved and self.is_stop_at_suc:
                 break
-        run_time = timer()
-        imgs_np = [img[0].permute(1, 2, 0).cpu().numpy() for img in imgs_out_dense]
-        return is_suc, imgs_np, run_time, all_full_pred_v, None
+        seconds = clock()
+        return solved, [o[0].permute(1, 2, 0).cpu().numpy() for o in observed], seconds, plans, None
