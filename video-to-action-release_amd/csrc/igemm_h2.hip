@@ -307,9 +307,9 @@ extern "C" {
 // 1 when v2a_conv2d_fwd_h2 takes this problem (bf16 storage, no split-K, enough tiles to fill the chip)
 int v2a_conv2d_h2_eligible(int M, int Cout, int K, int C1, int C2) {
     if (C1 % 32 || C2 % 32 || K % 32 || Cout % 8 || Cout < 128) return 0;
-    if (Cout % 256) return 0;          // the 256 x 128 instance measured slower than conv_igemm_h's 4-workgroups-per-CU form: not used
-    const int bn = (Cout % 256 == 0) ? 256 : 128;
-    const long tiles = (long)cdiv(M, 256) * cdiv(Cout, bn);
+    if (Cout % 256) return 0;          // 128-wide layers: both a 256x128 (5 stages) and a 512x128 (3 stages) instance measured slower
+                                       // than conv_igemm_h's four-workgroups-per-CU form (676 / 744 vs 791 TFLOP/s): not dispatched
+    const long tiles = (long)cdiv(M, 256) * (Cout / 256);
     return tiles >= 512 ? 1 : 0;
 }
 
@@ -333,13 +333,8 @@ int v2a_conv2d_fwd_h2(const void* x, const void* x2, const void* w_packed, const
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.fd_ow = make_fastdiv2((uint32_t)OW);
     p.fd_oh = make_fastdiv2((uint32_t)OH);
-    if (Cout % 256 == 0) {
-        const int tiles = cdiv(M, 256) * (Cout / 256);
-        hipLaunchKernelGGL((conv_igemm_h2<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, 4 stages x 32 KB
-    } else {
-        const int tiles = cdiv(M, 256) * cdiv(Cout, 128);
-        hipLaunchKernelGGL((conv_igemm_h2<4, 2, 2, 2, 5>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, 5 stages x 24 KB
-    }
+    const int tiles = cdiv(M, 256) * (Cout / 256);
+    hipLaunchKernelGGL((conv_igemm_h2<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, 4 stages x 32 KB
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
