@@ -82,6 +82,10 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
                       size_t workspace_bytes, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- elementwise (csrc/elementwise.hip) */
+/* backward helpers of the video UNet: 2x2 sum pooling (gradient of the folded nearest upsample, unet.py:86-115) and per-sample column
+ * sums (gradient of the embedding row vector broadcast over a sample's rows, unet.py:239-260) */
+int v2a_sumpool2x2(const float* du, float* dx, int N, int H, int W, int C, v2a_stream_t s);
+int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int accumulate, v2a_stream_t s);
 int v2a_act_fwd(const float* x, float* y, size_t n, int act, v2a_stream_t s);                 /* nn.Mish / nn.SiLU / nn.GELU */
 int v2a_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, v2a_stream_t s);
 int v2a_axpy(const float* a, const float* b, float* out, float alpha, size_t n, v2a_stream_t s);   /* out = a + alpha b */
@@ -119,6 +123,10 @@ int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
 /* ---------------------------------------------------------------------------------------------- attention (csrc/attention.hip) */
 /* QKVAttentionLegacy.forward (.../guided_diffusion/unet.py:341-358): qkv [n_frames*L][heads*3*ch] -> out [n_frames*L][heads*ch] */
 int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int heads, int head_ch, v2a_stream_t s);
+/* its backward (video-model training: the reference differentiates AttentionBlock through autograd, unet.py:303-358): d(qkv) from qkv,
+ * the forward output and d(output); fp32, deterministic */
+int v2a_attention_bwd(const float* qkv, const float* out, const float* dout, float* dqkv, int n_frames, int L, int heads, int head_ch,
+                      v2a_stream_t s);
 /* PerceiverAttention core (.../guided_diffusion/imagen.py:295-319): l2norm(q,k) * scales, sim * 8, softmax, @ v */
 int v2a_perceiver_attention(const float* q, const float* kv, const float* q_scale, const float* k_scale, float* out, int B, int Lq,
                             int Lk, int H, int D, float sim_scale, v2a_stream_t s);

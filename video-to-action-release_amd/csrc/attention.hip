@@ -100,6 +100,119 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
+// Backward of QKVAttentionLegacy (video-model training, reference unet.py:341-358 under autograd).  One workgroup per (frame, head);
+// Q, K, V and dO of the head live in LDS (fp32).  Phase A: thread = query row i recomputes its softmax statistics (m_i, l_i),
+// D_i = dO_i . O_i, and dQ_i = s^2 sum_j dS_ij K_j with dS_ij = P_ij (dO_i . V_j - D_i).  Phase B: thread = key row j accumulates
+// dV_j = sum_i P_ij dO_i and dK_j = s^2 sum_i dS_ij Q_i from the LDS-resident rows -- deterministic, no atomics.
+template <int CH>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dout,
+                                                       float* __restrict__ dqkv, int L, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float smb[];
+    float* Qs = smb;                 // [L][CH]
+    float* Ks = Qs + (size_t)L * CH;
+    float* Vs = Ks + (size_t)L * CH;
+    float* Gs = Vs + (size_t)L * CH;  // dO
+    float* Ms = Gs + (size_t)L * CH;  // [L] row max
+    float* Ls = Ms + L;               // [L] row sum
+    float* Ds = Ls + L;               // [L] dO_i . O_i
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C3 = heads * 3 * CH, C = heads * CH;
+    const float* base = qkv + (size_t)n * L * C3 + (size_t)h * 3 * CH;
+    float* dbase = dqkv + (size_t)n * L * C3 + (size_t)h * 3 * CH;
+    const float* ob = o + (size_t)n * L * C + (size_t)h * CH;
+    const float* gb = dout + (size_t)n * L * C + (size_t)h * CH;
+    const float s2 = 1.0f / sqrtf((float)CH);
+    for (int i = threadIdx.x; i < L * (CH / 4); i += blockDim.x) {
+        const int r = i / (CH / 4), c4 = (i % (CH / 4)) * 4;
+        const float* src = base + (size_t)r * C3 + c4;
+        *reinterpret_cast<f32x4*>(&Qs[r * CH + c4]) = *reinterpret_cast<const f32x4*>(src);
+        *reinterpret_cast<f32x4*>(&Ks[r * CH + c4]) = *reinterpret_cast<const f32x4*>(src + CH);
+        *reinterpret_cast<f32x4*>(&Vs[r * CH + c4]) = *reinterpret_cast<const f32x4*>(src + 2 * CH);
+        *reinterpret_cast<f32x4*>(&Gs[r * CH + c4]) = *reinterpret_cast<const f32x4*>(gb + (size_t)r * C + c4);
+    }
+    __syncthreads();
+    // ---- phase A: per query row
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        float q[CH], g[CH], dq[CH];
+        float D = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            q[c] = Qs[i * CH + c];
+            g[c] = Gs[i * CH + c];
+            D += g[c] * ob[(size_t)i * C + c];
+            dq[c] = 0.f;
+        }
+        float m = -INFINITY;
+        for (int j = 0; j < L; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) d += q[c] * Ks[j * CH + c];
+            m = fmaxf(m, d * s2);
+        }
+        float l = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) d += q[c] * Ks[j * CH + c];
+            l += expf(d * s2 - m);
+        }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < L; ++j) {
+            float d = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                d += q[c] * Ks[j * CH + c];
+                dp += g[c] * Vs[j * CH + c];
+            }
+            const float pij = expf(d * s2 - m) * inv;
+            const float ds = pij * (dp - D) * s2;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) dq[c] += ds * Ks[j * CH + c];
+        }
+        Ms[i] = m;
+        Ls[i] = inv;
+        Ds[i] = D;
+#pragma unroll
+        for (int c = 0; c < CH; c += 4) {
+            f32x4 v = {dq[c], dq[c + 1], dq[c + 2], dq[c + 3]};
+            *reinterpret_cast<f32x4*>(dbase + (size_t)i * C3 + c) = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase B: per key row
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        float k[CH], v[CH], dk[CH], dv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            k[c] = Ks[j * CH + c];
+            v[c] = Vs[j * CH + c];
+            dk[c] = 0.f;
+            dv[c] = 0.f;
+        }
+        for (int i = 0; i < L; ++i) {
+            float d = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                d += Qs[i * CH + c] * k[c];
+                dp += Gs[i * CH + c] * v[c];
+            }
+            const float pij = expf(d * s2 - Ms[i]) * Ls[i];
+            const float ds = pij * (dp - Ds[i]) * s2;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                dv[c] += pij * Gs[i * CH + c];
+                dk[c] += ds * Qs[i * CH + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c += 4) {
+            f32x4 a = {dk[c], dk[c + 1], dk[c + 2], dk[c + 3]}, b = {dv[c], dv[c + 1], dv[c + 2], dv[c + 3]};
+            *reinterpret_cast<f32x4*>(dbase + (size_t)j * C3 + CH + c) = a;
+            *reinterpret_cast<f32x4*>(dbase + (size_t)j * C3 + 2 * CH + c) = b;
+        }
+    }
+}
+
 // MFMA attention for the bf16-storage configuration (head_ch = 32).  One workgroup per (frame, head); K and V^T of the head live in
 // LDS, every wave owns 64 queries.  The scores are computed SWAPPED, S^T = K Q^T (32x32x16 bf16 MFMA, keys = rows, queries =
 // columns): the accumulator then holds, per lane, 16 keys of ONE query -- exactly the k-slot order in which the same registers,
@@ -338,6 +451,30 @@ int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int hea
         case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, float>), grid, dim3(threads), lds, s, qkv, out, L, heads); break;
         default: return V2A_ERR_ARG;
     }
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+// d(qkv) of the per-frame attention given qkv, its output `out` and d(out); fp32; L * head_ch limited by LDS (4 head matrices resident)
+int v2a_attention_bwd(const float* qkv, const float* out, const float* dout, float* dqkv, int n_frames, int L, int heads, int head_ch,
+                      hipStream_t s) {
+    if (!qkv || !out || !dout || !dqkv) return V2A_ERR_ARG;
+    const size_t lds = ((size_t)4 * L * head_ch + 3 * (size_t)L) * sizeof(float);
+    if (lds > 160 * 1024) return V2A_ERR_ARG;
+    const int threads = L >= 256 ? 256 : ((L + 63) / 64) * 64;
+    dim3 grid(n_frames * heads);
+#define ATTN_BWD(CH_)                                                                                                         \
+    do {                                                                                                                      \
+        if (lds > 64 * 1024)                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((attn_bwd_kernel<CH_>), grid, dim3(threads), lds, s, qkv, out, dout, dqkv, L, heads);              \
+    } while (0)
+    switch (head_ch) {
+        case 16: ATTN_BWD(16); break;
+        case 32: ATTN_BWD(32); break;
+        default: return V2A_ERR_ARG;
+    }
+#undef ATTN_BWD
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

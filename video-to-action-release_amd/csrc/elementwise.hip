@@ -260,6 +260,42 @@ __global__ void philox_randint_kernel(int64_t* out, int n, int high, uint64_t se
 }
 __global__ void advance_counter_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
 
+// backward of a folded nearest x2 upsample: dx[n][h][w][c] = sum of the 2x2 block of du[n][2h..2h+1][2w..2w+1][c]  (C % 4 == 0)
+__global__ void sumpool2x2_kernel(const float* __restrict__ du, float* __restrict__ dx, int N, int H, int W, int C4) {
+    const size_t total = (size_t)N * H * W * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C4);
+        size_t t = idx / C4;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const f32x4* src = reinterpret_cast<const f32x4*>(du) + (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C4 + c;
+        const size_t row = (size_t)2 * W * C4;
+        reinterpret_cast<f32x4*>(dx)[idx] = src[0] + src[C4] + src[row] + src[row + C4];
+    }
+}
+
+// out[b][c] (+)= sum over the `rows` rows of sample b of x[b][r][c]   (gradient of a per-sample broadcast row vector)
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int C, int accumulate) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;                       // 4 row partitions per column block
+    __shared__ double red[4][64];
+    double acc = 0.0;                                        // signed terms that mostly cancel: accumulate in fp64
+    if (c < C) {
+        const float* p = x + (size_t)b * rows * C + c;
+        for (int r = part; r < rows; r += 4) acc += (double)p[(size_t)r * C];
+    }
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float t = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float* dst = out + (size_t)b * C + c;
+        *dst = accumulate ? *dst + t : t;
+    }
+}
+
 extern "C" {
 
 int v2a_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t s) {
@@ -360,6 +396,23 @@ int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint6
 }
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, hipStream_t s) {
     hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, s, ctr, inc);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_sumpool2x2(const float* du, float* dx, int N, int H, int W, int C, hipStream_t s) {
+    if (!du || !dx || C % 4) return V2A_ERR_ARG;
+    const size_t total = (size_t)N * H * W * (C / 4);
+    int g = (int)((total + 255) / 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(g), dim3(256), 0, s, du, dx, N, H, W, C / 4);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int accumulate, hipStream_t s) {
+    if (!x || !out || B <= 0 || rows <= 0 || C <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, x, out, rows, C, accumulate);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

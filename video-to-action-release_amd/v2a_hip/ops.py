@@ -465,6 +465,34 @@ def attention(qkv, n_frames, L, heads, head_ch):
     return out
 
 
+def attention_bwd(qkv, out, dout, n_frames, L, heads, head_ch):
+    """d(qkv) [n_frames*L, 3*C] of attention(qkv) given its output and d(output) (fp32)."""
+    _chk(qkv, "qkv"); _chk(out, "out"); _chk(dout, "dout")
+    dqkv = torch.empty_like(qkv)
+    check(lib.v2a_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), n_frames, L, heads, head_ch, _stream()),
+          "attention_bwd")
+    return dqkv
+
+
+def sumpool2x2(du):
+    """[N, 2H, 2W, C] -> [N, H, W, C]: gradient of the nearest x2 upsample folded into a conv."""
+    _chk(du, "du")
+    N, H2, W2, C = du.shape
+    dx = torch.empty((N, H2 // 2, W2 // 2, C), dtype=torch.float32, device=du.device)
+    check(lib.v2a_sumpool2x2(du.data_ptr(), dx.data_ptr(), N, H2 // 2, W2 // 2, C, _stream()), "sumpool2x2")
+    return dx
+
+
+def colsum_batched(x3d, out=None, accumulate=False):
+    """x [B, rows, C] -> [B, C] column sums per sample."""
+    _chk(x3d, "x")
+    B, rows, C = x3d.shape
+    if out is None:
+        out = torch.empty((B, C), dtype=torch.float32, device=x3d.device)
+    check(lib.v2a_colsum_batched(x3d.data_ptr(), out.data_ptr(), B, rows, C, 1 if accumulate else 0, _stream()), "colsum_batched")
+    return out
+
+
 def perceiver_attention(q, kv, q_scale, k_scale, B, Lq, Lk, H, D, sim_scale=8.0):
     out = torch.empty((B, Lq, H * D), dtype=torch.float32, device=q.device)
     check(lib.v2a_perceiver_attention(q.data_ptr(), kv.data_ptr(), q_scale.data_ptr(), k_scale.data_ptr(), out.data_ptr(), B, Lq,

@@ -1,0 +1,290 @@
+"""Forward-with-tape and hand-written backward of the AVDC video UNet (video-model *training*, SURVEY.md section 8f rank 4:
+GoalGaussianDiffusion.forward / p_losses, reference goal_diffusion.py:690-724 over UNetModel.forward, unet.py:650-684, which
+the reference differentiates with autograd).  fp32 (the parity configuration); same kernels as the policy backward:
+
+  Conv3d            spatial conv + (3x1) temporal conv            -> data gradients as convs over flipped packs (input dilation for the
+                                                                     stride-2 Downsample, 2x2 sum-pool after the folded Upsample),
+                                                                     weight / bias gradients by the LDS-DMA weight-gradient kernel
+  GroupNorm32+SiLU  fused forward, saved (mean, rstd)              -> fused backward (dx, dgamma, dbeta); the decoder's channel concat
+                                                                     is materialised in training so that one backward covers it
+  ResBlock emb add  row vector in the conv epilogue                -> per-sample column sums of the conv's output gradient
+  AttentionBlock    GroupNorm -> qkv -> per-frame attention -> proj -> deterministic attention backward kernel
+  time embedding    Linear-SiLU-Linear on sinusoids                -> linear backward; d(label embedding) is returned to the caller
+
+Gradients are written into caller-provided tensors `grads[name]` (torch layout).  Packed operands are rebuilt by `refresh_packs()`
+(call after every optimiser step: the fused optimiser updates parameters behind torch's version counters)."""
+import torch
+from . import ops
+from .unet_engine import UNetEngine
+
+
+class UNetTrainEngine(UNetEngine):
+    def __init__(self, cfg, params: dict, prefix="unet."):
+        super().__init__(cfg, params, prefix)
+        self._flip = {}             # name -> flipped (data-gradient) pack
+
+    # ------------------------------------------------------------------ operands
+    def refresh_packs(self):
+        self.packs._c.clear()
+        self._flip.clear()
+
+    def wflip(self, name):
+        """K-contiguous operand of the conv that computes the data gradient of `name` ([Cin][taps reversed][Cout])."""
+        full = self.pre + name
+        pk = self._flip.get(full)
+        if pk is None:
+            w = self.P[full].detach().contiguous()
+            if w.dim() == 3:                                   # Conv1d over frames: taps = 3
+                w4 = w.view(w.shape[0], w.shape[1], w.shape[2], 1)
+            elif w.dim() == 2:
+                w4 = w.view(w.shape[0], w.shape[1], 1, 1)
+            else:
+                w4 = w
+            pk = ops.pack_weight(w4.contiguous(), 1)
+            self._flip[full] = pk
+        return pk
+
+    # ------------------------------------------------------------------ Conv3d
+    def conv3d_fwd(self, x, name, cout, stride=1, ups=False, rowvec=None, residual=None):
+        """Like UNetEngine.conv3d, additionally returning what the backward needs."""
+        B, Fr, H, W, C = x.shape
+        k = self.p(name + ".spatial_conv.weight").shape[-1]
+        has_t = self.has(name + ".temporal_conv.weight")
+        x4 = x.view(B * Fr, H, W, C)
+        y = ops.conv2d(x4, self.w(name + ".spatial_conv.weight"), self.p(name + ".spatial_conv.bias"), cout, k, k, (stride, stride),
+                       (k // 2, k // 2), ups=ups, rowvec=None if has_t else rowvec, rows_per_batch=1,
+                       residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout))
+        OH, OW = y.shape[1], y.shape[2]
+        st = dict(name=name, x=x, y=y, k=k, stride=stride, ups=ups, has_t=has_t, cout=cout, has_row=rowvec is not None,
+                  has_res=residual is not None)
+        if not has_t:
+            assert rowvec is None
+            return y.view(B, Fr, OH, OW, cout), st
+        z = ops.conv2d(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight"), self.p(name + ".temporal_conv.bias"), cout,
+                       3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW,
+                       residual=None if residual is None else residual.view(B, Fr, OH * OW, cout))
+        return z.view(B, Fr, OH, OW, cout), st
+
+    def conv3d_bwd(self, st, dz, grads, need_dx=True):
+        """dz [B,F,OH,OW,cout] -> (dx or None, d(rowvec) [B,cout] or None).  The residual's gradient is dz itself."""
+        name, x, y, k, stride, ups, cout = st["name"], st["x"], st["y"], st["k"], st["stride"], st["ups"], st["cout"]
+        B, Fr, H, W, C = x.shape
+        OH, OW = y.shape[1], y.shape[2]
+        pre = self.pre + name
+        drow = None
+        if st["has_row"]:
+            drow = ops.colsum_batched(dz.view(B, Fr * OH * OW, cout))
+        if st["has_t"]:
+            dz4 = dz.view(B, Fr, OH * OW, cout)
+            y4 = y.view(B, Fr, OH * OW, cout)
+            ops.conv2d_wgrad(y4, dz4, (cout, cout, 3, 1), 3, 1, (1, 1), (1, 0), dw=grads[pre + ".temporal_conv.weight"],
+                             dbias=grads[pre + ".temporal_conv.bias"])
+            dy = ops.conv2d(dz4, self.wflip(name + ".temporal_conv.weight"), None, cout, 3, 1, (1, 1), (1, 0)).view(B * Fr, OH, OW, cout)
+        else:
+            dy = dz.view(B * Fr, OH, OW, cout)
+        x4 = x.view(B * Fr, H, W, C)
+        ops.conv2d_wgrad(x4, dy, (cout, C, k, k), k, k, (stride, stride), (k // 2, k // 2), ups=ups, dw=grads[pre + ".spatial_conv.weight"],
+                         dbias=grads[pre + ".spatial_conv.bias"])
+        if not need_dx:
+            return None, drow
+        wf = self.wflip(name + ".spatial_conv.weight")
+        if ups:
+            du = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2))                  # gradient at the upsampled resolution
+            dx = ops.sumpool2x2(du)
+        elif stride > 1:
+            dx = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2), idil=stride, out_hw=(H, W))
+        else:
+            dx = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2))
+        return dx.view(B, Fr, H, W, C), drow
+
+    # ------------------------------------------------------------------ GroupNorm32 (+ SiLU)
+    def gn_fwd(self, x, name, act="silu", frames_separate=False):
+        B, Fr, H, W, C = x.shape
+        N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
+        x3 = x.view(N, S, C)
+        y, mean, rstd = ops.groupnorm_fwd(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act)
+        return y.view(B, Fr, H, W, C), dict(name=name, x3=x3, mean=mean, rstd=rstd, act=act, shape=tuple(x.shape))
+
+    def gn_bwd(self, st, dy, grads):
+        pre = self.pre + st["name"]
+        x3 = st["x3"]
+        dx, _, _, _, _ = ops.groupnorm_bwd(x3, self.p(st["name"] + ".weight"), self.p(st["name"] + ".bias"), 32, dy.view(x3.shape),
+                                           st["mean"], st["rstd"], st["act"], dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"])
+        return dx.view(st["shape"])
+
+    # ------------------------------------------------------------------ Linear
+    def lin_fwd(self, x2d, name):
+        return ops.linear(x2d, self.p(name + ".weight"), self.p(name + ".bias"))
+
+    def lin_bwd(self, x2d, name, dy2d, grads, need_dx=True):
+        pre = self.pre + name
+        w = self.p(name + ".weight")
+        M = x2d.shape[0]
+        ops.conv2d_wgrad(x2d.view(1, 1, M, -1), dy2d.view(1, 1, M, -1), tuple(w.shape), 1, 1, dw=grads[pre + ".weight"],
+                         dbias=grads[pre + ".bias"])
+        if not need_dx:
+            return None
+        return ops.conv2d(dy2d.view(1, 1, M, -1), self.wflip(name + ".weight"), None, w.shape[1], 1, 1).view(M, w.shape[1])
+
+    # ------------------------------------------------------------------ blocks
+    def res_fwd(self, x, name, cout, semb):
+        a, s_gn0 = self.gn_fwd(x, name + ".in_layers.0")
+        eo = self.lin_fwd(semb, name + ".emb_layers.1")
+        h, s_c0 = self.conv3d_fwd(a, name + ".in_layers.2", cout, rowvec=eo)
+        a2, s_gn1 = self.gn_fwd(h, name + ".out_layers.0")
+        s_skip = None
+        if self.has(name + ".skip_connection.spatial_conv.weight"):
+            xs, s_skip = self.conv3d_fwd(x, name + ".skip_connection", cout)
+        else:
+            xs = x
+        out, s_c1 = self.conv3d_fwd(a2, name + ".out_layers.3", cout, residual=xs)
+        return out, dict(kind="res", name=name, gn0=s_gn0, c0=s_c0, gn1=s_gn1, skip=s_skip, c1=s_c1, semb=semb)
+
+    def res_bwd(self, st, dout, grads, dsemb):
+        """Returns dx; accumulates d(SiLU(emb)) into dsemb [B, 4*mc]."""
+        name = st["name"]
+        da2, _ = self.conv3d_bwd(st["c1"], dout, grads)
+        dh = self.gn_bwd(st["gn1"], da2, grads)
+        da, deo = self.conv3d_bwd(st["c0"], dh, grads)
+        d_semb = self.lin_bwd(st["semb"], name + ".emb_layers.1", deo, grads)
+        ops.axpy(d_semb, dsemb, out=dsemb)
+        dx = self.gn_bwd(st["gn0"], da, grads)
+        if st["skip"] is not None:
+            dxs, _ = self.conv3d_bwd(st["skip"], dout, grads)
+        else:
+            dxs = dout
+        return ops.axpy(dx, dxs)
+
+    def attn_fwd(self, x, name, C):
+        B, Fr, H, W, _ = x.shape
+        N, L = B * Fr, H * W
+        hc = self.cfg.num_head_channels
+        heads = C // hc
+        n, s_gn = self.gn_fwd(x, name + ".norm", act="none", frames_separate=True)
+        n2 = n.view(N * L, C)
+        wq = self.p(name + ".qkv.weight").view(3 * C, C)
+        qkv = ops.linear(n2, wq, self.p(name + ".qkv.bias"))
+        a = ops.attention(qkv, N, L, heads, hc)
+        wo = self.p(name + ".proj_out.weight").view(C, C)
+        out = ops.linear(a, wo, self.p(name + ".proj_out.bias"), residual=x.view(N * L, C))
+        return out.view(B, Fr, H, W, C), dict(kind="attn", name=name, gn=s_gn, n2=n2, qkv=qkv, a=a, dims=(N, L, heads, hc, C),
+                                              shape=tuple(x.shape))
+
+    def attn_bwd(self, st, dout, grads):
+        name = st["name"]
+        N, L, heads, hc, C = st["dims"]
+        pre = self.pre + name
+        d2 = dout.view(N * L, C)
+        M = N * L
+        ops.conv2d_wgrad(st["a"].view(1, 1, M, C), d2.view(1, 1, M, C), (C, C, 1, 1), 1, 1, dw=grads[pre + ".proj_out.weight"],
+                         dbias=grads[pre + ".proj_out.bias"])
+        da = ops.conv2d(d2.view(1, 1, M, C), self.wflip(name + ".proj_out.weight"), None, C, 1, 1).view(M, C)
+        dqkv = ops.attention_bwd(st["qkv"], st["a"], da, N, L, heads, hc)
+        ops.conv2d_wgrad(st["n2"].view(1, 1, M, C), dqkv.view(1, 1, M, 3 * C), (3 * C, C, 1, 1), 1, 1, dw=grads[pre + ".qkv.weight"],
+                         dbias=grads[pre + ".qkv.bias"])
+        dn = ops.conv2d(dqkv.view(1, 1, M, 3 * C), self.wflip(name + ".qkv.weight"), None, C, 1, 1).view(st["shape"])
+        dx = self.gn_bwd(st["gn"], dn, grads)
+        return ops.axpy(dx, dout)
+
+    # ------------------------------------------------------------------ whole model
+    def _run_fwd(self, blk, h, semb, tape, skip=None):
+        for op in blk:
+            kind, name = op[0], op[1]
+            if kind == "conv":
+                h, st = self.conv3d_fwd(h, name, op[3])
+                tape.append(dict(kind="conv", c=st))
+            elif kind == "res":
+                csplit = None
+                if skip is not None:                             # decoder: normalise / convolve cat[h, skip]: materialised here
+                    B, Fr, H, W, C1 = h.shape
+                    C2 = skip.shape[-1]
+                    cat = torch.empty((B, Fr, H, W, C1 + C2), dtype=torch.float32, device=h.device)
+                    rows = B * Fr * H * W
+                    ops.copy2d(h, cat, rows, C1, C1, C1 + C2)
+                    ops.copy2d(skip, cat, rows, C2, C2, C1 + C2, dst_off=C1)
+                    h, csplit, skip = cat, (C1, C2), None
+                h, st = self.res_fwd(h, name, op[3], semb)
+                st["csplit"] = csplit
+                tape.append(st)
+            elif kind == "attn":
+                h, st = self.attn_fwd(h, name, op[2])
+                tape.append(st)
+            elif kind == "down":
+                h, st = self.conv3d_fwd(h, name + ".op", op[2], stride=2)
+                tape.append(dict(kind="conv", c=st))
+            elif kind == "up":
+                h, st = self.conv3d_fwd(h, name + ".conv", op[2], ups=True)
+                tape.append(dict(kind="conv", c=st))
+        return h
+
+    def forward_train(self, xin, t_long, label_emb):
+        """xin [B,F,H,W,Cin] channels-last fp32, t [B] int64, label_emb [B,4mc] -> (out [B,F,H,W,Cout], tape)."""
+        cfg = self.cfg
+        e0 = ops.sincos_embed(t_long, cfg.model_channels, 1)
+        e1 = self.lin_fwd(e0, "time_embed.0")
+        e1a = ops.act_fwd(e1, "silu")
+        e2 = self.lin_fwd(e1a, "time_embed.2")
+        emb = ops.axpy(e2, label_emb)
+        semb = ops.act_fwd(emb, "silu")
+        tape = dict(e0=e0, e1=e1, e1a=e1a, emb=emb, blocks=[], marks=[])
+        hs = []
+        h = xin
+        for blk in self.inp:
+            h = self._run_fwd(blk, h, semb, tape["blocks"])
+            hs.append(h)
+            tape["marks"].append(("push", len(tape["blocks"])))
+        h = self._run_fwd(self.mid, h, semb, tape["blocks"])
+        for blk in self.out:
+            tape["marks"].append(("pop", len(tape["blocks"])))
+            h = self._run_fwd(blk, h, semb, tape["blocks"], skip=hs.pop())
+        a, s_gn = self.gn_fwd(h, "out.0")
+        out, s_c = self.conv3d_fwd(a, "out.2", cfg.out_channels)
+        tape.update(out_gn=s_gn, out_c=s_c, semb_shape=tuple(semb.shape))
+        return out, tape
+
+    def backward(self, tape, dout, grads):
+        """dout [B,F,H,W,Cout] -> d(label_emb) [B,4mc]; parameter gradients land in grads[full parameter name]."""
+        da, _ = self.conv3d_bwd(tape["out_c"], dout, grads)
+        dh = self.gn_bwd(tape["out_gn"], da, grads)
+        dsemb = torch.zeros(tape["semb_shape"], dtype=torch.float32, device=dout.device)
+        blocks = tape["blocks"]
+        # skip gradients: every decoder block pops one encoder activation; its gradient joins that activation's gradient when the
+        # backward walk reaches the point where it was pushed (marks record tape positions of pushes / pops in forward order)
+        pops = [pos for kind, pos in tape["marks"] if kind == "pop"]
+        pushes = [pos for kind, pos in tape["marks"] if kind == "push"]
+        pending = []                                     # skip gradients in the order the backward produces them
+        i = len(blocks) - 1
+        while i >= 0:
+            st = blocks[i]
+            if st["kind"] == "conv":
+                first = (i == 0)
+                dh, _ = self.conv3d_bwd(st["c"], dh, grads, need_dx=not first)
+            elif st["kind"] == "attn":
+                dh = self.attn_bwd(st, dh, grads)
+            else:
+                dh = self.res_bwd(st, dh, grads, dsemb)
+                if st["csplit"] is not None:
+                    C1, C2 = st["csplit"]
+                    B, Fr, H, W, C = dh.shape
+                    rows = B * Fr * H * W
+                    d1 = torch.empty((B, Fr, H, W, C1), dtype=torch.float32, device=dh.device)
+                    d2 = torch.empty((B, Fr, H, W, C2), dtype=torch.float32, device=dh.device)
+                    ops.copy2d(dh, d1, rows, C1, C, C1)
+                    ops.copy2d(dh, d2, rows, C2, C, C2, src_off=C1)
+                    dh = d1
+                    pending.append(d2)
+            # an encoder activation was pushed right after block i-1 .. i => add the matching skip gradient (LIFO: the last pushed
+            # activation is consumed by the first decoder block, whose gradient was produced last)
+            while pushes and pushes[-1] == i:
+                pushes.pop()
+                if dh is not None:
+                    dh = ops.axpy(dh, pending.pop())
+                else:
+                    pending.pop()
+            i -= 1
+        assert not pending and not pushes, (len(pending), pushes)
+        demb = ops.act_bwd(tape["emb"], dsemb, "silu")
+        de1a = self.lin_bwd(tape["e1a"], "time_embed.2", demb, grads)
+        de1 = ops.act_bwd(tape["e1"], de1a, "silu")
+        self.lin_bwd(tape["e0"], "time_embed.0", de1, grads, need_dx=False)
+        return demb
