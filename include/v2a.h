@@ -131,6 +131,14 @@ int v2a_attention_bwd(const float* qkv, const float* out, const float* dout, flo
 int v2a_perceiver_attention(const float* q, const float* kv, const float* q_scale, const float* k_scale, float* out, int B, int Lq,
                             int Lk, int H, int D, float sim_scale, v2a_stream_t s);
 int v2a_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps, v2a_stream_t s); /* imagen.py:198-211 */
+/* backward passes of the text branch (video-model training; the reference differentiates PerceiverResampler with autograd,
+ * imagen.py:254-372): perceiver attention (dq, dkv, per-(b,head) scale gradients dscale [B*H][2][D]), LayerNorm (dx + per-row
+ * [rows][2][D] contributions to dg / db), and the broadcast that is the gradient of a mean over rows */
+int v2a_perceiver_attention_bwd(const float* q, const float* kv, const float* q_scale, const float* k_scale, const float* out,
+                                const float* dout, float* dq, float* dkv, float* dscale, int B, int Lq, int Lk, int H, int D,
+                                float sim_scale, v2a_stream_t s);
+int v2a_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* contrib, int rows, int D, float eps, v2a_stream_t s);
+int v2a_bcast_rows(const float* dout, float* dx, int B, int R, int D, float scale, v2a_stream_t s);
 int v2a_mean_rows(const float* x, float* out, int B, int R, int D, v2a_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------- pooling (csrc/pool.hip) */

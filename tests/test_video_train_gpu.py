@@ -62,22 +62,20 @@ def test_unet_backward_matches_oracle_autograd():
     # ---- HIP: forward with tape + hand-written backward
     params = dict(m.named_parameters())
     eng = UNetTrainEngine(m.unet.engine_cfg(), params, prefix="unet.")
-    lab = eng.label_embedding(y.cuda())
     xin = x.permute(0, 2, 3, 4, 1).contiguous().cuda()
-    out, tape = eng.forward_train(xin, t.cuda(), lab)
+    out, tape = eng.forward_train_tokens(xin, t.cuda(), y.cuda())
     ref_cl = out_ref.detach().permute(0, 2, 3, 4, 1)
     assert ((out.cpu().double() - ref_cl).abs().max() / ref_cl.abs().max()).item() < 1e-5
     grads = {n: torch.zeros_like(p) for n, p in params.items()}
     dlab = eng.backward(tape, R.permute(0, 2, 3, 4, 1).contiguous().cuda(), grads)
     assert ((dlab.cpu().double() - cap["lab"].grad).abs().max() / cap["lab"].grad.abs().max()).item() < 1e-4
-    gmax = max(P[n].grad.abs().max().item() for n in P if P[n].grad is not None and not n.startswith("unet.task_attnpool"))
+    text = lambda n: n.startswith("unet.task_attnpool")
+    gmax = {tb: max(P[n].grad.abs().max().item() for n in P if P[n].grad is not None and text(n) == tb) for tb in (False, True)}
     worst, worst_name, checked = 0.0, None, 0
     for n in params:
-        if n.startswith("unet.task_attnpool"):
-            continue                                                   # the text branch's backward is a separate step
         rg = P[n].grad
         assert rg is not None, n
-        scale = max(rg.abs().max().item(), 1e-3 * gmax)
+        scale = max(rg.abs().max().item(), 1e-3 * gmax[text(n)])
         err = ((grads[n].cpu().double() - rg).abs().max() / scale).item()
         err32 = ((P32[n].grad.double() - rg).abs().max() / scale).item()
         checked += 1

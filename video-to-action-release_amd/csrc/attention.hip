@@ -399,6 +399,189 @@ __global__ __launch_bounds__(128) void perceiver_attn_kernel(const float* __rest
     }
 }
 
+// Backward of perceiver_attn_kernel (PerceiverResampler training).  One workgroup per (b, head); K-hat, V, Q-hat, dO and the
+// per-query softmax statistics live in LDS.  Phase A (thread = query): m_i, l_i, D_i = dO_i . O_i, dQhat_i = s sum_j dS_ij Khat_j ->
+// dq_i through the l2-normalisation and the learned per-channel scale; phase B (thread = key): dV_j, dKhat_j -> dk_j.  The scale
+// gradients are per-row contributions reduced over rows inside the workgroup and written per (b, head): dscale [B*H][2][D].
+template <int D>
+__global__ __launch_bounds__(128) void perceiver_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                 const float* __restrict__ q_scale, const float* __restrict__ k_scale,
+                                                                 const float* __restrict__ out, const float* __restrict__ dout,
+                                                                 float* __restrict__ dq, float* __restrict__ dkv, float* __restrict__ dscale,
+                                                                 int Lq, int Lk, int H, float sim_scale) {
+    extern __shared__ __attribute__((aligned(16))) float smp[];
+    float* Kh = smp;                              // [Lk][D] normalised, scaled keys
+    float* Vs = Kh + (size_t)Lk * D;              // [Lk][D]
+    float* Qh = Vs + (size_t)Lk * D;              // [Lq][D] normalised, scaled queries
+    float* Gs = Qh + (size_t)Lq * D;              // [Lq][D] dO
+    float* Cs = Gs + (size_t)Lq * D;              // [max(Lq, Lk)][D] per-row scale-gradient contributions
+    float* Ms = Cs + (size_t)max(Lq, Lk) * D;     // [Lq] max, [Lq] 1/sum, [Lq] D_i, then [Lk] 1/|k|
+    float* Ls = Ms + Lq;
+    float* Ds = Ls + Lq;
+    float* Kn = Ds + Lq;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int HD = H * D;
+    for (int r = threadIdx.x; r < Lk; r += blockDim.x) {
+        const float* kr = kv + ((size_t)b * Lk + r) * 2 * HD + h * D;
+        float nrm = 0.f;
+        for (int c = 0; c < D; ++c) nrm += kr[c] * kr[c];
+        nrm = fmaxf(sqrtf(nrm), 1e-12f);
+        Kn[r] = 1.0f / nrm;
+        for (int c = 0; c < D; ++c) {
+            Kh[r * D + c] = kr[c] / nrm * k_scale[c];
+            Vs[r * D + c] = kr[HD + c];
+        }
+    }
+    __syncthreads();
+    // ---- phase A
+    for (int i = threadIdx.x; i < Lq; i += blockDim.x) {
+        const float* qr = q + ((size_t)b * Lq + i) * HD + h * D;
+        const float* gr = dout + ((size_t)b * Lq + i) * HD + h * D;
+        const float* orow = out + ((size_t)b * Lq + i) * HD + h * D;
+        float qn[D], g[D], dqh[D];
+        float nrm = 0.f, Dd = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) { qn[c] = qr[c]; nrm += qn[c] * qn[c]; g[c] = gr[c]; Dd += g[c] * orow[c]; dqh[c] = 0.f; }
+        nrm = fmaxf(sqrtf(nrm), 1e-12f);
+        const float inrm = 1.0f / nrm;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            qn[c] *= inrm;                                     // unit query
+            Qh[i * D + c] = qn[c] * q_scale[c];
+            Gs[i * D + c] = g[c];
+        }
+        float m = -INFINITY;
+        for (int j = 0; j < Lk; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) d += Qh[i * D + c] * Kh[j * D + c];
+            m = fmaxf(m, d * sim_scale);
+        }
+        float l = 0.f;
+        for (int j = 0; j < Lk; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) d += Qh[i * D + c] * Kh[j * D + c];
+            l += expf(d * sim_scale - m);
+        }
+        const float il = 1.0f / l;
+        for (int j = 0; j < Lk; ++j) {
+            float d = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { d += Qh[i * D + c] * Kh[j * D + c]; dp += g[c] * Vs[j * D + c]; }
+            const float ds = expf(d * sim_scale - m) * il * (dp - Dd) * sim_scale;
+#pragma unroll
+            for (int c = 0; c < D; ++c) dqh[c] += ds * Kh[j * D + c];
+        }
+        Ms[i] = m; Ls[i] = il; Ds[i] = Dd;
+        // through qhat = unit(q) * q_scale
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            Cs[i * D + c] = dqh[c] * qn[c];                    // contribution to d q_scale
+            dqh[c] *= q_scale[c];                              // d unit(q)
+            dot += dqh[c] * qn[c];
+        }
+        float* dst = dq + ((size_t)b * Lq + i) * HD + h * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dst[c] = (dqh[c] - qn[c] * dot) * inrm;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float t = 0.f;
+        for (int i = 0; i < Lq; ++i) t += Cs[i * D + c];
+        dscale[((size_t)blockIdx.x * 2 + 0) * D + c] = t;
+    }
+    __syncthreads();
+    // ---- phase B
+    for (int j = threadIdx.x; j < Lk; j += blockDim.x) {
+        float kh[D], v[D], dkh[D], dv[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) { kh[c] = Kh[j * D + c]; v[c] = Vs[j * D + c]; dkh[c] = 0.f; dv[c] = 0.f; }
+        for (int i = 0; i < Lq; ++i) {
+            float d = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { d += Qh[i * D + c] * kh[c]; dp += Gs[i * D + c] * v[c]; }
+            const float pij = expf(d * sim_scale - Ms[i]) * Ls[i];
+            const float ds = pij * (dp - Ds[i]) * sim_scale;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { dv[c] += pij * Gs[i * D + c]; dkh[c] += ds * Qh[i * D + c]; }
+        }
+        const float inrm = Kn[j];
+        float dot = 0.f;
+        float kn[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            kn[c] = (k_scale[c] != 0.f) ? kh[c] / k_scale[c] : 0.f;     // unit key
+            Cs[j * D + c] = dkh[c] * kn[c];
+            dkh[c] *= k_scale[c];
+            dot += dkh[c] * kn[c];
+        }
+        float* dst = dkv + ((size_t)b * Lk + j) * 2 * HD + h * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            dst[c] = (dkh[c] - kn[c] * dot) * inrm;
+            dst[HD + c] = dv[c];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float t = 0.f;
+        for (int j = 0; j < Lk; ++j) t += Cs[j * D + c];
+        dscale[((size_t)blockIdx.x * 2 + 1) * D + c] = t;
+    }
+}
+
+// LayerNorm backward, one workgroup per row: dx, and the row's contributions to dg (dy * xhat) and db (dy) in contrib [rows][2][D]
+// (summed over rows by a column-sum launch).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* g, const float* dy, float* dx, float* contrib,
+                                                            int rows, int D, float eps) {
+    __shared__ float red[12];
+    const int r = blockIdx.x;
+    const float* xr = x + (size_t)r * D;
+    const float* dr = dy + (size_t)r * D;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) s += xr[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)D;
+    float qv = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) { const float d = xr[i] - mu; qv += d * d; }
+    qv = wave_sum(qv);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = qv;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + eps);
+    float a = 0.f, bsum = 0.f;                    // sum dxhat, sum dxhat * xhat
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float xh = (xr[i] - mu) * rs, dxh = dr[i] * g[i];
+        a += dxh;
+        bsum += dxh * xh;
+    }
+    a = wave_sum(a);
+    bsum = wave_sum(bsum);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = bsum; }
+    __syncthreads();
+    const float ma = (red[0] + red[1] + red[2] + red[3]) / (float)D, mb = (red[4] + red[5] + red[6] + red[7]) / (float)D;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float xh = (xr[i] - mu) * rs, dxh = dr[i] * g[i];
+        dx[(size_t)r * D + i] = rs * (dxh - ma - xh * mb);
+        contrib[((size_t)r * 2 + 0) * D + i] = dr[i] * xh;
+        contrib[((size_t)r * 2 + 1) * D + i] = dr[i];
+    }
+}
+
+// dx[b][r][:] = scale * dout[b][:]  (backward of a mean over rows with scale = 1/R)
+__global__ void bcast_rows_kernel(const float* dout, float* dx, int B, int R, int D, float scale) {
+    const size_t total = (size_t)B * R * D;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D);
+        const int b = (int)(idx / ((size_t)R * D));
+        dx[idx] = dout[(size_t)b * D + d] * scale;
+    }
+}
+
 // LayerNorm over the last dim (biased variance, eps inside rsqrt): y = (x-mean)*rsqrt(var+eps)*g (+ b)
 // covers nn.LayerNorm (with bias) and imagen's LayerNorm (gain only) -- reference imagen.py:198-211.
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* g, const float* b, float* y, int rows, int D, float eps) {
@@ -527,6 +710,38 @@ int v2a_layernorm(const float* x, const float* g, const float* b, float* y, int 
 
 int v2a_mean_rows(const float* x, float* out, int B, int R, int D, hipStream_t s) {
     hipLaunchKernelGGL(mean_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, x, out, B, R, D);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_perceiver_attention_bwd(const float* q, const float* kv, const float* q_scale, const float* k_scale, const float* out,
+                                const float* dout, float* dq, float* dkv, float* dscale, int B, int Lq, int Lk, int H, int D,
+                                float sim_scale, hipStream_t s) {
+    if (D != 64 || !q || !kv || !out || !dout || !dq || !dkv || !dscale) return V2A_ERR_ARG;
+    const int Lm = Lq > Lk ? Lq : Lk;
+    const size_t lds = ((size_t)2 * Lk * D + (size_t)2 * Lq * D + (size_t)Lm * D + 3 * (size_t)Lq + Lk) * sizeof(float);
+    if (lds > 160 * 1024) return V2A_ERR_ARG;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)perceiver_attn_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((perceiver_attn_bwd_kernel<64>), dim3(B * H), dim3(128), lds, s, q, kv, q_scale, k_scale, out, dout, dq, dkv, dscale,
+                       Lq, Lk, H, sim_scale);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* contrib, int rows, int D, float eps, hipStream_t s) {
+    if (!x || !g || !dy || !dx || !contrib || rows <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows), dim3(256), 0, s, x, g, dy, dx, contrib, rows, D, eps);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_bcast_rows(const float* dout, float* dx, int B, int R, int D, float scale, hipStream_t s) {
+    if (!dout || !dx) return V2A_ERR_ARG;
+    const size_t total = (size_t)B * R * D;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(g), dim3(256), 0, s, dout, dx, B, R, D, scale);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -50,6 +50,10 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
             float sg = 1.0f / (1.0f + expf(-x));   // d softplus / dx
             return t + x * (1.0f - t * t) * sg;
         }
+        case ACT_GELU: {   // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+        }
         default: return 1.f;
     }
 }

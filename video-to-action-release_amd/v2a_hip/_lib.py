@@ -55,6 +55,9 @@ SIGNATURES = {
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
     "v2a_advance_counter": (I, [P, U64, P]),
     "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),
+    "v2a_perceiver_attention_bwd": (I, [P] * 9 + [I, I, I, I, I, F, P]),
+    "v2a_layernorm_bwd": (I, [P, P, P, P, P, I, I, F, P]),
+    "v2a_bcast_rows": (I, [P, P, I, I, I, F, P]),
     "v2a_attention_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "v2a_sumpool2x2": (I, [P, P, I, I, I, I, P]),
     "v2a_colsum_batched": (I, [P, P, I, I, I, I, P]),

@@ -507,6 +507,36 @@ def layernorm(x2d, g, b=None, eps=1e-5):
     return y
 
 
+def perceiver_attention_bwd(q, kv, q_scale, k_scale, out, dout, B, Lq, Lk, H, D, sim_scale=8.0):
+    """-> (dq [B,Lq,H*D], dkv [B,Lk,2*H*D], dq_scale [D], dk_scale [D])."""
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    part = torch.empty((B * H, 2, D), dtype=torch.float32, device=q.device)
+    check(lib.v2a_perceiver_attention_bwd(q.data_ptr(), kv.data_ptr(), q_scale.data_ptr(), k_scale.data_ptr(), out.data_ptr(),
+                                          dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), part.data_ptr(), B, Lq, Lk, H, D, sim_scale,
+                                          _stream()), "perceiver_attention_bwd")
+    sums = colsum(part.view(B * H, 2 * D))
+    return dq, dkv, sums[:D], sums[D:]
+
+
+def layernorm_bwd(x2d, g, dy2d, eps=1e-5):
+    """-> (dx [rows,D], dg [D], db [D]) of y = layernorm(x) * g (+ b)."""
+    rows, Dm = x2d.shape
+    dx = torch.empty_like(x2d)
+    contrib = torch.empty((rows, 2 * Dm), dtype=torch.float32, device=x2d.device)
+    check(lib.v2a_layernorm_bwd(x2d.data_ptr(), g.data_ptr(), dy2d.data_ptr(), dx.data_ptr(), contrib.data_ptr(), rows, Dm, eps, _stream()),
+          "layernorm_bwd")
+    sums = colsum(contrib)
+    return dx, sums[:Dm], sums[Dm:]
+
+
+def bcast_rows(dout2d, R, scale=1.0):
+    """[B,D] -> [B,R,D]: every row of sample b receives scale * dout[b] (gradient of a mean over R rows with scale = 1/R)."""
+    B, Dm = dout2d.shape
+    dx = torch.empty((B, R, Dm), dtype=torch.float32, device=dout2d.device)
+    check(lib.v2a_bcast_rows(dout2d.data_ptr(), dx.data_ptr(), B, R, Dm, float(scale), _stream()), "bcast_rows")
+    return dx
+
+
 def mean_rows(x3d):
     B, R, Dm = x3d.shape
     out = torch.empty((B, Dm), dtype=torch.float32, device=x3d.device)

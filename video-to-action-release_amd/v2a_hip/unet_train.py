@@ -121,7 +121,7 @@ class UNetTrainEngine(UNetEngine):
         w = self.p(name + ".weight")
         M = x2d.shape[0]
         ops.conv2d_wgrad(x2d.view(1, 1, M, -1), dy2d.view(1, 1, M, -1), tuple(w.shape), 1, 1, dw=grads[pre + ".weight"],
-                         dbias=grads[pre + ".bias"])
+                         dbias=grads.get(pre + ".bias") if self.has(name + ".bias") else None)
         if not need_dx:
             return None
         return ops.conv2d(dy2d.view(1, 1, M, -1), self.wflip(name + ".weight"), None, w.shape[1], 1, 1).view(M, w.shape[1])
@@ -186,6 +186,127 @@ class UNetTrainEngine(UNetEngine):
         dx = self.gn_bwd(st["gn"], dn, grads)
         return ops.axpy(dx, dout)
 
+    # ------------------------------------------------------------------ text branch (PerceiverResampler + Linear + mean)
+    def _ln_fwd(self, x2d, wname, bname=None):
+        return ops.layernorm(x2d, self.p(wname), None if bname is None else self.p(bname))
+
+    def _ln_bwd(self, x2d, wname, bname, dy2d, grads):
+        dx, dg, db = ops.layernorm_bwd(x2d, self.p(wname), dy2d)
+        grads[self.pre + wname].copy_(dg.view_as(grads[self.pre + wname]))
+        if bname is not None:
+            grads[self.pre + bname].copy_(db.view_as(grads[self.pre + bname]))
+        return dx
+
+    def label_embedding_train(self, y):
+        """Same arithmetic as UNetEngine.label_embedding, keeping what the backward needs."""
+        cfg = self.cfg
+        pre = "task_attnpool.0"
+        B, L, D = y.shape
+        y = y.float().contiguous()
+        pos = self.p(pre + ".pos_emb.weight")
+        xp = torch.empty_like(y)
+        for b in range(B):
+            ops.axpy(y[b], pos[:L], 1.0, out=xp[b])
+        n_lat, n_mp = cfg.pr_num_latents, cfg.pr_num_mean_pooled
+        NL = n_lat + n_mp
+        lat = torch.empty((B, NL, D), dtype=torch.float32, device=y.device)
+        lp = self.p(pre + ".latents")
+        for b in range(B):
+            ops.copy2d(lp, lat[b], n_lat, D, D, D, dst_off=n_mp * D)
+        tape = dict(B=B, L=L, D=D, NL=NL, n_mp=n_mp, n_lat=n_lat, layers=[])
+        if n_mp > 0:
+            mp0 = ops.mean_rows(y)
+            mp1 = self._ln_fwd(mp0, pre + ".to_latents_from_mean_pooled_seq.0.g")
+            mp = self.lin_fwd(mp1, pre + ".to_latents_from_mean_pooled_seq.1")
+            ops.copy2d(mp, lat, B, n_mp * D, n_mp * D, NL * D)
+            tape.update(mp0=mp0, mp1=mp1)
+        H, dh = cfg.pr_heads, cfg.pr_dim_head
+        xp2 = xp.view(B * L, D)
+        for li in range(cfg.pr_depth):
+            a = f"{pre}.layers.{li}.0"
+            f = f"{pre}.layers.{li}.1"
+            lat_in = lat.view(B * NL, D)
+            xn = self._ln_fwd(xp2, a + ".norm.weight", a + ".norm.bias")
+            ln = self._ln_fwd(lat_in, a + ".norm_latents.weight", a + ".norm_latents.bias")
+            q = ops.linear(ln, self.p(a + ".to_q.weight"))
+            kvin = torch.empty((B, L + NL, D), dtype=torch.float32, device=y.device)
+            ops.copy2d(xn, kvin, B, L * D, L * D, (L + NL) * D)
+            ops.copy2d(ln, kvin, B, NL * D, NL * D, (L + NL) * D, dst_off=L * D)
+            kv = ops.linear(kvin.view(B * (L + NL), D), self.p(a + ".to_kv.weight"))
+            o0 = ops.perceiver_attention(q, kv, self.p(a + ".q_scale"), self.p(a + ".k_scale"), B, NL, L + NL, H, dh, 8.0)
+            o1 = ops.linear(o0.view(B * NL, H * dh), self.p(a + ".to_out.0.weight"))
+            o2 = self._ln_fwd(o1, a + ".to_out.1.weight", a + ".to_out.1.bias")
+            lat_mid = ops.axpy(o2, lat_in)
+            f0 = self._ln_fwd(lat_mid, f + ".0.g")
+            f1 = ops.linear(f0, self.p(f + ".1.weight"))
+            f2 = ops.act_fwd(f1, "gelu")
+            f3 = self._ln_fwd(f2, f + ".3.g")
+            f4 = ops.linear(f3, self.p(f + ".4.weight"))
+            lat = ops.axpy(f4, lat_mid).view(B, NL, D)
+            tape["layers"].append(dict(a=a, f=f, lat_in=lat_in, xn=xn, ln=ln, q=q, kvin=kvin, kv=kv, o0=o0, o1=o1, lat_mid=lat_mid, f0=f0,
+                                       f1=f1, f2=f2, f3=f3))
+        lat2 = lat.view(B * NL, D)
+        z = self.lin_fwd(lat2, "task_attnpool.1")
+        tape.update(xp2=xp2, lat_out=lat2, H=H, dh=dh)
+        return ops.mean_rows(z.view(B, NL, -1)), tape
+
+    def label_embedding_bwd(self, tape, dlab, grads):
+        """dlab [B, 4mc] -> parameter gradients of task_attnpool.* (the token features themselves are inputs: no gradient)."""
+        B, L, D, NL, n_mp, n_lat, H, dh = (tape[k] for k in ("B", "L", "D", "NL", "n_mp", "n_lat", "H", "dh"))
+        pre = "task_attnpool.0"
+        dz = ops.bcast_rows(dlab, NL, 1.0 / NL).view(B * NL, -1)
+        dlat = self.lin_bwd(tape["lat_out"], "task_attnpool.1", dz, grads)                # [B*NL, D]
+        dxp = torch.zeros((B * L, D), dtype=torch.float32, device=dlab.device)
+        for st in reversed(tape["layers"]):
+            a, f = st["a"], st["f"]
+            # feed-forward: lat = lat_mid + W4 ln_g(gelu(W1 ln_g(lat_mid)))
+            df3 = self._lin_nobias_bwd(st["f3"], f + ".4.weight", dlat, grads)
+            df2 = self._ln_bwd(st["f2"], f + ".3.g", None, df3, grads)
+            df1 = ops.act_bwd(st["f1"], df2, "gelu")
+            df0 = self._lin_nobias_bwd(st["f0"], f + ".1.weight", df1, grads)
+            dmid = ops.axpy(self._ln_bwd(st["lat_mid"], f + ".0.g", None, df0, grads), dlat)
+            # attention: lat_mid = lat_in + LN(Wo attn(Wq LN(lat_in), Wkv [LN(x) ; LN(lat_in)]))
+            do1 = self._ln_bwd(st["o1"], a + ".to_out.1.weight", a + ".to_out.1.bias", dmid, grads)
+            do0 = self._lin_nobias_bwd(st["o0"].view(B * NL, H * dh), a + ".to_out.0.weight", do1, grads)
+            dq, dkv, dqs, dks = ops.perceiver_attention_bwd(st["q"], st["kv"], self.p(a + ".q_scale"), self.p(a + ".k_scale"), st["o0"],
+                                                            do0.view(B, NL, H * dh), B, NL, L + NL, H, dh, 8.0)
+            grads[self.pre + a + ".q_scale"].copy_(dqs)
+            grads[self.pre + a + ".k_scale"].copy_(dks)
+            dkvin = self._lin_nobias_bwd(st["kvin"].view(B * (L + NL), D), a + ".to_kv.weight", dkv.view(B * (L + NL), -1), grads)
+            dln = self._lin_nobias_bwd(st["ln"], a + ".to_q.weight", dq.view(B * NL, -1), grads)
+            dkvin3 = dkvin.view(B, L + NL, D)
+            dxn = torch.empty((B, L, D), dtype=torch.float32, device=dlab.device)
+            dln_kv = torch.empty((B, NL, D), dtype=torch.float32, device=dlab.device)
+            ops.copy2d(dkvin3, dxn, B, L * D, (L + NL) * D, L * D)
+            ops.copy2d(dkvin3, dln_kv, B, NL * D, (L + NL) * D, NL * D, src_off=L * D)
+            dln = ops.axpy(dln, dln_kv.view(B * NL, D))
+            dlat_in = self._ln_bwd(st["lat_in"], a + ".norm_latents.weight", a + ".norm_latents.bias", dln, grads)
+            dxp_l = self._ln_bwd(tape["xp2"], a + ".norm.weight", a + ".norm.bias", dxn.view(B * L, D), grads)
+            ops.axpy(dxp_l, dxp, out=dxp)
+            dlat = ops.axpy(dlat_in, dmid)
+        # initial latents: [mean-pooled branch | learned latents], positional embedding
+        dlat3 = dlat.view(B, NL, D)
+        gl = grads[self.pre + pre + ".latents"]
+        tmp = torch.empty((B, n_lat * D), dtype=torch.float32, device=dlab.device)
+        ops.copy2d(dlat3, tmp, B, n_lat * D, NL * D, n_lat * D, src_off=n_mp * D)
+        gl.copy_(ops.colsum(tmp).view_as(gl))
+        if n_mp > 0:
+            dmp = torch.empty((B, n_mp * D), dtype=torch.float32, device=dlab.device)
+            ops.copy2d(dlat3, dmp, B, n_mp * D, NL * D, n_mp * D)
+            dmp1 = self.lin_bwd(tape["mp1"], pre + ".to_latents_from_mean_pooled_seq.1", dmp, grads)
+            self._ln_bwd(tape["mp0"], pre + ".to_latents_from_mean_pooled_seq.0.g", None, dmp1, grads)
+        gp = grads[self.pre + pre + ".pos_emb.weight"]
+        gp.zero_()
+        dpos = ops.colsum(dxp.view(B, L * D))                         # sum over the batch of d(x + pos)
+        gp[:L].copy_(dpos.view(L, D))
+
+    def _lin_nobias_bwd(self, x2d, wname, dy2d, grads):
+        """Linear without bias given by its weight name; returns dx."""
+        w = self.p(wname)
+        M = x2d.shape[0]
+        ops.conv2d_wgrad(x2d.view(1, 1, M, -1), dy2d.view(1, 1, M, -1), tuple(w.shape), 1, 1, dw=grads[self.pre + wname])
+        return ops.conv2d(dy2d.view(1, 1, M, -1), self.wflip(wname), None, w.shape[1], 1, 1).view(M, w.shape[1])
+
     # ------------------------------------------------------------------ whole model
     def _run_fwd(self, blk, h, semb, tape, skip=None):
         for op in blk:
@@ -242,8 +363,16 @@ class UNetTrainEngine(UNetEngine):
         tape.update(out_gn=s_gn, out_c=s_c, semb_shape=tuple(semb.shape))
         return out, tape
 
+    def forward_train_tokens(self, xin, t_long, tokens):
+        """forward_train with the text branch inside the tape: tokens [B,L,512] (CLIP features)."""
+        lab, ttape = self.label_embedding_train(tokens)
+        out, tape = self.forward_train(xin, t_long, lab)
+        tape["text"] = ttape
+        return out, tape
+
     def backward(self, tape, dout, grads):
-        """dout [B,F,H,W,Cout] -> d(label_emb) [B,4mc]; parameter gradients land in grads[full parameter name]."""
+        """dout [B,F,H,W,Cout] -> d(label_emb) [B,4mc]; parameter gradients land in grads[full parameter name] (including the
+        text branch's when the tape came from forward_train_tokens)."""
         da, _ = self.conv3d_bwd(tape["out_c"], dout, grads)
         dh = self.gn_bwd(tape["out_gn"], da, grads)
         dsemb = torch.zeros(tape["semb_shape"], dtype=torch.float32, device=dout.device)
@@ -287,4 +416,6 @@ class UNetTrainEngine(UNetEngine):
         de1a = self.lin_bwd(tape["e1a"], "time_embed.2", demb, grads)
         de1 = ops.act_bwd(tape["e1"], de1a, "silu")
         self.lin_bwd(tape["e0"], "time_embed.0", de1, grads, need_dx=False)
+        if "text" in tape:
+            self.label_embedding_bwd(tape["text"], demb, grads)
         return demb
