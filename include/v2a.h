@@ -115,6 +115,20 @@ int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f
 int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                            float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
                            int frame_ch, v2a_stream_t s);
+/* video-model training (GoalGaussianDiffusion.forward / p_losses, flowdiffusion/flowdiffusion/goal_diffusion.py:674-724):
+ * q_sample (:674-680) with the [0,1] -> [-1,1] normalisation of forward (:722) folded in; per-sample mean of l2 / l1 (objective 0 =
+ * pred_noise, 1 = pred_x0, 2 = pred_v, :699-707) times loss_weight[t] then the batch mean (:709-713); and its gradient with respect to
+ * the model output, scaled by the device scalar `gscale` (NULL = 1).  out_cl / dout are channels-last [B,f,HW,ci]; img / noise keep the
+ * reference's 'b (f c) h w' layout. */
+int v2a_video_qsample(const float* img, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* out, int B,
+                      size_t per, int normalize, v2a_stream_t s);
+size_t v2a_video_loss_workspace_bytes(int B);
+int v2a_video_loss_fwd(const float* out_cl, const float* img, const float* noise, const int64_t* t, const float* sqrt_acp,
+                       const float* sqrt_1m_acp, const float* loss_weight, float* loss, int B, int f, int HW, int ci, int objective, int l1,
+                       int normalize, void* ws, size_t ws_bytes, v2a_stream_t s);
+int v2a_video_loss_bwd(const float* out_cl, const float* img, const float* noise, const int64_t* t, const float* sqrt_acp,
+                       const float* sqrt_1m_acp, const float* loss_weight, const float* gscale, float* dout, int B, int f, int HW, int ci,
+                       int objective, int l1, int normalize, v2a_stream_t s);
 /* counter-based Philox4x32-10 generators (replace torch.randn / torch.randint of compute_loss :246-252 in perf runs) */
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);

@@ -6,6 +6,8 @@ Follows /root/reference/flowdiffusion/flowdiffusion/goal_diffusion.py:
   both the guidance_weight==0 branch :549-553 and the CFG branch :501-514,:536-547),
   p_sample :571-580, p_sample_loop :582-599, ddim_sample :601-641, sample :643-650.
 
+p_losses / forward :690-724 (training): `p_losses` below, differentiated by torch autograd exactly as the reference does.
+
 torch.randn CPU streams cannot be reproduced on a GPU, so both loops take the noise tensors
 as an argument (`noises[0]` = initial image, `noises[i]` = the i-th randn_like drawn by the
 loop, in the reference's draw order -- see SURVEY.md Appendix A item 7).
@@ -126,3 +128,17 @@ def sample(model_fn, T, noises, x_cond, task_embed, guidance_weight=0.0, var_tem
                            sampling_timesteps, record=record)
     return p_sample_loop(model_fn, T, noises, x_cond, task_embed, guidance_weight, var_temp, num_timesteps,
                          record=record)
+
+
+def p_losses(model_fn, T, x_start, t, x_cond, task_embed, noise, objective="pred_v", loss_type="l2"):
+    """goal_diffusion.py:690-713.  x_start in [-1,1]; model_fn(x [B,C+3,H,W], t, task_embed) -> [B,C,H,W]; t, noise given (the
+    reference draws t = randint(0, T, (b,)) then noise = randn_like(x_start), :718 and :692)."""
+    shape = (-1,) + (1,) * (x_start.dim() - 1)
+    sa = T["sqrt_alphas_cumprod"].to(x_start.dtype)[t].view(shape)
+    s1 = T["sqrt_one_minus_alphas_cumprod"].to(x_start.dtype)[t].view(shape)
+    x = sa * x_start + s1 * noise                                                # q_sample :674-680
+    out = model_fn(torch.cat([x, x_cond], dim=1), t, task_embed)
+    target = {"pred_noise": noise, "pred_x0": x_start, "pred_v": sa * noise - s1 * x_start}[objective]
+    per = (out - target).abs() if loss_type == "l1" else (out - target) ** 2
+    per = per.flatten(1).mean(dim=1)                                             # reduce 'b ... -> b (...)' mean
+    return (per * T["loss_weight"].to(x_start.dtype)[t]).mean()

@@ -74,6 +74,28 @@ def test_oracle_unet_and_sampler_vs_reference(golden_dir):
         assert rel(out, g[f"sample_{name}"]) < 1e-5, name
 
 
+def test_oracle_video_p_losses_vs_reference(golden_dir):
+    """oracle p_losses + autograd through the oracle UNet == the reference's GoalGaussianDiffusion.forward + backward."""
+    from oracle.video_unet import UNetCfg, unet_libero_forward
+    from oracle import goal_diffusion as GD
+    g = np.load(f"{golden_dir}/video_train.npz", allow_pickle=True)
+    m, sd = _tiny_sd()
+    names = [str(n) for n in g["param_names"]]
+    assert names == [n for n, _ in m.named_parameters()]
+    cfg = UNetCfg(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+                  num_head_channels=16)
+    img, cond, te = (torch.from_numpy(g[k]) for k in ("img", "cond", "te"))
+    for tag, lt, obj in (("l2_v", "l2", "pred_v"), ("l1_noise", "l1", "pred_noise")):
+        P = {k: (v.clone().requires_grad_(True) if torch.is_floating_point(v) else v) for k, v in sd.items()}
+        T = GD.cosine_tables(100, objective=obj)
+        fn = lambda xx, tt, ee: unet_libero_forward(P, xx, tt, ee, cfg)
+        loss = GD.p_losses(fn, T, img * 2 - 1, torch.from_numpy(g[f"{tag}_t"]), cond, te, torch.from_numpy(g[f"{tag}_noise"]), obj, lt)
+        assert abs(loss.item() - float(g[f"{tag}_loss"])) < 2e-6 * max(1.0, abs(float(g[f"{tag}_loss"])))
+        loss.backward()
+        gn = np.array([float(P[n].grad.double().norm()) for n in names])
+        assert np.max(np.abs(gn - g[f"{tag}_grad_norms"]) / (g[f"{tag}_grad_norms"] + 1e-6 * g[f"{tag}_grad_norms"].max())) < 2e-4, tag
+
+
 def test_oracle_policy_vs_reference(golden_dir):
     from oracle import policy as OP
     from oracle.param_fill import fill_module

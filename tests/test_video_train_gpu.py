@@ -84,3 +84,108 @@ def test_unet_backward_matches_oracle_autograd():
             worst, worst_name = err, n
     print("worst gradient error vs fp64 truth", worst, worst_name)
     assert checked > 100
+
+
+# ------------------------------------------------------------------------------------------------ loss / Trainer arithmetic vs the reference
+def _diffusion(m, lt="l2", obj="pred_v"):
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    return GoalGaussianDiffusion(m, image_size=(32, 32), channels=9, timesteps=100, sampling_timesteps=100, loss_type=lt, objective=obj,
+                                 beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to("cuda:0")
+
+
+def _sample_idx(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, n, (k,), generator=g)
+
+
+@pytest.mark.parametrize("tag,lt,obj", [("l2_v", "l2", "pred_v"), ("l1_noise", "l1", "pred_noise")])
+def test_forward_loss_and_autograd_vs_reference(golden_dir, tag, lt, obj):
+    """`loss = diffusion(img, cond, emb); loss.backward()` (the reference's user code) against the reference's own loss and gradients."""
+    g = np.load(f"{golden_dir}/video_train.npz", allow_pickle=True)
+    m, _ = _tiny()
+    d = _diffusion(m, lt, obj)
+    d.__dict__["_t_hook"] = lambda b: torch.from_numpy(g[f"{tag}_t"])
+    d.__dict__["_noise_hook"] = lambda shape: torch.from_numpy(g[f"{tag}_noise"])
+    loss = d(torch.from_numpy(g["img"]).cuda(), torch.from_numpy(g["cond"]).cuda(), torch.from_numpy(g["te"]).cuda())
+    assert loss.requires_grad and loss.dim() == 0
+    ref = float(g[f"{tag}_loss"])
+    assert abs(loss.item() - ref) <= 1e-5 * max(1.0, abs(ref)), (loss.item(), ref)
+    (loss * 2.0).backward()                                            # upstream gradient 2: exercises the device-scalar scaling
+    names = [str(n) for n in g["param_names"]]
+    P = dict(m.named_parameters())
+    gmax = float(g[f"{tag}_grad_norms"].max())
+    for i, n in enumerate(names):
+        gr = P[n].grad
+        assert gr is not None, n
+        gr = gr.cpu() * 0.5
+        rn = float(g[f"{tag}_grad_norms"][i])
+        # l1: sign() flips on elements whose difference is within fp32 rounding of zero -> compare norms a little looser
+        tol = (2e-3 if lt == "l1" else 5e-4)
+        assert abs(float(gr.double().norm()) - rn) <= tol * max(rn, 1e-3 * gmax), (n, float(gr.double().norm()), rn)
+        if lt == "l2":
+            smp = gr.flatten()[_sample_idx(gr.numel(), 8, 9)].numpy()
+            scale = max(np.abs(g[f"{tag}_grad_samples"][i]).max(), rn / np.sqrt(gr.numel()), 1e-3 * gmax / np.sqrt(gr.numel()))
+            assert np.max(np.abs(smp - g[f"{tag}_grad_samples"][i])) <= 2e-3 * scale, n
+
+
+def test_six_trainer_steps_vs_reference(golden_dir):
+    """clip(1.0) -> Adam(1e-4, (0.9, 0.99)) -> EMA(0.995, every 2, after 2) on a fixed batch: losses, gradient norms, parameter travel and
+    the averaged copy after 6 steps against the reference's Trainer arithmetic (EMA = ema_pytorch 0.2.3 restated: third party)."""
+    import copy
+    from v2a_hip.video_train import VideoTrainStep
+    g = np.load(f"{golden_dir}/video_train.npz", allow_pickle=True)
+    m, sd = _tiny()
+    d = _diffusion(m)
+    ema_model = copy.deepcopy(d).requires_grad_(False)
+    p0 = {n: p.detach().clone() for n, p in m.named_parameters()}
+    ts = VideoTrainStep(d, ema_model, lr=1e-4, betas=(0.9, 0.99), ema_beta=0.995, ema_update_every=2, ema_update_after_step=2)
+    img, cond, te = (torch.from_numpy(g[k]).cuda() for k in ("img", "cond", "te"))
+    losses, norms = [], []
+    for it in range(6):
+        loss = ts.step(img, cond, te, t=torch.from_numpy(g["train_t"][it]), noise=torch.from_numpy(g["train_noise"][it]), normalize=True)
+        losses.append(loss.item())
+        norms.append(ts.opt.peek()[0])
+    assert np.max(np.abs(np.array(losses) - g["train_losses"]) / g["train_losses"]) < 2e-4, (losses, g["train_losses"])
+    assert np.max(np.abs(np.array(norms) - g["train_gnorms"]) / g["train_gnorms"]) < 2e-3, (norms, g["train_gnorms"])
+    names = [str(n) for n in g["param_names"]]
+    P = dict(m.named_parameters())
+    E = dict(ema_model.model.named_parameters())
+    delta = np.array([float((P[n].detach().double() - p0[n].double()).norm()) for n in names])
+    assert np.max(np.abs(delta - g["train_param_delta"]) / (g["train_param_delta"] + 1e-3 * g["train_param_delta"].max())) < 2e-2
+    pn = np.array([float(P[n].double().norm()) for n in names])
+    en = np.array([float(E[n].double().norm()) for n in names])
+    assert np.max(np.abs(pn - g["train_param_norms"]) / (g["train_param_norms"] + 1e-6)) < 1e-5
+    assert np.max(np.abs(en - g["train_ema_norms"]) / (g["train_ema_norms"] + 1e-6)) < 1e-5
+    assert np.max(np.abs(en - pn)) > 0                                  # the averaged copy is not simply the online weights
+
+
+def test_trainer_surface_runs_and_checkpoints(tmp_path):
+    """flowdiffusion Trainer: constructor keywords, train(), save/load round trip, sample() from the averaged model."""
+    from flowdiffusion.flowdiffusion.goal_diffusion import Trainer
+    from diffuser.libero.lb_train_utils import HashTokenizer, HashTextEncoder
+    m, _ = _tiny()
+    d = _diffusion(m)
+    d.sampling_timesteps, d.is_ddim_sampling = 4, True
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, i):
+            g = torch.Generator().manual_seed(i)
+            return torch.rand(9, 32, 32, generator=g), torch.rand(3, 32, 32, generator=g), ("open the drawer", "pick up the mug")[i % 2]
+
+    tr = Trainer(d, HashTokenizer(), HashTextEncoder(), DS(), DS(), train_batch_size=2, valid_batch_size=2, gradient_accumulate_every=2,
+                 train_num_steps=4, save_and_sample_every=2, num_samples=2, results_folder=str(tmp_path), cond_drop_chance=0.5)
+    tr.train()
+    assert tr.step == 4 and (tmp_path / "model-2.pt").exists() and (tmp_path / "imgs" / "outputs" / "sample-2.npy").exists()
+    assert np.isfinite(float(tr.last_loss))
+    w = {n: p.detach().clone() for n, p in d.named_parameters()}
+    tr.train_num_steps = 5
+    tr.train()
+    tr.load(2)
+    assert tr.step == 4
+    for n, p in d.named_parameters():
+        assert torch.equal(p, w[n]), n
+    vid = tr.sample(torch.rand(2, 3, 32, 32), ["open-the-drawer", "pick up the mug"])
+    assert vid.shape == (2, 9, 32, 32) and float(vid.min()) >= 0 and float(vid.max()) <= 1

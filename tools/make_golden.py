@@ -80,6 +80,69 @@ def g_unet_tiny():
     print("unet_tiny ok", out["weights_abs_sum"])
 
 
+def g_video_train():
+    """GoalGaussianDiffusion.forward (training loss) + autograd gradients + 3 Trainer-style steps (clip 1.0 -> Adam -> EMA) of the tiny UNet."""
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    torch.manual_seed(0)
+    m = build_ref_unet(tiny=True).train()
+    sd = fill_module(m, seed=11)
+    sd0 = {n: p.detach().clone() for n, p in m.named_parameters()}
+    B, f, H, W = 2, 3, 32, 32
+    g = torch.Generator().manual_seed(300)
+    img = torch.rand(B, 3 * f, H, W, generator=g)
+    cond = torch.rand(B, 3, H, W, generator=g)
+    te = torch.randn(B, 5, 512, generator=g)
+    out = {"weights_abs_sum": wsum(sd), "img": img.numpy(), "cond": cond.numpy(), "te": te.numpy()}
+    names = [n for n, _ in m.named_parameters()]
+    out["param_names"] = np.array(names)
+    for tag, lt, obj in (("l2_v", "l2", "pred_v"), ("l1_noise", "l1", "pred_noise")):
+        d = GoalGaussianDiffusion(m, image_size=(H, W), channels=3 * f, timesteps=100, sampling_timesteps=100, loss_type=lt, objective=obj,
+                                  beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0)
+        m.zero_grad()
+        torch.manual_seed(77)
+        loss = d(img, cond, te)
+        loss.backward()
+        torch.manual_seed(77)                         # replay the draws: t = randint (:718), noise = randn_like (:692)
+        t = torch.randint(0, 100, (B,)).long()
+        noise = torch.randn(B, 3 * f, H, W)
+        P = dict(m.named_parameters())
+        gn, gs = [], []
+        for n in names:
+            gr = P[n].grad
+            gn.append(float(gr.double().norm()))
+            gs.append(gr.flatten()[sample_idx(gr.numel(), 8, 9)].numpy())
+        out.update({f"{tag}_loss": loss.item(), f"{tag}_t": t.numpy(), f"{tag}_noise": noise.numpy(), f"{tag}_grad_norms": np.array(gn),
+                    f"{tag}_grad_samples": np.stack(gs)})
+    # Trainer.train's arithmetic (:962-996) on a fixed batch, ema_pytorch restated (third party): update_every=2 here so that the
+    # copy / lerp branches are both visited in a few steps (update_after_step=2)
+    from ema_pytorch import EMA
+    d = GoalGaussianDiffusion(m, image_size=(H, W), channels=3 * f, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
+                              beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0)
+    opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.9, 0.99))
+    ema = EMA(d, beta=0.995, update_every=2, update_after_step=2)
+    m.zero_grad()
+    losses, norms, ts, nzs = [], [], [], []
+    for it in range(6):
+        torch.manual_seed(80 + it)
+        l = d(img, cond, te)
+        l.backward()
+        torch.manual_seed(80 + it)
+        ts.append(torch.randint(0, 100, (B,)).long().numpy())
+        nzs.append(torch.randn(B, 3 * f, H, W).numpy())
+        norms.append(float(torch.nn.utils.clip_grad_norm_(d.parameters(), 1.0)))
+        opt.step(); opt.zero_grad(); ema.update()
+        losses.append(l.item())
+    P = dict(m.named_parameters())
+    E = dict(ema.ema_model.model.named_parameters())
+    out.update(train_losses=np.array(losses), train_gnorms=np.array(norms), train_t=np.stack(ts), train_noise=np.stack(nzs),
+               train_param_norms=np.array([float(P[n].double().norm()) for n in names]),
+               train_ema_norms=np.array([float(E[n].double().norm()) for n in names]),
+               train_param_delta=np.array([float((P[n].detach().double() - sd0[n].double()).norm()) for n in names]),
+               thirdparty_note=np.array("Adam / clip_grad_norm_ from torch (present); EMA via restated ema_pytorch 0.2.3: parity unpinned"))
+    np.savez_compressed(f"{OUT}/video_train.npz", **out)
+    print("video_train ok", out["l2_v_loss"], out["l1_noise_loss"], losses, norms)
+
+
 def g_unet_full():
     torch.manual_seed(0)
     m = build_ref_unet(tiny=False).eval()
@@ -211,7 +274,7 @@ def g_schedule():
     print("schedule ok", {k: v.shape for k, v in out.items()})
 
 
-GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "schedule": g_schedule}
+GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "schedule": g_schedule, "video_train": g_video_train}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

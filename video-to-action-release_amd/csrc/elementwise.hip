@@ -86,6 +86,78 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float* pred, const 
     __syncthreads();
     if (threadIdx.x == 0) loss[0] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (double)n);
 }
+// ---- video-model training (GoalGaussianDiffusion.forward / p_losses, goal_diffusion.py:674-724) -------------------------------------
+// q_sample on the 'b (f c) h w' layout: out = sqrt_acp[t_b] * x0 + sqrt(1-acp)[t_b] * noise, x0 = 2 img - 1 when `normalize`
+__global__ void video_qsample_kernel(const float* __restrict__ img, const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                     const float* __restrict__ sa_tab, const float* __restrict__ s1_tab, float* __restrict__ out, int B,
+                                     size_t per, int normalize) {
+    const size_t total = (size_t)B * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const float x0 = normalize ? img[i] * 2.0f - 1.0f : img[i];
+        out[i] = sa_tab[t[b]] * x0 + s1_tab[t[b]] * noise[i];
+    }
+}
+// difference between the model output (channels-last [B,f,HW,ci]) and the objective's target built from img / noise ('b (f c) h w')
+__device__ __forceinline__ float video_loss_diff(const float* out_cl, const float* img, const float* noise, size_t base, int e, int HW, int ci,
+                                                 float sa, float s1, int objective, int normalize) {
+    const int c = e % ci;
+    const int hw = (e / ci) % HW;
+    const int fr = e / (ci * HW);
+    const size_t j = base + ((size_t)(fr * ci + c)) * HW + hw;
+    const float x0 = normalize ? img[j] * 2.0f - 1.0f : img[j];
+    const float nz = noise[j];
+    const float tgt = objective == 0 ? nz : (objective == 1 ? x0 : sa * nz - s1 * x0);
+    return out_cl[base + e] - tgt;
+}
+__global__ __launch_bounds__(256) void video_loss_partial_kernel(const float* __restrict__ out_cl, const float* __restrict__ img,
+                                                                 const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                                 const float* __restrict__ sa_tab, const float* __restrict__ s1_tab,
+                                                                 double* __restrict__ partial, int f, int HW, int ci, int objective, int l1,
+                                                                 int normalize) {
+    __shared__ double sm[4];
+    const int b = blockIdx.y;
+    const int per = f * HW * ci;
+    const float sa = sa_tab[t[b]], s1 = s1_tab[t[b]];
+    double acc = 0.0;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
+        const float d = video_loss_diff(out_cl, img, noise, (size_t)b * per, e, HW, ci, sa, s1, objective, normalize);
+        acc += l1 ? (double)fabsf(d) : (double)d * d;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+// loss = mean_b( loss_weight[t_b] * mean_e(l) )       (fixed summation order: deterministic)
+__global__ void video_loss_final_kernel(const double* __restrict__ partial, const int64_t* __restrict__ t, const float* __restrict__ w_tab,
+                                        float* __restrict__ loss, int B, int G, double per) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double tot = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double sb = 0.0;
+        for (int g = 0; g < G; ++g) sb += partial[(size_t)b * G + g];
+        tot += (double)((float)(sb / per) * w_tab[t[b]]);
+    }
+    loss[0] = (float)(tot / B);
+}
+// d loss / d out (channels-last), scaled by the upstream gradient `gscale` (a device scalar: no host synchronisation)
+__global__ void video_loss_bwd_kernel(const float* __restrict__ out_cl, const float* __restrict__ img, const float* __restrict__ noise,
+                                      const int64_t* __restrict__ t, const float* __restrict__ sa_tab, const float* __restrict__ s1_tab,
+                                      const float* __restrict__ w_tab, const float* __restrict__ gscale, float* __restrict__ dout, int B, int f,
+                                      int HW, int ci, int objective, int l1, int normalize) {
+    const int per = f * HW * ci;
+    const size_t total = (size_t)B * per;
+    const float g = gscale ? gscale[0] : 1.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const int e = (int)(i - (size_t)b * per);
+        const int64_t tb = t[b];
+        const float d = video_loss_diff(out_cl, img, noise, (size_t)b * per, e, HW, ci, sa_tab[tb], s1_tab[tb], objective, normalize);
+        const float k = g * w_tab[tb] / ((float)B * (float)per);
+        dout[i] = l1 ? k * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : k * 2.0f * d;
+    }
+}
 // DDPM / DDIM scheduler step on the action trajectory (third-party diffusers algorithm, restated: see oracle/schedulers.py)
 // coef = {sqrt_b_t, sqrt_a_t, c0, ct, sigma} (DDPM) or {sqrt_b_t, sqrt_a_t, sqrt_a_prev, dir, 0} (DDIM, mode 1)
 __global__ void policy_sched_step_kernel(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb,
@@ -381,6 +453,35 @@ int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* i
                            int frame_ch, hipStream_t s) {
     DenoiseCoef k = {sa, s1, ra, rm, c1, c2, sigma, gw};
     hipLaunchKernelGGL(video_denoise_kernel, GRID_FOR((size_t)B * f * frame_ch * HW), dim3(256), 0, s, v, v_uncond, img, noise, out, B, f, HW, k, mode, final, frame_ch);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_video_qsample(const float* img, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* out, int B,
+                      size_t per, int normalize, hipStream_t s) {
+    if (!img || !noise || !t || !sqrt_acp || !sqrt_1m_acp || !out || B <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(video_qsample_kernel, GRID_FOR((size_t)B * per), dim3(256), 0, s, img, noise, t, sqrt_acp, sqrt_1m_acp, out, B, per, normalize);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+size_t v2a_video_loss_workspace_bytes(int B) { return (size_t)B * 64 * sizeof(double); }
+int v2a_video_loss_fwd(const float* out_cl, const float* img, const float* noise, const int64_t* t, const float* sqrt_acp,
+                       const float* sqrt_1m_acp, const float* loss_weight, float* loss, int B, int f, int HW, int ci, int objective, int l1,
+                       int normalize, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!out_cl || !img || !noise || !t || !loss || !ws || B <= 0 || objective < 0 || objective > 2) return V2A_ERR_ARG;
+    if (ws_bytes < v2a_video_loss_workspace_bytes(B)) return V2A_ERR_ARG;
+    const int G = 64;
+    hipLaunchKernelGGL(video_loss_partial_kernel, dim3(G, B), dim3(256), 0, s, out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp, (double*)ws, f, HW,
+                       ci, objective, l1, normalize);
+    hipLaunchKernelGGL(video_loss_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, t, loss_weight, loss, B, G, (double)f * HW * ci);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_video_loss_bwd(const float* out_cl, const float* img, const float* noise, const int64_t* t, const float* sqrt_acp,
+                       const float* sqrt_1m_acp, const float* loss_weight, const float* gscale, float* dout, int B, int f, int HW, int ci,
+                       int objective, int l1, int normalize, hipStream_t s) {
+    if (!out_cl || !img || !noise || !t || !dout || B <= 0 || objective < 0 || objective > 2) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(video_loss_bwd_kernel, GRID_FOR((size_t)B * f * HW * ci), dim3(256), 0, s, out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp,
+                       loss_weight, gscale, dout, B, f, HW, ci, objective, l1, normalize);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

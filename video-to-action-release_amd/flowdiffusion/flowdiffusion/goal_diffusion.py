@@ -4,7 +4,8 @@ same constructor, 13 registered fp32 buffers (cosine schedule evaluated in fp64 
 `.sample(x_cond, task_embed, batch_size, return_all_timesteps=False) -> [B,C,H,W] in [0,1]`.
 The sampling loops (:571-650) run on the MI355X: per step one HIP UNet forward + ONE fused denoise kernel (v-pred -> x0 ->
 clamp -> posterior mean + sigma*noise, or the DDIM update), with the t-independent text branch evaluated once per call.
-Training the video model (forward / p_losses) is outside this hot path (the policy trainer keeps it frozen)."""
+Training (:674-724 and Trainer, :762-1080): `forward` / `p_losses` return an autograd scalar whose forward and backward are HIP kernels
+(v2a_hip.video_train); `Trainer` drives the fused step (arena gradients, one all-reduce, clip + Adam + EMA in one launch set)."""
 import math
 import torch
 import torch.nn as nn
@@ -212,6 +213,179 @@ class GoalGaussianDiffusion(nn.Module):
         image_size, channels = self.image_size, self.channels
         return self._sample_loop((batch_size, channels, image_size[0], image_size[1]), x_cond, task_embed, return_all_timesteps)
 
+    # ------------------------------------------------------------------ training (reference :674-724)
+    def predict_v(self, x_start, t, noise):
+        return extract(self.sqrt_alphas_cumprod, t, x_start.shape) * noise - extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * x_start
+
+    def _draw_t(self, b):
+        hook = self.__dict__.get("_t_hook")            # parity hook: callable(b) -> timesteps, called before the noise hook
+        if hook is not None:
+            return hook(b).to(self.betas.device).long()
+        return torch.randint(0, self.num_timesteps, (b,), device=self.betas.device).long()
+
+    def p_losses(self, x_start, t, x_cond, task_embed, noise=None):
+        """x_start in [-1,1] 'b (f c) h w' -> scalar loss attached to torch autograd; forward and backward run on HIP kernels
+        (v2a_hip.video_train: q_sample, UNet with tape, weighted loss; hand-written backward when `.backward()` is called)."""
+        from v2a_hip.video_train import diffusion_loss
+        return diffusion_loss(self, x_start, x_cond, task_embed, t, noise, normalize=False)
+
     def forward(self, img, img_cond, task_embed):
-        raise NotImplementedError("training the video diffusion model is outside the MI355X hot path of this build "
-                                  "(the policy trainer keeps it frozen: lb_online_trainer_v7.py:83; SURVEY.md 8f rank 4)")
+        from v2a_hip.video_train import diffusion_loss
+        b, c, h, w = img.shape
+        assert h == self.image_size[0] and w == self.image_size[1], f"height and width of image must be {self.image_size}, got({h}, {w})"
+        t = self._draw_t(b)
+        return diffusion_loss(self, img, img_cond, task_embed, t, None, normalize=self.auto_normalize)
+
+
+def num_to_groups(num, divisor):
+    groups, rest = divmod(num, divisor)
+    return [divisor] * groups + ([rest] if rest > 0 else [])
+
+
+class _EmaHandle:
+    """`trainer.ema`: `.ema_model` (the averaged GoalGaussianDiffusion) and ema_pytorch's state-dict layout over the fused optimiser's
+    counters (`online_model.*`, `ema_model.*`, `initted`, `step`)."""
+
+    def __init__(self, online, ema_model, opt):
+        self.online_model, self.ema_model, self._opt = online, ema_model, opt
+
+    def to(self, device):
+        return self
+
+    def state_dict(self):
+        _, ema_step, initted = self._opt.counters()
+        sd = {f"online_model.{k}": v for k, v in self.online_model.state_dict().items()}
+        sd.update({f"ema_model.{k}": v for k, v in self.ema_model.state_dict().items()})
+        sd["initted"] = torch.Tensor([bool(initted)])
+        sd["step"] = torch.tensor([ema_step])
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        self.ema_model.load_state_dict({k[len("ema_model."):]: v for k, v in sd.items() if k.startswith("ema_model.")}, strict=strict)
+        step, _, _ = self._opt.counters()
+        self._opt.set_counters(step, int(sd["step"].item()), bool(sd["initted"].item()))
+
+
+class Trainer(object):
+    """Video-model trainer with the reference's surface (goal_diffusion.py:762-1080): same constructor keywords, `.train()`, `.save()`,
+    `.load()`, `.sample()`, `.encode_batch_text()`, `.step`, `.ema.ema_model`.  One step = for each of `gradient_accumulate_every`
+    micro-batches: text encode -> condition drop-out -> loss + hand-written backward (v2a_hip.video_train.VideoTrainStep); then one RCCL
+    all-reduce of the gradient arena (world > 1) and the fused clip(1.0) / Adam / zero / EMA launch.  fp32 (`amp` / `fp16` are accepted
+    and ignored: the HIP path does not autocast).  Data-parallel: launch one process per GPU with torch.distributed initialised; every
+    rank draws its own shuffled batches (seeded per rank), the reference's `split_batches` bookkeeping is not reproduced.
+    Periodic sampling writes `imgs/outputs/sample-{milestone}.npy` instead of a PNG grid (torchvision-free)."""
+
+    def __init__(self, diffusion_model, tokenizer, text_encoder, train_set, valid_set, channels=3, *, train_batch_size=1,
+                 valid_batch_size=1, gradient_accumulate_every=1, augment_horizontal_flip=True, train_lr=1e-4, train_num_steps=100000,
+                 ema_update_every=10, ema_decay=0.995, adam_betas=(0.9, 0.99), save_and_sample_every=1000, num_samples=3,
+                 results_folder="./results", amp=True, fp16=True, split_batches=True, convert_image_to=None, cond_drop_chance=0.1,
+                 num_workers=0):
+        import copy
+        from pathlib import Path
+        from torch.utils.data import DataLoader, Subset
+        from v2a_hip.video_train import VideoTrainStep
+        self.cond_drop_chance = cond_drop_chance
+        self.tokenizer, self.text_encoder = tokenizer, text_encoder
+        self.model = diffusion_model
+        self.channels = channels
+        self.num_samples = num_samples
+        self.save_and_sample_every = save_and_sample_every
+        self.batch_size, self.valid_batch_size = train_batch_size, valid_batch_size
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.train_num_steps = train_num_steps
+        self.image_size = diffusion_model.image_size
+        dist = torch.distributed
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.is_main_process = self.rank == 0
+        self.device = diffusion_model.betas.device
+        self.ds = train_set
+        self.valid_ds = Subset(valid_set, list(range(len(valid_set)))[:num_samples])
+        gen = torch.Generator().manual_seed(1234 + self.rank)
+        self.dl = cycle(DataLoader(self.ds, batch_size=train_batch_size, shuffle=True, pin_memory=True, num_workers=num_workers, generator=gen))
+        self.valid_dl = DataLoader(self.valid_ds, batch_size=valid_batch_size, shuffle=False, pin_memory=True, num_workers=num_workers)
+        ema_model = copy.deepcopy(diffusion_model).requires_grad_(False)
+        self._step_fn = VideoTrainStep(diffusion_model, ema_model, lr=train_lr, betas=adam_betas, eps=1e-8, weight_decay=0.0, max_norm=1.0,
+                                       ema_beta=ema_decay, ema_update_every=ema_update_every)
+        self.opt = self._step_fn.opt
+        self.ema = _EmaHandle(diffusion_model, ema_model, self.opt)
+        if hasattr(self.text_encoder, "to"):
+            self.text_encoder.to(self.device)
+        self.results_folder = Path(results_folder)
+        self.results_folder.mkdir(exist_ok=True)
+        self.step = 0
+        self.last_loss = None
+
+    # ------------------------------------------------------------------ checkpoints (reference :872-905)
+    def _order(self):
+        return list(range(len(self._step_fn.arena.names)))
+
+    def save(self, milestone):
+        if not self.is_main_process:
+            return
+        data = {"step": self.step, "model": self.model.state_dict(), "opt": self.opt.state_dict(self._order()), "ema": self.ema.state_dict(),
+                "scaler": None, "version": "v2a-mi355x"}
+        torch.save(data, str(self.results_folder / f"model-{milestone}.pt"))
+
+    def load(self, milestone):
+        data = torch.load(str(self.results_folder / f"model-{milestone}.pt"), map_location=self.device)
+        self.model.load_state_dict(data["model"])
+        self.step = data["step"]
+        self.opt.load_state_dict(data["opt"], self._order())
+        self.ema.load_state_dict(data["ema"])
+        for m in (self.model.model, self.ema.ema_model.model):          # parameters changed behind the engines' packed operands
+            for key in ("_train_eng", "_eng"):
+                m.__dict__.pop(key, None)
+        if "version" in data:
+            print(f"loading from version {data['version']}")
+
+    # ------------------------------------------------------------------ text / sampling (reference :931-950)
+    def encode_batch_text(self, batch_text):
+        tok = self.tokenizer(batch_text, return_tensors="pt", padding=True, truncation=True, max_length=128).to(self.device)
+        return self.text_encoder(**tok).last_hidden_state
+
+    def sample(self, x_conds, tasks):
+        assert x_conds.shape[0] == len(tasks)
+        tasks = [s.replace("-", " ") for s in tasks]
+        emb = self.encode_batch_text(tasks).to(self.device)
+        return self.ema.ema_model.sample(batch_size=x_conds.shape[0], x_cond=x_conds.to(self.device), task_embed=emb)
+
+    # ------------------------------------------------------------------ the loop (reference :953-1080)
+    def train_step(self):
+        """One optimiser step; returns the summed micro-batch loss as a device scalar (no host synchronisation)."""
+        acc = self.gradient_accumulate_every
+        total = None
+        for k in range(acc):
+            x, x_cond, goal = next(self.dl)
+            with torch.no_grad():
+                emb = self.encode_batch_text(list(goal)).to(self.device).float()
+                keep = (torch.rand(emb.shape[0], 1, 1, device=emb.device) > self.cond_drop_chance).float()
+                emb = emb * keep
+            loss = self._step_fn.loss_and_grads(x, x_cond, emb, normalize=self.model.auto_normalize, accumulate=k > 0, scale=1.0 / acc)
+            total = loss / acc if total is None else total + loss / acc
+        self._step_fn.apply()
+        self.step += 1
+        self.last_loss = total
+        return total
+
+    def train(self):
+        import numpy as np
+        while self.step < self.train_num_steps:
+            total = self.train_step()
+            if self.is_main_process and self.step % 50 == 0:
+                print(f"step {self.step}: loss {float(total):.4E}", flush=True)
+            if self.is_main_process and self.step != 0 and self.step % self.save_and_sample_every == 0:
+                milestone = self.step // self.save_and_sample_every
+                self.ema.ema_model.eval()
+                outs = []
+                with torch.no_grad():
+                    for x, x_cond, label in self.valid_dl:
+                        emb = self.encode_batch_text(list(label))
+                        outs.append(self.ema.ema_model.sample(batch_size=x_cond.shape[0], x_cond=x_cond.to(self.device), task_embed=emb).cpu())
+                print_gpu_utilization()
+                out_dir = self.results_folder / "imgs" / "outputs"
+                out_dir.mkdir(parents=True, exist_ok=True)
+                np.save(str(out_dir / f"sample-{milestone}.npy"), torch.cat(outs, dim=0).numpy())
+                self.save(milestone)
+        if self.is_main_process:
+            print("training complete")

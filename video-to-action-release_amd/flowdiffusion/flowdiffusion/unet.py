@@ -1,6 +1,6 @@
 """Unet_Libero with the reference's surface (flowdiffusion/flowdiffusion/unet.py:195-222): no-arg constructor, `.unet`
 (UNetModel, 201,087,649 parameters), forward(x [B,24,H,W], t [B], task_embed [B,L,512]) -> [B,21,H,W].  Executed by
-v2a_hip.unet_engine on HIP kernels; inference only (the reference keeps this model frozen, lb_online_trainer_v7.py:83)."""
+v2a_hip.unet_engine on HIP kernels (sampling); training goes through GoalGaussianDiffusion.forward -> v2a_hip.video_train."""
 import torch
 import torch.nn as nn
 from .guided_diffusion.guided_diffusion.unet import UNetModel
@@ -31,7 +31,7 @@ class _HipUnetWrapper(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k == "_eng" else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_eng", "_train_eng") else copy.deepcopy(v, memo)
         return new
 
     frame_channels = 3          # channels of one generated frame in the packed input/output (2 for optical-flow models)

@@ -633,3 +633,39 @@ def video_denoise_step(v, v_uncond, img, noise, coef, mode, final, f, HW, ci=3):
     check(lib.v2a_video_denoise_step(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, *[float(c) for c in coef],
                                      mode, 1 if final else 0, ci, _stream()), "video_denoise_step")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- video-model training loss
+_OBJECTIVES = {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}
+
+
+def video_qsample(img, noise, t, sqrt_acp, sqrt_1m_acp, normalize):
+    """goal_diffusion.py:674-680 on 'b (f c) h w' tensors (+ forward's 2x-1, :722, when `normalize`)."""
+    _chk(img, "img"); _chk(noise, "noise")
+    out = torch.empty_like(img)
+    B = img.shape[0]
+    check(lib.v2a_video_qsample(img.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_acp.data_ptr(), sqrt_1m_acp.data_ptr(), out.data_ptr(), B,
+                                img.numel() // B, 1 if normalize else 0, _stream()), "video_qsample")
+    return out
+
+
+def video_loss_fwd(out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp, loss_weight, objective, loss_type, normalize):
+    """out_cl [B,f,H,W,ci] (model output, channels-last), img / noise [B,f*ci,H,W] -> scalar loss tensor (goal_diffusion.py:699-713)."""
+    B, f, H, W, ci = out_cl.shape
+    loss = torch.empty((), dtype=torch.float32, device=out_cl.device)
+    nb = lib.v2a_video_loss_workspace_bytes(B)
+    ws = torch.empty(nb, dtype=torch.uint8, device=out_cl.device)
+    check(lib.v2a_video_loss_fwd(out_cl.data_ptr(), img.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_acp.data_ptr(), sqrt_1m_acp.data_ptr(),
+                                 loss_weight.data_ptr(), loss.data_ptr(), B, f, H * W, ci, _OBJECTIVES[objective], 1 if loss_type == "l1" else 0,
+                                 1 if normalize else 0, ws.data_ptr(), nb, _stream()), "video_loss_fwd")
+    return loss
+
+
+def video_loss_bwd(out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp, loss_weight, objective, loss_type, normalize, gscale=None):
+    """d loss / d out_cl, times the device scalar `gscale` when given."""
+    B, f, H, W, ci = out_cl.shape
+    dout = torch.empty_like(out_cl)
+    check(lib.v2a_video_loss_bwd(out_cl.data_ptr(), img.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_acp.data_ptr(), sqrt_1m_acp.data_ptr(),
+                                 loss_weight.data_ptr(), _p(gscale), dout.data_ptr(), B, f, H * W, ci, _OBJECTIVES[objective],
+                                 1 if loss_type == "l1" else 0, 1 if normalize else 0, _stream()), "video_loss_bwd")
+    return dout
