@@ -151,11 +151,18 @@ def test_six_trainer_steps_vs_reference(golden_dir):
     P = dict(m.named_parameters())
     E = dict(ema_model.model.named_parameters())
     delta = np.array([float((P[n].detach().double() - p0[n].double()).norm()) for n in names])
-    assert np.max(np.abs(delta - g["train_param_delta"]) / (g["train_param_delta"] + 1e-3 * g["train_param_delta"].max())) < 2e-2
+    derr = np.abs(delta - g["train_param_delta"]) / (g["train_param_delta"] + 1e-3 * g["train_param_delta"].max())
+    # with 32 channels in 32 groups the first ResBlock's GroupNorm removes its per-channel embedding shift exactly: the true gradient of
+    # that emb_layers is zero, Adam normalises pure rounding noise (in the reference too) -> not comparable, skipped
+    noise_only = g["l2_v_grad_norms"] < 1e-5 * g["l2_v_grad_norms"].max()
+    assert 0 < noise_only.sum() <= 16                       # (conv biases feeding such a GroupNorm are in the same situation)
+    derr[noise_only] = 0.0
+    assert derr.max() < 2e-2, [(names[i], delta[i], g["train_param_delta"][i]) for i in np.argsort(-derr)[:4]]
     pn = np.array([float(P[n].double().norm()) for n in names])
     en = np.array([float(E[n].double().norm()) for n in names])
-    assert np.max(np.abs(pn - g["train_param_norms"]) / (g["train_param_norms"] + 1e-6)) < 1e-5
-    assert np.max(np.abs(en - g["train_ema_norms"]) / (g["train_ema_norms"] + 1e-6)) < 1e-5
+    ok = ~noise_only
+    assert np.max(np.abs(pn - g["train_param_norms"])[ok] / (g["train_param_norms"][ok] + 1e-6)) < 1e-5
+    assert np.max(np.abs(en - g["train_ema_norms"])[ok] / (g["train_ema_norms"][ok] + 1e-6)) < 1e-5
     assert np.max(np.abs(en - pn)) > 0                                  # the averaged copy is not simply the online weights
 
 
