@@ -44,6 +44,7 @@ enum { V2A_ACT_NONE = 0, V2A_ACT_SILU = 1, V2A_ACT_RELU = 2, V2A_ACT_MISH = 3, V
 int v2a_set_precision(int mode);
 int v2a_get_precision(void);
 int v2a_debug_force_tile(int bm, int bn);   /* tuning aid: force the forward tile (128x128 | 128x64 | 64x64), 0,0 = heuristic */
+int v2a_debug_force_wgrad_plan(int bm, int bn, int split);   /* tuning aid: force the weight-gradient tile / split; 0,0,0 = heuristic */
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K);
 int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                    const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH, int OW,
@@ -85,7 +86,8 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
 /* backward helpers of the video UNet: 2x2 sum pooling (gradient of the folded nearest upsample, unet.py:86-115) and per-sample column
  * sums (gradient of the embedding row vector broadcast over a sample's rows, unet.py:239-260) */
 int v2a_sumpool2x2(const float* du, float* dx, int N, int H, int W, int C, v2a_stream_t s);
-int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int accumulate, v2a_stream_t s);
+size_t v2a_colsum_batched_workspace_bytes(int B, int rows, int C);
+int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int accumulate, void* workspace, size_t workspace_bytes, v2a_stream_t s);
 int v2a_act_fwd(const float* x, float* y, size_t n, int act, v2a_stream_t s);                 /* nn.Mish / nn.SiLU / nn.GELU */
 int v2a_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, v2a_stream_t s);
 int v2a_axpy(const float* a, const float* b, float* out, float alpha, size_t n, v2a_stream_t s);   /* out = a + alpha b */

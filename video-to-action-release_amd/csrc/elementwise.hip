@@ -348,24 +348,44 @@ __global__ void sumpool2x2_kernel(const float* __restrict__ du, float* __restric
     }
 }
 
-// out[b][c] (+)= sum over the `rows` rows of sample b of x[b][r][c]   (gradient of a per-sample broadcast row vector)
-__global__ __launch_bounds__(256) void colsum_batched_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int C, int accumulate) {
+// out[b][c] (+)= sum over the `rows` rows of sample b of x[b][r][c]   (gradient of a per-sample broadcast row vector).
+// Two passes: grid (C/64, B, slabs) -> fp64 partials [B][slabs][C]; then one thread per (b, c) adds the slabs in order (deterministic).
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const float* __restrict__ x, double* __restrict__ partial, int rows, int C,
+                                                             int rows_per_slab) {
     const int b = blockIdx.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;                       // 4 row partitions per column block
     __shared__ double red[4][64];
     double acc = 0.0;                                        // signed terms that mostly cancel: accumulate in fp64
+    const int r0 = blockIdx.z * rows_per_slab;
+    const int r1 = min(rows, r0 + rows_per_slab);
     if (c < C) {
         const float* p = x + (size_t)b * rows * C + c;
-        for (int r = part; r < rows; r += 4) acc += (double)p[(size_t)r * C];
+        int r = r0 + part;
+        for (; r + 12 < r1; r += 16) {                       // 4 independent loads in flight
+            const float v0 = p[(size_t)r * C], v1 = p[(size_t)(r + 4) * C], v2 = p[(size_t)(r + 8) * C], v3 = p[(size_t)(r + 12) * C];
+            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; r < r1; r += 4) acc += (double)p[(size_t)r * C];
     }
     red[part][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (part == 0 && c < C) {
-        const float t = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-        float* dst = out + (size_t)b * C + c;
-        *dst = accumulate ? *dst + t : t;
-    }
+    if (part == 0 && c < C)
+        partial[((size_t)b * gridDim.z + blockIdx.z) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_batched_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, int slabs, int C, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    double t = 0.0;
+    for (int sl = 0; sl < slabs; ++sl) t += partial[((size_t)b * slabs + sl) * C + c];
+    out[i] = accumulate ? out[i] + (float)t : (float)t;
+}
+static int colsum_batched_slabs(int B, int rows, int C) {
+    const int cb = (C + 63) / 64;
+    int slabs = 2048 / (cb * B);                             // ~2048 workgroups in flight (8 per CU)
+    if (slabs > rows / 64) slabs = rows / 64;                // at least 64 rows per slab
+    return slabs < 1 ? 1 : slabs;
 }
 
 extern "C" {
@@ -511,9 +531,16 @@ int v2a_sumpool2x2(const float* du, float* dx, int N, int H, int W, int C, hipSt
     return V2A_OK;
 }
 
-int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int accumulate, hipStream_t s) {
-    if (!x || !out || B <= 0 || rows <= 0 || C <= 0) return V2A_ERR_ARG;
-    hipLaunchKernelGGL(colsum_batched_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, x, out, rows, C, accumulate);
+size_t v2a_colsum_batched_workspace_bytes(int B, int rows, int C) {
+    return (size_t)B * colsum_batched_slabs(B, rows, C) * C * sizeof(double);
+}
+int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!x || !out || !ws || B <= 0 || rows <= 0 || C <= 0) return V2A_ERR_ARG;
+    if (ws_bytes < v2a_colsum_batched_workspace_bytes(B, rows, C)) return V2A_ERR_ARG;
+    const int slabs = colsum_batched_slabs(B, rows, C);
+    const int rps = (rows + slabs - 1) / slabs;
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3((C + 63) / 64, B, slabs), dim3(256), 0, s, x, (double*)ws, rows, C, rps);
+    hipLaunchKernelGGL(colsum_batched_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, (const double*)ws, out, B, slabs, C, accumulate);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -1080,8 +1080,34 @@ static void conv_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int*
     *tiles = cdiv(M, *bm) * cdiv(Cout, *bn);
     *s = pick_split(*tiles, cdiv(K, 32), 4);      // split granularity in 32-deep k tiles (valid for both BKT)
 }
+static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
+static int g_wforce_bm = 0, g_wforce_bn = 0, g_wforce_s = 0;     // experiments only (v2a_debug_force_wgrad_plan)
 static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int* s) {
-    // largest tile that still yields >= 192 workgroups; split the reduction only when even 64x64 tiles cannot fill the chip
+    if (g_wforce_bm) {
+        *bm = g_wforce_bm; *bn = g_wforce_bn;
+        *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
+        int smax = cdiv(M, BK) / 2;
+        *s = g_wforce_s < 1 ? 1 : (g_wforce_s > smax ? (smax < 1 ? 1 : smax) : g_wforce_s);
+        return;
+    }
+    if (g_precision == 0) {
+        // fp32 (tools/wgrad_sweep.py over the policy-step and video-training shapes): what matters is ~1000 workgroups in flight, not a
+        // single round of 512 -- 128x128 tiles for big contractions (>= 30 GFLOP), 64x64 otherwise; the reduction over M is split
+        // to reach the target as long as every slice keeps >= 8 row tiles.  (The fp32 slabs cost <= 70 MB of traffic.)
+        const double flops = 2.0 * (double)M * (double)K * (double)Cout;
+        const int tiles128 = cdiv(Cout, 128) * cdiv(K, 128);
+        const bool big = Cout > 64 && K > 64 && flops >= 30e9 && tiles128 >= 8;
+        *bm = *bn = big ? 128 : 64;
+        *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
+        int sp = 1024 / *tiles;
+        const int cap = big ? 128 : 64, deep = cdiv(M, 32) / 8;
+        if (sp > cap) sp = cap;
+        if (sp > deep) sp = deep;
+        *s = sp < 1 ? 1 : sp;
+        return;
+    }
+    // bf16 mode keeps the plan its kernels were tuned with: largest tile that still yields >= 192 workgroups; split the reduction only
+    // when even 64x64 tiles cannot fill the chip
     *bm = Cout > 64 ? 128 : 64;
     *bn = (K > 64 && *bm == 128) ? 128 : 64;
     *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
@@ -1105,7 +1131,6 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
 }
 
 static int g_wgrad_dma = -1;  // fp32 weight gradients with 128-row output tiles on the LDS-DMA kernel (V2A_WGRAD_DMA=0 / v2a_debug_wgrad_dma)
-static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
 
 extern "C" {
 
@@ -1132,6 +1157,12 @@ int v2a_debug_force_tile(int bm, int bn) {
     return V2A_OK;
 }
 
+// tuning aid (tools/wgrad_sweep.py): force the weight-gradient tile and split; 0,0,0 restores the heuristic
+int v2a_debug_force_wgrad_plan(int bm, int bn, int split) {
+    if (!((bm == 0 && bn == 0) || (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))) return V2A_ERR_ARG;
+    g_wforce_bm = bm; g_wforce_bn = bn; g_wforce_s = split;
+    return V2A_OK;
+}
 // the tile / split plan the launchers will use (for benchmarks that label kernels: bench.py)
 int v2a_conv2d_plan(int M, int Cout, int K, int* bm, int* bn, int* split) {
     int tiles;

@@ -22,6 +22,7 @@ SIGNATURES = {
     "v2a_set_precision": (I, [I]),
     "v2a_get_precision": (I, []),
     "v2a_debug_force_tile": (I, [I, I]),
+    "v2a_debug_force_wgrad_plan": (I, [I, I, I]),
     "v2a_conv2d_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_fwd": (I, [P] * 8 + [I] * 19 + [P, SZ, P]),
     "v2a_conv2d_wgrad_workspace_bytes": (SZ, [I, I, I]),
@@ -64,7 +65,8 @@ SIGNATURES = {
     "v2a_bcast_rows": (I, [P, P, I, I, I, F, P]),
     "v2a_attention_bwd": (I, [P, P, P, P, I, I, I, I, P]),
     "v2a_sumpool2x2": (I, [P, P, I, I, I, I, P]),
-    "v2a_colsum_batched": (I, [P, P, I, I, I, I, P]),
+    "v2a_colsum_batched_workspace_bytes": (SZ, [I, I, I]),
+    "v2a_colsum_batched": (I, [P, P, I, I, I, I, P, SZ, P]),
     "v2a_perceiver_attention": (I, [P, P, P, P, P, I, I, I, I, I, F, P]),
     "v2a_layernorm": (I, [P, P, P, P, I, I, F, P]),
     "v2a_mean_rows": (I, [P, P, I, I, I, P]),

@@ -489,7 +489,10 @@ def colsum_batched(x3d, out=None, accumulate=False):
     B, rows, C = x3d.shape
     if out is None:
         out = torch.empty((B, C), dtype=torch.float32, device=x3d.device)
-    check(lib.v2a_colsum_batched(x3d.data_ptr(), out.data_ptr(), B, rows, C, 1 if accumulate else 0, _stream()), "colsum_batched")
+    nb = lib.v2a_colsum_batched_workspace_bytes(B, rows, C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x3d.device)
+    check(lib.v2a_colsum_batched(x3d.data_ptr(), out.data_ptr(), B, rows, C, 1 if accumulate else 0, ws.data_ptr(), nb, _stream()),
+          "colsum_batched")
     return out
 
 
