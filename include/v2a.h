@@ -117,6 +117,14 @@ int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f
 int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                            float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
                            int frame_ch, v2a_stream_t s);
+/* Transformer policy backbone (flowdiffusion/flowdiffusion/diffusion_policy_baseline/transformer_for_diffusion.py:75-110, the
+ * torch.nn.MultiheadAttention inside its encoder / decoder layers): softmax(q k^T / sqrt(D) + mask) v per (batch, head); mask = additive
+ * float [Tq][Tk] (-inf blocks) or NULL.  q / k / v are column blocks of packed projections: row r of batch b at ptr + (b*T + r)*ld + h*D.
+ * The backward writes dq / dk / dv with the same leading dimensions. */
+int v2a_mha_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, int B, int Tq, int Tk, int H, int D, int ldq,
+                int ldk, int ldv, v2a_stream_t s);
+int v2a_mha_bwd(const float* q, const float* k, const float* v, const float* mask, const float* dout, float* dq, float* dk, float* dv, int B,
+                int Tq, int Tk, int H, int D, int ldq, int ldk, int ldv, v2a_stream_t s);
 /* video-model training (GoalGaussianDiffusion.forward / p_losses, flowdiffusion/flowdiffusion/goal_diffusion.py:674-724):
  * q_sample (:674-680) with the [0,1] -> [-1,1] normalisation of forward (:722) folded in; per-sample mean of l2 / l1 (objective 0 =
  * pred_noise, 1 = pred_x0, 2 = pred_v, :699-707) times loss_weight[t] then the batch mean (:709-713); and its gradient with respect to

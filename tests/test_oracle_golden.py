@@ -96,6 +96,56 @@ def test_oracle_video_p_losses_vs_reference(golden_dir):
         assert np.max(np.abs(gn - g[f"{tag}_grad_norms"]) / (g[f"{tag}_grad_norms"] + 1e-6 * g[f"{tag}_grad_norms"].max())) < 2e-4, tag
 
 
+TRANSFORMER_CFGS = {
+    "dec_causal": dict(input_dim=7, output_dim=7, horizon=16, n_obs_steps=3, cond_dim=64, n_layer=2, n_head=4, n_emb=64, p_drop_emb=0.0,
+                       p_drop_attn=0.0, causal_attn=True, time_as_cond=True, obs_as_cond=True, n_cond_layers=2),
+    "dec_mlp": dict(input_dim=4, output_dim=4, horizon=10, n_obs_steps=2, cond_dim=32, n_layer=1, n_head=2, n_emb=96, p_drop_emb=0.0,
+                    p_drop_attn=0.0, causal_attn=False, time_as_cond=True, obs_as_cond=True, n_cond_layers=0),
+    "bert_causal": dict(input_dim=7, output_dim=7, horizon=12, n_layer=2, n_head=4, n_emb=64, p_drop_emb=0.0, p_drop_attn=0.0,
+                        causal_attn=True, time_as_cond=False),
+}
+
+
+@pytest.mark.parametrize("tag", list(TRANSFORMER_CFGS))
+def test_oracle_transformer_vs_reference(golden_dir, tag):
+    """Shell (names, buffers, optimiser groups) and oracle forward / autograd of TransformerForDiffusion vs the reference class."""
+    from flowdiffusion.flowdiffusion.diffusion_policy_baseline.transformer_for_diffusion import TransformerForDiffusion
+    from oracle import transformer as OT
+    from oracle.param_fill import fill_module
+    from tools_wsum import wsum
+    g = np.load(f"{golden_dir}/transformer.npz", allow_pickle=True)
+    cfg = TRANSFORMER_CFGS[tag]
+    torch.manual_seed(0)
+    m = TransformerForDiffusion(**cfg)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g[f"{tag}_names"]]
+    assert list(m.state_dict().keys()) == [str(n) for n in g[f"{tag}_state_keys"]]
+    for n, p in m.named_parameters():                       # initialisation rule: unit LayerNorm, zero biases, N(0, 0.02) matrices
+        if "norm" in n or n.startswith("ln_f"):
+            assert torch.equal(p, torch.ones_like(p) if n.endswith("weight") else torch.zeros_like(p)), n
+        elif p.dim() == 1:
+            assert float(p.abs().max()) == 0.0, n
+        elif p.dim() == 2:
+            assert 0.015 < float(p.detach().std()) < 0.025, n
+    groups = m.get_optim_groups(1e-3)
+    assert sum(len(gr["params"]) for gr in groups) == len(list(m.parameters())) and all(p.dim() == 2 for p in groups[0]["params"])
+    sd = fill_module(m, seed=21)
+    assert abs(wsum({k: v for k, v in sd.items() if "mask" not in k}) - float(g[f"{tag}_wsum"])) < 1e-9 * float(g[f"{tag}_wsum"])
+    P = {k: (v.clone().requires_grad_(True) if k in dict(m.named_parameters()) else v) for k, v in sd.items()}
+    x = torch.from_numpy(g[f"{tag}_x"]).requires_grad_(True)
+    cond = torch.from_numpy(g[f"{tag}_cond"]).requires_grad_(True) if f"{tag}_cond" in g else None
+    y = OT.forward(P, x, torch.from_numpy(g[f"{tag}_t"]), cond, cfg["n_head"], cfg["n_layer"], cfg.get("n_cond_layers", 0), m.encoder_only)
+    assert rel(y, g[f"{tag}_y"]) < 1e-5
+    (y * torch.from_numpy(g[f"{tag}_R"])).sum().backward()
+    assert rel(x.grad, g[f"{tag}_dx"]) < 1e-4
+    if cond is not None:
+        assert rel(cond.grad, g[f"{tag}_dcond"]) < 1e-4
+    names = [str(n) for n in g[f"{tag}_names"]]
+    gn = np.array([float(P[n].grad.double().norm()) for n in names])
+    assert np.max(np.abs(gn - g[f"{tag}_grad_norms"]) / (g[f"{tag}_grad_norms"] + 1e-6 * g[f"{tag}_grad_norms"].max())) < 1e-4
+    with pytest.raises(RuntimeError):                        # the product module has no CPU path
+        m.eval()(x.detach(), torch.from_numpy(g[f"{tag}_t"]), None if cond is None else cond.detach())
+
+
 def test_oracle_policy_vs_reference(golden_dir):
     from oracle import policy as OP
     from oracle.param_fill import fill_module

@@ -143,6 +143,47 @@ def g_video_train():
     print("video_train ok", out["l2_v_loss"], out["l1_noise_loss"], losses, norms)
 
 
+TRANSFORMER_CFGS = {
+    # the shape family of TransformerNet (diffusion_policy_baseline/unet.py:57-70), scaled down
+    "dec_causal": dict(input_dim=7, output_dim=7, horizon=16, n_obs_steps=3, cond_dim=64, n_layer=2, n_head=4, n_emb=64, p_drop_emb=0.0,
+                       p_drop_attn=0.0, causal_attn=True, time_as_cond=True, obs_as_cond=True, n_cond_layers=2),
+    "dec_mlp": dict(input_dim=4, output_dim=4, horizon=10, n_obs_steps=2, cond_dim=32, n_layer=1, n_head=2, n_emb=96, p_drop_emb=0.0,
+                    p_drop_attn=0.0, causal_attn=False, time_as_cond=True, obs_as_cond=True, n_cond_layers=0),
+    "bert_causal": dict(input_dim=7, output_dim=7, horizon=12, n_layer=2, n_head=4, n_emb=64, p_drop_emb=0.0, p_drop_attn=0.0,
+                        causal_attn=True, time_as_cond=False),
+}
+
+
+def g_transformer():
+    """TransformerForDiffusion forward + autograd gradients (loss = <out, R>) from the reference class, three structural variants."""
+    from flowdiffusion.flowdiffusion.diffusion_policy_baseline.transformer_for_diffusion import TransformerForDiffusion as Ref
+    assert "/root/reference" in sys.modules[Ref.__module__].__file__
+    out = {}
+    for tag, cfg in TRANSFORMER_CFGS.items():
+        torch.manual_seed(0)
+        m = Ref(**cfg).train()
+        sd = fill_module(m, seed=21)
+        g = torch.Generator().manual_seed(400)
+        B, T = 3, cfg["horizon"]
+        x = torch.randn(B, T, cfg["input_dim"], generator=g, requires_grad=True)
+        t = torch.tensor([3, 50, 99])
+        cond = torch.randn(B, cfg["n_obs_steps"], cfg["cond_dim"], generator=g, requires_grad=True) if cfg.get("cond_dim", 0) > 0 else None
+        R = torch.randn(B, T, cfg["output_dim"], generator=g)
+        y = m(x, t, cond)
+        (y * R).sum().backward()
+        names = [n for n, _ in m.named_parameters()]
+        P = dict(m.named_parameters())
+        out.update({f"{tag}_x": x.detach().numpy(), f"{tag}_t": t.numpy(), f"{tag}_R": R.numpy(), f"{tag}_y": y.detach().numpy(),
+                    f"{tag}_dx": x.grad.numpy(), f"{tag}_names": np.array(names), f"{tag}_wsum": wsum({k: v for k, v in sd.items() if "mask" not in k}),
+                    f"{tag}_grad_norms": np.array([float(P[n].grad.double().norm()) for n in names]),
+                    f"{tag}_grad_samples": np.stack([P[n].grad.flatten()[sample_idx(P[n].numel(), 6, 9)].numpy() for n in names]),
+                    f"{tag}_state_keys": np.array(list(m.state_dict().keys()))})
+        if cond is not None:
+            out.update({f"{tag}_cond": cond.detach().numpy(), f"{tag}_dcond": cond.grad.numpy()})
+        print(tag, "ok", float(y.abs().max()), len(names))
+    np.savez_compressed(f"{OUT}/transformer.npz", **out)
+
+
 def g_unet_full():
     torch.manual_seed(0)
     m = build_ref_unet(tiny=False).eval()
@@ -274,7 +315,7 @@ def g_schedule():
     print("schedule ok", {k: v.shape for k, v in out.items()})
 
 
-GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "schedule": g_schedule, "video_train": g_video_train}
+GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

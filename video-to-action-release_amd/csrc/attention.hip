@@ -618,6 +618,121 @@ __global__ void mean_rows_kernel(const float* x, float* out, int B, int R, int D
     out[i] = s / (float)R;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Multi-head attention of the Transformer policy backbone (torch.nn.MultiheadAttention inside nn.TransformerEncoder/DecoderLayer,
+// reference transformer_for_diffusion.py:75-110): softmax(q k^T / sqrt(D) + mask) v per (batch, head), additive float mask [Tq][Tk]
+// (-inf = blocked) or none.  q / k / v are column blocks of packed projection outputs: row r of batch b lives at
+// ptr + (b*T + r)*ld + head*D.  Sequences are short (horizon 10-16, 2-17 condition tokens): one workgroup per (b, head), K and V
+// resident in LDS, one thread per query row.  The backward recomputes the probabilities (nothing but q, k, v is kept from the forward).
+__global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                     const float* __restrict__ mask, float* __restrict__ out, int Tq, int Tk, int H, int D,
+                                                     int ldq, int ldk, int ldv, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_mha[];
+    float* Ks = sm_mha;                       // [Tk][D]
+    float* Vs = Ks + (size_t)Tk * D;          // [Tk][D]
+    float* Ps = Vs + (size_t)Tk * D;          // [blockDim][Tk] scores of the row each thread owns
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    for (int e = threadIdx.x; e < Tk * D; e += blockDim.x) {
+        const int r = e / D, c = e - r * D;
+        Ks[e] = k[((size_t)b * Tk + r) * ldk + h * D + c];
+        Vs[e] = v[((size_t)b * Tk + r) * ldv + h * D + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tq; i += blockDim.x) {
+        const float* qr = q + ((size_t)b * Tq + i) * ldq + h * D;
+        float* pr = Ps + (size_t)threadIdx.x * Tk;
+        float m = -INFINITY;
+        for (int j = 0; j < Tk; ++j) {
+            float d = 0.f;
+            for (int c = 0; c < D; ++c) d += qr[c] * Ks[j * D + c];
+            d = d * scale + (mask ? mask[i * Tk + j] : 0.f);
+            pr[j] = d;
+            m = fmaxf(m, d);
+        }
+        float l = 0.f;
+        for (int j = 0; j < Tk; ++j) { const float e = expf(pr[j] - m); pr[j] = e; l += e; }
+        const float il = 1.0f / l;
+        float* orow = out + ((size_t)b * Tq + i) * (size_t)(H * D) + h * D;
+        for (int c = 0; c < D; ++c) {
+            float a = 0.f;
+            for (int j = 0; j < Tk; ++j) a += pr[j] * Vs[j * D + c];
+            orow[c] = a * il;
+        }
+    }
+}
+
+// dq / dk / dv land in buffers with the same packed layout (ld*) as q / k / v.  Phase A (thread = query row): P, dS rows into LDS and
+// dq; phase B (thread = key row): dv_j = sum_i P_ij dO_i, dk_j = sum_i dS_ij q_i.  Fixed summation order: deterministic.
+__global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                     const float* __restrict__ mask, const float* __restrict__ dout, float* __restrict__ dq,
+                                                     float* __restrict__ dk, float* __restrict__ dv, int Tq, int Tk, int H, int D, int ldq,
+                                                     int ldk, int ldv, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_mha[];
+    float* Ks = sm_mha;                       // [Tk][D]
+    float* Vs = Ks + (size_t)Tk * D;          // [Tk][D]
+    float* Qs = Vs + (size_t)Tk * D;          // [Tq][D]
+    float* Gs = Qs + (size_t)Tq * D;          // [Tq][D]  dO
+    float* Ps = Gs + (size_t)Tq * D;          // [Tq][Tk] probabilities
+    float* Ss = Ps + (size_t)Tq * Tk;         // [Tq][Tk] dS (already times scale)
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = H * D;
+    for (int e = threadIdx.x; e < Tk * D; e += blockDim.x) {
+        const int r = e / D, c = e - r * D;
+        Ks[e] = k[((size_t)b * Tk + r) * ldk + h * D + c];
+        Vs[e] = v[((size_t)b * Tk + r) * ldv + h * D + c];
+    }
+    for (int e = threadIdx.x; e < Tq * D; e += blockDim.x) {
+        const int r = e / D, c = e - r * D;
+        Qs[e] = q[((size_t)b * Tq + r) * ldq + h * D + c];
+        Gs[e] = dout[((size_t)b * Tq + r) * E + h * D + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tq; i += blockDim.x) {
+        float* pr = Ps + (size_t)i * Tk;
+        float* sr = Ss + (size_t)i * Tk;
+        float m = -INFINITY;
+        for (int j = 0; j < Tk; ++j) {
+            float d = 0.f;
+            for (int c = 0; c < D; ++c) d += Qs[i * D + c] * Ks[j * D + c];
+            d = d * scale + (mask ? mask[i * Tk + j] : 0.f);
+            pr[j] = d;
+            m = fmaxf(m, d);
+        }
+        float l = 0.f;
+        for (int j = 0; j < Tk; ++j) { const float e = expf(pr[j] - m); pr[j] = e; l += e; }
+        const float il = 1.0f / l;
+        float Dd = 0.f;
+        for (int j = 0; j < Tk; ++j) {
+            float dp = 0.f;
+            for (int c = 0; c < D; ++c) dp += Gs[i * D + c] * Vs[j * D + c];
+            pr[j] *= il;
+            sr[j] = dp;
+            Dd += pr[j] * dp;
+        }
+        for (int j = 0; j < Tk; ++j) sr[j] = pr[j] * (sr[j] - Dd) * scale;
+        float* dst = dq + ((size_t)b * Tq + i) * ldq + h * D;
+        for (int c = 0; c < D; ++c) {
+            float a = 0.f;
+            for (int j = 0; j < Tk; ++j) a += sr[j] * Ks[j * D + c];
+            dst[c] = a;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Tk; j += blockDim.x) {
+        float* dkr = dk + ((size_t)b * Tk + j) * ldk + h * D;
+        float* dvr = dv + ((size_t)b * Tk + j) * ldv + h * D;
+        for (int c = 0; c < D; ++c) {
+            float a = 0.f, g = 0.f;
+            for (int i = 0; i < Tq; ++i) {
+                a += Ss[i * Tk + j] * Qs[i * D + c];
+                g += Ps[i * Tk + j] * Gs[i * D + c];
+            }
+            dkr[c] = a;
+            dvr[c] = g;
+        }
+    }
+}
+
 extern "C" {
 
 int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int heads, int head_ch, hipStream_t s) {
@@ -742,6 +857,28 @@ int v2a_bcast_rows(const float* dout, float* dx, int B, int R, int D, float scal
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(bcast_rows_kernel, dim3(g), dim3(256), 0, s, dout, dx, B, R, D, scale);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+int v2a_mha_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, int B, int Tq, int Tk, int H, int D, int ldq,
+                int ldk, int ldv, hipStream_t s) {
+    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || D <= 0) return V2A_ERR_ARG;
+    const size_t lds = ((size_t)2 * Tk * D + (size_t)64 * Tk) * sizeof(float);
+    if (lds > 160 * 1024) return V2A_ERR_ARG;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * H), dim3(64), lds, s, q, k, v, mask, out, Tq, Tk, H, D, ldq, ldk, ldv, 1.0f / sqrtf((float)D));
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_mha_bwd(const float* q, const float* k, const float* v, const float* mask, const float* dout, float* dq, float* dk, float* dv, int B,
+                int Tq, int Tk, int H, int D, int ldq, int ldk, int ldv, hipStream_t s) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || D <= 0) return V2A_ERR_ARG;
+    const size_t lds = ((size_t)2 * Tk * D + (size_t)2 * Tq * D + (size_t)2 * Tq * Tk) * sizeof(float);
+    if (lds > 160 * 1024) return V2A_ERR_ARG;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * H), dim3(64), lds, s, q, k, v, mask, dout, dq, dk, dv, Tq, Tk, H, D, ldq, ldk, ldv,
+                       1.0f / sqrtf((float)D));
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

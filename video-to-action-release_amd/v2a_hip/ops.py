@@ -672,3 +672,19 @@ def video_loss_bwd(out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp, loss_weight, ob
                                  loss_weight.data_ptr(), _p(gscale), dout.data_ptr(), B, f, H * W, ci, _OBJECTIVES[objective],
                                  1 if loss_type == "l1" else 0, 1 if normalize else 0, _stream()), "video_loss_bwd")
     return dout
+
+
+# ---------------------------------------------------------------------------------------------- Transformer policy backbone
+def mha_fwd(q, k, v, mask, B, Tq, Tk, H, D, qoff=0, koff=0, voff=0):
+    """q / k / v: 2-D packed projection outputs (rows = B*T); *off = first column of the block.  -> out [B*Tq, H*D]."""
+    out = torch.empty((B * Tq, H * D), dtype=torch.float32, device=q.device)
+    check(lib.v2a_mha_fwd(q.data_ptr() + 4 * qoff, k.data_ptr() + 4 * koff, v.data_ptr() + 4 * voff, _p(mask), out.data_ptr(), B, Tq, Tk, H, D,
+                          q.shape[1], k.shape[1], v.shape[1], _stream()), "mha_fwd")
+    return out
+
+
+def mha_bwd(q, k, v, mask, dout, dq, dk, dv, B, Tq, Tk, H, D, qoff=0, koff=0, voff=0):
+    """Gradients are written into dq / dk / dv at the same column offsets (same packed layouts as q / k / v)."""
+    check(lib.v2a_mha_bwd(q.data_ptr() + 4 * qoff, k.data_ptr() + 4 * koff, v.data_ptr() + 4 * voff, _p(mask), dout.data_ptr(),
+                          dq.data_ptr() + 4 * qoff, dk.data_ptr() + 4 * koff, dv.data_ptr() + 4 * voff, B, Tq, Tk, H, D, q.shape[1], k.shape[1],
+                          v.shape[1], _stream()), "mha_bwd")
