@@ -17,12 +17,15 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tokens", type=int, default=8)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="MFMA input precision (fp32 storage either way)")
     a = ap.parse_args()
     import copy
     from flowdiffusion.flowdiffusion.unet import Unet_Libero
     from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
     from v2a_hip.video_train import VideoTrainStep
     from v2a_hip import ops
+    import v2a_hip
+    v2a_hip.set_precision(a.precision)
     torch.manual_seed(0)
     m = Unet_Libero().to("cuda:0")
     d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
@@ -47,7 +50,7 @@ def main():
     torch.cuda.synchronize(); t1 = time.perf_counter()
     ts.apply()
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    print({"batch": B, "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss": float(loss), "fwd_bwd_ms": (t1 - t0) * 1e3,
+    print({"precision": a.precision, "batch": B, "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "loss": float(loss), "fwd_bwd_ms": (t1 - t0) * 1e3,
            "opt_ms": (t2 - t1) * 1e3, "peak_GB": torch.cuda.max_memory_allocated() / 2 ** 30})
 
 

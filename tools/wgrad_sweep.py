@@ -10,6 +10,8 @@ from v2a_hip import ops
 from v2a_hip._lib import lib
 
 dev = "cuda:0"
+if "--bf16" in sys.argv:          # bf16 MFMA weight-gradient kernels (fp32 operands in HBM, converted while staging)
+    lib.v2a_set_precision(1)
 # (N, H, W, Cin, kh, kw, Cout), stride 1, "same" padding
 SHAPES = [(14, 128, 128, 128, 3, 3, 128), (14, 64, 64, 256, 3, 3, 256), (14, 32, 32, 384, 3, 3, 384), (14, 16, 16, 512, 3, 3, 512),
           (14, 8, 8, 640, 3, 3, 640), (2, 7, 16384, 128, 3, 1, 128), (2, 7, 4096, 256, 3, 1, 256), (2, 7, 1024, 384, 3, 1, 384),

@@ -22,11 +22,31 @@ class UNetTrainEngine(UNetEngine):
     def __init__(self, cfg, params: dict, prefix="unet."):
         super().__init__(cfg, params, prefix)
         self._flip = {}             # name -> flipped (data-gradient) pack
+        self._twins = {}            # data_ptr -> (fp32 pack, bf16 twin): keeps both alive while registered
 
     # ------------------------------------------------------------------ operands
     def refresh_packs(self):
         self.packs._c.clear()
         self._flip.clear()
+        self._twins.clear()
+
+    def w(self, name, half=False):
+        """Packed forward operand; in the bf16 MFMA mode (v2a_hip.set_precision('bf16')) a bf16 twin is registered next to it so that
+        ops.conv2d runs the layer on the LDS-DMA bf16 kernel (fp32 tensors stay in HBM, activations are rounded by a cast launch)."""
+        pk = super().w(name, half)
+        if not half:
+            self._twin(pk)
+        return pk
+
+    def _twin(self, pk):
+        if ops.lib.v2a_get_precision() != 1 or pk.numel() < 4096:
+            return
+        key = pk.data_ptr()
+        ent = self._twins.get(key)
+        if ent is None or ent[0] is not pk:
+            wh = ops.cast_h(pk.detach().contiguous())
+            ops.register_h_twin(pk, wh)
+            self._twins[key] = (pk, wh)
 
     def wflip(self, name):
         """K-contiguous operand of the conv that computes the data gradient of `name` ([Cin][taps reversed][Cout])."""
@@ -42,6 +62,7 @@ class UNetTrainEngine(UNetEngine):
                 w4 = w
             pk = ops.pack_weight(w4.contiguous(), 1)
             self._flip[full] = pk
+        self._twin(pk)
         return pk
 
     # ------------------------------------------------------------------ Conv3d
