@@ -196,3 +196,36 @@ def test_trainer_surface_runs_and_checkpoints(tmp_path):
         assert torch.equal(p, w[n]), n
     vid = tr.sample(torch.rand(2, 3, 32, 32), ["open-the-drawer", "pick up the mug"])
     assert vid.shape == (2, 9, 32, 32) and float(vid.min()) >= 0 and float(vid.max()) <= 1
+
+
+def test_full_size_bf16_mfma_training_mode_tracks_fp32():
+    """Unet_Libero (201 M parameters), one loss + backward in the fp32 parity configuration and in the bf16-MFMA performance mode
+    (v2a_hip.set_precision('bf16'): bf16 twins of every packed operand, activations rounded in front of each conv, bf16 weight-gradient
+    kernels): same loss to 2e-3, gradients aligned (cosine > 0.995 on the large weights)."""
+    import v2a_hip
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    from v2a_hip.video_train import VideoTrainStep
+    torch.manual_seed(0)
+    m = Unet_Libero().to("cuda:0")
+    d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
+                              beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to("cuda:0")
+    ts = VideoTrainStep(d, None)
+    g = torch.Generator().manual_seed(5)
+    img, cond, te = torch.rand(1, 21, 128, 128, generator=g), torch.rand(1, 3, 128, 128, generator=g), torch.randn(1, 6, 512, generator=g)
+    t, noise = torch.tensor([37]), torch.randn(1, 21, 128, 128, generator=g)
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            v2a_hip.set_precision(mode)
+            m.__dict__.pop("_train_eng", None)
+            loss = ts.loss_and_grads(img, cond, te, t=t, noise=noise)
+            res[mode] = (loss.item(), ts.arena.flat.clone())
+    finally:
+        v2a_hip.set_precision("fp32")
+    l32, l16 = res["fp32"][0], res["bf16"][0]
+    assert abs(l16 - l32) <= 2e-3 * abs(l32), (l32, l16)
+    g32, g16 = res["fp32"][1].double(), res["bf16"][1].double()
+    cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
+    assert cos > 0.995, cos
+    assert abs(float(g16.norm() / g32.norm()) - 1.0) < 2e-2

@@ -30,6 +30,7 @@ struct GnDesc {
     float* dgamma_acc;      // small backward path: atomically accumulate dgamma / dbeta over n here (or null)
     float* dbeta_acc;
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
+    float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
     int film_ld;            // elements between the FiLM rows of consecutive samples (2*C when the [N][2][C] tensor is dense)
     float eps;
 };
@@ -136,11 +137,28 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
             p.rstd[n * p.G + g] = (float)(1.0 / sqrt(var + (double)p.eps));
         }
     } else {
-        for (int i = tid; i < 2 * cg; i += 256) {
-            const int which = i / cg, c = g * cg + i % cg;
+        // one wave per output (which, channel): lanes split the chunk partials, then a wave reduction; the group's two gamma-weighted
+        // sums (what gn_apply_bwd needs per element) are formed here once instead of per float4 there
+        __shared__ float cs_s[2][64];
+        const int lane = tid & 63, wid = tid >> 6;
+        for (int o = wid; o < 2 * cg; o += 4) {
+            const int which = o / cg, c = g * cg + o % cg;
             double s = 0.0;
-            for (int k = 0; k < p.nchunk; ++k) s += p.partial[((size_t)n * p.nchunk + k) * 2 * C + which * C + c];
-            p.colsum[(size_t)n * 2 * C + which * C + c] = (float)s;
+            for (int k = lane; k < p.nchunk; k += 64) s += p.partial[((size_t)n * p.nchunk + k) * 2 * C + which * C + c];
+            s = wave_sum_d(s);
+            if (lane == 0) {
+                p.colsum[(size_t)n * 2 * C + which * C + c] = (float)s;
+                if (cg <= 64) cs_s[which][o % cg] = (float)s;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 && p.gsum) {
+            float a = 0.f;
+            for (int j = 0; j < cg; ++j) {
+                const float v = cg <= 64 ? cs_s[tid][j] : p.colsum[(size_t)n * 2 * C + tid * C + g * cg + j];
+                a += p.gamma[g * cg + j] * v;
+            }
+            p.gsum[(size_t)(n * p.G + g) * 2 + tid] = a;
         }
     }
 }
@@ -192,7 +210,6 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int n = (int)(i / per_n);
         const int c4 = (int)(i % L4);
-        const float* cs = p.colsum + (size_t)n * 2 * C;
         f32x4 v = x4[i], d = d4[i];
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (r4) r = r4[i];
@@ -203,13 +220,12 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
         for (int j = 0; j < 4; ++j) {
             const int c = c4 * 4 + j;
             const int g = c / cg;
-            if (g != gprev) {            // (re)compute the group sums only when the float4 crosses into another group
+            if (g != gprev) {            // group constants change only when the float4 crosses into another group
                 gprev = g;
                 mu = p.mean[n * p.G + g];
                 rs = p.rstd[n * p.G + g];
-                A1 = 0.f;
-                A2 = 0.f;
-                for (int cc = g * cg; cc < (g + 1) * cg; ++cc) { A1 += p.gamma[cc] * cs[cc]; A2 += p.gamma[cc] * cs[C + cc]; }
+                A1 = p.gsum[(size_t)(n * p.G + g) * 2];
+                A2 = p.gsum[(size_t)(n * p.G + g) * 2 + 1];
             }
             const float xh = (v[j] - mu) * rs;
             const float z = xh * p.gamma[c] + p.beta[c] + r[j];
@@ -363,7 +379,7 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
     if ((long)S * (C / G) <= GN_SMALL_MAX) return 0;
     int nchunk, rows;
     gn_chunks(N, S, C, &nchunk, &rows);
-    return (size_t)N * nchunk * 2 * C * sizeof(double);
+    return (size_t)N * nchunk * 2 * C * sizeof(double) + (size_t)N * G * 2 * sizeof(float);     // chunk partials + per-group sums
 }
 
 // y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
@@ -429,8 +445,9 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
         if (film || dfilm) return V2A_ERR_ARG;   // FiLM only occurs on the small (Conv1d) path
         if (C % 4 != 0) return V2A_ERR_ARG;
         gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
-        if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
+        if ((size_t)N * p.nchunk * 2 * C * sizeof(double) + (size_t)N * G * 2 * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
         p.partial = (double*)workspace;
+        p.gsum = (float*)((char*)workspace + (size_t)N * p.nchunk * 2 * C * sizeof(double));
         hipLaunchKernelGGL(gn_colreduce<1>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
         V2A_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_finalize<1>, dim3(N * G), dim3(256), 0, stream, p);

@@ -21,49 +21,64 @@ from .unet_engine import UNetEngine
 class UNetTrainEngine(UNetEngine):
     def __init__(self, cfg, params: dict, prefix="unet."):
         super().__init__(cfg, params, prefix)
-        self._flip = {}             # name -> flipped (data-gradient) pack
-        self._twins = {}            # data_ptr -> (fp32 pack, bf16 twin): keeps both alive while registered
+        self._mp = None             # multi-pack table: forward / flipped operands (+ bf16 twins) of every weight, two launches per refresh
+        self._fw, self._fl = {}, {}
 
     # ------------------------------------------------------------------ operands
     def refresh_packs(self):
+        """Re-pack every conv / linear weight after the parameters changed: two multi-tensor launches write all forward packs
+        ([Cout][taps][Cin]) and all data-gradient packs ([Cin][taps reversed][Cout]) into persistent buffers -- and, in the bf16 MFMA
+        mode (v2a_hip.set_precision('bf16')), the bf16 twin of each, which ops.conv2d picks up to run the layer on the LDS-DMA bf16
+        kernel (fp32 tensors stay in HBM, activations are rounded by a cast launch)."""
+        from ._lib import lib, check
         self.packs._c.clear()
-        self._flip.clear()
-        self._twins.clear()
+        bf16 = lib.v2a_get_precision() == 1
+        ptrs = [p.data_ptr() for p in self.P.values()]
+        mp = self._mp
+        if mp is None or mp["bf16"] != bf16 or mp["ptrs"] != ptrs:
+            rows, ch0, ch1 = [], [], []
+            ce = lib.v2a_pack_chunk_elems()
+            self._fw, self._fl, keep = {}, {}, []
+            for full, p in self.P.items():
+                if p.dim() < 2 or not full.endswith(".weight") or "pos_emb" in full:
+                    continue
+                w = p.detach()
+                assert w.is_contiguous(), full
+                co, ci = w.shape[0], w.shape[1]
+                taps = w.numel() // (co * ci)
+                twin = bf16 and w.numel() >= 4096
+                fw = torch.empty(w.numel(), dtype=torch.float32, device=self.device) if taps > 1 else w
+                fl = torch.empty(w.numel(), dtype=torch.float32, device=self.device)
+                fwh = torch.empty(w.numel(), dtype=torch.bfloat16, device=self.device) if twin else None
+                flh = torch.empty(w.numel(), dtype=torch.bfloat16, device=self.device) if twin else None
+                if taps > 1 or twin:
+                    rows.append([w.data_ptr(), fw.data_ptr() if taps > 1 else 0, co, ci, taps, 0, fwh.data_ptr() if twin else 0])
+                    ch0 += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
+                rows.append([w.data_ptr(), fl.data_ptr(), co, ci, taps, 1, flh.data_ptr() if twin else 0])
+                ch1 += [[len(rows) - 1, t] for t in range(-(-co // 64) * -(-(ci * taps) // 64))]
+                if twin:
+                    ops.register_h_twin(fw, fwh)
+                    ops.register_h_twin(fl, flh)
+                self._fw[full], self._fl[full] = fw, fl
+                keep += [fwh, flh]
+            t = lambda a, dt: torch.tensor(a, dtype=dt).to(self.device)
+            mp = self._mp = dict(tab=t(rows, torch.int64), ch0=t(ch0, torch.int32), n0=len(ch0), ch1=t(ch1, torch.int32), n1=len(ch1),
+                                 ptrs=ptrs, bf16=bf16, keep=keep)
+        check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch0"].data_ptr(), mp["n0"], 0, ops._stream()), "pack_weights_multi")
+        check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"].data_ptr(), mp["n1"], 1, ops._stream()), "pack_weights_multi_t")
 
     def w(self, name, half=False):
-        """Packed forward operand; in the bf16 MFMA mode (v2a_hip.set_precision('bf16')) a bf16 twin is registered next to it so that
-        ops.conv2d runs the layer on the LDS-DMA bf16 kernel (fp32 tensors stay in HBM, activations are rounded by a cast launch)."""
-        pk = super().w(name, half)
-        if not half:
-            self._twin(pk)
-        return pk
-
-    def _twin(self, pk):
-        if ops.lib.v2a_get_precision() != 1 or pk.numel() < 4096:
-            return
-        key = pk.data_ptr()
-        ent = self._twins.get(key)
-        if ent is None or ent[0] is not pk:
-            wh = ops.cast_h(pk.detach().contiguous())
-            ops.register_h_twin(pk, wh)
-            self._twins[key] = (pk, wh)
+        if half:
+            return super().w(name, half)
+        if self._mp is None:
+            self.refresh_packs()
+        return self._fw[self.pre + name]
 
     def wflip(self, name):
         """K-contiguous operand of the conv that computes the data gradient of `name` ([Cin][taps reversed][Cout])."""
-        full = self.pre + name
-        pk = self._flip.get(full)
-        if pk is None:
-            w = self.P[full].detach().contiguous()
-            if w.dim() == 3:                                   # Conv1d over frames: taps = 3
-                w4 = w.view(w.shape[0], w.shape[1], w.shape[2], 1)
-            elif w.dim() == 2:
-                w4 = w.view(w.shape[0], w.shape[1], 1, 1)
-            else:
-                w4 = w
-            pk = ops.pack_weight(w4.contiguous(), 1)
-            self._flip[full] = pk
-        self._twin(pk)
-        return pk
+        if self._mp is None:
+            self.refresh_packs()
+        return self._fl[self.pre + name]
 
     # ------------------------------------------------------------------ Conv3d
     def conv3d_fwd(self, x, name, cout, stride=1, ups=False, rowvec=None, residual=None):
