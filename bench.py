@@ -313,6 +313,42 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video"):
                                                for k, v in sorted(agg.items())}}}
 
 
+def video_train_leg(torch, device, batch=2, steps=4, warmup=2):
+    """One optimisation step of the video model: q_sample -> Unet_Libero forward with tape -> loss -> hand-written
+    backward -> clip + Adam + EMA, fp32 parity configuration and the bf16-MFMA mode."""
+    import copy
+    import v2a_hip
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    from v2a_hip.video_train import VideoTrainStep
+    torch.manual_seed(0)
+    m = Unet_Libero().to(device)
+    d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
+                              beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to(device)
+    ts = VideoTrainStep(d, copy.deepcopy(d).requires_grad_(False))
+    img, cond = torch.rand(batch, 21, 128, 128, device=device), torch.rand(batch, 3, 128, 128, device=device)
+    te = torch.randn(batch, 8, 512, device=device)
+    res = {"workload": "Unet_Libero (201 M parameters) training step, 7 frames 128x128, loss_type l2 / pred_v / min-SNR", "batch": batch}
+    old = "bf16" if v2a_hip.get_precision() == "bf16" else "fp32"
+    try:
+        for mode in ("fp32", "bf16"):
+            v2a_hip.set_precision(mode)
+            m.__dict__.pop("_train_eng", None)
+            for _ in range(warmup):
+                loss = ts.step(img, cond, te)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = ts.step(img, cond, te)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            res[mode] = {"ms_per_step": dt * 1e3, "samples_per_sec": batch / dt, "loss": float(loss)}
+    finally:
+        v2a_hip.set_precision(old)
+    res["note"] = "fp32 = parity configuration; bf16 = bf16 MFMA inputs (twins of every packed operand), fp32 storage / accumulate / optimiser"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,6 +358,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-video", action="store_true", help="skip the video-sampler leg (BASELINE.json configs[2])")
+    ap.add_argument("--no-video-train", action="store_true", help="skip the video-model training-step leg")
     ap.add_argument("--no-predict", action="store_true", help="skip the predict_action latency leg")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented eager pass (profiling runs)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
@@ -481,6 +518,12 @@ def main():
                               "deviation from the fp32 parity path per UNet forward (tests/test_video_gpu.py)")
                 out["video_bf16"] = vb
                 v2a_hip.set_video_storage("f32")
+            if not args.no_video_train:
+                try:
+                    torch.cuda.empty_cache()
+                    out["video_train"] = video_train_leg(torch, device)
+                except Exception as e:
+                    out["video_train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
