@@ -382,9 +382,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     pg = None
-    if world > 1:
+    force_dp = os.environ.get("V2A_FORCE_DP") == "1"      # one rank through the N > 1 step structure + RCCL (validation on a 1-GPU box)
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
         pg = dist.group.WORLD
 
@@ -526,9 +528,17 @@ def main():
                     out["video_train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    sys.stdout.flush()
+    if world > 1 or force_dp:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        try:                                   # the result line is out: never let communicator teardown turn into a failure
+            torch.cuda.synchronize()
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:
+            print(f"[bench] process-group teardown: {type(e).__name__}: {e}", file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(0)                            # skip interpreter teardown (RCCL watchdog threads vs. graph / allocator destructors)
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@ gradients per step (issued as two asynchronous slice all-reduces: the Conditiona
 backward), averaged by folding 1/world into the optimiser's gradient scale.
 """
 import copy
+import os
 import numpy as np
 import torch
 from . import ops
@@ -36,7 +37,10 @@ class PolicyTrainer:
         self.eng = policy.engine
         self.device = self.eng.device
         self.world, self.rank, self.pg = world_size, rank, process_group
-        if world_size > 1:
+        # the data-parallel step structure (three graphs + two asynchronous slice all-reduces); V2A_FORCE_DP=1 selects it for a
+        # single rank too, so that the RCCL path can be exercised on a one-GPU box
+        self.dp = world_size > 1 or (process_group is not None and os.environ.get("V2A_FORCE_DP") == "1")
+        if self.dp:
             self.eng.defer_unet_wgrad = False      # the model.* gradient slice must be final after phase 1 (its all-reduce starts there)
         opt_params = dict(lr=1e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6) if opt_params is None else dict(opt_params)
         ema_params = dict(update_after_step=0, inv_gamma=1.0, power=0.75, min_value=0.0, update_every=1) if ema_params is None else dict(ema_params)
@@ -159,10 +163,10 @@ class PolicyTrainer:
         self._draw_indices()
         if not self.use_graph or self._warm < 2:
             self._fwd_bwd()
-            if self.world > 1:
+            if self.dp:
                 self._reduce_async(0)
             self._bwd_encoders()
-            if self.world > 1:
+            if self.dp:
                 self._reduce_async(1)
                 self._reduce_wait()
             self._opt()
@@ -171,7 +175,7 @@ class PolicyTrainer:
             if self._g_fb is None:
                 torch.cuda.synchronize()
                 self._g_fb = torch.cuda.CUDAGraph()
-                if self.world == 1:                       # one graph: gather -> fwd -> bwd -> optimiser -> re-pack
+                if not self.dp:                       # one graph: gather -> fwd -> bwd -> optimiser -> re-pack
                     with torch.cuda.graph(self._g_fb):
                         self._fwd_bwd()
                         self._bwd_encoders()
@@ -187,7 +191,7 @@ class PolicyTrainer:
                         self._opt()
                 # capture does not execute: run the step for real
             self._g_fb.replay()
-            if self.world > 1:
+            if self.dp:
                 self._reduce_async(0)
                 self._g_enc.replay()
                 self._reduce_async(1)
