@@ -241,3 +241,23 @@ def test_graphed_predict_action_matches_eager(golden_dir):
     assert rel(out["action"], g["ddim_action"]) <= TOL
     out2 = gp(obs)                                       # device Philox noise: different sample, finite, in range
     assert torch.isfinite(out2["action_pred"]).all() and float(out2["action_pred"].abs().max()) <= 1.0
+
+
+def test_dp_step_structure_on_rccl_single_rank():
+    """The N > 1 step (three hipGraphs, two asynchronous slice all-reduces through torch.distributed 'nccl' = RCCL, averaging in the
+    optimiser) driven by one rank (V2A_FORCE_DP=1): same loss trajectory as the single-graph step, clean exit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-video", "--no-predict",
+           "--no-roofline-pass", "--no-bf16-extra"]
+    losses = {}
+    for tag, extra in (("single", {}), ("dp", {"V2A_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        losses[tag] = json.loads(line)["final_loss"]
+    assert abs(losses["dp"] - losses["single"]) <= 1e-5 * abs(losses["single"]), losses
