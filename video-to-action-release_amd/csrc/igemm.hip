@@ -672,15 +672,18 @@ __device__ __attribute__((aligned(128))) float g_zero_line[64];
 typedef const __attribute__((address_space(1))) void* gptr_w_t;
 typedef __attribute__((address_space(3))) void* lptr_w_t;
 
-template <int BM, int BN>
+template <int BM, int BN, int NST = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
+    // NST LDS stages of one 32-row k tile each (counted vmcnt: the DMAs of a tile complete in issue order).  Measured
+    // (tools/wgrad_sweep.py, V2A_WGRAD_STAGES=4): four stages at two workgroups per CU are 5-15 % SLOWER than two stages at five
+    // workgroups per CU on every 64x64 shape -- residency, not pipeline depth, is what hides the DMA latency here.  Default NST = 2.
     constexpr int BKR = 32;                                     // reduction rows per tile
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int ACH = BM / 4, BCH = BN / 4;                   // 16-B pieces per tile row
     constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;         // tile rows covered by one pass of the 256 threads
     constexpr int AL = BKR / AROWS, BL = BKR / BROWS;           // DMA pieces per thread per tile
     constexpr int ABYTES = BKR * BM * 4, BBYTES = BKR * BN * 4, BUF = ABYTES + BBYTES;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * BUF];
+    __shared__ __attribute__((aligned(128))) unsigned char smem[NST * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.K + BN - 1) / BN;
     const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
@@ -751,12 +754,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
     const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
     float bsum = 0.f;                                           // thread tid < BM: column sum of dY over this block's rows
 
-    if (rt_begin < rt_end) issue(rt_begin, 0);
+    constexpr int PER_TILE = AL + BL;                           // DMA instructions per thread per tile
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j)
+        if (rt_begin + j < rt_end) issue(rt_begin + j, j);
     int buf = 0;
     for (int rt = rt_begin; rt < rt_end; ++rt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile rt has landed once at most `ahead` younger tiles are still outstanding (ahead shrinks at the tail of the reduction)
+        const int ahead = min(NST - 2, rt_end - 1 - rt);
+        if (NST == 2 || ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_TILE) : "memory");
         __syncthreads();
-        if (rt + 1 < rt_end) issue(rt + 1, buf ^ 1);
+        {   // the stage that held tile rt-1 is free (every wave passed the barrier after computing it): refill it with tile rt+NST-1
+            int nb = buf + NST - 1;
+            if (nb >= NST) nb -= NST;
+            if (rt + NST - 1 < rt_end) issue(rt + NST - 1, nb);
+        }
         const float* As = reinterpret_cast<const float*>(smem + buf * BUF);
         const float* Bs = As + BKR * BM;
 #pragma unroll
@@ -776,7 +791,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
 #pragma unroll 8
             for (int r = 0; r < BKR; ++r) bsum += As[r * BM + tid];
         }
-        buf ^= 1;
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1141,6 +1156,7 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
     *s = (*tiles >= 192) ? 1 : pick_split(*tiles, cdiv(M, BK), 4);
 }
 
+static int g_wgrad_stages64 = 2;  // LDS stages of the 64x64 DMA weight-gradient kernel (V2A_WGRAD_STAGES=4: the four-stage experiment)
 static int g_wgrad_dma = -1;  // fp32 weight gradients with 128-row output tiles on the LDS-DMA kernel (V2A_WGRAD_DMA=0 / v2a_debug_wgrad_dma)
 
 extern "C" {
@@ -1156,6 +1172,8 @@ static int wgrad_dma_on() {
     if (g_wgrad_dma < 0) {
         const char* e = getenv("V2A_WGRAD_DMA");
         g_wgrad_dma = (e && e[0] == '0') ? 0 : 1;
+        const char* st = getenv("V2A_WGRAD_STAGES");
+        if (st && st[0] == '4') g_wgrad_stages64 = 4;
     }
     return g_wgrad_dma;
 }
@@ -1324,7 +1342,8 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 128>), grid, block, 0, stream, p);
         else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 64>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64>), grid, block, 0, stream, p);
+        else if (g_wgrad_stages64 == 2) hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64, 2>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64, 4>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
             size_t total = (size_t)Cout * p.K;
