@@ -525,3 +525,27 @@ def test_conv2d_h2_multistage_kernel_matches_fp64_reference():
         assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
     rows = y.float().view(-1, 64, Co)
     assert torch.allclose(st[:, 0], rows.sum(1), rtol=1e-4, atol=2e-3) and torch.allclose(st[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(28, 128, 32, 32, 128), (56, 128, 16, 16, 256), (256, 128, 8, 8, 256), (14, 128, 32, 64, 128),
+                                            (27, 128, 33, 32, 128), (4, 64, 32, 32, 64)])
+def test_wgrad_halo_kernel_vs_torch(N, Cin, H, W, Cout):
+    """3x3 / stride 1 / pad 1 weight gradient on the halo-tile kernel (conv_wgrad_halo_f32: 32-pixel patches, input halo shared by the
+    nine taps in LDS) -- including image borders, several patches per row, a split reduction with a ragged last slice and the fused
+    bias gradient; (27,128,33,32,128) has an odd height (still eligible: TW = 32 needs nothing of OH); the last case is below the
+    size threshold (8 GFLOP, 4 channel blocks) and runs on the generic kernel."""
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(1000 + N + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    db = torch.empty(Cout, device=dev())
+    dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), tuple(w.shape), 3, 3, (1, 1), (1, 1), dbias=db)
+    close(dw, w.grad, tol=2e-5, what="halo wgrad")
+    close(db, b.grad, tol=2e-5, what="halo wgrad fused bias grad")
+    acc = torch.ones_like(dw)
+    ops.conv2d_wgrad(nhwc(x), nhwc(dy), tuple(w.shape), 3, 3, (1, 1), (1, 1), dw=acc, accumulate=True)
+    close(acc - 1.0, w.grad, tol=2e-5, what="halo wgrad accumulate")

@@ -816,6 +816,135 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
     }
 }
 
+// Weight gradient of 3x3 / stride 1 / pad 1 convs with a spatial halo tile in LDS (exact-f32 MFMA).
+// The generic kernels above re-fetch every input pixel once per filter tap and every dY row once per K tile: for a 64 -> 64 channel
+// layer that is 9 x (dY + X) through the L2 fabric, which -- not the matrix pipe -- bounds them (~3.4 TB/s, 55-70 TFLOP/s).  Here a
+// workgroup owns 64 output channels x (64 input channels x all 9 taps): per k tile of 32 output pixels (a TH x TW patch, TW = min(OW,
+// 32)) it DMAs the dY rows (8 KB) and the (TH+2) x (TW+2) input halo of its 64-channel slice (<= 28 KB) ONCE, and the nine taps read
+// shifted windows of that halo straight from LDS: 4.2x less DMA traffic per FLOP, 144 MFMAs per wave per tile.  Accumulators: 9 x 16
+// VGPRs per lane.  Grid: (Cout/64 * Cin/64, splits); split slabs / bias partials / reduce kernel shared with the kernels above.
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_halo_f32(const WgradDesc p) {
+    constexpr int TH = 32 / TW, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    constexpr int NB = (HP + 15) / 16;                          // halo DMA passes (16 pixels x 64 channels per pass of 256 threads)
+    constexpr int ABYTES = 32 * 64 * 4, BBYTES = NB * 16 * 64 * 4, BUF = ABYTES + BBYTES;
+    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Cin = p.C1;
+    const int cin_blocks = Cin >> 6;
+    const int m0 = (blockIdx.x / cin_blocks) * 64, c0 = (blockIdx.x % cin_blocks) * 64;
+    const int split = blockIdx.y;
+    const int nrt = p.M >> 5;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    const int tiles_x = p.OW / TW, tiles_img = (p.OH / TH) * tiles_x;
+    const float* zline = g_zero_line;
+    const int piece = tid & 15, prow = tid >> 4;                // 16-B piece within a 64-float row; row / pixel within a pass
+
+    auto issue = [&](int rt, int buf) {
+        unsigned char* abase = smem + buf * BUF;
+        unsigned char* bbase = abase + ABYTES;
+        const size_t r0 = (size_t)rt * 32;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* g = p.dy + (r0 + prow + j * 16) * p.Cout + m0 + piece * 4;
+            __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(abase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+        const int img = rt / tiles_img, t = rt - img * tiles_img;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int ih0 = ty * TH - 1, iw0 = tx * TW - 1;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int pix = q * 16 + prow;
+            const int hy = pix / HWD, hx = pix - hy * HWD;
+            const int ih = ih0 + hy, iw = iw0 + hx;
+            const bool ok = pix < HP && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const float* g = ok ? p.x + ((size_t)(img * p.H + ih) * p.W + iw) * Cin + c0 + piece * 4 : zline;
+            __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(bbase + (q * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+    const int lr = lane & 31, lk = lane >> 5;
+    const bool do_bias = (p.dbias != nullptr) && (c0 == 0);
+    float bsum = 0.f;
+
+    if (rt_begin < rt_end) issue(rt_begin, 0);
+    int buf = 0;
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rt + 1 < rt_end) issue(rt + 1, buf ^ 1);
+        const float* As = reinterpret_cast<const float*>(smem + buf * BUF);
+        const float* Hs = As + 32 * 64;
+#pragma unroll 4
+        for (int kk = 0; kk < 32; kk += 2) {
+            const int r = kk + lk;
+            const float a = As[r * 64 + wm + lr];
+            const float* hp = Hs + ((r / TW) * HWD + (r % TW)) * 64 + wn + lr;      // tap (0,0) of this output pixel
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float b = hp[(kh * HWD + kw) * 64];
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+        if (do_bias && tid < 64) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) bsum += As[r * 64 + tid];
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int k = t * Cin + c0 + wn + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[t][r];
+            else wgrad_store(p, co, k, acc[t][r]);
+        }
+    }
+    if (do_bias && tid < 64) {
+        const int co = m0 + tid;
+        if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = bsum;
+        else p.dbias[co] = p.accumulate ? p.dbias[co] + bsum : bsum;
+    }
+}
+static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
+static int g_wforce_bm = 0;   // experiments only (v2a_debug_force_wgrad_plan)
+// split of the halo kernel: ~512 workgroups (two resident per CU), at least 8 k tiles per slice
+static int wgrad_halo_split(int M, int Cout, int K) {
+    const int Cin = K / 9;
+    const int combos = (Cout / 64) * (Cin / 64);
+    int s = 512 / (combos < 1 ? 1 : combos);
+    const int deep = (M / 32) / 8;
+    if (s > deep) s = deep;
+    return s < 1 ? 1 : s;
+}
+static int g_wgrad_halo = -1;      // V2A_WGRAD_HALO=0 disables the halo kernel
+static bool wgrad_halo_on() {
+    if (g_wgrad_halo < 0) {
+        const char* e = getenv("V2A_WGRAD_HALO");
+        g_wgrad_halo = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_wgrad_halo == 1;
+}
+// geometry-free part of the eligibility test (what the workspace query can know)
+static bool wgrad_halo_shape_ok(int M, int Cout, int K) {
+    // small problems lose: every workgroup writes a 64 x 576 slab, and with few (Cout, Cin) blocks all parallelism has to come from
+    // the split (64 -> 64 channels at 32x32x128 images: 115 us against 88 us on the generic kernel); from ~8 GFLOP and >= 4 blocks up
+    // the halo kernel wins by 20-40 % (tools/wgrad_sweep.py)
+    if (!(g_precision == 0 && wgrad_halo_on() && !g_wforce_bm && K % 9 == 0 && (K / 9) % 64 == 0 && Cout % 64 == 0 && M % 32 == 0)) return false;
+    return (Cout / 64) * (K / 9 / 64) >= 4 && 2.0 * (double)M * (double)K * (double)Cout >= 8e9;
+}
+
 // bf16-MFMA weight gradient.  The MFMA wants 8 consecutive reduction rows per lane while HBM is contiguous along the OTHER axis
 // (channels), so each loader thread owns a 8(rows) x 4(channels) register block: 8 coalesced float4 loads, then four b128 LDS
 // stores of 8 bf16 along the reduction axis ([channel][32 rows + pad] tiles).  Threads [0,BM) stage dY^T, [BM,BM+BN) the im2col.
@@ -1095,8 +1224,7 @@ static void conv_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int*
     *tiles = cdiv(M, *bm) * cdiv(Cout, *bn);
     *s = pick_split(*tiles, cdiv(K, 32), 4);      // split granularity in 32-deep k tiles (valid for both BKT)
 }
-static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
-static int g_wforce_bm = 0, g_wforce_bn = 0, g_wforce_s = 0;     // experiments only (v2a_debug_force_wgrad_plan)
+static int g_wforce_bn = 0, g_wforce_s = 0;     // experiments only (v2a_debug_force_wgrad_plan)
 static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int* s) {
     if (g_wforce_bm) {
         *bm = g_wforce_bm; *bn = g_wforce_bn;
@@ -1288,6 +1416,10 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
 size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K) {
     int bm, bn, tiles, s;
     wgrad_plan(M, Cout, K, &bm, &bn, &tiles, &s);
+    if (wgrad_halo_shape_ok(M, Cout, K)) {          // the halo kernel may take this problem (geometry permitting): cover its split too
+        const int sh = wgrad_halo_split(M, Cout, K);
+        if (sh > s) s = sh;
+    }
     return s > 1 ? ((size_t)s * Cout * K + (size_t)s * Cout) * sizeof(float) : 0;
 }
 
@@ -1311,6 +1443,28 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     p.fd_oh = make_fastdiv((uint32_t)OH);
     const bool veca = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     const bool vecb = (Cin % 4 == 0) && (C1 % 4 == 0) && (((uintptr_t)x & 15) == 0) && (!x2 || ((uintptr_t)x2 & 15) == 0);
+    // 3x3 / stride 1 / pad 1 layers whose output rows tile into 32-pixel patches: the halo kernel
+    if (KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && p.idil == 1 && !x2 && C2 == 0 && OH == H && OW == W &&
+        veca && vecb && wgrad_halo_shape_ok(p.M, Cout, p.K) && (OW == 8 || OW == 16 || OW % 32 == 0) && OH % (OW >= 32 ? 1 : 32 / OW) == 0 &&
+        (double)N * H * W * C1 < 2147483648.0) {
+        const int hs = wgrad_halo_split(p.M, Cout, p.K);
+        if (hs > 1 && ((size_t)hs * Cout * p.K + (size_t)hs * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+        p.splits = hs;
+        p.rtiles_per_split = cdiv(p.M / 32, hs);
+        dim3 hgrid((Cout / 64) * (C1 / 64), hs);
+        if (OW == 8) hipLaunchKernelGGL((conv_wgrad_halo_f32<8>), hgrid, dim3(256), 0, stream, p);
+        else if (OW == 16) hipLaunchKernelGGL((conv_wgrad_halo_f32<16>), hgrid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_halo_f32<32>), hgrid, dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        if (hs > 1) {
+            size_t total = (size_t)Cout * p.K;
+            int g = (int)((total + 255) / 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            V2A_CHECK_LAUNCH();
+        }
+        return V2A_OK;
+    }
     int bm, bn, tiles, s;
     wgrad_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     const int nrt = cdiv(p.M, BK);
