@@ -122,9 +122,13 @@ int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* i
  * float [Tq][Tk] (-inf blocks) or NULL.  q / k / v are column blocks of packed projections: row r of batch b at ptr + (b*T + r)*ld + h*D.
  * The backward writes dq / dk / dv with the same leading dimensions. */
 int v2a_mha_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, int B, int Tq, int Tk, int H, int D, int ldq,
-                int ldk, int ldv, v2a_stream_t s);
+                int ldk, int ldv, float p_drop, uint64_t seed, uint64_t stream_id, v2a_stream_t s);
 int v2a_mha_bwd(const float* q, const float* k, const float* v, const float* mask, const float* dout, float* dq, float* dk, float* dv, int B,
-                int Tq, int Tk, int H, int D, int ldq, int ldk, int ldv, v2a_stream_t s);
+                int Tq, int Tk, int H, int D, int ldq, int ldk, int ldv, float p_drop, uint64_t seed, uint64_t stream_id, v2a_stream_t s);
+/* nn.Dropout of the same backbone (p_drop_emb / p_drop_attn, transformer_for_diffusion.py:61,80,98): y = x * keep / (1 - p) with a stateless
+ * mask -- element i of random stream `stream_id` under `seed` is kept iff hash(seed, stream_id, i) >= p; the same call on dy is the backward.
+ * The attention kernels above apply the same rule to the probabilities (element index ((b*H + h)*Tq + i)*Tk + j). */
+int v2a_dropout(const float* x, float* y, size_t n, float p, uint64_t seed, uint64_t stream_id, v2a_stream_t s);
 /* video-model training (GoalGaussianDiffusion.forward / p_losses, flowdiffusion/flowdiffusion/goal_diffusion.py:674-724):
  * q_sample (:674-680) with the [0,1] -> [-1,1] normalisation of forward (:722) folded in; per-sample mean of l2 / l1 (objective 0 =
  * pred_noise, 1 = pred_x0, 2 = pred_v, :699-707) times loss_weight[t] then the batch mean (:709-713); and its gradient with respect to

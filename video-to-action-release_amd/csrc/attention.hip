@@ -626,7 +626,8 @@ __global__ void mean_rows_kernel(const float* x, float* out, int B, int R, int D
 // resident in LDS, one thread per query row.  The backward recomputes the probabilities (nothing but q, k, v is kept from the forward).
 __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                      const float* __restrict__ mask, float* __restrict__ out, int Tq, int Tk, int H, int D,
-                                                     int ldq, int ldk, int ldv, float scale) {
+                                                     int ldq, int ldk, int ldv, float scale, float pdrop, unsigned long long seed,
+                                                     unsigned long long stream) {
     extern __shared__ __attribute__((aligned(16))) float sm_mha[];
     float* Ks = sm_mha;                       // [Tk][D]
     float* Vs = Ks + (size_t)Tk * D;          // [Tk][D]
@@ -652,6 +653,10 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q
         float l = 0.f;
         for (int j = 0; j < Tk; ++j) { const float e = expf(pr[j] - m); pr[j] = e; l += e; }
         const float il = 1.0f / l;
+        if (pdrop > 0.f) {                       // dropout on the normalised probabilities (element index: ((b*H + h)*Tq + i)*Tk + j)
+            const float ik = 1.0f / (1.0f - pdrop);
+            for (int j = 0; j < Tk; ++j) pr[j] *= dropout_scale(seed, stream, ((size_t)blockIdx.x * Tq + i) * Tk + j, pdrop, ik);
+        }
         float* orow = out + ((size_t)b * Tq + i) * (size_t)(H * D) + h * D;
         for (int c = 0; c < D; ++c) {
             float a = 0.f;
@@ -666,7 +671,8 @@ __global__ __launch_bounds__(64) void mha_fwd_kernel(const float* __restrict__ q
 __global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                      const float* __restrict__ mask, const float* __restrict__ dout, float* __restrict__ dq,
                                                      float* __restrict__ dk, float* __restrict__ dv, int Tq, int Tk, int H, int D, int ldq,
-                                                     int ldk, int ldv, float scale) {
+                                                     int ldk, int ldv, float scale, float pdrop, unsigned long long seed,
+                                                     unsigned long long stream) {
     extern __shared__ __attribute__((aligned(16))) float sm_mha[];
     float* Ks = sm_mha;                       // [Tk][D]
     float* Vs = Ks + (size_t)Tk * D;          // [Tk][D]
@@ -702,14 +708,20 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ q
         for (int j = 0; j < Tk; ++j) { const float e = expf(pr[j] - m); pr[j] = e; l += e; }
         const float il = 1.0f / l;
         float Dd = 0.f;
+        const float ik = pdrop > 0.f ? 1.0f / (1.0f - pdrop) : 1.0f;
         for (int j = 0; j < Tk; ++j) {
             float dp = 0.f;
             for (int c = 0; c < D; ++c) dp += Gs[i * D + c] * Vs[j * D + c];
+            const float keep = pdrop > 0.f ? dropout_scale(seed, stream, ((size_t)blockIdx.x * Tq + i) * Tk + j, pdrop, ik) : 1.0f;
             pr[j] *= il;
+            dp *= keep;                          // gradient w.r.t. the probability before dropout
             sr[j] = dp;
             Dd += pr[j] * dp;
         }
-        for (int j = 0; j < Tk; ++j) sr[j] = pr[j] * (sr[j] - Dd) * scale;
+        for (int j = 0; j < Tk; ++j) {
+            sr[j] = pr[j] * (sr[j] - Dd) * scale;
+            if (pdrop > 0.f) pr[j] *= dropout_scale(seed, stream, ((size_t)blockIdx.x * Tq + i) * Tk + j, pdrop, ik);   // P' for dV
+        }
         float* dst = dq + ((size_t)b * Tq + i) * ldq + h * D;
         for (int c = 0; c < D; ++c) {
             float a = 0.f;
@@ -862,23 +874,25 @@ int v2a_bcast_rows(const float* dout, float* dx, int B, int R, int D, float scal
 }
 
 int v2a_mha_fwd(const float* q, const float* k, const float* v, const float* mask, float* out, int B, int Tq, int Tk, int H, int D, int ldq,
-                int ldk, int ldv, hipStream_t s) {
-    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || D <= 0) return V2A_ERR_ARG;
+                int ldk, int ldv, float p_drop, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+    if (!q || !k || !v || !out || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || D <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) return V2A_ERR_ARG;
     const size_t lds = ((size_t)2 * Tk * D + (size_t)64 * Tk) * sizeof(float);
     if (lds > 160 * 1024) return V2A_ERR_ARG;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * H), dim3(64), lds, s, q, k, v, mask, out, Tq, Tk, H, D, ldq, ldk, ldv, 1.0f / sqrtf((float)D));
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * H), dim3(64), lds, s, q, k, v, mask, out, Tq, Tk, H, D, ldq, ldk, ldv, 1.0f / sqrtf((float)D),
+                       p_drop, (unsigned long long)seed, (unsigned long long)stream_id);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 int v2a_mha_bwd(const float* q, const float* k, const float* v, const float* mask, const float* dout, float* dq, float* dk, float* dv, int B,
-                int Tq, int Tk, int H, int D, int ldq, int ldk, int ldv, hipStream_t s) {
-    if (!q || !k || !v || !dout || !dq || !dk || !dv || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || D <= 0) return V2A_ERR_ARG;
+                int Tq, int Tk, int H, int D, int ldq, int ldk, int ldv, float p_drop, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || B <= 0 || Tq <= 0 || Tk <= 0 || H <= 0 || D <= 0 || !(p_drop >= 0.f && p_drop < 1.f))
+        return V2A_ERR_ARG;
     const size_t lds = ((size_t)2 * Tk * D + (size_t)2 * Tq * D + (size_t)2 * Tq * Tk) * sizeof(float);
     if (lds > 160 * 1024) return V2A_ERR_ARG;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * H), dim3(64), lds, s, q, k, v, mask, dout, dq, dk, dv, Tq, Tk, H, D, ldq, ldk, ldv,
-                       1.0f / sqrtf((float)D));
+                       1.0f / sqrtf((float)D), p_drop, (unsigned long long)seed, (unsigned long long)stream_id);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -73,3 +73,15 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Stateless dropout: element `idx` of random stream `stream` under `seed` is kept with probability 1 - p.  A splitmix64 finaliser of
+// (seed, stream, idx); forward and backward recompute the same decision, nothing is stored.  Returns the multiplier 0 or 1/(1-p).
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long stream, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = seed ^ (stream * 0x9E3779B97F4A7C15ull) ^ (idx + 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);          // 24 uniform bits in [0, 1)
+    return u < p ? 0.0f : inv_keep;
+}
+

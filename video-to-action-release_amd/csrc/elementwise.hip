@@ -158,6 +158,12 @@ __global__ void video_loss_bwd_kernel(const float* __restrict__ out_cl, const fl
         dout[i] = l1 ? k * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : k * 2.0f * d;
     }
 }
+// y = x * keep/(1-p) with the stateless mask of common.h (the same call on dy is the backward)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p, float inv_keep, unsigned long long seed,
+                               unsigned long long stream) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * dropout_scale(seed, stream, i, p, inv_keep);
+}
 // DDPM / DDIM scheduler step on the action trajectory (third-party diffusers algorithm, restated: see oracle/schedulers.py)
 // coef = {sqrt_b_t, sqrt_a_t, c0, ct, sigma} (DDPM) or {sqrt_b_t, sqrt_a_t, sqrt_a_prev, dir, 0} (DDIM, mode 1)
 __global__ void policy_sched_step_kernel(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb,
@@ -502,6 +508,13 @@ int v2a_video_loss_bwd(const float* out_cl, const float* img, const float* noise
     if (!out_cl || !img || !noise || !t || !dout || B <= 0 || objective < 0 || objective > 2) return V2A_ERR_ARG;
     hipLaunchKernelGGL(video_loss_bwd_kernel, GRID_FOR((size_t)B * f * HW * ci), dim3(256), 0, s, out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp,
                        loss_weight, gscale, dout, B, f, HW, ci, objective, l1, normalize);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_dropout(const float* x, float* y, size_t n, float p, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+    if (!x || !y || !(p >= 0.f && p < 1.f)) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(dropout_kernel, GRID_FOR(n), dim3(256), 0, s, x, y, n, p, 1.0f / (1.0f - p), (unsigned long long)seed,
+                       (unsigned long long)stream_id);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

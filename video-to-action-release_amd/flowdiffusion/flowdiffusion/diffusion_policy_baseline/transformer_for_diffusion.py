@@ -2,7 +2,9 @@
 constructor keywords, parameter / buffer names (so its checkpoints load with strict=True), `forward(sample, timestep, cond)`,
 `get_optim_groups`, `configure_optimizers`.  The torch.nn Transformer layers below are *parameter containers only*: forward and
 backward run on HIP kernels (v2a_hip.transformer_engine) behind one autograd Function, so `loss.backward()` fills `.grad` as usual.
-HIP device only (no CPU fallback).  Dropout: the kernels implement p = 0 / eval mode; a training-mode call with p > 0 raises."""
+HIP device only (no CPU fallback).  Dropout (training mode): the same sites and rates as the torch layers (embeddings p_drop_emb;
+attention probabilities, attention / feed-forward outputs and the feed-forward activation p_drop_attn), masks from a stateless
+counter-based hash (`.dropout_seed`, default torch.initial_seed()) instead of torch's generator stream."""
 from typing import Optional, Tuple, Union
 import torch
 import torch.nn as nn
@@ -18,7 +20,12 @@ class _Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, sample, t, cond, *params):
         eng = module._engine()
-        out, tape = eng.forward(sample, t, cond)
+        drop = None
+        if module.training and max(module._p_emb, module._p_attn) > 0:
+            if module.dropout_seed is None:
+                module.dropout_seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+            drop = (module._p_emb, module._p_attn, module.dropout_seed)
+        out, tape = eng.forward(sample, t, cond, drop)
         ctx.pack = (module, eng, tape, cond is not None)
         return out
 
@@ -78,7 +85,8 @@ class TransformerForDiffusion(nn.Module):
         self.T, self.T_cond, self.horizon = T, T_cond, horizon
         self.time_as_cond, self.obs_as_cond = time_as_cond, obs_as_cond
         self._cfg = dict(n_emb=n_emb, n_head=n_head, n_layer=n_layer, n_cond_layers=n_cond_layers, encoder_only=self.encoder_only)
-        self._p_drop = max(p_drop_emb, p_drop_attn)
+        self._p_emb, self._p_attn = float(p_drop_emb), float(p_drop_attn)
+        self.dropout_seed = None
         self._init_all()
 
     def _init_all(self):
@@ -137,8 +145,6 @@ class TransformerForDiffusion(nn.Module):
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], cond: Optional[torch.Tensor] = None, **kwargs):
         """sample (B,T,input_dim), timestep (B,) or scalar, cond (B,T',cond_dim) -> (B,T,output_dim)."""
-        if self.training and self._p_drop > 0:
-            raise NotImplementedError("dropout is not implemented on the HIP path: construct with p_drop_emb = p_drop_attn = 0 or call .eval()")
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.long, device=sample.device)

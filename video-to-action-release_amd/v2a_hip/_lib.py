@@ -51,8 +51,9 @@ SIGNATURES = {
     "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),
     "v2a_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
     "v2a_video_pack": (I, [P, P, P, I, I, I, SZ, SZ, I, P]),
-    "v2a_mha_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
-    "v2a_mha_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "v2a_mha_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, U64, U64, P]),
+    "v2a_mha_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, U64, U64, P]),
+    "v2a_dropout": (I, [P, P, SZ, F, U64, U64, P]),
     "v2a_video_qsample": (I, [P, P, P, P, P, P, I, SZ, I, P]),
     "v2a_video_loss_workspace_bytes": (SZ, [I]),
     "v2a_video_loss_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, SZ, P]),

@@ -675,16 +675,25 @@ def video_loss_bwd(out_cl, img, noise, t, sqrt_acp, sqrt_1m_acp, loss_weight, ob
 
 
 # ---------------------------------------------------------------------------------------------- Transformer policy backbone
-def mha_fwd(q, k, v, mask, B, Tq, Tk, H, D, qoff=0, koff=0, voff=0):
-    """q / k / v: 2-D packed projection outputs (rows = B*T); *off = first column of the block.  -> out [B*Tq, H*D]."""
+def mha_fwd(q, k, v, mask, B, Tq, Tk, H, D, qoff=0, koff=0, voff=0, p_drop=0.0, seed=0, stream_id=0):
+    """q / k / v: 2-D packed projection outputs (rows = B*T); *off = first column of the block.  -> out [B*Tq, H*D].
+    p_drop > 0: dropout on the attention probabilities with the stateless mask (seed, stream_id) -- pass the same triple to mha_bwd."""
     out = torch.empty((B * Tq, H * D), dtype=torch.float32, device=q.device)
     check(lib.v2a_mha_fwd(q.data_ptr() + 4 * qoff, k.data_ptr() + 4 * koff, v.data_ptr() + 4 * voff, _p(mask), out.data_ptr(), B, Tq, Tk, H, D,
-                          q.shape[1], k.shape[1], v.shape[1], _stream()), "mha_fwd")
+                          q.shape[1], k.shape[1], v.shape[1], float(p_drop), int(seed), int(stream_id), _stream()), "mha_fwd")
     return out
 
 
-def mha_bwd(q, k, v, mask, dout, dq, dk, dv, B, Tq, Tk, H, D, qoff=0, koff=0, voff=0):
+def mha_bwd(q, k, v, mask, dout, dq, dk, dv, B, Tq, Tk, H, D, qoff=0, koff=0, voff=0, p_drop=0.0, seed=0, stream_id=0):
     """Gradients are written into dq / dk / dv at the same column offsets (same packed layouts as q / k / v)."""
     check(lib.v2a_mha_bwd(q.data_ptr() + 4 * qoff, k.data_ptr() + 4 * koff, v.data_ptr() + 4 * voff, _p(mask), dout.data_ptr(),
                           dq.data_ptr() + 4 * qoff, dk.data_ptr() + 4 * koff, dv.data_ptr() + 4 * voff, B, Tq, Tk, H, D, q.shape[1], k.shape[1],
-                          v.shape[1], _stream()), "mha_bwd")
+                          v.shape[1], float(p_drop), int(seed), int(stream_id), _stream()), "mha_bwd")
+
+
+def dropout(x, p, seed, stream_id):
+    """y = x * keep / (1 - p), keep decided per element by hash(seed, stream_id, index): the same call on dy is the backward."""
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    check(lib.v2a_dropout(x.data_ptr(), y.data_ptr(), x.numel(), float(p), int(seed), int(stream_id), _stream()), "dropout")
+    return y
