@@ -475,6 +475,7 @@ __global__ void conv_splitk_reduce(const ConvDesc p) {
 struct WgradDesc {
     const float* x; const float* x2;   // conv input (two sources as in ConvDesc)
     const float* dy;                   // [M][Cout]
+    const uint16_t* xh; const uint16_t* dyh;   // bf16 twins of x / dy (conv_wgrad_bf16h) or null
     float* dw;                         // torch layout [Cout][Cin][KH][KW]  (or [Cin][Cout][KH][KW]-free: see transposed)
     float* partial;                    // [splits][Cout][K'] followed by [splits][Cout] bias partials
     float* dbias;                      // optional: [Cout] = sum_r dY[r][co] (fused bias gradient) or null
@@ -1101,6 +1102,170 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
     }
 }
 
+// bf16-MFMA weight gradient fed from bf16 TWINS of the operands (x_h / dy_h: the rounded copies the bf16 forward / data-gradient convs
+// already made), instead of converting fp32 while staging: the kernel above is bound by operand traffic through the L2 fabric (32 KB
+// per workgroup per 256 MFMA cycles), so half the bytes is the lever.  Loader thread = 4 reduction rows x 8 channels (one 16-B load per
+// row), transposed into the [channel][32 rows + pad] LDS image with eight 8-B stores; MFMA loop, split slabs and epilogue as above.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
+    constexpr int BKT = 32, LDH = 40;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * LDH];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1;
+    const int nrt = (p.M + BKT - 1) / BKT;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    const bool isA = tid < BM;
+    const bool isB = !isA && tid < BM + BN;
+    const int t2 = isA ? tid : tid - BM;
+    const int c8 = isA ? t2 % (BM / 8) : t2 % (BN / 8);
+    const int rgrp = isA ? t2 / (BM / 8) : t2 / (BN / 8);          // 0..7: rows rgrp*4 .. +3 of the tile
+    int b_kh = 0, b_kw = 0, b_c = 0;
+    bool b_kok = false;
+    if (isB) {
+        const int k = n0 + c8 * 8;
+        b_kok = k < p.K;
+        const int kk = b_kok ? k : 0;
+        const int tap = kk / Cin;
+        b_c = kk - tap * Cin;
+        b_kh = tap / p.KW;
+        b_kw = tap - b_kh * p.KW;
+    }
+    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 rv[4];
+    auto load_tile = [&](int rt) {
+        const int r0 = rt * BKT + rgrp * 4;
+        if (isA) {
+            const int co = m0 + c8 * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e;
+                uint4 v = {0u, 0u, 0u, 0u};
+                if (r < p.M && co < p.Cout) v = *reinterpret_cast<const uint4*>(p.dyh + (size_t)r * p.Cout + co);
+                rv[e] = v;
+                if (do_bias) {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bsum[2 * q] += __uint_as_float(w[q] << 16);
+                        bsum[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+                    }
+                }
+            }
+        } else if (isB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + e;
+                uint4 v = {0u, 0u, 0u, 0u};
+                if (r < p.M && b_kok) {
+                    const int t = (int)fdiv((uint32_t)r, p.fd_ow);
+                    const int ow = r - t * p.OW;
+                    const int img = (int)fdiv((uint32_t)t, p.fd_oh);
+                    const int oh = t - img * p.OH;
+                    int ih = oh * p.sh - p.ph + b_kh, iw = ow * p.sw - p.pw + b_kw;
+                    bool ok = ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+                    if (p.idil > 1) {
+                        ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                        ih /= p.idil;
+                        iw /= p.idil;
+                    }
+                    if (p.ups) { ih >>= 1; iw >>= 1; }
+                    if (ok) v = *reinterpret_cast<const uint4*>(p.xh + (((size_t)img * p.H + ih) * p.W + iw) * Cin + b_c);
+                }
+                rv[e] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (isA || isB) {
+            uint16_t* dst = (isA ? &As[buf][0] : &Bs[buf][0]) + (c8 * 8) * LDH + rgrp * 4;
+            const uint32_t w[4][4] = {{rv[0].x, rv[0].y, rv[0].z, rv[0].w}, {rv[1].x, rv[1].y, rv[1].z, rv[1].w},
+                                      {rv[2].x, rv[2].y, rv[2].z, rv[2].w}, {rv[3].x, rv[3].y, rv[3].z, rv[3].w}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {            // channel pair (2q, 2q+1): low / high halves of word q of every row
+                uint2 lo = {(w[0][q] & 0xffffu) | (w[1][q] << 16), (w[2][q] & 0xffffu) | (w[3][q] << 16)};
+                uint2 hi = {(w[0][q] >> 16) | (w[1][q] & 0xffff0000u), (w[2][q] >> 16) | (w[3][q] & 0xffff0000u)};
+                *reinterpret_cast<uint2*>(dst + (2 * q) * LDH) = lo;
+                *reinterpret_cast<uint2*>(dst + (2 * q + 1) * LDH) = hi;
+            }
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    if (rt_begin < rt_end) {
+        load_tile(rt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        const bool more = (rt + 1) < rt_end;
+        if (more) load_tile(rt + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][(wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][(wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int k = n0 + wn + j * 32 + lr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co >= p.Cout) continue;
+                if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[i][j][r];
+                else wgrad_store(p, co, k, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&As[0][0]);        // [8][BM] floats (4 KB of the 20 KB image)
+        if (isA) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[rgrp * BM + c8 * 8 + j] = bsum[j];
+        }
+        __syncthreads();
+        if (tid < BM) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += red[g * BM + tid];
+            const int co = m0 + tid;
+            if (co < p.Cout) {
+                if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = t;
+                else p.dbias[co] = p.accumulate ? p.dbias[co] + t : t;
+            }
+        }
+    }
+}
+
 __global__ void wgrad_splitk_reduce(const WgradDesc p) {
     const size_t total = (size_t)p.Cout * p.K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1421,6 +1586,52 @@ size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K) {
         if (sh > s) s = sh;
     }
     return s > 1 ? ((size_t)s * Cout * K + (size_t)s * Cout) * sizeof(float) : 0;
+}
+
+// Weight gradient from the bf16 twins of the operands (bf16 MFMA, fp32 accumulate, dw in the torch layout as v2a_conv2d_wgrad).
+// For layers the 128-row bf16 tiles take: Cout > 64, K > 64, Cin % 8 == 0, Cout % 8 == 0, single input source.
+size_t v2a_conv2d_wgrad_h_workspace_bytes(int M, int Cout, int K) {
+    const int tiles = cdiv(Cout, 128) * cdiv(K, 128);
+    int s = 768 / tiles, deep = cdiv(M, 32) / 8;
+    if (deep > 256) deep = 256;
+    if (s > deep) s = deep;
+    if (s < 1) s = 1;
+    return s > 1 ? ((size_t)s * Cout * K + (size_t)s * Cout) * sizeof(float) : 0;
+}
+int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C, int OH, int OW, int Cout, int KH,
+                       int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream) {
+    if (!x_h || !dy_h || !dw || Cout <= 64 || C % 8 != 0 || Cout % 8 != 0) return V2A_ERR_ARG;
+    WgradDesc p = {};
+    p.xh = (const uint16_t*)x_h; p.dyh = (const uint16_t*)dy_h; p.dw = dw; p.dbias = dbias; p.partial = (float*)workspace;
+    p.N = N; p.H = H; p.W = W; p.C1 = C; p.C2 = 0; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.idil = idil < 1 ? 1 : idil; p.ups = ups;
+    p.HL = ups ? 2 * H : (p.idil > 1 ? (H - 1) * p.idil + 1 : H);
+    p.WL = ups ? 2 * W : (p.idil > 1 ? (W - 1) * p.idil + 1 : W);
+    p.M = N * OH * OW;
+    p.K = KH * KW * C;
+    if (p.K <= 64) return V2A_ERR_ARG;
+    p.accumulate = accumulate;
+    p.fd_ow = make_fastdiv((uint32_t)OW);
+    p.fd_oh = make_fastdiv((uint32_t)OH);
+    const int tiles = cdiv(Cout, 128) * cdiv(p.K, 128);
+    int s = 768 / tiles, deep = cdiv(p.M, 32) / 8;
+    if (deep > 256) deep = 256;
+    if (s > deep) s = deep;
+    if (s < 1) s = 1;
+    if (s > 1 && ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    p.splits = s;
+    p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
+    hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    if (s > 1) {
+        size_t total = (size_t)Cout * p.K;
+        int g = (int)((total + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+    }
+    return V2A_OK;
 }
 
 // Weight gradient of the conv described by the same geometry arguments; dw is written in the TORCH layout

@@ -145,8 +145,10 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
 
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
-           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0):
-    """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]."""
+           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None):
+    """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout].
+    bf16-MFMA mode: `x_h` = an existing bf16 twin of x (skips the cast launch); `keep_h` (a list) receives the twin that was used, so a
+    training engine can hand it to conv2d_wgrad later."""
     _chk(x, "x")
     N, H, W, C1 = x.shape
     C2 = 0
@@ -160,7 +162,10 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)
         if wh is not None:
-            return conv2d_h(cast_h(x), wh, bias, Cout, KH, KW, stride, pad, x2=None if x2 is None else cast_h(x2), rowvec=rowvec,
+            xh = x_h if x_h is not None else cast_h(x)
+            if keep_h is not None:
+                keep_h.append(xh)
+            return conv2d_h(xh, wh, bias, Cout, KH, KW, stride, pad, x2=None if x2 is None else cast_h(x2), rowvec=rowvec,
                             rows_per_batch=rows_per_batch, residual=residual, ups=ups, out_f32=True, idil=idil, out_hw=out_hw, y=y)
     sh, sw = stride
     ph, pw = pad
@@ -186,8 +191,10 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     return y
 
 
-def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None):
-    """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout]."""
+def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None,
+                 x_h=None, dy_h=None):
+    """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout].
+    bf16-MFMA mode with bf16 twins of both operands at hand (x_h, dy_h): the twin-fed kernel (half the operand traffic)."""
     _chk(x, "x"); _chk(dy, "dy")
     N, H, W, C1 = x.shape
     C2 = x2.shape[-1] if x2 is not None else 0
@@ -196,6 +203,16 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
         dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     M = N * OH * OW
     K = KH * KW * (C1 + C2)
+    if (x_h is not None and dy_h is not None and x2 is None and Cout > 64 and K > 64 and C1 % 8 == 0 and Cout % 8 == 0
+            and lib.v2a_get_precision() == 1):
+        _chk_h(x_h, "x_h"); _chk_h(dy_h, "dy_h")
+        wsb = lib.v2a_conv2d_wgrad_h_workspace_bytes(M, Cout, K)
+        ws = workspace(wsb, x.device) if wsb else None
+        check(lib.v2a_conv2d_wgrad_h(x_h.data_ptr(), dy_h.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, OH, OW, Cout, KH, KW, stride[0],
+                                     stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0, _p(ws), wsb, _stream()),
+              "conv2d_wgrad_h")
+        last_kernel[0] = "conv_wgrad_bf16h<128,128>"
+        return dw
     wsb = lib.v2a_conv2d_wgrad_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,

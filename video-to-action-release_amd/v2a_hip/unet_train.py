@@ -87,18 +87,21 @@ class UNetTrainEngine(UNetEngine):
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
         x4 = x.view(B * Fr, H, W, C)
+        kx, ky = [], []                                          # bf16 twins of the conv inputs (bf16-MFMA mode), kept for the weight gradients
         y = ops.conv2d(x4, self.w(name + ".spatial_conv.weight"), self.p(name + ".spatial_conv.bias"), cout, k, k, (stride, stride),
                        (k // 2, k // 2), ups=ups, rowvec=None if has_t else rowvec, rows_per_batch=1,
-                       residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout))
+                       residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout),
+                       keep_h=kx)
         OH, OW = y.shape[1], y.shape[2]
         st = dict(name=name, x=x, y=y, k=k, stride=stride, ups=ups, has_t=has_t, cout=cout, has_row=rowvec is not None,
-                  has_res=residual is not None)
+                  has_res=residual is not None, xh=kx[0] if kx else None, yh=None)
         if not has_t:
             assert rowvec is None
             return y.view(B, Fr, OH, OW, cout), st
         z = ops.conv2d(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight"), self.p(name + ".temporal_conv.bias"), cout,
                        3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW,
-                       residual=None if residual is None else residual.view(B, Fr, OH * OW, cout))
+                       residual=None if residual is None else residual.view(B, Fr, OH * OW, cout), keep_h=ky)
+        st["yh"] = ky[0] if ky else None
         return z.view(B, Fr, OH, OW, cout), st
 
     def conv3d_bwd(self, st, dz, grads, need_dx=True):
@@ -110,27 +113,30 @@ class UNetTrainEngine(UNetEngine):
         drow = None
         if st["has_row"]:
             drow = ops.colsum_batched(dz.view(B, Fr * OH * OW, cout))
+        twins = ops.lib.v2a_get_precision() == 1
         if st["has_t"]:
             dz4 = dz.view(B, Fr, OH * OW, cout)
             y4 = y.view(B, Fr, OH * OW, cout)
+            dzh = ops.cast_h(dz4) if (twins and st["yh"] is not None) else None      # one rounding serves data and weight gradient
             ops.conv2d_wgrad(y4, dz4, (cout, cout, 3, 1), 3, 1, (1, 1), (1, 0), dw=grads[pre + ".temporal_conv.weight"],
-                             dbias=grads[pre + ".temporal_conv.bias"])
-            dy = ops.conv2d(dz4, self.wflip(name + ".temporal_conv.weight"), None, cout, 3, 1, (1, 1), (1, 0)).view(B * Fr, OH, OW, cout)
+                             dbias=grads[pre + ".temporal_conv.bias"], x_h=st["yh"], dy_h=dzh)
+            dy = ops.conv2d(dz4, self.wflip(name + ".temporal_conv.weight"), None, cout, 3, 1, (1, 1), (1, 0), x_h=dzh).view(B * Fr, OH, OW, cout)
         else:
             dy = dz.view(B * Fr, OH, OW, cout)
         x4 = x.view(B * Fr, H, W, C)
+        dyh = ops.cast_h(dy) if (twins and st["xh"] is not None) else None
         ops.conv2d_wgrad(x4, dy, (cout, C, k, k), k, k, (stride, stride), (k // 2, k // 2), ups=ups, dw=grads[pre + ".spatial_conv.weight"],
-                         dbias=grads[pre + ".spatial_conv.bias"])
+                         dbias=grads[pre + ".spatial_conv.bias"], x_h=st["xh"], dy_h=dyh)
         if not need_dx:
             return None, drow
         wf = self.wflip(name + ".spatial_conv.weight")
         if ups:
-            du = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2))                  # gradient at the upsampled resolution
+            du = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2), x_h=dyh)         # gradient at the upsampled resolution
             dx = ops.sumpool2x2(du)
         elif stride > 1:
-            dx = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2), idil=stride, out_hw=(H, W))
+            dx = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2), idil=stride, out_hw=(H, W), x_h=dyh)
         else:
-            dx = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2))
+            dx = ops.conv2d(dy, wf, None, C, k, k, (1, 1), (k // 2, k // 2), x_h=dyh)
         return dx.view(B, Fr, H, W, C), drow
 
     # ------------------------------------------------------------------ GroupNorm32 (+ SiLU)
