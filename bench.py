@@ -429,7 +429,7 @@ def main():
         value = world * args.steps / dt
         P = 87219143
         flops_step = 8.722e9 * args.batch                  # fwd+bwd algorithmic FLOPs per sample
-        out = {"metric": "policy_train_steps_per_sec", "value": value, "unit": "steps/s (batch-64 steps, all ranks)", "n_gpus": world,
+        out = {"metric": "policy_train_steps_per_sec", "value": value, "unit": f"steps/s (batch-{args.batch} steps, all ranks)", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA inputs; f32 accumulate, f32 storage/optimizer)", "data": "synthetic",
                "config": {"workload": "Libero 8-task diffusion-policy train step (BASELINE.json configs[1]): R1 replay gather -> "
