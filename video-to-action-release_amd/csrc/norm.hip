@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     float* red = sm + E;
     const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
     float s = 0.f;
+#pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg;
         const float v = p.x[base + (size_t)row * C + cc];
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)E;
     __syncthreads();
     float q = 0.f;
+#pragma unroll 4
     for (int i = tid; i < E; i += 256) { const float d = sm[i] - mu; q += d * d; }
     q = wave_sum(q);
     if ((tid & 63) == 0) red[tid >> 6] = q;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     const float var = (red[0] + red[1] + red[2] + red[3]) / (float)E;
     const float rs = 1.0f / sqrtf(var + p.eps);
     if (tid == 0) { p.mean[n * p.G + g] = mu; p.rstd[n * p.G + g] = rs; }
+#pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
     const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
     float A1 = 0.f, A2 = 0.f;
+#pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     A1 = red[0] + red[1] + red[2] + red[3];
     A2 = red[4] + red[5] + red[6] + red[7];
     const float inv = 1.0f / (float)E;
+#pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
