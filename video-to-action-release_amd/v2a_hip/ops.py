@@ -99,12 +99,18 @@ def _plan_name_h(M, Cout, K, ept, tname):
 
 _SMALL_TILE_H = os.environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
 _WGRAD_DMA = os.environ.get('V2A_WGRAD_DMA', '1') != '0'
+_h_twin_regs = 0
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
 
 def register_h_twin(w_f32: torch.Tensor, w_h: torch.Tensor):
     """Declare `w_h` (bf16) to hold the same packed operand as `w_f32`: in the bf16 precision mode conv2d then runs eligible
     layers on the LDS-DMA bf16 kernel (csrc/igemm_h.hip) -- the fp32 activations are rounded to bf16 by a cast launch first."""
+    global _h_twin_regs
+    _h_twin_regs += 1
+    if _h_twin_regs % 64 == 0:                                  # drop twins whose fp32 operand died (rebuilt engines), or they leak
+        for k in [k for k, (ref, _) in _h_twin.items() if ref() is None]:
+            del _h_twin[k]
     _h_twin[w_f32.data_ptr()] = (weakref.ref(w_f32), w_h)      # validated by identity: a recycled address never matches
 
 
