@@ -61,6 +61,7 @@ struct ConvDescH {
     int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, ups, HL, WL, M, K;
     int rows_per_batch, splitk, ktiles_per_split;
     int idil;                 // input dilation 1 | 2 (strided data gradient / transposed conv): logical input = zero-interleaved x
+    int frame_tiles;          // > 0: frame-interleaved tile order for (3 x 1) convs, = tiles per frame (OW / BM); 0: row order
     FastDivH fd_ow, fd_oh;
 };
 
@@ -99,7 +100,19 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
+    int tm = lin / tiles_n;
+    const int n0 = (lin % tiles_n) * BN;
+    if (p.frame_tiles > 0) {
+        // (3 x 1) convs over frames ([B, F, HW, C] view: OH = F, OW = HW): tile (frame f, pixel block pb) reads blocks pb of frames
+        // f-1, f, f+1.  In row order the three readers of a block are frame_tiles slots apart -- one XCD streams ~16 MB between
+        // them through its 4 MB L2 and the block comes from the fabric three times (PMC: 2.7x the tensor).  Run the F frames of a
+        // pixel block back to back instead: slot -> (sample, pixel block, frame).
+        const int per_sample = p.OH * p.frame_tiles;
+        const int img = tm / per_sample, rem = tm - img * per_sample;
+        const int pb = rem / p.OH, f = rem - pb * p.OH;
+        tm = img * per_sample + f * p.frame_tiles + pb;
+    }
+    const int m0 = tm * BM;
     const int split = blockIdx.y;
     const int Cin = p.C1 + p.C2;
     const int nkt = p.K / EPT;
@@ -507,6 +520,15 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(p.K / ept, s);
+    static int frame_order = -1;                    // V2A_FRAME_TILES=0: row order for the temporal convs too
+    if (frame_order < 0) {
+        const char* e = getenv("V2A_FRAME_TILES");
+        frame_order = (e && e[0] == '0') ? 0 : 1;
+    }
+    p.frame_tiles = 0;
+    if (frame_order && KH == 3 && KW == 1 && sh == 1 && sw == 1 && ph == 1 && pw == 0 && !ups && idil == 1 && OH == H && OW == W &&
+        OH > 1 && OW % bm == 0 && s == 1)
+        p.frame_tiles = OW / bm;
     // fused GroupNorm statistics need the single-pass epilogue, an output in the storage type and whole 8-channel vectors
     if (stats) {
         if (s > 1 || !y || Cout % 8 || bm != 128) return V2A_ERR_ARG;
