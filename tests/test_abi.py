@@ -36,3 +36,28 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.V2AError):
         _lib._load()
+
+
+def test_argument_validation_returns_error_codes_without_touching_the_device():
+    """Entry points reject null / inconsistent arguments with V2A_ERR_ARG (-1) before any launch (so this runs without a GPU); the
+    workspace queries of the newer kernels are host arithmetic."""
+    from v2a_hip._lib import lib
+    ERR_ARG = -1
+    assert lib.v2a_conv2d_wgrad(None, None, None, None, None, 1, 8, 8, 64, 0, 8, 8, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_conv2d_wgrad_h(None, None, None, None, 1, 8, 8, 64, 8, 8, 128, 3, 3, 1, 1, 1, 1, 1, 0, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_groupnorm_fwd(None, None, 0, None, None, None, None, 0, None, None, None, 1, 16, 64, 8, 1e-5, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_mha_fwd(None, None, None, None, None, 1, 4, 4, 2, 16, 32, 32, 32, 0.0, 0, 0, None) == ERR_ARG
+    assert lib.v2a_mha_bwd(None, None, None, None, None, None, None, None, 1, 4, 4, 2, 16, 32, 32, 32, 0.0, 0, 0, None) == ERR_ARG
+    assert lib.v2a_dropout(None, None, 16, 0.1, 1, 2, None) == ERR_ARG
+    assert lib.v2a_video_qsample(None, None, None, None, None, None, 2, 64, 1, None) == ERR_ARG
+    assert lib.v2a_video_loss_fwd(None, None, None, None, None, None, None, None, 2, 3, 64, 3, 2, 0, 1, None, 0, None) == ERR_ARG
+    assert lib.v2a_video_loss_bwd(None, None, None, None, None, None, None, None, None, 2, 3, 64, 3, 2, 0, 1, None) == ERR_ARG
+    assert lib.v2a_colsum_batched(None, None, 2, 64, 32, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_layernorm_bwd(None, None, None, None, None, 4, 64, 1e-5, None) == ERR_ARG
+    assert lib.v2a_bcast_rows(None, None, 2, 4, 8, 1.0, None) == ERR_ARG
+    assert lib.v2a_debug_force_wgrad_plan(96, 96, 1) == ERR_ARG and lib.v2a_debug_force_wgrad_plan(0, 0, 0) == 0
+    # host-side sizing of the split slabs / partials
+    assert lib.v2a_conv2d_wgrad_workspace_bytes(65536, 64, 576) > 0
+    assert lib.v2a_conv2d_wgrad_h_workspace_bytes(229376, 128, 1152) >= 128 * 1152 * 4 * 2
+    assert lib.v2a_colsum_batched_workspace_bytes(2, 114688, 128) >= 2 * 128 * 8
+    assert lib.v2a_video_loss_workspace_bytes(4) >= 4 * 8
