@@ -379,13 +379,21 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const float* __rest
     if (part == 0 && c < C)
         partial[((size_t)b * gridDim.z + blockIdx.z) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void colsum_batched_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, int slabs, int C, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C;
+__global__ __launch_bounds__(256) void colsum_batched_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int B, int slabs,
+                                                                   int C, int accumulate) {
+    // one wave per (b, 64-column block): the four waves of a workgroup split the slabs, lanes own columns (coalesced 512-B rows)
+    __shared__ double red[4][64];
+    const int cb = (C + 63) / 64;
+    const int b = blockIdx.x / cb, c = (blockIdx.x % cb) * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     double t = 0.0;
-    for (int sl = 0; sl < slabs; ++sl) t += partial[((size_t)b * slabs + sl) * C + c];
-    out[i] = accumulate ? out[i] + (float)t : (float)t;
+    if (c < C)
+        for (int sl = w; sl < slabs; sl += 4) t += partial[((size_t)b * slabs + sl) * C + c];
+    red[w][threadIdx.x & 63] = t;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const float v = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[(size_t)b * C + c] = accumulate ? out[(size_t)b * C + c] + v : v;
+    }
 }
 static int colsum_batched_slabs(int B, int rows, int C) {
     const int cb = (C + 63) / 64;
@@ -553,7 +561,7 @@ int v2a_colsum_batched(const float* x, float* out, int B, int rows, int C, int a
     const int slabs = colsum_batched_slabs(B, rows, C);
     const int rps = (rows + slabs - 1) / slabs;
     hipLaunchKernelGGL(colsum_batched_kernel, dim3((C + 63) / 64, B, slabs), dim3(256), 0, s, x, (double*)ws, rows, C, rps);
-    hipLaunchKernelGGL(colsum_batched_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, (const double*)ws, out, B, slabs, C, accumulate);
+    hipLaunchKernelGGL(colsum_batched_final_kernel, dim3(B * ((C + 63) / 64)), dim3(256), 0, s, (const double*)ws, out, B, slabs, C, accumulate);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
