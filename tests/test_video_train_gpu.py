@@ -16,14 +16,42 @@ def _tiny():
     return m.to("cuda:0"), sd
 
 
-def test_unet_backward_matches_oracle_autograd():
+def _custom(num_res_blocks, attention_resolutions, channel_mult, image_size):
+    """A same-architecture model with another block structure (the released wrappers differ in exactly these: UnetThor / UnetBridge use
+    3 res-blocks, channel_mult (1,2,4), attention at 4 / 8; reference flowdiffusion/flowdiffusion/unet.py:7-35,122-152)."""
+    from flowdiffusion.flowdiffusion.unet import _HipUnetWrapper
+    from flowdiffusion.flowdiffusion.guided_diffusion.guided_diffusion.unet import UNetModel
+    from oracle.param_fill import fill_module
+
+    class _M(_HipUnetWrapper):
+        def __init__(self):
+            super().__init__()
+            self.unet = UNetModel(image_size=image_size, in_channels=6, model_channels=32, out_channels=3, num_res_blocks=num_res_blocks,
+                                  attention_resolutions=attention_resolutions, dropout=0, channel_mult=channel_mult, conv_resample=True,
+                                  dims=3, num_classes=None, task_tokens=True, task_token_channels=512, use_checkpoint=False, use_fp16=False,
+                                  num_head_channels=16)
+
+    torch.manual_seed(0)
+    m = _M()
+    sd = fill_module(m, seed=11)
+    return m.to("cuda:0"), sd
+
+
+@pytest.mark.parametrize("variant", ["tiny", "two_blocks_three_levels"])
+def test_unet_backward_matches_oracle_autograd(variant):
     import oracle.video_unet as OV
     from v2a_hip.unet_train import UNetTrainEngine
-    m, sd = _tiny()
-    cfg = OV.UNetCfg(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
-                     num_head_channels=16)
+    if variant == "tiny":
+        m, sd = _tiny()
+        cfg = OV.UNetCfg(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+                         num_head_channels=16)
+        B, Fr, H, W = 2, 3, 32, 32
+    else:           # two res-blocks per level (two skip pushes per level + the Downsample's), three levels, attention at two of them, H != W
+        m, sd = _custom(2, (2, 4), (1, 2, 4), (24, 32))
+        cfg = OV.UNetCfg(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=2, attention_resolutions=(2, 4), channel_mult=(1, 2, 4),
+                         num_head_channels=16)
+        B, Fr, H, W = 2, 2, 24, 32
     g = torch.Generator().manual_seed(3)
-    B, Fr, H, W = 2, 3, 32, 32
     x = torch.randn(B, 6, Fr, H, W, generator=g)
     t = torch.tensor([5, 77])
     y = torch.randn(B, 4, 512, generator=g)
