@@ -257,3 +257,59 @@ def test_full_size_bf16_mfma_training_mode_tracks_fp32():
     cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
     assert cos > 0.995, cos
     assert abs(float(g16.norm() / g32.norm()) - 1.0) < 2e-2
+
+
+def test_flow_model_training_loss_and_gradients_vs_oracle():
+    """UnetMWFlow-style packing (2 flow channels per frame + the RGB conditioning image, reference unet.py:66-93) through
+    GoalGaussianDiffusion.forward / backward: the q_sample / pack / loss kernels with frame_channels = 2, against the oracle's p_losses."""
+    import oracle.video_unet as OV
+    from oracle import goal_diffusion as GD
+    from oracle.param_fill import fill_module
+    from flowdiffusion.flowdiffusion.unet import _HipUnetWrapper
+    from flowdiffusion.flowdiffusion.guided_diffusion.guided_diffusion.unet import UNetModel
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+
+    class _Flow(_HipUnetWrapper):
+        frame_channels = 2
+
+        def __init__(self):
+            super().__init__()
+            self.unet = UNetModel(image_size=(32, 32), in_channels=5, model_channels=32, out_channels=2, num_res_blocks=1,
+                                  attention_resolutions=(2,), dropout=0, channel_mult=(1, 2), conv_resample=True, dims=3, num_classes=None,
+                                  task_tokens=True, task_token_channels=512, use_checkpoint=False, use_fp16=False, num_head_channels=16)
+
+    torch.manual_seed(0)
+    m = _Flow()
+    sd = fill_module(m, seed=31)
+    m = m.to("cuda:0")
+    B, f, H, W = 2, 3, 32, 32
+    d = GoalGaussianDiffusion(m, image_size=(H, W), channels=2 * f, timesteps=100, sampling_timesteps=100, loss_type="l1", objective="pred_x0",
+                              beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0, auto_normalize=False).to("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    img, cond, te = torch.randn(B, 2 * f, H, W, generator=g), torch.rand(B, 3, H, W, generator=g), torch.randn(B, 4, 512, generator=g)
+    t, noise = torch.tensor([11, 88]), torch.randn(B, 2 * f, H, W, generator=g)
+    d.__dict__["_t_hook"] = lambda b: t
+    d.__dict__["_noise_hook"] = lambda shape: noise
+    loss = d(img.cuda(), cond.cuda(), te.cuda())
+    loss.backward()
+    # oracle: the reference's flow pack around the functional UNet, then p_losses + autograd
+    cfg = OV.UNetCfg(in_channels=5, model_channels=32, out_channels=2, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+                     num_head_channels=16)
+    names = [n for n, _ in m.named_parameters()]
+    P = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+
+    def model_fn(x, tt, emb):
+        cnd = x[:, -3:, None].expand(B, 3, f, H, W)
+        xx = x[:, :-3].reshape(B, f, 2, H, W).permute(0, 2, 1, 3, 4)
+        out = OV.unet_forward(P, torch.cat([xx, cnd], 1), tt, emb, cfg, pre="unet.")
+        return out.permute(0, 2, 1, 3, 4).reshape(B, f * 2, H, W)
+
+    T = GD.cosine_tables(100, objective="pred_x0")
+    lo = GD.p_losses(model_fn, T, img, t, cond, te, noise, "pred_x0", "l1")
+    assert abs(loss.item() - lo.item()) <= 1e-5 * max(1.0, abs(lo.item())), (loss.item(), lo.item())
+    lo.backward()
+    Pm = dict(m.named_parameters())
+    gmax = max(float(P[n].grad.abs().max()) for n in names)
+    for n in names:
+        a, b = Pm[n].grad.cpu().double(), P[n].grad.double()
+        assert float((a.norm() - b.norm()).abs()) <= 2e-3 * max(float(b.norm()), 1e-3 * gmax), n      # l1: sign() flips at rounding-level zeros
