@@ -130,3 +130,36 @@ def test_transformer_eval_scalar_timestep_and_default_dropout():
         a = m(x, 3, c)
         b = m(x, torch.full((5,), 3, device="cuda:0"), c)
     assert a.shape == (5, 10, 4) and torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_transformer_net_sized_trunk_backward_vs_oracle():
+    """The trunk TransformerNet instantiates (diffusion_policy_baseline/unet.py:57-70: 8 decoder + 2 encoder layers, 384 wide, 8 heads of
+    48, 10 action tokens, 3 + 1 condition tokens of 512): forward and every gradient against the (reference-pinned) CPU oracle."""
+    from flowdiffusion.flowdiffusion.diffusion_policy_baseline.transformer_for_diffusion import TransformerForDiffusion
+    from oracle import transformer as OT
+    from oracle.param_fill import fill_module
+    cfg = dict(input_dim=4, output_dim=4, horizon=10, n_obs_steps=3, cond_dim=512, n_cond_layers=2, n_layer=8, n_head=8, n_emb=384,
+               p_drop_emb=0.0, p_drop_attn=0.0, causal_attn=True, time_as_cond=True, obs_as_cond=True)
+    torch.manual_seed(0)
+    m = TransformerForDiffusion(**cfg)
+    sd = fill_module(m, seed=41)
+    m = m.to("cuda:0").train()
+    g = torch.Generator().manual_seed(9)
+    B = 6
+    x, c = torch.randn(B, 10, 4, generator=g), torch.randn(B, 3, 512, generator=g)
+    t, R = torch.randint(0, 100, (B,), generator=g), torch.randn(B, 10, 4, generator=g)
+    xg, cg = x.cuda().requires_grad_(True), c.cuda().requires_grad_(True)
+    y = m(xg, t.cuda(), cg)
+    (y * R.cuda()).sum().backward()
+    names = [n for n, _ in m.named_parameters()]
+    P = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    xo, co = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    yo = OT.forward(P, xo, t, co, 8, 8, 2, False)
+    (yo * R).sum().backward()
+    assert rel(y, yo) <= 1e-4, rel(y, yo)
+    assert rel(xg.grad, xo.grad) <= 2e-4 and rel(cg.grad, co.grad) <= 2e-4
+    Pm = dict(m.named_parameters())
+    gmax = max(float(P[n].grad.abs().max()) for n in names)
+    for n in names:
+        err = float((Pm[n].grad.cpu().double() - P[n].grad.double()).abs().max())
+        assert err <= 2e-4 * max(float(P[n].grad.abs().max()), 1e-3 * gmax), (n, err)
