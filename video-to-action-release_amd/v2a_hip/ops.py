@@ -29,7 +29,14 @@ class ws_lane:
         _lane[0] = self.prev
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of torch's current stream on the current device.  The private accessor costs 0.1 us against 2.8 us for building a
+    torch.cuda.Stream object per launch (tools/host_overhead_probe.py) -- a third of the host time of an eager launch."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
