@@ -549,3 +549,36 @@ def test_wgrad_halo_kernel_vs_torch(N, Cin, H, W, Cout):
     acc = torch.ones_like(dw)
     ops.conv2d_wgrad(nhwc(x), nhwc(dy), tuple(w.shape), 3, 3, (1, 1), (1, 1), dw=acc, accumulate=True)
     close(acc - 1.0, w.grad, tol=2e-5, what="halo wgrad accumulate")
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,k,s_", [(4, 64, 24, 24, 96, 3, 1), (64, 256, 1, 8, 128, (1, 5), 1), (3, 128, 16, 16, 128, 3, 2),
+                                                  (8, 128, 32, 32, 256, 3, 1), (2, 72, 9, 11, 136, 3, 1)])
+def test_twin_fed_bf16_wgrad_lds_dma_tr_read(N, Cin, H, W, Cout, k, s_):
+    """conv_wgrad_tr_h (bf16 twins of x / dy staged by LDS-DMA, MFMA operands through ds_read_b64_tr_b16): inputs exactly representable
+    in bf16 make the bf16 products exact, so the result must match the fp32 reference to accumulation-order noise -- a transposed,
+    swizzle-mismatched or mis-ordered operand fragment cannot pass (random data, ragged Cout / K tiles, image borders, stride 2,
+    split reduction with a ragged tail, fused bias gradient, accumulate)."""
+    import v2a_hip
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(500 + N + Cout)
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, kh, kw, generator=g) / math.sqrt(Cin * kh * kw)).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=s_, padding=(kh // 2, kw // 2))
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    old = v2a_hip.set_precision("bf16")
+    try:
+        xd, dyd = nhwc(x), nhwc(dy)
+        xh, dyh = ops.cast_h(xd), ops.cast_h(dyd)
+        db = torch.empty(Cout, device=dev())
+        dw = ops.conv2d_wgrad(xd, dyd, tuple(w.shape), kh, kw, (s_, s_), (kh // 2, kw // 2), dbias=db, x_h=xh, dy_h=dyh)
+        assert ops.last_kernel[0].startswith("conv_wgrad_bf16h")
+        acc = torch.full_like(dw, 0.5)
+        ops.conv2d_wgrad(xd, dyd, tuple(w.shape), kh, kw, (s_, s_), (kh // 2, kw // 2), dw=acc, accumulate=True, x_h=xh, dy_h=dyh)
+    finally:
+        v2a_hip.set_precision(old)
+    close(dw, w.grad, tol=2e-5, what="twin-fed bf16 wgrad")
+    close(db, b.grad, tol=2e-5, what="twin-fed bf16 wgrad: fused bias grad")
+    close(acc - 0.5, w.grad, tol=2e-5, what="twin-fed bf16 wgrad: accumulate")

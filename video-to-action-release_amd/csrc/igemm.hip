@@ -1266,6 +1266,155 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
     }
 }
 
+// bf16 weight gradient with LDS-DMA staging and the gfx950 transposing LDS read.  Both operands are k-major in HBM (rows = reduction
+// rows, 128 channels contiguous), which is what `global_load_lds` can deliver (lane-linear 16-B pieces) but not what the bf16 MFMA
+// wants (8 consecutive reduction rows per lane).  `ds_read_b64_tr_b16` closes the gap: per 16-lane group it takes sixteen 8-B row
+// segments and hands lane i the i-th 16-bit column of the 4 x 16 block they form (measured: tools/probes/tr_read_probe.hip --
+// result(lane i, elem j) = segment[4j + (i >> 2)][i & 3]).  So source lane s of a group points at row (s >> 2), columns 4 (s & 3) ..
+// + 3 of a [4 rows][16 columns] block and every lane receives 4 consecutive reduction rows of ITS column; two reads make the 8-row
+// MFMA operand.  LDS image: [64 rows][128 columns] bf16 per operand (256-B rows), 16-B pieces XOR-swizzled by 4 * (row & 3) at the
+// DMA source so that the four rows of a block sit in different 64-B bank quarters.  Single buffer (32 KB, 4 workgroups per CU) like
+// the forward kernel; split slabs / bias partials / reduce kernel shared with the other weight-gradient kernels.
+__device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr) {
+    uint2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
+    constexpr int BM = 128, BN = 128, BKR = 64, PITCH = 256;      // tile: 128 output channels x 128 k' columns, 64 reduction rows
+    constexpr int ABYTES = BKR * PITCH, BUF = 2 * ABYTES;
+    __shared__ __attribute__((aligned(128))) unsigned char smem[BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1;
+    const int nrt = (p.M + BKR - 1) / BKR;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    const uint16_t* zline = reinterpret_cast<const uint16_t*>(g_zero_line);
+    // DMA slot of this thread in pass j: row j*16 + tid/16, piece position tid%16 holding source piece (pos ^ 4*(row & 3))
+    const int prow = tid >> 4;
+    const int piece = (tid & 15) ^ (4 * (prow & 3));
+    const int a_co = m0 + piece * 8;
+    const bool a_cok = a_co < p.Cout;
+    const int bk = n0 + piece * 8;
+    const bool b_kok = bk < p.K;
+    const int btap = (b_kok ? bk : 0) / Cin;
+    const int bci = (b_kok ? bk : 0) - btap * Cin;
+    const int bkh = btap / p.KW, bkw = btap - bkh * p.KW;
+
+    auto issue = [&](int rt) {
+        const int r0 = rt * BKR;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j * 16 + prow;
+            const uint16_t* g = (a_cok && r < p.M) ? p.dyh + (size_t)r * p.Cout + a_co : zline;
+            __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(smem + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j * 16 + prow;
+            const uint32_t rr = r < p.M ? (uint32_t)r : 0u;
+            const uint32_t t = fdiv(rr, p.fd_ow);
+            const int ow = (int)(rr - t * p.OW);
+            const uint32_t img = fdiv(t, p.fd_oh);
+            const int oh = (int)(t - img * p.OH);
+            int ih = oh * p.sh - p.ph + bkh, iw = ow * p.sw - p.pw + bkw;
+            bool ok = b_kok && r < p.M && (unsigned)ih < (unsigned)p.HL && (unsigned)iw < (unsigned)p.WL;
+            if (p.idil > 1) {
+                ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                ih /= p.idil;
+                iw /= p.idil;
+            }
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            const uint16_t* g = ok ? p.xh + ((size_t)((int)img * p.H + ih) * p.W + iw) * Cin + bci : zline;
+            __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(smem + ABYTES + (j * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    const int lr = lane & 31, lk = lane >> 5;
+    // transposing-read source address of this lane: group g = lane >> 4, segment s = lane & 15
+    const int grp = lane >> 4, seg = lane & 15;
+    const int trow = 8 * (grp >> 1) + (seg >> 2);                 // + kk (+ 4 for the second half of the operand)
+    const int tcol = 16 * (grp & 1) + 4 * (seg & 3);              // + wm / wn + 32 * i
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto tr_addr = [&](int col) -> uint32_t {                     // byte offset inside an operand image for (row trow, column col)
+        return (uint32_t)(trow * PITCH + (((col >> 3) ^ (4 * (trow & 3))) << 4) + ((col & 7) << 1));
+    };
+    uint32_t aoff[2], boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        aoff[i] = lds0 + tr_addr(wm + 32 * i + tcol);
+        boff[i] = lds0 + ABYTES + tr_addr(wn + 32 * i + tcol);
+    }
+    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    float bsum = 0.f;                                             // thread tid < 128: column sum of dY over this block's rows
+
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        issue(rt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BKR; kk += 16) {
+            uint2 al[2], ah[2], bl[2], bh[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                al[i] = lds_read_tr16(aoff[i] + kk * PITCH);
+                ah[i] = lds_read_tr16(aoff[i] + (kk + 4) * PITCH);
+                bl[i] = lds_read_tr16(boff[i] + kk * PITCH);
+                bh[i] = lds_read_tr16(boff[i] + (kk + 4) * PITCH);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint4 ua = {al[i].x, al[i].y, ah[i].x, ah[i].y}, ub = {bl[j].x, bl[j].y, bh[j].x, bh[j].y};
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[i][j], 0, 0, 0);
+                }
+        }
+        if (do_bias && tid < BM) {
+            const int ch = tid >> 3, within = tid & 7;
+#pragma unroll 8
+            for (int r = 0; r < BKR; ++r) {
+                const uint16_t h = *reinterpret_cast<const uint16_t*>(smem + r * PITCH + ((ch ^ (4 * (r & 3))) << 4) + within * 2);
+                bsum += __uint_as_float((uint32_t)h << 16);
+            }
+        }
+        __syncthreads();                                          // everyone is done reading before the next tile overwrites the buffer
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = n0 + wn + j * 32 + lr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co >= p.Cout) continue;
+                if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[i][j][r];
+                else wgrad_store(p, co, k, acc[i][j][r]);
+            }
+        }
+    if (do_bias && tid < BM) {
+        const int co = m0 + tid;
+        if (co < p.Cout) {
+            if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = bsum;
+            else p.dbias[co] = p.accumulate ? p.dbias[co] + bsum : bsum;
+        }
+    }
+}
+
 __global__ void wgrad_splitk_reduce(const WgradDesc p) {
     const size_t total = (size_t)p.Cout * p.K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1590,12 +1739,21 @@ size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K) {
 
 // Weight gradient from the bf16 twins of the operands (bf16 MFMA, fp32 accumulate, dw in the torch layout as v2a_conv2d_wgrad).
 // For layers the 128-row bf16 tiles take: Cout > 64, K > 64, Cin % 8 == 0, Cout % 8 == 0, single input source.
-size_t v2a_conv2d_wgrad_h_workspace_bytes(int M, int Cout, int K) {
+static int wgrad_h_split(int M, int Cout, int K) {
+    static int target = -1;                         // workgroups aimed at (V2A_WGRAD_H_TARGET: tuning aid)
+    if (target < 0) {
+        const char* e = getenv("V2A_WGRAD_H_TARGET");
+        target = e ? atoi(e) : 768;
+        if (target < 64) target = 768;
+    }
     const int tiles = cdiv(Cout, 128) * cdiv(K, 128);
-    int s = 768 / tiles, deep = cdiv(M, 32) / 8;
+    int s = target / tiles, deep = cdiv(M, 32) / 8;
     if (deep > 256) deep = 256;
     if (s > deep) s = deep;
-    if (s < 1) s = 1;
+    return s < 1 ? 1 : s;
+}
+size_t v2a_conv2d_wgrad_h_workspace_bytes(int M, int Cout, int K) {
+    const int s = wgrad_h_split(M, Cout, K);
     return s > 1 ? ((size_t)s * Cout * K + (size_t)s * Cout) * sizeof(float) : 0;
 }
 int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C, int OH, int OW, int Cout, int KH,
@@ -1615,14 +1773,21 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbia
     p.fd_ow = make_fastdiv((uint32_t)OW);
     p.fd_oh = make_fastdiv((uint32_t)OH);
     const int tiles = cdiv(Cout, 128) * cdiv(p.K, 128);
-    int s = 768 / tiles, deep = cdiv(p.M, 32) / 8;
-    if (deep > 256) deep = 256;
-    if (s > deep) s = deep;
-    if (s < 1) s = 1;
+    const int s = wgrad_h_split(p.M, Cout, p.K);
     if (s > 1 && ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splits = s;
-    p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
-    hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+    static int use_tr = -1;                         // V2A_WGRAD_TR=0: the register-staged twin kernel instead of the LDS-DMA / tr-read one
+    if (use_tr < 0) {
+        const char* e = getenv("V2A_WGRAD_TR");
+        use_tr = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (use_tr && (((uintptr_t)x_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * C < 2147483648.0) {
+        p.rtiles_per_split = cdiv(cdiv(p.M, 64), s);
+        hipLaunchKernelGGL(conv_wgrad_tr_h, dim3(tiles, s), dim3(256), 0, stream, p);
+    } else {
+        p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
+        hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+    }
     V2A_CHECK_LAUNCH();
     if (s > 1) {
         size_t total = (size_t)Cout * p.K;
