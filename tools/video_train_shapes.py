@@ -20,6 +20,8 @@ def main():
     from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
     from v2a_hip.video_train import VideoTrainStep
     from v2a_hip import ops
+    import v2a_hip
+    v2a_hip.set_precision(os.environ.get("V2A_PRECISION", "fp32"))
     torch.manual_seed(0)
     m = Unet_Libero().to("cuda:0")
     d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
