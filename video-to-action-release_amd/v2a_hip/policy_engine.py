@@ -219,6 +219,14 @@ class PolicyEngine:
         import os as _os2
         self.batch_film = _os2.environ.get("V2A_BATCH_FILM", "1") != "0"
 
+    @staticmethod
+    def _twin_dy(dy, x_h, cout):
+        """bf16 twin of an output gradient, made once when the twin-fed weight-gradient kernel will take the layer (bf16-MFMA mode,
+        the forward conv left a twin of its input, wide enough output); None otherwise (the convs then round on their own)."""
+        if x_h is None or cout <= 64 or ops.lib.v2a_get_precision() != 1:
+            return None
+        return ops.cast_h(dy)
+
     # ------------------------------------------------------------------ weight gradients off the critical path
     def _wg(self, *a, **k):
         """Weight gradients feed nothing until the optimiser: launch them on a side stream so they fill the CUs the latency-bound
@@ -370,17 +378,18 @@ class PolicyEngine:
             s, co = blk["stride"], blk["cout"]
             g = co // 16
             inp = h
-            o1 = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1))
+            k1, k2 = [], []                          # bf16 twins of the conv inputs (bf16-MFMA mode): reused by the weight gradients
+            o1 = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1)
             a, s1 = self._gn(o1, blk["pre"] + ".bn1", g, "relu")
-            o2 = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1))
+            o2 = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2)
             sd = None
             if blk["down"] is not None:
-                idn = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0))
+                idn = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0), x_h=k1[0] if k1 else None)
                 idn, sd = self._gn(idn, blk["pre"] + ".downsample.1", g, "none")
             else:
                 idn = inp
             h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn)
-            st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd))
+            st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd, inp_h=k1[0] if k1 else None, a_h=k2[0] if k2 else None))
         feat = h
         B, FH, FW, FC = feat.shape
         kl = ops.conv2d(feat, e["pool"].pf(), e["pool"].b, cfg.num_kp, 1, 1)
@@ -406,18 +415,22 @@ class PolicyEngine:
             s, co, ci = blk["stride"], blk["cout"], blk["cin"]
             inp = bs["inp"]
             do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True)
-            self._wg(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
-            da = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1))
+            th = self._twin_dy                       # one bf16 rounding of a gradient serves its data and weight gradient
+            do2h = th(do2, bs["a_h"], co)
+            self._wg(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname], x_h=bs["a_h"], dy_h=do2h)
+            da = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1), x_h=do2h)
             do1, _, _ = self._gn_bwd(bs["s1"], da, grads)
-            self._wg(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname])
+            do1h = th(do1, bs["inp_h"], co)
+            self._wg(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname], x_h=bs["inp_h"], dy_h=do1h)
             ih, iw = inp.shape[1], inp.shape[2]
             if blk["down"] is not None:
                 didn_raw, _, _ = self._gn_bwd(bs["sd"], didn, grads)
-                self._wg(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname])
-                d1 = _dgrad(didn_raw, blk["down"], None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw))
-                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1)
+                ddh = th(didn_raw, bs["inp_h"], co)
+                self._wg(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname], x_h=bs["inp_h"], dy_h=ddh)
+                d1 = _dgrad(didn_raw, blk["down"], None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw), x_h=ddh)
+                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1, x_h=do1h)
             else:
-                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn)
+                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn, x_h=do1h)
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
         # RGB stem: 3 input channels make every 16-B piece of the gathered operand straddle pixels (scalar-gather kernel, 0.4 ms
@@ -439,13 +452,13 @@ class PolicyEngine:
             self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
 
     # ------------------------------------------------------------------ ConditionalUnet1D
-    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None):
+    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None):
         """Conv1d on [B,T,C] (channels-last) via the (1 x k) view."""
         B, T, C = x.shape
         pad = k // 2 if pad is None else pad
         y = ops.conv2d(x.view(B, 1, T, C), cv.pf(), cv.b, cv.co, 1, k, (1, stride), (0, pad),
                        x2=None if x2 is None else x2.view(B, 1, T, -1),
-                       residual=None if residual is None else residual.view(B, 1, -1, cv.co))
+                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h)
         return y.view(B, -1, cv.co)
 
     def _res_fwd(self, r, x, mgf, save, x2=None):
@@ -460,7 +473,8 @@ class PolicyEngine:
             film = ops.linear(mgf, r["ce"].pf(), r["ce"].b)                       # [B, 2*co] == [B][2][co]
         a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film)
         a0 = a0.view(B, T, co)
-        c1 = self._c1d(a0, r["c1"], k)
+        ka = []
+        c1 = self._c1d(a0, r["c1"], k, keep_h=ka)
         a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish")
         a1 = a1.view(B, T, co)
         if r["rc"] is not None:
@@ -468,7 +482,7 @@ class PolicyEngine:
         else:
             out = ops.axpy(a1, x)
         if save is not None:
-            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1))
+            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None))
         return out
 
     def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True):
@@ -484,8 +498,10 @@ class PolicyEngine:
         d4 = dout.view(B, 1, T, co)
         dc1, _, _ = self._gn_bwd(st["s1"], d4, grads)
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
-        self._wg(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname])
-        da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2))
+        dc1h = self._twin_dy(dc1, st.get("a0_h"), co)
+        self._wg(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname],
+                 x_h=st.get("a0_h"), dy_h=dc1h)
+        da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2), x_h=dc1h)
         if self._dfilm_all is not None:          # batched FiLM: the gradient rows go into this block's columns of [B, NF]
             o = r["film_off"]
             dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co])
