@@ -1556,7 +1556,13 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
         const bool big = Cout > 64 && K > 64 && flops >= 30e9 && tiles128 >= 8;
         *bm = *bn = big ? 128 : 64;
         *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
-        int sp = 1024 / *tiles;
+        static int target = -1;                     // workgroups aimed at per launch (V2A_WGRAD_TARGET: tuning aid)
+        if (target < 0) {
+            const char* e = getenv("V2A_WGRAD_TARGET");
+            target = e ? atoi(e) : 1024;
+            if (target < 64) target = 1024;
+        }
+        int sp = target / *tiles;
         const int cap = big ? 128 : 64, deep = cdiv(M, 32) / 8;
         if (sp > cap) sp = cap;
         if (sp > deep) sp = deep;
