@@ -466,7 +466,8 @@ class PolicyEngine:
         k, G = cfg.kernel_size, cfg.n_groups
         B, T, _ = x.shape
         co = r["cout"]
-        c0 = self._c1d(x, r["c0"], k, x2=x2)
+        kx = []
+        c0 = self._c1d(x, r["c0"], k, x2=x2, keep_h=kx)
         if self._film_all is not None:
             film = self._film_all[:, r["film_off"]:r["film_off"] + 2 * co]         # column slice of the batched projection
         else:
@@ -477,12 +478,13 @@ class PolicyEngine:
         c1 = self._c1d(a0, r["c1"], k, keep_h=ka)
         a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish")
         a1 = a1.view(B, T, co)
+        x_h = kx[0] if (kx and x2 is None) else None             # single-source blocks: the twin also serves rc and both weight gradients
         if r["rc"] is not None:
             out = self._c1d(x, r["rc"], 1, x2=x2, residual=a1, pad=0)
         else:
             out = ops.axpy(a1, x)
         if save is not None:
-            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None))
+            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None, x_h=x_h))
         return out
 
     def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True):
@@ -511,17 +513,21 @@ class PolicyEngine:
             self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
             dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0),
                           residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
-        self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname])
+        xh = st.get("x_h")
+        dc0h = self._twin_dy(dc0, xh, co)
+        self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname], x_h=xh, dy_h=dc0h)
         rc = r["rc"]
+        d4h = None
         if rc is not None:
-            self._wg(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname])
+            d4h = self._twin_dy(d4, xh, co)
+            self._wg(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname], x_h=xh, dy_h=d4h)
         if not need_dx:
             return None, None, dmgf
         if rc is not None:
             first = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2),
-                               residual=None if extra is None else extra.view(B, 1, T, ci))
+                               residual=None if extra is None else extra.view(B, 1, T, ci), x_h=dc0h)
             if x2 is None:
-                dx = _dgrad(d4, rc, None, ci, 1, 1, residual=first).view(B, T, ci)
+                dx = _dgrad(d4, rc, None, ci, 1, 1, residual=first, x_h=d4h).view(B, T, ci)
                 return dx, None, dmgf
             C2 = ci - C1
             dxa = torch.empty((B, T, C1), dtype=torch.float32, device=x.device)
@@ -529,7 +535,7 @@ class PolicyEngine:
             _dgrad(d4, rc, None, ci, 1, 1, residual=first, y=dxa.view(B, 1, T, C1), y2=dxb.view(B, 1, T, C2), csplit=C1)
             return dxa, dxb, dmgf
         res = dout if extra is None else ops.axpy(dout, extra)
-        dx = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci)).view(B, T, ci)
+        dx = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci), x_h=dc0h).view(B, T, ci)
         return dx, None, dmgf
 
     def unet_fwd(self, sample, t_long, global_cond, save=None):
