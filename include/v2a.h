@@ -87,6 +87,15 @@ int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, con
                       const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm, float* colsum,
                       float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act, void* workspace,
                       size_t workspace_bytes, v2a_stream_t stream);
+/* the same two operations additionally emitting the bf16 twin of their output (y_h / dx_h, may be NULL): in the bf16-MFMA mode the conv
+ * that consumes the GroupNorm output (forward) or its input gradient (backward) reads the twin, which saves the cast launch */
+int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                        int act, void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- elementwise (csrc/elementwise.hip) */
 /* backward helpers of the video UNet: 2x2 sum pooling (gradient of the folded nearest upsample, unet.py:86-115) and per-sample column

@@ -582,3 +582,21 @@ def test_twin_fed_bf16_wgrad_lds_dma_tr_read(N, Cin, H, W, Cout, k, s_):
     close(dw, w.grad, tol=2e-5, what="twin-fed bf16 wgrad")
     close(db, b.grad, tol=2e-5, what="twin-fed bf16 wgrad: fused bias grad")
     close(acc - 0.5, w.grad, tol=2e-5, what="twin-fed bf16 wgrad: accumulate")
+
+
+@pytest.mark.parametrize("N,S,C,G", [(3, 40, 128, 8), (2, 9000, 128, 32)])
+def test_groupnorm_twin_outputs_are_the_rounded_outputs(N, S, C, G):
+    """groupnorm_fwd / groupnorm_bwd with twin_out: the bf16 twin is bit-for-bit the round-to-nearest-even cast of the fp32 output
+    (small LDS-resident path and large HBM path), so a conv fed with it computes exactly what it would after a cast launch."""
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(N, S, C, generator=g) * 1.5 + 0.3).to(dev())
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev()), (0.1 * torch.randn(C, generator=g)).to(dev())
+    dout = torch.randn(N, S, C, generator=g).to(dev())
+    tw = []
+    y, mean, rstd = ops.groupnorm_fwd(x, gamma, beta, G, "silu", twin_out=tw)
+    y0, _, _ = ops.groupnorm_fwd(x, gamma, beta, G, "silu")
+    assert torch.allclose(y, y0, rtol=0, atol=1e-5) and torch.equal(tw[0].view(torch.int16), ops.cast_h(y).view(torch.int16))
+    tb = []
+    dx, dg, db, _, _ = ops.groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, "silu", twin_out=tb)
+    assert torch.equal(tb[0].view(torch.int16), ops.cast_h(dx).view(torch.int16))

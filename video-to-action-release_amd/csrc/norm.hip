@@ -30,10 +30,23 @@ struct GnDesc {
     float* dgamma_acc;      // small backward path: atomically accumulate dgamma / dbeta over n here (or null)
     float* dbeta_acc;
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
+    unsigned short* yh;     // optional bf16 twin of the output (forward: y, backward: dx), same shape: feeds the bf16-MFMA convs
     float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
     int film_ld;            // elements between the FiLM rows of consecutive samples (2*C when the [N][2][C] tensor is dense)
     float eps;
 };
+
+__device__ __forceinline__ unsigned short gn_f2bf(float f) {      // round to nearest even, as v2a_cast_f32_bf16
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void gn_store_twin4(unsigned short* yh, size_t i4, const f32x4& o) {
+    uint2 u;
+    u.x = (unsigned int)gn_f2bf(o[0]) | ((unsigned int)gn_f2bf(o[1]) << 16);
+    u.y = (unsigned int)gn_f2bf(o[2]) | ((unsigned int)gn_f2bf(o[3]) << 16);
+    reinterpret_cast<uint2*>(yh)[i4] = u;
+}
 
 // -------------------------------------------------------------------------------------------- large path
 // MODE 0: (x, x^2).  MODE 1: (dz, dz * xhat) with dz = dout * act'(z), z = gn(x) [+ residual].
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
             o[j] = a;
         }
         y4[i] = o;
+        if (p.yh) gn_store_twin4(p.yh, i, o);
     }
 }
 
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
             o[j] = rs * (p.gamma[c] * dz - (A1 + xh * A2) * inv_cnt);
         }
         y4[i] = o;
+        if (p.yh) gn_store_twin4(p.yh, i, o);
         if (dr4) dr4[i] = dzv;
     }
 }
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
         float a = act_fwd(z, p.act);
         if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
         p.y[off] = a;
+        if (p.yh) p.yh[off] = gn_f2bf(a);
     }
 }
 
@@ -329,7 +345,9 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
-        p.y[off] = rs * (p.gamma[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
+        const float dxv = rs * (p.gamma[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
+        p.y[off] = dxv;
+        if (p.yh) p.yh[off] = gn_f2bf(dxv);
         if (p.dres) p.dres[off] = dzs[i];
     }
     for (int cc = tid; cc < cg; cc += 256) {
@@ -389,14 +407,25 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
 
 // y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
 // x2 != null: the input is the channel concat [x | x2] (decoder skip, reference unet.py:681) read from both sources in place.
+int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                        int act, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                       const float* film, int film_ld, float* y, float* mean, float* rstd, int N, int S, int C, int G, float eps, int act,
                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return v2a_groupnorm_fwd_t(x, x2, C1, gamma, beta, residual, film, film_ld, y, nullptr, mean, rstd, N, S, C, G, eps, act, workspace,
+                               workspace_bytes, stream);
+}
+// same, additionally writing the bf16 twin of y (y_h, may be null): the operand of the bf16-MFMA conv that consumes y
+int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                        int act, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
+    p.yh = (unsigned short*)y_h;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act; p.eps = eps;
     const int cg = C / G;
@@ -427,15 +456,27 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
 // Backward of v2a_groupnorm_fwd.  dx [N,S,C]; dres (optional) = gradient of the residual input;
 // dfilm (optional) [N][2][C]; colsum [N][2][C] scratch/output; dgamma/dbeta [C]: overwritten, or accumulated into when
 // accumulate_params = 1 (the gradient arena is zeroed by the fused optimiser; saves a reduction launch on the small path).
+int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* residual, const float* film,
                       int film_ld, const float* dout, const float* mean, const float* rstd, float* dx, float* dres, float* dfilm,
                       float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return v2a_groupnorm_bwd_t(x, gamma, beta, residual, film, film_ld, dout, mean, rstd, dx, nullptr, dres, dfilm, colsum, dgamma, dbeta,
+                               accumulate_params, N, S, C, G, act, workspace, workspace_bytes, stream);
+}
+// same, additionally writing the bf16 twin of dx (dx_h, may be null)
+int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !dout || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
-    p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;
+    p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.yh = (unsigned short*)dx_h; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;
     const long E = (long)S * cg;

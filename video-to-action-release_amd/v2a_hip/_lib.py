@@ -38,6 +38,8 @@ SIGNATURES = {
     "v2a_groupnorm_workspace_bytes": (SZ, [I, I, I, I]),
     "v2a_groupnorm_fwd": (I, [P, P, I, P, P, P, P, I, P, P, P, I, I, I, I, F, I, P, SZ, P]),
     "v2a_groupnorm_bwd": (I, [P] * 5 + [I] + [P] * 9 + [I, I, I, I, I, I, P, SZ, P]),
+    "v2a_groupnorm_fwd_t": (I, [P, P, I, P, P, P, P, I, P, P, P, P, I, I, I, I, F, I, P, SZ, P]),
+    "v2a_groupnorm_bwd_t": (I, [P] * 5 + [I] + [P] * 10 + [I, I, I, I, I, I, P, SZ, P]),
     "v2a_act_fwd": (I, [P, P, SZ, I, P]),
     "v2a_act_bwd": (I, [P, P, P, SZ, I, P]),
     "v2a_axpy": (I, [P, P, P, F, SZ, P]),

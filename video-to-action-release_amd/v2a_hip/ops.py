@@ -175,7 +175,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)
         if wh is not None:
-            xh = x_h if x_h is not None else cast_h(x)
+            xh = x_h.view(x.shape) if x_h is not None else cast_h(x)
             if keep_h is not None:
                 keep_h.append(xh)
             return conv2d_h(xh, wh, bias, Cout, KH, KW, stride, pad, x2=None if x2 is None else cast_h(x2), rowvec=rowvec,
@@ -356,9 +356,10 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ group norm
-def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None):
+def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
-    Returns (y [N,S,C(+C2)], mean, rstd)."""
+    Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
+    that consumes y takes it as x_h and skips its cast launch)."""
     _chk(x, "x")
     N, S, C1 = x.shape
     C = C1 + (x2.shape[-1] if x2 is not None else 0)
@@ -370,8 +371,12 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     ws = workspace(wsb, x.device) if wsb else None
     # film: [N, 2*C] rows (scale | shift); may be a column slice of a wider [N, NF] matrix (batched FiLM projections): row stride
     film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
-    check(lib.v2a_groupnorm_fwd(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
-                                mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
+    yh = None
+    if twin_out is not None and C % 4 == 0:
+        yh = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
+        twin_out.append(yh)
+    check(lib.v2a_groupnorm_fwd_t(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
+                                  _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
           "groupnorm_fwd")
     return y, mean, rstd
 
@@ -395,11 +400,15 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
-                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None):
+                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
-    as `film` (a column slice of the batched [N, NF] gradient matrix)."""
+    as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx."""
     N, S, C = x.shape
     dx = torch.empty_like(x)
+    dxh = None
+    if twin_out is not None and C % 4 == 0:
+        dxh = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        twin_out.append(dxh)
     dres = torch.empty_like(x) if want_dres else None
     dfilm = dfilm_out if dfilm_out is not None else (torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None)
     film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
@@ -410,10 +419,10 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_groupnorm_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
-                                mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dres), _p(dfilm), colsum_.data_ptr(),
-                                dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,
-                                _stream()),
+    check(lib.v2a_groupnorm_bwd_t(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), _p(dres), _p(dfilm), colsum_.data_ptr(),
+                                  dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,
+                                  _stream()),
           "groupnorm_bwd")
     return dx, dgamma, dbeta, dres, dfilm
 

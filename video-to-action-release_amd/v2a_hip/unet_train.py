@@ -91,7 +91,7 @@ class UNetTrainEngine(UNetEngine):
         y = ops.conv2d(x4, self.w(name + ".spatial_conv.weight"), self.p(name + ".spatial_conv.bias"), cout, k, k, (stride, stride),
                        (k // 2, k // 2), ups=ups, rowvec=None if has_t else rowvec, rows_per_batch=1,
                        residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout),
-                       keep_h=kx)
+                       keep_h=kx, x_h=getattr(x, "_h", None))
         OH, OW = y.shape[1], y.shape[2]
         st = dict(name=name, x=x, y=y, k=k, stride=stride, ups=ups, has_t=has_t, cout=cout, has_row=rowvec is not None,
                   has_res=residual is not None, xh=kx[0] if kx else None, yh=None)
@@ -117,14 +117,20 @@ class UNetTrainEngine(UNetEngine):
         if st["has_t"]:
             dz4 = dz.view(B, Fr, OH * OW, cout)
             y4 = y.view(B, Fr, OH * OW, cout)
-            dzh = ops.cast_h(dz4) if (twins and st["yh"] is not None) else None      # one rounding serves data and weight gradient
+            dzh = None                                                                 # one rounding serves data and weight gradient
+            if twins and st["yh"] is not None:
+                dzh = getattr(dz, "_h", None)
+                dzh = ops.cast_h(dz4) if dzh is None else dzh
             ops.conv2d_wgrad(y4, dz4, (cout, cout, 3, 1), 3, 1, (1, 1), (1, 0), dw=grads[pre + ".temporal_conv.weight"],
                              dbias=grads[pre + ".temporal_conv.bias"], x_h=st["yh"], dy_h=dzh)
             dy = ops.conv2d(dz4, self.wflip(name + ".temporal_conv.weight"), None, cout, 3, 1, (1, 1), (1, 0), x_h=dzh).view(B * Fr, OH, OW, cout)
         else:
             dy = dz.view(B * Fr, OH, OW, cout)
         x4 = x.view(B * Fr, H, W, C)
-        dyh = ops.cast_h(dy) if (twins and st["xh"] is not None) else None
+        dyh = None
+        if twins and st["xh"] is not None:
+            dyh = getattr(dz, "_h", None) if not st["has_t"] else None
+            dyh = ops.cast_h(dy) if dyh is None else dyh
         ops.conv2d_wgrad(x4, dy, (cout, C, k, k), k, k, (stride, stride), (k // 2, k // 2), ups=ups, dw=grads[pre + ".spatial_conv.weight"],
                          dbias=grads[pre + ".spatial_conv.bias"], x_h=st["xh"], dy_h=dyh)
         if not need_dx:
@@ -144,15 +150,22 @@ class UNetTrainEngine(UNetEngine):
         B, Fr, H, W, C = x.shape
         N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
         x3 = x.view(N, S, C)
-        y, mean, rstd = ops.groupnorm_fwd(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act)
-        return y.view(B, Fr, H, W, C), dict(name=name, x3=x3, mean=mean, rstd=rstd, act=act, shape=tuple(x.shape))
+        tw = [] if (ops.lib.v2a_get_precision() == 1 and C % 64 == 0) else None      # bf16-MFMA mode: the consuming conv reads the twin
+        y, mean, rstd = ops.groupnorm_fwd(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, twin_out=tw)
+        y = y.view(B, Fr, H, W, C)
+        y._h = tw[0] if tw else None
+        return y, dict(name=name, x3=x3, mean=mean, rstd=rstd, act=act, shape=tuple(x.shape))
 
     def gn_bwd(self, st, dy, grads):
         pre = self.pre + st["name"]
         x3 = st["x3"]
+        tw = [] if (ops.lib.v2a_get_precision() == 1 and x3.shape[-1] % 64 == 0) else None
         dx, _, _, _, _ = ops.groupnorm_bwd(x3, self.p(st["name"] + ".weight"), self.p(st["name"] + ".bias"), 32, dy.view(x3.shape),
-                                           st["mean"], st["rstd"], st["act"], dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"])
-        return dx.view(st["shape"])
+                                           st["mean"], st["rstd"], st["act"], dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"],
+                                           twin_out=tw)
+        dx = dx.view(st["shape"])
+        dx._h = tw[0] if tw else None
+        return dx
 
     # ------------------------------------------------------------------ Linear
     def lin_fwd(self, x2d, name):
