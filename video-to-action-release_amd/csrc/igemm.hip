@@ -1456,6 +1456,58 @@ __global__ void wgrad_splitk_reduce(const WgradDesc p) {
     }
 }
 
+// Split reduce for filters with several taps: the slabs are k'-major ([Cout][tap][Cin]), the gradient is torch-major ([Cout][Cin][tap]).
+// One workgroup owns (output channel, 64 input channels): slab reads are coalesced along Cin, the sums are transposed through LDS and
+// leave as ONE contiguous run of 64 * taps floats -- instead of 4-B stores 4 * taps bytes apart.  Cin % 64 == 0, taps <= 64.
+__global__ __launch_bounds__(256) void wgrad_splitk_reduce_taps(const WgradDesc p) {
+    __shared__ float tile[64 * 65];
+    const int Cin = p.C1 + p.C2, taps = p.KH * p.KW;
+    const int cblocks = Cin >> 6;
+    const int co = blockIdx.x / cblocks, ci0 = (blockIdx.x % cblocks) << 6;
+    const size_t total = (size_t)p.Cout * p.K;
+    const int n = 64 * taps;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int tap = t >> 6, cl = t & 63;
+        const float* src = p.partial + (size_t)co * p.K + (size_t)tap * Cin + ci0 + cl;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int sl = 0;
+        for (; sl + 4 <= p.splits; sl += 4) {
+            v0 += src[(size_t)sl * total];
+            v1 += src[(size_t)(sl + 1) * total];
+            v2 += src[(size_t)(sl + 2) * total];
+            v3 += src[(size_t)(sl + 3) * total];
+        }
+        for (; sl < p.splits; ++sl) v0 += src[(size_t)sl * total];
+        tile[cl * (taps + 1 > 65 ? 65 : taps + 1) + tap] = (v0 + v1) + (v2 + v3);
+    }
+    __syncthreads();
+    float* dst = p.dw + ((size_t)co * Cin + ci0) * taps;
+    const int ld = taps + 1 > 65 ? 65 : taps + 1;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int cl = t / taps, tap = t - cl * taps;
+        const float v = tile[cl * ld + tap];
+        dst[t] = p.accumulate ? dst[t] + v : v;
+    }
+    if (p.dbias && (blockIdx.x % cblocks) == 0 && threadIdx.x == 0) {
+        const float* bp = p.partial + (size_t)p.splits * total;
+        float v = 0.f;
+        for (int s = 0; s < p.splits; ++s) v += bp[(size_t)s * p.Cout + co];
+        p.dbias[co] = p.accumulate ? p.dbias[co] + v : v;
+    }
+}
+static void launch_wgrad_reduce(const WgradDesc& p, hipStream_t stream) {
+    const int Cin = p.C1 + p.C2, taps = p.KH * p.KW;
+    if (taps > 1 && taps <= 64 && (Cin & 63) == 0) {
+        hipLaunchKernelGGL(wgrad_splitk_reduce_taps, dim3(p.Cout * (Cin >> 6)), dim3(256), 0, stream, p);
+        return;
+    }
+    size_t total = (size_t)p.Cout * p.K;
+    if ((p.K & 3) == 0) total >>= 2;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+}
+
 // ------------------------------------------------------------------------------------------------ weight packs
 // mode 0 (forward pack):        dst[co][kh][kw][ci]    = src[co][ci][kh][kw]
 // mode 1 (data-gradient pack):  dst[ci][kh'][kw'][co]  = src[co][ci][KH-1-kh'][KW-1-kw']
@@ -1819,11 +1871,7 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbia
     }
     V2A_CHECK_LAUNCH();
     if (s > 1) {
-        size_t total = (size_t)Cout * p.K;
-        if ((p.K & 3) == 0) total >>= 2;
-        int g = (int)((total + 255) / 256);
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+        launch_wgrad_reduce(p, stream);
         V2A_CHECK_LAUNCH();
     }
     return V2A_OK;
@@ -1863,11 +1911,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         else hipLaunchKernelGGL((conv_wgrad_halo_f32<32>), hgrid, dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (hs > 1) {
-            size_t total = (size_t)Cout * p.K;
-            if ((p.K & 3) == 0) total >>= 2;
-            int g = (int)((total + 255) / 256);
-            if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            launch_wgrad_reduce(p, stream);
             V2A_CHECK_LAUNCH();
         }
         return V2A_OK;
@@ -1890,11 +1934,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         else hipLaunchKernelGGL((conv_wgrad_bf16<64, 64>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
-            size_t total = (size_t)Cout * p.K;
-            if ((p.K & 3) == 0) total >>= 2;
-            int g = (int)((total + 255) / 256);
-            if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            launch_wgrad_reduce(p, stream);
             V2A_CHECK_LAUNCH();
         }
         return V2A_OK;
@@ -1908,11 +1948,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         else hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64, 4>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
-            size_t total = (size_t)Cout * p.K;
-            if ((p.K & 3) == 0) total >>= 2;
-            int g = (int)((total + 255) / 256);
-            if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            launch_wgrad_reduce(p, stream);
             V2A_CHECK_LAUNCH();
         }
         return V2A_OK;
@@ -1930,11 +1966,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
 #undef LAUNCHW
     V2A_CHECK_LAUNCH();
     if (s > 1) {
-        size_t total = (size_t)Cout * p.K;
-        if ((p.K & 3) == 0) total >>= 2;
-        int g = (int)((total + 255) / 256);
-        if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+        launch_wgrad_reduce(p, stream);
         V2A_CHECK_LAUNCH();
     }
     return V2A_OK;
