@@ -552,7 +552,8 @@ def test_wgrad_halo_kernel_vs_torch(N, Cin, H, W, Cout):
 
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout,k,s_", [(4, 64, 24, 24, 96, 3, 1), (64, 256, 1, 8, 128, (1, 5), 1), (3, 128, 16, 16, 128, 3, 2),
-                                                  (8, 128, 32, 32, 256, 3, 1), (2, 72, 9, 11, 136, 3, 1)])
+                                                  (8, 128, 32, 32, 256, 3, 1), (2, 72, 9, 11, 136, 3, 1), (6, 64, 32, 32, 64, 3, 1),
+                                                  (3, 128, 16, 16, 64, 3, 2)])
 def test_twin_fed_bf16_wgrad_lds_dma_tr_read(N, Cin, H, W, Cout, k, s_):
     """conv_wgrad_tr_h (bf16 twins of x / dy staged by LDS-DMA, MFMA operands through ds_read_b64_tr_b16): inputs exactly representable
     in bf16 make the bf16 products exact, so the result must match the fp32 reference to accumulation-order noise -- a transposed,

@@ -1280,9 +1280,15 @@ __device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
     return r;
 }
+template <int BM>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
-    constexpr int BM = 128, BN = 128, BKR = 64, PITCH = 256;      // tile: 128 output channels x 128 k' columns, 64 reduction rows
-    constexpr int ABYTES = BKR * PITCH, BUF = 2 * ABYTES;
+    // tile: BM (128 | 64) output channels x 128 k' columns, 64 reduction rows; BM = 64 serves the 64-channel layers (one wave row less
+    // per workgroup column: waves 2 x 2 over 64 x 128, each 32 x 64)
+    constexpr int BN = 128, BKR = 64, PITCH = 256, PITCH_A = BM * 2;
+    constexpr int ACH = BM / 8, AROWS = 256 / ACH, APASS = BKR / AROWS;     // 16-B pieces per A row, rows per DMA pass, passes
+    constexpr int ABYTES = BKR * PITCH_A, BBYTES = BKR * PITCH, BUF = ABYTES + BBYTES;
+    constexpr int WMT = BM / 2, TM = WMT / 32;                                // rows per wave, 32-row MFMA tiles per wave
+    constexpr int ASWZ = BM == 128 ? 4 : 2;      // piece XOR per (row & 3): conflict-free for 256-B / 128-B rows (enumerated bank model; PMC = 0)
     __shared__ __attribute__((aligned(128))) unsigned char smem[BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.K + BN - 1) / BN;
@@ -1296,7 +1302,9 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     // DMA slot of this thread in pass j: row j*16 + tid/16, piece position tid%16 holding source piece (pos ^ 4*(row & 3))
     const int prow = tid >> 4;
     const int piece = (tid & 15) ^ (4 * (prow & 3));
-    const int a_co = m0 + piece * 8;
+    const int arow = tid / ACH;                                   // A image: ACH pieces per row
+    const int apiece = (tid % ACH) ^ (ASWZ * (arow & 3));
+    const int a_co = m0 + apiece * 8;
     const bool a_cok = a_co < p.Cout;
     const int bk = n0 + piece * 8;
     const bool b_kok = bk < p.K;
@@ -1307,8 +1315,8 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     auto issue = [&](int rt) {
         const int r0 = rt * BKR;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + j * 16 + prow;
+        for (int j = 0; j < APASS; ++j) {
+            const int r = r0 + j * AROWS + arow;
             const uint16_t* g = (a_cok && r < p.M) ? p.dyh + (size_t)r * p.Cout + a_co : zline;
             __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(smem + (j * 256 + wid * 64) * 16), 16, 0, 0);
         }
@@ -1333,29 +1341,28 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+    const int wm = (wid >> 1) * WMT, wn = (wid & 1) * 64;
     const int lr = lane & 31, lk = lane >> 5;
     // transposing-read source address of this lane: group g = lane >> 4, segment s = lane & 15
     const int grp = lane >> 4, seg = lane & 15;
     const int trow = 8 * (grp >> 1) + (seg >> 2);                 // + kk (+ 4 for the second half of the operand)
     const int tcol = 16 * (grp & 1) + 4 * (seg & 3);              // + wm / wn + 32 * i
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    auto tr_addr = [&](int col) -> uint32_t {                     // byte offset inside an operand image for (row trow, column col)
-        return (uint32_t)(trow * PITCH + (((col >> 3) ^ (4 * (trow & 3))) << 4) + ((col & 7) << 1));
+    auto tr_addr = [&](int col, int pitch, int swz) -> uint32_t {       // byte offset inside an operand image for (row trow, column col)
+        return (uint32_t)(trow * pitch + (((col >> 3) ^ (swz * (trow & 3))) << 4) + ((col & 7) << 1));
     };
-    uint32_t aoff[2], boff[2];
+    uint32_t aoff[TM], boff[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        aoff[i] = lds0 + tr_addr(wm + 32 * i + tcol);
-        boff[i] = lds0 + ABYTES + tr_addr(wn + 32 * i + tcol);
-    }
+    for (int i = 0; i < TM; ++i) aoff[i] = lds0 + tr_addr(wm + 32 * i + tcol, PITCH_A, ASWZ);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) boff[i] = lds0 + ABYTES + tr_addr(wn + 32 * i + tcol, PITCH, 4);
     const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
     float bsum = 0.f;                                             // thread tid < 128: column sum of dY over this block's rows
 
@@ -1365,17 +1372,33 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BKR; kk += 16) {
+            // all transposing reads of a k step and the wait for them live in ONE asm statement: the compiler does not know that the
+            // outputs of a `ds_read` asm arrive asynchronously and is free to copy such a register before a separate s_waitcnt
             uint2 al[2], ah[2], bl[2], bh[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                al[i] = lds_read_tr16(aoff[i] + kk * PITCH);
-                ah[i] = lds_read_tr16(aoff[i] + (kk + 4) * PITCH);
-                bl[i] = lds_read_tr16(boff[i] + kk * PITCH);
-                bh[i] = lds_read_tr16(boff[i] + (kk + 4) * PITCH);
+            const uint32_t a0 = aoff[0] + kk * PITCH_A, b0 = boff[0] + kk * PITCH, b1 = boff[1] + kk * PITCH;
+            if constexpr (TM == 2) {
+                const uint32_t a1 = aoff[TM - 1] + kk * PITCH_A;
+                asm volatile(
+                    "ds_read_b64_tr_b16 %0, %8\n ds_read_b64_tr_b16 %1, %8 offset:%12\n"
+                    "ds_read_b64_tr_b16 %2, %9\n ds_read_b64_tr_b16 %3, %9 offset:%12\n"
+                    "ds_read_b64_tr_b16 %4, %10\n ds_read_b64_tr_b16 %5, %10 offset:%13\n"
+                    "ds_read_b64_tr_b16 %6, %11\n ds_read_b64_tr_b16 %7, %11 offset:%13\n"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(bl[0]), "=&v"(bh[0]), "=&v"(bl[1]), "=&v"(bh[1])
+                    : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "n"(4 * PITCH_A), "n"(4 * PITCH)
+                    : "memory");
+            } else {
+                asm volatile(
+                    "ds_read_b64_tr_b16 %0, %6\n ds_read_b64_tr_b16 %1, %6 offset:%9\n"
+                    "ds_read_b64_tr_b16 %2, %7\n ds_read_b64_tr_b16 %3, %7 offset:%10\n"
+                    "ds_read_b64_tr_b16 %4, %8\n ds_read_b64_tr_b16 %5, %8 offset:%10\n"
+                    "s_waitcnt lgkmcnt(0)"
+                    : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(bl[0]), "=&v"(bh[0]), "=&v"(bl[1]), "=&v"(bh[1])
+                    : "v"(a0), "v"(b0), "v"(b1), "n"(4 * PITCH_A), "n"(4 * PITCH)
+                    : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const uint4 ua = {al[i].x, al[i].y, ah[i].x, ah[i].y}, ub = {bl[j].x, bl[j].y, bh[j].x, bh[j].y};
@@ -1386,14 +1409,14 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
             const int ch = tid >> 3, within = tid & 7;
 #pragma unroll 8
             for (int r = 0; r < BKR; ++r) {
-                const uint16_t h = *reinterpret_cast<const uint16_t*>(smem + r * PITCH + ((ch ^ (4 * (r & 3))) << 4) + within * 2);
+                const uint16_t h = *reinterpret_cast<const uint16_t*>(smem + r * PITCH_A + ((ch ^ (ASWZ * (r & 3))) << 4) + within * 2);
                 bsum += __uint_as_float((uint32_t)h << 16);
             }
         }
         __syncthreads();                                          // everyone is done reading before the next tile overwrites the buffer
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = n0 + wn + j * 32 + lr;
@@ -1827,7 +1850,7 @@ static int wgrad_h_split(int M, int Cout, int K) {
         target = e ? atoi(e) : 768;
         if (target < 64) target = 768;
     }
-    const int tiles = cdiv(Cout, 128) * cdiv(K, 128);
+    const int tiles = cdiv(Cout, Cout <= 64 ? 64 : 128) * cdiv(K, 128);
     int s = target / tiles, deep = cdiv(M, 32) / 8;
     if (deep > 256) deep = 256;
     if (s > deep) s = deep;
@@ -1840,7 +1863,7 @@ size_t v2a_conv2d_wgrad_h_workspace_bytes(int M, int Cout, int K) {
 int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C, int OH, int OW, int Cout, int KH,
                        int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate, void* workspace, size_t workspace_bytes,
                        hipStream_t stream) {
-    if (!x_h || !dy_h || !dw || Cout <= 64 || C % 8 != 0 || Cout % 8 != 0) return V2A_ERR_ARG;
+    if (!x_h || !dy_h || !dw || Cout < 64 || C % 8 != 0 || Cout % 8 != 0) return V2A_ERR_ARG;
     WgradDesc p = {};
     p.xh = (const uint16_t*)x_h; p.dyh = (const uint16_t*)dy_h; p.dw = dw; p.dbias = dbias; p.partial = (float*)workspace;
     p.N = N; p.H = H; p.W = W; p.C1 = C; p.C2 = 0; p.OH = OH; p.OW = OW; p.Cout = Cout;
@@ -1853,7 +1876,8 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbia
     p.accumulate = accumulate;
     p.fd_ow = make_fastdiv((uint32_t)OW);
     p.fd_oh = make_fastdiv((uint32_t)OH);
-    const int tiles = cdiv(Cout, 128) * cdiv(p.K, 128);
+    const bool bm64 = Cout <= 64;                   // 64-channel layers: the 64 x 128 instance
+    const int tiles = cdiv(Cout, bm64 ? 64 : 128) * cdiv(p.K, 128);
     const int s = wgrad_h_split(p.M, Cout, p.K);
     if (s > 1 && ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splits = s;
@@ -1862,9 +1886,11 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbia
         const char* e = getenv("V2A_WGRAD_TR");
         use_tr = (e && e[0] == '0') ? 0 : 1;
     }
+    if (!use_tr && bm64) return V2A_ERR_ARG;        // (the register-staged fallback has no 64-row instance)
     if (use_tr && (((uintptr_t)x_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * C < 2147483648.0) {
         p.rtiles_per_split = cdiv(cdiv(p.M, 64), s);
-        hipLaunchKernelGGL(conv_wgrad_tr_h, dim3(tiles, s), dim3(256), 0, stream, p);
+        if (bm64) hipLaunchKernelGGL(conv_wgrad_tr_h<64>, dim3(tiles, s), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_wgrad_tr_h<128>, dim3(tiles, s), dim3(256), 0, stream, p);
     } else {
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
         hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);

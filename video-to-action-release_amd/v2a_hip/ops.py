@@ -216,7 +216,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
         dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     M = N * OH * OW
     K = KH * KW * (C1 + C2)
-    if (x_h is not None and dy_h is not None and x2 is None and Cout > 64 and K > 64 and C1 % 8 == 0 and Cout % 8 == 0
+    if (x_h is not None and dy_h is not None and x2 is None and Cout >= 64 and K > 64 and C1 % 8 == 0 and Cout % 8 == 0
             and lib.v2a_get_precision() == 1):
         _chk_h(x_h, "x_h"); _chk_h(dy_h, "dy_h")
         wsb = lib.v2a_conv2d_wgrad_h_workspace_bytes(M, Cout, K)
@@ -224,7 +224,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
         check(lib.v2a_conv2d_wgrad_h(x_h.data_ptr(), dy_h.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, OH, OW, Cout, KH, KW, stride[0],
                                      stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0, _p(ws), wsb, _stream()),
               "conv2d_wgrad_h")
-        last_kernel[0] = "conv_wgrad_bf16h<128,128>"
+        last_kernel[0] = "conv_wgrad_bf16h<128,128>" if Cout > 64 else "conv_wgrad_bf16h<64,128>"
         return dw
     wsb = lib.v2a_conv2d_wgrad_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None

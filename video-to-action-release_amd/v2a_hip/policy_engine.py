@@ -223,7 +223,7 @@ class PolicyEngine:
     def _twin_dy(dy, x_h, cout):
         """bf16 twin of an output gradient, made once when the twin-fed weight-gradient kernel will take the layer (bf16-MFMA mode,
         the forward conv left a twin of its input, wide enough output); None otherwise (the convs then round on their own)."""
-        if x_h is None or cout <= 64 or ops.lib.v2a_get_precision() != 1:
+        if x_h is None or cout < 64 or ops.lib.v2a_get_precision() != 1:
             return None
         return ops.cast_h(dy)
 
