@@ -1275,11 +1275,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
 // MFMA operand.  LDS image: [64 rows][128 columns] bf16 per operand (256-B rows), 16-B pieces XOR-swizzled by 4 * (row & 3) at the
 // DMA source so that the four rows of a block sit in different 64-B bank quarters.  Single buffer (32 KB, 4 workgroups per CU) like
 // the forward kernel; split slabs / bias partials / reduce kernel shared with the other weight-gradient kernels.
-__device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr) {
-    uint2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-    return r;
-}
 template <int BM>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     // tile: BM (128 | 64) output channels x 128 k' columns, 64 reduction rows; BM = 64 serves the 64-channel layers (one wave row less
