@@ -59,9 +59,9 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
 /* the same weight gradient from bf16 twins of x [N,H,W,C] and dy [N,OH,OW,Cout] (the rounded copies the bf16 forward / data-gradient
  * convs of the bf16-MFMA mode already made): half the operand traffic of the converting kernel.  Cout >= 64, K > 64, C % 8 == 0. */
 size_t v2a_conv2d_wgrad_h_workspace_bytes(int M, int Cout, int K);
-int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C, int OH, int OW, int Cout, int KH,
-                       int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate, void* workspace, size_t workspace_bytes,
-                       v2a_stream_t stream);
+int v2a_conv2d_wgrad_h(const void* x_h, const void* x2_h /* twin of the second input of a channel concat, or NULL */, const void* dy_h,
+                       float* dw, float* dbias, int N, int H, int W, int C, int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw,
+                       int ph, int pw, int idil, int ups, int accumulate, void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 /* tile / split-K plan the two launchers above will use for a problem size (benchmark labelling) */
 int v2a_conv2d_plan(int M, int Cout, int K, int* bm, int* bn, int* split);
 int v2a_debug_wgrad_dma(int on);   /* tuning aid: fp32 weight gradients on the LDS-DMA kernel (default on); returns the old value */

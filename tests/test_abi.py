@@ -44,7 +44,7 @@ def test_argument_validation_returns_error_codes_without_touching_the_device():
     from v2a_hip._lib import lib
     ERR_ARG = -1
     assert lib.v2a_conv2d_wgrad(None, None, None, None, None, 1, 8, 8, 64, 0, 8, 8, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, None, 0, None) == ERR_ARG
-    assert lib.v2a_conv2d_wgrad_h(None, None, None, None, 1, 8, 8, 64, 8, 8, 128, 3, 3, 1, 1, 1, 1, 1, 0, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_conv2d_wgrad_h(None, None, None, None, None, 1, 8, 8, 64, 0, 8, 8, 128, 3, 3, 1, 1, 1, 1, 1, 0, 0, None, 0, None) == ERR_ARG
     assert lib.v2a_groupnorm_fwd(None, None, 0, None, None, None, None, 0, None, None, None, 1, 16, 64, 8, 1e-5, 0, None, 0, None) == ERR_ARG
     assert lib.v2a_mha_fwd(None, None, None, None, None, 1, 4, 4, 2, 16, 32, 32, 32, 0.0, 0, 0, None) == ERR_ARG
     assert lib.v2a_mha_bwd(None, None, None, None, None, None, None, None, 1, 4, 4, 2, 16, 32, 32, 32, 0.0, 0, 0, None) == ERR_ARG

@@ -601,3 +601,30 @@ def test_groupnorm_twin_outputs_are_the_rounded_outputs(N, S, C, G):
     tb = []
     dx, dg, db, _, _ = ops.groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, "silu", twin_out=tb)
     assert torch.equal(tb[0].view(torch.int16), ops.cast_h(dx).view(torch.int16))
+
+
+def test_twin_fed_bf16_wgrad_two_source_concat():
+    """conv_wgrad_tr_h over a channel concat [x | x2] read from both sources in place (ConditionalUnet1D decoder blocks: (1 x 5) conv over
+    [h | skip]): exact-product inputs, fused bias gradient."""
+    import v2a_hip
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(77)
+    N, C1, C2, T, Cout = 64, 128, 64, 16, 256
+    xa = torch.randn(N, C1, 1, T, generator=g).bfloat16().float()
+    xb = torch.randn(N, C2, 1, T, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, C1 + C2, 1, 5, generator=g) / math.sqrt((C1 + C2) * 5)).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv2d(torch.cat([xa, xb], 1), w, b, padding=(0, 2))
+    dy = torch.randn(y.shape, generator=g).bfloat16().float()
+    y.backward(dy)
+    old = v2a_hip.set_precision("bf16")
+    try:
+        xad, xbd, dyd = nhwc(xa), nhwc(xb), nhwc(dy)
+        db = torch.empty(Cout, device=dev())
+        dw = ops.conv2d_wgrad(xad, dyd, tuple(w.shape), 1, 5, (1, 1), (0, 2), x2=xbd, dbias=db, x_h=ops.cast_h(xad), x2_h=ops.cast_h(xbd),
+                              dy_h=ops.cast_h(dyd))
+        assert ops.last_kernel[0].startswith("conv_wgrad_bf16h")
+    finally:
+        v2a_hip.set_precision(old)
+    close(dw, w.grad, tol=2e-5, what="two-source twin-fed wgrad")
+    close(db, b.grad, tol=2e-5, what="two-source twin-fed wgrad: bias")

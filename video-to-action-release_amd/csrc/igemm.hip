@@ -475,7 +475,8 @@ __global__ void conv_splitk_reduce(const ConvDesc p) {
 struct WgradDesc {
     const float* x; const float* x2;   // conv input (two sources as in ConvDesc)
     const float* dy;                   // [M][Cout]
-    const uint16_t* xh; const uint16_t* dyh;   // bf16 twins of x / dy (conv_wgrad_bf16h) or null
+    const uint16_t* xh; const uint16_t* dyh;   // bf16 twins of x / dy (conv_wgrad_bf16h / conv_wgrad_tr_h) or null
+    const uint16_t* x2h;               // twin of x2 (two-source gather of conv_wgrad_tr_h) or null
     float* dw;                         // torch layout [Cout][Cin][KH][KW]  (or [Cin][Cout][KH][KW]-free: see transposed)
     float* partial;                    // [splits][Cout][K'] followed by [splits][Cout] bias partials
     float* dbias;                      // optional: [Cout] = sum_r dY[r][co] (fused bias gradient) or null
@@ -1289,7 +1290,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     const int tiles_n = (p.K + BN - 1) / BN;
     const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
     const int split = blockIdx.y;
-    const int Cin = p.C1;
+    const int Cin = p.C1 + p.C2;
     const int nrt = (p.M + BKR - 1) / BKR;
     const int rt_begin = split * p.rtiles_per_split;
     const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
@@ -1306,6 +1307,9 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     const int btap = (b_kok ? bk : 0) / Cin;
     const int bci = (b_kok ? bk : 0) - btap * Cin;
     const int bkh = btap / p.KW, bkw = btap - bkh * p.KW;
+    const bool bfirst = bci < p.C1;                               // piece from x or from x2 (channel concat [x | x2]; C1 % 8 == 0)
+    const uint16_t* bsrc = bfirst ? p.xh : p.x2h;
+    const int bCs = bfirst ? p.C1 : p.C2, bcc = bfirst ? bci : bci - p.C1;
 
     auto issue = [&](int rt) {
         const int r0 = rt * BKR;
@@ -1331,7 +1335,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
                 iw /= p.idil;
             }
             if (p.ups) { ih >>= 1; iw >>= 1; }
-            const uint16_t* g = ok ? p.xh + ((size_t)((int)img * p.H + ih) * p.W + iw) * Cin + bci : zline;
+            const uint16_t* g = ok ? bsrc + ((size_t)((int)img * p.H + ih) * p.W + iw) * bCs + bcc : zline;
             __builtin_amdgcn_global_load_lds((gptr_w_t)g, (lptr_w_t)(smem + ABYTES + (j * 256 + wid * 64) * 16), 16, 0, 0);
         }
     };
@@ -1855,18 +1859,19 @@ size_t v2a_conv2d_wgrad_h_workspace_bytes(int M, int Cout, int K) {
     const int s = wgrad_h_split(M, Cout, K);
     return s > 1 ? ((size_t)s * Cout * K + (size_t)s * Cout) * sizeof(float) : 0;
 }
-int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C, int OH, int OW, int Cout, int KH,
-                       int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate, void* workspace, size_t workspace_bytes,
-                       hipStream_t stream) {
-    if (!x_h || !dy_h || !dw || Cout < 64 || C % 8 != 0 || Cout % 8 != 0) return V2A_ERR_ARG;
+int v2a_conv2d_wgrad_h(const void* x_h, const void* x2_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C, int C2, int OH,
+                       int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
+    if (!x_h || !dy_h || !dw || Cout < 64 || C % 8 != 0 || Cout % 8 != 0 || C2 < 0 || C2 % 8 != 0 || (C2 > 0 && !x2_h)) return V2A_ERR_ARG;
     WgradDesc p = {};
-    p.xh = (const uint16_t*)x_h; p.dyh = (const uint16_t*)dy_h; p.dw = dw; p.dbias = dbias; p.partial = (float*)workspace;
-    p.N = N; p.H = H; p.W = W; p.C1 = C; p.C2 = 0; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.xh = (const uint16_t*)x_h; p.x2h = (const uint16_t*)x2_h; p.dyh = (const uint16_t*)dy_h; p.dw = dw; p.dbias = dbias;
+    p.partial = (float*)workspace;
+    p.N = N; p.H = H; p.W = W; p.C1 = C; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.idil = idil < 1 ? 1 : idil; p.ups = ups;
     p.HL = ups ? 2 * H : (p.idil > 1 ? (H - 1) * p.idil + 1 : H);
     p.WL = ups ? 2 * W : (p.idil > 1 ? (W - 1) * p.idil + 1 : W);
     p.M = N * OH * OW;
-    p.K = KH * KW * C;
+    p.K = KH * KW * (C + C2);
     if (p.K <= 64) return V2A_ERR_ARG;
     p.accumulate = accumulate;
     p.fd_ow = make_fastdiv((uint32_t)OW);
@@ -1881,8 +1886,8 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* dy_h, float* dw, float* dbia
         const char* e = getenv("V2A_WGRAD_TR");
         use_tr = (e && e[0] == '0') ? 0 : 1;
     }
-    if (!use_tr && bm64) return V2A_ERR_ARG;        // (the register-staged fallback has no 64-row instance)
-    if (use_tr && (((uintptr_t)x_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * C < 2147483648.0) {
+    if (!use_tr && (bm64 || C2 > 0)) return V2A_ERR_ARG;        // (the register-staged fallback has no 64-row / two-source instance)
+    if (use_tr && (((uintptr_t)x_h | (uintptr_t)x2_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * (C > C2 ? C : C2) < 2147483648.0) {
         p.rtiles_per_split = cdiv(cdiv(p.M, 64), s);
         if (bm64) hipLaunchKernelGGL(conv_wgrad_tr_h<64>, dim3(tiles, s), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL(conv_wgrad_tr_h<128>, dim3(tiles, s), dim3(256), 0, stream, p);

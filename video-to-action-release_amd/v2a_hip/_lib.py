@@ -28,7 +28,7 @@ SIGNATURES = {
     "v2a_conv2d_wgrad_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_wgrad": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_conv2d_wgrad_h_workspace_bytes": (SZ, [I, I, I]),
-    "v2a_conv2d_wgrad_h": (I, [P, P, P, P] + [I] * 16 + [P, SZ, P]),
+    "v2a_conv2d_wgrad_h": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),
     "v2a_pack_chunk_elems": (I, []),
     "v2a_debug_wgrad_dma": (I, [I]),

@@ -176,9 +176,12 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
         wh = _twin_of(w_packed)
         if wh is not None:
             xh = x_h.view(x.shape) if x_h is not None else cast_h(x)
+            x2h = None if x2 is None else cast_h(x2)
             if keep_h is not None:
                 keep_h.append(xh)
-            return conv2d_h(xh, wh, bias, Cout, KH, KW, stride, pad, x2=None if x2 is None else cast_h(x2), rowvec=rowvec,
+                if x2h is not None:
+                    keep_h.append(x2h)
+            return conv2d_h(xh, wh, bias, Cout, KH, KW, stride, pad, x2=x2h, rowvec=rowvec,
                             rows_per_batch=rows_per_batch, residual=residual, ups=ups, out_f32=True, idil=idil, out_hw=out_hw, y=y)
     sh, sw = stride
     ph, pw = pad
@@ -205,7 +208,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
 
 
 def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None,
-                 x_h=None, dy_h=None):
+                 x_h=None, dy_h=None, x2_h=None):
     """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout].
     bf16-MFMA mode with bf16 twins of both operands at hand (x_h, dy_h): the twin-fed kernel (half the operand traffic)."""
     _chk(x, "x"); _chk(dy, "dy")
@@ -216,13 +219,15 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
         dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     M = N * OH * OW
     K = KH * KW * (C1 + C2)
-    if (x_h is not None and dy_h is not None and x2 is None and Cout >= 64 and K > 64 and C1 % 8 == 0 and Cout % 8 == 0
+    if (x_h is not None and dy_h is not None and (x2 is None or x2_h is not None) and Cout >= 64 and K > 64 and C1 % 8 == 0
+            and C2 % 8 == 0 and Cout % 8 == 0
             and lib.v2a_get_precision() == 1):
         _chk_h(x_h, "x_h"); _chk_h(dy_h, "dy_h")
         wsb = lib.v2a_conv2d_wgrad_h_workspace_bytes(M, Cout, K)
         ws = workspace(wsb, x.device) if wsb else None
-        check(lib.v2a_conv2d_wgrad_h(x_h.data_ptr(), dy_h.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, OH, OW, Cout, KH, KW, stride[0],
-                                     stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0, _p(ws), wsb, _stream()),
+        check(lib.v2a_conv2d_wgrad_h(x_h.data_ptr(), _p(x2_h if x2 is not None else None), dy_h.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W,
+                                     C1, C2, OH, OW, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0,
+                                     1 if accumulate else 0, _p(ws), wsb, _stream()),
               "conv2d_wgrad_h")
         last_kernel[0] = "conv_wgrad_bf16h<128,128>" if Cout > 64 else "conv_wgrad_bf16h<64,128>"
         return dw

@@ -478,13 +478,16 @@ class PolicyEngine:
         c1 = self._c1d(a0, r["c1"], k, keep_h=ka)
         a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish")
         a1 = a1.view(B, T, co)
-        x_h = kx[0] if (kx and x2 is None) else None             # single-source blocks: the twin also serves rc and both weight gradients
+        x_h = kx[0] if kx else None                              # the twins also serve rc's and both weight gradients
+        x2_h = kx[1] if (len(kx) > 1 and x2 is not None) else None
+        if x2 is not None and x2_h is None:
+            x_h = None
         if r["rc"] is not None:
             out = self._c1d(x, r["rc"], 1, x2=x2, residual=a1, pad=0)
         else:
             out = ops.axpy(a1, x)
         if save is not None:
-            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None, x_h=x_h))
+            save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None, x_h=x_h, x2_h=x2_h))
         return out
 
     def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True):
@@ -513,14 +516,15 @@ class PolicyEngine:
             self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
             dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0),
                           residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
-        xh = st.get("x_h")
+        xh, x2h = st.get("x_h"), st.get("x2_h")
         dc0h = self._twin_dy(dc0, xh, co)
-        self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname], x_h=xh, dy_h=dc0h)
+        self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname], x_h=xh, dy_h=dc0h,
+                 x2_h=x2h)
         rc = r["rc"]
         d4h = None
         if rc is not None:
             d4h = self._twin_dy(d4, xh, co)
-            self._wg(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname], x_h=xh, dy_h=d4h)
+            self._wg(x4, d4, rc.shape, 1, 1, x2=x24, dw=grads[rc.wname], dbias=grads[rc.bname], x_h=xh, dy_h=d4h, x2_h=x2h)
         if not need_dx:
             return None, None, dmgf
         if rc is not None:
