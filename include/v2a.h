@@ -112,14 +112,16 @@ int v2a_colsum(const float* x, float* out, int rows, int cols, int accumulate, v
 /* kind 0: SinusoidalPosEmb (diffuser/diffusion_policy/model/positional_embedding.py:10-17); kind 1: timestep_embedding (.../nn.py:171-189) */
 int v2a_sincos_embed(const int64_t* t, float* out, int B, int dim, int kind, v2a_stream_t s);
 /* normalise actions + DDPMScheduler.add_noise (diffusion_unet_image_policy.py:255; normalizer.py:139-146) */
-int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const float* alphas_cumprod, float* out, int B, int per, v2a_stream_t s);
+/* act_min / act_max [act_dim]: the action limits of shape_meta (lb_train_diffusion_unet_image_orn10.yaml:27); NULL = -1 / +1 */
+int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const float* alphas_cumprod, float* out, int B, int per,
+                  const float* act_min, const float* act_max, int act_dim, v2a_stream_t s);
 /* F.mse_loss(...).mean() and its gradient (diffusion_unet_image_policy.py:273-276) */
 int v2a_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int n, v2a_stream_t s);
 /* DDPMScheduler.step (mode 0) / DDIMScheduler.step (mode 1) on the action trajectory (diffusion_unet_image_policy.py:121-128) */
 int v2a_policy_sched_step(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb, float c_sa,
                           float c0, float c1, float sigma, int mode, v2a_stream_t s);
-/* LimitsConstNormalizer.unnormalize for the Libero action limits (normalizer.py:148-161) */
-int v2a_unnormalize_action(const float* x, float* out, int n, v2a_stream_t s);
+/* LimitsConstNormalizer.unnormalize with the policy's action limits (normalizer.py:148-161); NULL limits = -1 / +1 */
+int v2a_unnormalize_action(const float* x, float* out, int n, const float* act_min, const float* act_max, int act_dim, v2a_stream_t s);
 /* NCHW -> NHWC (+ 2x-1 image normalisation, normalizer.py:139-146; uint8 / 255, diffuser/datasets/img_utils.py:27-37) */
 int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);
 int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);

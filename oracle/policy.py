@@ -43,6 +43,8 @@ class PolicyCfg:
     num_inference_steps_ddim: int = 8
     # ResNet-18 widths (torchvision): only overridden by tiny test configs
     widths: tuple = (64, 128, 256, 512)
+    act_min: tuple = None        # per-channel action limits of shape_meta (None = the Libero -1 / +1, diffuser/datasets/__init__.py:21-27)
+    act_max: tuple = None
 
 
 LIBERO_POLICY = PolicyCfg()
@@ -53,15 +55,25 @@ def normalize_img(x):
     return 2 * ((x - 0.0) / (1.0 - 0.0)) - 1
 
 
-def normalize_act(a):
-    return 2 * ((a + 1.0) / 2.0) - 1
+def _limits(cfg, like):
+    lo = torch.full((like.shape[-1],), -1.0) if cfg is None or cfg.act_min is None else torch.tensor(cfg.act_min, dtype=torch.float32)
+    hi = torch.full((like.shape[-1],), 1.0) if cfg is None or cfg.act_max is None else torch.tensor(cfg.act_max, dtype=torch.float32)
+    return lo, hi
 
 
-def unnormalize_act(x):
+def normalize_act(a, cfg=None):
+    """LimitsConstNormalizer.normalize (normalizer.py:139-146)."""
+    lo, hi = _limits(cfg, a)
+    return 2 * ((a - lo) / (hi - lo)) - 1
+
+
+def unnormalize_act(x, cfg=None):
+    """LimitsConstNormalizer.unnormalize (normalizer.py:148-161): clamp only when something is out of range."""
+    lo, hi = _limits(cfg, x)
     if x.max() > 1 or x.min() < -1:
         x = torch.clamp(x, -1, 1)
     x = (x + 1) / 2.0
-    return x * 2.0 + (-1.0)
+    return x * (hi - lo) + lo
 
 
 # ----------------------------------------------------------------------------- image encoder
@@ -182,7 +194,7 @@ def cond_unet1d(P, sample, t, global_cond, cfg: PolicyCfg, pre="model."):
 def compute_loss(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY):
     """compute_loss with the two RNG draws (randn then randint, :246-252) injected."""
     nobs = {k: normalize_img(v)[:, 0] for k, v in batch["obs"].items()}
-    nact = normalize_act(batch["action"])
+    nact = normalize_act(batch["action"], cfg)
     gc = obs_encoder(P, nobs, cfg).reshape(nact.shape[0], -1)
     ac = S.squaredcos_alphas_cumprod(cfg.num_train_timesteps)
     noisy = S.add_noise(ac, nact, noise, timesteps)
@@ -227,6 +239,6 @@ def predict_action(P, obs, init_noise, step_noises, cfg: PolicyCfg = LIBERO_POLI
                 nz = step_noises[k]
                 k += 1
             traj = S.ddpm_step(ac, eps, t, traj, nz)
-    act = unnormalize_act(traj[..., :cfg.action_dim])
+    act = unnormalize_act(traj[..., :cfg.action_dim], cfg)
     start = cfg.n_obs_steps - 1
     return {"action": act[:, start:start + cfg.n_action_steps], "action_pred": act}

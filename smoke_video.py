@@ -1,4 +1,5 @@
-"""Tiny video-UNet denoise step on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke)."""
+"""Tiny video-UNet denoise step on cuda:0 checked against the CPU oracle.  Checker-side code (it imports oracle/): lives next to
+__graft_entry__.py, not inside the product package."""
 import torch
 
 

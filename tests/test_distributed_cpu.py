@@ -1,6 +1,8 @@
-"""world_size-2 gloo test of the data-parallel path: the gradient arena all-reduce + 1/world scaling + identical replicas.
-The HIP kernels cannot run here; what is exercised is exactly the host logic PolicyTrainer uses around them: a flat fp32 arena,
-ONE sum all-reduce, averaging folded into the optimiser, per-rank RNG / replay shards, replicas staying bit-identical."""
+"""world_size-2 gloo tests of the data-parallel path.  The HIP kernels cannot run here; what runs is the product's own exchange
+code -- v2a_hip.dp.GradReducer, the object PolicyTrainer drives on the GPU (two asynchronous slice all-reduces of one flat fp32
+arena in gradient-ready order, averaging folded into the consumer) -- plus the native replay sampler on per-rank generator states:
+gradient equality (N ranks x B/N rows == 1 rank x B rows, the reference's DDP mean: lb_online_trainer_v7.py:604-608), replicas
+staying bit-identical, and loud failure when ranks disagree on the collective layout."""
 import os
 import sys
 import numpy as np
@@ -33,14 +35,18 @@ def _worker(rank, world, port, out):
     st = O.EmaState(power=0.75)
     np.random.seed(100 + rank); random.seed(100 + rank)      # per-rank replay stream (trainer: seed + rank)
     lens = np.full(12, 121, dtype=np.int32)
+    from v2a_hip.dp import GradReducer
+    red = GradReducer(arena, [(300, total), (0, 300)], dist.group.WORLD, world)      # second tensor's slice is ready first
     for step in range(1, 4):
         ep, start = sample_indices(lens, 8, 16)              # native sampler on this rank's own generator states
         g = torch.Generator().manual_seed(1000 * rank + step)
-        for v in views:
-            v.copy_(torch.randn(v.shape, generator=g) + float(ep.sum() % 7))
-        dist.all_reduce(arena, op=dist.ReduceOp.SUM)         # the ONE collective of the path (RCCL on the GPU box)
-        arena.mul_(1.0 / world)                              # v2a_opt_scale_grads
+        views[1].copy_(torch.randn(views[1].shape, generator=g) + float(ep.sum() % 7))
+        red.launch(0)                                        # travels while the rest of the "backward" runs
+        views[0].copy_(torch.randn(views[0].shape, generator=g) + float(ep.sum() % 7))
+        red.launch(1)
+        red.finish()                                         # wait + 1/world (the fused optimiser's gradient scale on the GPU)
         O.train_tail(params, [v.clone() for v in views], ms, vs, em, step, st)
+    assert red.launches == 6 and red.bytes_per_step() == 4 * total
     gathered = [torch.zeros(total) for _ in range(world)]
     dist.all_gather(gathered, torch.cat([p.flatten() for p in params]))
     if rank == 0:
@@ -103,3 +109,88 @@ def test_video_trainer_arena_allreduce_two_ranks():
     assert res[0] == res[1]
     for n, v in res[0].items():
         assert abs(v - 1.5 * (1 + len(n))) < 1e-6                     # mean of rank values (1, 2) x the per-parameter factor
+
+
+def _equality_worker(rank, world, port, out):
+    """Gradient equality: rank r holds the gradient of the mean loss over ITS half of the rows; sum / world must equal the
+    gradient of the mean over all rows, which is what clip + AdamW then consume."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2a_hip.dp import GradReducer
+    torch.manual_seed(3)
+    w = torch.randn(40, 9, dtype=torch.float64)
+    x = torch.randn(8, 9, dtype=torch.float64)
+    y = torch.randn(8, 40, dtype=torch.float64)
+
+    def grad(rows):                                           # d/dw mean((x w^T - y)^2) over the given rows
+        r = x[rows] @ w.T - y[rows]
+        return (2.0 / r.numel()) * r.T @ x[rows]
+
+    full = grad(slice(0, 8)).float().flatten()
+    arena = torch.zeros(360)
+    arena.copy_(grad(slice(4 * rank, 4 * rank + 4)).float().flatten())
+    red = GradReducer(arena, [(0, 200), (200, 360)], dist.group.WORLD, world)
+    red.launch(0); red.launch(1)
+    try:
+        red.launch(1)
+        raised = False
+    except RuntimeError:
+        raised = True
+    red.finish()
+    out.put((rank, float((arena - full).abs().max()), float(full.abs().max()), raised))
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_equality_two_ranks_vs_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + os.getpid() % 500
+    procs = [ctx.Process(target=_equality_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, scale, raised in res:
+        assert err <= 1e-6 * scale, (rank, err, scale)
+        assert raised                                         # launching a slice twice in one step is refused
+
+
+def _mismatch_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2a_hip.dp import GradReducer
+    arena = torch.zeros(100)
+    res = []
+    for slices in ([(0, 60 + rank), (60 + rank, 100)], [(0, 50)] if rank == 0 else [(0, 25), (25, 50)]):
+        try:
+            GradReducer(arena, slices, dist.group.WORLD, world)
+            res.append("accepted")
+        except RuntimeError as e:
+            res.append(str(e)[:40])
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_dp_layout_disagreement_fails_loudly_on_every_rank():
+    """a per-rank fallback decision would issue mismatched collectives (a hang under RCCL).  There is no fallback any
+    more, and ranks whose slice tables differ -- in boundaries or in count -- refuse to start, all of them."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31300 + os.getpid() % 500
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert all(r.startswith("data-parallel ranks disagree") for r in res[rank]), res

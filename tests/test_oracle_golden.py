@@ -169,6 +169,45 @@ def test_oracle_policy_vs_reference(golden_dir):
     assert rel(o["action_pred"], g["ddim_action_pred"]) < 1e-6 and rel(o["action"], g["ddim_action"]) < 1e-6
 
 
+def test_oracle_policy_action_limits_vs_reference(golden_dir):
+    """Non-identity action limits (lb_action_minmax_orn01, diffuser/datasets/__init__.py:30-37): the oracle's normalise /
+    unnormalise against the reference run with that normaliser; the product shell accepts the limits and rejects what the HIP
+    loaders do not implement (wrong limits must fail, not mis-scale)."""
+    import copy
+    import dataclasses
+    from oracle import policy as OP
+    from oracle.param_fill import fill_module
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF, _RESOLVERS
+    g = np.load(f"{golden_dir}/policy_orn01.npz")
+    p0 = np.load(f"{golden_dir}/policy.npz", allow_pickle=True)
+    conf = copy.deepcopy(DEFAULT_CONF)
+    img = {"shape": [3, 128, 128], "minmax_shape": _RESOLVERS["image_minmax_01"](), "type": "rgb"}
+    conf["shape_meta"] = {"obs": {"img_obs_1": dict(img), "img_goal_1": dict(img)},
+                          "action": {"shape": [7], "minmax_shape": _RESOLVERS["lb_action_minmax_orn01"]()}}
+    torch.manual_seed(0)
+    pol = build_policy(conf)
+    sd = fill_module(pol, seed=13)
+    assert np.allclose(pol._cfg.act_limits[1], g["act_max"]) and np.allclose(pol._cfg.act_limits[0], g["act_min"])
+    cfg = dataclasses.replace(OP.LIBERO_POLICY, act_min=tuple(g["act_min"].tolist()), act_max=tuple(g["act_max"].tolist()))
+    batch = {"obs": {"img_obs_1": torch.from_numpy(p0["img_obs"]), "img_goal_1": torch.from_numpy(p0["img_goal"])},
+             "action": torch.from_numpy(g["action"])}
+    loss = OP.compute_loss(sd, batch, torch.from_numpy(g["noise"]), torch.from_numpy(g["timesteps"]), cfg)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    torch.manual_seed(70)
+    o = OP.predict_action(sd, batch["obs"], torch.randn(2, 16, 7), [], cfg, use_ddim=True)
+    assert rel(o["action_pred"], g["ddim_action_pred"]) < 1e-6
+    # what the fused loaders do not implement is refused at construction
+    bad = copy.deepcopy(conf)
+    bad["shape_meta"]["obs"]["img_obs_1"]["minmax_shape"] = (np.zeros(3, np.float32), np.full(3, 255, np.float32), [1, 3, 1, 1])
+    with pytest.raises(NotImplementedError):
+        build_policy(bad)
+    from diffuser.diffusion_policy import schedulers as S
+    sch = S.DDPMScheduler(num_train_timesteps=100, beta_schedule="squaredcos_cap_v2", clip_sample=True, prediction_type="epsilon")
+    sch.alphas_cumprod = torch.linspace(0.999, 0.01, 100)                       # e.g. a linear-beta scheduler object
+    with pytest.raises(NotImplementedError):
+        type(pol)._check_fused_constants(conf["shape_meta"], sch, None)
+
+
 def test_oracle_optimiser_vs_torch():
     """oracle/optim.py against torch.optim.AdamW + clip_grad_norm_ (both present here) and the ema decay formula."""
     from oracle import optim as O

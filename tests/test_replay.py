@@ -100,3 +100,89 @@ def test_store_gather_matches_reference_semantics(golden_dir):
     o0, o1, _ = st8.gather(np.array([0]), np.array([2]))
     assert torch.equal(o0[0].cpu(), raw[2].permute(2, 0, 1).float() / 255.0)
     assert torch.equal(o1[0].cpu(), raw[18].permute(2, 0, 1).float() / 255.0)
+
+
+def _decode(codes):
+    which = codes // 1000000
+    return which, (codes % 1000000) // 1000, codes % 1000
+
+
+def test_mixed_two_buffer_draw_vs_reference_golden(golden_dir):
+    """replay_mixed.npz was produced by the reference's LB_Online_Trainer_V7.sample_from_bufs ('rand_prob', :826-851) + merge_batch
+    (train_utils.py:40-74) over two of its own buffers: the oracle's C restatement and the product's native sampler must both give the
+    same (n_rand, episode, start) stream -- rand rows first -- and leave numpy's / CPython's generators where the reference left them."""
+    from oracle import replay as R
+    from v2a_hip.replay import sample_indices, count_uniform_below
+    g = np.load(f"{golden_dir}/replay_mixed.npz")
+    for seed in (0, 77, 4242):
+        lr, lv = g[f"lens_rand_{seed}"], g[f"lens_vid_{seed}"]
+        nps, pys = R.np_seeded(seed), R.py_seeded(seed)
+        np.random.seed(seed); random.seed(seed)
+        for it in range(4):
+            which, ep_ref, st_ref = _decode(g[f"codes_{seed}"][it])
+            n_ref = int(g[f"n_rand_{seed}"][it])
+            assert (which[:n_ref] == 0).all() and (which[n_ref:] == 1).all()
+            n, ep, st = R.sample_mixed(nps, pys, lr, lv, 64, 16, 0.3)                    # oracle
+            assert n == n_ref and (ep == ep_ref).all() and (st == st_ref).all()
+            n2 = count_uniform_below(64, 0.3)                                             # product, on the live generators
+            e0, s0 = sample_indices(lr, n2, 16)
+            e1, s1 = sample_indices(lv, 64 - n2, 16)
+            assert n2 == n_ref
+            assert (np.concatenate([e0, e1]) == ep_ref).all() and (np.concatenate([s0, s1]) == st_ref).all()
+        assert [np.random.randint(0, 1 << 30), random.randint(0, 1 << 30)] == g[f"tail_{seed}"].tolist()
+
+
+@pytest.mark.gpu
+def test_mixed_draw_payload_vs_reference_golden(golden_dir):
+    """sample_mixed over two ReplayStores sharing one HBM pool returns the very rows the reference's sample_from_bufs returned."""
+    from v2a_hip.replay import ReplayStore, sample_mixed
+    g = np.load(f"{golden_dir}/replay_mixed.npz")
+    seed = 77
+    lr, lv = g[f"lens_rand_{seed}"], g[f"lens_vid_{seed}"]
+    a, b = ReplayStore.pair(1200, 600, 700, 30, capacity_a=int(lr.sum()) + 4, capacity_b=int(lv.sum()) + 4, image_hw=(4, 4),
+                            dtype=torch.float32)
+    for which, (store, lens) in enumerate(((a, lr), (b, lv))):
+        for e, L in enumerate(lens):
+            base = which * 1000000 + e * 1000
+            # frames carry the code modulo 2^24-exactness is not needed: float32 holds integers < 16.7 M exactly
+            store.add_one_episode(f"task{which}_{e}", "agentview", e, [torch.full((3, 4, 4), float(base + i)) for i in range(L)],
+                                  [torch.full((7,), float(base + i)) for i in range(L - 1)])
+    np.random.seed(seed); random.seed(seed)
+    for it in range(4):
+        s, gl, act, tasks, info = sample_mixed(a, b, 64, 0.3)
+        codes = g[f"codes_{seed}"][it]
+        assert (s[:, 0, 0, 0].long().cpu().numpy() == codes).all()
+        assert (gl[:, 0, 0, 0].long().cpu().numpy() == codes + 16).all()
+        assert torch.equal(act[:, :, 0].cpu().long(), torch.from_numpy(codes)[:, None] + torch.arange(16)[None])
+        which, ep, _ = _decode(codes)
+        assert tasks == [f"task{w}_{e}" for w, e in zip(which, ep)] and len(info["cams_str"]) == 64
+    assert [np.random.randint(0, 1 << 30), random.randint(0, 1 << 30)] == g[f"tail_{seed}"].tolist()
+
+
+@pytest.mark.gpu
+def test_reference_import_path_buffer_is_a_drop_in(golden_dir):
+    """`from diffuser.datasets.env_img_replay_buffer import Global_EnvReplayBuffer_Img` with the reference's constructor keywords
+    (env_img_replay_buffer.py:12-16) and call sequence, against the reference-made index fixture."""
+    from diffuser.datasets.env_img_replay_buffer import Global_EnvReplayBuffer_Img
+
+    class _EnvList:
+        camera_list = ["agentview"]
+
+    g = np.load(f"{golden_dir}/replay.npz")
+    seed = 9001
+    lens = g[f"lens_{seed}"]
+    buf = Global_EnvReplayBuffer_Img(task_list=["t"], max_num_unitBufs=1200, max_len_uB=700, min_len_uB=30, env_list=_EnvList(),
+                                     render_img_size=(4, 4), env_buf_config={"sample_act_seq_len": 16}, dtype=torch.float32,
+                                     capacity_frames=int(lens.sum()) + 8)
+    for e, L in enumerate(lens):
+        buf.add_one_episode("t", "agentview", e, [torch.full((3, 4, 4), float(e * 1000 + i)) for i in range(L)],
+                            [torch.full((7,), float(e * 1000 + i)) for i in range(L - 1)])
+    assert len(buf.buffers) == len(buf.bufs_task) == len(buf.bufs_cam) == len(lens) and buf.cnt_all_history_episodes == len(lens)
+    np.random.seed(seed); random.seed(seed)
+    for it in range(5):
+        s, gl, a, tasks, info = buf.sample_random_batch_seq(64)
+        assert ((s[:, 0, 0, 0] // 1000).long().cpu().numpy() == g[f"episodes_{seed}"][it]).all()
+        assert ((s[:, 0, 0, 0] % 1000).long().cpu().numpy() == g[f"starts_{seed}"][it]).all()
+        assert set(info) >= {"env_idxs", "cams_str"} and tasks == ["t"] * 64
+    with pytest.raises(KeyError):
+        Global_EnvReplayBuffer_Img(["t"], 10, 700, 30, _EnvList(), (4, 4), env_buf_config={})

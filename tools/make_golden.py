@@ -300,6 +300,88 @@ def g_replay():
     print("replay ok", out["episodes_123"][0][:8], out["starts_123"][0][:8])
 
 
+def g_replay_mixed():
+    """The two-buffer draw: LB_Online_Trainer_V7.sample_from_bufs in 'rand_prob' mode (lb_online_trainer_v7.py:826-851) + merge_batch
+    (diffuser/models/train_utils.py:40-74), called on the REFERENCE method with an attribute bag for `self`; payload encodes
+    (buffer, episode, frame) so that rows can be decoded from the returned tensors."""
+    from types import SimpleNamespace
+    from diffuser.datasets.env_img_replay_buffer import Global_EnvReplayBuffer_Img
+    from diffuser.libero.lb_online_trainer_v7 import LB_Online_Trainer_V7 as Ref
+    assert "/root/reference" in sys.modules[Ref.__module__].__file__
+
+    class _EnvList:
+        camera_list = ["agentview"]
+
+    out = {}
+    for seed in (0, 77, 4242):
+        rng = np.random.RandomState(seed + 5)
+        bufs, lens_all = [], []
+        for which, n_ep in ((0, 10), (1, 6)):
+            lens = rng.randint(40, 90, size=n_ep) if which == 0 else rng.randint(60, 200, size=n_ep)
+            buf = Global_EnvReplayBuffer_Img(task_list=["t"], max_num_unitBufs=1200, max_len_uB=700, min_len_uB=30, env_list=_EnvList(),
+                                             render_img_size=(4, 4), env_buf_config={"sample_act_seq_len": 16})
+            for e, L in enumerate(lens):
+                base = which * 1000000 + e * 1000
+                buf.add_one_episode(f"task{which}_{e}", "agentview", e, [torch.full((3, 4, 4), float(base + i)) for i in range(L)],
+                                    [torch.full((7,), float(base + i)) for i in range(L - 1)])
+            bufs.append(buf); lens_all.append(lens)
+        me = SimpleNamespace(envBuf_rand=bufs[0], envBuf_vid=bufs[1], buf_sample_batch_size=64, buf_sample_method='rand_prob',
+                             buf_sample_randBuf_prob=0.3, input_img_size=(4, 4), init_rand_steps=10, iter_type='rand-bias')
+        np.random.seed(seed); random.seed(seed)
+        rows, nr = [], []
+        for _ in range(4):
+            s, gl, a, tasks, info = Ref.sample_from_bufs(me)
+            code = s[:, 0, 0, 0].long().numpy()
+            assert (gl[:, 0, 0, 0].long().numpy() == code + 16).all() and (a[:, 0, 0].long().numpy() == code).all()
+            assert len(tasks) == 64 and len(info["cams_str"]) == 64
+            which = code // 1000000
+            assert (np.diff(which) >= 0).all()                      # rand rows first, rollout rows after
+            rows.append(code); nr.append(int((which == 0).sum()))
+        out[f"lens_rand_{seed}"], out[f"lens_vid_{seed}"] = lens_all
+        out[f"codes_{seed}"] = np.stack(rows)
+        out[f"n_rand_{seed}"] = np.array(nr)
+        # the stream continues: one more np / python draw after the four batches pins the generator end states
+        out[f"tail_{seed}"] = np.array([np.random.randint(0, 1 << 30), random.randint(0, 1 << 30)])
+    np.savez_compressed(f"{OUT}/replay_mixed.npz", **out)
+    print("replay_mixed ok", out["n_rand_77"], out["codes_77"][0][:6])
+
+
+def g_policy_limits():
+    """Non-identity action limits (lb_action_minmax_orn01: orientation channels in +-0.1, diffuser/datasets/__init__.py:30-37):
+    compute_loss and DDIM-8 predict_action of the reference with that normaliser."""
+    import tools.ref_build as RB
+    from diffuser.datasets import lb_action_minmax_orn01_f
+    import diffuser.datasets as D
+    orig = D.lb_action_minmax_f
+    D.lb_action_minmax_f = lb_action_minmax_orn01_f            # build_ref_policy imports the name at call time
+    try:
+        torch.manual_seed(0)
+        pol = RB.build_ref_policy()
+        sd = fill_module(pol, seed=13)
+        assert float(pol.normalizer["action"].maxs.flatten()[4]) == np.float32(0.1)
+        g = torch.Generator().manual_seed(102)
+        B = 2
+        batch = {"obs": {"img_obs_1": torch.rand(B, 1, 3, 128, 128, generator=g), "img_goal_1": torch.rand(B, 1, 3, 128, 128, generator=g)},
+                 "action": torch.rand(B, 16, 7, generator=g) * 2 - 1}
+        batch["action"][..., 3:6] *= 0.1
+        pol.train()
+        torch.manual_seed(55)
+        loss = pol.compute_loss(batch)
+        torch.manual_seed(55)
+        torch.randn(B, 32, 2); torch.randn(B, 32, 2)
+        noise = torch.randn(B, 16, 7)
+        ts = torch.randint(0, 100, (B,)).long()
+        pol.eval()
+        torch.manual_seed(70)
+        o = pol.predict_action(batch["obs"], use_ddim=True)
+        np.savez_compressed(f"{OUT}/policy_orn01.npz", weights_abs_sum=wsum(sd), action=batch["action"].numpy(), loss=loss.item(),
+                            noise=noise.numpy(), timesteps=ts.numpy(), ddim_action_pred=o["action_pred"].numpy(),
+                            act_min=pol.normalizer["action"].mins.flatten().numpy(), act_max=pol.normalizer["action"].maxs.flatten().numpy())
+        print("policy_orn01 ok loss", loss.item(), float(o["action_pred"].abs().max()))
+    finally:
+        D.lb_action_minmax_f = orig
+
+
 from tests.tools_schedule import _schedule_trace, schedule_stub, SCHEDULE_CFGS  # noqa: E402  (shared with tests/test_joint_loop.py)
 
 
@@ -315,7 +397,7 @@ def g_schedule():
     print("schedule ok", {k: v.shape for k, v in out.items()})
 
 
-GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer}
+GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

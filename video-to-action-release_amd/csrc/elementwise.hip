@@ -62,14 +62,17 @@ __global__ void sincos_embed_kernel(const int64_t* t, float* out, int B, int dim
 }
 
 // ----------------------------------------------------------------------------------------- policy DDPM glue
-// noisy = sqrt(ac[t_b]) * act + sqrt(1 - ac[t_b]) * noise   (reference diffusion_unet_image_policy.py:255; normalise = identity for
-// the Libero action limits [-1, 1]: normalizer.py:139-146 gives 2*((a+1)/2)-1 which is evaluated literally here)
-__global__ void add_noise_kernel(const float* act, const float* noise, const int64_t* t, const float* ac, float* out, int B, int per) {
+// noisy = sqrt(ac[t_b]) * normalise(act) + sqrt(1 - ac[t_b]) * noise   (reference diffusion_unet_image_policy.py:255).  normalise is
+// LimitsConstNormalizer.normalize (normalizer.py:139-146), 2*((a-min)/(max-min))-1 evaluated literally, with the per-channel action
+// limits of the policy's shape_meta (amin / amax [act_dim]; NULL = the Libero limits -1 / +1).
+__global__ void add_noise_kernel(const float* act, const float* noise, const int64_t* t, const float* ac, float* out, int B, int per,
+                                 const float* amin, const float* amax, int act_dim) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * per) return;
     const int b = i / per;
     const float a = ac[t[b]];
-    const float na = 2.0f * ((act[i] - (-1.0f)) / (1.0f - (-1.0f))) - 1.0f;
+    const float lo = amin ? amin[i % act_dim] : -1.0f, hi = amax ? amax[i % act_dim] : 1.0f;
+    const float na = 2.0f * ((act[i] - lo) / (hi - lo)) - 1.0f;
     out[i] = sqrtf(a) * na + sqrtf(1.0f - a) * noise[i];
 }
 // loss = mean((pred - target)^2) ; dpred = 2 (pred - target) / n      (single workgroup: n = B*16*7 is tiny)
@@ -181,8 +184,10 @@ __global__ void policy_sched_step_kernel(const float* eps, const float* sample, 
     }
     out[i] = v;
 }
-// unnormalize actions: clamp to [-1,1] only if ANY element is out of range (normalizer.py:152-157), then (x+1)/2*2-1.
-__global__ __launch_bounds__(256) void unnormalize_action_kernel(const float* x, float* out, int n) {
+// unnormalize actions: clamp to [-1,1] only if ANY element is out of range (normalizer.py:152-157), then (x+1)/2*(max-min)+min with
+// the per-channel action limits (NULL = -1 / +1).
+__global__ __launch_bounds__(256) void unnormalize_action_kernel(const float* x, float* out, int n, const float* amin, const float* amax,
+                                                                 int act_dim) {
     __shared__ int any;
     if (threadIdx.x == 0) any = 0;
     __syncthreads();
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(256) void unnormalize_action_kernel(const float* x,
         float v = x[i];
         if (clampit) v = fminf(fmaxf(v, -1.f), 1.f);
         v = (v + 1.f) / 2.0f;
-        out[i] = v * (1.0f - (-1.0f)) + (-1.0f);
+        const float lo = amin ? amin[i % act_dim] : -1.0f, hi = amax ? amax[i % act_dim] : 1.0f;
+        out[i] = v * (hi - lo) + lo;
     }
 }
 
@@ -440,8 +446,11 @@ int v2a_sincos_embed(const int64_t* t, float* out, int B, int dim, int kind, hip
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
-int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const float* alphas_cumprod, float* out, int B, int per, hipStream_t s) {
-    hipLaunchKernelGGL(add_noise_kernel, dim3((B * per + 255) / 256), dim3(256), 0, s, act, noise, t, alphas_cumprod, out, B, per);
+int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const float* alphas_cumprod, float* out, int B, int per,
+                  const float* act_min, const float* act_max, int act_dim, hipStream_t s) {
+    if ((act_min == nullptr) != (act_max == nullptr) || (act_min && (act_dim <= 0 || per % act_dim))) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((B * per + 255) / 256), dim3(256), 0, s, act, noise, t, alphas_cumprod, out, B, per,
+                       act_min, act_max, act_dim > 0 ? act_dim : 1);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -456,8 +465,9 @@ int v2a_policy_sched_step(const float* eps, const float* sample, const float* no
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
-int v2a_unnormalize_action(const float* x, float* out, int n, hipStream_t s) {
-    hipLaunchKernelGGL(unnormalize_action_kernel, dim3(1), dim3(256), 0, s, x, out, n);
+int v2a_unnormalize_action(const float* x, float* out, int n, const float* act_min, const float* act_max, int act_dim, hipStream_t s) {
+    if ((act_min == nullptr) != (act_max == nullptr) || (act_min && (act_dim <= 0 || n % act_dim))) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(unnormalize_action_kernel, dim3(1), dim3(256), 0, s, x, out, n, act_min, act_max, act_dim > 0 ? act_dim : 1);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

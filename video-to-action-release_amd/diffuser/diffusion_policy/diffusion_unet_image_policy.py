@@ -7,6 +7,7 @@ import copy
 import weakref
 from types import SimpleNamespace
 from typing import Dict
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -70,16 +71,48 @@ class DiffusionUnetImagePolicy(BaseImagePolicy):
             num_inference_steps = noise_scheduler.config.num_train_timesteps
         self.num_inference_steps = num_inference_steps
         self.num_inference_steps_ddim = num_inference_steps_ddim
+        self._check_fused_constants(shape_meta, noise_scheduler, noise_scheduler_ddim)
+        a_min, a_max, _ = shape_meta["action"]["minmax_shape"]
+        a_min, a_max = np.asarray(a_min, dtype=np.float32).reshape(-1), np.asarray(a_max, dtype=np.float32).reshape(-1)
+        act_limits = None if (np.all(a_min == -1.0) and np.all(a_max == 1.0)) else (a_min, a_max)
         img_shape = tuple(next(iter(shape_meta["obs"].values()))["shape"])
         core = next(iter(obs_encoder.key_model_map.values()))
         self._cfg = SimpleNamespace(
             image_hw=img_shape[1:], action_dim=action_dim, horizon=horizon, dsed=diffusion_step_embed_dim,
             down_dims=tuple(down_dims), kernel_size=kernel_size, n_groups=n_groups, num_kp=core.pool._num_kp,
             feature_dim=core.feature_dimension, rgb_keys=tuple(obs_encoder.rgb_keys),
-            num_train_timesteps=noise_scheduler.config.num_train_timesteps, widths=tuple(core.backbone._widths))
+            num_train_timesteps=noise_scheduler.config.num_train_timesteps, widths=tuple(core.backbone._widths),
+            act_limits=act_limits)
         self.__dict__["_engine"] = None
         # injected-RNG hook for parity tests: callable(shape, kind) -> tensor, kind in {"noise", "timesteps", "init", "step"}
         self.__dict__["_rng_hook"] = None
+
+    @staticmethod
+    def _check_fused_constants(shape_meta, sched, sched_ddim):
+        """The HIP loaders fuse the image normalisation (2x-1 of [0,1] pixels) and evaluate the squaredcos_cap_v2 / epsilon /
+        clip_sample schedule from its closed form.  Anything else must fail HERE, not come out silently mis-scaled."""
+        from v2a_hip.policy_engine import squaredcos_alphas_cumprod
+        for key, val in shape_meta["obs"].items():
+            lo, hi, _ = val["minmax_shape"]
+            if not (np.all(np.asarray(lo) == 0.0) and np.all(np.asarray(hi) == 1.0)):
+                raise NotImplementedError(f"image limits of {key!r} are {lo}..{hi}: the fused image loader implements [0, 1] -> [-1, 1] only")
+        a_lo, a_hi, _ = shape_meta["action"]["minmax_shape"]
+        if not np.all(np.asarray(a_hi, dtype=np.float64) > np.asarray(a_lo, dtype=np.float64)):
+            raise ValueError("action limits need max > min in every channel")
+        n = sched.config.num_train_timesteps
+        want = squaredcos_alphas_cumprod(n)
+        for name, sc in (("noise_scheduler", sched), ("noise_scheduler_ddim", sched_ddim)):
+            if sc is None:
+                continue
+            cfg = sc.config
+            if getattr(cfg, "prediction_type", "epsilon") != "epsilon" or not getattr(cfg, "clip_sample", True):
+                raise NotImplementedError(f"{name}: the fused scheduler step implements prediction_type='epsilon' with clip_sample=True")
+            if cfg.num_train_timesteps != n:
+                raise ValueError("both schedulers must share num_train_timesteps")
+            ac = torch.as_tensor(sc.alphas_cumprod, dtype=torch.float32).cpu()
+            if ac.shape != want.shape or float((ac - want).abs().max()) > 1e-6:
+                raise NotImplementedError(f"{name}: alphas_cumprod is not the squaredcos_cap_v2 table the HIP kernels evaluate "
+                                          f"(beta_schedule={getattr(cfg, 'beta_schedule', '?')!r})")
 
     # ------------------------------------------------------------------ engine plumbing
     def __deepcopy__(self, memo):
@@ -166,7 +199,7 @@ class DiffusionUnetImagePolicy(BaseImagePolicy):
                 eps = eng.unet_fwd(traj, tt, gc)
                 noise = self._draw((B, T, Da), "step", dev).float().contiguous() if t > 0 else None
                 traj = ops.policy_sched_step(eps, traj, noise, ddpm_coeffs(eng.ac_host, t, Ttr), mode=0)
-        action_pred = ops.unnormalize_action(traj).detach()
+        action_pred = ops.unnormalize_action(traj, eng.act_limits).detach()
         start = To - 1
         return {"action": action_pred[:, start:start + self.n_action_steps], "action_pred": action_pred}
 

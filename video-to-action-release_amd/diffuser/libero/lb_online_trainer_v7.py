@@ -22,9 +22,7 @@ import contextlib
 import json
 import os
 import os.path as osp
-import random
 from copy import deepcopy
-from functools import partial
 from pathlib import Path
 
 import numpy as np
@@ -48,6 +46,27 @@ def cycle(dl):
     while True:
         for data in dl:
             yield data
+
+
+_PHASES = ('explo', 'no-explo')
+
+
+def _tick_phase(obj, buf, counted, quota, always_check):
+    """One call of the explore / pause machine of buffer `buf` ('rand' | 'vid'); state lives on `obj` under the reference's
+    attribute names (explo_type_<buf>, cnt_exp_<buf>, cnt_no_exp_<buf>: they are checkpoint / logging surface)."""
+    kind_attr = f'explo_type_{buf}'
+    counter = {'explo': f'cnt_exp_{buf}', 'no-explo': f'cnt_no_exp_{buf}'}
+    if counted:
+        kind = getattr(obj, kind_attr)
+        if kind not in counter:
+            raise AssertionError(f"unknown exploration phase {kind!r}")
+        setattr(obj, counter[kind], getattr(obj, counter[kind]) + 1)
+    elif not always_check:
+        return
+    for i, kind in enumerate(_PHASES):
+        if getattr(obj, counter[kind]) == quota[i]:
+            setattr(obj, counter[kind], 0)
+            setattr(obj, kind_attr, _PHASES[1 - i])
 
 
 class _Accelerator:
@@ -153,7 +172,9 @@ class _EMAHandle:
 
     def state_dict(self):
         _, ema_step, initted = self._t.opt.counters()
-        sd = {f"online_model.{k}": v for k, v in self._t.policy.state_dict().items()}
+        sd = {}
+        if self._t.ema_include_online_model:            # ema_pytorch 0.2.3: `include_online_model=False` keeps online_model.* out
+            sd.update({f"online_model.{k}": v for k, v in self._t.policy.state_dict().items()})
         sd.update({f"ema_model.{k}": v for k, v in self._t.ema_policy.state_dict().items()})
         sd["initted"] = torch.tensor([initted])
         sd["step"] = torch.tensor([ema_step])
@@ -347,20 +368,15 @@ class LB_Online_Trainer_V7(object):
         return self.accelerator.device
 
     # ------------------------------------------------------------------------------------------------------ checkpoints
+    # keys of the reference's checkpoint dict (lb_online_trainer_v7.py:371-382): the compatibility contract of save / load
+    _CKPT_SCALARS = ('step', 'num_steps_in_env', 'cnt_vid_rollouts', 'cnt_vid_rout_per_tk')
+
     def save(self, milestone):
         if not self.accelerator.is_local_main_process:
             return
-        data = {
-            'step': self.step,
-            'num_steps_in_env': self.num_steps_in_env,
-            'gcp_model': self.accelerator.get_state_dict(self.gcp_model),
-            'opt': self.opt.state_dict(),
-            'ema': self.ema.state_dict(),
-            'scaler': None,
-            'version': __version__,
-            'cnt_vid_rollouts': self.cnt_vid_rollouts,
-            'cnt_vid_rout_per_tk': self.cnt_vid_rout_per_tk,
-        }
+        data = {k: getattr(self, k) for k in self._CKPT_SCALARS}
+        data.update(gcp_model=self.accelerator.get_state_dict(self.gcp_model), opt=self.opt.state_dict(), ema=self.ema.state_dict(),
+                    scaler=None, version=__version__)
         savepath = str(self.results_folder / f'model-{milestone}.pt')
         torch.save(data, savepath)
         utils.print_color(f'[ utils/training ] Saved model to {savepath}', c='y')
@@ -381,16 +397,6 @@ class LB_Online_Trainer_V7(object):
         return self.text_encoder(**ids).last_hidden_state
 
     # ---------------------------------------------------------------------------------------------------- env utilities
-    def reset_all_envs(self):
-        self.env_list.check_no_envs_exist()
-
-    def reset_given_envs(self, tasks_str, env_idxs):
-        self.env_list.recreate_given_envs(tasks_str, env_idxs, is_rand=True)
-        for i_sam, tk in enumerate(tasks_str):
-            e_idx = env_idxs[i_sam]
-            assert e_idx in self.task_env_states[tk].keys()
-            self.task_env_states[tk][e_idx] = self.env_list.env_init_states[tk][e_idx]
-
     def env_get_preproc_imgs(self, tasks_str, cams_str, env_idxs):
         assert len(tasks_str) == 1
         imgs = []
@@ -400,49 +406,16 @@ class LB_Online_Trainer_V7(object):
             imgs.append(img)
         return self.rendered_imgs_preproc_fn(np.array(imgs))
 
-    def env_get_preproc_img(self, tk, cam_name, env_idx):
-        tmp_img = self.env_list.render_an_env_with_preproc(tk, cam_name, env_idx, imgs_preproc_fn=partial(self.rendered_imgs_preproc_fn))
-        assert tmp_img.shape[1:3] == self.input_img_size
-        return tmp_img
-
-    def get_is_envs_exception(self, tasks_str, env_idxs):
-        return [False for _ in tasks_str]
-
-    def get_new_env_buffer(self, max_num_unitBufs):
-        return ReplayStore(max_num_unitBufs, self.max_len_uB, self.min_len_uB, image_hw=self.input_img_size, act_dim=self.act_dim,
-                           act_len=self.model_act_horizon, device=self.device)
-
     # --------------------------------------------------------------------------------------------------- schedule logic
     def update_explo_type(self):
-        """Alternate `explo` / `no-explo` phases per buffer once it holds enough episodes (reference :432-468)."""
+        """Per buffer, alternate an exploring phase and a pause once the buffer holds `noExp_start_buf_len_*` episodes: a phase ends
+        after `Exp_noExp_*[phase]` counted calls.  Behaviour pinned by a trace of the reference's method (:432-468) over three
+        configurations (tests/golden/schedule.npz); the rand buffer evaluates its phase ends on every call, the rollout buffer only
+        on counted calls -- visible when a quota is 0."""
         if not self.enable_noExp:
             return
-        if len(self.envBuf_rand) >= self.noExp_start_buf_len_rand:
-            if self.explo_type_rand == 'no-explo':
-                self.cnt_no_exp_rand += 1
-            elif self.explo_type_rand == 'explo':
-                self.cnt_exp_rand += 1
-            else:
-                assert False
-        if self.cnt_exp_rand == self.Exp_noExp_rand[0]:
-            self.cnt_exp_rand = 0
-            self.explo_type_rand = 'no-explo'
-        if self.cnt_no_exp_rand == self.Exp_noExp_rand[1]:
-            self.cnt_no_exp_rand = 0
-            self.explo_type_rand = 'explo'
-        if len(self.envBuf_vid) >= self.noExp_start_buf_len_vid:
-            if self.explo_type_vid == 'no-explo':
-                self.cnt_no_exp_vid += 1
-            elif self.explo_type_vid == 'explo':
-                self.cnt_exp_vid += 1
-            else:
-                assert False
-            if self.cnt_exp_vid == self.Exp_noExp_vid[0]:
-                self.cnt_exp_vid = 0
-                self.explo_type_vid = 'no-explo'
-            if self.cnt_no_exp_vid == self.Exp_noExp_vid[1]:
-                self.cnt_no_exp_vid = 0
-                self.explo_type_vid = 'explo'
+        _tick_phase(self, 'rand', len(self.envBuf_rand) >= self.noExp_start_buf_len_rand, self.Exp_noExp_rand, always_check=True)
+        _tick_phase(self, 'vid', len(self.envBuf_vid) >= self.noExp_start_buf_len_vid, self.Exp_noExp_vid, always_check=False)
 
     def update_iter_type(self):
         """rand-bias for the first `init_rand_steps`, then cycles of rand_cycle_steps / vid_cycle_steps (reference :942-970)."""
@@ -469,6 +442,28 @@ class LB_Online_Trainer_V7(object):
         self.step += 1
         return loss
 
+    def _explore_due(self, every, phase):
+        """Exploration of one kind runs on every `every`-th step after the initial random phase, while its phase is 'explo'."""
+        return self.step > self.init_rand_steps and self.step % every == 0 and phase == 'explo'
+
+    def _top_up_rand_buffer(self):
+        """The next `rand_explo_num_Ep_per_tk` episodes per task from the random-action file; the cursor wraps around the file, a
+        window never straddles its end (reference :517-526)."""
+        per_task = self.h5_total_num_ep_per_task
+        first = self.h5_randsam_start_idx % per_task
+        count = min(per_task - first, self.rand_explo_num_episodes_per_tk)
+        self.h5_add_rand_act_episodes_to_Buf(first, first + count)
+        self.h5_randsam_start_idx += count
+        self.is_all_randsam_visited = self.is_all_randsam_visited or self.h5_randsam_start_idx >= per_task
+
+    def _count_iteration(self):
+        counter = {'rand-bias': 'rand_iter_cnt', 'vid-bias': 'vid_iter_cnt'}.get(self.iter_type)
+        if counter is None:
+            raise NotImplementedError(self.iter_type)
+        if self.iter_type == 'vid-bias' and len(self.envBuf_rand) == 0 and self.init_rand_steps != -1:
+            raise AssertionError("vid-bias iterations need a non-empty random buffer")
+        setattr(self, counter, getattr(self, counter) + 1)
+
     def train(self):
         acc = self.accelerator
         timer = utils.Timer()
@@ -483,22 +478,11 @@ class LB_Online_Trainer_V7(object):
         while self.step < self.train_num_steps:
             self.update_iter_type()
             self.update_explo_type()
-            if self.step > self.init_rand_steps and self.step % self.video_explo_freq == 0 and self.explo_type_vid == 'explo':
+            if self._explore_due(self.video_explo_freq, self.explo_type_vid):
                 self.video_guided_explore()
-            if self.step > self.init_rand_steps and self.step % self.rand_explo_freq == 0 and self.explo_type_rand == 'explo':
-                st_idx = self.h5_randsam_start_idx % self.h5_total_num_ep_per_task
-                n_add = min(self.h5_total_num_ep_per_task - st_idx, self.rand_explo_num_episodes_per_tk)
-                self.h5_add_rand_act_episodes_to_Buf(st_idx, st_idx + n_add)
-                self.h5_randsam_start_idx += n_add
-                if self.h5_randsam_start_idx >= self.h5_total_num_ep_per_task:
-                    self.is_all_randsam_visited = True
-            if self.iter_type == 'rand-bias':
-                self.rand_iter_cnt += 1
-            elif self.iter_type == 'vid-bias':
-                assert len(self.envBuf_rand) > 0 or self.init_rand_steps == -1
-                self.vid_iter_cnt += 1
-            else:
-                raise NotImplementedError()
+            if self._explore_due(self.rand_explo_freq, self.explo_type_rand):
+                self._top_up_rand_buffer()
+            self._count_iteration()
 
             loss = self.train_step()
 
@@ -548,28 +532,26 @@ class LB_Online_Trainer_V7(object):
 
     # ------------------------------------------------------------------------------------------- video-guided exploration
     def video_guided_explore(self):
-        """For every (task, cam, env) of this rank: predict a goal video, follow it, store the episode (reference :859-938)."""
-        self.reset_all_envs()
-        buf_len_0 = len(self.envBuf_vid)
+        """One exploration round (reference :859-938): for every (task, camera, env) combination of this rank -- one at a time, as
+        the reference does -- sample the 7 goal frames from the current render (HIP UNet sampler), follow them (lb_rollout.py) and
+        push the episode into envBuf_vid."""
+        self.env_list.check_no_envs_exist()
+        n_before = len(self.envBuf_vid)
         utils.print_color(f'[Vid Exp] self.step {self.step}', c='y')
-        for _, batch in enumerate(self.dl_vid):
-            tasks_str, cams_str, env_idxs = batch
-            tasks_str, cams_str = list(tasks_str), list(cams_str)
-            env_idxs = env_idxs.cpu().numpy()
-            assert len(tasks_str) == 1
-            self.env_list.init_1_given_env(tk_name=tasks_str[0], env_idx=env_idxs[0], is_rand=True)
-            imgs_start = self.env_get_preproc_imgs(tasks_str, cams_str, env_idxs)
+        for tasks, cams, idxs in self.dl_vid:
+            tasks, cams, idxs = list(tasks), list(cams), idxs.cpu().numpy()
+            if len(tasks) != 1:
+                raise AssertionError("rollouts run one combination at a time (video_batch_size == 1)")
+            self.env_list.init_1_given_env(tk_name=tasks[0], env_idx=idxs[0], is_rand=True)
+            start = self.env_get_preproc_imgs(tasks, cams, idxs)
             with torch.no_grad():
-                preds_video = self.video_model.forward(imgs_start.to(self.device), tasks_str)
-            batch_imgs, batch_acts = self.envs_video_guided_execute(tasks_str, cams_str, env_idxs, imgs_start, preds_video)
-            is_except = self.get_is_envs_exception(tasks_str, env_idxs)
-            self.env_list.close_1_given_env(tk_name=tasks_str[0], env_idx=env_idxs[0])
-            for i_sam, tk in enumerate(tasks_str):
-                if is_except[i_sam]:
-                    continue
-                self.envBuf_vid.add_one_episode(tk, cams_str[i_sam], env_idxs[i_sam], batch_imgs[i_sam], batch_acts[i_sam])
-        utils.print_color(f'Finish Vid Explore, vid buf before: {buf_len_0}, after: {len(self.envBuf_vid)}')
-        self.reset_all_envs()
+                video = self.video_model.forward(start.to(self.device), tasks)
+            frames, acts = self.envs_video_guided_execute(tasks, cams, idxs, start, video)
+            self.env_list.close_1_given_env(tk_name=tasks[0], env_idx=idxs[0])
+            for i, tk in enumerate(tasks):
+                self.envBuf_vid.add_one_episode(tk, cams[i], idxs[i], frames[i], acts[i])
+        utils.print_color(f'Finish Vid Explore, vid buf before: {n_before}, after: {len(self.envBuf_vid)}')
+        self.env_list.check_no_envs_exist()
 
     def _predict(self, img_st, img_goal):
         """EMA policy, DDIM-8: `[1,3,H,W]` start / goal -> clamped actions [n_acts_per_pred, 7] on the host."""
@@ -586,91 +568,35 @@ class LB_Online_Trainer_V7(object):
         assert len(act) == self.n_acts_per_pred
         return act.clamp(min=self.act_min, max=self.act_max)
 
+    def _rollout_runner(self):
+        td = self.trainer_dict
+        from .lb_rollout import RolloutRunner
+        return RolloutRunner(self.env_list, lambda o, g: self._predict(o.to(self.device), g), self.rendered_imgs_preproc_fn,
+                             n_acts=self.n_acts_per_pred, n_preds=self.n_preds_betw_vframes, grip_force=self.close_grp_force,
+                             descend_steps=self.n_acts_down_range, close_steps=self.n_acts_close_grp, descend_speed=self.act_down_val,
+                             descend_speed_per_task=getattr(self, 'act_down_val_range_per_tk', None),
+                             close_descend_speed=self.close_grp_act_down_val, z_gap=self.grasp_z_diff_limit,
+                             z_ceiling=self.grasp_abs_z_limit, wrist_cam=self.grp_cam_name, stop_at_success=self.is_stop_at_suc)
+
     def envs_video_guided_execute(self, tasks_str, cams_str, env_idxs, imgs_start, preds_video, vis_rollout=False):
-        """Follow each predicted frame for n_preds policy calls of n_acts_per_pred actions; close the gripper and descend when the
-        wrist depth says an object is under the fingers (reference :995-1291).  Returns per sample a uint8 [T+1,H,W,3] frame
-        array and a float [T,7] action tensor."""
+        """Per sample: follow the 7 predicted frames with the EMA policy (diffuser/libero/lb_rollout.py) -> uint8 [T+1,H,W,3] frames
+        and float [T,7] actions, the episode format of the HBM replay store."""
         preds_video = preds_video.detach().to(self.device)
-        assert imgs_start.shape[2:4] == self.input_img_size
-        v_hzn = len(preds_video[0])
-        assert v_hzn == self.video_model.video_future_horizon
-        batch_imgs_out_dense, batch_acts_out = [], []
-        for i_sam, tk in enumerate(tasks_str):
-            pred_v = preds_video[i_sam]
-            img_st = imgs_start[i_sam:i_sam + 1]
-            env_idx, cam = env_idxs[i_sam], cams_str[i_sam]
-            is_suc = False
-            frames = [self.env_list.render_an_env(tk, cam, env_idx)]            # uint8 HWC: what the store keeps
-            acts_out = []
-            do_grasp = False
-            num_acc_acts = 0
-
-            def step_and_record(a):
-                _, _, done, _ = self.env_list.step_an_env(tk, env_idx, a.numpy())
-                frames.append(self.env_list.render_an_env(tk, cam, env_idx))
-                return done
-
-            for g_idx in range(v_hzn):
-                img_goal = pred_v[None, g_idx]
-                n_preds = random.randint(*self.n_preds_betw_vframes)
-                for i_p in range(n_preds):
-                    with torch.no_grad():
-                        act = self._predict(img_st.to(self.device), img_goal)
-                    act[:, -1] = self.close_grp_force if do_grasp else -self.close_grp_force
-                    e_done = False
-                    for i_a in range(self.n_acts_per_pred):
-                        e_done = step_and_record(act[i_a])
-                        self.num_steps_in_env += 1
-                    is_suc = e_done or is_suc
-                    img_st = self.rendered_imgs_preproc_fn(frames[-1][None])
-                    acts_out.append(act)
-                    num_acc_acts += len(act)
-
-                    # ---- grasp heuristic on the wrist depth
-                    grp_depth = self.env_list.render_an_env_with_depth(tk, self.grp_cam_name, env_idx)[1]
-                    assert grp_depth.shape[:2] == (128, 128)
-                    assert (grp_depth >= 0).all(), 'sanity check'
-                    h, w = grp_depth.shape[:2]
-                    h_st, h_e = round(h * 0.75), round(h * 0.82)
-                    w_st, w_e = round(w * 0.35), round(w * 0.65)
-                    d_m = np.mean(grp_depth[h_st:h_e, w_st:w_e])
-                    ee_pos = self.env_list.get_an_env_obs(tk, env_idx)['robot0_eef_pos']
-                    assert ee_pos.shape == (3,)
-                    z_diff = np.abs(ee_pos[2] - d_m).item()
-                    if z_diff > self.grasp_z_diff_limit and ee_pos[2] < self.grasp_abs_z_limit and not do_grasp:
-                        do_grasp = True
-                        assert self.control_mode == 'delta'
-                        n_acts_down = random.randint(self.n_acts_down_range[0], self.n_acts_down_range[1])
-                        if self.act_down_val is None:
-                            actd_rg = self.act_down_val_range_per_tk[self.env_list.task_to_task_idx[tk]]
-                            down_val = np.random.uniform(low=actd_rg[0], high=actd_rg[1], size=1).item()
-                        else:
-                            down_val = self.act_down_val
-                        assert down_val <= 0
-                        act_down = torch.tensor([[0, 0, down_val, 0, 0, 0, 0]] * n_acts_down)
-                        for i_a in range(len(act_down)):
-                            step_and_record(act_down[i_a])
-                        acts_out.append(act_down)
-                        act_grasp = torch.tensor([[0, 0, self.close_grp_act_down_val, 0, 0, 0, self.close_grp_force]] * self.n_acts_close_grp)
-                        for i_a in range(len(act_grasp)):
-                            step_and_record(act_grasp[i_a])
-                        acts_out.append(act_grasp)
-                        img_st = self.rendered_imgs_preproc_fn(frames[-1][None])
-                        num_acc_acts += len(act_down) + len(act_grasp)
-                if is_suc and self.is_stop_at_suc:
-                    break
-
-            acts_cat = torch.cat(acts_out).float()
-            assert len(frames) == len(acts_cat) + 1
-            assert num_acc_acts == len(acts_cat)
-            batch_imgs_out_dense.append(torch.from_numpy(np.stack(frames)))
-            batch_acts_out.append(acts_cat)
-            if is_suc:
-                self.cnt_explore_suc += 1
-                self.cnt_explo_suc_per_tk[tk] += 1
+        if tuple(imgs_start.shape[2:4]) != self.input_img_size or preds_video.shape[1] != self.video_model.video_future_horizon:
+            raise AssertionError("start images / predicted video do not have the configured size")
+        assert self.control_mode == 'delta'
+        runner = self._rollout_runner()
+        frames_out, acts_out = [], []
+        for i, tk in enumerate(tasks_str):
+            frames, acts, ok = runner.run(tk, cams_str[i], env_idxs[i], imgs_start[i:i + 1], preds_video[i])
+            frames_out.append(frames)
+            acts_out.append(acts)
+            self.cnt_explore_suc += int(ok)
+            self.cnt_explo_suc_per_tk[tk] += int(ok)
             self.cnt_vid_rollouts += 1
             self.cnt_vid_rout_per_tk[tk] += 1
-        return batch_imgs_out_dense, batch_acts_out
+        self.num_steps_in_env += runner.env_steps
+        return frames_out, acts_out
 
     # ------------------------------------------------------------------------------------------------------------ misc
     def to_batch_dict(self, imgs_start, imgs_goal, acts_gt, goal_embed=None):

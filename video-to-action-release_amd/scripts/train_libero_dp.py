@@ -1,7 +1,7 @@
 """Entry point with the flow of the reference's scripts/train_libero_dp.py:36-162 (dataset -> video model -> policy -> trainer ->
 forward/backward smoke test -> train) on the MI355X path.  One process per GPU:
 
-    python scripts/train_libero_dp.py --config config/libero/released_8task.py                      # real data + checkpoints
+    python scripts/train_libero_dp.py --config config/libero/lb_tk8_65to72.py                      # real data + checkpoints
     python scripts/train_libero_dp.py --synthetic --n_train_steps 400 --init_rand_steps 100         # no simulator / files needed
     torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_libero_dp.py ...  # data parallel over RCCL
 
@@ -31,7 +31,7 @@ def load_config(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default=os.path.join(os.path.dirname(HERE), "config/libero/released_8task.py"))
+    ap.add_argument("--config", default=os.path.join(os.path.dirname(HERE), "config/libero/lb_tk8_65to72.py"))
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--savepath", default="logs/libero/diffusion/run0")
     ap.add_argument("--n_train_steps", type=int, default=None)

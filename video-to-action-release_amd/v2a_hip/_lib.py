@@ -47,10 +47,10 @@ SIGNATURES = {
     "v2a_copy2d": (I, [P, P, I, I, I, I, I, P]),
     "v2a_colsum": (I, [P, P, I, I, I, P]),
     "v2a_sincos_embed": (I, [P, P, I, I, I, P]),
-    "v2a_add_noise": (I, [P, P, P, P, P, I, I, P]),
+    "v2a_add_noise": (I, [P, P, P, P, P, I, I, P, P, I, P]),
     "v2a_mse_loss": (I, [P, P, P, P, I, P]),
     "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
-    "v2a_unnormalize_action": (I, [P, P, I, P]),
+    "v2a_unnormalize_action": (I, [P, P, I, P, P, I, P]),
     "v2a_nchw_to_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),
     "v2a_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),

@@ -1,0 +1,86 @@
+"""Data-parallel gradient exchange of the policy train step: the ONE collective of the path.
+
+The reference wraps the policy in torch DDP through `accelerator.prepare` (lb_online_trainer_v7.py:72-76,153-154); its hooks
+all-reduce(mean) the gradients inside `accelerator.backward` (:604) before `clip_grad_norm_` (:608).  Here every gradient already
+lives in one flat fp32 arena, so the exchange is a sum all-reduce of arena slices (torch.distributed 'nccl' = RCCL over xGMI on a
+node; 'gloo' in the CPU tests and when ranks share one GPU) issued asynchronously in gradient-ready order, and the 1/world
+averaging is folded into the consumer (the fused optimiser's gradient scale).
+
+The class is device-agnostic on purpose: tests/test_distributed_cpu.py drives exactly this code with CPU tensors under gloo, and
+PolicyTrainer drives it with the HBM arena.  There is no fallback path: an unsupported backend raises on the first launch, and
+a rank whose slice layout differs from rank 0's raises at construction (mismatched collectives would hang RCCL).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, arena: torch.Tensor, slices, process_group=None, world_size=None):
+        """arena: flat fp32 gradient buffer; slices: [(lo, hi), ...] element ranges in launch order (they must tile a prefix-free,
+        non-overlapping part of the arena; empty ranges are skipped on every rank alike)."""
+        assert arena.dim() == 1 and arena.is_contiguous()
+        self.arena = arena
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if world_size is None else int(world_size)
+        self.slices = [(int(lo), int(hi)) for lo, hi in slices]
+        for lo, hi in self.slices:
+            if not (0 <= lo <= hi <= arena.numel()):
+                raise ValueError(f"slice ({lo}, {hi}) outside the arena of {arena.numel()} elements")
+        self._works = []
+        self._launched = set()
+        self.launches = 0
+        # a single rank with a live communicator still issues its collectives (V2A_FORCE_DP: the RCCL path on a one-GPU box)
+        self.active = dist.is_available() and dist.is_initialized()
+        self._agree_on_layout()
+
+    def _agree_on_layout(self):
+        """Every rank must issue the same collectives in the same order: compare the slice table with rank 0's (one tiny
+        all-reduce pair, at construction only)."""
+        if self.world <= 1:
+            return
+        desc = [self.arena.numel(), len(self.slices)] + [v for s in self.slices for v in s]
+        dev = self.arena.device if self.arena.is_cuda and dist.get_backend(self.pg) != "gloo" else "cpu"
+        mine = torch.tensor(desc, dtype=torch.int64, device=dev)
+        n = torch.tensor([mine.numel()], dtype=torch.int64, device=dev)
+        nmax, nmin = n.clone(), n.clone()
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=self.pg)
+        dist.all_reduce(nmin, op=dist.ReduceOp.MIN, group=self.pg)
+        if int(nmax) != int(nmin):
+            raise RuntimeError(f"data-parallel ranks disagree on the number of gradient slices ({int(nmin)} vs {int(nmax)} table entries)")
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        if not torch.equal(hi, lo):
+            raise RuntimeError(f"data-parallel ranks disagree on the gradient arena layout: this rank {desc}, "
+                               f"element-wise min {lo.tolist()}, max {hi.tolist()}")
+
+    def launch(self, which: int):
+        """Start the sum all-reduce of slice `which` (asynchronous; the caller's stream keeps running)."""
+        if which in self._launched:
+            raise RuntimeError(f"slice {which} was already launched in this step")
+        self._launched.add(which)
+        lo, hi = self.slices[which]
+        if hi <= lo or not self.active:
+            return
+        self._works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.launches += 1
+
+    def finish(self, scale_fn=None):
+        """Wait for every launched slice (on a GPU: makes the current stream wait on the communicator's stream), then average:
+        `scale_fn(1/world)` (the fused optimiser's gradient scale) or an in-place multiply of the reduced slices."""
+        if len(self._launched) != len(self.slices):
+            missing = sorted(set(range(len(self.slices))) - self._launched)
+            raise RuntimeError(f"finish() before slices {missing} were launched: ranks would issue different collectives")
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._launched = set()
+        if self.world > 1:
+            if scale_fn is not None:
+                scale_fn(1.0 / self.world)
+            else:
+                for lo, hi in self.slices:
+                    self.arena[lo:hi].mul_(1.0 / self.world)
+
+    def bytes_per_step(self):
+        return 4 * sum(hi - lo for lo, hi in self.slices)

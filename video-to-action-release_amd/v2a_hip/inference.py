@@ -35,7 +35,7 @@ class GraphedPredictAction:
                 traj = ops.policy_sched_step(eps, traj, None, ddim_coeffs(eng.ac_host, t, self.Ttr, pol.num_inference_steps_ddim), mode=1)
             else:
                 traj = ops.policy_sched_step(eps, traj, self.step_noise[i] if t > 0 else None, ddpm_coeffs(eng.ac_host, t, self.Ttr), mode=0)
-        self.out = ops.unnormalize_action(traj)
+        self.out = ops.unnormalize_action(traj, eng.act_limits)
 
     def _draw(self):
         ops.philox_normal(self.init, self.seed, offset_dev=self.counter)

@@ -12,6 +12,7 @@ from ._lib import lib, check
 ACT = {"none": 0, "silu": 1, "relu": 2, "mish": 3, "gelu": 4}
 
 _ws = {}
+_ws_retired = []        # outgrown scratch buffers stay allocated: captured hipGraphs hold their raw pointers (see workspace)
 _lane = [0]
 
 
@@ -45,7 +46,10 @@ def _p(t):
 
 
 def workspace(nbytes: int, device=None) -> torch.Tensor:
-    """Grow-only scratch buffer per device (not resized during graph capture: call reserve_workspace first)."""
+    """Grow-only scratch buffer per (device, lane); never resized during graph capture (run one eager step first).
+    A captured hipGraph (PolicyTrainer's step, GraphedPredictAction) has the buffer's address baked into its split-K / GroupNorm
+    nodes, so a buffer that is outgrown later (a bigger batch, the video sampler) is RETIRED, not freed: were it returned to the
+    caching allocator, every replay would keep writing partial sums into memory that now belongs to some other tensor."""
     device = torch.device(device if device is not None else torch.cuda.current_device())
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, _lane[0])          # one scratch buffer per (device, lane): a side-stream launch sequence sets lane 1 (see ws_lane)
@@ -53,6 +57,8 @@ def workspace(nbytes: int, device=None) -> torch.Tensor:
     if cur is None or cur.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("v2a workspace would grow during graph capture; run one eager step first")
+        if cur is not None:
+            _ws_retired.append(cur)
         cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{idx}")
         _ws[key] = cur
     return cur
@@ -464,11 +470,13 @@ def sincos_embed(t_long, dim, kind):
     return out
 
 
-def add_noise(act, noise, t_long, alphas_cumprod):
+def add_noise(act, noise, t_long, alphas_cumprod, limits=None):
+    """limits: (min [Da], max [Da]) device tensors of the action normaliser, or None for -1 / +1."""
     out = torch.empty_like(act)
     B = act.shape[0]
+    lo, hi = limits if limits is not None else (None, None)
     check(lib.v2a_add_noise(act.data_ptr(), noise.data_ptr(), t_long.data_ptr(), alphas_cumprod.data_ptr(), out.data_ptr(), B,
-                            act.numel() // B, _stream()), "add_noise")
+                            act.numel() // B, _p(lo), _p(hi), act.shape[-1], _stream()), "add_noise")
     return out
 
 
@@ -641,9 +649,10 @@ def policy_sched_step(eps, sample, noise, coef, mode):
     return out
 
 
-def unnormalize_action(x):
+def unnormalize_action(x, limits=None):
     out = torch.empty_like(x)
-    check(lib.v2a_unnormalize_action(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "unnormalize_action")
+    lo, hi = limits if limits is not None else (None, None)
+    check(lib.v2a_unnormalize_action(x.data_ptr(), out.data_ptr(), x.numel(), _p(lo), _p(hi), x.shape[-1], _stream()), "unnormalize_action")
     return out
 
 

@@ -112,6 +112,10 @@ class PolicyEngine:
         self.device = next(iter(params.values())).device
         self.ac_host = squaredcos_alphas_cumprod(cfg.num_train_timesteps)
         self.ac = self.ac_host.to(self.device)
+        # action limits of the policy's normaliser (None = the Libero -1 / +1, where normalise is the identity up to rounding)
+        lim = getattr(cfg, "act_limits", None)
+        self.act_limits = None if lim is None else tuple(torch.as_tensor(v, dtype=torch.float32).reshape(-1).contiguous().to(self.device)
+                                                        for v in lim)
         self._convs = {}
         import os as _os
         # the two camera encoders (separate weights, no shared state) run as parallel branches of the step graph: +17 % steps/s
@@ -723,7 +727,7 @@ class PolicyEngine:
         buffer feeds the RCCL all-reduce and the fused optimiser.  Returns (loss[1], {name: grad view}, arena)."""
         if not need_grad:
             gc = self.global_cond(imgs, None)
-            noisy = ops.add_noise(action, noise, timesteps, self.ac)
+            noisy = ops.add_noise(action, noise, timesteps, self.ac, self.act_limits)
             pred = self.unet_fwd(noisy, timesteps, gc, None)
             loss, _ = ops.mse_loss(pred, noise, want_grad=False)
             return loss, None, None
@@ -736,7 +740,7 @@ class PolicyEngine:
         start while phase 2 runs).  Returns the state phase 2 needs."""
         save_enc = {}
         gc = self.global_cond(imgs, save_enc)
-        noisy = ops.add_noise(action, noise, timesteps, self.ac)
+        noisy = ops.add_noise(action, noise, timesteps, self.ac, self.act_limits)
         save = {}
         pred = self.unet_fwd(noisy, timesteps, gc, save)
         loss, dpred = ops.mse_loss(pred, noise, want_grad=True)

@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .optim import FusedAdamWEMA
 from .replay import ReplayStore, sample_indices, count_uniform_below
+from .dp import GradReducer
 from ._lib import lib, check
 
 
@@ -44,7 +45,9 @@ class PolicyTrainer:
             self.eng.defer_unet_wgrad = False      # the model.* gradient slice must be final after phase 1 (its all-reduce starts there)
         opt_params = dict(lr=1e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6) if opt_params is None else dict(opt_params)
         ema_params = dict(update_after_step=0, inv_gamma=1.0, power=0.75, min_value=0.0, update_every=1) if ema_params is None else dict(ema_params)
-        ema_params.pop("include_online_model", None)
+        # ema_pytorch keeps the online model out of the EMA module tree (and out of its state_dict) when this is False -- the released
+        # config's setting; the checkpoint writer (_EMAHandle.state_dict) honours it
+        self.ema_include_online_model = bool(ema_params.pop("include_online_model", True))
         # EMA replica (ema_pytorch deep-copies the online model: lb_online_trainer_v7.py:135)
         self.ema_policy = copy.deepcopy(policy)
         self.ema_policy.requires_grad_(False)
@@ -74,9 +77,12 @@ class PolicyTrainer:
         self._g_fb = None
         self._g_enc = None
         self._g_opt = None
-        self._works = []
-        self._blocking_reduce = False
         self._slices = self.eng.arena_slices(self.names)
+        # the one collective of the path (v2a_hip/dp.py): slice 0 = ConditionalUnet1D gradients (final after phase 1), slice 1 = encoders
+        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size) if self.dp else None
+        self.feed = None               # parity / test hook (eager mode): dict(rows=int64[B] pool offsets, noise=[B,T,Da], timesteps=int64[B])
+        self.on_grads_ready = None     # diagnostics hook (eager mode): called with the arena right before the optimiser consumes it
+        self.comm_events = None        # bench: [(before_wait, after_wait)] HIP event pairs bracketing the stream's wait on the communicator
         self._st = None
         self._warm = 0
         self.step_count = 0
@@ -84,7 +90,13 @@ class PolicyTrainer:
     # ------------------------------------------------------------------ pieces
     def _draw_indices(self):
         sv = self.store_vid
-        if sv is None or len(sv) == 0:
+        if self.feed is not None:                      # injected rows (parity tests): no RNG state is consumed
+            if self.use_graph and self._warm >= 2:
+                raise RuntimeError("PolicyTrainer.feed is an eager-mode hook (use_graph=False)")
+            offs = np.asarray(self.feed["rows"], dtype=np.int64)
+            assert offs.shape == (self.B,)
+            ep = st = None
+        elif sv is None or len(sv) == 0:
             ep, st = sample_indices(self.store.episode_lengths(), self.B, self.store.act_len)
             offs = self.store.pool_rows(ep, st)
         elif len(self.store) == 0:
@@ -118,10 +130,14 @@ class PolicyTrainer:
                                     self.frame_start.data_ptr(), o0.data_ptr(), o1.data_ptr(), oa.data_ptr(), B, st.H, st.W,
                                     st.act_len, st.act_dim, 0, 1, ops._stream()), "replay_gather")
         n_noise = self.noise.numel()
-        ops.philox_normal(self.noise, self.seed, offset_dev=self.counter)
-        ops.philox_randint(self.timesteps, self.policy.noise_scheduler.config.num_train_timesteps, self.seed ^ 0x5DEECE66D,
-                           offset_dev=self.counter)
-        check(lib.v2a_advance_counter(self.counter.data_ptr(), (n_noise + 3) // 4 + B, ops._stream()), "advance_counter")
+        if self.feed is not None:
+            self.noise.copy_(self.feed["noise"].to(self.device, torch.float32))
+            self.timesteps.copy_(self.feed["timesteps"].to(self.device, torch.int64))
+        else:
+            ops.philox_normal(self.noise, self.seed, offset_dev=self.counter)
+            ops.philox_randint(self.timesteps, self.policy.noise_scheduler.config.num_train_timesteps, self.seed ^ 0x5DEECE66D,
+                               offset_dev=self.counter)
+            check(lib.v2a_advance_counter(self.counter.data_ptr(), (n_noise + 3) // 4 + B, ops._stream()), "advance_counter")
         imgs = {"img_obs_1": o0, "img_goal_1": o1}
         self._st = self.eng.backward_phase1(imgs, oa, self.noise, self.timesteps, names=self.names, arena=self.arena)
         ops.copy2d(self._st["loss"], self.loss, 1, 1, 1, 1)
@@ -131,27 +147,18 @@ class PolicyTrainer:
 
     def _reduce_async(self, which):
         """Sum all-reduce of one arena slice (RCCL over xGMI), asynchronous: the ConditionalUnet1D slice (74 % of the bytes) is
-        final before the image-encoder backward starts and travels underneath it."""
-        import torch.distributed as dist
-        lo, hi = self._slices[which]
-        if hi <= lo or self._blocking_reduce:
-            return
-        try:
-            self._works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        except Exception as e:      # a backend without async slices: one blocking all-reduce of the whole arena in _reduce_wait
-            if self._works or self.step_count > 0:
-                raise
-            print(f"[v2a] async slice all-reduce unavailable ({type(e).__name__}: {e}); using one blocking all-reduce per step")
-            self._blocking_reduce = True
+        final before the image-encoder backward starts and travels underneath it.  No fallback: a backend that cannot do this raises."""
+        self.reducer.launch(which)
 
     def _reduce_wait(self):
-        import torch.distributed as dist
-        if self._blocking_reduce:
-            dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.pg)
-        for w in self._works:
-            w.wait()
-        self._works = []
-        self.opt.scale_grads(1.0 / self.world)
+        ev = None
+        if self.comm_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self.reducer.finish(self.opt.scale_grads)           # averaging folded into the optimiser's gradient scale
+        if ev is not None:
+            ev[1].record()
+            self.comm_events.append(ev)
 
     def _opt(self):
         self.opt.step(zero_grad=True)
@@ -169,6 +176,8 @@ class PolicyTrainer:
             if self.dp:
                 self._reduce_async(1)
                 self._reduce_wait()
+            if self.on_grads_ready is not None:
+                self.on_grads_ready(self.arena)
             self._opt()
             self._warm += 1
         else:
