@@ -96,6 +96,9 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
                         float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+/* dgamma / dbeta of many GroupNorm layers in ONE launch (pass dgamma = dbeta = NULL to v2a_groupnorm_bwd and keep its colsum):
+   table [nrows][5] int64 rows {colsum ptr, dgamma ptr, dbeta ptr, N, C}; work [nwork][2] int32 = (row, 64-channel block) */
+int v2a_gn_param_grads_multi(const void* table, const void* work, int nwork, v2a_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------- elementwise (csrc/elementwise.hip) */
 /* backward helpers of the video UNet: 2x2 sum pooling (gradient of the folded nearest upsample, unet.py:86-115) and per-sample column

@@ -163,7 +163,7 @@ def cond_unet1d(P, sample, t, global_cond, cfg: PolicyCfg, pre="model."):
     if t.dim() == 0:
         t = t[None]
     t = t.expand(B)
-    e = sinusoidal_pos_emb(t, cfg.dsed)
+    e = sinusoidal_pos_emb(t, cfg.dsed).to(P[pre + "diffusion_step_encoder.1.weight"].dtype)   # (fp64 runs of the oracle: tolerance studies)
     e = F.linear(e, P[pre + "diffusion_step_encoder.1.weight"], P[pre + "diffusion_step_encoder.1.bias"])
     e = F.linear(F.mish(e), P[pre + "diffusion_step_encoder.3.weight"], P[pre + "diffusion_step_encoder.3.bias"])
     gf = torch.cat([e, global_cond], dim=-1)

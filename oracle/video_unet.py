@@ -22,6 +22,12 @@ import torch
 import torch.nn.functional as F
 
 
+# The reference casts to fp32 at three places (GroupNorm32, nn.py:26-28; the attention softmax, unet.py:356; `h = x.type(self.dtype)`,
+# unet.py:666).  Tolerance studies run this restatement in fp64 (tests: "how far is the reference's own fp32 run from exact
+# arithmetic?") and set WORK_DTYPE = torch.float64 for the duration; the default reproduces the reference bit for bit.
+WORK_DTYPE = torch.float32
+
+
 @dataclass(frozen=True)
 class UNetCfg:
     in_channels: int = 6
@@ -116,7 +122,7 @@ def conv3d(P, pre, x, stride=1):
 
 
 def gn32(P, pre, x):
-    return F.group_norm(x.float(), 32, P[pre + ".weight"], P[pre + ".bias"], eps=1e-5)
+    return F.group_norm(x.to(WORK_DTYPE), 32, P[pre + ".weight"], P[pre + ".bias"], eps=1e-5)
 
 
 def resblock(P, pre, x, emb):
@@ -137,7 +143,7 @@ def attention_block(P, pre, x, head_ch):
     N, _, L = qkv.shape
     q, k, v = qkv.reshape(N * nh, 3 * head_ch, L).split(head_ch, dim=1)
     s = 1.0 / math.sqrt(math.sqrt(head_ch))
-    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).to(WORK_DTYPE), dim=-1)
     a = torch.einsum("bts,bcs->bct", w, v).reshape(N, C, L)
     h = F.conv1d(a, P[pre + ".proj_out.weight"], P[pre + ".proj_out.bias"])
     return (xf + h).reshape(B, Fr, C, H, W).permute(0, 2, 1, 3, 4)
@@ -193,7 +199,7 @@ def label_embedding(P, y, cfg: UNetCfg, pre=""):
 
 
 def time_embedding(P, t, cfg: UNetCfg, pre=""):
-    e = timestep_embedding(t, cfg.model_channels)
+    e = timestep_embedding(t, cfg.model_channels).to(P[pre + "time_embed.0.weight"].dtype)     # (fp64 runs of the oracle: tolerance studies)
     e = F.linear(e, P[pre + "time_embed.0.weight"], P[pre + "time_embed.0.bias"])
     return F.linear(F.silu(e), P[pre + "time_embed.2.weight"], P[pre + "time_embed.2.bias"])
 
@@ -221,7 +227,7 @@ def unet_forward(P, x, t, y, cfg: UNetCfg = LIBERO_CFG, pre=""):
     inp, mid, out, _ = build_program(cfg)
     emb = time_embedding(P, t, cfg, pre) + label_embedding(P, y, cfg, pre)
     hs = []
-    h = x.float()
+    h = x.to(WORK_DTYPE)
     for blk in inp:
         h = _run_block(P, pre, blk, h, emb, cfg)
         hs.append(h)

@@ -72,7 +72,17 @@ def test_predict_action_vs_golden(golden_dir, use_ddim, seed, key):
     pol.__dict__["_rng_hook"] = lambda shape, kind: torch.randn(shape)
     out = pol.predict_action(_batch(g)["obs"], use_ddim=use_ddim)
     assert out["action"].shape == (2, 8, 7) and out["action_pred"].shape == (2, 16, 7)
-    assert rel(out["action_pred"], g[key]) <= (TOL if use_ddim else 5e-4)
+    err = rel(out["action_pred"], g[key])
+    # yard-stick for the 100-step loop: the reference's own fp32 run against exact (fp64) arithmetic on the same noise
+    from oracle import policy as OP
+    sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in _policy()[1].items()}
+    torch.manual_seed(seed)
+    init = torch.randn(2, 16, 7).double()
+    stepn = [] if use_ddim else [torch.randn(2, 16, 7).double() for _ in range(99)]
+    exact = OP.predict_action(sd64, {k: v.double() for k, v in _batch(g)["obs"].items()}, init, stepn, use_ddim=use_ddim)["action_pred"]
+    ref_dev, err_exact = rel(g[key], exact), rel(out["action_pred"], exact)
+    print(f"[predict_action {key}] HIP vs reference {err:.2e}; HIP vs fp64 {err_exact:.2e}; reference fp32 vs fp64 {ref_dev:.2e}")
+    assert err <= max(TOL, 4 * ref_dev), (err, ref_dev)
     if use_ddim:
         assert rel(out["action"], g["ddim_action"]) <= TOL
 
@@ -114,8 +124,13 @@ def test_three_train_steps_vs_golden(golden_dir):
         opt.step(zero_grad=True)
         eng.refresh_packs()
         gn, cc, st, dec = opt.peek()
-        assert abs(loss.item() - g["train_losses"][it]) <= 2e-4 * abs(g["train_losses"][it]), (it, loss.item(), g["train_losses"][it])
-        assert abs(gn - g["train_gnorms"][it]) <= 2e-4 * g["train_gnorms"][it], (it, gn, g["train_gnorms"][it])
+        e_l = abs(loss.item() - g["train_losses"][it]) / abs(g["train_losses"][it])
+        e_g = abs(gn - g["train_gnorms"][it]) / g["train_gnorms"][it]
+        print(f"[train step {it}] loss rel err {e_l:.2e}, grad-norm rel err {e_g:.2e}")
+        # steps 2 and 3 start from Adam-updated weights: first-step Adam moves every weight by ~lr * sign(g), so elements whose
+        # gradient is rounding noise move by +-lr in either implementation -- measured 2-6e-5 on the loss, bounded at 2e-4
+        assert e_l <= (TOL if it == 0 else 2e-4), (it, loss.item(), g["train_losses"][it])
+        assert e_g <= (TOL if it == 0 else 2e-4), (it, gn, g["train_gnorms"][it])
         assert st == it + 1 and float(arena.abs().max()) == 0.0     # zero_grad folded into the fused kernel
     pn = np.array([float(P[n].double().norm()) for n in gnames])
     en = np.array([float(EP[n].double().norm()) for n in gnames])
@@ -143,12 +158,40 @@ def test_trainer_graph_replay_matches_eager():
         tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=use_graph)
         losses = [tr.step().item() for _ in range(5)]
         res.append((losses, [p.detach().double().norm().item() for p in pol.parameters()]))
-    # LDS float atomics in the GroupNorm reductions make runs differ in the last bits; Adam turns a near-zero gradient's noise
-    # into +-lr sized steps on parameters whose true gradient is zero by symmetry -> compare losses tightly, norms loosely
-    assert np.allclose(res[0][0], res[1][0], rtol=1e-3), (res[0][0], res[1][0])
-    tot = [float(np.sqrt(np.sum(np.square(r[1])))) for r in res]
-    assert abs(tot[0] - tot[1]) <= 1e-5 * tot[0], tot
+    # every reduction of the step has a fixed summation order (no float atomics: csrc/norm.hip), and the captured graph launches the
+    # same kernels in the same order as the eager step -> bitwise equality, not closeness
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]
     assert all(np.isfinite(res[1][0]))
+
+
+def test_policy_step_is_bitwise_reproducible():
+    """two runs of the same seeded train steps give bitwise identical parameters, EMA weights and losses (graph
+    replay included).  Replicas that stay bit-identical under data parallelism depend on exactly this."""
+    import random
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from v2a_hip.replay import ReplayStore
+    from v2a_hip.trainer import PolicyTrainer
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        pol = build_policy(DEFAULT_CONF).to("cuda:0")
+        store = ReplayStore(64, 200, 30, capacity_frames=40 * 16)
+        gen = torch.Generator().manual_seed(3)
+        for e in range(16):
+            n = 30 + e
+            store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
+                                  torch.rand(n - 1, 7, generator=gen) * 2 - 1)
+        np.random.seed(5); random.seed(5)
+        tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=True)
+        losses = [tr.step().item() for _ in range(5)]
+        flat = torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu()
+        ema = torch.cat([p.detach().flatten() for p in tr.ema_policy.parameters()]).cpu()
+        runs.append((losses, flat, ema))
+        del tr, pol, store
+        torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
 def test_bf16_mode_policy_close_to_fp32(golden_dir):
@@ -380,3 +423,41 @@ def test_action_limits_reach_the_kernels(golden_dir):
     out = pol.predict_action({k: v.cuda() for k, v in batch["obs"].items()}, use_ddim=True)
     assert rel(out["action_pred"], g["ddim_action_pred"]) <= TOL
     assert float(out["action_pred"][..., 3:6].abs().max()) <= 0.1 + 1e-6
+
+
+def test_batch_256_step_ties_to_oracle_through_linearity():
+    """BASELINE configs[4]'s policy half (B=256; its 16-bit dtype is the bf16 mode here -- gfx950 runs bf16 and fp16 MFMA at the same
+    rate and the repo keeps ONE 16-bit format).  The loss is a mean over rows, so loss / gradients at B=256 must equal the mean of
+    the 32 chunk results at B=8 (size-independent property), and chunk 0 is checked against the CPU oracle."""
+    from oracle import policy as OP
+    pol, sd = _policy()
+    eng = pol.engine
+    names = pol.trainable_names()
+    g = torch.Generator().manual_seed(256)
+    B = 256
+    imgs = {k: torch.rand(B, 3, 128, 128, generator=g) for k in ("img_obs_1", "img_goal_1")}
+    act = torch.rand(B, 16, 7, generator=g) * 2 - 1
+    noise, ts = torch.randn(B, 16, 7, generator=g), torch.randint(0, 100, (B,), generator=g)
+
+    def run(lo, hi):
+        loss, _, arena = eng.loss_fwd_bwd({k: v[lo:hi].cuda().contiguous() for k, v in imgs.items()}, act[lo:hi].cuda().contiguous(),
+                                          noise[lo:hi].cuda().contiguous(), ts[lo:hi].cuda().contiguous(), need_grad=True, names=names)
+        return float(loss.item()), arena.double().cpu()
+
+    L, G = run(0, B)
+    acc_l, acc_g, first = 0.0, None, None
+    for c in range(B // 8):
+        l, gr = run(8 * c, 8 * c + 8)
+        acc_l += l / (B // 8)
+        acc_g = gr / (B // 8) if acc_g is None else acc_g + gr / (B // 8)
+        if c == 0:
+            first = (l, gr)
+    gmax = float(G.abs().max())
+    e_l, e_g = abs(L - acc_l) / abs(acc_l), float((G - acc_g).abs().max()) / gmax
+    print(f"[B=256] loss {L:.6f} vs mean of 32 chunks {acc_l:.6f} (rel {e_l:.1e}); gradient max err {e_g:.1e} of max |g|")
+    assert e_l <= 1e-5 and e_g <= 1e-4
+    batch0 = {"obs": {k: v[:8, None] for k, v in imgs.items()}, "action": act[:8]}
+    ol, og = OP.loss_and_grads(sd, batch0, noise[:8], ts[:8], names=names)
+    ref = torch.cat([og[n].flatten() for n in names]).double()
+    assert abs(first[0] - ol.item()) <= TOL * abs(ol.item())
+    assert float((first[1] - ref).abs().max()) <= TOL * float(ref.abs().max())

@@ -27,8 +27,6 @@ struct GnDesc {
     float* rstd;            // [N][G]
     float* colsum;          // [N][2][C] (stats: sum x, sum x^2; backward: sum dz, sum dz*xhat)
     double* partial;        // [N][nchunk][2][C]
-    float* dgamma_acc;      // small backward path: atomically accumulate dgamma / dbeta over n here (or null)
-    float* dbeta_acc;
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
     unsigned short* yh;     // optional bf16 twin of the output (forward: y, backward: dx), same shape: feeds the bf16-MFMA convs
     float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
@@ -51,15 +49,14 @@ __device__ __forceinline__ void gn_store_twin4(unsigned short* yh, size_t i4, co
 // -------------------------------------------------------------------------------------------- large path
 // MODE 0: (x, x^2).  MODE 1: (dz, dz * xhat) with dz = dout * act'(z), z = gn(x) [+ residual].
 // Thread -> fixed float4 column(s): with L4 = C/4 columns, rpi = max(1, 256 / L4) rows are processed in parallel and a
-// thread keeps its column's partial sums in registers for the whole slab (4 independent loads in flight per thread);
-// LDS float atomics are touched once per (thread, column) at the end.
+// thread keeps its column's partial sums in registers for the whole slab (4 independent loads in flight per thread).
+// Deterministic: every (row lane, column) owns one LDS slot ([rpi][2][C] floats); the rpi lanes of a column are then added in lane
+// order by one thread -- no float atomics anywhere, so two runs give bitwise equal statistics.
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
-    extern __shared__ __attribute__((aligned(16))) float bins[];   // [2][C]
+    extern __shared__ __attribute__((aligned(16))) float bins[];   // [rpi][2][C]
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int C = p.C, L4 = C >> 2, cg = C / p.G;
-    for (int i = tid; i < 2 * C; i += 256) bins[i] = 0.f;
-    __syncthreads();
     const int s0 = chunk * p.rows_per_chunk, s1 = min(p.S, s0 + p.rows_per_chunk);
     const int nrows = s1 - s0;
     const bool two = (MODE == 0) && p.x2 != nullptr;
@@ -110,15 +107,20 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
                 }
             }
         }
+        float* slot = bins + (size_t)row0 * 2 * C;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            atomicAdd(&bins[cc + j], a0[j]);
-            atomicAdd(&bins[C + cc + j], a1[j]);
+            slot[cc + j] = a0[j];
+            slot[C + cc + j] = a1[j];
         }
     }
     __syncthreads();
     double* out = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
-    for (int i = tid; i < 2 * C; i += 256) out[i] = (double)bins[i];
+    for (int i = tid; i < 2 * C; i += 256) {
+        double a = 0.0;
+        for (int l = 0; l < rpi; ++l) a += (double)bins[(size_t)l * 2 * C + i];
+        out[i] = a;
+    }
 }
 
 // one block per (n, group): sums the chunk partials of the group's channels in fp64.
@@ -297,17 +299,21 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
 }
 
 // backward of the small path.  Also emits per-(n, c) sums: colsum[n][0][c] = sum_s dz, colsum[n][1][c] = sum_s dz*xhat
-// (dgamma / dbeta = their sum over n) and dfilm[n][0][c] = sum_s dout * a, dfilm[n][1][c] = sum_s dout.
+// (dgamma / dbeta = their sum over n: gn_param_grads / gn_param_grads_multi) and dfilm[n][0][c] = sum_s dout * a,
+// dfilm[n][1][c] = sum_s dout.  Deterministic: the per-element terms are staged in LDS and every column is summed over its rows in
+// a fixed order (thread = (row slice, column), then the slices in order) -- no float atomics, in LDS or in HBM.
 __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // xhat[E], dz[E], bins[4][cg], red[8]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // xhat[E], dz[E], (film: dout*a[E], dout[E]), part[nsl][4][cg], red[8]
     const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
     const int C = p.C, cg = C / p.G, E = p.S * cg;
+    const bool film = p.film != nullptr;
     float* xh = sm;
     float* dzs = sm + E;
-    float* bins = sm + 2 * E;
-    float* red = bins + 4 * cg;
-    for (int i = tid; i < 4 * cg; i += 256) bins[i] = 0.f;
-    __syncthreads();
+    float* fa = sm + 2 * E;                 // film only
+    float* fd = sm + 3 * E;
+    const int nsl = cg >= 256 ? 1 : 256 / cg;                 // row slices summed in parallel per column
+    float* part = sm + (film ? 4 : 2) * E;  // [nsl][4][cg]
+    float* red = part + (size_t)nsl * 4 * cg;
     const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
     const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
     float A1 = 0.f, A2 = 0.f;
@@ -320,17 +326,15 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         if (p.residual) z += p.residual[off];
         const float dout = p.dout[off];
         float da = dout;
-        if (p.film) {
+        if (film) {
             const float a = act_fwd(z, p.act);
             da = dout * p.film[(size_t)n * p.film_ld + c];
-            atomicAdd(&bins[2 * cg + cc], dout * a);
-            atomicAdd(&bins[3 * cg + cc], dout);
+            fa[i] = dout * a;
+            fd[i] = dout;
         }
         const float dz = da * act_bwd(z, p.act);
         xh[i] = h;
         dzs[i] = dz;
-        atomicAdd(&bins[cc], dz);
-        atomicAdd(&bins[cg + cc], dz * h);
         A1 += dz * p.gamma[c];
         A2 += dz * p.gamma[c] * h;
     }
@@ -350,17 +354,33 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         if (p.yh) p.yh[off] = gn_f2bf(dxv);
         if (p.dres) p.dres[off] = dzs[i];
     }
-    for (int cc = tid; cc < cg; cc += 256) {
-        const int c = g * cg + cc;
-        p.colsum[(size_t)n * 2 * C + c] = bins[cc];
-        p.colsum[(size_t)n * 2 * C + C + c] = bins[cg + cc];
-        if (p.dgamma_acc) {
-            atomicAdd(&p.dgamma_acc[c], bins[cg + cc]);
-            atomicAdd(&p.dbeta_acc[c], bins[cc]);
+    // column sums: thread (slice, cc) adds rows slice, slice + nsl, ... in order; then the slices in order
+    for (int t = tid; t < nsl * cg; t += 256) {
+        const int sl = t / cg, cc = t - sl * cg;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int row = sl; row < p.S; row += nsl) {
+            const int i = row * cg + cc;
+            const float dz = dzs[i];
+            s0 += dz;
+            s1 += dz * xh[i];
+            if (film) { s2 += fa[i]; s3 += fd[i]; }
         }
+        float* dst = part + (size_t)sl * 4 * cg;
+        dst[cc] = s0; dst[cg + cc] = s1; dst[2 * cg + cc] = s2; dst[3 * cg + cc] = s3;
+    }
+    __syncthreads();
+    for (int cc = tid; cc < cg; cc += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int sl = 0; sl < nsl; ++sl) {
+            const float* src = part + (size_t)sl * 4 * cg;
+            s0 += src[cc]; s1 += src[cg + cc]; s2 += src[2 * cg + cc]; s3 += src[3 * cg + cc];
+        }
+        const int c = g * cg + cc;
+        p.colsum[(size_t)n * 2 * C + c] = s0;
+        p.colsum[(size_t)n * 2 * C + C + c] = s1;
         if (p.dfilm) {
-            p.dfilm[(size_t)n * p.film_ld + c] = bins[2 * cg + cc];
-            p.dfilm[(size_t)n * p.film_ld + C + c] = bins[3 * cg + cc];
+            p.dfilm[(size_t)n * p.film_ld + c] = s2;
+            p.dfilm[(size_t)n * p.film_ld + C + c] = s3;
         }
     }
 }
@@ -383,7 +403,35 @@ __global__ __launch_bounds__(256) void gn_param_grads(const float* colsum, float
     }
 }
 
+// the same for many GroupNorm layers in one launch: table rows = {colsum ptr, dgamma ptr, dbeta ptr, N, C}, work = (row, 64-channel block)
+__global__ __launch_bounds__(256) void gn_param_grads_multi(const long long* table, const int* work) {
+    __shared__ double sm[2][4][64];
+    const long long* row = table + (size_t)work[2 * blockIdx.x] * 5;
+    const float* colsum = reinterpret_cast<const float*>(row[0]);
+    float* dgamma = reinterpret_cast<float*>(row[1]);
+    float* dbeta = reinterpret_cast<float*>(row[2]);
+    const int N = (int)row[3], C = (int)row[4];
+    const int c = work[2 * blockIdx.x + 1] * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int n = w; n < N; n += 4) { b += colsum[(size_t)n * 2 * C + c]; a += colsum[(size_t)n * 2 * C + C + c]; }
+    sm[0][w][threadIdx.x & 63] = a;
+    sm[1][w][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int l = threadIdx.x;
+        dgamma[c] = (float)(sm[0][0][l] + sm[0][1][l] + sm[0][2][l] + sm[0][3][l]);
+        dbeta[c] = (float)(sm[1][0][l] + sm[1][1][l] + sm[1][2][l] + sm[1][3][l]);
+    }
+}
+
 #define GN_SMALL_MAX 12288
+
+static size_t gn_colreduce_lds(int C) {           // [rpi][2][C] floats, rpi = row lanes of gn_colreduce
+    const int L4 = C >> 2;
+    const int rpi = L4 >= 256 ? 1 : 256 / L4;
+    return (size_t)rpi * 2 * C * sizeof(float);
+}
 
 static void gn_chunks(int N, int S, int C, int* nchunk, int* rows) {
     // >= ~1024 workgroups overall, slabs of at least 16 KB
@@ -441,7 +489,7 @@ int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* ga
     gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
     if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.partial = (double*)workspace;
-    hipLaunchKernelGGL(gn_colreduce<0>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+    hipLaunchKernelGGL(gn_colreduce<0>, dim3(p.nchunk, N), dim3(256), gn_colreduce_lds(C), stream, p);
     V2A_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize<0>, dim3(N * G), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
@@ -454,8 +502,9 @@ int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* ga
 }
 
 // Backward of v2a_groupnorm_fwd.  dx [N,S,C]; dres (optional) = gradient of the residual input;
-// dfilm (optional) [N][2][C]; colsum [N][2][C] scratch/output; dgamma/dbeta [C]: overwritten, or accumulated into when
-// accumulate_params = 1 (the gradient arena is zeroed by the fused optimiser; saves a reduction launch on the small path).
+// dfilm (optional) [N][2][C]; colsum [N][2][C] output (per-sample sums of dz and dz*xhat); dgamma/dbeta [C]: overwritten (added to
+// when accumulate_params = 1) by a reduction launch over n, or null when the caller batches that reduction for many layers
+// (v2a_gn_param_grads_multi).  No atomics anywhere: results are bitwise reproducible.
 int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
                         float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
@@ -480,10 +529,10 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;
     const long E = (long)S * cg;
-    bool params_done = false;
     if (E <= GN_SMALL_MAX) {
-        if (accumulate_params && dgamma && dbeta) { p.dgamma_acc = dgamma; p.dbeta_acc = dbeta; params_done = true; }
-        size_t lds = (2 * E + 4 * cg + 8) * sizeof(float);
+        const int nsl = cg >= 256 ? 1 : 256 / cg;
+        size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 8) * sizeof(float);
+        if (lds > 160 * 1024) return V2A_ERR_ARG;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(gn_small_bwd, dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
@@ -494,7 +543,7 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
         if ((size_t)N * p.nchunk * 2 * C * sizeof(double) + (size_t)N * G * 2 * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
         p.partial = (double*)workspace;
         p.gsum = (float*)((char*)workspace + (size_t)N * p.nchunk * 2 * C * sizeof(double));
-        hipLaunchKernelGGL(gn_colreduce<1>, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+        hipLaunchKernelGGL(gn_colreduce<1>, dim3(p.nchunk, N), dim3(256), gn_colreduce_lds(C), stream, p);
         V2A_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_finalize<1>, dim3(N * G), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
@@ -504,10 +553,20 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
         hipLaunchKernelGGL(gn_apply_bwd, dim3(grid), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
     }
-    if (dgamma && dbeta && !params_done) {
+    if (dgamma && dbeta) {        // null: the caller sums colsum over n later (v2a_gn_param_grads_multi, one launch for many layers)
         hipLaunchKernelGGL(gn_param_grads, dim3((C + 63) / 64), dim3(256), 0, stream, colsum, dgamma, dbeta, N, C, accumulate_params);
         V2A_CHECK_LAUNCH();
     }
+    return V2A_OK;
+}
+
+// dgamma / dbeta of many GroupNorm layers in one launch (fixed summation order over n, fp64): table [nrows][5] int64 rows
+// {colsum ptr ([N][2][C], as written by v2a_groupnorm_bwd), dgamma ptr, dbeta ptr, N, C}; work [nwork][2] int32 = (row, 64-channel block).
+int v2a_gn_param_grads_multi(const void* table, const void* work, int nwork, hipStream_t stream) {
+    if (!table || !work || nwork < 0) return V2A_ERR_ARG;
+    if (nwork == 0) return V2A_OK;
+    hipLaunchKernelGGL(gn_param_grads_multi, dim3(nwork), dim3(256), 0, stream, (const long long*)table, (const int*)work);
+    V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 

@@ -40,11 +40,9 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 
 __global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
-    extern __shared__ __attribute__((aligned(16))) float bins[];   // [2][C]
+    extern __shared__ __attribute__((aligned(16))) float bins[];   // [rpi][2][C]: one slot per (row lane, column), combined in lane order
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int C = p.C, L8 = C >> 3;
-    for (int i = tid; i < 2 * C; i += 256) bins[i] = 0.f;
-    __syncthreads();
     const int s0 = chunk * p.rows_per_chunk, s1 = min(p.S, s0 + p.rows_per_chunk);
     const int nrows = s1 - s0;
     const int C1 = p.x2 ? p.C1 : C, C2 = C - C1;
@@ -80,15 +78,20 @@ __global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
         }
+        float* slot = bins + (size_t)row0 * 2 * C;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            atomicAdd(&bins[c + e], s[e]);
-            atomicAdd(&bins[C + c + e], q[e]);
+            slot[c + e] = s[e];
+            slot[C + c + e] = q[e];
         }
     }
     __syncthreads();
     float* dst = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
-    for (int i = tid; i < 2 * C; i += 256) dst[i] = bins[i];
+    for (int i = tid; i < 2 * C; i += 256) {
+        float a = 0.f;
+        for (int l = 0; l < rpi; ++l) a += bins[(size_t)l * 2 * C + i];
+        dst[i] = a;
+    }
 }
 
 // statistics that came with the tensors (per-64-row [2][C_src] slabs from the conv epilogue, csrc/igemm_h.hip) -> the same
@@ -236,7 +239,7 @@ int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamm
     p.partial = (float*)workspace;
     p.ab = p.partial + (size_t)N * p.nchunk * 2 * C;
     if (!stats1) {
-        hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), 2 * C * sizeof(float), stream, p);
+        hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), (size_t)((C >> 3) >= 256 ? 1 : 256 / (C >> 3)) * 2 * C * sizeof(float), stream, p);
         V2A_CHECK_LAUNCH();
     } else {
         const int nb = S >> 6;

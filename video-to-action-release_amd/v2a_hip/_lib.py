@@ -50,6 +50,7 @@ SIGNATURES = {
     "v2a_add_noise": (I, [P, P, P, P, P, I, I, P, P, I, P]),
     "v2a_mse_loss": (I, [P, P, P, P, I, P]),
     "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
+    "v2a_gn_param_grads_multi": (I, [P, P, I, P]),
     "v2a_unnormalize_action": (I, [P, P, I, P, P, I, P]),
     "v2a_nchw_to_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),

@@ -411,9 +411,11 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
-                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None):
+                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None, colsum=None, defer_params=False):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
-    as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx."""
+    as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx.
+    defer_params: only fill `colsum` [N,2,C] (per-sample sums); the caller reduces it over n for many layers at once
+    (gn_param_grads_multi) -- dgamma / dbeta are returned as None."""
     N, S, C = x.shape
     dx = torch.empty_like(x)
     dxh = None
@@ -425,17 +427,26 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
     film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
     if dfilm_out is not None:
         assert film is not None and dfilm_out.stride(0) == film_ld
-    colsum_ = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
+    colsum_ = torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if colsum is None else colsum
+    assert colsum_.numel() == N * 2 * C and colsum_.is_contiguous()
+    if defer_params:
+        dgamma = dbeta = None
+    else:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
     check(lib.v2a_groupnorm_bwd_t(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
                                   mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), _p(dres), _p(dfilm), colsum_.data_ptr(),
-                                  dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,
+                                  _p(dgamma), _p(dbeta), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,
                                   _stream()),
           "groupnorm_bwd")
     return dx, dgamma, dbeta, dres, dfilm
+
+
+def gn_param_grads_multi(table, work, nwork):
+    """dgamma / dbeta of many GroupNorm layers from their colsum buffers in one launch (see v2a_gn_param_grads_multi)."""
+    check(lib.v2a_gn_param_grads_multi(table.data_ptr(), work.data_ptr(), nwork, _stream()), "gn_param_grads_multi")
 
 
 # ------------------------------------------------------------------------------------------------ elementwise

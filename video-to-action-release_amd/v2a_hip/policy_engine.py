@@ -138,6 +138,12 @@ class PolicyEngine:
         # of the N-major loader over the forward pack: the K-contiguous form is what the LDS-DMA kernels take
         self.flip_dgrad = _os.environ.get("V2A_FLIP_DGRAD", "1") != "0"
         self._deferred = []
+        # GroupNorm parameter gradients: every layer's backward leaves its per-sample column sums in a persistent [N,2,C] buffer; ONE
+        # multi-tensor launch per chain (ConditionalUnet1D, each camera encoder) reduces them over n in a fixed order -- no atomics,
+        # bitwise reproducible, and 60 reduction launches per step fewer
+        self._gn_cs = {}
+        self._gn_chain = None
+        self._gn_tables = {}
         self._collect_wg = False
         self._wg_stream = None
         self._side = None
@@ -362,11 +368,48 @@ class PolicyEngine:
     def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None):
         x3, mean, rstd, r3, film, pre, G, act = saved
         d3 = dout4.view(x3.shape)
-        dx, dg, db, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
-                                                    residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
-                                                    dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], accumulate_params=True,
-                                                    dfilm_out=dfilm_out)
+        N, _, C = x3.shape
+        chain = self._gn_chain
+        if chain is None:            # outside a chain (stand-alone use): reduce this layer's parameter gradients right away
+            dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
+                                                      residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
+                                                      dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], dfilm_out=dfilm_out)
+        else:
+            cs = self._gn_cs.get((pre, N, C))
+            if cs is None:
+                cs = torch.empty((N, 2, C), dtype=torch.float32, device=self.device)
+                self._gn_cs[(pre, N, C)] = cs
+            chain.append((pre, N, C))
+            dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
+                                                      residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
+                                                      dfilm_out=dfilm_out, colsum=cs, defer_params=True)
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
+
+    def _gn_begin(self):
+        """Start collecting GroupNorm layers of one backward chain (returns the token _gn_flush takes)."""
+        prev, self._gn_chain = self._gn_chain, []
+        return prev
+
+    def _gn_flush(self, prev, grads):
+        """dgamma / dbeta of every GroupNorm layer the chain visited, in one launch.  The pointer table is cached per (layer list,
+        destination addresses): the captured train step re-uses the table built by its eager warm-up steps."""
+        chain, self._gn_chain = self._gn_chain, prev
+        if not chain:
+            return
+        key = (tuple(chain), tuple(grads[pre + ".weight"].data_ptr() for pre, _, _ in chain))
+        ent = self._gn_tables.get(key)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("GroupNorm gradient table missing during graph capture; run one eager step first")
+            rows, work = [], []
+            for i, (pre, N, C) in enumerate(chain):
+                rows.append([self._gn_cs[(pre, N, C)].data_ptr(), grads[pre + ".weight"].data_ptr(), grads[pre + ".bias"].data_ptr(), N, C])
+                work += [[i, b] for b in range((C + 63) // 64)]
+            if len(self._gn_tables) > 64:
+                self._gn_tables.clear()
+            ent = (torch.tensor(rows, dtype=torch.int64).to(self.device), torch.tensor(work, dtype=torch.int32).to(self.device), len(work))
+            self._gn_tables[key] = ent
+        ops.gn_param_grads_multi(*ent)
 
     def encode_fwd(self, key, img_nchw, save):
         """img [B,3,H,W] in [0,1] (float or uint8) -> feature [B, feature_dim].  save: list collecting backward state (or None)."""
@@ -405,6 +448,13 @@ class PolicyEngine:
         return f
 
     def encode_bwd(self, key, df, st, grads):
+        tok = self._gn_begin()
+        try:
+            self._encode_bwd(key, df, st, grads)
+        finally:
+            self._gn_flush(tok, grads)
+
+    def _encode_bwd(self, key, df, st, grads):
         e = self.enc[key]
         cfg = self.cfg
         B = df.shape[0]
@@ -749,10 +799,12 @@ class PolicyEngine:
             arena = torch.zeros(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)   # GN param grads accumulate
         grads = self.grad_views(arena, names)
         self._collect_wg = True
+        tok = self._gn_begin()
         try:
             dgc = self.unet_bwd(dpred, save, grads)
         finally:
             self._collect_wg = False
+            self._gn_flush(tok, grads)
         self._join_side()
         return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc, keep=save)
 
