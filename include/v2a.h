@@ -264,6 +264,22 @@ int v2a_mt_seed_python(uint32_t* state, const uint32_t* key, int key_len);      
 int v2a_replay_gather(const void* frames, int dtype_u8, const float* acts, const int64_t* frame_start, float* out_start, float* out_goal,
                       float* out_acts, int B, int H, int W, int act_len, int act_dim, int normalize, int chw_out, v2a_stream_t s);
 
+/* ---------------------------------------------------------------------------------------------- random-action episode file (csrc/h5read.hip)
+ * Native reader for the HDF5 file of the reference's generator (environment/libero/lb_data/lb_randsam.py:84-104: groups
+ * `{task}/{episode}` holding `agentview_image` uint8 [T+1,128,128,3], `action` float [T,7], `ee_poses` float [T+1,3]), replacing the
+ * h5py calls of the loader (diffuser/libero/lb_online_trainer_v7.py:718-780).  HOST functions, HOST pointers, no stream; every
+ * function returns 0 / a count, or -1 with the reason in v2a_h5_last_error().  Supported: the "earliest" on-disk format h5py writes by
+ * default (superblock 0/1, symbol-table groups, version-1 object headers, contiguous / compact / unfiltered chunked datasets of
+ * little-endian integers and floats); everything else is refused, not guessed. */
+int v2a_h5_open(const char* path, void** handle_out);
+void v2a_h5_close(void* handle);
+const char* v2a_h5_last_error(void* handle);
+int v2a_h5_exists(void* handle, const char* path);                                   /* 1 / 0 / -1 */
+long v2a_h5_list(void* handle, const char* group_path, char* buf, size_t cap);       /* member names, '\n'-separated; -2: buf too small */
+int v2a_h5_dataset_info(void* handle, const char* path, int* type_class, int* elem_size, int* is_signed, int* ndim, long long* dims,
+                        long long* nbytes);                                        /* type_class 0 integer, 1 float; dims[8] */
+int v2a_h5_read(void* handle, const char* path, void* dst_host, size_t dst_bytes);   /* whole dataset, row-major */
+
 #ifdef __cplusplus
 }
 #endif

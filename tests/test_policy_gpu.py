@@ -458,6 +458,13 @@ def test_batch_256_step_ties_to_oracle_through_linearity():
     assert e_l <= 1e-5 and e_g <= 1e-4
     batch0 = {"obs": {k: v[:8, None] for k, v in imgs.items()}, "action": act[:8]}
     ol, og = OP.loss_and_grads(sd, batch0, noise[:8], ts[:8], names=names)
-    ref = torch.cat([og[n].flatten() for n in names]).double()
     assert abs(first[0] - ol.item()) <= TOL * abs(ol.item())
-    assert float((first[1] - ref).abs().max()) <= TOL * float(ref.abs().max())
+    # per tensor, against max(|its gradient|, 1e-3 x the largest gradient norm): the criterion of the B=2 golden test above
+    gsc = max(float(og[n].double().norm()) for n in names)
+    off, worst = 0, 0.0
+    for n in names:
+        k = og[n].numel()
+        worst = max(worst, float((first[1][off:off + k] - og[n].flatten().double()).abs().max()) / max(float(og[n].abs().max()), 1e-3 * gsc))
+        off += k
+    print(f"[B=256] chunk 0 vs CPU oracle: worst per-tensor gradient error {worst:.2e}")
+    assert worst <= TOL, worst

@@ -33,7 +33,7 @@ from v2a_hip.replay import ReplayStore, sample_mixed
 from v2a_hip.trainer import PolicyTrainer
 from . import _host_utils as utils
 from ._host_utils import imgs_preproc_simple_noCrop_v1
-from .lb_randsam_io import open_randsam
+from .lb_randsam_io import open_randsam, check_and_clip_actions
 
 __version__ = "v2a-mi355x-0.1"
 
@@ -514,9 +514,7 @@ class LB_Online_Trainer_V7(object):
                     assert not self.randsam.has(tk, i_ep)
                     break
                 imgs_ep, acts_ep = self.randsam.episode(tk, i_ep)
-                assert (acts_ep > self.act_min_np[None] - 0.012).all()
-                assert (acts_ep < self.act_max_np[None] + 0.012).all()
-                acts_ep = np.clip(acts_ep, a_min=self.act_min_np[None], a_max=self.act_max_np[None]).astype(np.float32)
+                acts_ep = check_and_clip_actions(acts_ep, self.act_min_np, self.act_max_np)
                 assert len(imgs_ep) - 1 == len(acts_ep)
                 if not self.is_all_randsam_visited:
                     self.num_steps_in_env += len(acts_ep)

@@ -6,33 +6,93 @@ environment/libero/lb_data/lb_randsam.py:84-104 --
     {task}/{episode}/ee_poses         float  [T+1,3]          attrs: env_seed, env_list_name
 
 -- feeding the HBM-resident uint8 replay store directly (the reference re-expands every frame to an fp32 CPU tensor,
-lb_online_trainer_v7.py:718-780).  Three back ends behind one interface: HDF5 (needs h5py, like the reference), a directory of
-`.npz` episodes with the same keys (for machines without h5py; `convert_h5_to_npz` writes it), and a synthetic generator that
-rolls uniform random actions in the toy environment (benchmarks / tests)."""
+lb_online_trainer_v7.py:718-780).  Three back ends behind one interface: the HDF5 file through the library's native reader
+(csrc/h5read.hip -- h5py is not needed), a directory of `.npz` episodes with the same keys, and a synthetic generator that rolls
+uniform random actions in the toy environment (benchmarks / tests)."""
 import os
 import numpy as np
 
 
 class RandSamH5:
+    """The HDF5 file itself, through the library's own reader (csrc/h5read.hip: v2a_h5_*; no h5py, no libhdf5).  The file stays
+    memory-mapped while the object lives; `episode` copies one episode's frames / actions out as numpy arrays (uint8 frames go on to
+    the HBM replay store unchanged).  Unsupported on-disk features (compression, libver='latest' structures) raise with the reason."""
+
+    _NP = {(0, 1, 0): np.uint8, (0, 1, 1): np.int8, (0, 2, 0): np.uint16, (0, 2, 1): np.int16, (0, 4, 0): np.uint32, (0, 4, 1): np.int32,
+           (0, 8, 0): np.uint64, (0, 8, 1): np.int64, (1, 4, 1): np.float32, (1, 8, 1): np.float64}
+
     def __init__(self, path):
-        import h5py                                  # not installed in every image: raised at construction, loudly
-        self._h5py = h5py
+        import ctypes
+        from v2a_hip._lib import lib
+        self._ct, self._lib = ctypes, lib
         self.path = path
         if not os.path.exists(path):
             raise FileNotFoundError(path)
+        self._h = ctypes.c_void_p()
+        if lib.v2a_h5_open(os.fsencode(path), ctypes.byref(self._h)) != 0:
+            msg = self._err()
+            lib.v2a_h5_close(self._h)
+            self._h = None
+            raise OSError(f"{path}: {msg}")
+
+    def _err(self):
+        return (self._lib.v2a_h5_last_error(self._h) or b"").decode(errors="replace")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.v2a_h5_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def members(self, group):
+        cap = 1 << 16
+        while True:
+            buf = self._ct.create_string_buffer(cap)
+            n = self._lib.v2a_h5_list(self._h, group.encode(), buf, cap)
+            if n == -2:
+                cap *= 4
+                continue
+            if n < 0:
+                raise KeyError(f"{group}: {self._err()}")
+            return buf.value.decode().split("\n")[:n]
+
+    def read(self, path):
+        ct = self._ct
+        tc, es, sg, nd, nb = ct.c_int(), ct.c_int(), ct.c_int(), ct.c_int(), ct.c_longlong()
+        dims = (ct.c_longlong * 8)()
+        if self._lib.v2a_h5_dataset_info(self._h, path.encode(), ct.byref(tc), ct.byref(es), ct.byref(sg), ct.byref(nd), dims, ct.byref(nb)):
+            raise KeyError(f"{path}: {self._err()}")
+        dt = self._NP.get((tc.value, es.value, sg.value if tc.value == 0 else 1))
+        if dt is None:
+            raise TypeError(f"{path}: unsupported element type (class {tc.value}, {es.value} bytes)")
+        out = np.empty(tuple(dims[i] for i in range(nd.value)), dtype=dt)
+        if self._lib.v2a_h5_read(self._h, path.encode(), out.ctypes.data, out.nbytes):
+            raise OSError(f"{path}: {self._err()}")
+        return out
 
     def num_episodes(self, task):
-        with self._h5py.File(self.path, 'r') as f:
-            return sorted(int(k) for k in f[f'{task}'].keys())[-1] + 1      # lb_online_trainer_v7.py:246-252
+        return sorted(int(k) for k in self.members(task))[-1] + 1           # lb_online_trainer_v7.py:246-252
 
     def has(self, task, i_ep):
-        with self._h5py.File(self.path, 'r') as f:
-            return f'{task}/{i_ep}' in f
+        r = self._lib.v2a_h5_exists(self._h, f"{task}/{i_ep}".encode())
+        if r < 0:
+            raise OSError(f"{self.path}: {self._err()}")
+        return bool(r)
 
     def episode(self, task, i_ep):
-        with self._h5py.File(self.path, 'r') as f:
-            g = f[f'{task}/{i_ep}']
-            return g['agentview_image'][:], g['action'][:]
+        return self.read(f"{task}/{i_ep}/agentview_image"), self.read(f"{task}/{i_ep}/action")
+
+
+def check_and_clip_actions(acts, act_min, act_max, slack=0.012):
+    """The loader's contract on stored actions (lb_online_trainer_v7.py:749-752): every component strictly inside the limits widened
+    by `slack` (the generator's orientation noise overshoots +-0.1 by up to 0.011), then clipped to the limits; float32 out."""
+    acts = np.asarray(acts)
+    lo, hi = np.asarray(act_min)[None], np.asarray(act_max)[None]
+    if not (acts > lo - slack).all() or not (acts < hi + slack).all():
+        raise AssertionError("stored action outside the action limits by more than the loader's slack")
+    return np.clip(acts, a_min=lo, a_max=hi).astype(np.float32)
 
 
 class RandSamNpzDir:
@@ -107,9 +167,8 @@ def open_randsam(spec, env_list=None):
 
 def convert_h5_to_npz(h5_path, out_root):
     src = RandSamH5(h5_path)
-    with src._h5py.File(h5_path, 'r') as f:
-        for task in f.keys():
-            for ep in f[task].keys():
-                g = f[f'{task}/{ep}']
-                RandSamNpzDir.write_episode(out_root, task, int(ep), g['agentview_image'][:], g['action'][:],
-                                            g['ee_poses'][:] if 'ee_poses' in g else None, int(g.attrs.get('env_seed', 0)))
+    for task in src.members("/"):
+        for ep in src.members(task):
+            g = f"{task}/{ep}"
+            ee = src.read(g + "/ee_poses") if "ee_poses" in src.members(g) else None
+            RandSamNpzDir.write_episode(out_root, task, int(ep), src.read(g + "/agentview_image"), src.read(g + "/action"), ee)

@@ -51,6 +51,13 @@ SIGNATURES = {
     "v2a_mse_loss": (I, [P, P, P, P, I, P]),
     "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
     "v2a_gn_param_grads_multi": (I, [P, P, I, P]),
+    "v2a_h5_open": (I, [ctypes.c_char_p, P]),
+    "v2a_h5_close": (None, [P]),
+    "v2a_h5_last_error": (ctypes.c_char_p, [P]),
+    "v2a_h5_exists": (I, [P, ctypes.c_char_p]),
+    "v2a_h5_list": (ctypes.c_long, [P, ctypes.c_char_p, P, SZ]),
+    "v2a_h5_dataset_info": (I, [P, ctypes.c_char_p, P, P, P, P, P, P]),
+    "v2a_h5_read": (I, [P, ctypes.c_char_p, P, SZ]),
     "v2a_unnormalize_action": (I, [P, P, I, P, P, I, P]),
     "v2a_nchw_to_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),
