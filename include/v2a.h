@@ -96,6 +96,20 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
                         float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+/* The same two operations taking the normalised tensor (forward: x; backward: dout) as the still-unreduced split-K slabs of the conv
+   that produces it: element = sum_s slabs[s][idx] + cbias[c] (forward) / + sresid[idx] (backward).  The conv's reduce launch disappears;
+   `x` (forward) / `dout_sum` (backward, optional) receive the finished tensor.  Only for shapes v2a_groupnorm_takes_slabs() accepts
+   (one wave per (sample, group): S * C / G <= 1024, C / G in {16, 32, 64, 128}); nslab = 0 behaves like the _t functions. */
+int v2a_groupnorm_takes_slabs(int S, int C, int G);
+int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* reserved,
+                        void* workspace, size_t workspace_bytes, v2a_stream_t s);
+int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
+                        void* workspace, size_t workspace_bytes, v2a_stream_t s);
 /* dgamma / dbeta of many GroupNorm layers in ONE launch (pass dgamma = dbeta = NULL to v2a_groupnorm_bwd and keep its colsum):
    table [nrows][5] int64 rows {colsum ptr, dgamma ptr, dbeta ptr, N, C}; work [nwork][2] int32 = (row, 64-channel block) */
 int v2a_gn_param_grads_multi(const void* table, const void* work, int nwork, v2a_stream_t s);
@@ -215,6 +229,12 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
                            const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
                            int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, float* stats,
                            void* workspace, size_t workspace_bytes, v2a_stream_t s);
+/* same, leaving the split-K reduce to the consuming GroupNorm launch (v2a_groupnorm_fwd_s / _bwd_s): *nslab_out (HOST) = number of
+   fp32 slabs [M][Cout] left in `workspace` (bias / residual not applied, y untouched), or 0 when the conv finished y itself */
+int v2a_conv2d_fwd_dma_f32_d(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
+                             const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
+                             int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, int* nslab_out,
+                             void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 /* residual (bf16) xor residual_f32; idil 1 | 2; stats (optional, only when v2a_conv2d_h_workspace_bytes() == 0 and y is bf16):
  * [ceil(M/64)][2][Cout] per-64-row sum / sum of squares of the rounded outputs, consumed by v2a_groupnorm_fwd_h */
 /* multi-stage 256-row variant of v2a_conv2d_fwd_h for the large layers (csrc/igemm_h2.hip: 8 waves, 4-5 LDS stages, counted vmcnt):

@@ -456,15 +456,29 @@ def test_batch_256_step_ties_to_oracle_through_linearity():
     e_l, e_g = abs(L - acc_l) / abs(acc_l), float((G - acc_g).abs().max()) / gmax
     print(f"[B=256] loss {L:.6f} vs mean of 32 chunks {acc_l:.6f} (rel {e_l:.1e}); gradient max err {e_g:.1e} of max |g|")
     assert e_l <= 1e-5 and e_g <= 1e-4
+    # chunk 0 against the CPU oracle.  Yard-stick: the oracle's own fp32 run against its fp64 run on the same rows -- some gradients
+    # (sums of large cancelling terms over 8 x 4096 pixels) carry 1e-3 relative rounding noise in ANY fp32 implementation.
     batch0 = {"obs": {k: v[:8, None] for k, v in imgs.items()}, "action": act[:8]}
-    ol, og = OP.loss_and_grads(sd, batch0, noise[:8], ts[:8], names=names)
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(32, old))
+    try:
+        ol, og = OP.loss_and_grads(sd, batch0, noise[:8], ts[:8], names=names)
+        sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
+        b64 = {"obs": {k: v.double() for k, v in batch0["obs"].items()}, "action": batch0["action"].double()}
+        _, og64 = OP.loss_and_grads(sd64, b64, noise[:8].double(), ts[:8], names=names)
+    finally:
+        torch.set_num_threads(old)
     assert abs(first[0] - ol.item()) <= TOL * abs(ol.item())
-    # per tensor, against max(|its gradient|, 1e-3 x the largest gradient norm): the criterion of the B=2 golden test above
-    gsc = max(float(og[n].double().norm()) for n in names)
-    off, worst = 0, 0.0
+    gsc = max(float(og64[n].norm()) for n in names)
+    off, worst, worst_ref, bad = 0, 0.0, 0.0, []
     for n in names:
         k = og[n].numel()
-        worst = max(worst, float((first[1][off:off + k] - og[n].flatten().double()).abs().max()) / max(float(og[n].abs().max()), 1e-3 * gsc))
+        scale = max(float(og64[n].abs().max()), 1e-3 * gsc)
+        e_hip = float((first[1][off:off + k] - og64[n].flatten()).abs().max()) / scale
+        e_ref = float((og[n].flatten().double() - og64[n].flatten()).abs().max()) / scale
+        worst, worst_ref = max(worst, e_hip), max(worst_ref, e_ref)
+        if e_hip > max(TOL, 4 * e_ref):
+            bad.append((n, e_hip, e_ref))
         off += k
-    print(f"[B=256] chunk 0 vs CPU oracle: worst per-tensor gradient error {worst:.2e}")
-    assert worst <= TOL, worst
+    print(f"[B=256] chunk 0 vs fp64 oracle: worst per-tensor gradient error HIP {worst:.2e}, CPU fp32 oracle {worst_ref:.2e}")
+    assert not bad, bad[:5]

@@ -493,8 +493,9 @@ template <typename T>
 static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                            const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2,
                            int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
-                           float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                           float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream, int* nslab_out = nullptr) {
     constexpr int ept = 128 / (int)sizeof(T);
+    if (nslab_out) *nslab_out = 0;
     if (!x || !w_packed || !zeros || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
     if (C1 <= 0 || C1 % ept || C2 < 0 || C2 % ept || (C2 > 0 && !x2)) return V2A_ERR_ARG;
     if ((idil != 1 && idil != 2) || (idil == 2 && ups) || (residual && residual_f32)) return V2A_ERR_ARG;
@@ -544,6 +545,10 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     else hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     if (s > 1) {
+        if (nslab_out && !rowvec && !residual_f32) {       // the consumer (a GroupNorm launch) sums the slabs itself: no reduce launch
+            *nslab_out = s;
+            return V2A_OK;
+        }
         const size_t total = (size_t)p.M * Cout;
         int g = (int)((total + 255) / 256);
         if (g > 4096) g = 4096;
@@ -576,6 +581,18 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
     if (!y) return V2A_ERR_ARG;
     return conv_dma_launch<float>(x, x2, w_packed, bias, rowvec, residual, nullptr, y, nullptr, zeros, N, H, W, C1, C2, Cout, KH, KW, sh, sw,
                                   ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
+}
+
+// The same conv with the split-K reduce left to the consumer: when the plan splits K, the fp32 slabs [nslab][M][Cout] stay in
+// `workspace` (bias and residual NOT applied, y untouched) and *nslab_out = their number; a GroupNorm launch then sums them
+// (v2a_groupnorm_fwd_s / _bwd_s).  *nslab_out = 0: the conv finished y itself (no split, or a rowvec epilogue).
+int v2a_conv2d_fwd_dma_f32_d(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
+                             const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
+                             int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, int* nslab_out,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!y || !nslab_out) return V2A_ERR_ARG;
+    return conv_dma_launch<float>(x, x2, w_packed, bias, rowvec, residual, nullptr, y, nullptr, zeros, N, H, W, C1, C2, Cout, KH, KW, sh, sw,
+                                  ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes, stream, nslab_out);
 }
 
 // torch-layout fp32 weight [Cout][Cin][taps] -> bf16 [Cout][taps][Cin]

@@ -11,6 +11,7 @@
 // Statistics are combined in fp64 (sum / sum-of-squares of fp32 partials) so that mean / rstd carry < 1e-6
 // relative error -- the parity budget of the path is 1e-4.
 #include "common.h"
+#include <stdlib.h>
 
 struct GnDesc {
     const float* x;         // [N][S][C]   (or channels [0, C1) of a virtual concat when x2 != null: row stride C1)
@@ -32,6 +33,15 @@ struct GnDesc {
     float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
     int film_ld;            // elements between the FiLM rows of consecutive samples (2*C when the [N][2][C] tensor is dense)
     float eps;
+    // wave path only -- the tensor this GroupNorm normalises (forward: x; backward: dout) may still be the split-K slabs of the conv that
+    // produced it: element = sum_s slab[s][idx] (+ cbias[c]) (+ sresid[idx]), summed here in the reduce kernel's order instead of in a
+    // launch of its own; `sout` (optional) receives the finished tensor for other readers (the tape / weight gradients).
+    const float* slabs;     // [nslab][N*S*C] or null
+    const float* cbias;     // [C] conv bias or null
+    const float* sresid;    // [N][S][C] residual the conv epilogue would have added, or null
+    float* sout;            // [N][S][C] or null
+    int nslab;
+    size_t slab_stride;
 };
 
 __device__ __forceinline__ unsigned short gn_f2bf(float f) {      // round to nearest even, as v2a_cast_f32_bf16
@@ -385,6 +395,156 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------- wave path
+// One WAVE per (n, group) for slabs of E = S * CG <= 1024 elements with CG in {16, 32, 64, 128}: the ConditionalUnet1D blocks
+// (E = 512: 16 x 32, 8 x 64, 4 x 128) and the deep ResNet stages.  Everything lives in registers (E / 64 values per lane), the only
+// cross-lane traffic is wave shuffles -- no LDS, no __syncthreads -- so a launch costs what its loads cost (3-4 us instead of the
+// 9 / 15 us of the workgroup-per-slab kernels: these launches sit on the serial chain of the train step).  Element i of the slab
+// (row i / CG, channel i % CG) belongs to lane i % 64, so a lane sees a fixed set of channels: per-channel sums over the rows
+// (dgamma / dbeta / dFiLM contributions) are lane-local for CG >= 64 and need log2(64 / CG) shuffles otherwise.  Deterministic.
+template <int CG>
+__device__ __forceinline__ float gn_wave_load(const GnDesc& p, const float* dense, size_t off, int c) {
+    if (p.nslab > 0) {
+        float t = 0.f;
+        for (int sI = 0; sI < p.nslab; ++sI) t += p.slabs[(size_t)sI * p.slab_stride + off];
+        if (p.cbias) t += p.cbias[c];
+        if (p.sresid) t += p.sresid[off];
+        if (p.sout) p.sout[off] = t;
+        return t;
+    }
+    return dense[off];
+}
+
+template <int CG>
+__global__ __launch_bounds__(256) void gn_wave_fwd(const GnDesc p) {
+    constexpr int MAXE = 16;
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= p.N * p.G) return;
+    const int n = wv / p.G, g = wv - n * p.G;
+    const int C = p.C, epl = (p.S * CG) >> 6;
+    const size_t base = (size_t)n * p.S * C + (size_t)g * CG;
+    float v[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        v[j] = 0.f;
+        if (j < epl) {
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG;
+            v[j] = gn_wave_load<CG>(p, p.x, base + (size_t)row * C + cc, g * CG + cc);
+            s += v[j];
+        }
+    }
+    const float inv = 1.0f / (float)(p.S * CG);
+    const float mu = wave_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j)
+        if (j < epl) { const float d = v[j] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * inv + p.eps);
+    if (lane == 0) { p.mean[wv] = mu; p.rstd[wv] = rs; }
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j)
+        if (j < epl) {
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            const size_t off = base + (size_t)row * C + cc;
+            float z = (v[j] - mu) * rs * p.gamma[c] + p.beta[c];
+            if (p.residual) z += p.residual[off];
+            float a = act_fwd(z, p.act);
+            if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
+            p.y[off] = a;
+            if (p.yh) p.yh[off] = gn_f2bf(a);
+        }
+}
+
+template <int CG>
+__global__ __launch_bounds__(256) void gn_wave_bwd(const GnDesc p) {
+    constexpr int MAXE = 16;
+    constexpr int NCOL = CG >= 64 ? CG / 64 : 1;          // channels a lane owns
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= p.N * p.G) return;
+    const int n = wv / p.G, g = wv - n * p.G;
+    const int C = p.C, epl = (p.S * CG) >> 6;
+    const size_t base = (size_t)n * p.S * C + (size_t)g * CG;
+    const float mu = p.mean[wv], rs = p.rstd[wv];
+    const bool film = p.film != nullptr;
+    float xh[MAXE], dz[MAXE];
+    float c0[NCOL], c1[NCOL], c2[NCOL], c3[NCOL];
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0.f;
+    float A1 = 0.f, A2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        xh[j] = dz[j] = 0.f;
+        if (j < epl) {
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            const size_t off = base + (size_t)row * C + cc;
+            const float h = (p.x[off] - mu) * rs;
+            const float gm = p.gamma[c];
+            float z = h * gm + p.beta[c];
+            if (p.residual) z += p.residual[off];
+            const float dout = gn_wave_load<CG>(p, p.dout, off, c);
+            float da = dout;
+            const int k = CG >= 64 ? (j % NCOL) : 0;
+            if (film) {
+                const float a = act_fwd(z, p.act);
+                da = dout * p.film[(size_t)n * p.film_ld + c];
+                c2[k] += dout * a;
+                c3[k] += dout;
+            }
+            const float d = da * act_bwd(z, p.act);
+            xh[j] = h;
+            dz[j] = d;
+            c0[k] += d;
+            c1[k] += d * h;
+            A1 += d * gm;
+            A2 += d * gm * h;
+        }
+    }
+    A1 = wave_sum(A1);
+    A2 = wave_sum(A2);
+    const float inv = 1.0f / (float)(p.S * CG);
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j)
+        if (j < epl) {
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            const size_t off = base + (size_t)row * C + cc;
+            const float dxv = rs * (p.gamma[c] * dz[j] - (A1 + xh[j] * A2) * inv);
+            p.y[off] = dxv;
+            if (p.yh) p.yh[off] = gn_f2bf(dxv);
+            if (p.dres) p.dres[off] = dz[j];
+        }
+    if (CG < 64) {                       // lanes l, l + CG, l + 2 CG ... hold the same channel: fixed xor tree
+#pragma unroll
+        for (int o = 32; o >= CG; o >>= 1) {
+            c0[0] += __shfl_xor(c0[0], o, 64);
+            c1[0] += __shfl_xor(c1[0], o, 64);
+            if (film) { c2[0] += __shfl_xor(c2[0], o, 64); c3[0] += __shfl_xor(c3[0], o, 64); }
+        }
+    }
+    if (lane < (CG < 64 ? CG : 64)) {
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) {
+            const int c = g * CG + lane + 64 * k;
+            p.colsum[(size_t)n * 2 * C + c] = c0[k];
+            p.colsum[(size_t)n * 2 * C + C + c] = c1[k];
+            if (p.dfilm) {
+                p.dfilm[(size_t)n * p.film_ld + c] = c2[k];
+                p.dfilm[(size_t)n * p.film_ld + C + c] = c3[k];
+            }
+        }
+    }
+}
+
+static bool gn_wave_ok(int S, int cg) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2A_GN_WAVE"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || !(cg == 16 || cg == 32 || cg == 64 || cg == 128)) return false;
+    const long E = (long)S * cg;
+    return E % 64 == 0 && E / 64 <= 16;
+}
+
 // dgamma[c] = sum_n colsum[n][1][c], dbeta[c] = sum_n colsum[n][0][c]
 __global__ __launch_bounds__(256) void gn_param_grads(const float* colsum, float* dgamma, float* dbeta, int N, int C, int accumulate) {
     __shared__ double sm[2][4][64];
@@ -453,6 +613,15 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
     return (size_t)N * nchunk * 2 * C * sizeof(double) + (size_t)N * G * 2 * sizeof(float);     // chunk partials + per-group sums
 }
 
+int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* unused_resid,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream);
+int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream);
 // y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
 // x2 != null: the input is the channel concat [x | x2] (decoder skip, reference unet.py:681) read from both sources in place.
 int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
@@ -468,7 +637,20 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
 int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                         int act, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return v2a_groupnorm_fwd_s(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, mean, rstd, N, S, C, G, eps, act, nullptr, 0, 0,
+                               nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+// 1 when a GroupNorm over [N, S, C] with G groups runs on the wave path, i.e. accepts its input as split-K slabs (v2a_groupnorm_*_s)
+int v2a_groupnorm_takes_slabs(int S, int C, int G) { return (G > 0 && C % G == 0 && gn_wave_ok(S, C / G)) ? 1 : 0; }
+// same as v2a_groupnorm_fwd_t; with nslab > 0 the normalised tensor is sum_s slabs[s][.] + cbias[c] (the split-K partial sums and bias
+// of the conv that produces it: its reduce launch is folded into this one) and `x` receives that sum (kept for the backward).
+int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* unused_resid,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    (void)unused_resid;
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
+    if (nslab > 0 && (!slabs || x2 || !gn_wave_ok(S, C / G))) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x2 = x2; p.C1 = x2 ? C1 : C;
@@ -478,6 +660,16 @@ int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* ga
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act; p.eps = eps;
     const int cg = C / G;
     const long E = (long)S * cg;
+    if (!x2 && gn_wave_ok(S, cg)) {
+        if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.cbias = cbias; p.sout = (float*)x; }
+        const dim3 grid((N * G + 3) / 4), block(256);
+        if (cg == 16) hipLaunchKernelGGL(gn_wave_fwd<16>, grid, block, 0, stream, p);
+        else if (cg == 32) hipLaunchKernelGGL(gn_wave_fwd<32>, grid, block, 0, stream, p);
+        else if (cg == 64) hipLaunchKernelGGL(gn_wave_fwd<64>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(gn_wave_fwd<128>, grid, block, 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
+    }
     if (E <= GN_SMALL_MAX) {
         size_t lds = (E + 8) * sizeof(float);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -521,7 +713,18 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
                         float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !gamma || !beta || !dout || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
+    return v2a_groupnorm_bwd_s(x, gamma, beta, residual, film, film_ld, dout, mean, rstd, dx, dx_h, dres, dfilm, colsum, dgamma, dbeta,
+                               accumulate_params, N, S, C, G, act, nullptr, 0, 0, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+// same; with nslab > 0 the incoming gradient is sum_s slabs[s][.] + sresid[.] (split-K partial sums and epilogue residual of the data-
+// gradient conv that produces it) and `dout_sum` (optional) receives that sum for its other readers; `dout` is then ignored.
+int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || (!dout && nslab <= 0) || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
+    if (nslab > 0 && (!slabs || !gn_wave_ok(S, C / G))) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
@@ -529,7 +732,15 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;
     const long E = (long)S * cg;
-    if (E <= GN_SMALL_MAX) {
+    if (gn_wave_ok(S, cg)) {
+        if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.sresid = sresid; p.sout = dout_sum; }
+        const dim3 grid((N * G + 3) / 4), block(256);
+        if (cg == 16) hipLaunchKernelGGL(gn_wave_bwd<16>, grid, block, 0, stream, p);
+        else if (cg == 32) hipLaunchKernelGGL(gn_wave_bwd<32>, grid, block, 0, stream, p);
+        else if (cg == 64) hipLaunchKernelGGL(gn_wave_bwd<64>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(gn_wave_bwd<128>, grid, block, 0, stream, p);
+        V2A_CHECK_LAUNCH();
+    } else if (E <= GN_SMALL_MAX) {
         const int nsl = cg >= 256 ? 1 : 256 / cg;
         size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 8) * sizeof(float);
         if (lds > 160 * 1024) return V2A_ERR_ARG;

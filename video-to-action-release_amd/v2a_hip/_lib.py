@@ -51,6 +51,9 @@ SIGNATURES = {
     "v2a_mse_loss": (I, [P, P, P, P, I, P]),
     "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
     "v2a_gn_param_grads_multi": (I, [P, P, I, P]),
+    "v2a_groupnorm_takes_slabs": (I, [I, I, I]),
+    "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, SZ, P]),
+    "v2a_groupnorm_bwd_s": (I, [P] * 5 + [I] + [P] * 10 + [I, I, I, I, I, I, P, I, SZ, P, P, P, SZ, P]),
     "v2a_h5_open": (I, [ctypes.c_char_p, P]),
     "v2a_h5_close": (None, [P]),
     "v2a_h5_last_error": (ctypes.c_char_p, [P]),
@@ -100,6 +103,7 @@ SIGNATURES = {
     "v2a_conv2d_dma_f32_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_h_can_emit_stats": (I, [I, I, I]),
     "v2a_conv2d_fwd_dma_f32": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
+    "v2a_conv2d_fwd_dma_f32_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_h2_eligible": (I, [I, I, I, I, I]),
     "v2a_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P] + [I] * 16 + [P, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),

@@ -138,8 +138,25 @@ def _twin_of(w_packed):
     return ent[1]
 
 
-def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y):
-    """fp32 conv on the LDS-DMA kernel (exact-f32 MFMA): same results as the register-staged kernel up to summation order."""
+class Slabs:
+    """Split-K partial sums a conv left for its consumer (conv2d(..., defer=True)): the tensor is sum_s ws[s] (+ bias) (+ residual).
+    Only valid until the next launch that uses the same scratch lane -- the consumer must be the very next user."""
+    __slots__ = ("ws", "n", "stride", "bias", "residual")
+
+    def __init__(self, ws, n, stride, bias, residual):
+        self.ws, self.n, self.stride, self.bias, self.residual = ws, n, stride, bias, residual
+
+
+def gn_takes_slabs(S, C, G):
+    return bool(lib.v2a_groupnorm_takes_slabs(S, C, G))
+
+
+_DEFER = os.environ.get('V2A_DEFER_REDUCE', '1') != '0'
+
+
+def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y, defer=False):
+    """fp32 conv on the LDS-DMA kernel (exact-f32 MFMA): same results as the register-staged kernel up to summation order.
+    defer: returns (y, Slabs | None) -- with Slabs the split-K reduce is left to the consuming GroupNorm launch."""
     N, H, W, C1 = x.shape
     C2 = x2.shape[-1] if x2 is not None else 0
     sh, sw = stride
@@ -156,16 +173,24 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
         y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
     wsb = lib.v2a_conv2d_dma_f32_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
+    last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
+    if defer and _DEFER and wsb and rowvec is None:
+        import ctypes
+        ns = ctypes.c_int(0)
+        check(lib.v2a_conv2d_fwd_dma_f32_d(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), None, _p(residual), y.data_ptr(),
+                                           _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0,
+                                           idil, OH, OW, rows_per_batch, ctypes.byref(ns), _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32_d")
+        return y, (Slabs(ws, ns.value, M * Cout, bias, residual) if ns.value > 0 else None)
     check(lib.v2a_conv2d_fwd_dma_f32(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
                                      _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil,
                                      OH, OW, rows_per_batch, None, _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32")
-    last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
-    return y
+    return (y, None) if defer else y
 
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
-           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None):
-    """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout].
+           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None, defer=False):
+    """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]; with defer=True
+    (y, Slabs | None): when Slabs is returned, y is NOT written yet -- hand both to the GroupNorm that consumes the conv.
     bf16-MFMA mode: `x_h` = an existing bf16 twin of x (skips the cast launch); `keep_h` (a list) receives the twin that was used, so a
     training engine can hand it to conv2d_wgrad later."""
     _chk(x, "x")
@@ -176,7 +201,11 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
         C2 = x2.shape[-1]
     if (bmode == 0 and y2 is None and not csplit and C1 % 32 == 0 and C2 % 32 == 0 and idil in (1, 2) and not (ups and idil > 1)
             and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] and lib.v2a_get_precision() == 0):
-        return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y)
+        return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y,
+                               defer=defer)
+    if defer:          # every other route finishes y itself
+        return conv2d(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
+                      idil=idil, ups=ups, out_hw=out_hw, y=y, y2=y2, csplit=csplit, bmode=bmode, x_h=x_h, keep_h=keep_h), None
     if (_h_twin and bmode == 0 and y2 is None and not csplit and C1 % 64 == 0 and C2 % 64 == 0 and idil in (1, 2)
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)
@@ -367,7 +396,7 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ group norm
-def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None):
+def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
     Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
     that consumes y takes it as x_h and skips its cast launch)."""
@@ -386,6 +415,12 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     if twin_out is not None and C % 4 == 0:
         yh = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
         twin_out.append(yh)
+    if slabs is not None:      # x is the (still unwritten) conv output: the kernel sums the conv's split-K slabs and stores x too
+        assert slabs.residual is None
+        check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), None, C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
+                                      _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], slabs.ws.data_ptr(), slabs.n,
+                                      slabs.stride, _p(slabs.bias), None, None, 0, _stream()), "groupnorm_fwd_s")
+        return y, mean, rstd
     check(lib.v2a_groupnorm_fwd_t(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
                                   _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),
           "groupnorm_fwd")
@@ -411,7 +446,8 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
-                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None, colsum=None, defer_params=False):
+                  dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None, colsum=None, defer_params=False,
+                  dout_slabs=None, dout_sum=None):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
     as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx.
     defer_params: only fill `colsum` [N,2,C] (per-sample sums); the caller reduces it over n for many layers at once
@@ -436,6 +472,14 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
+    if dout_slabs is not None:      # dout = sum of the producing data-gradient conv's split-K slabs (+ its epilogue residual)
+        sl = dout_slabs
+        assert sl.bias is None
+        check(lib.v2a_groupnorm_bwd_s(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, None,
+                                      mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), _p(dres), _p(dfilm), colsum_.data_ptr(),
+                                      _p(dgamma), _p(dbeta), 1 if accumulate_params else 0, N, S, C, G, ACT[act], sl.ws.data_ptr(), sl.n,
+                                      sl.stride, _p(sl.residual), _p(dout_sum), None, 0, _stream()), "groupnorm_bwd_s")
+        return dx, dgamma, dbeta, dres, dfilm
     check(lib.v2a_groupnorm_bwd_t(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
                                   mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), _p(dres), _p(dfilm), colsum_.data_ptr(),
                                   _p(dgamma), _p(dbeta), 1 if accumulate_params else 0, N, S, C, G, ACT[act], _p(ws), wsb,

@@ -357,23 +357,31 @@ class PolicyEngine:
             self._film_ver = self._film_key()
 
     # ------------------------------------------------------------------ encoder
-    def _gn(self, x4, pre, G, act, residual=None, film=None):
+    def _gn(self, x4, pre, G, act, residual=None, film=None, slabs=None):
+        """slabs: x4 is the not-yet-reduced output of a conv launched with defer=True (ops.Slabs); the GroupNorm launch finishes it."""
         N = x4.shape[0]
         C = x4.shape[-1]
         x3 = x4.view(N, -1, C)
         r3 = residual.view(N, -1, C) if residual is not None else None
-        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film)
+        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs)
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
-    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None):
+    def _defer_ok(self, rows, C, G):
+        """May a conv whose [N, rows, C] output feeds GroupNorm(G) directly leave its split-K reduce to that launch?"""
+        return ops.gn_takes_slabs(rows, C, G) and ops.lib.v2a_get_precision() == 0
+
+    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None, dslabs=None, keep_dout=False):
+        """dslabs: dout4 is the not-yet-reduced output of a data-gradient conv (ops.Slabs); keep_dout: other launches read dout4 later,
+        so the GroupNorm launch also stores the finished sum into it."""
         x3, mean, rstd, r3, film, pre, G, act = saved
         d3 = dout4.view(x3.shape)
         N, _, C = x3.shape
+        kw = dict(dout_slabs=dslabs, dout_sum=d3 if (dslabs is not None and keep_dout) else None)
         chain = self._gn_chain
         if chain is None:            # outside a chain (stand-alone use): reduce this layer's parameter gradients right away
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                       residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
-                                                      dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], dfilm_out=dfilm_out)
+                                                      dgamma=grads[pre + ".weight"], dbeta=grads[pre + ".bias"], dfilm_out=dfilm_out, **kw)
         else:
             cs = self._gn_cs.get((pre, N, C))
             if cs is None:
@@ -382,7 +390,7 @@ class PolicyEngine:
             chain.append((pre, N, C))
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                       residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
-                                                      dfilm_out=dfilm_out, colsum=cs, defer_params=True)
+                                                      dfilm_out=dfilm_out, colsum=cs, defer_params=True, **kw)
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
     def _gn_begin(self):
@@ -426,16 +434,23 @@ class PolicyEngine:
             g = co // 16
             inp = h
             k1, k2 = [], []                          # bf16 twins of the conv inputs (bf16-MFMA mode): reused by the weight gradients
-            o1 = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1)
-            a, s1 = self._gn(o1, blk["pre"] + ".bn1", g, "relu")
-            o2 = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2)
+            # every conv is followed at once by the GroupNorm that consumes it: on the deep stages that launch also sums the conv's
+            # split-K slabs (no reduce launch of its own), so nothing else may touch the scratch lane in between
+            oh, ow = inp.shape[1] // s, inp.shape[2] // s
+            dfr = self._defer_ok(oh * ow, co, g)
+            o1, sl = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1, defer=dfr) if dfr else \
+                (ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1), None)
+            a, s1 = self._gn(o1, blk["pre"] + ".bn1", g, "relu", slabs=sl)
             sd = None
             if blk["down"] is not None:
-                idn = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0), x_h=k1[0] if k1 else None)
-                idn, sd = self._gn(idn, blk["pre"] + ".downsample.1", g, "none")
+                idn, sl = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0), x_h=k1[0] if k1 else None, defer=dfr) if dfr else \
+                    (ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0), x_h=k1[0] if k1 else None), None)
+                idn, sd = self._gn(idn, blk["pre"] + ".downsample.1", g, "none", slabs=sl)
             else:
                 idn = inp
-            h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn)
+            o2, sl = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, defer=dfr) if dfr else \
+                (ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2), None)
+            h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn, slabs=sl)
             st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd, inp_h=k1[0] if k1 else None, a_h=k2[0] if k2 else None))
         feat = h
         B, FH, FW, FC = feat.shape
@@ -465,15 +480,22 @@ class PolicyEngine:
         feat = st["feat"]
         self._wg(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
         dh = _dgrad(dkl, pool, None, pool.ci, 1, 1)
-        for blk, bs in zip(reversed(e["blocks"]), reversed(st["blocks"])):
+        dh_sl = None
+        nblk = len(e["blocks"])
+        for bi, (blk, bs) in enumerate(zip(reversed(e["blocks"]), reversed(st["blocks"]))):
             s, co, ci = blk["stride"], blk["cout"], blk["cin"]
             inp = bs["inp"]
-            do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True)
+            g = co // 16
+            dfr = self._defer_ok(bs["a"].shape[1] * bs["a"].shape[2], co, g)              # consumer: this block's bn1
+            # consumer of this block's input gradient: bn2 of the block before (none for the first block: maxpool)
+            dfr_in = bi + 1 < nblk and self._defer_ok(inp.shape[1] * inp.shape[2], ci, ci // 16)
+            do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True, dslabs=dh_sl)
             th = self._twin_dy                       # one bf16 rounding of a gradient serves its data and weight gradient
             do2h = th(do2, bs["a_h"], co)
             self._wg(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname], x_h=bs["a_h"], dy_h=do2h)
-            da = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1), x_h=do2h)
-            do1, _, _ = self._gn_bwd(bs["s1"], da, grads)
+            da, sl = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1), x_h=do2h, defer=True) if dfr else \
+                (_dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1), x_h=do2h), None)
+            do1, _, _ = self._gn_bwd(bs["s1"], da, grads, dslabs=sl)
             do1h = th(do1, bs["inp_h"], co)
             self._wg(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname], x_h=bs["inp_h"], dy_h=do1h)
             ih, iw = inp.shape[1], inp.shape[2]
@@ -482,9 +504,13 @@ class PolicyEngine:
                 ddh = th(didn_raw, bs["inp_h"], co)
                 self._wg(inp, didn_raw, blk["down"].shape, 1, 1, (s, s), (0, 0), dw=grads[blk["down"].wname], x_h=bs["inp_h"], dy_h=ddh)
                 d1 = _dgrad(didn_raw, blk["down"], None, ci, 1, 1, (1, 1), (0, 0), idil=s, out_hw=(ih, iw), x_h=ddh)
-                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=d1, x_h=do1h)
+                res_in = d1
             else:
-                dh = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=didn, x_h=do1h)
+                res_in = didn
+            if dfr_in:
+                dh, dh_sl = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=res_in, x_h=do1h, defer=True)
+            else:
+                dh, dh_sl = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=res_in, x_h=do1h), None
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
         # RGB stem: 3 input channels make every 16-B piece of the gathered operand straddle pixels (scalar-gather kernel, 0.4 ms
@@ -506,13 +532,15 @@ class PolicyEngine:
             self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
 
     # ------------------------------------------------------------------ ConditionalUnet1D
-    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None):
-        """Conv1d on [B,T,C] (channels-last) via the (1 x k) view."""
+    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None, defer=False):
+        """Conv1d on [B,T,C] (channels-last) via the (1 x k) view.  defer: returns (y, ops.Slabs | None), see ops.conv2d."""
         B, T, C = x.shape
         pad = k // 2 if pad is None else pad
         y = ops.conv2d(x.view(B, 1, T, C), cv.pf(), cv.b, cv.co, 1, k, (1, stride), (0, pad),
                        x2=None if x2 is None else x2.view(B, 1, T, -1),
-                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h)
+                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h, defer=defer)
+        if defer:
+            return y[0].view(B, -1, cv.co), y[1]
         return y.view(B, -1, cv.co)
 
     def _res_fwd(self, r, x, mgf, save, x2=None):
@@ -521,16 +549,17 @@ class PolicyEngine:
         B, T, _ = x.shape
         co = r["cout"]
         kx = []
-        c0 = self._c1d(x, r["c0"], k, x2=x2, keep_h=kx)
         if self._film_all is not None:
             film = self._film_all[:, r["film_off"]:r["film_off"] + 2 * co]         # column slice of the batched projection
         else:
             film = ops.linear(mgf, r["ce"].pf(), r["ce"].b)                       # [B, 2*co] == [B][2][co]
-        a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film)
+        dfr = self._defer_ok(T, co, G)        # the GroupNorm launch right behind each conv also sums its split-K slabs
+        c0, sl = self._c1d(x, r["c0"], k, x2=x2, keep_h=kx, defer=True) if dfr else (self._c1d(x, r["c0"], k, x2=x2, keep_h=kx), None)
+        a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film, slabs=sl)
         a0 = a0.view(B, T, co)
         ka = []
-        c1 = self._c1d(a0, r["c1"], k, keep_h=ka)
-        a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish")
+        c1, sl = self._c1d(a0, r["c1"], k, keep_h=ka, defer=True) if dfr else (self._c1d(a0, r["c1"], k, keep_h=ka), None)
+        a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish", slabs=sl)
         a1 = a1.view(B, T, co)
         x_h = kx[0] if kx else None                              # the twins also serve rc's and both weight gradients
         x2_h = kx[1] if (len(kx) > 1 and x2 is not None) else None
@@ -544,8 +573,11 @@ class PolicyEngine:
             save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None, x_h=x_h, x2_h=x2_h))
         return out
 
-    def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True):
-        """Returns (dx, dx2, dmgf).  dx2 only for two-source (concat) inputs.  `extra` is added to dx."""
+    def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True, dslabs=None, defer_dx=False):
+        """Returns (dx, dx2, dmgf).  dx2 only for two-source (concat) inputs.  `extra` is added to dx.
+        dslabs: `dout` still is the split-K slabs of the conv that produced it (ops.Slabs): the first GroupNorm backward sums them.
+        defer_dx: the caller's next consumer of dx is a GroupNorm backward, so dx may come back unreduced: then the return value is
+        ((dx, slabs), dx2, dmgf)."""
         cfg = self.cfg
         r, x, x2 = st["r"], st["x"], st["x2"]
         k = cfg.kernel_size
@@ -555,17 +587,19 @@ class PolicyEngine:
         x4 = x.view(B, 1, T, C1)
         x24 = None if x2 is None else x2.view(B, 1, T, -1)
         d4 = dout.view(B, 1, T, co)
-        dc1, _, _ = self._gn_bwd(st["s1"], d4, grads)
+        dc1, _, _ = self._gn_bwd(st["s1"], d4, grads, dslabs=dslabs, keep_dout=True)      # d4 is read again below (rc, residual)
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
         dc1h = self._twin_dy(dc1, st.get("a0_h"), co)
         self._wg(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname],
                  x_h=st.get("a0_h"), dy_h=dc1h)
-        da0 = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2), x_h=dc1h)
+        dfr = self._defer_ok(T, co, cfg.n_groups)
+        da0, sl = _dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2), x_h=dc1h, defer=True) if dfr else \
+            (_dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2), x_h=dc1h), None)
         if self._dfilm_all is not None:          # batched FiLM: the gradient rows go into this block's columns of [B, NF]
             o = r["film_off"]
-            dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co])
+            dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co], dslabs=sl)
         else:
-            dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True)
+            dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dslabs=sl)
             df2 = dfilm.view(B, 2 * co)
             self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
             dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0),
@@ -585,6 +619,9 @@ class PolicyEngine:
             first = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2),
                                residual=None if extra is None else extra.view(B, 1, T, ci), x_h=dc0h)
             if x2 is None:
+                if defer_dx:
+                    dx, sl = _dgrad(d4, rc, None, ci, 1, 1, residual=first, x_h=d4h, defer=True)
+                    return (dx.view(B, T, ci), sl), None, dmgf
                 dx = _dgrad(d4, rc, None, ci, 1, 1, residual=first, x_h=d4h).view(B, T, ci)
                 return dx, None, dmgf
             C2 = ci - C1
@@ -593,6 +630,9 @@ class PolicyEngine:
             _dgrad(d4, rc, None, ci, 1, 1, residual=first, y=dxa.view(B, 1, T, C1), y2=dxb.view(B, 1, T, C2), csplit=C1)
             return dxa, dxb, dmgf
         res = dout if extra is None else ops.axpy(dout, extra)
+        if defer_dx:
+            dx, sl = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci), x_h=dc0h, defer=True)
+            return (dx.view(B, T, ci), sl), None, dmgf
         dx = _dgrad(dc0, c0v, None, ci, 1, k, (1, 1), (0, k // 2), residual=res.view(B, 1, T, ci), x_h=dc0h).view(B, T, ci)
         return dx, None, dmgf
 
@@ -641,8 +681,9 @@ class PolicyEngine:
             if tape is not None:
                 tape.append(dict(us=us, x=xin))
         k = cfg.kernel_size
-        c = self._c1d(x, self.fin0, k)
-        a, sf = self._gn(c.view(B, 1, -1, self.fin0.co), "model.final_conv.0.block.1", 8, "mish")
+        dfr = self._defer_ok(x.shape[1], self.fin0.co, 8)
+        c, sl = self._c1d(x, self.fin0, k, defer=True) if dfr else (self._c1d(x, self.fin0, k), None)
+        a, sf = self._gn(c.view(B, 1, -1, self.fin0.co), "model.final_conv.0.block.1", 8, "mish", slabs=sl)
         a = a.view(B, -1, self.fin0.co)
         pred = self._c1d(a, self.fin1, 1, pad=0)
         if save is not None:
@@ -667,6 +708,7 @@ class PolicyEngine:
         self._dfilm_all = None
         if self._film_all is not None and self._film_grads_contiguous(grads):
             self._dfilm_all = torch.empty((B, self.film_nf), dtype=torch.float32, device=dpred.device)
+        dx_sl = None               # set when dx still is the split-K slabs of its conv (the next residual block's GroupNorm sums them)
         pending_skip = []          # gradients flowing into hs entries from the up path (LIFO order of use)
         # walk the tape backwards
         i = len(tape) - 1
@@ -699,7 +741,14 @@ class PolicyEngine:
                 # the first mid block consumes hs[-1] directly (Identity downsample on the last level)
                 if e["r"] is self.mid[0]:
                     extra = pending_skip.pop()
-                dx, dx2, dmgf = self._res_bwd(e, dx, grads, dmgf, extra=extra, need_dx=not first_block)
+                # dx may stay unreduced when the next consumer is the GroupNorm backward of another residual block on the wave path
+                nxt = tape[i - 1] if i > 0 else None
+                defer_dx = (not first_block and nxt is not None and "r" in nxt and e["x2"] is None
+                            and self._defer_ok(dx.shape[1], e["r"]["cin"], cfg.n_groups))
+                dx, dx2, dmgf = self._res_bwd(e, dx, grads, dmgf, extra=extra, need_dx=not first_block, dslabs=dx_sl, defer_dx=defer_dx)
+                dx_sl = None
+                if isinstance(dx, tuple):
+                    dx, dx_sl = dx
                 if dx2 is not None:
                     pending_skip.append(dx2)
             i -= 1
