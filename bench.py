@@ -76,6 +76,7 @@ def instrumented_pass(torch, trainer, steps):
         x, cout, kh, kw = a[0], a[3], a[4], a[5]
         c2 = k.get("x2").shape[-1] if k.get("x2") is not None else 0
         y = out if k.get("y") is None else k["y"]
+        y = y[0] if isinstance(y, tuple) else y          # conv2d(..., defer=True) returns (y, slabs)
         m = y.shape[0] * y.shape[1] * y.shape[2]
         K = kh * kw * (x.shape[-1] + c2)
         return (ops.last_kernel[0], 2.0 * m * cout * K, (m, cout, K, kh, kw, int(k.get("bmode", 0) or 0)))     # name: the launcher's plan

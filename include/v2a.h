@@ -235,6 +235,13 @@ int v2a_conv2d_fwd_dma_f32_d(const float* x, const float* x2, const float* w_pac
                              const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
                              int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, int* nslab_out,
                              void* workspace, size_t workspace_bytes, v2a_stream_t stream);
+/* bf16-operand variant (fp32 output): only for problems whose plan splits K (v2a_conv2d_h_splits() > 1); slabs hold neither bias nor
+   the fp32 residual -- the consumer adds both */
+int v2a_conv2d_h_splits(int M, int Cout, int K);
+int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, const float* bias, const void* reserved,
+                       const float* residual_f32, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH,
+                       int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, int* nslab_out,
+                       void* workspace, size_t workspace_bytes, v2a_stream_t stream);
 /* residual (bf16) xor residual_f32; idil 1 | 2; stats (optional, only when v2a_conv2d_h_workspace_bytes() == 0 and y is bf16):
  * [ceil(M/64)][2][Cout] per-64-row sum / sum of squares of the rounded outputs, consumed by v2a_groupnorm_fwd_h */
 /* multi-stage 256-row variant of v2a_conv2d_fwd_h for the large layers (csrc/igemm_h2.hip: 8 waves, 4-5 LDS stages, counted vmcnt):

@@ -458,8 +458,14 @@ static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* 
     }
     int sp = 1;
     const int nkt = K / ept;                       // k tiles of 128 B: 64 bf16 or 32 fp32
-    if (*tiles < 448) {                            // one round over the 512 workgroup slots, >= 6 k tiles per slice, <= 16 slices
-        sp = 512 / *tiles;
+    static int slots = -1;                         // workgroups aimed at per launch (V2A_CONV_SLOTS: tuning aid)
+    if (slots < 0) {
+        const char* e = getenv("V2A_CONV_SLOTS");
+        slots = e ? atoi(e) : 512;
+        if (slots < 256) slots = 512;
+    }
+    if (*tiles < slots - slots / 8) {              // one round over the workgroup slots, >= 6 k tiles per slice, <= 16 slices
+        sp = slots / *tiles;
         const int smax = nkt / 6 < 16 ? nkt / 6 : 16;
         if (sp > smax) sp = smax;
         if (sp < 1) sp = 1;
@@ -569,6 +575,30 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
     if (!y == !y_f32) return V2A_ERR_ARG;
     return conv_dma_launch<uint16_t>(x, x2, w_packed, bias, rowvec, residual, residual_f32, y, y_f32, zeros, N, H, W, C1, C2, Cout, KH, KW,
                                      sh, sw, ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
+}
+
+// v2a_conv2d_fwd_h with an fp32 output whose split-K reduce is left to the consuming GroupNorm launch (see v2a_conv2d_fwd_dma_f32_d)
+int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, const float* bias, const void* residual_unused,
+                       const float* residual_f32, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH,
+                       int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, int* nslab_out,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    (void)residual_unused;
+    if (!y_f32 || !nslab_out) return V2A_ERR_ARG;
+    // the fp32 residual of the epilogue travels with the slabs (the consumer adds it): pass it through the `residual` slot of the
+    // reduce-less path by clearing it here when the plan splits -- conv_dma_launch only defers when residual_f32 is null
+    int ns = 0;
+    const int rc = conv_dma_launch<uint16_t>(x, x2, w_packed, bias, nullptr, nullptr, nullptr, nullptr, y_f32, zeros, N, H, W, C1, C2, Cout, KH,
+                                             KW, sh, sw, ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes,
+                                             stream, &ns);
+    *nslab_out = ns;
+    if (rc != V2A_OK || ns > 0 || !residual_f32) return rc;
+    return V2A_ERR_ARG;      // unsplit plan with a residual: the caller must use v2a_conv2d_fwd_h (it asked v2a_conv2d_h_splits first)
+}
+// number of split-K slices v2a_conv2d_fwd_h / _d will use for this problem (1 = the conv finishes its output itself)
+int v2a_conv2d_h_splits(int M, int Cout, int K) {
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 64, &bm, &bn, &tiles, &s);
+    return s;
 }
 
 // The same LDS-DMA kernel over fp32 tensors with the exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the parity configuration's

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
 
 // -------------------------------------------------------------------------------------------- small path
 // one workgroup per (n, g): E = S * cg elements staged in LDS.  Forward: two-pass (centred) variance.
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [E] + 8 scratch
     const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
@@ -274,12 +275,23 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     float* red = sm + E;
     const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
     float s = 0.f;
+    if (VEC) {               // cg % 4 == 0: 16-B loads (a group's channels of one row are contiguous)
+        const int cg4 = cg >> 2, E4 = E >> 2;
 #pragma unroll 4
-    for (int i = tid; i < E; i += 256) {
-        const int row = i / cg, cc = i - row * cg;
-        const float v = p.x[base + (size_t)row * C + cc];
-        sm[i] = v;
-        s += v;
+        for (int i = tid; i < E4; i += 256) {
+            const int row = i / cg4, c4 = i - row * cg4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + base + (size_t)row * C + c4 * 4);
+            *reinterpret_cast<f32x4*>(sm + i * 4) = v;
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < E; i += 256) {
+            const int row = i / cg, cc = i - row * cg;
+            const float v = p.x[base + (size_t)row * C + cc];
+            sm[i] = v;
+            s += v;
+        }
     }
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -295,6 +307,28 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     const float var = (red[0] + red[1] + red[2] + red[3]) / (float)E;
     const float rs = 1.0f / sqrtf(var + p.eps);
     if (tid == 0) { p.mean[n * p.G + g] = mu; p.rstd[n * p.G + g] = rs; }
+    if (VEC) {
+        const int cg4 = cg >> 2, E4 = E >> 2;
+#pragma unroll 2
+        for (int i = tid; i < E4; i += 256) {
+            const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
+            const size_t off = base + (size_t)row * C + c4 * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(sm + i * 4);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = act_fwd((xv[j] - mu) * rs * gm[j] + bt[j] + r[j], p.act);
+                if (p.film) a = p.film[(size_t)n * p.film_ld + c + j] * a + p.film[(size_t)n * p.film_ld + C + c + j];
+                o[j] = a;
+            }
+            *reinterpret_cast<f32x4*>(p.y + off) = o;
+            if (p.yh) gn_store_twin4(p.yh, off >> 2, o);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
@@ -312,6 +346,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
 // (dgamma / dbeta = their sum over n: gn_param_grads / gn_param_grads_multi) and dfilm[n][0][c] = sum_s dout * a,
 // dfilm[n][1][c] = sum_s dout.  Deterministic: the per-element terms are staged in LDS and every column is summed over its rows in
 // a fixed order (thread = (row slice, column), then the slices in order) -- no float atomics, in LDS or in HBM.
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // xhat[E], dz[E], (film: dout*a[E], dout[E]), part[nsl][4][cg], red[8]
     const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
@@ -327,6 +362,31 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
     const float mu = p.mean[n * p.G + g], rs = p.rstd[n * p.G + g];
     float A1 = 0.f, A2 = 0.f;
+    if (VEC && !film) {
+        const int cg4 = cg >> 2, E4 = E >> 2;
+#pragma unroll 2
+        for (int i = tid; i < E4; i += 256) {
+            const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
+            const size_t off = base + (size_t)row * C + c4 * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off), dv = *reinterpret_cast<const f32x4*>(p.dout + off);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
+            f32x4 hv, zv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = (xv[j] - mu) * rs;
+                const float z = h * gm[j] + bt[j] + r[j];
+                const float dz = dv[j] * act_bwd(z, p.act);
+                hv[j] = h;
+                zv[j] = dz;
+                A1 += dz * gm[j];
+                A2 += dz * gm[j] * h;
+            }
+            *reinterpret_cast<f32x4*>(xh + i * 4) = hv;
+            *reinterpret_cast<f32x4*>(dzs + i * 4) = zv;
+        }
+    } else {
 #pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
@@ -348,6 +408,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         A1 += dz * p.gamma[c];
         A2 += dz * p.gamma[c] * h;
     }
+    }
     A1 = wave_sum(A1);
     A2 = wave_sum(A2);
     if ((tid & 63) == 0) { red[tid >> 6] = A1; red[4 + (tid >> 6)] = A2; }
@@ -355,6 +416,22 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     A1 = red[0] + red[1] + red[2] + red[3];
     A2 = red[4] + red[5] + red[6] + red[7];
     const float inv = 1.0f / (float)E;
+    if (VEC) {
+        const int cg4 = cg >> 2, E4 = E >> 2;
+#pragma unroll 2
+        for (int i = tid; i < E4; i += 256) {
+            const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
+            const size_t off = base + (size_t)row * C + c4 * 4;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(xh + i * 4), zv = *reinterpret_cast<const f32x4*>(dzs + i * 4);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs * (gm[j] * zv[j] - (A1 + hv[j] * A2) * inv);
+            *reinterpret_cast<f32x4*>(p.y + off) = o;
+            if (p.yh) gn_store_twin4(p.yh, off >> 2, o);
+            if (p.dres) *reinterpret_cast<f32x4*>(p.dres + off) = zv;
+        }
+    } else {
 #pragma unroll 4
     for (int i = tid; i < E; i += 256) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
@@ -363,6 +440,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         p.y[off] = dxv;
         if (p.yh) p.yh[off] = gn_f2bf(dxv);
         if (p.dres) p.dres[off] = dzs[i];
+    }
     }
     // column sums: thread (slice, cc) adds rows slice, slice + nsl, ... in order; then the slices in order
     for (int t = tid; t < nsl * cg; t += 256) {
@@ -402,39 +480,58 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
 // 9 / 15 us of the workgroup-per-slab kernels: these launches sit on the serial chain of the train step).  Element i of the slab
 // (row i / CG, channel i % CG) belongs to lane i % 64, so a lane sees a fixed set of channels: per-channel sums over the rows
 // (dgamma / dbeta / dFiLM contributions) are lane-local for CG >= 64 and need log2(64 / CG) shuffles otherwise.  Deterministic.
-template <int CG>
-__device__ __forceinline__ float gn_wave_load(const GnDesc& p, const float* dense, size_t off, int c) {
-    if (p.nslab > 0) {
-        float t = 0.f;
-        for (int sI = 0; sI < p.nslab; ++sI) t += p.slabs[(size_t)sI * p.slab_stride + off];
-        if (p.cbias) t += p.cbias[c];
-        if (p.sresid) t += p.sresid[off];
-        if (p.sout) p.sout[off] = t;
-        return t;
+// the lane's `epl` elements of the tensor the wave normalises (forward: x, backward: dout): a plain read, or -- when the producing
+// conv left its split-K slabs -- the slab sum in slab order (+ bias, + residual), loaded in batches of four slabs so that up to
+// 4 * epl independent loads are in flight per lane (the launch is latency-bound: two waves per CU).
+template <int CG, int MAXE>
+__device__ __forceinline__ void gn_wave_gather(const GnDesc& p, const float* dense, size_t base, int g, int lane, int epl, float (&v)[MAXE]) {
+    const int C = p.C;
+    size_t off[MAXE];
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        const int i = lane + 64 * j;
+        off[j] = base + (size_t)(i / CG) * C + (i % CG);
+        v[j] = 0.f;
     }
-    return dense[off];
+    if (p.nslab <= 0) {
+#pragma unroll
+        for (int j = 0; j < MAXE; ++j)
+            if (j < epl) v[j] = dense[off[j]];
+        return;
+    }
+    for (int s0 = 0; s0 < p.nslab; s0 += 4) {
+        float u[4][MAXE];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j)
+                u[q][j] = (s0 + q < p.nslab && j < epl) ? p.slabs[(size_t)(s0 + q) * p.slab_stride + off[j]] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < MAXE; ++j) v[j] += u[q][j];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j)
+        if (j < epl) {
+            if (p.cbias) v[j] += p.cbias[g * CG + (lane + 64 * j) % CG];
+            if (p.sresid) v[j] += p.sresid[off[j]];
+            if (p.sout) p.sout[off[j]] = v[j];
+        }
 }
 
-template <int CG>
-__global__ __launch_bounds__(256) void gn_wave_fwd(const GnDesc p) {
-    constexpr int MAXE = 16;
-    const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= p.N * p.G) return;
+template <int CG, int MAXE>
+__global__ __launch_bounds__(64) void gn_wave_fwd(const GnDesc p) {
+    const int lane = threadIdx.x;
+    const int wv = blockIdx.x;
     const int n = wv / p.G, g = wv - n * p.G;
     const int C = p.C, epl = (p.S * CG) >> 6;
     const size_t base = (size_t)n * p.S * C + (size_t)g * CG;
     float v[MAXE];
+    gn_wave_gather<CG, MAXE>(p, p.x, base, g, lane, epl, v);
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXE; ++j) {
-        v[j] = 0.f;
-        if (j < epl) {
-            const int i = lane + 64 * j, row = i / CG, cc = i % CG;
-            v[j] = gn_wave_load<CG>(p, p.x, base + (size_t)row * C + cc, g * CG + cc);
-            s += v[j];
-        }
-    }
+    for (int j = 0; j < MAXE; ++j) s += v[j];
     const float inv = 1.0f / (float)(p.S * CG);
     const float mu = wave_sum(s) * inv;
     float q = 0.f;
@@ -457,19 +554,18 @@ __global__ __launch_bounds__(256) void gn_wave_fwd(const GnDesc p) {
         }
 }
 
-template <int CG>
-__global__ __launch_bounds__(256) void gn_wave_bwd(const GnDesc p) {
-    constexpr int MAXE = 16;
+template <int CG, int MAXE>
+__global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
     constexpr int NCOL = CG >= 64 ? CG / 64 : 1;          // channels a lane owns
-    const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= p.N * p.G) return;
+    const int lane = threadIdx.x;
+    const int wv = blockIdx.x;
     const int n = wv / p.G, g = wv - n * p.G;
     const int C = p.C, epl = (p.S * CG) >> 6;
     const size_t base = (size_t)n * p.S * C + (size_t)g * CG;
     const float mu = p.mean[wv], rs = p.rstd[wv];
     const bool film = p.film != nullptr;
-    float xh[MAXE], dz[MAXE];
+    float xh[MAXE], dz[MAXE], dov[MAXE];
+    gn_wave_gather<CG, MAXE>(p, p.dout, base, g, lane, epl, dov);
     float c0[NCOL], c1[NCOL], c2[NCOL], c3[NCOL];
 #pragma unroll
     for (int k = 0; k < NCOL; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0.f;
@@ -484,7 +580,7 @@ __global__ __launch_bounds__(256) void gn_wave_bwd(const GnDesc p) {
             const float gm = p.gamma[c];
             float z = h * gm + p.beta[c];
             if (p.residual) z += p.residual[off];
-            const float dout = gn_wave_load<CG>(p, p.dout, off, c);
+            const float dout = dov[j];
             float da = dout;
             const int k = CG >= 64 ? (j % NCOL) : 0;
             if (film) {
@@ -585,7 +681,7 @@ __global__ __launch_bounds__(256) void gn_param_grads_multi(const long long* tab
     }
 }
 
-#define GN_SMALL_MAX 12288
+#define GN_SMALL_MAX 16384      // 64 KB of LDS forward, 128 KB backward: the ResNet layer-1 slabs (32 x 32 x 16) still take one launch
 
 static size_t gn_colreduce_lds(int C) {           // [rpi][2][C] floats, rpi = row lanes of gn_colreduce
     const int L4 = C >> 2;
@@ -662,18 +758,27 @@ int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* ga
     const long E = (long)S * cg;
     if (!x2 && gn_wave_ok(S, cg)) {
         if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.cbias = cbias; p.sout = (float*)x; }
-        const dim3 grid((N * G + 3) / 4), block(256);
-        if (cg == 16) hipLaunchKernelGGL(gn_wave_fwd<16>, grid, block, 0, stream, p);
-        else if (cg == 32) hipLaunchKernelGGL(gn_wave_fwd<32>, grid, block, 0, stream, p);
-        else if (cg == 64) hipLaunchKernelGGL(gn_wave_fwd<64>, grid, block, 0, stream, p);
-        else hipLaunchKernelGGL(gn_wave_fwd<128>, grid, block, 0, stream, p);
+        const dim3 grid(N * G), block(64);
+        const bool small = E <= 512;             // 8 values per lane (the ConditionalUnet1D slabs) or 16
+#define V2A_GNW_F(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_fwd<CGV, 8>), grid, block, 0, stream, p); \
+                            else hipLaunchKernelGGL((gn_wave_fwd<CGV, 16>), grid, block, 0, stream, p); } while (0)
+        if (cg == 16) V2A_GNW_F(16);
+        else if (cg == 32) V2A_GNW_F(32);
+        else if (cg == 64) V2A_GNW_F(64);
+        else V2A_GNW_F(128);
+#undef V2A_GNW_F
         V2A_CHECK_LAUNCH();
         return V2A_OK;
     }
     if (E <= GN_SMALL_MAX) {
         size_t lds = (E + 8) * sizeof(float);
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gn_small_fwd, dim3(N * G), dim3(256), lds, stream, p);
+        const bool vec = cg % 4 == 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+        if (lds > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void*)gn_small_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (vec) hipLaunchKernelGGL(gn_small_fwd<true>, dim3(N * G), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL(gn_small_fwd<false>, dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
         return V2A_OK;
     }
@@ -734,18 +839,28 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     const long E = (long)S * cg;
     if (gn_wave_ok(S, cg)) {
         if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.sresid = sresid; p.sout = dout_sum; }
-        const dim3 grid((N * G + 3) / 4), block(256);
-        if (cg == 16) hipLaunchKernelGGL(gn_wave_bwd<16>, grid, block, 0, stream, p);
-        else if (cg == 32) hipLaunchKernelGGL(gn_wave_bwd<32>, grid, block, 0, stream, p);
-        else if (cg == 64) hipLaunchKernelGGL(gn_wave_bwd<64>, grid, block, 0, stream, p);
-        else hipLaunchKernelGGL(gn_wave_bwd<128>, grid, block, 0, stream, p);
+        const dim3 grid(N * G), block(64);
+        const bool small = E <= 512;
+#define V2A_GNW_B(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_bwd<CGV, 8>), grid, block, 0, stream, p); \
+                            else hipLaunchKernelGGL((gn_wave_bwd<CGV, 16>), grid, block, 0, stream, p); } while (0)
+        if (cg == 16) V2A_GNW_B(16);
+        else if (cg == 32) V2A_GNW_B(32);
+        else if (cg == 64) V2A_GNW_B(64);
+        else V2A_GNW_B(128);
+#undef V2A_GNW_B
         V2A_CHECK_LAUNCH();
     } else if (E <= GN_SMALL_MAX) {
         const int nsl = cg >= 256 ? 1 : 256 / cg;
         size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 8) * sizeof(float);
         if (lds > 160 * 1024) return V2A_ERR_ARG;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_small_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gn_small_bwd, dim3(N * G), dim3(256), lds, stream, p);
+        const bool vec = cg % 4 == 0 && C % 4 == 0 &&
+                         (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout | (uintptr_t)residual | (uintptr_t)dres | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+        if (lds > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void*)gn_small_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (vec) hipLaunchKernelGGL(gn_small_bwd<true>, dim3(N * G), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL(gn_small_bwd<false>, dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
     } else {
         if (film || dfilm) return V2A_ERR_ARG;   // FiLM only occurs on the small (Conv1d) path

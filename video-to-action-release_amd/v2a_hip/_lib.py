@@ -104,6 +104,8 @@ SIGNATURES = {
     "v2a_conv2d_h_can_emit_stats": (I, [I, I, I]),
     "v2a_conv2d_fwd_dma_f32": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_fwd_dma_f32_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
+    "v2a_conv2d_h_splits": (I, [I, I, I]),
+    "v2a_conv2d_fwd_h_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_h2_eligible": (I, [I, I, I, I, I]),
     "v2a_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P] + [I] * 16 + [P, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),

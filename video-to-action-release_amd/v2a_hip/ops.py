@@ -203,9 +203,6 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
             and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] and lib.v2a_get_precision() == 0):
         return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y,
                                defer=defer)
-    if defer:          # every other route finishes y itself
-        return conv2d(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
-                      idil=idil, ups=ups, out_hw=out_hw, y=y, y2=y2, csplit=csplit, bmode=bmode, x_h=x_h, keep_h=keep_h), None
     if (_h_twin and bmode == 0 and y2 is None and not csplit and C1 % 64 == 0 and C2 % 64 == 0 and idil in (1, 2)
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)
@@ -217,7 +214,11 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
                 if x2h is not None:
                     keep_h.append(x2h)
             return conv2d_h(xh, wh, bias, Cout, KH, KW, stride, pad, x2=x2h, rowvec=rowvec,
-                            rows_per_batch=rows_per_batch, residual=residual, ups=ups, out_f32=True, idil=idil, out_hw=out_hw, y=y)
+                            rows_per_batch=rows_per_batch, residual=residual, ups=ups, out_f32=True, idil=idil, out_hw=out_hw, y=y,
+                            defer=defer)
+    if defer:          # every other route finishes y itself
+        return conv2d(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
+                      idil=idil, ups=ups, out_hw=out_hw, y=y, y2=y2, csplit=csplit, bmode=bmode, x_h=x_h, keep_h=keep_h), None
     sh, sw = stride
     ph, pw = pad
     if out_hw is None:
@@ -328,7 +329,7 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1, residual=None,
-             ups=False, out_f32=False, idil=1, out_hw=None, y=None, want_stats=False):
+             ups=False, out_f32=False, idil=1, out_hw=None, y=None, want_stats=False, defer=False):
     """bf16-storage conv: x [N,H,W,C1] (+x2) bf16, w_packed bf16 [Cout][KH][KW][C1+C2], bias / rowvec fp32, residual bf16.
     Returns bf16 [N,OH,OW,Cout] (fp32 when out_f32).  Needs C1 % 64 == 0 and C2 % 64 == 0."""
     _chk_h(x, "x")
@@ -363,6 +364,18 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         return (y, stats) if want_stats else y
     wsb = lib.v2a_conv2d_h_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
+    if defer:        # fp32 output, split-K plan: leave the reduce (and bias / residual) to the consuming GroupNorm launch
+        assert out_f32 and res_h is None and not want_stats
+        if _DEFER and wsb and rowvec is None and lib.v2a_conv2d_h_splits(M, Cout, K) > 1:
+            import ctypes
+            ns = ctypes.c_int(0)
+            check(lib.v2a_conv2d_fwd_h_d(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), None, _p(res_f), y.data_ptr(),
+                                         _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0,
+                                         idil, OH, OW, rows_per_batch, ctypes.byref(ns), _p(ws), wsb, _stream()), "conv2d_fwd_h_d")
+            last_kernel[0] = _plan_name_h(M, Cout, K, 64, "bf16")
+            return y, Slabs(ws, ns.value, M * Cout, bias, res_f)
+        return conv2d_h(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
+                        ups=ups, out_f32=out_f32, idil=idil, out_hw=out_hw, y=y), None
     stats = None
     if want_stats and _FUSED_STATS and not out_f32 and lib.v2a_conv2d_h_can_emit_stats(M, Cout, K):      # GroupNorm statistics ride along
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device)

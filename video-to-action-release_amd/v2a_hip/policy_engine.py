@@ -229,12 +229,15 @@ class PolicyEngine:
         import os as _os2
         self.batch_film = _os2.environ.get("V2A_BATCH_FILM", "1") != "0"
 
-    @staticmethod
-    def _twin_dy(dy, x_h, cout):
+    def _twin_dy(self, dy, x_h, cout):
         """bf16 twin of an output gradient, made once when the twin-fed weight-gradient kernel will take the layer (bf16-MFMA mode,
         the forward conv left a twin of its input, wide enough output); None otherwise (the convs then round on their own)."""
         if x_h is None or cout < 64 or ops.lib.v2a_get_precision() != 1:
             return None
+        tw = getattr(self, "_tw", None)              # left by the GroupNorm backward that produced dy (same storage: no cast launch)
+        if tw is not None and tw.numel() == dy.numel():
+            self._tw = None
+            return tw.view(dy.shape)
         return ops.cast_h(dy)
 
     # ------------------------------------------------------------------ weight gradients off the critical path
@@ -363,20 +366,25 @@ class PolicyEngine:
         C = x4.shape[-1]
         x3 = x4.view(N, -1, C)
         r3 = residual.view(N, -1, C) if residual is not None else None
-        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs)
+        tw = [] if (C % 64 == 0 and ops.lib.v2a_get_precision() == 1) else None      # bf16-MFMA mode: the consuming conv's operand twin
+        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs,
+                                          twin_out=tw)
+        self._tw = tw[0] if tw else None             # read by the caller right after (x_h of the next conv): no cast launch
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
     def _defer_ok(self, rows, C, G):
         """May a conv whose [N, rows, C] output feeds GroupNorm(G) directly leave its split-K reduce to that launch?"""
-        return ops.gn_takes_slabs(rows, C, G) and ops.lib.v2a_get_precision() == 0
+        return ops.gn_takes_slabs(rows, C, G)
 
-    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None, dslabs=None, keep_dout=False):
+    def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None, dslabs=None, keep_dout=False, want_twin=False):
         """dslabs: dout4 is the not-yet-reduced output of a data-gradient conv (ops.Slabs); keep_dout: other launches read dout4 later,
         so the GroupNorm launch also stores the finished sum into it."""
         x3, mean, rstd, r3, film, pre, G, act = saved
         d3 = dout4.view(x3.shape)
         N, _, C = x3.shape
         kw = dict(dout_slabs=dslabs, dout_sum=d3 if (dslabs is not None and keep_dout) else None)
+        tw = [] if (want_twin and C % 64 == 0 and ops.lib.v2a_get_precision() == 1) else None
+        kw["twin_out"] = tw
         chain = self._gn_chain
         if chain is None:            # outside a chain (stand-alone use): reduce this layer's parameter gradients right away
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
@@ -391,6 +399,7 @@ class PolicyEngine:
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                       residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
                                                       dfilm_out=dfilm_out, colsum=cs, defer_params=True, **kw)
+        self._tw = tw[0] if tw else None             # bf16 twin of dx (want_twin): operand of the data / weight gradients that follow
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
     def _gn_begin(self):
@@ -429,6 +438,7 @@ class PolicyEngine:
         a1, s_gn1 = self._gn(c1, e["bb"] + ".1", w0 // 16, "relu")
         h, pidx = ops.maxpool_fwd(a1)
         st = dict(x0=x0, gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
+        h_tw = None                                  # bf16 twin of the running activation (emitted by the GroupNorm launches)
         for blk in e["blocks"]:
             s, co = blk["stride"], blk["cout"]
             g = co // 16
@@ -438,9 +448,10 @@ class PolicyEngine:
             # split-K slabs (no reduce launch of its own), so nothing else may touch the scratch lane in between
             oh, ow = inp.shape[1] // s, inp.shape[2] // s
             dfr = self._defer_ok(oh * ow, co, g)
-            o1, sl = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1, defer=dfr) if dfr else \
-                (ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1), None)
+            o1, sl = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1, x_h=h_tw, defer=dfr) if dfr else \
+                (ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1, x_h=h_tw), None)
             a, s1 = self._gn(o1, blk["pre"] + ".bn1", g, "relu", slabs=sl)
+            a_tw = self._tw
             sd = None
             if blk["down"] is not None:
                 idn, sl = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0), x_h=k1[0] if k1 else None, defer=dfr) if dfr else \
@@ -448,9 +459,10 @@ class PolicyEngine:
                 idn, sd = self._gn(idn, blk["pre"] + ".downsample.1", g, "none", slabs=sl)
             else:
                 idn = inp
-            o2, sl = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, defer=dfr) if dfr else \
-                (ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2), None)
+            o2, sl = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, x_h=a_tw, defer=dfr) if dfr else \
+                (ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, x_h=a_tw), None)
             h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn, slabs=sl)
+            h_tw = self._tw
             st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd, inp_h=k1[0] if k1 else None, a_h=k2[0] if k2 else None))
         feat = h
         B, FH, FW, FC = feat.shape
@@ -489,13 +501,13 @@ class PolicyEngine:
             dfr = self._defer_ok(bs["a"].shape[1] * bs["a"].shape[2], co, g)              # consumer: this block's bn1
             # consumer of this block's input gradient: bn2 of the block before (none for the first block: maxpool)
             dfr_in = bi + 1 < nblk and self._defer_ok(inp.shape[1] * inp.shape[2], ci, ci // 16)
-            do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True, dslabs=dh_sl)
+            do2, didn, _ = self._gn_bwd(bs["s2"], dh, grads, want_dres=True, dslabs=dh_sl, want_twin=bs["a_h"] is not None and co >= 64)
             th = self._twin_dy                       # one bf16 rounding of a gradient serves its data and weight gradient
             do2h = th(do2, bs["a_h"], co)
             self._wg(bs["a"], do2, blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname], x_h=bs["a_h"], dy_h=do2h)
             da, sl = _dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1), x_h=do2h, defer=True) if dfr else \
                 (_dgrad(do2, blk["conv2"], None, co, 3, 3, (1, 1), (1, 1), x_h=do2h), None)
-            do1, _, _ = self._gn_bwd(bs["s1"], da, grads, dslabs=sl)
+            do1, _, _ = self._gn_bwd(bs["s1"], da, grads, dslabs=sl, want_twin=bs["inp_h"] is not None and co >= 64)
             do1h = th(do1, bs["inp_h"], co)
             self._wg(inp, do1, blk["conv1"].shape, 3, 3, (s, s), (1, 1), dw=grads[blk["conv1"].wname], x_h=bs["inp_h"], dy_h=do1h)
             ih, iw = inp.shape[1], inp.shape[2]
@@ -532,13 +544,13 @@ class PolicyEngine:
             self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
 
     # ------------------------------------------------------------------ ConditionalUnet1D
-    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None, defer=False):
+    def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None, defer=False, x_h=None):
         """Conv1d on [B,T,C] (channels-last) via the (1 x k) view.  defer: returns (y, ops.Slabs | None), see ops.conv2d."""
         B, T, C = x.shape
         pad = k // 2 if pad is None else pad
         y = ops.conv2d(x.view(B, 1, T, C), cv.pf(), cv.b, cv.co, 1, k, (1, stride), (0, pad),
                        x2=None if x2 is None else x2.view(B, 1, T, -1),
-                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h, defer=defer)
+                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h, defer=defer, x_h=x_h)
         if defer:
             return y[0].view(B, -1, cv.co), y[1]
         return y.view(B, -1, cv.co)
@@ -557,8 +569,9 @@ class PolicyEngine:
         c0, sl = self._c1d(x, r["c0"], k, x2=x2, keep_h=kx, defer=True) if dfr else (self._c1d(x, r["c0"], k, x2=x2, keep_h=kx), None)
         a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film, slabs=sl)
         a0 = a0.view(B, T, co)
+        a0_tw = self._tw
         ka = []
-        c1, sl = self._c1d(a0, r["c1"], k, keep_h=ka, defer=True) if dfr else (self._c1d(a0, r["c1"], k, keep_h=ka), None)
+        c1, sl = self._c1d(a0, r["c1"], k, keep_h=ka, defer=True, x_h=a0_tw) if dfr else (self._c1d(a0, r["c1"], k, keep_h=ka, x_h=a0_tw), None)
         a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish", slabs=sl)
         a1 = a1.view(B, T, co)
         x_h = kx[0] if kx else None                              # the twins also serve rc's and both weight gradients
@@ -587,7 +600,8 @@ class PolicyEngine:
         x4 = x.view(B, 1, T, C1)
         x24 = None if x2 is None else x2.view(B, 1, T, -1)
         d4 = dout.view(B, 1, T, co)
-        dc1, _, _ = self._gn_bwd(st["s1"], d4, grads, dslabs=dslabs, keep_dout=True)      # d4 is read again below (rc, residual)
+        dc1, _, _ = self._gn_bwd(st["s1"], d4, grads, dslabs=dslabs, keep_dout=True,      # d4 is read again below (rc, residual)
+                                 want_twin=st.get("a0_h") is not None and co >= 64)
         c1v, c0v, cev = r["c1"], r["c0"], r["ce"]
         dc1h = self._twin_dy(dc1, st.get("a0_h"), co)
         self._wg(st["a0"].view(B, 1, T, co), dc1, c1v.shape, 1, k, (1, 1), (0, k // 2), dw=grads[c1v.wname], dbias=grads[c1v.bname],
@@ -597,14 +611,18 @@ class PolicyEngine:
             (_dgrad(dc1, c1v, None, co, 1, k, (1, 1), (0, k // 2), x_h=dc1h), None)
         if self._dfilm_all is not None:          # batched FiLM: the gradient rows go into this block's columns of [B, NF]
             o = r["film_off"]
-            dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co], dslabs=sl)
+            dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co], dslabs=sl,
+                                     want_twin=st.get("x_h") is not None and co >= 64)
+            dc0_tw = self._tw
         else:
             dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dslabs=sl)
+            dc0_tw = None
             df2 = dfilm.view(B, 2 * co)
             self._wg(self._mgf.view(1, 1, B, -1), df2.view(1, 1, B, -1), cev.shape, 1, 1, dw=grads[cev.wname], dbias=grads[cev.bname])
             dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0),
                           residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
         xh, x2h = st.get("x_h"), st.get("x2_h")
+        self._tw = dc0_tw
         dc0h = self._twin_dy(dc0, xh, co)
         self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname], x_h=xh, dy_h=dc0h,
                  x2_h=x2h)

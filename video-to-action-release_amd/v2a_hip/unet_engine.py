@@ -16,7 +16,7 @@ import math
 import torch
 from . import ops
 
-GN_SMALL_MAX = 12288
+GN_SMALL_MAX = 16384
 
 
 def build_program(cfg):
