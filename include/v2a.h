@@ -291,6 +291,21 @@ int v2a_mt_seed_python(uint32_t* state, const uint32_t* key, int key_len);      
 int v2a_replay_gather(const void* frames, int dtype_u8, const float* acts, const int64_t* frame_start, float* out_start, float* out_goal,
                       float* out_acts, int B, int H, int W, int act_len, int act_dim, int normalize, int chw_out, v2a_stream_t s);
 
+/* ---- deferred weight-gradient reduces: one launch sums the split-K slabs of MANY layers (same summation order as the per-layer
+ * reduce kernels).  v2a_conv2d_wgrad_deferred / _h_deferred = v2a_conv2d_wgrad / _h with the reduce left out: `slabs` is the layer's own
+ * scratch (it must stay untouched until v2a_wgrad_reduce_multi ran); item_out (HOST, v2a_wgrad_item_bytes() bytes), *blocks_out and
+ * *form_out describe the pending reduce (blocks_out = 0: dw is already final).  The caller copies the items to the device and lists the
+ * work as [nwork][4] int32 rows {item, block, blocks of the item, form}. */
+int v2a_wgrad_item_bytes(void);
+int v2a_conv2d_wgrad_deferred(const float* x, const float* x2, const float* dy, float* dw, float* dbias, int N, int H, int W, int C1, int C2,
+                              int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate,
+                              void* slabs, size_t slab_bytes, void* item_out, int* blocks_out, int* form_out, v2a_stream_t stream);
+int v2a_conv2d_wgrad_h_deferred(const void* x_h, const void* x2_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C1,
+                                int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups,
+                                int accumulate, void* slabs, size_t slab_bytes, void* item_out, int* blocks_out, int* form_out,
+                                v2a_stream_t stream);
+int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwork, v2a_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- random-action episode file (csrc/h5read.hip)
  * Native reader for the HDF5 file of the reference's generator (environment/libero/lb_data/lb_randsam.py:84-104: groups
  * `{task}/{episode}` holding `agentview_image` uint8 [T+1,128,128,3], `action` float [T,7], `ee_poses` float [T+1,3]), replacing the

@@ -1437,13 +1437,13 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     }
 }
 
-__global__ void wgrad_splitk_reduce(const WgradDesc p) {
+__device__ __forceinline__ void wgrad_reduce_body(const WgradDesc& p, const unsigned bid, const unsigned nblk) {
     const size_t total = (size_t)p.Cout * p.K;
     if ((p.K & 3) == 0) {
         // four consecutive k' (same output channel, same tap when Cin % 4 == 0) per thread as one 16-B load per slab, four slabs in
         // flight: the slabs are read once at close to HBM speed instead of one dependent 4-B load at a time
         const size_t total4 = total >> 2;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        for (size_t i = (size_t)bid * 256 + threadIdx.x; i < total4; i += (size_t)nblk * 256) {
             const float* src = p.partial + i * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             int sl = 0;
@@ -1461,7 +1461,7 @@ __global__ void wgrad_splitk_reduce(const WgradDesc p) {
             for (int e = 0; e < 4; ++e) wgrad_store(p, co, k + e, v[e]);
         }
     } else {
-        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        for (size_t idx = (size_t)bid * 256 + threadIdx.x; idx < total; idx += (size_t)nblk * 256) {
             float v = 0.f;
             for (int s = 0; s < p.splits; ++s) v += p.partial[(size_t)s * total + idx];
             const int co = (int)(idx / p.K), k = (int)(idx - (size_t)co * p.K);
@@ -1470,7 +1470,7 @@ __global__ void wgrad_splitk_reduce(const WgradDesc p) {
     }
     if (p.dbias) {
         const float* bp = p.partial + (size_t)p.splits * total;
-        for (int co = blockIdx.x * blockDim.x + threadIdx.x; co < p.Cout; co += gridDim.x * blockDim.x) {
+        for (int co = (int)(bid * 256 + threadIdx.x); co < p.Cout; co += (int)(nblk * 256)) {
             float v = 0.f;
             for (int s = 0; s < p.splits; ++s) v += bp[(size_t)s * p.Cout + co];
             p.dbias[co] = p.accumulate ? p.dbias[co] + v : v;
@@ -1481,11 +1481,11 @@ __global__ void wgrad_splitk_reduce(const WgradDesc p) {
 // Split reduce for filters with several taps: the slabs are k'-major ([Cout][tap][Cin]), the gradient is torch-major ([Cout][Cin][tap]).
 // One workgroup owns (output channel, 64 input channels): slab reads are coalesced along Cin, the sums are transposed through LDS and
 // leave as ONE contiguous run of 64 * taps floats -- instead of 4-B stores 4 * taps bytes apart.  Cin % 64 == 0, taps <= 64.
-__global__ __launch_bounds__(256) void wgrad_splitk_reduce_taps(const WgradDesc p) {
-    __shared__ float tile[64 * 65];
+__global__ __launch_bounds__(256) void wgrad_splitk_reduce(const WgradDesc p) { wgrad_reduce_body(p, blockIdx.x, gridDim.x); }
+__device__ __forceinline__ void wgrad_reduce_taps_body(const WgradDesc& p, const unsigned bid, float* tile) {
     const int Cin = p.C1 + p.C2, taps = p.KH * p.KW;
     const int cblocks = Cin >> 6;
-    const int co = blockIdx.x / cblocks, ci0 = (blockIdx.x % cblocks) << 6;
+    const int co = bid / cblocks, ci0 = (bid % cblocks) << 6;
     const size_t total = (size_t)p.Cout * p.K;
     const int n = 64 * taps;
     for (int t = threadIdx.x; t < n; t += 256) {
@@ -1510,24 +1510,58 @@ __global__ __launch_bounds__(256) void wgrad_splitk_reduce_taps(const WgradDesc 
         const float v = tile[cl * ld + tap];
         dst[t] = p.accumulate ? dst[t] + v : v;
     }
-    if (p.dbias && (blockIdx.x % cblocks) == 0 && threadIdx.x == 0) {
+    if (p.dbias && (bid % cblocks) == 0 && threadIdx.x == 0) {
         const float* bp = p.partial + (size_t)p.splits * total;
         float v = 0.f;
         for (int s = 0; s < p.splits; ++s) v += bp[(size_t)s * p.Cout + co];
         p.dbias[co] = p.accumulate ? p.dbias[co] + v : v;
     }
 }
-static void launch_wgrad_reduce(const WgradDesc& p, hipStream_t stream) {
+__global__ __launch_bounds__(256) void wgrad_splitk_reduce_taps(const WgradDesc p) {
+    __shared__ float tile[64 * 65];
+    wgrad_reduce_taps_body(p, blockIdx.x, tile);
+}
+// The reduces of MANY weight gradients in one launch (deterministic: same per-element summation order as the single kernels).
+// descs: the WgradDesc of every deferred gradient (its `partial` = that layer's own slab buffer); work[b] = {desc, block within it,
+// blocks of that desc, 1 = multi-tap transposing form}.
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradDesc* descs, const int4* work) {
+    __shared__ float tile[64 * 65];
+    const int4 w = work[blockIdx.x];
+    const WgradDesc p = descs[w.x];
+    if (w.w) wgrad_reduce_taps_body(p, (unsigned)w.y, tile);
+    else wgrad_reduce_body(p, (unsigned)w.y, (unsigned)w.z);
+}
+static bool wgrad_reduce_is_taps(const WgradDesc& p) {
     const int Cin = p.C1 + p.C2, taps = p.KH * p.KW;
-    if (taps > 1 && taps <= 64 && (Cin & 63) == 0) {
-        hipLaunchKernelGGL(wgrad_splitk_reduce_taps, dim3(p.Cout * (Cin >> 6)), dim3(256), 0, stream, p);
-        return;
-    }
+    return taps > 1 && taps <= 64 && (Cin & 63) == 0;
+}
+static int wgrad_reduce_blocks(const WgradDesc& p) {
+    if (wgrad_reduce_is_taps(p)) return p.Cout * ((p.C1 + p.C2) >> 6);
     size_t total = (size_t)p.Cout * p.K;
     if ((p.K & 3) == 0) total >>= 2;
     int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+    return g > 4096 ? 4096 : g;
+}
+// v2a_conv2d_wgrad_deferred: the launchers below hand the finished descriptor to this thread's collector instead of launching
+struct WgradDeferred {
+    WgradDesc desc;
+    int blocks, taps_form;
+};
+static thread_local WgradDeferred* tl_wgrad_defer = nullptr;
+static void launch_wgrad_reduce(const WgradDesc& p, hipStream_t stream) {
+    if (tl_wgrad_defer) {
+        // the reduce reads only partial / dw / dbias and the shape: hand out a canonical descriptor (everything else zero, padding
+        // included) so that equal pending reduces give byte-equal items -- the caller caches its device tables by item contents
+        WgradDesc& q = tl_wgrad_defer->desc;
+        __builtin_memset(&q, 0, sizeof(WgradDesc));
+        q.dw = p.dw; q.partial = p.partial; q.dbias = p.dbias;
+        q.C1 = p.C1; q.C2 = p.C2; q.Cout = p.Cout; q.KH = p.KH; q.KW = p.KW; q.K = p.K; q.splits = p.splits; q.accumulate = p.accumulate;
+        tl_wgrad_defer->blocks = wgrad_reduce_blocks(p);
+        tl_wgrad_defer->taps_form = wgrad_reduce_is_taps(p) ? 1 : 0;
+        return;
+    }
+    if (wgrad_reduce_is_taps(p)) hipLaunchKernelGGL(wgrad_splitk_reduce_taps, dim3(wgrad_reduce_blocks(p)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(wgrad_splitk_reduce, dim3(wgrad_reduce_blocks(p)), dim3(256), 0, stream, p);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packs
@@ -1995,6 +2029,53 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         launch_wgrad_reduce(p, stream);
         V2A_CHECK_LAUNCH();
     }
+    return V2A_OK;
+}
+
+// ---- deferred reduces: run the weight-gradient kernel(s) now, sum the split slabs of MANY layers later in one launch.
+// `slabs` is the layer's OWN scratch buffer (>= v2a_conv2d_wgrad_workspace_bytes / _h_workspace_bytes; it must stay untouched until
+// v2a_wgrad_reduce_multi ran).  item_out (HOST, v2a_wgrad_item_bytes() bytes) receives the reduce descriptor, *blocks_out the number
+// of workgroups it needs (0: the kernel wrote dw itself, nothing to reduce) and *form_out the kernel form (work[].w).
+int v2a_wgrad_item_bytes(void) { return (int)sizeof(WgradDesc); }
+int v2a_conv2d_wgrad_deferred(const float* x, const float* x2, const float* dy, float* dw, float* dbias, int N, int H, int W, int C1, int C2,
+                              int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups, int accumulate,
+                              void* slabs, size_t slab_bytes, void* item_out, int* blocks_out, int* form_out, hipStream_t stream) {
+    if (!item_out || !blocks_out || !form_out) return V2A_ERR_ARG;
+    WgradDeferred d;
+    d.blocks = 0;
+    d.taps_form = 0;
+    tl_wgrad_defer = &d;
+    const int rc = v2a_conv2d_wgrad(x, x2, dy, dw, dbias, N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, ups, accumulate, slabs,
+                                    slab_bytes, stream);
+    tl_wgrad_defer = nullptr;
+    *blocks_out = d.blocks;
+    *form_out = d.taps_form;
+    if (d.blocks > 0) *reinterpret_cast<WgradDesc*>(item_out) = d.desc;
+    return rc;
+}
+int v2a_conv2d_wgrad_h_deferred(const void* x_h, const void* x2_h, const void* dy_h, float* dw, float* dbias, int N, int H, int W, int C1,
+                                int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups,
+                                int accumulate, void* slabs, size_t slab_bytes, void* item_out, int* blocks_out, int* form_out,
+                                hipStream_t stream) {
+    if (!item_out || !blocks_out || !form_out) return V2A_ERR_ARG;
+    WgradDeferred d;
+    d.blocks = 0;
+    d.taps_form = 0;
+    tl_wgrad_defer = &d;
+    const int rc = v2a_conv2d_wgrad_h(x_h, x2_h, dy_h, dw, dbias, N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, ups, accumulate,
+                                      slabs, slab_bytes, stream);
+    tl_wgrad_defer = nullptr;
+    *blocks_out = d.blocks;
+    *form_out = d.taps_form;
+    if (d.blocks > 0) *reinterpret_cast<WgradDesc*>(item_out) = d.desc;
+    return rc;
+}
+// items_dev: the collected descriptors (device copy, v2a_wgrad_item_bytes() each); work_dev: [nwork][4] int32 = {item, block, blocks, form}
+int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwork, hipStream_t stream) {
+    if (!items_dev || !work_dev || nwork < 0) return V2A_ERR_ARG;
+    if (nwork == 0) return V2A_OK;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nwork), dim3(256), 0, stream, (const WgradDesc*)items_dev, (const int4*)work_dev);
+    V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 

@@ -30,6 +30,10 @@ SIGNATURES = {
     "v2a_conv2d_wgrad_h_workspace_bytes": (SZ, [I, I, I]),
     "v2a_conv2d_wgrad_h": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P]),
     "v2a_pack_weight": (I, [P, P, I, I, I, I, I, P]),
+    "v2a_wgrad_item_bytes": (I, []),
+    "v2a_conv2d_wgrad_deferred": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P, P, P, P]),
+    "v2a_conv2d_wgrad_h_deferred": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P, P, P, P]),
+    "v2a_wgrad_reduce_multi": (I, [P, P, I, P]),
     "v2a_pack_chunk_elems": (I, []),
     "v2a_debug_wgrad_dma": (I, [I]),
     "v2a_conv2d_plan": (I, [I, I, I, P, P, P]),

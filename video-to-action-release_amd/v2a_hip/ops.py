@@ -243,8 +243,63 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     return y
 
 
+class WgradCollector:
+    """Weight gradients whose split-K reduce is postponed: every layer keeps its slabs in a scratch buffer of its own (owned here,
+    keyed by the gradient's address) and ONE multi-tensor launch (`flush`) finishes all of them -- 40-55 reduce launches per train
+    step become three.  The device tables are cached per list of pending reduces, so the captured step re-uses the tables its eager
+    warm-up steps built (flush never copies from the host during capture)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.slabs = {}
+        self.pending = []
+        self.tables = {}
+        self.item_bytes = lib.v2a_wgrad_item_bytes()
+
+    def slab(self, key, nbytes):
+        t = self.slabs.get(key)
+        if t is None or t.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("weight-gradient slab buffer missing during graph capture; run one eager step first")
+            if len(self.slabs) > 1024:          # callers without stable keys (gradient buffers re-allocated per call): do not hoard
+                self.slabs.clear()
+            t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self.slabs[key] = t          # (cached tables that point at the old buffer can never match a pending list again)
+        return t
+
+    def add(self, item, blocks, form):
+        if blocks > 0:
+            self.pending.append((bytes(item), blocks, form))
+
+    def flush(self):
+        pend, self.pending = self.pending, []
+        if not pend:
+            return
+        key = tuple(pend)
+        ent = self.tables.get(key)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                if os.environ.get("V2A_DEBUG_WGC"):
+                    for k2 in self.tables:
+                        if len(k2) == len(key):
+                            for i, (a, b) in enumerate(zip(k2, key)):
+                                if a != b:
+                                    diff = [j for j in range(len(a[0])) if a[0][j] != b[0][j]]
+                                    print("[wgc] item", i, "differs at bytes", diff[:40], a[1:], b[1:], flush=True)
+                    print("[wgc] cached keys", [len(k2) for k2 in self.tables], "wanted", len(key), flush=True)
+                raise RuntimeError("weight-gradient reduce table missing during graph capture; run one eager step first")
+            import numpy as np
+            items = np.frombuffer(b"".join(p[0] for p in pend), dtype=np.uint8).copy()
+            work = np.array([[i, b, nb, f] for i, (_, nb, f) in enumerate(pend) for b in range(nb)], dtype=np.int32)
+            if len(self.tables) > 32:
+                self.tables.clear()
+            ent = (torch.from_numpy(items).to(self.device), torch.from_numpy(work).to(self.device), int(work.shape[0]))
+            self.tables[key] = ent
+        check(lib.v2a_wgrad_reduce_multi(ent[0].data_ptr(), ent[1].data_ptr(), ent[2], _stream()), "wgrad_reduce_multi")
+
+
 def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None,
-                 x_h=None, dy_h=None, x2_h=None):
+                 x_h=None, dy_h=None, x2_h=None, collector=None, slab_key=None):
     """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout].
     bf16-MFMA mode with bf16 twins of both operands at hand (x_h, dy_h): the twin-fed kernel (half the operand traffic)."""
     _chk(x, "x"); _chk(dy, "dy")
@@ -260,6 +315,18 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
             and lib.v2a_get_precision() == 1):
         _chk_h(x_h, "x_h"); _chk_h(dy_h, "dy_h")
         wsb = lib.v2a_conv2d_wgrad_h_workspace_bytes(M, Cout, K)
+        last_kernel[0] = "conv_wgrad_bf16h<128,128>" if Cout > 64 else "conv_wgrad_bf16h<64,128>"
+        if collector is not None and wsb:
+            import ctypes
+            ws = collector.slab(slab_key if slab_key is not None else dw.data_ptr(), wsb)
+            item = ctypes.create_string_buffer(collector.item_bytes)
+            nb, fm = ctypes.c_int(0), ctypes.c_int(0)
+            check(lib.v2a_conv2d_wgrad_h_deferred(x_h.data_ptr(), _p(x2_h if x2 is not None else None), dy_h.data_ptr(), dw.data_ptr(),
+                                                  _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1], idil,
+                                                  1 if ups else 0, 1 if accumulate else 0, ws.data_ptr(), wsb, item, ctypes.byref(nb),
+                                                  ctypes.byref(fm), _stream()), "conv2d_wgrad_h_deferred")
+            collector.add(item.raw, nb.value, fm.value)
+            return dw
         ws = workspace(wsb, x.device) if wsb else None
         check(lib.v2a_conv2d_wgrad_h(x_h.data_ptr(), _p(x2_h if x2 is not None else None), dy_h.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W,
                                      C1, C2, OH, OW, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0,
@@ -268,10 +335,20 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
         last_kernel[0] = "conv_wgrad_bf16h<128,128>" if Cout > 64 else "conv_wgrad_bf16h<64,128>"
         return dw
     wsb = lib.v2a_conv2d_wgrad_workspace_bytes(M, Cout, K)
-    ws = workspace(wsb, x.device) if wsb else None
-    check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
-                               stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
-                               _p(ws), wsb, _stream()), "conv2d_wgrad")
+    if collector is not None and wsb:
+        import ctypes
+        ws = collector.slab(slab_key if slab_key is not None else dw.data_ptr(), wsb)
+        item = ctypes.create_string_buffer(collector.item_bytes)
+        nb, fm = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib.v2a_conv2d_wgrad_deferred(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
+                                            stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
+                                            ws.data_ptr(), wsb, item, ctypes.byref(nb), ctypes.byref(fm), _stream()), "conv2d_wgrad_deferred")
+        collector.add(item.raw, nb.value, fm.value)
+    else:
+        ws = workspace(wsb, x.device) if wsb else None
+        check(lib.v2a_conv2d_wgrad(x.data_ptr(), _p(x2), dy.data_ptr(), dw.data_ptr(), _p(dbias), N, H, W, C1, C2, OH, OW, Cout, KH, KW,
+                                   stride[0], stride[1], pad[0], pad[1], idil, 1 if ups else 0, 1 if accumulate else 0,
+                                   _p(ws), wsb, _stream()), "conv2d_wgrad")
     if lib.v2a_get_precision() == 1:
         kn = "conv_wgrad_bf16"
     else:       # mirrors the dispatch in v2a_conv2d_wgrad: whole 16-B pieces -> the LDS-DMA kernel

@@ -144,6 +144,9 @@ class PolicyEngine:
         self._gn_cs = {}
         self._gn_chain = None
         self._gn_tables = {}
+        # weight gradients: split-K reduces postponed to one multi-tensor launch per chain (ops.WgradCollector)
+        self._wgc = None
+        self._wgc_on = _os.environ.get("V2A_WGRAD_MULTI_REDUCE", "1") != "0"
         self._collect_wg = False
         self._wg_stream = None
         self._side = None
@@ -243,10 +246,15 @@ class PolicyEngine:
     # ------------------------------------------------------------------ weight gradients off the critical path
     def _wg(self, *a, **k):
         """Weight gradients feed nothing until the optimiser: launch them on a side stream so they fill the CUs the latency-bound
-        data-gradient chain leaves idle (captured as a parallel branch of the hipGraph).  Operands are kept alive until the join."""
+        data-gradient chain leaves idle (captured as a parallel branch of the hipGraph).  Operands are kept alive until the join.
+        immediate=True: the caller reads the gradient right away (no postponed split-K reduce)."""
+        k = dict(k)
+        immediate = k.pop("immediate", False)
         if self.defer_unet_wgrad and self._collect_wg:
             self._deferred.append((a, k))
             return None
+        if self._wgc_active and not immediate:
+            k = dict(k, collector=self._collector(), slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
         if not (self.async_wgrad or (self._wg_mode == "unet" and not self._in_enc)):
             return ops.conv2d_wgrad(*a, **k)
         if self._side is None:
@@ -256,6 +264,30 @@ class PolicyEngine:
         self._keep.append((a, k))
         with torch.cuda.stream(self._side), ops.ws_lane(1):
             ops.conv2d_wgrad(*a, **k)
+
+    def _collector(self):
+        if self._wgc is None:
+            self._wgc = ops.WgradCollector(self.device)
+        return self._wgc
+
+    _wgc_active = False
+    _dw_names = None
+
+    def _slab_key(self, dw):
+        """Stable name of the layer a gradient view belongs to (its slab buffer is kept per layer, not per address: the autograd path
+        hands in a fresh arena on every call)."""
+        if dw is None or self._dw_names is None:
+            return None
+        return self._dw_names.get(dw.data_ptr(), ("tmp", tuple(dw.shape)))
+
+    def _wg_begin(self):
+        """From here on weight gradients only run their main kernels; _wg_flush sums all their split slabs in one launch."""
+        self._wgc_active = self._wgc_on and not self.async_wgrad and self._wg_mode != "unet"
+
+    def _wg_flush(self):
+        if self._wgc_active:
+            self._collector().flush()
+        self._wgc_active = False
 
     def _join_side(self):
         if self._side is not None and self._keep:
@@ -476,10 +508,12 @@ class PolicyEngine:
 
     def encode_bwd(self, key, df, st, grads):
         tok = self._gn_begin()
+        self._wg_begin()
         try:
             self._encode_bwd(key, df, st, grads)
         finally:
             self._gn_flush(tok, grads)
+            self._wg_flush()
 
     def _encode_bwd(self, key, df, st, grads):
         e = self.enc[key]
@@ -538,7 +572,8 @@ class PolicyEngine:
                 self._stem_pad[key] = xp
             ops.copy2d(x0, xp, N0 * H0 * W0, 3, 3, 4)
             dw4 = torch.empty((c1.co, 4, 7, 7), dtype=torch.float32, device=x0.device)
-            self._wg(xp, dc1, (c1.co, 4, 7, 7), 7, 7, (2, 2), (3, 3), dw=dw4)
+            # its result is repacked right below: finished at once, not with the chain's postponed reduces
+            self._wg(xp, dc1, (c1.co, 4, 7, 7), 7, 7, (2, 2), (3, 3), dw=dw4, immediate=True)
             ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
         else:
             self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
@@ -865,13 +900,16 @@ class PolicyEngine:
         if arena is None:
             arena = torch.zeros(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)   # GN param grads accumulate
         grads = self.grad_views(arena, names)
+        self._dw_names = {v.data_ptr(): n for n, v in grads.items()}
         self._collect_wg = True
         tok = self._gn_begin()
+        self._wg_begin()
         try:
             dgc = self.unet_bwd(dpred, save, grads)
         finally:
             self._collect_wg = False
             self._gn_flush(tok, grads)
+            self._wg_flush()
         self._join_side()
         return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc, keep=save)
 
@@ -894,8 +932,11 @@ class PolicyEngine:
                 self._wg_stream = torch.cuda.Stream(device=self.device)
             self._wg_stream.wait_stream(main)
             with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
+                col = self._collector() if self._wgc_on else None
                 for a, k in deferred:
-                    ops.conv2d_wgrad(*a, **k)
+                    ops.conv2d_wgrad(*a, **dict(k, collector=col, slab_key=k.get("slab_key") or self._slab_key(k.get("dw"))))
+                if col is not None:
+                    col.flush()
         self._in_enc = True
         try:
             self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
