@@ -71,15 +71,14 @@ def test_unet_backward_matches_oracle_autograd(variant):
     OV.label_embedding = spy
     orig_te = OV.timestep_embedding
     OV.timestep_embedding = lambda *a, **k: orig_te(*a, **k).double()
-    keep_float = torch.Tensor.float
-    torch.Tensor.float = lambda self, *a, **k: self if self.dtype == torch.float64 else keep_float(self, *a, **k)   # the oracle's
-    try:                                                               # fp32 casts (GroupNorm32, softmax) would cap the truth at fp32
+    OV.WORK_DTYPE = torch.float64            # the oracle's fp32 casts (GroupNorm32, softmax, h = x.type(dtype)) would cap the truth at fp32
+    try:
         out_ref = OV.unet_forward(P, x.double(), t, y.double(), cfg, pre="unet.")
         (out_ref * R.double()).sum().backward()
     finally:
         OV.label_embedding = orig
         OV.timestep_embedding = orig_te
-        torch.Tensor.float = keep_float
+        OV.WORK_DTYPE = torch.float32
 
     # ---- the same autograd in fp32 (what the reference itself computes): its distance from the fp64 truth is the yardstick for
     # gradients that are sums of thousands of cancelling terms (the emb_layers weights see a 3072-row column sum per sample)

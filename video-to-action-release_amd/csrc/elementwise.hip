@@ -30,16 +30,27 @@ __global__ void copy2d_kernel(const float* src, float* dst, int rows, int cols, 
     }
 }
 // out[c] = sum_r x[r][c]   (bias gradients); one wave per 64 columns, fp64 accumulate across row-chunks
+// 16 columns per workgroup, 16 row lanes per column (rows r, r + 16, ... summed in order, then the lanes in order: deterministic);
+// fp64 accumulation.  (The 64-column form ran 8 workgroups for a 512-channel bias gradient: 47 us of one-load-at-a-time latency.)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int rows, int cols, int accumulate) {
-    __shared__ double sm[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    double s = 0.0;
-    if (c < cols)
-        for (int r = w; r < rows; r += 4) s += (double)x[(size_t)r * cols + c];
-    sm[w][threadIdx.x & 63] = s;
+    __shared__ double sm[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < cols) {
+        int r = rl;
+        for (; r + 16 < rows; r += 32) {             // two independent loads in flight
+            s0 += (double)x[(size_t)r * cols + c];
+            s1 += (double)x[(size_t)(r + 16) * cols + c];
+        }
+        if (r < rows) s0 += (double)x[(size_t)r * cols + c];
+    }
+    sm[rl][cl] = s0 + s1;
     __syncthreads();
-    if (w == 0 && c < cols) {
-        double t = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (rl == 0 && c < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += sm[l][cl];
         out[c] = accumulate ? out[c] + (float)t : (float)t;
     }
 }
@@ -436,7 +447,7 @@ int v2a_copy2d(const float* src, float* dst, int rows, int cols, int ld_src, int
     return V2A_OK;
 }
 int v2a_colsum(const float* x, float* out, int rows, int cols, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, x, out, rows, cols, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, x, out, rows, cols, accumulate);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

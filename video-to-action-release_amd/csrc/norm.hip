@@ -265,6 +265,34 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
     }
 }
 
+// element(s) of the tensor a small-path launch normalises: a plain read, or the sum of the producing conv's split-K slabs in slab
+// order (+ bias / + residual), written back to `sout` for the other readers (see GnDesc::slabs)
+__device__ __forceinline__ float gn_src1(const GnDesc& p, const float* dense, size_t off, int c) {
+    if (p.nslab <= 0) return dense[off];
+    float t = 0.f;
+    for (int sI = 0; sI < p.nslab; ++sI) t += p.slabs[(size_t)sI * p.slab_stride + off];
+    if (p.cbias) t += p.cbias[c];
+    if (p.sresid) t += p.sresid[off];
+    if (p.sout) p.sout[off] = t;
+    return t;
+}
+__device__ __forceinline__ f32x4 gn_src4(const GnDesc& p, const float* dense, size_t off, int c) {
+    if (p.nslab <= 0) return *reinterpret_cast<const f32x4*>(dense + off);
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    int sI = 0;
+    for (; sI + 2 <= p.nslab; sI += 2) {             // two independent 16-B loads in flight, added in slab order
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.slabs + (size_t)sI * p.slab_stride + off);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.slabs + (size_t)(sI + 1) * p.slab_stride + off);
+        t += a;
+        t += b;
+    }
+    if (sI < p.nslab) t += *reinterpret_cast<const f32x4*>(p.slabs + (size_t)sI * p.slab_stride + off);
+    if (p.cbias) t += *reinterpret_cast<const f32x4*>(p.cbias + c);
+    if (p.sresid) t += *reinterpret_cast<const f32x4*>(p.sresid + off);
+    if (p.sout) *reinterpret_cast<f32x4*>(p.sout + off) = t;
+    return t;
+}
+
 // -------------------------------------------------------------------------------------------- small path
 // one workgroup per (n, g): E = S * cg elements staged in LDS.  Forward: two-pass (centred) variance.
 template <bool VEC>
@@ -280,7 +308,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
 #pragma unroll 4
         for (int i = tid; i < E4; i += 256) {
             const int row = i / cg4, c4 = i - row * cg4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + base + (size_t)row * C + c4 * 4);
+            const f32x4 v = gn_src4(p, p.x, base + (size_t)row * C + c4 * 4, g * cg + c4 * 4);
             *reinterpret_cast<f32x4*>(sm + i * 4) = v;
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
 #pragma unroll 4
         for (int i = tid; i < E; i += 256) {
             const int row = i / cg, cc = i - row * cg;
-            const float v = p.x[base + (size_t)row * C + cc];
+            const float v = gn_src1(p, p.x, base + (size_t)row * C + cc, g * cg + cc);
             sm[i] = v;
             s += v;
         }
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         for (int i = tid; i < E4; i += 256) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off), dv = *reinterpret_cast<const f32x4*>(p.dout + off);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off), dv = gn_src4(p, p.dout, off, c);
             const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
@@ -394,7 +422,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         const float h = (p.x[off] - mu) * rs;
         float z = h * p.gamma[c] + p.beta[c];
         if (p.residual) z += p.residual[off];
-        const float dout = p.dout[off];
+        const float dout = gn_src1(p, p.dout, off, c);
         float da = dout;
         if (film) {
             const float a = act_fwd(z, p.act);
@@ -737,7 +765,9 @@ int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* ga
                                nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 // 1 when a GroupNorm over [N, S, C] with G groups runs on the wave path, i.e. accepts its input as split-K slabs (v2a_groupnorm_*_s)
-int v2a_groupnorm_takes_slabs(int S, int C, int G) { return (G > 0 && C % G == 0 && gn_wave_ok(S, C / G)) ? 1 : 0; }
+int v2a_groupnorm_takes_slabs(int S, int C, int G) {
+    return (G > 0 && C % G == 0 && (gn_wave_ok(S, C / G) || (long)S * (C / G) <= GN_SMALL_MAX)) ? 1 : 0;
+}
 // same as v2a_groupnorm_fwd_t; with nslab > 0 the normalised tensor is sum_s slabs[s][.] + cbias[c] (the split-K partial sums and bias
 // of the conv that produces it: its reduce launch is folded into this one) and `x` receives that sum (kept for the backward).
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
@@ -746,7 +776,7 @@ int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* ga
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     (void)unused_resid;
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
-    if (nslab > 0 && (!slabs || x2 || !gn_wave_ok(S, C / G))) return V2A_ERR_ARG;
+    if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x2 = x2; p.C1 = x2 ? C1 : C;
@@ -756,8 +786,8 @@ int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* ga
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act; p.eps = eps;
     const int cg = C / G;
     const long E = (long)S * cg;
+    if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.cbias = cbias; p.sout = (float*)x; }
     if (!x2 && gn_wave_ok(S, cg)) {
-        if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.cbias = cbias; p.sout = (float*)x; }
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;             // 8 values per lane (the ConditionalUnet1D slabs) or 16
 #define V2A_GNW_F(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_fwd<CGV, 8>), grid, block, 0, stream, p); \
@@ -829,7 +859,7 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
                         const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || (!dout && nslab <= 0) || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
-    if (nslab > 0 && (!slabs || !gn_wave_ok(S, C / G))) return V2A_ERR_ARG;
+    if (nslab > 0 && (!slabs || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
     GnDesc p = {};
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
@@ -837,8 +867,8 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;
     const long E = (long)S * cg;
+    if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.sresid = sresid; p.sout = dout_sum; }
     if (gn_wave_ok(S, cg)) {
-        if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.sresid = sresid; p.sout = dout_sum; }
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;
 #define V2A_GNW_B(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_bwd<CGV, 8>), grid, block, 0, stream, p); \
