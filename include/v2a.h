@@ -246,6 +246,11 @@ int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, cons
  * [ceil(M/64)][2][Cout] per-64-row sum / sum of squares of the rounded outputs, consumed by v2a_groupnorm_fwd_h */
 /* multi-stage 256-row variant of v2a_conv2d_fwd_h for the large layers (csrc/igemm_h2.hip: 8 waves, 4-5 LDS stages, counted vmcnt):
  * bf16 in / bf16 out, optional bf16 residual and statistics, no split-K; v2a_conv2d_h2_eligible says whether a problem qualifies */
+/* Halo-tile 3x3 / stride 1 / pad 1 convolution of the bf16-storage video UNet (csrc/igemm_h3.hip): the 18 x 18 input halo of a
+   16 x 16 output patch is DMA-ed once per 32-channel chunk and shared by the nine taps (Conv3d spatial part, nn.py:45,64-69) */
+int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2);
+int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
+                      const void* zeros, int N, int H, int W, int C, int Cout, int rows_per_batch, float* stats, v2a_stream_t stream);
 int v2a_conv2d_h2_eligible(int M, int Cout, int K, int C1, int C2);
 int v2a_conv2d_fwd_h2(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                       void* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh, int sw, int ph,

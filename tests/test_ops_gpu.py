@@ -1,6 +1,7 @@
 """Per-kernel parity: every HIP op (through the C ABI) against a plain torch-CPU fp32 restatement of the same op.
 Tolerance: 1e-4 relative to the tensor's max magnitude (north_star's fp32 budget), typically met at ~1e-6."""
 import math
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -525,6 +526,48 @@ def test_conv2d_h2_multistage_kernel_matches_fp64_reference():
         assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
     rows = y.float().view(-1, 64, Co)
     assert torch.allclose(st[:, 0], rows.sum(1), rtol=1e-4, atol=2e-3) and torch.allclose(st[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,C,Co", [(34, 64, 64, 96, 256), (36, 48, 80, 64, 128), (44, 32, 32, 128, 384)])
+def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
+    """The halo-tile 3x3 kernel (csrc/igemm_h3.hip: 16 x 16 output patches, the 18 x 18 input halo DMA-ed once per 32-channel chunk and
+    read by the nine taps through shifted LDS windows, counted-vmcnt weight ring): both instances (256x256 / 256x128), image borders on
+    every side of the patch grid, non-square frames, three chunk counts, bias + per-sample row vector + residual + statistics.  Within
+    one bf16 ulp of an fp64 conv of the same rounded operands, and equal to the tap-by-tap kernel up to summation order."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(31 + N)
+    assert lib.v2a_conv2d_h3_eligible(N, H, W, C, Co, 3, 3, 1, 1, 1, 1, 0, 0) == 1
+    x = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    rowvec = torch.randn(N, Co, generator=g).to(dev)
+    res = torch.randn(N, H, W, Co, generator=g).to(torch.bfloat16).to(dev)
+    wp = ops.pack_weight_h(w)
+    y, st = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rowvec, rows_per_batch=H * W, residual=res, want_stats=True)
+    assert ops.last_kernel[0].startswith("conv_halo_h3") and st is not None
+    os.environ["V2A_CONV_H3_OFF_FOR_TEST"] = "1"
+    try:
+        y1 = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rowvec, rows_per_batch=H * W, residual=res)
+    finally:
+        os.environ.pop("V2A_CONV_H3_OFF_FOR_TEST")
+    assert not ops.last_kernel[0].startswith("conv_halo_h3")
+    d = (y.float() - y1.float()).abs()
+    assert (d <= y1.float().abs() * 2.0 ** -7 + 1e-5).all() and (d > 0).float().mean().item() < 0.01
+    xin = x.float().permute(0, 3, 1, 2).cpu().double()
+    wq = w.to(torch.bfloat16).float().cpu().double()
+    for n in (0, N - 1):
+        ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=1).permute(0, 2, 3, 1)[0]
+        ref = ref + rowvec[n].cpu().double() + res[n].cpu().double()
+        err = (y[n].cpu().double() - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
+    # statistics: blocks are numbered per (patch, 64-row group), so compare per FRAME (what GroupNorm reduces over)
+    yf = y.float().view(N, H * W, Co)
+    nb = H * W // 64
+    assert torch.allclose(st[:, 0].view(N, nb, Co).sum(1), yf.sum(1), rtol=1e-4, atol=5e-2)
+    assert torch.allclose(st[:, 1].view(N, nb, Co).sum(1), (yf * yf).sum(1), rtol=1e-4, atol=5e-2)
 
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout", [(28, 128, 32, 32, 128), (56, 128, 16, 16, 256), (256, 128, 8, 8, 256), (14, 128, 32, 64, 128),

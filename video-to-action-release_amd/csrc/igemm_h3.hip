@@ -1,0 +1,332 @@
+// Halo-tile 3x3 convolution for the bf16-storage video UNet (stride 1, pad 1, one source): the forward counterpart of
+// conv_wgrad_halo_f32.
+//
+// conv_igemm_h / conv_igemm_h2 DMA an A tile (output pixels x 32..64 input channels) for EVERY filter tap: nine fetches of what is,
+// up to a one-pixel shift, the same patch of the input.  At bf16 rates those kernels are bound by bytes in flight per CU (29-37 % MFMA
+// utilisation at ~3 TB/s of L2 -> LDS traffic, PMC: 2.7x the algorithmic bytes), so the lever is bytes per FLOP, not scheduling.
+// Here a 512-thread workgroup owns a 16 x 16 pixel patch of one frame (BM = 256 output rows) x BN output channels and walks the
+// reduction as (32-channel chunk c) x (tap t):
+//   * per chunk the 18 x 18 pixel HALO of the patch (324 rows x 64 B) is DMA-ed ONCE into one of two halo buffers; the nine taps
+//     read it through shifted row windows (output pixel (py, px), tap (kh, kw) -> halo row (py + kh) * 18 + px + kw);
+//   * per (chunk, tap) only the weight tile (BN rows x 64 B) moves, through a ring of SB stages.
+// Bytes per 256 x 256 x 32 MAC step: 16 KB (B) + 20.7 KB / 9 (A) = 18.3 KB instead of 32 KB; for BN = 128: 10.3 instead of 24 KB.
+// Synchronisation as in conv_igemm_h2 (counted `s_waitcnt vmcnt`, one raw `s_barrier` per step, never drained): DMAs of one wave
+// retire in issue order, the halo of chunk c+1 is issued in three pieces at taps 1 / 3 / 5 of chunk c (all of them ahead of the
+// first weight tile of chunk c+1 in the queue), and EVERY step issues the same number of DMA instructions -- past the end of the
+// reduction they read the zero line -- so the wait count of a step depends on its tap alone and is a compile-time constant of the
+// unrolled nine-tap body.  LDS: 2 x 24 KB halo + SB x BN x 64 B ring (112 KB at BN = 256, SB = 4; 96 KB at BN = 128, SB = 6).
+// 64-B rows: slot (row r, position p) holds the row's 16-B chunk p ^ ((r >> 2) & 3); a 16-lane group reads 16 consecutive halo
+// rows starting anywhere, and rows r, r+4, r+8, r+12 always differ in (r >> 2) & 3, so the operand fetches stay conflict-free under
+// every tap shift.  Epilogue = conv_igemm_h2's (rows of the patch mapped back to NHWC rows).
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_3;
+typedef const __attribute__((address_space(1))) void* gptr3_t;
+typedef __attribute__((address_space(3))) void* lptr3_t;
+
+struct ConvDescH3 {
+    const uint16_t* x;          // [N, H, W, C] bf16
+    const uint16_t* w;          // [Cout][3][3][C] bf16
+    const float* bias;
+    const float* rowvec;        // [M / rows_per_batch][Cout] or null
+    const uint16_t* residual;   // [M][Cout] bf16 or null
+    uint16_t* y;                // [M][Cout] bf16
+    float* stats;               // optional [M / 64][2][Cout]
+    const uint16_t* zeros;
+    int N, H, W, C, Cout, M, K, rows_per_batch, tiles_x, tiles_img;
+};
+
+__device__ __forceinline__ int xcd_remap3(int bid, int nblk) {
+    int q = nblk >> 3, r = nblk & 7;
+    int xcd = bid & 7, slot = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+__device__ __forceinline__ uint16_t f2bf3(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f3(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt3() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// number of halo pieces issued at steps s-(SB-1) .. s-1 when step s has tap T (halo pieces go out at taps 1, 3, 5)
+template <int T, int SB>
+struct HaloLater {
+    static constexpr int count() {
+        int c = 0;
+        for (int d = 1; d <= SB - 1; ++d) {
+            int u = ((T - d) % 9 + 9) % 9;
+            if (u == 1 || u == 3 || u == 5) ++c;
+        }
+        return c;
+    }
+    static constexpr int value = count();
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int SB>
+__global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
+    constexpr int BM = 256, BN = WAVES_N * TN * 32;
+    static_assert(WAVES_M * TM * 32 == BM && WAVES_M * WAVES_N == 8, "tile shape");
+    constexpr int ROWB = 64;                               // bytes per row: 32 bf16
+    constexpr int HW_ = 18, HROWS = HW_ * HW_;             // halo: 18 x 18 pixels
+    constexpr int HPIECES = 3;                             // DMA instructions per thread per halo (3 x 512 x 16 B = 24 KB >= 20.7 KB)
+    constexpr int HBUF = HPIECES * 512 * 16;
+    constexpr int BL = BN / 128;                           // DMA instructions per thread per weight tile (128 rows x 4 chunks per pass)
+    constexpr int BSTAGE = BN * ROWB;
+    constexpr int SMEM = 2 * HBUF + SB * BSTAGE;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert((SB - 2) * BL + 3 <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(128))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = p.Cout / BN;
+    const int tiles_m = p.N * p.tiles_img;
+    const int lin = xcd_remap3(blockIdx.x, tiles_m * tiles_n);
+    const int tm = lin / tiles_n, n0 = (lin % tiles_n) * BN;
+    const int img = tm / p.tiles_img, trem = tm - img * p.tiles_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int nchunks = p.C >> 5;
+
+    // ---- halo DMA source state: piece q = j * 512 + tid -> halo row q >> 2, position q & 3, carrying chunk (q & 3) ^ ((row >> 2) & 3).
+    // 32-bit element offsets from p.x (0xffffffff = the zero line): the kernel sits at the 256-VGPR cap
+    uint32_t h_off[HPIECES];
+    const uint16_t* zsrc = p.zeros;
+#pragma unroll
+    for (int j = 0; j < HPIECES; ++j) {
+        const int q = j * 512 + tid;
+        const int hr = q >> 2;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int ih = oy0 - 1 + hy, iw = ox0 - 1 + hx;
+        const int chunk = (q & 3) ^ ((hr >> 2) & 3);
+        const bool ok = hr < HROWS && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        h_off[j] = ok ? ((uint32_t)(img * p.H + ih) * (uint32_t)p.W + (uint32_t)iw) * (uint32_t)p.C + (uint32_t)chunk * 8u : 0xffffffffu;
+    }
+    // ---- weight DMA source state: pass j fills rows j*128 .. +127; slot (row j*128 + tid/4, position tid%4), chunk (tid%4) ^ ((row>>2)&3)
+    const uint32_t b_off0 = (uint32_t)(n0 + (tid >> 2)) * (uint32_t)p.K + (uint32_t)(((tid & 3) ^ ((tid >> 4) & 3)) * 8);
+    const uint32_t b_step = 128u * (uint32_t)p.K;
+
+    auto issue_halo_piece = [&](int j, int chunk_idx, int hb) {     // chunk_idx >= nchunks: the zero line (keeps the DMA count uniform)
+        const uint16_t* g = (h_off[j] != 0xffffffffu && chunk_idx < nchunks) ? p.x + h_off[j] + chunk_idx * 32 : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr3_t)g, (lptr3_t)(smem + hb * HBUF + (j * 512 + wid * 64) * 16), 16, 0, 0);
+    };
+    auto issue_b = [&](int bc, int bt, int stage) {                 // weight tile of (chunk bc, tap bt); bc >= nchunks: the zero line
+        const bool live = bc < nchunks;
+        const uint32_t koff = (uint32_t)(bt * p.C + bc * 32);
+        unsigned char* bbase = smem + 2 * HBUF + stage * BSTAGE;
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const uint16_t* g = live ? p.w + b_off0 + j * b_step + koff : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr3_t)g, (lptr3_t)(bbase + (j * 512 + wid * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wid / WAVES_N) * TM * 32, wn = (wid % WAVES_N) * TN * 32;
+    const int lr = lane & 31, lk = lane >> 5;
+    int a_hr[TM];                                            // halo row of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm + i * 32 + lr;                      // row inside the patch: (py, px) = (r / 16, r % 16)
+        a_hr[i] = (r >> 4) * HW_ + (r & 15);
+    }
+    const int brswz = (lr >> 2) & 3;
+    int b_off[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j] = (wn + j * 32 + lr) * ROWB;
+
+    // ---- prologue: halo of chunk 0, then SB-1 weight tiles
+#pragma unroll
+    for (int j = 0; j < HPIECES; ++j) issue_halo_piece(j, 0, 0);
+#pragma unroll
+    for (int s = 0; s < SB - 1; ++s) issue_b(s / 9, s % 9, s);
+    int cstage = 0, istage = SB - 1;
+
+    auto mma_step = [&](const unsigned char* hbase, const unsigned char* bbase, int shift) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8_3 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hr = a_hr[i] + shift;
+                a[i] = *reinterpret_cast<const bf16x8_3*>(hbase + hr * ROWB + ((((h << 1) | lk) ^ ((hr >> 2) & 3)) << 4));
+            }
+            const int bpos = (((h << 1) | lk) ^ brswz) << 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_3*>(bbase + b_off[j] + bpos);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+#define V2A_H3_TAP(T)                                                                                                  \
+    {                                                                                                                  \
+        if (c == 0) wait_vmcnt3<(SB - 2) * BL>();      /* start-up: no halo pieces of a previous chunk in the queue */  \
+        else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB>::value>();                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        issue_b(c + (T + SB - 1) / 9, (T + SB - 1) % 9, istage);                                                       \
+        if (T == 1 || T == 3 || T == 5) issue_halo_piece((T - 1) / 2, c + 1, (c + 1) & 1);                             \
+        mma_step(smem + (c & 1) * HBUF, smem + 2 * HBUF + cstage * BSTAGE, (T / 3) * HW_ + (T % 3));                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+        cstage = (cstage + 1 == SB) ? 0 : cstage + 1;                                                                  \
+        istage = (istage + 1 == SB) ? 0 : istage + 1;                                                                  \
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        // keep the 72 (sub-tile, tap, k-half) operand addresses out of registers: they are chunk-invariant and the compiler would
+        // hoist them all (spilling the accumulators' neighbours); making the row indices opaque per chunk re-derives them under the MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(a_hr[i]));
+        V2A_H3_TAP(0) V2A_H3_TAP(1) V2A_H3_TAP(2) V2A_H3_TAP(3) V2A_H3_TAP(4) V2A_H3_TAP(5) V2A_H3_TAP(6) V2A_H3_TAP(7) V2A_H3_TAP(8)
+    }
+#undef V2A_H3_TAP
+
+    // ---- epilogue (conv_igemm_h2's, with patch rows mapped back to NHWC rows)
+    wait_vmcnt3<0>();
+    __syncthreads();
+    constexpr int WNC = TN * 32, LDC = WNC;
+    static_assert(8 * 32 * LDC * 4 <= SMEM, "epilogue staging exceeds the LDS buffers");
+    float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;
+    constexpr int V = WNC / 8;
+    const int vrow = lane / V, vcol = (lane % V) * 8;
+    const int n = n0 + wn + vcol;
+    float bv[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bv[e] = p.bias ? p.bias[n + e] : 0.f;
+        ssum[e] = 0.f;
+        ssq[e] = 0.f;
+    }
+    const size_t img_row0 = (size_t)img * p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                cw[row * LDC + ((j * 32 + lr) ^ ((row & 1) << 2))] = acc[i][j][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 64 / V) {
+            const int ml = rr + vrow;
+            const int pr = wm + i * 32 + ml;                              // row inside the patch
+            const size_t m = img_row0 + (size_t)(oy0 + (pr >> 4)) * p.W + ox0 + (pr & 15);
+            const int sx = (ml & 1) << 2;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
+            float v[8] = {c0[0] + bv[0], c0[1] + bv[1], c0[2] + bv[2], c0[3] + bv[3], c1[0] + bv[4], c1[1] + bv[5], c1[2] + bv[6], c1[3] + bv[7]};
+            const size_t o = m * p.Cout + n;
+            if (p.rowvec) {
+                const float* rv = p.rowvec + (m / p.rows_per_batch) * p.Cout + n;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+            }
+            if (p.residual) {
+                const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
+                v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+            }
+            uint16_t h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = f2bf3(v[e]);
+                const float r = bf2f3(h[e]);
+                ssum[e] += r;
+                ssq[e] += r * r;
+            }
+            uint4 u;
+            u.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+            u.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+            u.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16);
+            u.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+            *reinterpret_cast<uint4*>(p.y + o) = u;
+        }
+        if ((i & 1) == 1 && p.stats) {
+            // two 32-row sub-tiles = one 64-row statistics block of this wave.  Blocks are numbered (tile, 64-row group of the
+            // patch): another order than NHWC rows / 64, but every block still lies inside ONE frame, which is all the GroupNorm
+            // reduction over a sample's blocks needs
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o2 = V; o2 < 64; o2 <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], o2, 64);
+                    ssq[e] += __shfl_xor(ssq[e], o2, 64);
+                }
+            }
+            if (lane < V) {
+                const size_t blk = (size_t)tm * 4 + ((wm + (i - 1) * 32) >> 6);
+                float* dst = p.stats + blk * 2 * p.Cout + n;
+                f32x4 a0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, a1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
+                f32x4 q0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, q1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
+                *reinterpret_cast<f32x4*>(dst) = a0;
+                *reinterpret_cast<f32x4*>(dst + 4) = a1;
+                *reinterpret_cast<f32x4*>(dst + p.Cout) = q0;
+                *reinterpret_cast<f32x4*>(dst + p.Cout + 4) = q1;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        }
+    }
+}
+
+extern "C" {
+
+// 1 when v2a_conv2d_fwd_h3 takes this problem: 3x3 / stride 1 / pad 1, one bf16 source, frames that tile into 16 x 16 patches,
+// 128-multiple output width, enough tiles to fill the chip.  V2A_CONV_H3=0 disables the path.
+int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2A_CONV_H3"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || KH != 3 || KW != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || ups || C2) return 0;
+    if (C % 32 || Cout % 128 || H % 16 || W % 16) return 0;
+    const long tiles = (long)N * (H / 16) * (W / 16) * (Cout / (Cout % 256 == 0 ? 256 : 128));
+    if (tiles < 512) return 0;
+    if ((double)N * H * W * C >= 4294967296.0 || (double)Cout * 9 * C >= 4294967296.0) return 0;
+    return 1;
+}
+
+// bf16 in / bf16 out; bias fp32 [Cout]; rowvec fp32 [M / rows_per_batch][Cout]; residual bf16 [M][Cout]; stats fp32 [M/64][2][Cout].
+int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
+                      const void* zeros, int N, int H, int W, int C, int Cout, int rows_per_batch, float* stats, hipStream_t stream) {
+    if (!x || !w_packed || !zeros || !y || N <= 0) return V2A_ERR_ARG;
+    if (!v2a_conv2d_h3_eligible(N, H, W, C, Cout, 3, 3, 1, 1, 1, 1, 0, 0)) return V2A_ERR_ARG;
+    if ((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)rowvec) & 15) != 0)
+        return V2A_ERR_ARG;
+    ConvDescH3 p;
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual;
+    p.y = (uint16_t*)y; p.stats = stats; p.zeros = (const uint16_t*)zeros;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.M = N * H * W; p.K = 9 * C;
+    p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.tiles_x = W / 16;
+    p.tiles_img = (H / 16) * (W / 16);
+    if (Cout % 256 == 0) {
+        const int tiles = N * p.tiles_img * (Cout / 256);
+        hipLaunchKernelGGL((conv_halo_h3<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, ring of 4 x 16 KB
+    } else {
+        const int tiles = N * p.tiles_img * (Cout / 128);
+        hipLaunchKernelGGL((conv_halo_h3<4, 2, 2, 2, 6>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, ring of 6 x 8 KB
+    }
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+}  // extern "C"
