@@ -250,7 +250,7 @@ int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, cons
    16 x 16 output patch is DMA-ed once per 32-channel chunk and shared by the nine taps (Conv3d spatial part, nn.py:45,64-69) */
 int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2);
 int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
-                      const void* zeros, int N, int H, int W, int C, int Cout, int rows_per_batch, float* stats, v2a_stream_t stream);
+                      const void* zeros, int N, int H, int W, int C, int Cout, int ups, int rows_per_batch, float* stats, v2a_stream_t stream);
 int v2a_conv2d_h2_eligible(int M, int Cout, int K, int C1, int C2);
 int v2a_conv2d_fwd_h2(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                       void* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh, int sw, int ph,

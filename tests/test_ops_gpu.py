@@ -529,7 +529,7 @@ def test_conv2d_h2_multistage_kernel_matches_fp64_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,H,W,C,Co", [(34, 64, 64, 96, 256), (36, 48, 80, 64, 128), (44, 32, 32, 128, 384)])
+@pytest.mark.parametrize("N,H,W,C,Co", [(34, 64, 64, 96, 256), (36, 48, 80, 64, 128), (44, 32, 32, 128, 384), (56, 64, 32, 64, 128)])
 def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
     """The halo-tile 3x3 kernel (csrc/igemm_h3.hip: 16 x 16 output patches, the 18 x 18 input halo DMA-ed once per 32-channel chunk and
     read by the nine taps through shifted LDS windows, counted-vmcnt weight ring): both instances (256x256 / 256x128), image borders on
@@ -568,6 +568,29 @@ def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
     nb = H * W // 64
     assert torch.allclose(st[:, 0].view(N, nb, Co).sum(1), yf.sum(1), rtol=1e-4, atol=5e-2)
     assert torch.allclose(st[:, 1].view(N, nb, Co).sum(1), (yf * yf).sum(1), rtol=1e-4, atol=5e-2)
+
+
+@pytest.mark.gpu
+def test_conv2d_halo_h3_folds_the_nearest_upsample():
+    """Upsample (nearest x2 on H, W) + 3x3 conv (unet.py:105-115) on the halo kernel: the gather reads source pixel (ih >> 1, iw >> 1)."""
+    from v2a_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(77)
+    N, H, W, C, Co = 30, 16, 16, 64, 256                              # runs over 32 x 32 frames: 30 x 4 = 120 patches x 1 column tile ... x
+    N = 60                                                            # 240 tiles
+    x = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    wp = ops.pack_weight_h(w)
+    y = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), ups=True)
+    assert ops.last_kernel[0].startswith("conv_halo_h3") and y.shape == (N, 2 * H, 2 * W, Co)
+    xin = x.float().permute(0, 3, 1, 2).cpu().double()
+    xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+    wq = w.to(torch.bfloat16).float().cpu().double()
+    for n in (0, N - 1):
+        ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=1).permute(0, 2, 3, 1)[0]
+        err = (y[n].cpu().double() - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
 
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout", [(28, 128, 32, 32, 128), (56, 128, 16, 16, 256), (256, 128, 8, 8, 256), (14, 128, 32, 64, 128),

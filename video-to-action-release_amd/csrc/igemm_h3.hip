@@ -35,6 +35,7 @@ struct ConvDescH3 {
     float* stats;               // optional [M / 64][2][Cout]
     const uint16_t* zeros;
     int N, H, W, C, Cout, M, K, rows_per_batch, tiles_x, tiles_img;
+    int ups;                    // 1: nearest x2 upsample folded into the halo gather (Upsample + conv, unet.py:105-115): source frame is (H/2, W/2)
 };
 
 __device__ __forceinline__ int xcd_remap3(int bid, int nblk) {
@@ -55,33 +56,45 @@ __device__ __forceinline__ void wait_vmcnt3() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// number of halo pieces issued at steps s-(SB-1) .. s-1 when step s has tap T (halo pieces go out at taps 1, 3, 5)
-template <int T, int SB>
+// halo piece j of the next chunk goes out at tap halo_tap(j, HP): 1, 3, 5 for three pieces, 1 .. 5 for five -- all of them ahead
+// of the first weight tile of the next chunk in the queue as long as SB - 1 <= 3 (issued at tap 9 - (SB - 1) >= 6) ...
+__host__ __device__ constexpr int halo_tap(int j, int HP) { return HP <= 3 ? 1 + 2 * j : 1 + j; }
+__host__ __device__ constexpr int halo_piece_at(int tap, int HP) {       // piece index issued at `tap`, or -1
+    for (int j = 0; j < HP; ++j)
+        if (halo_tap(j, HP) == tap) return j;
+    return -1;
+}
+// number of halo pieces issued at steps s-(SB-1) .. s-1 when step s has tap T
+template <int T, int SB, int HP>
 struct HaloLater {
     static constexpr int count() {
         int c = 0;
         for (int d = 1; d <= SB - 1; ++d) {
             int u = ((T - d) % 9 + 9) % 9;
-            if (u == 1 || u == 3 || u == 5) ++c;
+            if (halo_piece_at(u, HP) >= 0) ++c;
         }
         return c;
     }
     static constexpr int value = count();
 };
 
+// BM = 256 (16 x 16 patch) or 512 (32 rows x 16 pixels: the 128-wide instance -- 12.3 KB of DMA per 512 x 128 x 32 step).
 template <int WAVES_M, int WAVES_N, int TM, int TN, int SB>
 __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
-    constexpr int BM = 256, BN = WAVES_N * TN * 32;
-    static_assert(WAVES_M * TM * 32 == BM && WAVES_M * WAVES_N == 8, "tile shape");
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    static_assert((BM == 256 || BM == 512) && WAVES_M * WAVES_N == 8, "tile shape");
+    constexpr int PH = BM / 16;                            // patch: PH rows of 16 pixels
     constexpr int ROWB = 64;                               // bytes per row: 32 bf16
-    constexpr int HW_ = 18, HROWS = HW_ * HW_;             // halo: 18 x 18 pixels
-    constexpr int HPIECES = 3;                             // DMA instructions per thread per halo (3 x 512 x 16 B = 24 KB >= 20.7 KB)
+    constexpr int HW_ = 18, HROWS = HW_ * (PH + 2);        // halo: (PH + 2) x 18 pixels
+    constexpr int HPIECES = (HROWS * 4 + 511) / 512;       // DMA instructions per thread per halo (3: 24 KB >= 20.7 KB; 5: 40 KB >= 38.3 KB)
+    static_assert(HPIECES <= 4 || SB >= 2, "halo pieces");
     constexpr int HBUF = HPIECES * 512 * 16;
     constexpr int BL = BN / 128;                           // DMA instructions per thread per weight tile (128 rows x 4 chunks per pass)
     constexpr int BSTAGE = BN * ROWB;
     constexpr int SMEM = 2 * HBUF + SB * BSTAGE;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static_assert((SB - 2) * BL + 3 <= 63, "vmcnt is a 6-bit counter");
+    static_assert((SB - 2) * BL + HPIECES <= 63, "vmcnt is a 6-bit counter");
+    static_assert(9 - (SB - 1) > halo_tap(HPIECES - 1, HPIECES), "the last halo piece must precede the next chunk's first weight tile");
     __shared__ __attribute__((aligned(128))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     const int tm = lin / tiles_n, n0 = (lin % tiles_n) * BN;
     const int img = tm / p.tiles_img, trem = tm - img * p.tiles_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int oy0 = ty * PH, ox0 = tx * 16;
     const int nchunks = p.C >> 5;
 
     // ---- halo DMA source state: piece q = j * 512 + tid -> halo row q >> 2, position q & 3, carrying chunk (q & 3) ^ ((row >> 2) & 3).
@@ -106,7 +119,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
         const int ih = oy0 - 1 + hy, iw = ox0 - 1 + hx;
         const int chunk = (q & 3) ^ ((hr >> 2) & 3);
         const bool ok = hr < HROWS && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        h_off[j] = ok ? ((uint32_t)(img * p.H + ih) * (uint32_t)p.W + (uint32_t)iw) * (uint32_t)p.C + (uint32_t)chunk * 8u : 0xffffffffu;
+        const int sh_ = p.ups ? (p.H >> 1) : p.H, sw_ = p.ups ? (p.W >> 1) : p.W;
+        const int ihs = p.ups ? (ih >> 1) : ih, iws = p.ups ? (iw >> 1) : iw;
+        h_off[j] = ok ? ((uint32_t)(img * sh_ + ihs) * (uint32_t)sw_ + (uint32_t)iws) * (uint32_t)p.C + (uint32_t)chunk * 8u : 0xffffffffu;
     }
     // ---- weight DMA source state: pass j fills rows j*128 .. +127; slot (row j*128 + tid/4, position tid%4), chunk (tid%4) ^ ((row>>2)&3)
     const uint32_t b_off0 = (uint32_t)(n0 + (tid >> 2)) * (uint32_t)p.K + (uint32_t)(((tid & 3) ^ ((tid >> 4) & 3)) * 8);
@@ -178,10 +193,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
 #define V2A_H3_TAP(T)                                                                                                  \
     {                                                                                                                  \
         if (c == 0) wait_vmcnt3<(SB - 2) * BL>();      /* start-up: no halo pieces of a previous chunk in the queue */  \
-        else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB>::value>();                                                   \
+        else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB, HPIECES>::value>();                                          \
         __builtin_amdgcn_s_barrier();                                                                                  \
         issue_b(c + (T + SB - 1) / 9, (T + SB - 1) % 9, istage);                                                       \
-        if (T == 1 || T == 3 || T == 5) issue_halo_piece((T - 1) / 2, c + 1, (c + 1) & 1);                             \
+        if (halo_piece_at(T, HPIECES) >= 0) issue_halo_piece(halo_piece_at(T, HPIECES), c + 1, (c + 1) & 1);           \
         mma_step(smem + (c & 1) * HBUF, smem + 2 * HBUF + cstage * BSTAGE, (T / 3) * HW_ + (T % 3));                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
         cstage = (cstage + 1 == SB) ? 0 : cstage + 1;                                                                  \
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
                 }
             }
             if (lane < V) {
-                const size_t blk = (size_t)tm * 4 + ((wm + (i - 1) * 32) >> 6);
+                const size_t blk = (size_t)tm * (BM / 64) + ((wm + (i - 1) * 32) >> 6);
                 float* dst = p.stats + blk * 2 * p.Cout + n;
                 f32x4 a0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, a1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
                 f32x4 q0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, q1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
@@ -296,19 +311,23 @@ extern "C" {
 int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("V2A_CONV_H3"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || KH != 3 || KW != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || ups || C2) return 0;
+    if (!on || KH != 3 || KW != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || C2) return 0;
+    if (ups) { H *= 2; W *= 2; }                          // H, W: the SOURCE frame; the conv runs over the upsampled one
     if (C % 32 || Cout % 128 || H % 16 || W % 16) return 0;
-    const long tiles = (long)N * (H / 16) * (W / 16) * (Cout / (Cout % 256 == 0 ? 256 : 128));
-    if (tiles < 512) return 0;
+    const bool wide = Cout % 256 == 0;                    // 256 x 256 tiles; otherwise 512 x 128 (needs H % 32 == 0) or 256 x 128
+    const long tiles = wide ? (long)N * (H / 16) * (W / 16) * (Cout / 256)
+                            : (long)N * (H / (H % 32 == 0 ? 32 : 16)) * (W / 16) * (Cout / 128);
+    if (tiles < 208) return 0;                            // at least ~80 % of the CUs busy in the single round
     if ((double)N * H * W * C >= 4294967296.0 || (double)Cout * 9 * C >= 4294967296.0) return 0;
     return 1;
 }
 
-// bf16 in / bf16 out; bias fp32 [Cout]; rowvec fp32 [M / rows_per_batch][Cout]; residual bf16 [M][Cout]; stats fp32 [M/64][2][Cout].
+// x [N, H, W, C] (ups: the conv runs over the nearest-x2 upsampled [N, 2H, 2W, C]); bf16 in / bf16 out; bias fp32 [Cout]; rowvec fp32 [M / rows_per_batch][Cout]; residual bf16 [M][Cout]; stats fp32 [M/64][2][Cout].
 int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
-                      const void* zeros, int N, int H, int W, int C, int Cout, int rows_per_batch, float* stats, hipStream_t stream) {
+                      const void* zeros, int N, int H, int W, int C, int Cout, int ups, int rows_per_batch, float* stats, hipStream_t stream) {
     if (!x || !w_packed || !zeros || !y || N <= 0) return V2A_ERR_ARG;
-    if (!v2a_conv2d_h3_eligible(N, H, W, C, Cout, 3, 3, 1, 1, 1, 1, 0, 0)) return V2A_ERR_ARG;
+    if (!v2a_conv2d_h3_eligible(N, H, W, C, Cout, 3, 3, 1, 1, 1, 1, ups, 0)) return V2A_ERR_ARG;
+    if (ups) { H *= 2; W *= 2; }
     if ((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)rowvec) & 15) != 0)
         return V2A_ERR_ARG;
     ConvDescH3 p;
@@ -316,14 +335,19 @@ int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, co
     p.y = (uint16_t*)y; p.stats = stats; p.zeros = (const uint16_t*)zeros;
     p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.M = N * H * W; p.K = 9 * C;
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.ups = ups ? 1 : 0;
     p.tiles_x = W / 16;
     p.tiles_img = (H / 16) * (W / 16);
     if (Cout % 256 == 0) {
         const int tiles = N * p.tiles_img * (Cout / 256);
         hipLaunchKernelGGL((conv_halo_h3<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, ring of 4 x 16 KB
+    } else if (H % 32 == 0) {
+        p.tiles_img = (H / 32) * (W / 16);
+        const int tiles = N * p.tiles_img * (Cout / 128);
+        hipLaunchKernelGGL((conv_halo_h3<4, 2, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 512 x 128, ring of 4 x 8 KB
     } else {
         const int tiles = N * p.tiles_img * (Cout / 128);
-        hipLaunchKernelGGL((conv_halo_h3<4, 2, 2, 2, 6>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, ring of 6 x 8 KB
+        hipLaunchKernelGGL((conv_halo_h3<4, 2, 2, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, ring of 4 x 8 KB
     }
     V2A_CHECK_LAUNCH();
     return V2A_OK;

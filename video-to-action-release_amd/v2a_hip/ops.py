@@ -436,8 +436,9 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         # 3x3 / stride 1: the halo-tile kernel (csrc/igemm_h3.hip) -- the nine taps share one DMA of the input patch
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
         check(lib.v2a_conv2d_fwd_h3(x.data_ptr(), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(res_h), y.data_ptr(),
-                                    _zero_line(x.device).data_ptr(), N, H, W, C1, Cout, rows_per_batch, _p(stats), _stream()), "conv2d_fwd_h3")
-        last_kernel[0] = f"conv_halo_h3<{'256x256' if Cout % 256 == 0 else '256x128'}>"
+                                    _zero_line(x.device).data_ptr(), N, H, W, C1, Cout, 1 if ups else 0, rows_per_batch, _p(stats), _stream()),
+              "conv2d_fwd_h3")
+        last_kernel[0] = f"conv_halo_h3<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
         return (y, stats) if want_stats else y
     if (_H2 and idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16
             and lib.v2a_conv2d_h2_eligible(M, Cout, K, C1, C2)):
