@@ -251,6 +251,12 @@ int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, cons
 int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2);
 int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
                       const void* zeros, int N, int H, int W, int C, int Cout, int ups, int rows_per_batch, float* stats, v2a_stream_t stream);
+/* Temporal (3 x 1 x 1) part of the factorised Conv3d (nn.py:45-69: temporal_conv) on the frame-stack tile (csrc/igemm_h3.hip,
+   conv_frames_h3): all F = 7 frames of 64 pixels in one workgroup, the input DMA-ed once per 32-channel chunk for the three taps.
+   Same argument meaning as v2a_conv2d_fwd_h3 with x viewed as [B, F, HW, C] */
+int v2a_conv2d_t3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2);
+int v2a_conv2d_fwd_t3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
+                      const void* zeros, int B, int F, int HW, int C, int Cout, int rows_per_batch, float* stats, v2a_stream_t stream);
 int v2a_conv2d_h2_eligible(int M, int Cout, int K, int C1, int C2);
 int v2a_conv2d_fwd_h2(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                       void* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW, int sh, int sw, int ph,

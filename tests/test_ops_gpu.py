@@ -593,6 +593,48 @@ def test_conv2d_halo_h3_folds_the_nearest_upsample():
         assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,HW,C,Co", [(16, 1024, 128, 128), (4, 4096, 192, 256), (30, 512, 64, 128), (18, 256, 320, 384)])
+def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co):
+    """The frame-stack temporal kernel (csrc/igemm_h3.hip conv_frames_h3: all 7 frames of 64 pixels per workgroup, operand fragments
+    kept in registers across the three taps, products against frames -1 / 7 not issued): first / last frame borders, several
+    pixel tiles per sample, 2 .. 5 channel chunks (fewer than, equal to and more than the three LDS stages), bias + per-sample
+    row vector + bf16 residual + statistics in natural 64-row blocks.  Within one bf16 ulp of an fp64 conv of the same rounded
+    operands, and equal to the tap-by-tap kernel up to summation order."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    dev, F = "cuda:0", 7
+    g = torch.Generator().manual_seed(5 + B)
+    assert lib.v2a_conv2d_t3_eligible(B, F, HW, C, Co, 3, 1, 1, 1, 1, 0, 0, 0) == 1
+    x = torch.randn(B, F, HW, C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Co, C, 3, 1, generator=g) * 0.08).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    rowvec = torch.randn(B, Co, generator=g).to(dev)
+    res = torch.randn(B, F, HW, Co, generator=g).to(torch.bfloat16).to(dev)
+    wp = ops.pack_weight_h(w)
+    y, st = ops.conv2d_h(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res, want_stats=True)
+    assert ops.last_kernel[0].startswith("conv_frames_h3") and st is not None
+    os.environ["V2A_CONV_H3_OFF_FOR_TEST"] = "1"
+    try:
+        y1 = ops.conv2d_h(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res)
+    finally:
+        os.environ.pop("V2A_CONV_H3_OFF_FOR_TEST")
+    assert not ops.last_kernel[0].startswith("conv_frames_h3")
+    d = (y.float() - y1.float()).abs()
+    assert (d <= y1.float().abs() * 2.0 ** -7 + 1e-5).all() and (d > 0).float().mean().item() < 0.01
+    xin = x.float().permute(0, 3, 1, 2).cpu().double()
+    wq = w.to(torch.bfloat16).float().cpu().double()
+    for n in (0, B - 1):
+        ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=(1, 0)).permute(0, 2, 3, 1)[0]
+        ref = ref + rowvec[n].cpu().double() + res[n].cpu().double()
+        err = (y[n].cpu().double() - ref).abs()
+        assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
+    rows = y.float().view(-1, 64, Co)                                  # natural block numbering: rows / 64
+    assert torch.allclose(st[:, 0], rows.sum(1), rtol=1e-4, atol=2e-3) and torch.allclose(st[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=2e-3)
+    y2, st2 = ops.conv2d_h(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(st, st2)                 # fixed summation order
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout", [(28, 128, 32, 32, 128), (56, 128, 16, 16, 256), (256, 128, 8, 8, 256), (14, 128, 32, 64, 128),
                                             (27, 128, 33, 32, 128), (4, 64, 32, 32, 64)])
 def test_wgrad_halo_kernel_vs_torch(N, Cin, H, W, Cout):

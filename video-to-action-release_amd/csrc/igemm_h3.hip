@@ -304,6 +304,256 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Temporal (3 x 1 x 1) convolution of the factorised Conv3d (unet.py: temporal_conv over [B, F, H*W, C]) -- the frame-stack tile.
+// conv_igemm_h / _h2 fetch the input three times (once per tap) and run at 470-770 TFLOP/s on these layers.  Here a 512-thread
+// workgroup owns ALL F frames of 64 consecutive pixels of one sample (BM = F * 64 = 448 output rows) x 128 output channels; per
+// 32-channel chunk one DMA brings the F x 64 input rows (28 KB) plus the three taps' weight tiles (3 x 8 KB) into one of three LDS
+// stages, a wave loads its F operand fragments ONCE into registers and uses each of them for up to three taps
+// (output frame f, tap t <- input frame f + t - 1), and the products against the out-of-range frames -1 and F are simply not issued
+// (19 instead of 21 MFMAs per k-half: 9.5 % fewer than the zero-padded GEMM).  One barrier per chunk (~2400 MFMA cycles per SIMD),
+// a counted vmcnt wait with one newer stage always in flight; 0.53 KB of LDS reads per MFMA (the halo kernel: 0.75).
+// K = 3 C is short (4 chunks at C = 128), so the launch is PERSISTENT: one workgroup per CU walks tiles lin, lin + G, ... as one
+// chunk stream and the next tile's first two chunks land while this tile's epilogue runs (a one-tile-per-workgroup launch of the
+// same body spends a third of its time filling and draining the pipeline; these layers sit near the HBM roofline).
+// The two M-waves split every frame's 64 pixels in halves, so a 64-row statistics block is completed through LDS in the epilogue
+// (fixed order: deterministic); the per-column sums come from a column pass over the staged tile, not a lane butterfly.
+struct ConvDescT3 {
+    const uint16_t* x;          // [B, F, HW, C] bf16
+    const uint16_t* w;          // [Cout][3][C] bf16
+    const float* bias;
+    const float* rowvec;        // [M / rows_per_batch][Cout] or null
+    const uint16_t* residual;   // [M][Cout] bf16 or null
+    uint16_t* y;                // [M][Cout] bf16
+    float* stats;               // optional [M / 64][2][Cout]
+    const uint16_t* zeros;
+    int B, HW, C, Cout, K, rows_per_batch, tiles_b;
+};
+
+template <int F>
+__global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
+    constexpr int PX = 64, BM = F * PX, BN = 128, ROWB = 64, NST = 3;
+    constexpr int ABYTES = BM * ROWB, BBYTES = 3 * BN * ROWB, STAGE = ABYTES + BBYTES;
+    constexpr int AJ = (BM * 4 + 511) / 512;               // DMA instructions per thread for the input rows; the last one covers
+    constexpr int ALAST_WAVES = (BM * 4 - (AJ - 1) * 512) / 64;   // only the first ALAST_WAVES waves (whole waves: BM * 4 % 64 == 0)
+    constexpr int LDC = 32, V = 4;
+    constexpr int ST_OFF = 8 * 32 * LDC * 4;               // epilogue scratch inside the stage consumed last: staging rows, then statistics
+    constexpr int SMEM = NST * STAGE;                      // 156 KB at F = 7
+    static_assert(SMEM <= 160 * 1024 && (BM * 4) % 64 == 0, "LDS budget / whole-wave tail");
+    static_assert(ST_OFF + 2 * F * 4 * 64 * 4 <= STAGE, "epilogue scratch must fit one stage");
+    __shared__ __attribute__((aligned(128))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = p.Cout / BN;
+    const int total = p.B * p.tiles_b * tiles_n;
+    const int G = gridDim.x;
+    int lin = xcd_remap3(blockIdx.x, G);
+    if (lin >= total) return;
+    const int nchunks = p.C >> 5;
+    const bool a_tail = wid < ALAST_WAVES;                 // wave-uniform
+
+    // thread part of the DMA source offsets (BYTES, 32 bit); the tile / chunk part is a wave-uniform 64-bit base, so the DMA takes
+    // the scalar-base + 32-bit-offset address form and no per-thread 64-bit pointers stay live across the MFMA loop
+    uint32_t a_thr[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int q = j * 512 + tid;
+        const int row = q >> 2, f = row >> 6, px = row & 63;
+        const int chunk = (q & 3) ^ ((row >> 2) & 3);
+        a_thr[j] = (((uint32_t)f * (uint32_t)p.HW + (uint32_t)px) * (uint32_t)p.C + (uint32_t)chunk * 8u) * 2u;
+    }
+    const uint32_t b_thr = ((uint32_t)(tid >> 2) * (uint32_t)p.K + (uint32_t)(((tid & 3) ^ ((tid >> 4) & 3)) * 8)) * 2u;
+
+    // the chunk stream this workgroup walks: tiles lin, lin + G, ... x chunks 0 .. nchunks-1; `iq_*` is the next chunk to ISSUE (two
+    // ahead of the one computed, across tile boundaries: the next tile's first chunks land while this tile's epilogue runs).  Past
+    // the end of the stream the DMAs read the zero line, so every step issues the same number and the wait counts stay constants
+    int iq_lin = lin, iq_c = 0;
+    auto tile_base = [&](int l, size_t& ta, size_t& tb) {
+        const int t2 = l / tiles_n;
+        const int bb = t2 / p.tiles_b;
+        ta = ((size_t)(bb * F) * p.HW + (size_t)(t2 - bb * p.tiles_b) * PX) * p.C;
+        tb = (size_t)(l - t2 * tiles_n) * BN * p.K;
+    };
+    size_t iq_ta, iq_tb;
+    tile_base(iq_lin, iq_ta, iq_tb);
+    auto issue_next = [&](int stage) {
+        unsigned char* base = smem + stage * STAGE;
+        const bool live = iq_lin < total;
+        const char* xb = reinterpret_cast<const char*>(p.x) + (iq_ta + (size_t)iq_c * 32) * 2;
+        const char* wb = reinterpret_cast<const char*>(p.w) + (iq_tb + (size_t)iq_c * 32) * 2;
+        const char* zb = reinterpret_cast<const char*>(p.zeros);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            if (j == AJ - 1 && !a_tail) break;
+            __builtin_amdgcn_global_load_lds((gptr3_t)(live ? xb + a_thr[j] : zb), (lptr3_t)(base + (j * 512 + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_global_load_lds((gptr3_t)(live ? wb + (size_t)j * p.C * 2 + b_thr : zb),
+                                             (lptr3_t)(base + ABYTES + (j * 512 + wid * 64) * 16), 16, 0, 0);
+        if (live && ++iq_c == nchunks) {
+            iq_c = 0;
+            iq_lin += G;
+            if (iq_lin < total) tile_base(iq_lin, iq_ta, iq_tb);
+        }
+    };
+
+    const int w = wid >> 2, wn = (wid & 3) * 32;           // M half (pixels w*32 .. +31 of every frame), output-channel group
+    const int lr = lane & 31, lk = lane >> 5;
+    const int swz = (lr >> 2) & 3;
+    int a_base = (w * 32 + lr) * ROWB;
+    const int b_base = ABYTES + (wn + lr) * ROWB;
+    const int vrow = lane / V, vcol = (lane % V) * 8;
+
+    issue_next(0);
+    issue_next(1);
+    int cstage = 0, istage = 2;
+    for (; lin < total; lin += G) {
+        const int tmi = lin / tiles_n;
+        const int b = tmi / p.tiles_b, p0 = (tmi - b * p.tiles_b) * PX, n0 = (lin - tmi * tiles_n) * BN;
+        f32x16 acc[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            // chunk c must have landed; chunk c+1 may stay in flight -- except at a tile's first chunk, where the previous tile's
+            // epilogue stores sit in the same counter (stores and loads do not retire in one order): drain it there
+            if (c == 0) wait_vmcnt3<0>();
+            else if (a_tail) wait_vmcnt3<AJ + 3>();
+            else wait_vmcnt3<AJ - 1 + 3>();
+            __builtin_amdgcn_s_barrier();
+            issue_next(istage);
+            const unsigned char* sb = smem + cstage * STAGE;
+            asm volatile("" : "+v"(a_base));
+            // operand fragments: the ten of k-half 0 go out first, the ten of k-half 1 behind the first tap's MFMAs (lgkmcnt is a
+            // 4-bit counter: more than 15 reads in flight make the compiler drain the queue).  Left alone the compiler fetches one
+            // weight fragment at a time and waits for it before every tap
+            bf16x8_3 a[2][F], bt[2][3];
+            auto load_half = [&](int h) {
+                const int pos = (((h << 1) | lk) ^ swz) << 4;
+#pragma unroll
+                for (int i = 0; i < F; ++i) a[h][i] = *reinterpret_cast<const bf16x8_3*>(sb + a_base + i * (PX * ROWB) + pos);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bt[h][t] = *reinterpret_cast<const bf16x8_3*>(sb + b_base + t * (BN * ROWB) + pos);
+            };
+            auto mma_tap = [&](int h, int t) {
+#pragma unroll
+                for (int i = 0; i < F; ++i) {
+                    const int src = i + t - 1;
+                    if (src >= 0 && src < F) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][src], bt[h][t], acc[i], 0, 0, 0);
+                }
+            };
+            load_half(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(0, 1);
+            mma_tap(0, 2);
+            mma_tap(1, 0);
+            mma_tap(1, 1);
+            mma_tap(1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cstage = (cstage + 1 == NST) ? 0 : cstage + 1;
+            istage = (istage + 1 == NST) ? 0 : istage + 1;
+        }
+
+        // `istage` now names the stage consumed last: nothing is in flight to it until the next step's barrier, so -- once every wave
+        // has read its last fragments -- it carries the epilogue's staging rows (private to each wave) and the statistics exchange
+        __builtin_amdgcn_s_barrier();
+        float* cw = reinterpret_cast<float*>(smem + istage * STAGE) + wid * 32 * LDC;
+        float* st = reinterpret_cast<float*>(smem + istage * STAGE + ST_OFF);       // [2 (w)][F][4 (wn)][2][32]
+        // ---- epilogue: sub-tile i of this wave = frame i, pixels p0 + w*32 .. +31 (staging rows private to the wave)
+        const int n = n0 + wn + vcol;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                cw[row * LDC + (lr ^ ((row & 1) << 2))] = acc[i][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const size_t m0 = ((size_t)(b * F + i) * p.HW) + p0 + w * 32;
+#pragma unroll
+            for (int rr = 0; rr < 32; rr += 64 / V) {
+                const int ml = rr + vrow;
+                const size_t m = m0 + ml;
+                const int sx = (ml & 1) << 2;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
+                float v[8] = {c0[0] + bv[0], c0[1] + bv[1], c0[2] + bv[2], c0[3] + bv[3], c1[0] + bv[4], c1[1] + bv[5], c1[2] + bv[6], c1[3] + bv[7]};
+                const size_t o = m * p.Cout + n;
+                if (p.rowvec) {
+                    const float* rv = p.rowvec + (size_t)((uint32_t)m / (uint32_t)p.rows_per_batch) * p.Cout + n;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                }
+                if (p.residual) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
+                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+                    v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
+                    v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                }
+                uint16_t hh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hh[e] = f2bf3(v[e]);
+                if (p.stats) {                                        // the stored values go back into the staging rows for the column pass
+                    const f32x4 w0 = {bf2f3(hh[0]), bf2f3(hh[1]), bf2f3(hh[2]), bf2f3(hh[3])}, w1 = {bf2f3(hh[4]), bf2f3(hh[5]), bf2f3(hh[6]), bf2f3(hh[7])};
+                    *reinterpret_cast<f32x4*>(&cw[ml * LDC + (vcol ^ sx)]) = w0;
+                    *reinterpret_cast<f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]) = w1;
+                }
+                uint4 u;
+                u.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
+                u.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+                u.z = (uint32_t)hh[4] | ((uint32_t)hh[5] << 16);
+                u.w = (uint32_t)hh[6] | ((uint32_t)hh[7] << 16);
+                *reinterpret_cast<uint4*>(p.y + o) = u;
+            }
+            if (p.stats) {
+                // column pass: lane = (column lane & 31, rows (lane >> 5) * 16 .. +15) of the 32 x 32 sub-tile, sixteen conflict-free
+                // ds_read_b32 and in-lane adds, ONE cross-lane exchange per statistic.  (A 16-lane butterfly over the row-major lanes
+                // costs 64 ds_bpermute per sub-tile -- a third of this kernel's time at C = 128.)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int col = lane & 31, r0 = (lane >> 5) * 16;
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int row = r0 + rr;
+                    const float x = cw[row * LDC + (col ^ ((row & 1) << 2))];
+                    s += x;
+                    q += x * x;
+                }
+                s += __shfl_xor(s, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (lane < 32) {
+                    float* d = st + (((w * F + i) * 4 + (wid & 3)) * 2) * 32 + col;
+                    d[0] = s;
+                    d[32] = q;
+                }
+            }
+        }
+        if (p.stats) {
+            __syncthreads();
+            const int half = lane >> 5, col = lane & 31;
+            for (int i = w; i < F; i += 2) {               // the two pixel halves of frame i's 64-row block, added in a fixed order
+                const float v = st[(((0 * F + i) * 4 + (wid & 3)) * 2 + half) * 32 + col] + st[(((1 * F + i) * 4 + (wid & 3)) * 2 + half) * 32 + col];
+                const size_t blk = (((size_t)(b * F + i) * p.HW) + p0) >> 6;
+                p.stats[blk * 2 * p.Cout + (size_t)half * p.Cout + n0 + wn + col] = v;
+            }
+        }
+    }
+}
+
 extern "C" {
 
 // 1 when v2a_conv2d_fwd_h3 takes this problem: 3x3 / stride 1 / pad 1, one bf16 source, frames that tile into 16 x 16 patches,
@@ -349,6 +599,44 @@ int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, co
         const int tiles = N * p.tiles_img * (Cout / 128);
         hipLaunchKernelGGL((conv_halo_h3<4, 2, 2, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, ring of 4 x 8 KB
     }
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+// 1 when v2a_conv2d_fwd_t3 takes this problem: the temporal tap of the factorised Conv3d seen as a 2-d conv over [B, F, HW, C] with
+// a 3 x 1 filter, stride 1, pad (1, 0); F = 7 (Libero: seven predicted frames), HW % 64 == 0, C % 32 == 0, Cout % 128 == 0.
+int v2a_conv2d_t3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2A_CONV_T3"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || KH != 3 || KW != 1 || sh != 1 || sw != 1 || ph != 1 || pw != 0 || C2 || ups) return 0;
+    if (H != 7 || W % 64 || C % 32 || Cout % 128) return 0;
+    if ((long)N * (W / 64) * (Cout / 128) < 208) return 0;
+    if ((double)N * H * W * C >= 4294967296.0 || (double)H * W * C >= 1073741824.0 || (double)Cout * 3 * C >= 1073741824.0) return 0;
+    return 1;
+}
+
+// x [B, F, HW, C] bf16; w_packed [Cout][3][C] bf16; y [B, F, HW, Cout] bf16; bias / rowvec fp32; residual bf16; stats fp32 [M/64][2][Cout].
+int v2a_conv2d_fwd_t3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
+                      const void* zeros, int B, int F, int HW, int C, int Cout, int rows_per_batch, float* stats, hipStream_t stream) {
+    if (!x || !w_packed || !zeros || !y || B <= 0) return V2A_ERR_ARG;
+    if (!v2a_conv2d_t3_eligible(B, F, HW, C, Cout, 3, 1, 1, 1, 1, 0, 0, 0)) return V2A_ERR_ARG;
+    if ((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)rowvec) & 15) != 0)
+        return V2A_ERR_ARG;
+    ConvDescT3 p;
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual;
+    p.y = (uint16_t*)y; p.stats = stats; p.zeros = (const uint16_t*)zeros;
+    p.B = B; p.HW = HW; p.C = C; p.Cout = Cout; p.K = 3 * C;
+    p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.tiles_b = HW / 64;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+    }
+    const int total = B * p.tiles_b * (Cout / 128);
+    hipLaunchKernelGGL((conv_frames_h3<7>), dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);      // one persistent workgroup per CU
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -112,6 +112,8 @@ SIGNATURES = {
     "v2a_conv2d_fwd_h_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_h2_eligible": (I, [I, I, I, I, I]),
     "v2a_conv2d_h3_eligible": (I, [I] * 13),
+    "v2a_conv2d_t3_eligible": (I, [I] * 13),
+    "v2a_conv2d_fwd_t3": (I, [P] * 7 + [I] * 6 + [P, P]),
     "v2a_conv2d_fwd_h3": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P]),
     "v2a_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P] + [I] * 16 + [P, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),

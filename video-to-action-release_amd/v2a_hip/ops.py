@@ -440,6 +440,15 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
               "conv2d_fwd_h3")
         last_kernel[0] = f"conv_halo_h3<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
         return (y, stats) if want_stats else y
+    if (idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16 and not defer and x2 is None and not ups
+            and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
+            and lib.v2a_conv2d_t3_eligible(N, H, W, C1, Cout, KH, KW, sh, sw, ph, pw, 0, C2)):
+        # temporal 3x1 over [B, F, HW, C]: the frame-stack kernel (csrc/igemm_h3.hip) -- the three taps share one DMA of the frames
+        stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
+        check(lib.v2a_conv2d_fwd_t3(x.data_ptr(), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(res_h), y.data_ptr(),
+                                    _zero_line(x.device).data_ptr(), N, H, W, C1, Cout, rows_per_batch, _p(stats), _stream()), "conv2d_fwd_t3")
+        last_kernel[0] = "conv_frames_h3<448x128>"
+        return (y, stats) if want_stats else y
     if (_H2 and idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16
             and lib.v2a_conv2d_h2_eligible(M, Cout, K, C1, C2)):
         # large layer: the multi-stage 256-row kernel (csrc/igemm_h2.hip)
