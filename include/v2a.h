@@ -100,6 +100,13 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
    that produces it: element = sum_s slabs[s][idx] + cbias[c] (forward) / + sresid[idx] (backward).  The conv's reduce launch disappears;
    `x` (forward) / `dout_sum` (backward, optional) receive the finished tensor.  Only for shapes v2a_groupnorm_takes_slabs() accepts
    (one wave per (sample, group): S * C / G <= 1024, C / G in {16, 32, 64, 128}); nslab = 0 behaves like the _t functions. */
+/* v2a_groupnorm_fwd whose statistics pass is replaced by the producing convs' epilogue sums (per-64-row blocks, as
+   v2a_conv2d_fwd_dma_f32(..., stats, ...) writes them when v2a_conv2d_dma_f32_can_emit_stats says it can): the normalised tensor is
+   read once instead of twice (GroupNorm32 of the fp32 sampler, guided_diffusion/nn.py:95-97 after Conv3d nn.py:53-87) */
+int v2a_conv2d_dma_f32_can_emit_stats(int M, int Cout, int K);
+int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         int N, int S, int C, int G, float eps, int act, const float* stats1, const float* stats2, void* workspace,
+                         size_t workspace_bytes, v2a_stream_t stream);
 int v2a_groupnorm_takes_slabs(int S, int C, int G);
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,

@@ -594,6 +594,43 @@ def test_conv2d_halo_h3_folds_the_nearest_upsample():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("two", [False, True])
+def test_fp32_groupnorm_takes_statistics_from_the_conv_epilogue(two):
+    """fp32 sampler: the LDS-DMA fp32 conv leaves per-64-row (sum, sum of squares) blocks in its epilogue and
+    v2a_groupnorm_fwd_st reduces those (in double, fixed order) instead of re-reading the tensor with gn_colreduce.  Same mean / rstd /
+    output as the statistics pass to fp32 round-off, also for the virtual channel concat [x | x2] of the decoder blocks; bitwise
+    repeatable."""
+    from v2a_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(123)
+    N, H, W, C, Co = 112, 32, 32, 64, 128                               # M = 114688: a single-pass plan on 128-row tiles
+    x = torch.randn(N, H, W, C, generator=g).to(dev)
+    w = ops.pack_weight((torch.randn(Co, C, 3, 3, generator=g) * 0.05).to(dev))
+    b = torch.randn(Co, generator=g).to(dev)
+    y, st = ops.conv2d(x, w, b, Co, 3, 3, (1, 1), (1, 1), want_stats=True)
+    assert st is not None and ops.last_kernel[0].startswith("conv_igemm_h<128") and st.shape == (N * H * W // 64, 2, Co)
+    rows = y.view(-1, 64, Co)
+    assert torch.allclose(st[:, 0], rows.sum(1), rtol=1e-5, atol=1e-4) and torch.allclose(st[:, 1], (rows * rows).sum(1), rtol=1e-5, atol=1e-4)
+    y2 = st2 = None
+    if two:
+        w2 = ops.pack_weight((torch.randn(64, C, 3, 3, generator=g) * 0.05).to(dev))
+        y2, st2 = ops.conv2d(x, w2, None, 64, 3, 3, (1, 1), (1, 1), want_stats=True)
+        assert st2 is not None
+    Ct = Co + (64 if two else 0)
+    gamma, beta = torch.randn(Ct, generator=g).to(dev), torch.randn(Ct, generator=g).to(dev)
+    S = 7 * H * W                                                       # seven frames per sample: 16 samples
+    a = y.view(N // 7, S, Co)
+    a2 = None if y2 is None else y2.view(N // 7, S, 64)
+    ref, m0, r0 = ops.groupnorm_fwd(a, gamma, beta, 32, "silu", x2=a2)
+    assert ops.lib.v2a_groupnorm_takes_slabs(S, Ct, 32) == 0            # the large (three-launch) path
+    out, m1, r1 = ops.groupnorm_fwd(a, gamma, beta, 32, "silu", x2=a2, stats=st, stats2=st2)
+    assert torch.allclose(m1, m0, rtol=0, atol=2e-6) and torch.allclose(r1, r0, rtol=2e-6, atol=0)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    out_b, m2, r2 = ops.groupnorm_fwd(a, gamma, beta, 32, "silu", x2=a2, stats=st, stats2=st2)
+    assert torch.equal(out, out_b) and torch.equal(m1, m2) and torch.equal(r1, r2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,HW,C,Co", [(16, 1024, 128, 128), (4, 4096, 192, 256), (30, 512, 64, 128), (18, 256, 320, 384)])
 def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co):
     """The frame-stack temporal kernel (csrc/igemm_h3.hip conv_frames_h3: all 7 frames of 64 pixels per workgroup, operand fragments

@@ -486,6 +486,12 @@ int v2a_conv2d_h_can_emit_stats(int M, int Cout, int K) {
     conv_plan_h(M, Cout, K, 64, &bm, &bn, &tiles, &s);
     return (s == 1 && bm == 128 && Cout % 8 == 0) ? 1 : 0;
 }
+// the same question for v2a_conv2d_fwd_dma_f32 (k tile = 32 floats)
+int v2a_conv2d_dma_f32_can_emit_stats(int M, int Cout, int K) {
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);
+    return (s == 1 && bm == 128 && Cout % 8 == 0) ? 1 : 0;
+}
 size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K) {
     int bm, bn, tiles, s;
     conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);

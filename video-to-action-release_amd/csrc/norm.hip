@@ -28,6 +28,8 @@ struct GnDesc {
     float* rstd;            // [N][G]
     float* colsum;          // [N][2][C] (stats: sum x, sum x^2; backward: sum dz, sum dz*xhat)
     double* partial;        // [N][nchunk][2][C]
+    const float* st1;       // forward large path: per-64-row (sum, sum of squares) blocks of x from the producing conv's epilogue
+    const float* st2;       // ... and of x2 ([N * S/64][2][C1] / [N * S/64][2][C - C1]); replaces the gn_colreduce pass over the tensor
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
     unsigned short* yh;     // optional bf16 twin of the output (forward: y, backward: dx), same shape: feeds the bf16-MFMA convs
     float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
@@ -135,6 +137,34 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
 
 // one block per (n, group): sums the chunk partials of the group's channels in fp64.
 // MODE 0 -> mean / rstd.  MODE 1 -> colsum[n][2][C] (fp32) for the group's channels.
+// The statistics pass without reading the tensor: the fp32 conv epilogue (csrc/igemm_h.hip, conv_igemm_h<.., float, ..>) left
+// the sums of every 64-row block; this kernel adds a chunk's blocks in double, in block order, into the same [N][nchunk][2][C] partials
+// gn_colreduce<0> writes (rows_per_chunk counts 64-row blocks here).  Thread = one column of the virtual [2][C] slab.
+__global__ __launch_bounds__(256) void gn_reduce_blocks_f32(const GnDesc p) {
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int nb = p.S >> 6;
+    const int b0 = chunk * p.rows_per_chunk, b1 = min(nb, b0 + p.rows_per_chunk);
+    const int C = p.C, C1 = p.st2 ? p.C1 : C, C2 = C - C1;
+    double* dst = p.partial + ((size_t)n * p.nchunk + chunk) * 2 * C;
+    for (int col = threadIdx.x; col < 2 * C; col += 256) {
+        const int half = col >= C, c = half ? col - C : col;
+        const bool first = c < C1;
+        const float* src = first ? p.st1 + (size_t)half * C1 + c : p.st2 + (size_t)half * C2 + (c - C1);
+        const size_t stride = first ? 2 * (size_t)C1 : 2 * (size_t)C2;
+        const float* q = src + ((size_t)n * nb + b0) * stride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = b0;
+        for (; b + 3 < b1; b += 4, q += 4 * stride) {
+            a0 += (double)q[0];
+            a1 += (double)q[stride];
+            a2 += (double)q[2 * stride];
+            a3 += (double)q[3 * stride];
+        }
+        for (; b < b1; ++b, q += stride) a0 += (double)q[0];
+        dst[col] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
     __shared__ double red[2][4];
@@ -770,11 +800,32 @@ int v2a_groupnorm_takes_slabs(int S, int C, int G) {
 }
 // same as v2a_groupnorm_fwd_t; with nslab > 0 the normalised tensor is sum_s slabs[s][.] + cbias[c] (the split-K partial sums and bias
 // of the conv that produces it: its reduce launch is folded into this one) and `x` receives that sum (kept for the backward).
+static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                       const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                       int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
+                       const float* stats2, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                         int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* unused_resid,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     (void)unused_resid;
+    return gn_fwd_impl(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, mean, rstd, N, S, C, G, eps, act, slabs, nslab, slab_stride,
+                       cbias, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+// v2a_groupnorm_fwd with the statistics pass replaced by the producing convs' epilogue sums: stats1 [N * S/64][2][C1] (x) and, for a
+// virtual concat, stats2 [N * S/64][2][C - C1] (x2), as v2a_conv2d_fwd_dma_f32(..., stats, ...) writes them.  Needs S % 64 == 0 and the
+// large path (S * C/G above the one-workgroup limit); otherwise the arguments are ignored and the statistics are computed from x.
+int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         int N, int S, int C, int G, float eps, int act, const float* stats1, const float* stats2, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+    return gn_fwd_impl(x, x2, C1, gamma, beta, nullptr, nullptr, 0, y, nullptr, mean, rstd, N, S, C, G, eps, act, nullptr, 0, 0, nullptr,
+                       stats1, stats2, workspace, workspace_bytes, stream);
+}
+}  // extern "C"
+static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
+                       const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
+                       int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
+                       const float* stats2, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
     if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
@@ -816,7 +867,17 @@ int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* ga
     gn_chunks(N, S, C, &p.nchunk, &p.rows_per_chunk);
     if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.partial = (double*)workspace;
-    hipLaunchKernelGGL(gn_colreduce<0>, dim3(p.nchunk, N), dim3(256), gn_colreduce_lds(C), stream, p);
+    if (stats1 && S % 64 == 0 && (!x2 || stats2)) {
+        const int nb = S >> 6;
+        int nch = nb < 64 ? nb : 64;                 // the workspace was sized for gn_chunks' count, which is never below this
+        if (nch > p.nchunk) nch = p.nchunk;
+        p.nchunk = nch;
+        p.rows_per_chunk = (nb + nch - 1) / nch;     // 64-row blocks per chunk
+        p.st1 = stats1; p.st2 = x2 ? stats2 : nullptr;
+        hipLaunchKernelGGL(gn_reduce_blocks_f32, dim3(p.nchunk, N), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(gn_colreduce<0>, dim3(p.nchunk, N), dim3(256), gn_colreduce_lds(C), stream, p);
+    }
     V2A_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize<0>, dim3(N * G), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
@@ -827,6 +888,7 @@ int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* ga
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
+extern "C" {
 
 // Backward of v2a_groupnorm_fwd.  dx [N,S,C]; dres (optional) = gradient of the residual input;
 // dfilm (optional) [N][2][C]; colsum [N][2][C] output (per-sample sums of dz and dz*xhat); dgamma/dbeta [C]: overwritten (added to

@@ -111,6 +111,8 @@ SIGNATURES = {
     "v2a_conv2d_h_splits": (I, [I, I, I]),
     "v2a_conv2d_fwd_h_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_h2_eligible": (I, [I, I, I, I, I]),
+    "v2a_conv2d_dma_f32_can_emit_stats": (I, [I, I, I]),
+    "v2a_groupnorm_fwd_st": (I, [P, P, I, P, P, P, P, P, I, I, I, I, F, I, P, P, P, SZ, P]),
     "v2a_conv2d_h3_eligible": (I, [I] * 13),
     "v2a_conv2d_t3_eligible": (I, [I] * 13),
     "v2a_conv2d_fwd_t3": (I, [P] * 7 + [I] * 6 + [P, P]),

@@ -154,9 +154,11 @@ def gn_takes_slabs(S, C, G):
 _DEFER = os.environ.get('V2A_DEFER_REDUCE', '1') != '0'
 
 
-def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y, defer=False):
+def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y, defer=False,
+                    want_stats=False):
     """fp32 conv on the LDS-DMA kernel (exact-f32 MFMA): same results as the register-staged kernel up to summation order.
-    defer: returns (y, Slabs | None) -- with Slabs the split-K reduce is left to the consuming GroupNorm launch."""
+    defer: returns (y, Slabs | None) -- with Slabs the split-K reduce is left to the consuming GroupNorm launch.
+    want_stats: returns (y, stats | None) -- per-64-row (sum, sum of squares) blocks of y for groupnorm_fwd(stats=...)."""
     N, H, W, C1 = x.shape
     C2 = x2.shape[-1] if x2 is not None else 0
     sh, sw = stride
@@ -181,14 +183,20 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
                                            _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0,
                                            idil, OH, OW, rows_per_batch, ctypes.byref(ns), _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32_d")
         return y, (Slabs(ws, ns.value, M * Cout, bias, residual) if ns.value > 0 else None)
+    stats = None
+    if want_stats and _FUSED_STATS and lib.v2a_conv2d_dma_f32_can_emit_stats(M, Cout, K):
+        stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device)
     check(lib.v2a_conv2d_fwd_dma_f32(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), _p(rowvec), _p(residual), y.data_ptr(),
                                      _zero_line(x.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, idil,
-                                     OH, OW, rows_per_batch, None, _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32")
+                                     OH, OW, rows_per_batch, _p(stats), _p(ws), wsb, _stream()), "conv2d_fwd_dma_f32")
+    if want_stats:
+        return y, stats
     return (y, None) if defer else y
 
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
-           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None, defer=False):
+           residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None, defer=False,
+           want_stats=False):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]; with defer=True
     (y, Slabs | None): when Slabs is returned, y is NOT written yet -- hand both to the GroupNorm that consumes the conv.
     bf16-MFMA mode: `x_h` = an existing bf16 twin of x (skips the cast launch); `keep_h` (a list) receives the twin that was used, so a
@@ -202,7 +210,11 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     if (bmode == 0 and y2 is None and not csplit and C1 % 32 == 0 and C2 % 32 == 0 and idil in (1, 2) and not (ups and idil > 1)
             and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] and lib.v2a_get_precision() == 0):
         return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y,
-                               defer=defer)
+                               defer=defer, want_stats=want_stats)
+    if want_stats:     # only the LDS-DMA fp32 kernel emits statistics
+        assert not defer
+        return conv2d(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
+                      idil=idil, ups=ups, out_hw=out_hw, y=y, y2=y2, csplit=csplit, bmode=bmode, x_h=x_h, keep_h=keep_h), None
     if (_h_twin and bmode == 0 and y2 is None and not csplit and C1 % 64 == 0 and C2 % 64 == 0 and idil in (1, 2)
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)
@@ -505,7 +517,8 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ group norm
-def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None):
+def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None,
+                  stats=None, stats2=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
     Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
     that consumes y takes it as x_h and skips its cast launch)."""
@@ -529,6 +542,12 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
         check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), None, C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
                                       _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], slabs.ws.data_ptr(), slabs.n,
                                       slabs.stride, _p(slabs.bias), None, None, 0, _stream()), "groupnorm_fwd_s")
+        return y, mean, rstd
+    if (stats is not None and (x2 is None or stats2 is not None) and S % 64 == 0 and residual is None and film is None and yh is None):
+        # statistics from the producing convs' epilogues (conv2d(want_stats=True)): the tensor is read once, by the apply pass
+        check(lib.v2a_groupnorm_fwd_st(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), N, S, C, G, eps, ACT[act], stats.data_ptr(), _p(stats2), _p(ws), wsb, _stream()),
+              "groupnorm_fwd_st")
         return y, mean, rstd
     check(lib.v2a_groupnorm_fwd_t(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
                                   _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], _p(ws), wsb, _stream()),

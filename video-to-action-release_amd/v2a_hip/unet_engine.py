@@ -170,14 +170,21 @@ class UNetEngine:
         has_t = self.has(name + ".temporal_conv.weight")
         x4 = x.view(B * Fr, H, W, C)
         x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
+        # the LAST kernel of the Conv3d also leaves the per-64-row sums GroupNorm needs (fp32 LDS-DMA kernel epilogue)
         y = ops.conv2d(x4, wsp, self.p(name + ".spatial_conv.bias"), cout, k, k, (stride, stride), (k // 2, k // 2), x2=x24, ups=ups,
                        rowvec=None if has_t else rowvec, rows_per_batch=1,
-                       residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout))
+                       residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout),
+                       want_stats=not has_t)
+        stats = None
+        if not has_t:
+            y, stats = y
         OH, OW = y.shape[1], y.shape[2]
         if not has_t:
             if rowvec is not None:
                 raise NotImplementedError("rowvec on a conv without temporal part")
-            return y.view(B, Fr, OH, OW, cout)
+            out = y.view(B, Fr, OH, OW, cout)
+            out._gn_stats = stats
+            return out
         if self.storage == "bf16" and cout % 64 == 0:      # stem: fp32 spatial conv (Cin = 6), the 128-wide temporal conv on the bf16 kernel
             z, stats = ops.conv2d_h(ops.cast_h(y).view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
                                     self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
@@ -187,10 +194,12 @@ class UNetEngine:
             out._gn_stats = stats
             return out
         wt = self.w(name + ".temporal_conv.weight")
-        z = ops.conv2d(y.view(B, Fr, OH * OW, cout), wt, self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0),
-                       rowvec=rowvec, rows_per_batch=Fr * OH * OW,
-                       residual=None if residual is None else residual.view(B, Fr, OH * OW, cout))
-        return z.view(B, Fr, OH, OW, cout)
+        z, stats = ops.conv2d(y.view(B, Fr, OH * OW, cout), wt, self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0),
+                              rowvec=rowvec, rows_per_batch=Fr * OH * OW,
+                              residual=None if residual is None else residual.view(B, Fr, OH * OW, cout), want_stats=True)
+        out = z.view(B, Fr, OH, OW, cout)
+        out._gn_stats = stats
+        return out
 
     def gn_silu(self, x, name, act="silu", x2=None, frames_separate=False):
         """GroupNorm32 over (C/32 x F x H x W) per sample (or per frame when frames_separate), fused activation."""
@@ -208,7 +217,8 @@ class UNetEngine:
             ops.copy2d(x3, cat, N * S, C1, C1, C)
             ops.copy2d(x23, cat, N * S, C - C1, C - C1, C, dst_off=C1)
             x3, x23 = cat, None
-        y, _, _ = ops.groupnorm_fwd(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23)
+        y, _, _ = ops.groupnorm_fwd(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
+                                    stats=getattr(x, "_gn_stats", None), stats2=None if x2 is None else getattr(x2, "_gn_stats", None))
         return y.view(B, Fr, H, W, C)
 
     def resblock(self, x, name, cin, cout, semb, x2=None):
