@@ -30,6 +30,7 @@ for leg in policy video video_bf16; do
 done
 # keep only summaries small enough to travel back (<= 64 MiB total)
 python $R/tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
+python -c "import json,sys; j=json.load(open('$OUT/pmc_summary.json')); json.dump(j['roofline_traffic'], open('$OUT/roofline_traffic.json','w'), indent=1)"
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
 ls -la $OUT $OUT/* | head -60

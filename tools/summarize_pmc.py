@@ -10,8 +10,24 @@ from collections import defaultdict
 
 root = sys.argv[1]
 out = {}
+leg_totals = {}
+
+
+def _units(leg):
+    """Steps (policy) / UNet forwards (sampler) the PMC command of this leg ran, from the JSON line in its log."""
+    for ctr in ("fetch", "write"):
+        try:
+            lines = [l for l in open(os.path.join(root, f"pmc_{ctr}_{leg}.log")) if l.startswith('{"metric')]
+            j = json.loads(lines[-1])
+            return j["unet_forwards"] if "unet_forwards" in j else j["steps"] + j["warmup"]
+        except Exception:
+            continue
+    return None
+
+
 for leg in ("policy", "video", "video_bf16"):
     res = defaultdict(lambda: {"n": 0})
+    tot = {"fetch": 0.0, "write": 0.0}
     for ctr in ("fetch", "write"):
         files = glob.glob(os.path.join(root, f"pmc_{ctr}_{leg}", "**", "*counter_collection.csv"), recursive=True)
         acc = defaultdict(lambda: [0.0, 0])
@@ -23,6 +39,7 @@ for leg in ("policy", "video", "video_bf16"):
                 a = acc[short]
                 a[0] += val
                 a[1] += 1
+                tot[ctr] += val
         for k, (s, n) in acc.items():
             res[k][f"{ctr}_kib_avg"] = s / max(n, 1)
             res[k]["n"] = max(res[k]["n"], n)
@@ -31,6 +48,10 @@ for leg in ("policy", "video", "video_bf16"):
         v["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
         v["hbm_bytes_per_launch_raw"] = (f + w) * 1024.0
     out[leg] = dict(sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0) * kv[1]["n"])[:40])
+    u = _units(leg)
+    if u:       # whole-leg HBM bytes per step / per UNet forward: every kernel of the run, same correction
+        leg_totals[leg] = {"units_in_run": u, "hbm_bytes_per_unit": (2.0 * tot["fetch"] + tot["write"]) * 1024.0 / u,
+                           "fetch_bytes_per_unit": 2.0 * tot["fetch"] * 1024.0 / u, "write_bytes_per_unit": tot["write"] * 1024.0 / u}
 # bench.py reads profiles/roofline_traffic.json: {"policy"|"video": {"<kernel><BM,BN>": corrected HBM bytes per launch}}
 import re
 rt = {}
@@ -39,12 +60,21 @@ for leg_name in ("policy", "video", "video_bf16"):
     for k, v in out[leg_name].items():
         m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
         mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)(?:, \d+)?>", k)
-        if m or mh:
-            key = (f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else
-                   f"conv_igemm_h<{mh.group(1)},{mh.group(2)},{'float' if mh.group(3) == 'float' else 'bf16'}>")
+        m3 = re.match(r"(conv_halo_h3|conv_igemm_h2)<(\d+), (\d+), (\d+), (\d+), \d+>", k)      # <WAVES_M, WAVES_N, TM, TN, SB> -> BM x BN
+        mf = re.match(r"conv_frames_h3<(\d+)>", k)
+        if m or mh or m3 or mf:
+            if m3:
+                wm_, wn_, tm_, tn_ = (int(m3.group(i)) for i in (2, 3, 4, 5))
+                key = f"{m3.group(1)}<{wm_ * tm_ * 32}x{wn_ * tn_ * 32}>"
+            elif mf:
+                key = f"conv_frames_h3<{int(mf.group(1)) * 64}x128>"
+            else:
+                key = (f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else
+                       f"conv_igemm_h<{mh.group(1)},{mh.group(2)},{'float' if mh.group(3) == 'float' else 'bf16'}>")
             a = traffic.setdefault(key, [0.0, 0])     # template variants sharing a tile: launch-count weighted mean
             a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
             a[1] += v["n"]
     rt[leg_name] = {k: a[0] / max(a[1], 1) for k, a in traffic.items()}
+rt["legs"] = leg_totals
 out["roofline_traffic"] = rt
 print(json.dumps(out, indent=1))
