@@ -39,6 +39,31 @@ def test_tiny_unet_forward_vs_golden_and_oracle(golden_dir):
     assert rel(y, yo) <= TOL
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_unet_forward_is_bitwise_reproducible(golden_dir, storage):
+    """no float atomics anywhere on the path -- two forwards of the same inputs through the HIP UNet give bitwise
+    equal outputs (split-K slabs, GroupNorm column sums and the conv-epilogue statistics are all added in a fixed order), in the
+    fp32 parity configuration and in the bf16-storage configuration; a full-size Unet_Libero forward at B = 2 as well."""
+    import v2a_hip
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    g = np.load(f"{golden_dir}/unet_tiny.npz", allow_pickle=True)
+    m, _, _ = _tiny()
+    x, t, te = torch.from_numpy(g["fwd_x"]).cuda(), torch.from_numpy(g["fwd_t"]).cuda(), torch.from_numpy(g["fwd_te"]).cuda()
+    v2a_hip.set_video_storage(storage)
+    try:
+        y0 = m(x, t, te).clone()
+        y1 = m(x, t, te)
+        assert torch.equal(y0, y1)
+        torch.manual_seed(3)
+        big = Unet_Libero().to("cuda:0").eval()
+        xb, tb, teb = torch.randn(2, 24, 128, 128, device="cuda:0"), torch.tensor([10, 80], device="cuda:0"), torch.randn(2, 10, 512, device="cuda:0")
+        z0 = big(xb, tb, task_embed=teb).clone()
+        z1 = big(xb, tb, task_embed=teb)
+        assert torch.isfinite(z0).all() and torch.equal(z0, z1)
+    finally:
+        v2a_hip.set_video_storage("f32")
+
+
 def _tiny_fp64_sample(sd, x_cond, te, steps, gw, seed=1234):
     """The same sampling loop in fp64 (CPU oracle with its fp32 casts lifted): the yard-stick for 'how exact is the reference's own
     fp32 run' -- a tolerance above 1e-4 is only accepted up to a small multiple of that deviation."""

@@ -18,10 +18,7 @@ __device__ __forceinline__ f32x4 ld4(const uint16_t* p) {
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void st4(uint16_t* p, f32x4 v) {
-    uint32_t u[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { u[i] = __float_as_uint(v[i]); u[i] += 0x7fffu + ((u[i] >> 16) & 1u); }
-    uint2 o = {(u[0] >> 16) | (u[1] & 0xffff0000u), (u[2] >> 16) | (u[3] & 0xffff0000u)};
+    uint2 o = {v2a_pack_bf16x2(v[0], v[1]), v2a_pack_bf16x2(v[2], v[3])};
     *reinterpret_cast<uint2*>(p) = o;
 }
 
@@ -224,10 +221,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_a;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_a;
 
 __device__ __forceinline__ uint32_t pack_bf16_2(float a, float b) {
-    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7fffu + ((ua >> 16) & 1u);
-    ub += 0x7fffu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xffff0000u);
+    return v2a_pack_bf16x2(a, b);
 }
 
 __global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L, int heads) {

@@ -22,6 +22,20 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // activation ids shared by norm/elementwise kernels and the C ABI
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_MISH = 3, ACT_GELU = 4 };
 
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, one instruction where the integer
+// add-and-shift idiom takes four); finite values round identically, NaNs stay NaNs.
+__device__ __forceinline__ unsigned short v2a_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+typedef __attribute__((ext_vector_type(2))) float v2a_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 v2a_bf16x2;
+__device__ __forceinline__ unsigned int v2a_pack_bf16x2(float lo, float hi) {
+    v2a_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, v2a_bf16x2));
+}
+// SiLU for outputs that are rounded to bf16 anyway: exp2 + reciprocal approximations (~2 ulp of fp32) instead of expf + IEEE division
+__device__ __forceinline__ float v2a_silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
+
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
         case ACT_SILU: return x / (1.0f + expf(-x));

@@ -312,10 +312,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvDesc p) {
 // LDS rows hold 32 bf16 (+8 pad) = 80 B: b64 stores of 4 converted values, b128 operand reads (8 consecutive k per lane).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7fffu + ((ua >> 16) & 1u);
-    ub += 0x7fffu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xffff0000u);
+    return v2a_pack_bf16x2(a, b);
 }
 
 template <int BM, int BN>
@@ -1595,9 +1592,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 // A non-zero 7th column also writes the bf16 twin of the operand (the LDS-DMA kernels' weight operand).
 #define PACK_CHUNK 16384
 __device__ __forceinline__ uint16_t f2bf_pack(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return v2a_f2bf(f);
 }
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* table, const int* chunks) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];

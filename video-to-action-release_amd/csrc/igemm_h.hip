@@ -73,9 +73,7 @@ __device__ __forceinline__ int xcd_remap_h(int bid, int nblk) {
 }
 
 __device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return v2a_f2bf(f);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 

@@ -62,9 +62,7 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
     return base + slot;
 }
 __device__ __forceinline__ uint16_t f2bf2(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return v2a_f2bf(f);
 }
 __device__ __forceinline__ float bf2f2(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 

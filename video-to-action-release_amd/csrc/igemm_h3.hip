@@ -45,9 +45,7 @@ __device__ __forceinline__ int xcd_remap3(int bid, int nblk) {
     return base + slot;
 }
 __device__ __forceinline__ uint16_t f2bf3(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return v2a_f2bf(f);
 }
 __device__ __forceinline__ float bf2f3(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
@@ -304,270 +302,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Persistent form of conv_halo_h3 (same tiles, same step body): one workgroup per CU walks tiles lin, lin + G, ... as ONE step stream.
-// The weight ring and the halo double buffer keep running across tile boundaries -- during a tile's last chunk the halo pieces and
-// the first SB-1 weight tiles of the NEXT tile are issued, so they land while this tile's epilogue runs -- and the epilogue gets LDS
-// of its own (8 waves x 32 rows x 32 fp32, one 32 x 32 sub-tile at a time) instead of re-using the pipeline buffers behind a drain.
-// At C = 128 a tile is only 36 steps long: the one-tile-per-workgroup launch spends more than half of a tile's time filling the
-// pipeline and writing the tile out with nothing in flight (38 us per tile against 17 us of MFMA work).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int SB>
-__global__ __launch_bounds__(512, 1) void conv_halo_h3p(const ConvDescH3 p) {
-    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    static_assert((BM == 256 || BM == 512) && WAVES_M * WAVES_N == 8, "tile shape");
-    constexpr int PH = BM / 16;
-    constexpr int ROWB = 64;
-    constexpr int HW_ = 18, HROWS = HW_ * (PH + 2);
-    constexpr int HPIECES = (HROWS * 4 + 511) / 512;
-    constexpr int HBUF = HPIECES * 512 * 16;
-    constexpr int BL = BN / 128;
-    constexpr int BSTAGE = BN * ROWB;
-    constexpr int LDC = 32, V = 4;
-    constexpr int CW_OFF = 2 * HBUF + SB * BSTAGE;
-    constexpr int SMEM = CW_OFF + 8 * 32 * LDC * 4;
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static_assert((SB - 2) * BL + HPIECES <= 63, "vmcnt is a 6-bit counter");
-    static_assert(9 - (SB - 1) > halo_tap(HPIECES - 1, HPIECES), "the last halo piece must precede the next chunk's first weight tile");
-    __shared__ __attribute__((aligned(128))) unsigned char smem[SMEM];
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tiles_n = p.Cout / BN;
-    const int total = p.N * p.tiles_img * tiles_n;
-    const int G = gridDim.x;
-    int lin = xcd_remap3(blockIdx.x, G);
-    if (lin >= total) return;
-    const int nchunks = p.C >> 5;
-    const uint16_t* zsrc = p.zeros;
-    const int sh_ = p.ups ? (p.H >> 1) : p.H, sw_ = p.ups ? (p.W >> 1) : p.W;
-
-    struct Tile { int tm, n0, img, oy0, ox0; };
-    auto tile_of = [&](int l) {
-        Tile t;
-        t.tm = l / tiles_n;
-        t.n0 = (l - t.tm * tiles_n) * BN;
-        t.img = t.tm / p.tiles_img;
-        const int trem = t.tm - t.img * p.tiles_img;
-        const int ty = trem / p.tiles_x;
-        t.oy0 = ty * PH;
-        t.ox0 = (trem - ty * p.tiles_x) * 16;
-        return t;
-    };
-    // halo source offsets of a tile (elements from p.x, 0xffffffff = the zero line) and the weight-tile row offset
-    auto halo_offsets = [&](const Tile& t, uint32_t (&h)[HPIECES]) {
-#pragma unroll
-        for (int j = 0; j < HPIECES; ++j) {
-            const int q = j * 512 + tid;
-            const int hr = q >> 2;
-            const int hy = hr / HW_, hx = hr - hy * HW_;
-            const int ih = t.oy0 - 1 + hy, iw = t.ox0 - 1 + hx;
-            const int chunk = (q & 3) ^ ((hr >> 2) & 3);
-            const bool ok = hr < HROWS && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const int ihs = p.ups ? (ih >> 1) : ih, iws = p.ups ? (iw >> 1) : iw;
-            h[j] = ok ? ((uint32_t)(t.img * sh_ + ihs) * (uint32_t)sw_ + (uint32_t)iws) * (uint32_t)p.C + (uint32_t)chunk * 8u : 0xffffffffu;
-        }
-    };
-    const uint32_t b_thr = (uint32_t)(tid >> 2) * (uint32_t)p.K + (uint32_t)(((tid & 3) ^ ((tid >> 4) & 3)) * 8);
-    const uint32_t b_step = 128u * (uint32_t)p.K;
-
-    Tile cur = tile_of(lin), nxt = cur;
-    bool more = false;
-    uint32_t h_off[HPIECES], h_nxt[HPIECES];
-    halo_offsets(cur, h_off);
-#pragma unroll
-    for (int j = 0; j < HPIECES; ++j) h_nxt[j] = 0xffffffffu;
-
-    auto issue_halo_piece = [&](int j, int c, int hb) {          // halo piece j of chunk c+1 of this tile, or of chunk 0 of the next one
-        const bool last = c + 1 >= nchunks;
-        const uint32_t off = last ? h_nxt[j] : h_off[j];
-        const bool live = off != 0xffffffffu && (!last || more);
-        const uint16_t* g = live ? p.x + off + (last ? 0 : (c + 1) * 32) : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr3_t)g, (lptr3_t)(smem + hb * HBUF + (j * 512 + wid * 64) * 16), 16, 0, 0);
-    };
-    auto issue_b = [&](int bc, int bt, int stage) {              // weight tile of (chunk bc, tap bt); bc == nchunks: the next tile's chunk 0
-        const bool over = bc >= nchunks;
-        const bool live = !over || more;
-        const uint32_t base = (uint32_t)(over ? nxt.n0 : cur.n0) * (uint32_t)p.K + (uint32_t)(bt * p.C + (over ? 0 : bc * 32));
-        unsigned char* bbase = smem + 2 * HBUF + stage * BSTAGE;
-#pragma unroll
-        for (int j = 0; j < BL; ++j) {
-            const uint16_t* g = live ? p.w + base + b_thr + j * b_step : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr3_t)g, (lptr3_t)(bbase + (j * 512 + wid * 64) * 16), 16, 0, 0);
-        }
-    };
-
-    const int wm = (wid / WAVES_N) * TM * 32, wn = (wid % WAVES_N) * TN * 32;
-    const int lr = lane & 31, lk = lane >> 5;
-    int a_hr[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm + i * 32 + lr;
-        a_hr[i] = (r >> 4) * HW_ + (r & 15);
-    }
-    const int brswz = (lr >> 2) & 3;
-    int b_off[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_off[j] = (wn + j * 32 + lr) * ROWB;
-    float* cw = reinterpret_cast<float*>(smem + CW_OFF) + wid * 32 * LDC;
-    const int vrow = lane / V, vcol = (lane % V) * 8;
-
-    // ---- prologue of the stream: halo of the first tile's chunk 0, then SB-1 weight tiles
-#pragma unroll
-    for (int j = 0; j < HPIECES; ++j) {
-        const uint16_t* g = h_off[j] != 0xffffffffu ? p.x + h_off[j] : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr3_t)g, (lptr3_t)(smem + (j * 512 + wid * 64) * 16), 16, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < SB - 1; ++s) issue_b(s / 9, s % 9, s);
-    int cstage = 0, istage = SB - 1, hb = 0;
-
-    f32x16 acc[TM][TN];
-    auto mma_step = [&](const unsigned char* hbase, const unsigned char* bbase, int shift) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8_3 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int hr = a_hr[i] + shift;
-                a[i] = *reinterpret_cast<const bf16x8_3*>(hbase + hr * ROWB + ((((h << 1) | lk) ^ ((hr >> 2) & 3)) << 4));
-            }
-            const int bpos = (((h << 1) | lk) ^ brswz) << 4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_3*>(bbase + b_off[j] + bpos);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    // the first chunk of a tile follows an epilogue whose stores share the counter with the DMAs (and do not retire in one order with
-    // them): tap 0 drains it; the later taps of that chunk use the count without the previous chunk's halo pieces (already landed)
-#define V2A_H3P_TAP(T)                                                                                                 \
-    {                                                                                                                  \
-        if (c == 0) { if (T == 0) wait_vmcnt3<0>(); else wait_vmcnt3<(SB - 2) * BL>(); }                               \
-        else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB, HPIECES>::value>();                                          \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        issue_b(c + (T + SB - 1) / 9, (T + SB - 1) % 9, istage);                                                       \
-        if (halo_piece_at(T, HPIECES) >= 0) issue_halo_piece(halo_piece_at(T, HPIECES), c, hb ^ 1);                    \
-        mma_step(smem + hb * HBUF, smem + 2 * HBUF + cstage * BSTAGE, (T / 3) * HW_ + (T % 3));                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-        cstage = (cstage + 1 == SB) ? 0 : cstage + 1;                                                                  \
-        istage = (istage + 1 == SB) ? 0 : istage + 1;                                                                  \
-    }
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
-            if (c == nchunks - 1) {                                  // the next tile's sources, needed from this chunk's first halo piece on
-                more = lin + G < total;
-                if (more) {
-                    nxt = tile_of(lin + G);
-                    halo_offsets(nxt, h_nxt);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(a_hr[i]));
-            V2A_H3P_TAP(0) V2A_H3P_TAP(1) V2A_H3P_TAP(2) V2A_H3P_TAP(3) V2A_H3P_TAP(4) V2A_H3P_TAP(5) V2A_H3P_TAP(6) V2A_H3P_TAP(7) V2A_H3P_TAP(8)
-            hb ^= 1;
-        }
-
-        // ---- epilogue of tile `cur`: one 32 x 32 sub-tile at a time through the wave's private staging rows
-        const size_t img_row0 = (size_t)cur.img * p.H * p.W;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = cur.n0 + wn + j * 32 + vcol;
-            float bv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
-            float s_blk = 0.f, q_blk = 0.f;                          // column (lane & 31) of the current 64-row statistics block
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    cw[row * LDC + (lr ^ ((row & 1) << 2))] = acc[i][j][r];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int rr = 0; rr < 32; rr += 64 / V) {
-                    const int ml = rr + vrow;
-                    const int pr = wm + i * 32 + ml;                              // row inside the patch
-                    const size_t m = img_row0 + (size_t)(cur.oy0 + (pr >> 4)) * p.W + cur.ox0 + (pr & 15);
-                    const int sx = (ml & 1) << 2;
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
-                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
-                    float v[8] = {c0[0] + bv[0], c0[1] + bv[1], c0[2] + bv[2], c0[3] + bv[3], c1[0] + bv[4], c1[1] + bv[5], c1[2] + bv[6], c1[3] + bv[7]};
-                    const size_t o = m * p.Cout + n;
-                    if (p.rowvec) {
-                        const float* rv = p.rowvec + (size_t)((uint32_t)m / (uint32_t)p.rows_per_batch) * p.Cout + n;
-                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
-                    }
-                    if (p.residual) {
-                        const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
-                        v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                        v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                        v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                        v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
-                    }
-                    uint16_t hh[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hh[e] = f2bf3(v[e]);
-                    if (p.stats) {                                    // the stored values go back into the staging rows for the column pass
-                        const f32x4 w0 = {bf2f3(hh[0]), bf2f3(hh[1]), bf2f3(hh[2]), bf2f3(hh[3])}, w1 = {bf2f3(hh[4]), bf2f3(hh[5]), bf2f3(hh[6]), bf2f3(hh[7])};
-                        *reinterpret_cast<f32x4*>(&cw[ml * LDC + (vcol ^ sx)]) = w0;
-                        *reinterpret_cast<f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]) = w1;
-                    }
-                    uint4 u;
-                    u.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16);
-                    u.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
-                    u.z = (uint32_t)hh[4] | ((uint32_t)hh[5] << 16);
-                    u.w = (uint32_t)hh[6] | ((uint32_t)hh[7] << 16);
-                    *reinterpret_cast<uint4*>(p.y + o) = u;
-                }
-                if (p.stats) {
-                    // column pass (see conv_frames_h3): lane = (column lane & 31, rows (lane >> 5) * 16 .. +15); two sub-tiles = one
-                    // 64-row block of this wave.  Blocks are numbered (tile, 64-row group of the patch): another order than NHWC
-                    // rows / 64, but every block lies inside ONE frame, which is all the GroupNorm reduction over a sample needs
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const int col = lane & 31, r0 = (lane >> 5) * 16;
-#pragma unroll
-                    for (int rr = 0; rr < 16; ++rr) {
-                        const int row = r0 + rr;
-                        const float x = cw[row * LDC + (col ^ ((row & 1) << 2))];
-                        s_blk += x;
-                        q_blk += x * x;
-                    }
-                    if ((i & 1) == 1) {
-                        s_blk += __shfl_xor(s_blk, 32, 64);
-                        q_blk += __shfl_xor(q_blk, 32, 64);
-                        if (lane < 32) {
-                            const size_t blk = (size_t)cur.tm * (BM / 64) + ((wm + (i - 1) * 32) >> 6);
-                            float* dst = p.stats + blk * 2 * p.Cout + cur.n0 + wn + j * 32 + col;
-                            dst[0] = s_blk;
-                            dst[p.Cout] = q_blk;
-                        }
-                        s_blk = 0.f;
-                        q_blk = 0.f;
-                    }
-                }
-            }
-        }
-        if (!more) break;
-        lin += G;
-        cur = nxt;
-#pragma unroll
-        for (int j = 0; j < HPIECES; ++j) h_off[j] = h_nxt[j];
-    }
-#undef V2A_H3P_TAP
-}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Temporal (3 x 1 x 1) convolution of the factorised Conv3d (unet.py: temporal_conv over [B, F, H*W, C]) -- the frame-stack tile.
@@ -852,32 +586,17 @@ int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, co
     p.ups = ups ? 1 : 0;
     p.tiles_x = W / 16;
     p.tiles_img = (H / 16) * (W / 16);
-    static int persist = -1, ncu = 0;
-    if (persist < 0) {
-        const char* e = getenv("V2A_CONV_H3_PERSIST");
-        persist = (e && e[0] == '0') ? 0 : 1;
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (ncu <= 0) ncu = 256;
-    }
-#define V2A_H3_LAUNCH(...)                                                                                                       \
-    do {                                                                                                                         \
-        if (persist) hipLaunchKernelGGL((conv_halo_h3p<__VA_ARGS__>), dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, stream, p); \
-        else hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__>), dim3(tiles), dim3(512), 0, stream, p);                              \
-    } while (0)
     if (Cout % 256 == 0) {
         const int tiles = N * p.tiles_img * (Cout / 256);
-        V2A_H3_LAUNCH(2, 4, 4, 2, 4);                                                                  // 256 x 256, ring of 4 x 16 KB
+        hipLaunchKernelGGL((conv_halo_h3<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, ring of 4 x 16 KB
     } else if (H % 32 == 0) {
         p.tiles_img = (H / 32) * (W / 16);
         const int tiles = N * p.tiles_img * (Cout / 128);
-        V2A_H3_LAUNCH(4, 2, 4, 2, 4);                                                                  // 512 x 128, ring of 4 x 8 KB
+        hipLaunchKernelGGL((conv_halo_h3<4, 2, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 512 x 128, ring of 4 x 8 KB
     } else {
         const int tiles = N * p.tiles_img * (Cout / 128);
-        V2A_H3_LAUNCH(4, 2, 2, 2, 4);                                                                  // 256 x 128, ring of 4 x 8 KB
+        hipLaunchKernelGGL((conv_halo_h3<4, 2, 2, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, ring of 4 x 8 KB
     }
-#undef V2A_H3_LAUNCH
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

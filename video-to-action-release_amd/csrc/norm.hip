@@ -47,9 +47,7 @@ struct GnDesc {
 };
 
 __device__ __forceinline__ unsigned short gn_f2bf(float f) {      // round to nearest even, as v2a_cast_f32_bf16
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    return v2a_f2bf(f);
 }
 __device__ __forceinline__ void gn_store_twin4(unsigned short* yh, size_t i4, const f32x4& o) {
     uint2 u;

@@ -32,12 +32,9 @@ __device__ __forceinline__ void unpack8(const uint4 u, float* f) {
     f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
     f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua += 0x7fffu + ((ua >> 16) & 1u);
-    ub += 0x7fffu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xffff0000u);
-}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return v2a_pack_bf16x2(a, b); }
+// activation of the bf16-storage path: the result is rounded to 8 mantissa bits, so SiLU runs on the approximate exp2 / rcp units
+__device__ __forceinline__ float act_fwd_h(float x, int act) { return act == ACT_SILU ? v2a_silu_fast(x) : act_fwd(x, act); }
 
 __global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
     extern __shared__ __attribute__((aligned(16))) float bins[];   // [rpi][2][C]: one slot per (row lane, column), combined in lane order
@@ -191,8 +188,8 @@ __global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
             float o[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = act_fwd(f[e] * a0[e] + b0[e], p.act);
-                o[e + 4] = act_fwd(f[e + 4] * a1[e] + b1[e], p.act);
+                o[e] = act_fwd_h(f[e] * a0[e] + b0[e], p.act);
+                o[e + 4] = act_fwd_h(f[e + 4] * a1[e] + b1[e], p.act);
             }
             uint4 v = {pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
             *reinterpret_cast<uint4*>(yo + (size_t)row[k] * p.C + c[k]) = v;
