@@ -47,10 +47,9 @@ for name, N, H, W, C, Co in SHAPES:
     res = {}
     for rnd in range(2):
         for tag in ("h3", "old"):
+            os.environ.pop("V2A_CONV_H3_OFF_FOR_TEST", None)
             if tag == "old":
                 os.environ["V2A_CONV_H3_OFF_FOR_TEST"] = "1"
-            else:
-                os.environ.pop("V2A_CONV_H3_OFF_FOR_TEST", None)
             t = bench(f)
             kn = ops.last_kernel[0]
             res[tag] = min(res.get(tag, (1e9, ""))[0], t), kn
