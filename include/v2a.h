@@ -277,6 +277,9 @@ int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamm
 int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int heads, int head_ch, v2a_stream_t s);
 int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, v2a_stream_t s);   /* [Cout][Cin][taps] f32 -> [Cout][taps][Cin] bf16 */
 int v2a_cast_f32_bf16(const float* x, void* y, size_t n, v2a_stream_t s);
+/* fp32 [M][Cin] -> bf16 [M][Cpad] with zero channels behind Cin: the 6-channel stem input of Unet_Libero (unet.py:195-222) padded to
+   one 32-channel chunk of the bf16 conv kernels */
+int v2a_pad_cast_f32_bf16(const float* x, void* y, size_t M, int Cin, int Cpad, v2a_stream_t s);
 int v2a_cast_bf16_f32(const void* x, float* y, size_t n, v2a_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------- optimiser (csrc/optim.hip)

@@ -186,3 +186,20 @@ def test_reference_import_path_buffer_is_a_drop_in(golden_dir):
         assert set(info) >= {"env_idxs", "cams_str"} and tasks == ["t"] * 64
     with pytest.raises(KeyError):
         Global_EnvReplayBuffer_Img(["t"], 10, 700, 30, _EnvList(), (4, 4), env_buf_config={})
+
+
+def test_capacity_eviction_before_max_episodes_warns():
+    """a frame pool smaller than max_episodes x episode length evicts by capacity, which the reference's
+    deque(maxlen) never does -- the store says so (once) and counts the evictions instead of diverging silently."""
+    import warnings
+    import torch
+    from v2a_hip.replay import ReplayStore
+    st = ReplayStore(max_episodes=10, max_len=40, min_len=5, image_hw=(8, 8), capacity_frames=50, device="cpu")
+    imgs = torch.zeros(21, 8, 8, 3, dtype=torch.uint8)
+    acts = torch.zeros(20, 7)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for i in range(4):
+            st.add_one_episode("t", "cam", i, imgs, acts)
+    assert len(st) == 2 and st.capacity_evictions == 2
+    assert sum(issubclass(x.category, RuntimeWarning) and "evicting the oldest by capacity" in str(x.message) for x in w) == 1

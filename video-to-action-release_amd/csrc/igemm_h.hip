@@ -431,6 +431,25 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __re
         reinterpret_cast<uint2*>(y)[i] = o;
     }
 }
+// [M][Cin] fp32 -> [M][Cpad] bf16, channels Cin .. Cpad-1 zero: the 6-channel input of the sampler's stem padded to one 32-channel
+// chunk so that the stem conv runs on the halo kernel.  Thread = one 8-channel (16-B) piece of a row.
+__global__ void pad_cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t M, int Cin, int Cpad) {
+    const int pieces = Cpad >> 3;
+    const size_t total = M * (size_t)pieces;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / pieces;
+        const int c0 = (int)(i - m * pieces) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < Cin) ? x[m * Cin + c0 + e] : 0.f;
+        uint4 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        reinterpret_cast<uint4*>(y)[i] = o;
+    }
+}
 __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const uint2 u = reinterpret_cast<const uint2*>(x)[i];
@@ -647,6 +666,17 @@ int v2a_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
     int g = (int)((n / 4 + 255) / 256);
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+// x fp32 [M][Cin] -> y bf16 [M][Cpad], zero-padded channels (Cpad % 8 == 0, Cin <= Cpad, y 16-B aligned)
+int v2a_pad_cast_f32_bf16(const float* x, void* y, size_t M, int Cin, int Cpad, hipStream_t stream) {
+    if (!x || !y || Cin <= 0 || Cpad % 8 || Cin > Cpad || ((uintptr_t)y & 15)) return V2A_ERR_ARG;
+    if (M == 0) return V2A_OK;
+    const size_t total = M * (size_t)(Cpad / 8);
+    int g = (int)((total + 255) / 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(pad_cast_f32_bf16_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, M, Cin, Cpad);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -120,6 +120,7 @@ SIGNATURES = {
     "v2a_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P] + [I] * 16 + [P, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),
     "v2a_cast_f32_bf16": (I, [P, P, SZ, P]),
+    "v2a_pad_cast_f32_bf16": (I, [P, P, SZ, I, I, P]),
     "v2a_cast_bf16_f32": (I, [P, P, SZ, P]),
     "v2a_opt_state_peek": (I, [P, P, P, P, P]),
     "v2a_opt_state_counters": (I, [P, P, P, P]),

@@ -409,6 +409,15 @@ def cast_h(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def pad_cast_h(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    """fp32 [..., C] -> bf16 [..., cpad] with zero channels behind C (C <= cpad, cpad % 8 == 0)."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (cpad,), dtype=torch.bfloat16, device=x.device)
+    check(lib.v2a_pad_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel() // C, C, cpad, _stream()), "pad_cast_f32_bf16")
+    return y
+
+
 def cast_f(x: torch.Tensor) -> torch.Tensor:
     """bf16 -> fp32, same shape."""
     _chk_h(x, "x")

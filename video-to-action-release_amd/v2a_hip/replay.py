@@ -114,9 +114,21 @@ class ReplayStore:
         if self._head + n > cap:
             self._head = 0
         lo, hi = self._head, self._head + n
-        # evict (FIFO) anything overlapping the region we are about to overwrite
+        # evict (FIFO) anything overlapping the region we are about to overwrite.  The reference's deque(maxlen) only drops an episode
+        # when max_episodes is reached; a frame pool sized below max_episodes * (longest episode) can run out earlier -- say so once
+        # instead of diverging silently (size the pool with capacity_frames / frames_per_episode)
+        evicted = 0
         while self.episodes and self.episodes[0][0] < hi and self.episodes[0][0] + self.episodes[0][1] > lo:
             self.episodes.popleft()
+            evicted += 1
+        if evicted:
+            self.capacity_evictions = getattr(self, "capacity_evictions", 0) + evicted
+            if len(self.episodes) + 1 < self.max_episodes and not getattr(self, "_warned_capacity", False):
+                import warnings
+                self._warned_capacity = True
+                warnings.warn(f"ReplayStore: frame pool ({cap} frames = {cap * self.frames[0].numel() * self.frames.element_size() / 2**30:.1f} GiB) "
+                              f"is full with {len(self.episodes)} of max {self.max_episodes} episodes: evicting the oldest by capacity, "
+                              f"earlier than the reference's deque(maxlen) would", RuntimeWarning, stacklevel=3)
         self._head = hi
         return lo
 

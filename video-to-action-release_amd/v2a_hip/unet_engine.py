@@ -13,6 +13,7 @@ Mirrors UNetModel.forward (reference guided_diffusion/guided_diffusion/unet.py:6
 Parameters are ordinary torch tensors under the reference's names (checkpoints load unchanged).
 """
 import math
+import os
 import torch
 from . import ops
 
@@ -69,13 +70,19 @@ class _Packs:
         self.P = P
         self._c = {}
 
-    def get(self, name, half=False):
+    def get(self, name, half=False, pad_cin=0):
+        """pad_cin: bf16 pack with the input-channel axis zero-padded to `pad_cin` (the 6-channel stem on the 32-channel-chunk kernels)."""
         w = self.P[name]
         key = (w.data_ptr(), w._version)
-        ck = (name, half)
+        ck = (name, half, pad_cin)
         ent = self._c.get(ck)
         if ent is None or ent[0] != key:
             wd = w.detach()
+            if pad_cin:
+                assert half and wd.shape[1] <= pad_cin
+                wp = torch.zeros((wd.shape[0], pad_cin) + tuple(wd.shape[2:]), dtype=wd.dtype, device=wd.device)
+                wp[:, :wd.shape[1]] = wd
+                wd = wp
             taps = 1
             for s in wd.shape[2:]:
                 taps *= s
@@ -111,8 +118,8 @@ class UNetEngine:
                 raise ValueError(f"bf16 storage needs channel widths that are multiples of 64, got {widths}")
         self.storage = mode
 
-    def w(self, name, half=False):
-        return self.packs.get(self.pre + name, half)
+    def w(self, name, half=False, pad_cin=0):
+        return self.packs.get(self.pre + name, half, pad_cin)
 
     def p(self, name):
         return self.P[self.pre + name]
@@ -165,11 +172,26 @@ class UNetEngine:
         B, Fr, H, W, C = x.shape
         if x.dtype == torch.bfloat16:
             return self._conv3d_h(x, name, cout, stride, ups, x2, rowvec, residual, out_f32)
-        wsp = self.w(name + ".spatial_conv.weight")
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
         x4 = x.view(B * Fr, H, W, C)
         x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
+        if (self.storage == "bf16" and has_t and cout % 128 == 0 and C < 32 and k == 3 and stride == 1 and x2 is None and not ups
+                and not os.environ.get("V2A_STEM_F32")):
+            # stem (Cin = 6) in the bf16-storage configuration: input padded to one 32-channel chunk, so that the spatial conv runs on the
+            # halo kernel (135 GFLOP of padded work at ~1 PFLOP/s instead of 25 GFLOP on the scalar-gather fp32 kernel at 33 TFLOP/s) and
+            # its output is born bf16 (no cast launch in front of the temporal conv)
+            xh = ops.pad_cast_h(x4, 32)
+            y = ops.conv2d_h(xh, self.w(name + ".spatial_conv.weight", half=True, pad_cin=32), self.p(name + ".spatial_conv.bias"), cout, 3, 3,
+                             (1, 1), (1, 1))
+            z, stats = ops.conv2d_h(y.view(B, Fr, H * W, cout), self.w(name + ".temporal_conv.weight", half=True),
+                                    self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
+                                    rows_per_batch=Fr * H * W, residual=None if residual is None else residual.view(B, Fr, H * W, cout),
+                                    want_stats=True)
+            out = z.view(B, Fr, H, W, cout)
+            out._gn_stats = stats
+            return out
+        wsp = self.w(name + ".spatial_conv.weight")
         # the LAST kernel of the Conv3d also leaves the per-64-row sums GroupNorm needs (fp32 LDS-DMA kernel epilogue)
         y = ops.conv2d(x4, wsp, self.p(name + ".spatial_conv.bias"), cout, k, k, (stride, stride), (k // 2, k // 2), x2=x24, ups=ups,
                        rowvec=None if has_t else rowvec, rows_per_batch=1,
