@@ -28,6 +28,7 @@ struct GnDesc {
     float* rstd;            // [N][G]
     float* colsum;          // [N][2][C] (stats: sum x, sum x^2; backward: sum dz, sum dz*xhat)
     double* partial;        // [N][nchunk][2][C]
+    unsigned int l4_magic, l4_shift;   // idx / (C/4) == umulhi(idx, l4_magic) >> l4_shift for idx < 2^31 (gn_apply_fwd_rows)
     const float* st1;       // forward large path: per-64-row (sum, sum of squares) blocks of x from the producing conv's epilogue
     const float* st2;       // ... and of x2 ([N * S/64][2][C1] / [N * S/64][2][C - C1]); replaces the gn_colreduce pass over the tensor
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
@@ -212,6 +213,59 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
                 a += p.gamma[g * cg + j] * v;
             }
             p.gsum[(size_t)(n * p.G + g) * 2 + tid] = a;
+        }
+    }
+}
+
+// The apply pass of the large path, sample-major: grid (chunks, N), 32-bit indexing inside one sample with the row / column split by a
+// launch-invariant reciprocal, four independent 16-B loads in flight per thread, one (mean, rstd) pair per float4 (needs cg % 4 == 0).
+// Same arithmetic, in the same order, as gn_apply_fwd below -- which divides 64-bit indices three times per float4 and ran at 3.2 TB/s.
+__global__ __launch_bounds__(256) void gn_apply_fwd_rows(const GnDesc p) {
+    const int C = p.C, L4 = C >> 2, cg = C / p.G;
+    const uint32_t per_n = (uint32_t)p.S * (uint32_t)L4;
+    const int n = blockIdx.y;
+    const int C1 = p.x2 ? p.C1 : C, C2 = C - C1;
+    const float* xa = p.x + (size_t)n * p.S * C1;
+    const float* xb = p.x2 ? p.x2 + (size_t)n * p.S * C2 : nullptr;
+    const float* rs = p.residual ? p.residual + (size_t)n * p.S * C : nullptr;
+    float* yo = p.y + (size_t)n * p.S * C;
+    const float* mean = p.mean + (size_t)n * p.G;
+    const float* rstd = p.rstd + (size_t)n * p.G;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < per_n; i0 += 4 * stride) {
+        f32x4 v[4], r[4];
+        uint32_t row[4];
+        int cc[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t idx = i0 + k * stride;
+            ok[k] = idx < per_n;
+            const uint32_t id = ok[k] ? idx : 0u;
+            row[k] = (L4 == 1) ? id : (__umulhi(id, p.l4_magic) >> p.l4_shift);
+            cc[k] = (int)(id - row[k] * (uint32_t)L4) * 4;
+            const float* src = (cc[k] < C1) ? xa + (size_t)row[k] * C1 + cc[k] : xb + (size_t)row[k] * C2 + (cc[k] - C1);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            v[k] = ok[k] ? *reinterpret_cast<const f32x4*>(src) : z4;
+            r[k] = (ok[k] && rs) ? *reinterpret_cast<const f32x4*>(rs + (size_t)row[k] * C + cc[k]) : z4;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int c = cc[k], g = c / cg;
+            const float mu = mean[g], rsd = rstd[g];
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = (v[k][j] - mu) * rsd * gm[j] + bt[j] + r[k][j];
+                float a = act_fwd(z, p.act);
+                if (p.film) a = p.film[(size_t)n * p.film_ld + c + j] * a + p.film[(size_t)n * p.film_ld + C + c + j];
+                o[j] = a;
+            }
+            const size_t off4 = ((size_t)row[k] * C + c) >> 2;
+            reinterpret_cast<f32x4*>(yo)[off4] = o;
+            if (p.yh) gn_store_twin4(p.yh + (size_t)n * p.S * C, off4, o);
         }
     }
 }
@@ -879,6 +933,23 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
     V2A_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_finalize<0>, dim3(N * G), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
+    const bool aligned = (((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+    if (cg % 4 == 0 && aligned && (!x2 || C1 % 4 == 0) && (double)S * (C / 4) < 2147483648.0) {
+        const uint32_t d = (uint32_t)(C / 4);            // round-up reciprocal of L4: exact quotient for every idx < 2^31
+        uint32_t sft = 0;
+        while ((1u << sft) < d) ++sft;
+        p.l4_magic = (uint32_t)(((1ull << (31 + sft)) + d - 1) / d);
+        p.l4_shift = sft - 1;
+        if (d == 1) { p.l4_magic = 0; p.l4_shift = 0; }
+        const size_t vecs = (size_t)S * (C / 4);
+        int g = (int)((vecs + 1023) / 1024);
+        const int cap = (2048 + N - 1) / N;               // ~2048 workgroups over the whole tensor
+        if (g > cap) g = cap;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(gn_apply_fwd_rows, dim3(g, N), dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
+    }
     size_t total4 = (size_t)N * S * (C / 4);
     int grid = (int)((total4 + 255) / 256);
     if (grid > 16384) grid = 16384;
