@@ -1485,19 +1485,40 @@ __device__ __forceinline__ void wgrad_reduce_taps_body(const WgradDesc& p, const
     const int co = bid / cblocks, ci0 = (bid % cblocks) << 6;
     const size_t total = (size_t)p.Cout * p.K;
     const int n = 64 * taps;
-    for (int t = threadIdx.x; t < n; t += 256) {
-        const int tap = t >> 6, cl = t & 63;
-        const float* src = p.partial + (size_t)co * p.K + (size_t)tap * Cin + ci0 + cl;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int sl = 0;
-        for (; sl + 4 <= p.splits; sl += 4) {
-            v0 += src[(size_t)sl * total];
-            v1 += src[(size_t)(sl + 1) * total];
-            v2 += src[(size_t)(sl + 2) * total];
-            v3 += src[(size_t)(sl + 3) * total];
+    const int ldt = taps + 1 > 65 ? 65 : taps + 1;
+    if ((total & 3) == 0 && ((uintptr_t)p.partial & 15) == 0) {
+        // 16-B loads: thread = (tap, four consecutive input channels); same per-element summation order as the scalar form below
+        for (int t = threadIdx.x; t < 16 * taps; t += 256) {
+            const int tap = t >> 4, c4 = (t & 15) << 2;
+            const float* src = p.partial + (size_t)co * p.K + (size_t)tap * Cin + ci0 + c4;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+            int sl = 0;
+            for (; sl + 4 <= p.splits; sl += 4) {
+                v0 += *reinterpret_cast<const f32x4*>(src + (size_t)sl * total);
+                v1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sl + 1) * total);
+                v2 += *reinterpret_cast<const f32x4*>(src + (size_t)(sl + 2) * total);
+                v3 += *reinterpret_cast<const f32x4*>(src + (size_t)(sl + 3) * total);
+            }
+            for (; sl < p.splits; ++sl) v0 += *reinterpret_cast<const f32x4*>(src + (size_t)sl * total);
+            const f32x4 r = (v0 + v1) + (v2 + v3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(c4 + e) * ldt + tap] = r[e];
         }
-        for (; sl < p.splits; ++sl) v0 += src[(size_t)sl * total];
-        tile[cl * (taps + 1 > 65 ? 65 : taps + 1) + tap] = (v0 + v1) + (v2 + v3);
+    } else {
+        for (int t = threadIdx.x; t < n; t += 256) {
+            const int tap = t >> 6, cl = t & 63;
+            const float* src = p.partial + (size_t)co * p.K + (size_t)tap * Cin + ci0 + cl;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            int sl = 0;
+            for (; sl + 4 <= p.splits; sl += 4) {
+                v0 += src[(size_t)sl * total];
+                v1 += src[(size_t)(sl + 1) * total];
+                v2 += src[(size_t)(sl + 2) * total];
+                v3 += src[(size_t)(sl + 3) * total];
+            }
+            for (; sl < p.splits; ++sl) v0 += src[(size_t)sl * total];
+            tile[cl * ldt + tap] = (v0 + v1) + (v2 + v3);
+        }
     }
     __syncthreads();
     float* dst = p.dw + ((size_t)co * Cin + ci0) * taps;
