@@ -418,22 +418,24 @@ class LB_Online_Trainer_V7(object):
         _tick_phase(self, 'vid', len(self.envBuf_vid) >= self.noExp_start_buf_len_vid, self.Exp_noExp_vid, always_check=False)
 
     def update_iter_type(self):
-        """rand-bias for the first `init_rand_steps`, then cycles of rand_cycle_steps / vid_cycle_steps (reference :942-970)."""
-        if self.step < self.init_rand_steps:
-            self.iter_type = 'rand-bias'
-        elif self.step == self.init_rand_steps:
-            self.rand_iter_cnt = 0
+        """Which buffer the next batches favour (reference :942-970, pinned by the schedule trace fixture): the rand buffer for the
+        first `init_rand_steps`; afterwards the two counters hand over to each other when one reaches its cycle length; a cycle
+        length of 0 disables that side altogether."""
+        RAND, VID = 'rand-bias', 'vid-bias'
+        step, warm = self.step, self.init_rand_steps
+        if step < warm:
+            self.iter_type = RAND
+        elif step == warm:
+            self.rand_iter_cnt = 0                     # the cycles start counting here
         elif self.rand_iter_cnt == self.rand_cycle_steps:
-            self.rand_iter_cnt = 0
-            self.iter_type = 'vid-bias'
+            self.rand_iter_cnt, self.iter_type = 0, VID
         elif self.vid_iter_cnt == self.vid_cycle_steps:
-            self.vid_iter_cnt = 0
-            self.iter_type = 'rand-bias'
-        if self.vid_cycle_steps == 0:
-            self.iter_type = 'rand-bias'
-        elif self.rand_cycle_steps == 0:
-            self.iter_type = 'vid-bias'
-        assert self.iter_type in ['rand-bias', 'vid-bias']
+            self.vid_iter_cnt, self.iter_type = 0, RAND
+        forced = RAND if self.vid_cycle_steps == 0 else (VID if self.rand_cycle_steps == 0 else None)
+        if forced is not None:
+            self.iter_type = forced
+        if self.iter_type not in (RAND, VID):
+            raise AssertionError(f"iter_type {self.iter_type!r}")
 
     # -------------------------------------------------------------------------------------------------------- train loop
     def train_step(self):
@@ -507,22 +509,24 @@ class LB_Online_Trainer_V7(object):
     def h5_add_rand_act_episodes_to_Buf(self, start_ep_idx, end_ep_idx):
         """Random-action episodes [start, end) of every task -> envBuf_rand (reference :718-780): range check (+-0.012 slack),
         clip to the action limits, uint8 frames go to HBM as they are."""
-        len_before = len(self.envBuf_rand)
-        for i_t, tk in enumerate(self.task_list):
-            for i_ep in range(start_ep_idx, end_ep_idx):
-                if i_ep >= self.h5_total_num_ep_per_task:
-                    assert not self.randsam.has(tk, i_ep)
-                    break
-                imgs_ep, acts_ep = self.randsam.episode(tk, i_ep)
-                acts_ep = check_and_clip_actions(acts_ep, self.act_min_np, self.act_max_np)
-                assert len(imgs_ep) - 1 == len(acts_ep)
-                if not self.is_all_randsam_visited:
-                    self.num_steps_in_env += len(acts_ep)
-                tmp_e_idx = self.env_list.seed_sets[tk][0]
-                self.envBuf_rand.add_one_episode(tk, self.env_list.camera_list[0], tmp_e_idx, torch.from_numpy(np.ascontiguousarray(imgs_ep)),
-                                                 torch.from_numpy(acts_ep))
-        utils.print_color(f'[Rand Buf Size Before Load] ep {len_before}', c='y')
-        utils.print_color(f'[Rand Buf Size After Load] ep {len(self.envBuf_rand)}', c='y')
+        buf, src = self.envBuf_rand, self.randsam
+        had = len(buf)
+        cam = self.env_list.camera_list[0]
+        last = min(end_ep_idx, self.h5_total_num_ep_per_task)
+        for tk in self.task_list:
+            if end_ep_idx > last:                      # asked past the end of the file: it must really end there
+                assert not src.has(tk, max(start_ep_idx, last))
+            env_idx = self.env_list.seed_sets[tk][0]
+            for ep in range(start_ep_idx, last):
+                frames, actions = src.episode(tk, ep)
+                actions = check_and_clip_actions(actions, self.act_min_np, self.act_max_np)
+                if len(frames) != len(actions) + 1:
+                    raise AssertionError(f"{tk}/{ep}: {len(frames)} frames for {len(actions)} actions")
+                if not self.is_all_randsam_visited:    # environment steps are only counted on the first pass over the file
+                    self.num_steps_in_env += len(actions)
+                buf.add_one_episode(tk, cam, env_idx, torch.from_numpy(np.ascontiguousarray(frames)), torch.from_numpy(actions))
+        utils.print_color(f'[Rand Buf Size Before Load] ep {had}', c='y')
+        utils.print_color(f'[Rand Buf Size After Load] ep {len(buf)}', c='y')
 
     def sample_from_bufs(self):
         """(imgs_start, imgs_goal, acts, tasks_str, info) with the reference's mixing rule (:787-851); tensors are on the GPU."""
