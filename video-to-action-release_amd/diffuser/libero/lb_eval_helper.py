@@ -19,21 +19,16 @@ class LB_DP_Eval(object):
                  device='cuda'):
         self.gcp_model, self.ema, self.video_model, self.trainer = gcp_model, ema, video_model, trainer
         self.env_list, self.task_list, self.cam_list = env_list, task_list, cam_list
-        self.valid_seeds = valid_seeds
-        self.max_episode_steps = max_episode_steps
-        self.render_img_size = render_img_size
-        self.rendered_imgs_preproc_fn = rendered_imgs_preproc_fn
-        self.n_acts_per_pred = self.trainer.n_acts_per_pred
-        self.input_img_size = self.trainer.input_img_size
-        self.accelerator = self.trainer.accelerator
-        self.video_model.ema.ema_model.is_ddim_sampling = is_video_ddim
-        self.is_dp_ddim = is_dp_ddim
-        self.eval_n_preds_betw_vframes = eval_n_preds_betw_vframes
-        self.num_vid_pred_per_ep = num_vid_pred_per_ep
-        self.use_vid_first_n_frames = use_vid_first_n_frames
-        self.save_path = save_path
-        self.vid_use_autocast = vid_use_autocast
-        self.device = device
+        # plain keyword -> attribute copies (the reference's attribute names are the surface other modules read)
+        for name, val in dict(valid_seeds=valid_seeds, max_episode_steps=max_episode_steps, render_img_size=render_img_size,
+                              rendered_imgs_preproc_fn=rendered_imgs_preproc_fn, is_dp_ddim=is_dp_ddim,
+                              eval_n_preds_betw_vframes=eval_n_preds_betw_vframes, num_vid_pred_per_ep=num_vid_pred_per_ep,
+                              use_vid_first_n_frames=use_vid_first_n_frames, save_path=save_path, vid_use_autocast=vid_use_autocast,
+                              device=device).items():
+            setattr(self, name, val)
+        for name in ("n_acts_per_pred", "input_img_size", "accelerator"):          # mirrored from the trainer
+            setattr(self, name, getattr(trainer, name))
+        video_model.ema.ema_model.is_ddim_sampling = is_video_ddim
         assert max_episode_steps == 500
         assert self.rendered_imgs_preproc_fn == imgs_preproc_simple_noCrop_v1
         self.pre_vid_gen_fn = lambda **kargs: None
