@@ -377,8 +377,17 @@ __device__ __forceinline__ f32x4 gn_src4(const GnDesc& p, const float* dense, si
 
 // -------------------------------------------------------------------------------------------- small path
 // one workgroup per (n, g): E = S * cg elements staged in LDS.  Forward: two-pass (centred) variance.
-template <bool VEC>
-__global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
+// sum of the per-wave partials of a workgroup, in wave order (deterministic); pairs first for the four-wave case's historical order
+template <int NW>
+__device__ __forceinline__ float gn_wave_partials(const float* red) {
+    if (NW == 4) return red[0] + red[1] + red[2] + red[3];
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w];
+    return t;
+}
+template <bool VEC, int NT>
+__global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [E] + 8 scratch
     const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
     const int C = p.C, cg = C / p.G, E = p.S * cg;
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     if (VEC) {               // cg % 4 == 0: 16-B loads (a group's channels of one row are contiguous)
         const int cg4 = cg >> 2, E4 = E >> 2;
 #pragma unroll 4
-        for (int i = tid; i < E4; i += 256) {
+        for (int i = tid; i < E4; i += NT) {
             const int row = i / cg4, c4 = i - row * cg4;
             const f32x4 v = gn_src4(p, p.x, base + (size_t)row * C + c4 * 4, g * cg + c4 * 4);
             *reinterpret_cast<f32x4*>(sm + i * 4) = v;
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
         }
     } else {
 #pragma unroll 4
-        for (int i = tid; i < E; i += 256) {
+        for (int i = tid; i < E; i += NT) {
             const int row = i / cg, cc = i - row * cg;
             const float v = gn_src1(p, p.x, base + (size_t)row * C + cc, g * cg + cc);
             sm[i] = v;
@@ -406,21 +415,21 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)E;
+    const float mu = gn_wave_partials<NT / 64>(red) / (float)E;
     __syncthreads();
     float q = 0.f;
 #pragma unroll 4
-    for (int i = tid; i < E; i += 256) { const float d = sm[i] - mu; q += d * d; }
+    for (int i = tid; i < E; i += NT) { const float d = sm[i] - mu; q += d * d; }
     q = wave_sum(q);
     if ((tid & 63) == 0) red[tid >> 6] = q;
     __syncthreads();
-    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)E;
+    const float var = gn_wave_partials<NT / 64>(red) / (float)E;
     const float rs = 1.0f / sqrtf(var + p.eps);
     if (tid == 0) { p.mean[n * p.G + g] = mu; p.rstd[n * p.G + g] = rs; }
     if (VEC) {
         const int cg4 = cg >> 2, E4 = E >> 2;
 #pragma unroll 2
-        for (int i = tid; i < E4; i += 256) {
+        for (int i = tid; i < E4; i += NT) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(sm + i * 4);
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
         return;
     }
 #pragma unroll 4
-    for (int i = tid; i < E; i += 256) {
+    for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
         float z = (sm[i] - mu) * rs * p.gamma[c] + p.beta[c];
@@ -456,8 +465,8 @@ __global__ __launch_bounds__(256) void gn_small_fwd(const GnDesc p) {
 // (dgamma / dbeta = their sum over n: gn_param_grads / gn_param_grads_multi) and dfilm[n][0][c] = sum_s dout * a,
 // dfilm[n][1][c] = sum_s dout.  Deterministic: the per-element terms are staged in LDS and every column is summed over its rows in
 // a fixed order (thread = (row slice, column), then the slices in order) -- no float atomics, in LDS or in HBM.
-template <bool VEC>
-__global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
+template <bool VEC, int NT>
+__global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // xhat[E], dz[E], (film: dout*a[E], dout[E]), part[nsl][4][cg], red[8]
     const int n = blockIdx.x / p.G, g = blockIdx.x % p.G, tid = threadIdx.x;
     const int C = p.C, cg = C / p.G, E = p.S * cg;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     float* dzs = sm + E;
     float* fa = sm + 2 * E;                 // film only
     float* fd = sm + 3 * E;
-    const int nsl = cg >= 256 ? 1 : 256 / cg;                 // row slices summed in parallel per column
+    const int nsl = cg >= NT ? 1 : NT / cg;                 // row slices summed in parallel per column
     float* part = sm + (film ? 4 : 2) * E;  // [nsl][4][cg]
     float* red = part + (size_t)nsl * 4 * cg;
     const size_t base = (size_t)n * p.S * C + (size_t)g * cg;
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     if (VEC && !film) {
         const int cg4 = cg >> 2, E4 = E >> 2;
 #pragma unroll 2
-        for (int i = tid; i < E4; i += 256) {
+        for (int i = tid; i < E4; i += NT) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off), dv = gn_src4(p, p.dout, off, c);
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         }
     } else {
 #pragma unroll 4
-    for (int i = tid; i < E; i += 256) {
+    for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
         const float h = (p.x[off] - mu) * rs;
@@ -521,15 +530,15 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     }
     A1 = wave_sum(A1);
     A2 = wave_sum(A2);
-    if ((tid & 63) == 0) { red[tid >> 6] = A1; red[4 + (tid >> 6)] = A2; }
+    if ((tid & 63) == 0) { red[tid >> 6] = A1; red[NT / 64 + (tid >> 6)] = A2; }
     __syncthreads();
-    A1 = red[0] + red[1] + red[2] + red[3];
-    A2 = red[4] + red[5] + red[6] + red[7];
+    A1 = gn_wave_partials<NT / 64>(red);
+    A2 = gn_wave_partials<NT / 64>(red + NT / 64);
     const float inv = 1.0f / (float)E;
     if (VEC) {
         const int cg4 = cg >> 2, E4 = E >> 2;
 #pragma unroll 2
-        for (int i = tid; i < E4; i += 256) {
+        for (int i = tid; i < E4; i += NT) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 hv = *reinterpret_cast<const f32x4*>(xh + i * 4), zv = *reinterpret_cast<const f32x4*>(dzs + i * 4);
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         }
     } else {
 #pragma unroll 4
-    for (int i = tid; i < E; i += 256) {
+    for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
         const float dxv = rs * (p.gamma[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
     }
     }
     // column sums: thread (slice, cc) adds rows slice, slice + nsl, ... in order; then the slices in order
-    for (int t = tid; t < nsl * cg; t += 256) {
+    for (int t = tid; t < nsl * cg; t += NT) {
         const int sl = t / cg, cc = t - sl * cg;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         for (int row = sl; row < p.S; row += nsl) {
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd(const GnDesc p) {
         dst[cc] = s0; dst[cg + cc] = s1; dst[2 * cg + cc] = s2; dst[3 * cg + cc] = s3;
     }
     __syncthreads();
-    for (int cc = tid; cc < cg; cc += 256) {
+    for (int cc = tid; cc < cg; cc += NT) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         for (int sl = 0; sl < nsl; ++sl) {
             const float* src = part + (size_t)sl * 4 * cg;
@@ -904,14 +913,19 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
         return V2A_OK;
     }
     if (E <= GN_SMALL_MAX) {
-        size_t lds = (E + 8) * sizeof(float);
+        size_t lds = (E + 32) * sizeof(float);
         const bool vec = cg % 4 == 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+        // 1024 threads per slab from 8 K elements up: with one 256-thread workgroup per (sample, group) a 64-KB slab was fetched in four
+        // dependent rounds of loads by four waves per CU (19 us for the first ResNet stage); sixteen waves fetch it in one
+        const bool wide = vec && E >= 8192;
         if (lds > 64 * 1024) {
-            (void)hipFuncSetAttribute((const void*)gn_small_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gn_small_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_fwd<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_fwd<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_fwd<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
-        if (vec) hipLaunchKernelGGL(gn_small_fwd<true>, dim3(N * G), dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL(gn_small_fwd<false>, dim3(N * G), dim3(256), lds, stream, p);
+        if (wide) hipLaunchKernelGGL((gn_small_fwd<true, 1024>), dim3(N * G), dim3(1024), lds, stream, p);
+        else if (vec) hipLaunchKernelGGL((gn_small_fwd<true, 256>), dim3(N * G), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((gn_small_fwd<false, 256>), dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
         return V2A_OK;
     }
@@ -1011,17 +1025,26 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
 #undef V2A_GNW_B
         V2A_CHECK_LAUNCH();
     } else if (E <= GN_SMALL_MAX) {
-        const int nsl = cg >= 256 ? 1 : 256 / cg;
-        size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 8) * sizeof(float);
-        if (lds > 160 * 1024) return V2A_ERR_ARG;
         const bool vec = cg % 4 == 0 && C % 4 == 0 &&
                          (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout | (uintptr_t)residual | (uintptr_t)dres | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
-        if (lds > 64 * 1024) {
-            (void)hipFuncSetAttribute((const void*)gn_small_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gn_small_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        bool wide = vec && E >= 8192;
+        int nt = wide ? 1024 : 256;
+        int nsl = cg >= nt ? 1 : nt / cg;
+        size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 32) * sizeof(float);
+        if (lds > 160 * 1024 && wide) {                 // the wider column-sum scratch does not fit: fall back to 256 threads
+            wide = false; nt = 256;
+            nsl = cg >= nt ? 1 : nt / cg;
+            lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 32) * sizeof(float);
         }
-        if (vec) hipLaunchKernelGGL(gn_small_bwd<true>, dim3(N * G), dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL(gn_small_bwd<false>, dim3(N * G), dim3(256), lds, stream, p);
+        if (lds > 160 * 1024) return V2A_ERR_ARG;
+        if (lds > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void*)gn_small_bwd<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_bwd<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gn_small_bwd<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+        if (wide) hipLaunchKernelGGL((gn_small_bwd<true, 1024>), dim3(N * G), dim3(1024), lds, stream, p);
+        else if (vec) hipLaunchKernelGGL((gn_small_bwd<true, 256>), dim3(N * G), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((gn_small_bwd<false, 256>), dim3(N * G), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
     } else {
         if (film || dfilm) return V2A_ERR_ARG;   // FiLM only occurs on the small (Conv1d) path
