@@ -168,24 +168,34 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     for (int s = 0; s < SB - 1; ++s) issue_b(s / 9, s % 9, s);
     int cstage = 0, istage = SB - 1;
 
-    auto mma_step = [&](const unsigned char* hbase, const unsigned char* bbase, int shift) {
+    // one step: all twelve operand fragments are requested first, the step's DMAs are issued while those reads are in flight (a DMA
+    // instruction costs the issuing wave 100-185 cycles inside a busy phase), then the sixteen MFMAs run back to back.  Measured
+    // +2...4.5 % on every shape over "DMA issue, then per k-half: reads, MFMAs".  (Fetching the next k-half / next step's fragments
+    // under the MFMAs with a second register set was 5 % SLOWER: the step is bound by the weight tiles' L2 -> LDS traffic, not by
+    // the LDS read latency.)
+    auto mma_step = [&](const unsigned char* hbase, const unsigned char* bbase, int shift, auto&& issue) {
+        bf16x8_3 a[2][TM], b[2][TN];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            bf16x8_3 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int hr = a_hr[i] + shift;
-                a[i] = *reinterpret_cast<const bf16x8_3*>(hbase + hr * ROWB + ((((h << 1) | lk) ^ ((hr >> 2) & 3)) << 4));
+                a[h][i] = *reinterpret_cast<const bf16x8_3*>(hbase + hr * ROWB + ((((h << 1) | lk) ^ ((hr >> 2) & 3)) << 4));
             }
             const int bpos = (((h << 1) | lk) ^ brswz) << 4;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_3*>(bbase + b_off[j] + bpos);
+            for (int j = 0; j < TN; ++j) b[h][j] = *reinterpret_cast<const bf16x8_3*>(bbase + b_off[j] + bpos);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
     };
 
 #define V2A_H3_TAP(T)                                                                                                  \
@@ -193,9 +203,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
         if (c == 0) wait_vmcnt3<(SB - 2) * BL>();      /* start-up: no halo pieces of a previous chunk in the queue */  \
         else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB, HPIECES>::value>();                                          \
         __builtin_amdgcn_s_barrier();                                                                                  \
-        issue_b(c + (T + SB - 1) / 9, (T + SB - 1) % 9, istage);                                                       \
-        if (halo_piece_at(T, HPIECES) >= 0) issue_halo_piece(halo_piece_at(T, HPIECES), c + 1, (c + 1) & 1);           \
-        mma_step(smem + (c & 1) * HBUF, smem + 2 * HBUF + cstage * BSTAGE, (T / 3) * HW_ + (T % 3));                   \
+        mma_step(smem + (c & 1) * HBUF, smem + 2 * HBUF + cstage * BSTAGE, (T / 3) * HW_ + (T % 3), [&]() {            \
+            issue_b(c + (T + SB - 1) / 9, (T + SB - 1) % 9, istage);                                                   \
+            if (halo_piece_at(T, HPIECES) >= 0) issue_halo_piece(halo_piece_at(T, HPIECES), c + 1, (c + 1) & 1);       \
+        });                                                                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
         cstage = (cstage + 1 == SB) ? 0 : cstage + 1;                                                                  \
         istage = (istage + 1 == SB) ? 0 : istage + 1;                                                                  \
