@@ -1623,15 +1623,23 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
     const int Cout = (int)table[t * 7 + 2], Cin = (int)table[t * 7 + 3], taps = (int)table[t * 7 + 4];
     const long long total = (long long)Cout * Cin * taps;
     const int cnt = (int)min((long long)PACK_CHUNK, total - start);
+    // (co, tap, ci) of the thread's first element by one 32-bit decomposition, then carried forward in steps of 256 elements (the
+    // first version divided 64-bit indices three times per element: ~200 instructions per 4 bytes moved)
+    const unsigned idx0 = (unsigned)start + threadIdx.x;             // every operand has fewer than 2^31 elements
+    unsigned q = idx0 / (unsigned)Cin;
+    int ci = (int)(idx0 - q * (unsigned)Cin);
+    int co = (int)(q / (unsigned)taps);
+    int tap = (int)(q - (unsigned)co * (unsigned)taps);
     for (int i = threadIdx.x; i < cnt; i += 256) {
-        const long long idx = (long long)start + i;
-        const int ci = (int)(idx % Cin);
-        const long long q = idx / Cin;
-        const int tap = (int)(q % taps);
-        const int co = (int)(q / taps);
+        const size_t idx = (size_t)start + i;
         const float v = src[((size_t)co * Cin + ci) * taps + tap];
         if (dst) dst[idx] = v;
         if (dsth) dsth[idx] = f2bf_pack(v);
+        ci += 256;
+        while (ci >= Cin) {
+            ci -= Cin;
+            if (++tap == taps) { tap = 0; ++co; }
+        }
     }
 }
 __global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t* table, const int* chunks) {
