@@ -258,6 +258,18 @@ int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, cons
 int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2);
 int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
                       const void* zeros, int N, int H, int W, int C, int Cout, int ups, int rows_per_batch, float* stats, v2a_stream_t stream);
+/* GroupNorm folded into the consuming 3x3 conv (bf16-storage sampler: GroupNorm32 + SiLU in front of every Conv3d of a ResBlock,
+   guided_diffusion/unet.py:180-260): v2a_groupnorm_prep_h turns the statistics into a per-(sample, channel) scale / shift table
+   ab [N][2][C]; v2a_conv2d_fwd_h3_gn applies y = act(x * a + b) to its input halo while it sits in LDS (x [N,H,W,C1] | x2 [N,H,W,C-C1]
+   along channels; gn_frames images per GroupNorm sample; act 0 = none, 1 = SiLU), so the normalised tensor is never written;
+   v2a_groupnorm_apply_h is the stand-alone apply pass for consumers that cannot (same arithmetic) */
+int v2a_groupnorm_prep_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, float* mean, float* rstd,
+                         const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, float* ab_out, void* workspace,
+                         size_t workspace_bytes, v2a_stream_t stream);
+int v2a_groupnorm_apply_h(const void* x, const void* x2, int C1, const float* ab, void* y, int N, int S, int C, int act, v2a_stream_t stream);
+int v2a_conv2d_fwd_h3_gn(const void* x, const void* x2, int C1, const float* gn_ab, int gn_frames, int act, const void* w_packed,
+                         const float* bias, const float* rowvec, const void* residual, void* y, const void* zeros, int N, int H, int W, int C,
+                         int Cout, int rows_per_batch, float* stats, v2a_stream_t stream);
 /* Temporal (3 x 1 x 1) part of the factorised Conv3d (nn.py:45-69: temporal_conv) on the frame-stack tile (csrc/igemm_h3.hip,
    conv_frames_h3): all F = 7 frames of 64 pixels in one workgroup, the input DMA-ed once per 32-channel chunk for the three taps.
    Same argument meaning as v2a_conv2d_fwd_h3 with x viewed as [B, F, HW, C] */

@@ -571,6 +571,39 @@ def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,C1,C2,Co,act", [(112, 32, 32, 128, 0, 128, "silu"), (56, 32, 32, 128, 64, 256, "silu"), (35, 16, 48, 64, 32, 384, "none"),
+                                                 (28, 64, 64, 32, 0, 128, "silu")])
+def test_conv2d_halo_h3_applies_groupnorm_in_the_loader(N, H, W, C1, C2, Co, act):
+    """GroupNorm + SiLU folded into the 3x3 halo conv (v2a_groupnorm_prep_h -> v2a_conv2d_fwd_h3_gn): the conv normalises its input
+    halo in LDS -- y = act(x * a[n, c] + b[n, c]), rounded to bf16, padding ring left at zero -- instead of reading a tensor the
+    apply pass wrote.  Same arithmetic as gn_apply_h, so the result must equal apply-then-conv on the same kernel bit for bit; also
+    for the decoder's two-source input [x | x2], per-sample statistics over 7 frames, 1 .. 6 channel chunks, and bitwise repeatable."""
+    from v2a_hip import ops
+    dev, F = "cuda:0", 7
+    g = torch.Generator().manual_seed(N + C1)
+    C = C1 + C2
+    x = (torch.randn(N, H, W, C1, generator=g) * 1.5 + 0.3).to(torch.bfloat16).to(dev)
+    x2 = (torch.randn(N, H, W, C2, generator=g) * 0.7 - 0.2).to(torch.bfloat16).to(dev) if C2 else None
+    gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    w = ops.pack_weight_h((torch.randn(Co, C, 3, 3, generator=g) * 0.05).to(dev))
+    b = torch.randn(Co, generator=g).to(dev)
+    rowvec = torch.randn(N // F, Co, generator=g).to(dev)
+    assert ops.gn_fusable(N, H, W, C, Co, 3, 3, (1, 1), (1, 1), False)
+    S = F * H * W
+    pg = ops.groupnorm_prep_h(x.view(N // F, S, C1), gamma, beta, 32 if C % 32 == 0 else 8, act, x2=None if x2 is None else x2.view(N // F, S, C2))
+    y, st = ops.conv2d_h(x, w, b, Co, 3, 3, (1, 1), (1, 1), x2=x2, rowvec=rowvec, rows_per_batch=S, want_stats=True, pre_gn=pg)
+    assert ops.last_kernel[0].startswith("conv_halo_h3_gn") and st is not None
+    a = pg.apply().view(N, H, W, C)                                   # the stand-alone apply pass on the same table
+    ref_fwd = ops.groupnorm_fwd_h(x.view(N // F, S, C1), gamma, beta, 32 if C % 32 == 0 else 8, act, x2=None if x2 is None else x2.view(N // F, S, C2))
+    assert torch.equal(a.view(N // F, S, C), ref_fwd)                 # prep + apply == the one-call GroupNorm
+    y1, st1 = ops.conv2d_h(a, w, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rowvec, rows_per_batch=S, want_stats=True)
+    assert ops.last_kernel[0].startswith("conv_halo_h3<")
+    assert torch.equal(y, y1) and torch.equal(st, st1)
+    y2, _ = ops.conv2d_h(x, w, b, Co, 3, 3, (1, 1), (1, 1), x2=x2, rowvec=rowvec, rows_per_batch=S, want_stats=True, pre_gn=pg)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.gpu
 def test_conv2d_halo_h3_folds_the_nearest_upsample():
     """Upsample (nearest x2 on H, W) + 3x3 conv (unet.py:105-115) on the halo kernel: the gather reads source pixel (ih >> 1, iw >> 1)."""
     from v2a_hip import ops

@@ -36,6 +36,11 @@ struct ConvDescH3 {
     const uint16_t* zeros;
     int N, H, W, C, Cout, M, K, rows_per_batch, tiles_x, tiles_img;
     int ups;                    // 1: nearest x2 upsample folded into the halo gather (Upsample + conv, unet.py:105-115): source frame is (H/2, W/2)
+    // GroupNorm + activation applied to the input while it sits in LDS (conv_halo_h3<.., GN = 1>): the conv reads the tensor the
+    // GroupNorm would have read, [x | x2] along channels, and normalises it itself
+    const uint16_t* x2;         // channels [C1, C) of the input or null
+    const float* ab;            // [N / fps][2][C]: per (sample, channel) scale and shift (gn_finalize_h)
+    int C1, fps, act;           // channels of x; frames (images) per GroupNorm sample; ACT_SILU / ACT_NONE
 };
 
 __device__ __forceinline__ int xcd_remap3(int bid, int nblk) {
@@ -56,20 +61,21 @@ __device__ __forceinline__ void wait_vmcnt3() {
 
 // halo piece j of the next chunk goes out at tap halo_tap(j, HP): 1, 3, 5 for three pieces, 1 .. 5 for five -- all of them ahead
 // of the first weight tile of the next chunk in the queue as long as SB - 1 <= 3 (issued at tap 9 - (SB - 1) >= 6) ...
-__host__ __device__ constexpr int halo_tap(int j, int HP) { return HP <= 3 ? 1 + 2 * j : 1 + j; }
-__host__ __device__ constexpr int halo_piece_at(int tap, int HP) {       // piece index issued at `tap`, or -1
+// (gn: one tap earlier -- 0, 2, 4 / 0 .. 4 -- so that every piece has landed four taps later, where the fused GroupNorm transforms it)
+__host__ __device__ constexpr int halo_tap(int j, int HP, bool gn = false) { return (HP <= 3 ? 1 + 2 * j : 1 + j) - (gn ? 1 : 0); }
+__host__ __device__ constexpr int halo_piece_at(int tap, int HP, bool gn = false) {       // piece index issued at `tap`, or -1
     for (int j = 0; j < HP; ++j)
-        if (halo_tap(j, HP) == tap) return j;
+        if (halo_tap(j, HP, gn) == tap) return j;
     return -1;
 }
 // number of halo pieces issued at steps s-(SB-1) .. s-1 when step s has tap T
-template <int T, int SB, int HP>
+template <int T, int SB, int HP, bool GNF = false>
 struct HaloLater {
     static constexpr int count() {
         int c = 0;
         for (int d = 1; d <= SB - 1; ++d) {
             int u = ((T - d) % 9 + 9) % 9;
-            if (halo_piece_at(u, HP) >= 0) ++c;
+            if (halo_piece_at(u, HP, GNF) >= 0) ++c;
         }
         return c;
     }
@@ -77,7 +83,7 @@ struct HaloLater {
 };
 
 // BM = 256 (16 x 16 patch) or 512 (32 rows x 16 pixels: the 128-wide instance -- 12.3 KB of DMA per 512 x 128 x 32 step).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int SB>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int SB, int GN = 0>
 __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     static_assert((BM == 256 || BM == 512) && WAVES_M * WAVES_N == 8, "tile shape");
@@ -89,10 +95,12 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     constexpr int HBUF = HPIECES * 512 * 16;
     constexpr int BL = BN / 128;                           // DMA instructions per thread per weight tile (128 rows x 4 chunks per pass)
     constexpr int BSTAGE = BN * ROWB;
-    constexpr int SMEM = 2 * HBUF + SB * BSTAGE;
+    constexpr int PIPE = 2 * HBUF + SB * BSTAGE;
+    constexpr int SMEM = PIPE + (GN ? 2 * 1024 * 4 : 0);   // GN: scale / shift of the tile's sample, [2][C <= 1024] fp32, behind the pipeline buffers
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     static_assert((SB - 2) * BL + HPIECES <= 63, "vmcnt is a 6-bit counter");
-    static_assert(9 - (SB - 1) > halo_tap(HPIECES - 1, HPIECES), "the last halo piece must precede the next chunk's first weight tile");
+    static_assert(9 - (SB - 1) > halo_tap(HPIECES - 1, HPIECES, GN != 0), "the last halo piece must precede the next chunk's first weight tile");
+    static_assert(!GN || halo_tap(HPIECES - 1, HPIECES, true) + 4 <= 8, "a piece is transformed four taps after it was issued");
     __shared__ __attribute__((aligned(128))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
 
     // ---- halo DMA source state: piece q = j * 512 + tid -> halo row q >> 2, position q & 3, carrying chunk (q & 3) ^ ((row >> 2) & 3).
     // 32-bit element offsets from p.x (0xffffffff = the zero line): the kernel sits at the 256-VGPR cap
-    uint32_t h_off[HPIECES];
+    uint32_t h_off[HPIECES];                                 // GN: the PIXEL index (the channel part depends on which source the chunk lies in)
     const uint16_t* zsrc = p.zeros;
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) {
@@ -119,15 +127,54 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
         const bool ok = hr < HROWS && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         const int sh_ = p.ups ? (p.H >> 1) : p.H, sw_ = p.ups ? (p.W >> 1) : p.W;
         const int ihs = p.ups ? (ih >> 1) : ih, iws = p.ups ? (iw >> 1) : iw;
-        h_off[j] = ok ? ((uint32_t)(img * sh_ + ihs) * (uint32_t)sw_ + (uint32_t)iws) * (uint32_t)p.C + (uint32_t)chunk * 8u : 0xffffffffu;
+        const uint32_t pix = (uint32_t)(img * sh_ + ihs) * (uint32_t)sw_ + (uint32_t)iws;
+        if (GN) h_off[j] = ok ? pix : 0xffffffffu;
+        else h_off[j] = ok ? pix * (uint32_t)p.C + (uint32_t)chunk * 8u : 0xffffffffu;
     }
     // ---- weight DMA source state: pass j fills rows j*128 .. +127; slot (row j*128 + tid/4, position tid%4), chunk (tid%4) ^ ((row>>2)&3)
     const uint32_t b_off0 = (uint32_t)(n0 + (tid >> 2)) * (uint32_t)p.K + (uint32_t)(((tid & 3) ^ ((tid >> 4) & 3)) * 8);
     const uint32_t b_step = 128u * (uint32_t)p.K;
 
     auto issue_halo_piece = [&](int j, int chunk_idx, int hb) {     // chunk_idx >= nchunks: the zero line (keeps the DMA count uniform)
-        const uint16_t* g = (h_off[j] != 0xffffffffu && chunk_idx < nchunks) ? p.x + h_off[j] + chunk_idx * 32 : zsrc;
+        const uint16_t* g = zsrc;
+        if (GN) {
+            if (h_off[j] != 0xffffffffu && chunk_idx < nchunks) {
+                const int q = j * 512 + tid;
+                const uint32_t cp = (uint32_t)(((q & 3) ^ ((q >> 4) & 3)) * 8);          // (hr >> 2) & 3 with hr = q >> 2
+                const uint32_t c0 = (uint32_t)chunk_idx * 32u;
+                const uint32_t C2 = (uint32_t)(p.C - p.C1);
+                g = (c0 < (uint32_t)p.C1) ? p.x + (size_t)h_off[j] * (uint32_t)p.C1 + c0 + cp
+                                          : p.x2 + (size_t)h_off[j] * C2 + (c0 - (uint32_t)p.C1) + cp;
+            }
+        } else {
+            if (h_off[j] != 0xffffffffu && chunk_idx < nchunks) g = p.x + h_off[j] + chunk_idx * 32;
+        }
         __builtin_amdgcn_global_load_lds((gptr3_t)g, (lptr3_t)(smem + hb * HBUF + (j * 512 + wid * 64) * 16), 16, 0, 0);
+    };
+    // fused GroupNorm: this thread normalises the piece IT fetched (its own vmcnt wait covers the landing), in place:
+    // y = act(x * a[n, c] + b[n, c]) on eight channels, rounded back to bf16 -- the arithmetic of gn_apply_h.  Padding pixels stay 0.
+    float* ab_lds = reinterpret_cast<float*>(smem + PIPE);
+    auto gn_piece = [&](int j, int chunk_idx, int hb) {
+        if (h_off[j] == 0xffffffffu || chunk_idx >= nchunks) return;
+        const int q = j * 512 + tid;
+        const int ch0 = chunk_idx * 32 + (((q & 3) ^ ((q >> 4) & 3)) << 3);
+        uint4* slot = reinterpret_cast<uint4*>(smem + hb * HBUF + q * 16);
+        const uint4 u = *slot;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ab_lds + ch0), a1 = *reinterpret_cast<const f32x4*>(ab_lds + ch0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0), b1 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0 + 4);
+        float f[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+                      __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z0 = f[e] * a0[e] + b0[e], z1 = f[e + 4] * a1[e] + b1[e];
+            o[e] = p.act == ACT_SILU ? v2a_silu_fast(z0) : z0;
+            o[e + 4] = p.act == ACT_SILU ? v2a_silu_fast(z1) : z1;
+        }
+        uint4 r;
+        r.x = v2a_pack_bf16x2(o[0], o[1]); r.y = v2a_pack_bf16x2(o[2], o[3]);
+        r.z = v2a_pack_bf16x2(o[4], o[5]); r.w = v2a_pack_bf16x2(o[6], o[7]);
+        *slot = r;
     };
     auto issue_b = [&](int bc, int bt, int stage) {                 // weight tile of (chunk bc, tap bt); bc >= nchunks: the zero line
         const bool live = bc < nchunks;
@@ -162,11 +209,21 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     for (int j = 0; j < TN; ++j) b_off[j] = (wn + j * 32 + lr) * ROWB;
 
     // ---- prologue: halo of chunk 0, then SB-1 weight tiles
+    f32x4 abv = {0.f, 0.f, 0.f, 0.f};
+    if (GN && tid * 4 < 2 * p.C) abv = *reinterpret_cast<const f32x4*>(p.ab + (size_t)(img / p.fps) * 2 * p.C + tid * 4);   // 2 C <= 2048 floats
 #pragma unroll
     for (int j = 0; j < HPIECES; ++j) issue_halo_piece(j, 0, 0);
 #pragma unroll
     for (int s = 0; s < SB - 1; ++s) issue_b(s / 9, s % 9, s);
     int cstage = 0, istage = SB - 1;
+    if (GN) {
+        if (tid * 4 < 2 * p.C) *reinterpret_cast<f32x4*>(ab_lds + tid * 4) = abv;
+        wait_vmcnt3<(SB - 1) * BL>();                      // this thread's halo pieces of chunk 0 (the weight tiles stay in flight)
+        __syncthreads();                                   // scale / shift visible
+#pragma unroll
+        for (int j = 0; j < HPIECES; ++j) gn_piece(j, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // published by the barrier of the first step
+    }
 
     // one step: all twelve operand fragments are requested first, the step's DMAs are issued while those reads are in flight (a DMA
     // instruction costs the issuing wave 100-185 cycles inside a busy phase), then the sixteen MFMAs run back to back.  Measured
@@ -201,12 +258,15 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
 #define V2A_H3_TAP(T)                                                                                                  \
     {                                                                                                                  \
         if (c == 0) wait_vmcnt3<(SB - 2) * BL>();      /* start-up: no halo pieces of a previous chunk in the queue */  \
-        else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB, HPIECES>::value>();                                          \
+        else wait_vmcnt3<(SB - 2) * BL + HaloLater<T, SB, HPIECES, GN != 0>::value>();                                 \
         __builtin_amdgcn_s_barrier();                                                                                  \
         mma_step(smem + (c & 1) * HBUF, smem + 2 * HBUF + cstage * BSTAGE, (T / 3) * HW_ + (T % 3), [&]() {            \
             issue_b(c + (T + SB - 1) / 9, (T + SB - 1) % 9, istage);                                                   \
-            if (halo_piece_at(T, HPIECES) >= 0) issue_halo_piece(halo_piece_at(T, HPIECES), c + 1, (c + 1) & 1);       \
+            if (halo_piece_at(T, HPIECES, GN != 0) >= 0)                                                               \
+                issue_halo_piece(halo_piece_at(T, HPIECES, GN != 0), c + 1, (c + 1) & 1);                              \
         });                                                                                                            \
+        if (GN && T >= 4 && halo_piece_at(T - 4, HPIECES, true) >= 0)     /* landed: older than this step's weight tile */ \
+            gn_piece(halo_piece_at(T - 4, HPIECES, true), c + 1, (c + 1) & 1);                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
         cstage = (cstage + 1 == SB) ? 0 : cstage + 1;                                                                  \
         istage = (istage + 1 == SB) ? 0 : istage + 1;                                                                  \
@@ -224,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     wait_vmcnt3<0>();
     __syncthreads();
     constexpr int WNC = TN * 32, LDC = WNC;
-    static_assert(8 * 32 * LDC * 4 <= SMEM, "epilogue staging exceeds the LDS buffers");
+    static_assert(8 * 32 * LDC * 4 <= PIPE, "epilogue staging exceeds the LDS buffers");
     float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;
     constexpr int V = WNC / 8;
     const int vrow = lane / V, vcol = (lane % V) * 8;
@@ -581,13 +641,14 @@ int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW,
     return 1;
 }
 
-// x [N, H, W, C] (ups: the conv runs over the nearest-x2 upsampled [N, 2H, 2W, C]); bf16 in / bf16 out; bias fp32 [Cout]; rowvec fp32 [M / rows_per_batch][Cout]; residual bf16 [M][Cout]; stats fp32 [M/64][2][Cout].
-int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
-                      const void* zeros, int N, int H, int W, int C, int Cout, int ups, int rows_per_batch, float* stats, hipStream_t stream) {
+static int conv_h3_launch(const void* x, const void* x2, int C1, const float* gn_ab, int gn_fps, int gn_act, const void* w_packed,
+                          const float* bias, const float* rowvec, const void* residual, void* y, const void* zeros, int N, int H, int W, int C,
+                          int Cout, int ups, int rows_per_batch, float* stats, hipStream_t stream) {
     if (!x || !w_packed || !zeros || !y || N <= 0) return V2A_ERR_ARG;
     if (!v2a_conv2d_h3_eligible(N, H, W, C, Cout, 3, 3, 1, 1, 1, 1, ups, 0)) return V2A_ERR_ARG;
     if (ups) { H *= 2; W *= 2; }
-    if ((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)rowvec) & 15) != 0)
+    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)w_packed | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias |
+          (uintptr_t)rowvec | (uintptr_t)gn_ab) & 15) != 0)
         return V2A_ERR_ARG;
     ConvDescH3 p;
     p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = bias; p.rowvec = rowvec; p.residual = (const uint16_t*)residual;
@@ -595,21 +656,48 @@ int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, co
     p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.M = N * H * W; p.K = 9 * C;
     p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.ups = ups ? 1 : 0;
+    p.x2 = (const uint16_t*)x2; p.C1 = x2 ? C1 : C; p.ab = gn_ab; p.fps = gn_fps > 0 ? gn_fps : 1; p.act = gn_act;
     p.tiles_x = W / 16;
     p.tiles_img = (H / 16) * (W / 16);
+    const bool gn = gn_ab != nullptr;
+#define V2A_H3_LAUNCH(...)                                                                                                   \
+    do {                                                                                                                     \
+        if (gn) hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 1>), dim3(tiles), dim3(512), 0, stream, p);                    \
+        else hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 0>), dim3(tiles), dim3(512), 0, stream, p);                       \
+    } while (0)
     if (Cout % 256 == 0) {
         const int tiles = N * p.tiles_img * (Cout / 256);
-        hipLaunchKernelGGL((conv_halo_h3<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, ring of 4 x 16 KB
+        V2A_H3_LAUNCH(2, 4, 4, 2, 4);                                                                  // 256 x 256, ring of 4 x 16 KB
     } else if (H % 32 == 0) {
         p.tiles_img = (H / 32) * (W / 16);
         const int tiles = N * p.tiles_img * (Cout / 128);
-        hipLaunchKernelGGL((conv_halo_h3<4, 2, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 512 x 128, ring of 4 x 8 KB
+        V2A_H3_LAUNCH(4, 2, 4, 2, 4);                                                                  // 512 x 128, ring of 4 x 8 KB
     } else {
         const int tiles = N * p.tiles_img * (Cout / 128);
-        hipLaunchKernelGGL((conv_halo_h3<4, 2, 2, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 128, ring of 4 x 8 KB
+        V2A_H3_LAUNCH(4, 2, 2, 2, 4);                                                                  // 256 x 128, ring of 4 x 8 KB
     }
+#undef V2A_H3_LAUNCH
     V2A_CHECK_LAUNCH();
     return V2A_OK;
+}
+
+// x [N, H, W, C] (ups: the conv runs over the nearest-x2 upsampled [N, 2H, 2W, C]); bf16 in / bf16 out; bias fp32 [Cout]; rowvec fp32 [M / rows_per_batch][Cout]; residual bf16 [M][Cout]; stats fp32 [M/64][2][Cout].
+int v2a_conv2d_fwd_h3(const void* x, const void* w_packed, const float* bias, const float* rowvec, const void* residual, void* y,
+                      const void* zeros, int N, int H, int W, int C, int Cout, int ups, int rows_per_batch, float* stats, hipStream_t stream) {
+    return conv_h3_launch(x, nullptr, C, nullptr, 1, 0, w_packed, bias, rowvec, residual, y, zeros, N, H, W, C, Cout, ups, rows_per_batch,
+                          stats, stream);
+}
+
+// The same conv over act(GroupNorm([x | x2])): the normalisation is applied to the input halo while it sits in LDS, from the
+// per-(sample, channel) scale / shift table `gn_ab` [N / gn_frames][2][C] that v2a_groupnorm_prep_h leaves (gn_frames images of the
+// N belong to one GroupNorm sample; act = 0 none / 1 SiLU).  x [N,H,W,C1], x2 [N,H,W,C-C1] or null; C <= 1024, C1 % 32 == 0.
+int v2a_conv2d_fwd_h3_gn(const void* x, const void* x2, int C1, const float* gn_ab, int gn_frames, int act, const void* w_packed,
+                         const float* bias, const float* rowvec, const void* residual, void* y, const void* zeros, int N, int H, int W, int C,
+                         int Cout, int rows_per_batch, float* stats, hipStream_t stream) {
+    if (!gn_ab || C > 1024 || (x2 && (C1 <= 0 || C1 >= C || C1 % 32)) || (act != 0 && act != ACT_SILU) || gn_frames <= 0 || N % gn_frames)
+        return V2A_ERR_ARG;
+    return conv_h3_launch(x, x2, C1, gn_ab, gn_frames, act, w_packed, bias, rowvec, residual, y, zeros, N, H, W, C, Cout, 0, rows_per_batch,
+                          stats, stream);
 }
 
 // 1 when v2a_conv2d_fwd_t3 takes this problem: the temporal tap of the factorised Conv3d seen as a 2-d conv over [B, F, HW, C] with

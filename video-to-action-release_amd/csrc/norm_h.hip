@@ -215,26 +215,26 @@ size_t v2a_groupnorm_h_workspace_bytes(int N, int S, int C) {
     return ((size_t)N * nchunk * 2 * C + (size_t)N * 2 * C) * sizeof(float);
 }
 
+}  // extern "C"
+
 // y = act(GroupNorm_G(cat[x, x2]) * gamma + beta), all activations bf16 [N][S][C]; mean / rstd ([N][G], fp32) optional outputs.
 // C % 8 == 0, C1 % 8 == 0, C % G == 0.  stats1 / stats2 (optional): per-64-row [2][C_src] sum / sum-of-squares slabs written by
 // v2a_conv2d_fwd_h for x / x2 -- the statistics pass is skipped (S % 64 == 0 required).
-int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                        const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, int act, void* workspace,
-                        size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !gamma || !beta || !y || N <= 0 || S <= 0 || C <= 0 || G <= 0 || C % G || C % 8) return V2A_ERR_ARG;
+static int gn_prep_h(GnDescH& p, const void* x, const void* x2, int C1, const float* gamma, const float* beta, float* mean, float* rstd,
+                     const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, float* ab_out, void* workspace,
+                     size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || N <= 0 || S <= 0 || C <= 0 || G <= 0 || C % G || C % 8) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 8)) return V2A_ERR_ARG;
     if (2 * C * sizeof(float) > 64 * 1024) return V2A_ERR_ARG;
-    GnDescH p;
-    p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.gamma = gamma; p.beta = beta; p.y = (uint16_t*)y;
+    p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.gamma = gamma; p.beta = beta; p.y = nullptr;
     p.mean = mean; p.rstd = rstd;
     p.st1 = stats1; p.st2 = stats2;
     if (stats1 && ((S & 63) || (x2 && !stats2))) return V2A_ERR_ARG;      // 64-row statistic blocks must tile every sample
-    p.N = N; p.S = S; p.C = C; p.C1 = x2 ? C1 : C; p.G = G; p.act = act; p.eps = eps;
+    p.N = N; p.S = S; p.C = C; p.C1 = x2 ? C1 : C; p.G = G; p.act = 0; p.eps = eps;
     gn_chunks_h(N, S, &p.nchunk, &p.rows_per_chunk);
     const size_t need = ((size_t)N * p.nchunk * 2 * C + (size_t)N * 2 * C) * sizeof(float);
     if (!workspace || workspace_bytes < need) return V2A_ERR_WORKSPACE;
     p.partial = (float*)workspace;
-    p.ab = p.partial + (size_t)N * p.nchunk * 2 * C;
     if (!stats1) {
         hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), (size_t)((C >> 3) >= 256 ? 1 : 256 / (C >> 3)) * 2 * C * sizeof(float), stream, p);
         V2A_CHECK_LAUNCH();
@@ -244,12 +244,16 @@ int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamm
         if (nch > p.nchunk) nch = p.nchunk;                       // stay inside the workspace sized for the statistics pass
         p.nchunk = nch;
         p.rows_per_chunk = cdiv(nb, nch);                         // 64-row slabs per chunk
-        p.ab = p.partial + (size_t)N * p.nchunk * 2 * C;
         hipLaunchKernelGGL(gn_reduce_blocks_h, dim3(p.nchunk, N), dim3(256), 0, stream, p);
         V2A_CHECK_LAUNCH();
     }
+    p.ab = ab_out ? ab_out : p.partial + (size_t)N * p.nchunk * 2 * C;      // scale / shift table [N][2][C]
     hipLaunchKernelGGL(gn_finalize_h, dim3(N * G), dim3(64), 0, stream, p);
     V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+static int gn_apply_launch_h(GnDescH& p, hipStream_t stream) {
+    const int N = p.N, S = p.S, C = p.C;
     {   // round-up reciprocal of L8: exact quotient for every idx < 2^31 (Granlund-Montgomery with a 32+s bit magic, s = ceil(log2 d))
         const uint32_t d = (uint32_t)(C / 8);
         uint32_t sft = 0;
@@ -270,4 +274,33 @@ int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamm
     return V2A_OK;
 }
 
+
+extern "C" {
+int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, int act, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream) {
+    if (!y) return V2A_ERR_ARG;
+    GnDescH p;
+    const int rc = gn_prep_h(p, x, x2, C1, gamma, beta, mean, rstd, stats1, stats2, N, S, C, G, eps, nullptr, workspace, workspace_bytes, stream);
+    if (rc != V2A_OK) return rc;
+    p.y = (uint16_t*)y; p.act = act;
+    return gn_apply_launch_h(p, stream);
+}
+// The two halves of v2a_groupnorm_fwd_h on their own.  prep: statistics (or the conv epilogues' blocks) -> per-(sample, channel)
+// scale / shift table ab_out [N][2][C] (fp32, 16-B aligned): y = act(x * ab[n][0][c] + ab[n][1][c]).  A consumer that applies the
+// table itself (v2a_conv2d_fwd_h3_gn: the normalisation happens on the conv's input tile in LDS) makes the apply pass unnecessary.
+int v2a_groupnorm_prep_h(const void* x, const void* x2, int C1, const float* gamma, const float* beta, float* mean, float* rstd,
+                         const float* stats1, const float* stats2, int N, int S, int C, int G, float eps, float* ab_out, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+    if (!ab_out || ((uintptr_t)ab_out & 15)) return V2A_ERR_ARG;
+    GnDescH p;
+    return gn_prep_h(p, x, x2, C1, gamma, beta, mean, rstd, stats1, stats2, N, S, C, G, eps, ab_out, workspace, workspace_bytes, stream);
+}
+int v2a_groupnorm_apply_h(const void* x, const void* x2, int C1, const float* ab, void* y, int N, int S, int C, int act, hipStream_t stream) {
+    if (!x || !ab || !y || N <= 0 || S <= 0 || C <= 0 || C % 8 || (x2 && (C1 <= 0 || C1 >= C || C1 % 8))) return V2A_ERR_ARG;
+    GnDescH p = {};
+    p.x = (const uint16_t*)x; p.x2 = (const uint16_t*)x2; p.y = (uint16_t*)y; p.ab = (float*)ab;
+    p.N = N; p.S = S; p.C = C; p.C1 = x2 ? C1 : C; p.G = 1; p.act = act;
+    return gn_apply_launch_h(p, stream);
+}
 }  // extern "C"

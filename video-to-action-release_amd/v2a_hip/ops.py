@@ -426,10 +426,54 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+_GN_FUSE = os.environ.get('V2A_GN_FUSE', '1') != '0'
+
+
+def gn_fusable(N, H, W, C, Cout, KH, KW, stride, pad, ups):
+    """True when a GroupNorm + activation in front of this conv can run inside the halo kernel (v2a_conv2d_fwd_h3_gn)."""
+    return bool(_GN_FUSE and not ups and C <= 1024 and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
+                and lib.v2a_conv2d_h3_eligible(N, H, W, C, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1], 0, 0))
+
+
+class PendingGN:
+    """A GroupNorm + activation whose statistics are done (scale / shift table `ab` [N][2][C]) and whose apply pass has not run:
+    either the consuming conv applies it to its input tile in LDS, or `apply()` materialises the normalised tensor."""
+
+    def __init__(self, x, x2, ab, act):
+        self.x, self.x2, self.ab, self.act = x, x2, ab, act
+        self.N, self.S, self.C1 = x.shape
+        self.C = self.C1 + (x2.shape[-1] if x2 is not None else 0)
+
+    def apply(self):
+        y = torch.empty((self.N, self.S, self.C), dtype=torch.bfloat16, device=self.x.device)
+        check(lib.v2a_groupnorm_apply_h(self.x.data_ptr(), _p(self.x2), self.C1, self.ab.data_ptr(), y.data_ptr(), self.N, self.S, self.C,
+                                        ACT[self.act], _stream()), "groupnorm_apply_h")
+        return y
+
+
+def groupnorm_prep_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None, stats2=None):
+    """Statistics half of groupnorm_fwd_h: returns a PendingGN (same arguments)."""
+    _chk_h(x, "x")
+    N, S, C1 = x.shape
+    C = C1 + (x2.shape[-1] if x2 is not None else 0)
+    if x2 is not None:
+        _chk_h(x2, "x2")
+    wsb = lib.v2a_groupnorm_h_workspace_bytes(N, S, C)
+    ws = workspace(wsb, x.device)
+    if stats is None or S % 64 or (x2 is not None and stats2 is None):
+        stats = stats2 = None
+    ab = torch.empty((N, 2, C), dtype=torch.float32, device=x.device)
+    check(lib.v2a_groupnorm_prep_h(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), None, None, _p(stats), _p(stats2),
+                                   N, S, C, G, eps, ab.data_ptr(), ws.data_ptr(), wsb, _stream()), "groupnorm_prep_h")
+    return PendingGN(x, x2, ab, act)
+
+
 def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1, residual=None,
-             ups=False, out_f32=False, idil=1, out_hw=None, y=None, want_stats=False, defer=False):
+             ups=False, out_f32=False, idil=1, out_hw=None, y=None, want_stats=False, defer=False, pre_gn=None):
     """bf16-storage conv: x [N,H,W,C1] (+x2) bf16, w_packed bf16 [Cout][KH][KW][C1+C2], bias / rowvec fp32, residual bf16.
-    Returns bf16 [N,OH,OW,Cout] (fp32 when out_f32).  Needs C1 % 64 == 0 and C2 % 64 == 0."""
+    Returns bf16 [N,OH,OW,Cout] (fp32 when out_f32).  Needs C1 % 64 == 0 and C2 % 64 == 0.
+    pre_gn (a PendingGN over [x | x2]): the conv input is act(GroupNorm(.)) of the given tensors, applied inside the halo kernel --
+    the caller checked gn_fusable() first."""
     _chk_h(x, "x")
     N, H, W, C1 = x.shape
     C2 = 0
@@ -451,6 +495,14 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     else:
         out_f32 = y.dtype == torch.float32
+    if pre_gn is not None:
+        assert gn_fusable(N, H, W, C1 + C2, Cout, KH, KW, stride, pad, ups) and idil == 1 and not out_f32 and res_f is None and not defer
+        stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
+        check(lib.v2a_conv2d_fwd_h3_gn(x.data_ptr(), _p(x2), C1, pre_gn.ab.data_ptr(), N // pre_gn.N, ACT[pre_gn.act], w_packed.data_ptr(),
+                                       _p(bias), _p(rowvec), _p(res_h), y.data_ptr(), _zero_line(x.device).data_ptr(), N, H, W, C1 + C2, Cout,
+                                       rows_per_batch, _p(stats), _stream()), "conv2d_fwd_h3_gn")
+        last_kernel[0] = f"conv_halo_h3_gn<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
+        return (y, stats) if want_stats else y
     if (idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16 and not defer and x2 is None
             and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
             and lib.v2a_conv2d_h3_eligible(N, H, W, C1, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, C2)):

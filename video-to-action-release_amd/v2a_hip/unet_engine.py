@@ -95,6 +95,18 @@ class _Packs:
         return ent[1]
 
 
+class _LazyGN:
+    """GroupNorm + activation of a [B,F,H,W,C] tensor whose apply pass is postponed (ops.PendingGN): the ResBlock convs that can,
+    normalise their input inside the conv kernel; every other consumer calls `materialize()`."""
+
+    def __init__(self, pending, shape, frames_separate):
+        self.pending, self.shape, self.frames_separate = pending, tuple(shape), frames_separate
+        self.dtype = torch.bfloat16
+
+    def materialize(self):
+        return self.pending.apply().view(self.shape)
+
+
 class UNetEngine:
     def __init__(self, cfg, params: dict, prefix="unet."):
         self.cfg = cfg
@@ -135,13 +147,24 @@ class UNetEngine:
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
         t_half = has_t and cout % 64 == 0
-        x4 = x.view(B * Fr, H, W, C)
-        x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
         sp_f32 = (has_t and not t_half) or (out_f32 and not has_t)
+        pre_gn = None
+        if isinstance(x, _LazyGN):
+            assert x2 is None
+            if (not sp_f32 and not x.frames_separate
+                    and ops.gn_fusable(B * Fr, H, W, C, cout, k, k, (stride, stride), (k // 2, k // 2), ups)):
+                pre_gn = x.pending                       # normalised inside the halo conv: the GroupNorm apply pass never runs
+                x4 = pre_gn.x.view(B * Fr, H, W, pre_gn.C1)
+                x24 = None if pre_gn.x2 is None else pre_gn.x2.view(B * Fr, H, W, -1)
+            else:
+                x = x.materialize()
+        if pre_gn is None:
+            x4 = x.view(B * Fr, H, W, C)
+            x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
         y = ops.conv2d_h(x4, self.w(name + ".spatial_conv.weight", half=True), self.p(name + ".spatial_conv.bias"), cout, k, k,
                          (stride, stride), (k // 2, k // 2), x2=x24, ups=ups, rowvec=None if has_t else rowvec, rows_per_batch=1,
                          residual=None if (has_t or residual is None) else residual.view(B * Fr, residual.shape[2], residual.shape[3], cout),
-                         out_f32=sp_f32, want_stats=not has_t and not sp_f32)
+                         out_f32=sp_f32, want_stats=not has_t and not sp_f32, pre_gn=pre_gn)
         stats = None
         if not has_t and not sp_f32:
             y, stats = y
@@ -170,7 +193,7 @@ class UNetEngine:
     def conv3d(self, x, name, cout, stride=1, ups=False, x2=None, rowvec=None, residual=None, out_f32=False):
         """x [B,F,H,W,C] (+x2) -> [B,F,OH,OW,cout].  rowvec [B,cout] / residual [B,F,OH,OW,cout] land in the LAST kernel."""
         B, Fr, H, W, C = x.shape
-        if x.dtype == torch.bfloat16:
+        if x.dtype == torch.bfloat16:                      # (a _LazyGN reports bf16)
             return self._conv3d_h(x, name, cout, stride, ups, x2, rowvec, residual, out_f32)
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
@@ -223,13 +246,19 @@ class UNetEngine:
         out._gn_stats = stats
         return out
 
-    def gn_silu(self, x, name, act="silu", x2=None, frames_separate=False):
-        """GroupNorm32 over (C/32 x F x H x W) per sample (or per frame when frames_separate), fused activation."""
+    def gn_silu(self, x, name, act="silu", x2=None, frames_separate=False, lazy=False):
+        """GroupNorm32 over (C/32 x F x H x W) per sample (or per frame when frames_separate), fused activation.
+        lazy (bf16 storage): only the statistics run; returns a _LazyGN for conv3d, which applies the normalisation inside its
+        3x3 kernel when it can and materialises it otherwise."""
         B, Fr, H, W, C1 = x.shape
         C = C1 + (0 if x2 is None else x2.shape[-1])
         N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
         x3 = x.view(N, S, C1)
         x23 = None if x2 is None else x2.view(N, S, -1)
+        if lazy and x.dtype == torch.bfloat16 and ops._GN_FUSE:
+            pg = ops.groupnorm_prep_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
+                                      stats=getattr(x, "_gn_stats", None), stats2=None if x2 is None else getattr(x2, "_gn_stats", None))
+            return _LazyGN(pg, (B, Fr, H, W, C), frames_separate)
         if x.dtype == torch.bfloat16:
             return ops.groupnorm_fwd_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
                                        stats=getattr(x, "_gn_stats", None),
@@ -245,10 +274,10 @@ class UNetEngine:
 
     def resblock(self, x, name, cin, cout, semb, x2=None):
         B = x.shape[0]
-        a = self.gn_silu(x, name + ".in_layers.0", x2=x2)
+        a = self.gn_silu(x, name + ".in_layers.0", x2=x2, lazy=True)
         eo = ops.linear(semb, self.p(name + ".emb_layers.1.weight"), self.p(name + ".emb_layers.1.bias"))      # [B,cout]
         h = self.conv3d(a, name + ".in_layers.2", cout, rowvec=eo)
-        a2 = self.gn_silu(h, name + ".out_layers.0")
+        a2 = self.gn_silu(h, name + ".out_layers.0", lazy=True)
         if self.has(name + ".skip_connection.spatial_conv.weight"):
             xs = self.conv3d(x, name + ".skip_connection", cout, x2=x2)
         else:
