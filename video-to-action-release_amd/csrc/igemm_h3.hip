@@ -154,20 +154,28 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     // fused GroupNorm: this thread normalises the piece IT fetched (its own vmcnt wait covers the landing), in place:
     // y = act(x * a[n, c] + b[n, c]) on eight channels, rounded back to bf16 -- the arithmetic of gn_apply_h.  Padding pixels stay 0.
     float* ab_lds = reinterpret_cast<float*>(smem + PIPE);
+    // every piece of a thread carries the same eight channels of a chunk ((q >> 4) & 3 does not depend on the piece index: 512 / 16 is a
+    // multiple of 4), so the scale / shift of those channels is fetched once per chunk, not once per piece
+    const int gn_cp8 = ((tid & 3) ^ ((tid >> 4) & 3)) << 3;
+    f32x4 gn_a0, gn_a1, gn_b0, gn_b1;
+    auto gn_load_ab = [&](int chunk_idx) {
+        const int ch0 = (chunk_idx < nchunks ? chunk_idx : 0) * 32 + gn_cp8;
+        gn_a0 = *reinterpret_cast<const f32x4*>(ab_lds + ch0); gn_a1 = *reinterpret_cast<const f32x4*>(ab_lds + ch0 + 4);
+        gn_b0 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0); gn_b1 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0 + 4);
+    };
+    // (Pinning this arithmetic between the step's MFMAs -- one channel behind every second MFMA -- was tried: 256 x 256 tiles -2 %,
+    // 512 x 128 tiles +5 %, end to end slower; it runs behind the MFMA issue instead, overlapping the matrix pipe's tail and the partner wave.)
     auto gn_piece = [&](int j, int chunk_idx, int hb) {
         if (h_off[j] == 0xffffffffu || chunk_idx >= nchunks) return;
         const int q = j * 512 + tid;
-        const int ch0 = chunk_idx * 32 + (((q & 3) ^ ((q >> 4) & 3)) << 3);
         uint4* slot = reinterpret_cast<uint4*>(smem + hb * HBUF + q * 16);
         const uint4 u = *slot;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ab_lds + ch0), a1 = *reinterpret_cast<const f32x4*>(ab_lds + ch0 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0), b1 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0 + 4);
         float f[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
                       __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
         float o[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float z0 = f[e] * a0[e] + b0[e], z1 = f[e + 4] * a1[e] + b1[e];
+            const float z0 = f[e] * gn_a0[e] + gn_b0[e], z1 = f[e + 4] * gn_a1[e] + gn_b1[e];
             o[e] = p.act == ACT_SILU ? v2a_silu_fast(z0) : z0;
             o[e + 4] = p.act == ACT_SILU ? v2a_silu_fast(z1) : z1;
         }
@@ -220,6 +228,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
         if (tid * 4 < 2 * p.C) *reinterpret_cast<f32x4*>(ab_lds + tid * 4) = abv;
         wait_vmcnt3<(SB - 1) * BL>();                      // this thread's halo pieces of chunk 0 (the weight tiles stay in flight)
         __syncthreads();                                   // scale / shift visible
+        gn_load_ab(0);
 #pragma unroll
         for (int j = 0; j < HPIECES; ++j) gn_piece(j, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // published by the barrier of the first step
@@ -265,8 +274,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
             if (halo_piece_at(T, HPIECES, GN != 0) >= 0)                                                               \
                 issue_halo_piece(halo_piece_at(T, HPIECES, GN != 0), c + 1, (c + 1) & 1);                              \
         });                                                                                                            \
-        if (GN && T >= 4 && halo_piece_at(T - 4, HPIECES, true) >= 0)     /* landed: older than this step's weight tile */ \
+        if (GN && T >= 4 && halo_piece_at(T - 4, HPIECES, true) >= 0) {   /* landed: older than this step's weight tile */ \
+            if (T == 4) gn_load_ab(c + 1);                                                                             \
             gn_piece(halo_piece_at(T - 4, HPIECES, true), c + 1, (c + 1) & 1);                                         \
+        }                                                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
         cstage = (cstage + 1 == SB) ? 0 : cstage + 1;                                                                  \
         istage = (istage + 1 == SB) ? 0 : istage + 1;                                                                  \
