@@ -60,12 +60,12 @@ for leg_name in ("policy", "video", "video_bf16"):
     for k, v in out[leg_name].items():
         m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
         mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)(?:, \d+)?>", k)
-        m3 = re.match(r"(conv_halo_h3|conv_igemm_h2)<(\d+), (\d+), (\d+), (\d+), \d+>", k)      # <WAVES_M, WAVES_N, TM, TN, SB> -> BM x BN
+        m3 = re.match(r"(conv_halo_h3|conv_igemm_h2)<(\d+), (\d+), (\d+), (\d+), \d+(?:, (\d+))?>", k)      # <WAVES_M, WAVES_N, TM, TN, SB[, GN]> -> BM x BN
         mf = re.match(r"conv_frames_h3<(\d+)>", k)
         if m or mh or m3 or mf:
             if m3:
                 wm_, wn_, tm_, tn_ = (int(m3.group(i)) for i in (2, 3, 4, 5))
-                key = f"{m3.group(1)}<{wm_ * tm_ * 32}x{wn_ * tn_ * 32}>"
+                key = f"{m3.group(1)}{'_gn' if m3.group(6) == '1' else ''}<{wm_ * tm_ * 32}x{wn_ * tn_ * 32}>"
             elif mf:
                 key = f"conv_frames_h3<{int(mf.group(1)) * 64}x128>"
             else:
