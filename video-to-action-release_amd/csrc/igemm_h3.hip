@@ -164,7 +164,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
         gn_b0 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0); gn_b1 = *reinterpret_cast<const f32x4*>(ab_lds + p.C + ch0 + 4);
     };
     // (Pinning this arithmetic between the step's MFMAs -- one channel behind every second MFMA -- was tried: 256 x 256 tiles -2 %,
-    // 512 x 128 tiles +5 %, end to end slower; it runs behind the MFMA issue instead, overlapping the matrix pipe's tail and the partner wave.)
+    // 512 x 128 tiles +5 %, end to end slower; letting the first-dispatched half of the waves normalise BEFORE their MFMAs and the other
+    // half after -- role alternation of the two waves of a SIMD -- cost +15 %: the step barrier waits for the slower half.  It runs behind
+    // the MFMA issue instead, overlapping the matrix pipe's tail and the partner wave.)
     auto gn_piece = [&](int j, int chunk_idx, int hb) {
         if (h_off[j] == 0xffffffffu || chunk_idx >= nchunks) return;
         const int q = j * 512 + tid;
