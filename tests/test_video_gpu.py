@@ -64,6 +64,42 @@ def test_unet_forward_is_bitwise_reproducible(golden_dir, storage):
         v2a_hip.set_video_storage("f32")
 
 
+def test_bf16_unet_with_fused_groupnorm_equals_the_unfused_forward():
+    """The GroupNorm + SiLU that the bf16-storage ResBlocks fold into their 3x3 halo convs (v2a_conv2d_fwd_h3_gn) uses the arithmetic
+    of the stand-alone apply pass, so a full-size Unet_Libero forward must not change by a bit when the fusion is switched off
+    (B = 4: the 128x128 and 64x64 levels take the fused kernel, the deeper ones materialise the normalised tensor)."""
+    import v2a_hip
+    from v2a_hip import ops
+    from flowdiffusion.flowdiffusion.unet import Unet_Libero
+    torch.manual_seed(5)
+    big = Unet_Libero().to("cuda:0").eval()
+    xb, tb = torch.randn(4, 24, 128, 128, device="cuda:0"), torch.tensor([3, 40, 77, 99], device="cuda:0")
+    teb = torch.randn(4, 10, 512, device="cuda:0")
+    v2a_hip.set_video_storage("bf16")
+    old = ops._GN_FUSE
+    try:
+        ops._GN_FUSE = True
+        seen = []
+        orig = ops.conv2d_h
+
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            seen.append(ops.last_kernel[0])
+            return r
+        ops.conv2d_h = spy
+        try:
+            z1 = big(xb, tb, task_embed=teb).clone()
+        finally:
+            ops.conv2d_h = orig
+        assert any(n.startswith("conv_halo_h3_gn") for n in seen)
+        ops._GN_FUSE = False
+        z0 = big(xb, tb, task_embed=teb)
+        assert torch.isfinite(z0).all() and torch.equal(z0, z1)
+    finally:
+        ops._GN_FUSE = old
+        v2a_hip.set_video_storage("f32")
+
+
 def _tiny_fp64_sample(sd, x_cond, te, steps, gw, seed=1234):
     """The same sampling loop in fp64 (CPU oracle with its fp32 casts lifted): the yard-stick for 'how exact is the reference's own
     fp32 run' -- a tolerance above 1e-4 is only accepted up to a small multiple of that deviation."""
