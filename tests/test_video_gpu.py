@@ -141,6 +141,34 @@ def test_sampler_vs_golden(golden_dir, name, steps, gw):
     assert err_exact <= max(TOL, 4 * ref_dev), (err_exact, ref_dev)
 
 
+def test_ddpm_sampler_with_variance_temperature():
+    """`var_temp != 1` (goal_diffusion.py:365,578: the ancestral noise is scaled by the temperature): the fused denoise step takes the
+    factor as sigma * var_temp; 100 DDPM steps of the tiny UNet against the CPU oracle on the same injected noise, and the
+    temperature must actually change the sample."""
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    from oracle import goal_diffusion as OG
+    import oracle.video_unet as VU
+    m, sd, _ = _tiny()
+    cfg = VU.UNetCfg(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+                     num_head_channels=16)
+    gen = torch.Generator().manual_seed(99)
+    x_cond, te = torch.rand(2, 3, 32, 32, generator=gen), torch.randn(2, 4, 512, generator=gen)
+    nz = [torch.randn(2, 9, 32, 32, generator=gen) for _ in range(101)]
+    outs = {}
+    for vt in (0.6, 1.0):
+        d = GoalGaussianDiffusion(m, image_size=(32, 32), channels=9, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
+                                  beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0, var_temp=vt).to("cuda:0")
+        it = iter(nz)
+        d.__dict__["_noise_hook"] = lambda shape: next(it)
+        outs[vt] = d.sample(x_cond.cuda(), te.cuda(), batch_size=2).cpu()
+    ref = OG.sample(lambda x, t, e: VU.unet_libero_forward(sd, x, t, e, cfg), OG.cosine_tables(), nz, x_cond, te, guidance_weight=0.0,
+                    var_temp=0.6, sampling_timesteps=100)
+    err = rel(outs[0.6], ref)
+    print(f"[sampler var_temp=0.6] HIP vs oracle {err:.2e}")
+    assert err <= TOL, err
+    assert rel(outs[0.6], outs[1.0]) > 1e-2
+
+
 def test_full_size_sampler_multi_step_and_batch_rows():
     """error accumulation over sequential FULL-SIZE UNet calls, and C3's batch of 16 inside the GPU suite.
     (a) 5 DDIM steps of the 201 M-parameter Unet_Libero at B=2 against the CPU oracle on the same injected noise (1e-4);
@@ -213,7 +241,7 @@ def test_cpu_unet_raises():
         Unet_Tiny()(torch.zeros(1, 12, 32, 32), torch.zeros(1, dtype=torch.long), torch.zeros(1, 4, 512))
 
 
-@pytest.mark.parametrize("cls_name,ci,res,frames", [("UnetThor", 3, 16, 2), ("UnetMWFlow", 2, 32, 2), ("UnetBridge", 3, 16, 2)])
+@pytest.mark.parametrize("cls_name,ci,res,frames", [("UnetThor", 3, 16, 2), ("UnetMWFlow", 2, 32, 2), ("UnetBridge", 3, 16, 2), ("UnetMW", 3, 32, 2)])
 def test_other_unet_wrappers_vs_oracle(cls_name, ci, res, frames):
     """the other AVDC wrappers (same kernels, other hyper-parameters; UnetBridge has 160 base channels -> GroupNorm
     groups of 5/10/20 channels, UnetMWFlow packs 2 flow channels per frame) against the CPU oracle with the same parameters."""
