@@ -137,8 +137,17 @@ struct Child {
     uint64_t ohdr;
 };
 
-bool walk_group_btree(H5* f, uint64_t node, uint64_t heap, std::vector<Child>* out, int depth) {
+// A malformed file may link B-tree nodes into cycles: besides the depth limit every walk spends from a node budget (a v1 B-tree
+// node is >= 24 bytes, so a well-formed file can never hold more nodes than size / 24).
+bool spend_node(H5* f, uint64_t* budget) {
+    if (*budget == 0) return fail(f, "B-tree visits more nodes than the file can hold (cycle?)");
+    --*budget;
+    return true;
+}
+
+bool walk_group_btree(H5* f, uint64_t node, uint64_t heap, std::vector<Child>* out, int depth, uint64_t* budget) {
     if (depth > 32) return fail(f, "group B-tree deeper than 32 levels");
+    if (!spend_node(f, budget)) return false;
     Cur c(f, f->base + node);
     if (c.sig("SNOD")) {
         c.skip(2);
@@ -162,7 +171,7 @@ bool walk_group_btree(H5* f, uint64_t node, uint64_t heap, std::vector<Child>* o
         t.skip(f->sl);                   // key i
         const uint64_t child = t.u(f->so);
         if (!t.ok) return fail(f, "truncated B-tree node");
-        if (!walk_group_btree(f, child, heap, out, depth + 1)) return false;
+        if (!walk_group_btree(f, child, heap, out, depth + 1, budget)) return false;
     }
     return true;
 }
@@ -185,7 +194,8 @@ bool group_children(H5* f, uint64_t ohdr, std::vector<Child>* out) {
         hp = c.u(f->so);
         if (!c.ok) return fail(f, "bad symbol table message");
     }
-    return walk_group_btree(f, bt, hp, out, 0);
+    uint64_t budget = f->size / 24 + 16;
+    return walk_group_btree(f, bt, hp, out, 0, &budget);
 }
 
 bool resolve(H5* f, const char* path, uint64_t* ohdr) {
@@ -258,8 +268,12 @@ bool dataset_info(H5* f, uint64_t ohdr, DsInfo* d) {
         if (bits0 & 1) return fail(f, "big-endian data: not supported");
         d->is_signed = d->tclass == 0 ? ((bits0 >> 3) & 1) : 1;
     }
+    if (d->esize < 1 || d->esize > 16) return fail(f, "unsupported element size");
     uint64_t n = (uint64_t)d->esize;
-    for (int i = 0; i < d->ndim; ++i) n *= d->dims[i];
+    for (int i = 0; i < d->ndim; ++i) {
+        if (d->dims[i] != 0 && n > (UINT64_MAX >> 1) / d->dims[i]) return fail(f, "dataset size overflows 63 bits");
+        n *= d->dims[i];
+    }
     d->nbytes = n;
     {   // layout
         Cur c(f, lay->pos);
@@ -302,8 +316,9 @@ bool dataset_info(H5* f, uint64_t ohdr, DsInfo* d) {
 }
 
 // copy every chunk under `node` into its place of the row-major destination
-bool read_chunks(H5* f, const DsInfo& d, uint64_t node, uint8_t* dst, int depth) {
+bool read_chunks(H5* f, const DsInfo& d, uint64_t node, uint8_t* dst, int depth, uint64_t* budget) {
     if (depth > 32) return fail(f, "chunk B-tree deeper than 32 levels");
+    if (!spend_node(f, budget)) return false;
     Cur t(f, f->base + node);
     if (!t.sig("TREE")) return fail(f, "expected a TREE node in a chunk B-tree");
     const int ntype = (int)t.u(1), level = (int)t.u(1), used = (int)t.u(2);
@@ -311,6 +326,10 @@ bool read_chunks(H5* f, const DsInfo& d, uint64_t node, uint8_t* dst, int depth)
     if (ntype != 1) return fail(f, "chunk B-tree node has the wrong type");
     const int rank = d.cnd - 1;
     if (rank != d.ndim) return fail(f, "chunk rank does not match the dataspace");
+    if (rank < 1 || rank > 8) return fail(f, "chunked dataset needs 1..8 dimensions");
+    if (d.cdims[rank] != (uint32_t)d.esize) return fail(f, "chunk element size does not match the datatype");
+    for (int k = 0; k < rank; ++k)
+        if (d.cdims[k] == 0 || d.dims[k] == 0) return fail(f, "zero-sized chunk or dataset dimension");
     for (int i = 0; i < used; ++i) {
         const uint64_t csz = t.u(4);
         const uint64_t mask = t.u(4);
@@ -319,12 +338,15 @@ bool read_chunks(H5* f, const DsInfo& d, uint64_t node, uint8_t* dst, int depth)
         const uint64_t child = t.u(f->so);
         if (!t.ok) return fail(f, "truncated chunk B-tree node");
         if (level > 0) {
-            if (!read_chunks(f, d, child, dst, depth + 1)) return false;
+            if (!read_chunks(f, d, child, dst, depth + 1, budget)) return false;
             continue;
         }
         if (mask != 0) return fail(f, "filtered chunk: not supported");
         uint64_t want = d.esize;
-        for (int k = 0; k < rank; ++k) want *= d.cdims[k];
+        for (int k = 0; k < rank; ++k) {
+            if (want > f->size / d.cdims[k] + 1) return fail(f, "chunk larger than the file");
+            want *= d.cdims[k];
+        }
         if (csz != want) return fail(f, "chunk size does not match its dimensions (filtered?)");
         if (f->base + child > f->size || csz > f->size - (f->base + child)) return fail(f, "chunk outside the file");
         const uint8_t* src = f->map + f->base + child;
@@ -419,7 +441,9 @@ int v2a_h5_exists(void* h, const char* path) {
     uint64_t oh;
     f->err.clear();
     if (resolve(f, path, &oh)) return 1;
-    return f->err.rfind("no such object", 0) == 0 ? 0 : -1;
+    // h5py's `path in f` is False both for a missing member and for a path that runs through a dataset
+    if (f->err.rfind("no such object", 0) == 0 || f->err == "not a group") { f->err.clear(); return 0; }
+    return -1;
 }
 
 // names of the members of group `path`, '\n'-separated, into buf (cap bytes incl. the terminator).  Returns the number of members,
@@ -477,7 +501,8 @@ int v2a_h5_read(void* h, const char* path, void* dst, size_t dst_bytes) {
     }
     if (d.chunk_btree == UNDEF) { f->err = "chunked dataset without an index"; return -1; }
     memset(dst, 0, dst_bytes);            // chunks never written read as the (zero) fill value
-    return read_chunks(f, d, d.chunk_btree, (uint8_t*)dst, 0) ? 0 : -1;
+    uint64_t budget = f->size / 24 + 16;
+    return read_chunks(f, d, d.chunk_btree, (uint8_t*)dst, 0, &budget) ? 0 : -1;
 }
 
 }  // extern "C"

@@ -73,7 +73,8 @@ class RandSamH5:
         return out
 
     def num_episodes(self, task):
-        return sorted(int(k) for k in self.members(task))[-1] + 1           # lb_online_trainer_v7.py:246-252
+        # lb_online_trainer_v7.py:246-252 (episode groups are named by their integer index; anything else in the task group is ignored)
+        return sorted(int(k) for k in self.members(task) if k.isdigit())[-1] + 1
 
     def has(self, task, i_ep):
         r = self._lib.v2a_h5_exists(self._h, f"{task}/{i_ep}".encode())

@@ -259,24 +259,53 @@ class WgradCollector:
     """Weight gradients whose split-K reduce is postponed: every layer keeps its slabs in a scratch buffer of its own (owned here,
     keyed by the gradient's address) and ONE multi-tensor launch (`flush`) finishes all of them -- 40-55 reduce launches per train
     step become three.  The device tables are cached per list of pending reduces, so the captured step re-uses the tables its eager
-    warm-up steps built (flush never copies from the host during capture)."""
+    warm-up steps built (flush never copies from the host during capture).
+
+    Lifetime rules (a captured hipGraph has the raw addresses of its tables and slabs baked in): an entry that was used while a
+    stream was capturing is PINNED and never evicted; other entries are evicted oldest-first, tables beyond MAX_TABLES and slabs beyond
+    MAX_SLABS, and a slab is only evicted while no un-flushed pending item points at it."""
+    MAX_TABLES, MAX_SLABS = 32, 1024
 
     def __init__(self, device):
         self.device = torch.device(device)
-        self.slabs = {}
+        self.slabs = {}             # key -> tensor (insertion / last-use order)
         self.pending = []
-        self.tables = {}
+        self._pending_keys = set()  # slab keys the un-flushed pending items point at
+        self.tables = {}            # key -> (items, work, n)
+        self._pinned_slabs, self._pinned_tables = set(), set()
         self.item_bytes = lib.v2a_wgrad_item_bytes()
 
+    def _evict(self, table, pinned, limit, busy=()):
+        if len(table) <= limit:
+            return
+        for k in list(table):
+            if len(table) <= limit:
+                break
+            if k not in pinned and k not in busy:
+                del table[k]
+
     def slab(self, key, nbytes):
+        capturing = torch.cuda.is_current_stream_capturing()
         t = self.slabs.get(key)
         if t is None or t.numel() < nbytes:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError("weight-gradient slab buffer missing during graph capture; run one eager step first")
-            if len(self.slabs) > 1024:          # callers without stable keys (gradient buffers re-allocated per call): do not hoard
-                self.slabs.clear()
+            if key in self._pinned_slabs:
+                raise RuntimeError("a weight-gradient slab a captured hipGraph points at would have to grow; rebuild the trainer "
+                                   "(its graph) for the new shapes instead of re-using this engine")
+            if key in self._pending_keys:
+                raise RuntimeError("two un-flushed weight gradients share one slab key")
+            # callers without stable keys (gradient buffers re-allocated per call) must not hoard: drop the oldest slabs nothing
+            # pending and no captured graph refers to
+            self._evict(self.slabs, self._pinned_slabs, self.MAX_SLABS, busy=self._pending_keys)
             t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self.slabs.pop(key, None)
             self.slabs[key] = t          # (cached tables that point at the old buffer can never match a pending list again)
+        elif key in self._pending_keys:
+            raise RuntimeError("two un-flushed weight gradients share one slab key")
+        if capturing:
+            self._pinned_slabs.add(key)
+        self._pending_keys.add(key)
         return t
 
     def add(self, item, blocks, form):
@@ -285,28 +314,25 @@ class WgradCollector:
 
     def flush(self):
         pend, self.pending = self.pending, []
+        self._pending_keys = set()
         if not pend:
             return
         key = tuple(pend)
         ent = self.tables.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if ent is None:
-            if torch.cuda.is_current_stream_capturing():
-                if os.environ.get("V2A_DEBUG_WGC"):
-                    for k2 in self.tables:
-                        if len(k2) == len(key):
-                            for i, (a, b) in enumerate(zip(k2, key)):
-                                if a != b:
-                                    diff = [j for j in range(len(a[0])) if a[0][j] != b[0][j]]
-                                    print("[wgc] item", i, "differs at bytes", diff[:40], a[1:], b[1:], flush=True)
-                    print("[wgc] cached keys", [len(k2) for k2 in self.tables], "wanted", len(key), flush=True)
+            if capturing:
                 raise RuntimeError("weight-gradient reduce table missing during graph capture; run one eager step first")
             import numpy as np
             items = np.frombuffer(b"".join(p[0] for p in pend), dtype=np.uint8).copy()
             work = np.array([[i, b, nb, f] for i, (_, nb, f) in enumerate(pend) for b in range(nb)], dtype=np.int32)
-            if len(self.tables) > 32:
-                self.tables.clear()
+            self._evict(self.tables, self._pinned_tables, self.MAX_TABLES)
             ent = (torch.from_numpy(items).to(self.device), torch.from_numpy(work).to(self.device), int(work.shape[0]))
-            self.tables[key] = ent
+        else:
+            del self.tables[key]          # re-insert: most recently used last
+        self.tables[key] = ent
+        if capturing:
+            self._pinned_tables.add(key)
         check(lib.v2a_wgrad_reduce_multi(ent[0].data_ptr(), ent[1].data_ptr(), ent[2], _stream()), "wgrad_reduce_multi")
 
 

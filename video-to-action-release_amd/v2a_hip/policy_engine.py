@@ -144,6 +144,7 @@ class PolicyEngine:
         self._gn_cs = {}
         self._gn_chain = None
         self._gn_tables = {}
+        self._gn_pinned = set()
         # weight gradients: split-K reduces postponed to one multi-tensor launch per chain (ops.WgradCollector)
         self._wgc = None
         self._wgc_on = _os.environ.get("V2A_WGRAD_MULTI_REDUCE", "1") != "0"
@@ -237,11 +238,24 @@ class PolicyEngine:
         the forward conv left a twin of its input, wide enough output); None otherwise (the convs then round on their own)."""
         if x_h is None or cout < 64 or ops.lib.v2a_get_precision() != 1:
             return None
-        tw = getattr(self, "_tw", None)              # left by the GroupNorm backward that produced dy (same storage: no cast launch)
-        if tw is not None and tw.numel() == dy.numel():
-            self._tw = None
+        tw = self._take_tw(dy)                       # left by the GroupNorm backward that produced dy (same storage: no cast launch)
+        if tw is not None:
             return tw.view(dy.shape)
         return ops.cast_h(dy)
+
+    _tw = None
+    _tw_tag = 0
+
+    def _set_tw(self, twin, of):
+        """Remember `twin` as the bf16 copy of the fp32 tensor `of` (tagged with its address: a stale twin is never handed out)."""
+        self._tw, self._tw_tag = twin, (of.data_ptr() if twin is not None else 0)
+
+    def _take_tw(self, of):
+        tw = self._tw
+        if tw is None or self._tw_tag != of.data_ptr() or tw.numel() != of.numel():
+            return None
+        self._tw, self._tw_tag = None, 0
+        return tw
 
     # ------------------------------------------------------------------ weight gradients off the critical path
     def _wg(self, *a, **k):
@@ -272,17 +286,23 @@ class PolicyEngine:
 
     _wgc_active = False
     _dw_names = None
+    _tmp_seq = 0
 
     def _slab_key(self, dw):
         """Stable name of the layer a gradient view belongs to (its slab buffer is kept per layer, not per address: the autograd path
         hands in a fresh arena on every call)."""
         if dw is None or self._dw_names is None:
             return None
-        return self._dw_names.get(dw.data_ptr(), ("tmp", tuple(dw.shape)))
+        name = self._dw_names.get(dw.data_ptr())
+        if name is None:             # a temporary: two of equal shape in one un-flushed chain must not share a slab
+            self._tmp_seq += 1
+            return ("tmp", tuple(dw.shape), self._tmp_seq)
+        return name
 
     def _wg_begin(self):
         """From here on weight gradients only run their main kernels; _wg_flush sums all their split slabs in one launch."""
         self._wgc_active = self._wgc_on and not self.async_wgrad and self._wg_mode != "unet"
+        self._tmp_seq = 0
 
     def _wg_flush(self):
         if self._wgc_active:
@@ -401,7 +421,7 @@ class PolicyEngine:
         tw = [] if (C % 64 == 0 and ops.lib.v2a_get_precision() == 1) else None      # bf16-MFMA mode: the consuming conv's operand twin
         y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs,
                                           twin_out=tw)
-        self._tw = tw[0] if tw else None             # read by the caller right after (x_h of the next conv): no cast launch
+        self._set_tw(tw[0] if tw else None, y)       # taken by the caller right after (x_h of the next conv): no cast launch
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
     def _defer_ok(self, rows, C, G):
@@ -431,7 +451,7 @@ class PolicyEngine:
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                       residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
                                                       dfilm_out=dfilm_out, colsum=cs, defer_params=True, **kw)
-        self._tw = tw[0] if tw else None             # bf16 twin of dx (want_twin): operand of the data / weight gradients that follow
+        self._set_tw(tw[0] if tw else None, dx)      # bf16 twin of dx (want_twin): operand of the data / weight gradients that follow
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
     def _gn_begin(self):
@@ -454,10 +474,17 @@ class PolicyEngine:
             for i, (pre, N, C) in enumerate(chain):
                 rows.append([self._gn_cs[(pre, N, C)].data_ptr(), grads[pre + ".weight"].data_ptr(), grads[pre + ".bias"].data_ptr(), N, C])
                 work += [[i, b] for b in range((C + 63) // 64)]
-            if len(self._gn_tables) > 64:
-                self._gn_tables.clear()
+            for k in list(self._gn_tables):              # evict oldest-first, never a table a captured hipGraph points at
+                if len(self._gn_tables) <= 64:
+                    break
+                if k not in self._gn_pinned:
+                    del self._gn_tables[k]
             ent = (torch.tensor(rows, dtype=torch.int64).to(self.device), torch.tensor(work, dtype=torch.int32).to(self.device), len(work))
-            self._gn_tables[key] = ent
+        else:
+            del self._gn_tables[key]                     # re-insert: most recently used last
+        self._gn_tables[key] = ent
+        if torch.cuda.is_current_stream_capturing():
+            self._gn_pinned.add(key)
         ops.gn_param_grads_multi(*ent)
 
     def encode_fwd(self, key, img_nchw, save):
@@ -483,7 +510,7 @@ class PolicyEngine:
             o1, sl = ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1, x_h=h_tw, defer=dfr) if dfr else \
                 (ops.conv2d(inp, blk["conv1"].pf(), None, co, 3, 3, (s, s), (1, 1), keep_h=k1, x_h=h_tw), None)
             a, s1 = self._gn(o1, blk["pre"] + ".bn1", g, "relu", slabs=sl)
-            a_tw = self._tw
+            a_tw = self._take_tw(a)
             sd = None
             if blk["down"] is not None:
                 idn, sl = ops.conv2d(inp, blk["down"].pf(), None, co, 1, 1, (s, s), (0, 0), x_h=k1[0] if k1 else None, defer=dfr) if dfr else \
@@ -494,7 +521,7 @@ class PolicyEngine:
             o2, sl = ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, x_h=a_tw, defer=dfr) if dfr else \
                 (ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, x_h=a_tw), None)
             h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn, slabs=sl)
-            h_tw = self._tw
+            h_tw = self._take_tw(h)
             st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd, inp_h=k1[0] if k1 else None, a_h=k2[0] if k2 else None))
         feat = h
         B, FH, FW, FC = feat.shape
@@ -604,7 +631,7 @@ class PolicyEngine:
         c0, sl = self._c1d(x, r["c0"], k, x2=x2, keep_h=kx, defer=True) if dfr else (self._c1d(x, r["c0"], k, x2=x2, keep_h=kx), None)
         a0, s0 = self._gn(c0.view(B, 1, T, co), r["pre"] + ".blocks.0.block.1", G, "mish", film=film, slabs=sl)
         a0 = a0.view(B, T, co)
-        a0_tw = self._tw
+        a0_tw = self._take_tw(a0)
         ka = []
         c1, sl = self._c1d(a0, r["c1"], k, keep_h=ka, defer=True, x_h=a0_tw) if dfr else (self._c1d(a0, r["c1"], k, keep_h=ka, x_h=a0_tw), None)
         a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish", slabs=sl)
@@ -648,7 +675,7 @@ class PolicyEngine:
             o = r["film_off"]
             dc0, _, _ = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dfilm_out=self._dfilm_all[:, o:o + 2 * co], dslabs=sl,
                                      want_twin=st.get("x_h") is not None and co >= 64)
-            dc0_tw = self._tw
+            dc0_tw = self._take_tw(dc0)
         else:
             dc0, _, dfilm = self._gn_bwd(st["s0"], da0, grads, want_dfilm=True, dslabs=sl)
             dc0_tw = None
@@ -657,7 +684,7 @@ class PolicyEngine:
             dmgf = _dgrad(df2.view(1, 1, B, -1), cev, None, cev.ci, 1, 1, (1, 1), (0, 0),
                           residual=None if dmgf is None else dmgf.view(1, 1, B, -1)).view(B, -1)
         xh, x2h = st.get("x_h"), st.get("x2_h")
-        self._tw = dc0_tw
+        self._set_tw(dc0_tw, dc0)
         dc0h = self._twin_dy(dc0, xh, co)
         self._wg(x4, dc0, c0v.shape, 1, k, (1, 1), (0, k // 2), x2=x24, dw=grads[c0v.wname], dbias=grads[c0v.bname], x_h=xh, dy_h=dc0h,
                  x2_h=x2h)
