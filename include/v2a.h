@@ -158,6 +158,24 @@ int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f
 int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                            float sa, float s1, float ra, float rm, float c1, float c2, float sigma, float gw, int mode, int final,
                            int frame_ch, v2a_stream_t s);
+/* Table-driven sampler step for ALL three objectives (goal_diffusion.py:499-559 model_predictions; objective 0 pred_noise, 1 pred_x0,
+ * 2 pred_v) with the step index read from device memory, so one captured hipGraph {UNet forward, this step, v2a_video_sampler_advance}
+ * is replayed for every step of p_sample_loop / ddim_sample (:582-641).  table_dev: rows of v2a_video_denoise_row_bytes() bytes =
+ * {sa, s1, ra, rm, c1, c2, sigma, gw: float; mode, final, t, pad: int32} (coefficient meaning as v2a_video_denoise_step).  state_dev:
+ * uint64[3] = {current row, Philox seed, Philox counter of the initial image} or NULL (row step_imm).  noise: explicit tensor, or NULL
+ * with use_philox = 1: drawn in the kernel (the values v2a_philox_normal(seed, state[2] + (row + 1) * ceil(total / 4)) would write), not
+ * drawn at all where sigma = 0.  `out` may alias `img`. */
+int v2a_video_denoise_row_bytes(void);
+int v2a_video_denoise_step2(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
+                            int frame_ch, int objective, const void* table_dev, const uint64_t* state_dev, int step_imm, int use_philox,
+                            v2a_stream_t s);
+/* state_dev[0] += 1; tt[0..B) = t of the new row (the time step the next UNet forward embeds) */
+int v2a_video_sampler_advance(uint64_t* state_dev, const void* table_dev, int64_t* tt, int B, int nrows, v2a_stream_t s);
+/* out_i = x W_i^T + bias_i for n <= v2a_emb_linear_multi_max() weight matrices sharing x [B <= 16][K]: the per-ResBlock `emb_layers`
+ * Linears of the video UNet (guided_diffusion/guided_diffusion/unet.py:204-210,248-257) in one launch.  w / bias / out / couts: HOST arrays. */
+int v2a_emb_linear_multi_max(void);
+int v2a_emb_linear_multi(const float* x, int B, int K, const float* const* w, const float* const* bias, float* const* out, const int* couts,
+                         int n, v2a_stream_t s);
 /* Transformer policy backbone (flowdiffusion/flowdiffusion/diffusion_policy_baseline/transformer_for_diffusion.py:75-110, the
  * torch.nn.MultiheadAttention inside its encoder / decoder layers): softmax(q k^T / sqrt(D) + mask) v per (batch, head); mask = additive
  * float [Tq][Tk] (-inf blocks) or NULL.  q / k / v are column blocks of packed projections: row r of batch b at ptr + (b*T + r)*ld + h*D.
@@ -188,6 +206,7 @@ int v2a_video_loss_bwd(const float* out_cl, const float* img, const float* noise
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
+int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */
 
 /* ---------------------------------------------------------------------------------------------- attention (csrc/attention.hip) */
 /* QKVAttentionLegacy.forward (.../guided_diffusion/unet.py:341-358): qkv [n_frames*L][heads*3*ch] -> out [n_frames*L][heads*ch] */
@@ -338,6 +357,22 @@ int v2a_conv2d_wgrad_h_deferred(const void* x_h, const void* x2_h, const void* d
                                 int accumulate, void* slabs, size_t slab_bytes, void* item_out, int* blocks_out, int* form_out,
                                 v2a_stream_t stream);
 int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwork, v2a_stream_t stream);
+
+/* ---- grouped weight gradients: up to v2a_wgrad_multi_max() gradients of different layers in ONE launch (descriptors travel in the
+ * kernel arguments; replaces the per-layer torch autograd weight-gradient calls of ResNet18 / ConditionalUnet1D in the policy step,
+ * diffuser/diffusion_policy/common/vision_nets.py:29-39, model/conditional_unet1d.py:46-66).
+ * v2a_conv2d_wgrad_describe launches nothing.  want_splits = 0 (planning): writes *variant_out (0 = exact-f32 LDS-DMA body on x / dy,
+ * 1 / 2 = bf16 twin-fed 128- / 64-row body on x_h / dy_h, -1 = not eligible: use v2a_conv2d_wgrad), *tiles_out, *rtiles_out.
+ * want_splits >= 1: also item_out (HOST, v2a_wgrad_item_bytes()), *splits_out (<= want_splits) and the reduce item (ritem_out,
+ * *rblocks_out, *rform_out) for v2a_wgrad_reduce_multi; `slabs` = the layer's own scratch, (splits * Cout * K + splits * Cout) * 4 B.
+ * v2a_conv2d_wgrad_multi: items / variants / tiles are HOST arrays of n entries. */
+int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, const void* x_h, const void* x2_h, const void* dy_h, float* dw,
+                              float* dbias, int N, int H, int W, int C1, int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph,
+                              int pw, int idil, int ups, int accumulate, int want_splits, void* slabs, size_t slab_bytes, void* item_out,
+                              int* variant_out, int* tiles_out, int* rtiles_out, int* splits_out, void* ritem_out, int* rblocks_out,
+                              int* rform_out);
+int v2a_wgrad_multi_max(void);
+int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* tiles, int n, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- random-action episode file (csrc/h5read.hip)
  * Native reader for the HDF5 file of the reference's generator (environment/libero/lb_data/lb_randsam.py:84-104: groups

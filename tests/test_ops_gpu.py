@@ -806,3 +806,64 @@ def test_twin_fed_bf16_wgrad_two_source_concat():
         v2a_hip.set_precision(old)
     close(dw, w.grad, tol=2e-5, what="two-source twin-fed wgrad")
     close(db, b.grad, tol=2e-5, what="two-source twin-fed wgrad: bias")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_grouped_weight_gradients_one_launch_vs_torch(mode):
+    """conv_wgrad_multi_kernel: several layers' weight gradients (ResNet 3x3 at two widths incl. stride 2, a 1x1 downsample, a
+    (1 x 5) ConditionalUnet1D conv with a channel concat, fused bias gradients, one accumulate) described into ONE launch, the split
+    slabs finished by the collector's multi-tensor reduce.  fp32: the exact-f32 64x64 LDS-DMA body; bf16: the twin-fed bodies (inputs
+    exactly representable in bf16, so the products are exact and only the summation order differs from torch).  An ineligible
+    gradient (3 input channels) must be refused by `add`.  Run twice: bitwise reproducible."""
+    import v2a_hip
+    from v2a_hip import ops
+    g = torch.Generator().manual_seed(77)
+    rnd = (lambda *s: torch.randn(*s, generator=g).bfloat16().float()) if mode == "bf16" else (lambda *s: torch.randn(*s, generator=g))
+    # N, Cin, H, W, Cout, (kh, kw), stride, Cin2, bias
+    cases = [(6, 64, 32, 32, 64, (3, 3), 1, 0, False), (5, 64, 16, 16, 128, (3, 3), 2, 0, False), (5, 64, 16, 16, 128, (1, 1), 2, 0, False),
+             (16, 256, 1, 8, 512, (1, 5), 1, 256, True), (3, 128, 16, 16, 128, (3, 3), 1, 0, True), (9, 512, 4, 4, 512, (3, 3), 1, 0, False),
+             (4, 256, 8, 8, 256, (3, 3), 1, 0, True)]     # fp32: cases 0 / 4 / 6 take the halo-tile body (patch width 32 / 16 / 8)
+    old = v2a_hip.set_precision(mode)
+    try:
+        col = ops.WgradCollector(dev())
+        prob = []
+        for (N, Cin, H, W, Cout, (kh, kw), s_, C2, bias) in cases:
+            x = rnd(N, Cin + C2, H, W)
+            w = (torch.randn(Cout, Cin + C2, kh, kw, generator=g) / math.sqrt((Cin + C2) * kh * kw)).requires_grad_(True)
+            b = torch.zeros(Cout, requires_grad=True)
+            y = F.conv2d(x, w, b, stride=s_, padding=(kh // 2, kw // 2))
+            dy = rnd(*y.shape)
+            y.backward(dy)
+            xd = nhwc(x[:, :Cin])
+            x2d = nhwc(x[:, Cin:]) if C2 else None
+            dyd = nhwc(dy)
+            tw = mode == "bf16"
+            prob.append(dict(args=(xd, dyd, tuple(w.shape), kh, kw, (s_, s_), (kh // 2, kw // 2)),
+                             kw=dict(x2=x2d, x_h=ops.cast_h(xd) if tw else None, dy_h=ops.cast_h(dyd) if tw else None,
+                                     x2_h=ops.cast_h(x2d) if (tw and C2) else None),
+                             ref_w=w.grad, ref_b=b.grad if bias else None, Cout=Cout, shape=tuple(w.shape)))
+        outs = []
+        for rep in range(2):
+            batch = ops.WgradBatch(col)
+            res = []
+            for i, pr in enumerate(prob):
+                dw = torch.full(pr["shape"], 0.25 if i == 1 else float("nan"), device=dev())
+                db = torch.full((pr["Cout"],), float("nan"), device=dev()) if pr["ref_b"] is not None else None
+                assert batch.add(*pr["args"], dw=dw, dbias=db, accumulate=(i == 1), slab_key=("t", i), **pr["kw"])
+                res.append((dw, db))
+            x3 = torch.randn(2, 16, 16, 3, device=dev())
+            assert not batch.add(x3, torch.randn(2, 16, 16, 64, device=dev()), (64, 3, 3, 3), 3, 3, (1, 1), (1, 1),
+                                 dw=torch.empty(64, 3, 3, 3, device=dev()))
+            batch.launch()
+            assert ops.last_kernel[0] == "conv_wgrad_multi"
+            col.flush()
+            torch.cuda.synchronize()
+            outs.append(res)
+        for i, (pr, (dw, db)) in enumerate(zip(prob, outs[0])):
+            close(dw - (0.25 if i == 1 else 0.0), pr["ref_w"], tol=2e-5, what=f"grouped wgrad {i}")
+            if db is not None:
+                close(db, pr["ref_b"], tol=2e-5, what=f"grouped wgrad {i}: bias grad")
+        for (a, ab), (b2, bb) in zip(outs[0], outs[1]):
+            assert torch.equal(a, b2) and (ab is None or torch.equal(ab, bb))
+    finally:
+        v2a_hip.set_precision(old)

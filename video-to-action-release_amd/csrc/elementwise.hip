@@ -342,6 +342,141 @@ __global__ void philox_normal_kernel(float* out, size_t n, uint64_t seed, const 
             if (q * 4 + j < n) out[q * 4 + j] = z[j];
     }
 }
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t ctr, float (&z)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+        const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float rr = sqrtf(-2.0f * logf(u1));
+        z[2 * h] = rr * cosf(6.283185307179586f * u2);
+        z[2 * h + 1] = rr * sinf(6.283185307179586f * u2);
+    }
+}
+
+// Table-driven denoise step for the whole-loop sampler (goal_diffusion.py:499-559 model_predictions for all three objectives,
+// :561-580 p_sample, :617-634 the DDIM update): the coefficients of step s come from row s of a device table and s itself from
+// device memory (`state[0]`), so ONE captured hipGraph {UNet forward, this kernel, video_sampler_advance} serves every step of
+// every sample() call.  Noise: an explicit tensor (parity tests inject the reference's stream) or drawn in-kernel with Philox
+// (`state[1]` = seed, `state[2]` = counter of the initial image; step s uses counters state[2] + (s + 1) * ceil(total / 4) + q, the
+// values v2a_philox_normal would write) -- no randn launch, no draw at all when sigma = 0 (DDIM with eta = 0, last ancestral step).
+// objective 0 pred_noise, 1 pred_x0, 2 pred_v; CFG (gw > 0): pred_v mixes the two noise estimates (:536-547), the others the outputs.
+struct DenoiseRow { float sa, s1, ra, rm, c1, c2, sigma, gw; int mode, final, t, pad; };
+__global__ void video_denoise_kernel2(const float* v, const float* v_u, const float* img, const float* noise, float* out, int B, int f,
+                                      int HW, int ci, int objective, const DenoiseRow* table, const uint64_t* state, int step_imm,
+                                      int use_philox) {
+    const uint64_t step = state ? state[0] : (uint64_t)step_imm;
+    const DenoiseRow k = table[step];
+    const size_t total = (size_t)B * f * ci * HW;
+    const size_t nq = (total + 3) / 4;
+    const bool draw = use_philox && !noise && k.sigma != 0.f && k.mode != 2;
+    const uint64_t seed = (state && use_philox) ? state[1] : 0ull;
+    const uint64_t ctr0 = (state && use_philox) ? state[2] + (step + 1) * (uint64_t)nq : 0ull;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (draw) philox_normal4(seed, ctr0 + q, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t i = q * 4 + e;
+            if (i >= total) break;
+            const int hw = (int)(i % HW);
+            size_t t = i / HW;
+            const int c = (int)(t % ci);
+            t /= ci;
+            const int fr = (int)(t % f);
+            const int b = (int)(t / f);
+            const size_t vi = ((((size_t)b * f + fr) * HW) + hw) * ci + c;
+            const float x = img[i];
+            float x0, eps;
+            if (objective == 2) {
+                if (k.gw > 0.f) {
+                    const float x0c = k.sa * x - k.s1 * v[vi];
+                    const float x0u = k.sa * x - k.s1 * v_u[vi];
+                    const float nu = (k.ra * x - x0u) / k.rm;
+                    const float nc = (k.ra * x - x0c) / k.rm;
+                    eps = (1.f + k.gw) * nc - k.gw * nu;
+                    x0 = k.ra * x - k.rm * eps;
+                } else {
+                    x0 = k.sa * x - k.s1 * v[vi];
+                    eps = (k.ra * x - x0) / k.rm;
+                }
+            } else {
+                float mo = v[vi];
+                if (k.gw > 0.f) mo = (1.f + k.gw) * mo - k.gw * v_u[vi];
+                if (objective == 0) { eps = mo; x0 = k.ra * x - k.rm * eps; }
+                else { x0 = mo; eps = (k.ra * x - x0) / k.rm; }
+            }
+            float o;
+            const float nz = noise ? noise[i] : z[e];
+            if (k.mode == 0) {
+                x0 = fminf(fmaxf(x0, -1.f), 1.f);
+                o = k.c1 * x0 + k.c2 * x;
+                if (noise || draw) o += k.sigma * nz;
+            } else if (k.mode == 1) {
+                o = x0 * k.c1 + k.c2 * eps;
+                if (noise || draw) o += k.sigma * nz;
+            } else {
+                o = x0;
+            }
+            if (k.final) o = fminf(fmaxf((o + 1.f) * 0.5f, 0.f), 1.f);
+            out[i] = o;
+        }
+    }
+}
+// state[0] += 1; tt[0..B) = time step of the new row (what the next UNet forward embeds)
+__global__ void video_sampler_advance_kernel(uint64_t* state, const DenoiseRow* table, int64_t* tt, int B, int nrows) {
+    const uint64_t s = state[0] + 1;
+    const int row = s < (uint64_t)nrows ? (int)s : nrows - 1;
+    const int t = table[row].t;
+    __syncthreads();
+    if (threadIdx.x == 0) state[0] = s;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) tt[b] = t;
+}
+
+// out_i[b][n] = bias_i[n] + sum_k x[b][k] * W_i[n][k] for up to 32 weight matrices sharing the input x [B][K] (B <= 16, K % 256 == 0,
+// K <= 1024): the 27 `emb_layers` Linears of the video UNet's ResBlocks (guided_diffusion/unet.py:204-210,248-257) all read the same
+// SiLU(emb) -- one launch instead of 27 latency-bound GEMMs.  One wave per output column: the weight row is read once (coalesced),
+// x sits in LDS.  Fixed summation order (lane-local chunks, then a shuffle tree).
+#define EMB_MAX 32
+struct EmbMultiArgs { int n, B, K, total_cols; int col_end[EMB_MAX]; const float* w[EMB_MAX]; const float* bias[EMB_MAX]; float* out[EMB_MAX]; };
+__global__ __launch_bounds__(256) void emb_linear_multi_kernel(const float* __restrict__ x, const EmbMultiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];           // [B][K]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < a.B * a.K; i += 256) xs[i] = x[i];
+    __syncthreads();
+    const int per = a.K / 64;                                             // floats per lane: 4, 8, 12 or 16
+    for (int col = blockIdx.x * 4 + wid; col < a.total_cols; col += gridDim.x * 4) {
+        int i = 0;
+        while (i + 1 < a.n && col >= a.col_end[i]) ++i;
+        const int n = col - (i ? a.col_end[i - 1] : 0);
+        const int cout = a.col_end[i] - (i ? a.col_end[i - 1] : 0);
+        const float* wr = a.w[i] + (size_t)n * a.K;
+        float wv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j * 4 < per) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(wr + j * 256 + lane * 4);
+                wv[4 * j] = t[0]; wv[4 * j + 1] = t[1]; wv[4 * j + 2] = t[2]; wv[4 * j + 3] = t[3];
+            }
+        const float bv = a.bias[i] ? a.bias[i][n] : 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j * 4 < per) {
+                    const float* xp = xs + b * a.K + j * 256 + lane * 4;
+                    acc += wv[4 * j] * xp[0] + wv[4 * j + 1] * xp[1] + wv[4 * j + 2] * xp[2] + wv[4 * j + 3] * xp[3];
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == 0) a.out[i][(size_t)b * cout + n] = acc + bv;
+        }
+    }
+}
+
 __global__ void philox_randint_kernel(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_ptr, uint64_t offset_imm) {
     const uint64_t off = offset_ptr ? *offset_ptr : offset_imm;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -547,6 +682,48 @@ int v2a_dropout(const float* x, float* y, size_t n, float p, uint64_t seed, uint
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
+int v2a_video_denoise_row_bytes(void) { return (int)sizeof(DenoiseRow); }
+// table_dev: [rows] of {sa, s1, ra, rm, c1, c2, sigma, gw (floats), mode, final, t, pad (int32)}; state_dev: uint64[3] = {step, Philox
+// seed, Philox counter of the initial image} or null (then row `step_imm`, no in-kernel noise).  `out` may alias `img`.
+int v2a_video_denoise_step2(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
+                            int frame_ch, int objective, const void* table_dev, const uint64_t* state_dev, int step_imm, int use_philox,
+                            hipStream_t s) {
+    if (!v || !img || !out || !table_dev || objective < 0 || objective > 2) return V2A_ERR_ARG;
+    const size_t total = (size_t)B * f * frame_ch * HW;
+    hipLaunchKernelGGL(video_denoise_kernel2, GRID_FOR((total + 3) / 4), dim3(256), 0, s, v, v_uncond, img, noise, out, B, f, HW, frame_ch,
+                       objective, (const DenoiseRow*)table_dev, state_dev, step_imm, use_philox);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_video_sampler_advance(uint64_t* state_dev, const void* table_dev, int64_t* tt, int B, int nrows, hipStream_t s) {
+    if (!state_dev || !table_dev || !tt || B < 1 || nrows < 1) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(video_sampler_advance_kernel, dim3(1), dim3(64), 0, s, state_dev, (const DenoiseRow*)table_dev, tt, B, nrows);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_emb_linear_multi_max(void) { return EMB_MAX; }
+// HOST arrays w / bias / out / couts of n <= 32 entries (device pointers inside); x [B][K] fp32
+int v2a_emb_linear_multi(const float* x, int B, int K, const float* const* w, const float* const* bias, float* const* out, const int* couts,
+                         int n, hipStream_t s) {
+    if (!x || !w || !bias || !out || !couts || n < 1 || n > EMB_MAX || B < 1 || B > 16 || K % 256 || K < 256 || K > 1024) return V2A_ERR_ARG;
+    EmbMultiArgs a;
+    __builtin_memset(&a, 0, sizeof(a));
+    a.n = n; a.B = B; a.K = K;
+    int tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || !out[i] || couts[i] < 1) return V2A_ERR_ARG;
+        a.w[i] = w[i]; a.bias[i] = bias[i]; a.out[i] = out[i];
+        tot += couts[i];
+        a.col_end[i] = tot;
+    }
+    for (int i = n; i < EMB_MAX; ++i) a.col_end[i] = tot;
+    a.total_cols = tot;
+    int g = (tot + 3) / 4;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(emb_linear_multi_kernel, dim3(g), dim3(256), (size_t)B * K * sizeof(float), s, x, a);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, hipStream_t s) {
     hipLaunchKernelGGL(philox_normal_kernel, GRID_FOR((n + 3) / 4), dim3(256), 0, s, out, n, seed, offset_dev, offset_imm);
     V2A_CHECK_LAUNCH();
@@ -554,6 +731,16 @@ int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offse
 }
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, hipStream_t s) {
     hipLaunchKernelGGL(philox_randint_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n, high, seed, offset_dev, offset_imm);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+// measurement aid (tools/, bench.py phase timeline): one lane stores the constant-rate wall clock (100 MHz on gfx950) when the stream
+// reaches this point -- the only way to see the REAL overlap of the step's parallel branches (rocprofv3's kernel trace serialises
+// the hardware queues: tools/probes/graph_branch_probe.py)
+__global__ void timestamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+int v2a_debug_timestamp(uint64_t* dst, hipStream_t s) {
+    if (!dst) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)dst);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -671,8 +671,8 @@ __device__ __attribute__((aligned(128))) float g_zero_line[64];
 typedef const __attribute__((address_space(1))) void* gptr_w_t;
 typedef __attribute__((address_space(3))) void* lptr_w_t;
 
-template <int BM, int BN, int NST = 2>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
+template <int BM, int BN, int NST>
+__device__ __forceinline__ void wgrad_dma_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
     // NST LDS stages of one 32-row k tile each (counted vmcnt: the DMAs of a tile complete in issue order).  Measured
     // (tools/wgrad_sweep.py, V2A_WGRAD_STAGES=4): four stages at two workgroups per CU are 5-15 % SLOWER than two stages at five
     // workgroups per CU on every 64x64 shape -- residency, not pipeline depth, is what hides the DMA latency here.  Default NST = 2.
@@ -682,11 +682,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
     constexpr int AROWS = 256 / ACH, BROWS = 256 / BCH;         // tile rows covered by one pass of the 256 threads
     constexpr int AL = BKR / AROWS, BL = BKR / BROWS;           // DMA pieces per thread per tile
     constexpr int ABYTES = BKR * BM * 4, BBYTES = BKR * BN * 4, BUF = ABYTES + BBYTES;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[NST * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.K + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-    const int split = blockIdx.y;
+    const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
     const int Cin = p.C1 + p.C2;
     const int nrt = (p.M + BKR - 1) / BKR;
     const int rt_begin = split * p.rtiles_per_split;
@@ -750,7 +748,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
     const int lr = lane & 31, lk = lane >> 5;
-    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    const bool do_bias = (p.dbias != nullptr) && (tile_id % tiles_n == 0);
     float bsum = 0.f;                                           // thread tid < BM: column sum of dY over this block's rows
 
     constexpr int PER_TILE = AL + BL;                           // DMA instructions per thread per tile
@@ -814,6 +812,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
         }
     }
 }
+template <int BM, int BN, int NST = 2>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[NST * 32 * (BM + BN) * 4];
+    wgrad_dma_body<BM, BN, NST>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
 
 // Weight gradient of 3x3 / stride 1 / pad 1 convs with a spatial halo tile in LDS (exact-f32 MFMA).
 // The generic kernels above re-fetch every input pixel once per filter tap and every dY row once per K tile: for a 64 -> 64 channel
@@ -823,16 +826,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_f32(const WgradDesc p) {
 // shifted windows of that halo straight from LDS: 4.2x less DMA traffic per FLOP, 144 MFMAs per wave per tile.  Accumulators: 9 x 16
 // VGPRs per lane.  Grid: (Cout/64 * Cin/64, splits); split slabs / bias partials / reduce kernel shared with the kernels above.
 template <int TW>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_halo_f32(const WgradDesc p) {
+__device__ __forceinline__ void wgrad_halo_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
     constexpr int TH = 32 / TW, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
     constexpr int NB = (HP + 15) / 16;                          // halo DMA passes (16 pixels x 64 channels per pass of 256 threads)
     constexpr int ABYTES = 32 * 64 * 4, BBYTES = NB * 16 * 64 * 4, BUF = ABYTES + BBYTES;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int Cin = p.C1;
     const int cin_blocks = Cin >> 6;
-    const int m0 = (blockIdx.x / cin_blocks) * 64, c0 = (blockIdx.x % cin_blocks) * 64;
-    const int split = blockIdx.y;
+    const int m0 = (tile_id / cin_blocks) * 64, c0 = (tile_id % cin_blocks) * 64;
     const int nrt = p.M >> 5;
     const int rt_begin = split * p.rtiles_per_split;
     const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
@@ -915,6 +916,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_f32(const WgradDesc p)
         if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = bsum;
         else p.dbias[co] = p.accumulate ? p.dbias[co] + bsum : bsum;
     }
+}
+template <int TW>
+constexpr int wgrad_halo_lds() { return 2 * (32 * 64 * 4 + (((TW + 2) * (32 / TW + 2) + 15) / 16) * 16 * 64 * 4); }
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_halo_f32(const WgradDesc p) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[wgrad_halo_lds<TW>()];
+    wgrad_halo_body<TW>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
 static int g_wforce_bm = 0;   // experiments only (v2a_debug_force_wgrad_plan)
@@ -1274,19 +1282,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
 // DMA source so that the four rows of a block sit in different 64-B bank quarters.  Single buffer (32 KB, 4 workgroups per CU) like
 // the forward kernel; split slabs / bias partials / reduce kernel shared with the other weight-gradient kernels.
 template <int BM>
-__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
+__device__ __forceinline__ void wgrad_tr_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
     // tile: BM (128 | 64) output channels x 128 k' columns, 64 reduction rows; BM = 64 serves the 64-channel layers (one wave row less
     // per workgroup column: waves 2 x 2 over 64 x 128, each 32 x 64)
     constexpr int BN = 128, BKR = 64, PITCH = 256, PITCH_A = BM * 2;
     constexpr int ACH = BM / 8, AROWS = 256 / ACH, APASS = BKR / AROWS;     // 16-B pieces per A row, rows per DMA pass, passes
-    constexpr int ABYTES = BKR * PITCH_A, BBYTES = BKR * PITCH, BUF = ABYTES + BBYTES;
+    constexpr int ABYTES = BKR * PITCH_A;
     constexpr int WMT = BM / 2, TM = WMT / 32;                                // rows per wave, 32-row MFMA tiles per wave
     constexpr int ASWZ = BM == 128 ? 4 : 2;      // piece XOR per (row & 3): conflict-free for 256-B / 128-B rows (enumerated bank model; PMC = 0)
-    __shared__ __attribute__((aligned(128))) unsigned char smem[BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.K + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-    const int split = blockIdx.y;
+    const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
     const int Cin = p.C1 + p.C2;
     const int nrt = (p.M + BKR - 1) / BKR;
     const int rt_begin = split * p.rtiles_per_split;
@@ -1359,7 +1365,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     for (int i = 0; i < TM; ++i) aoff[i] = lds0 + tr_addr(wm + 32 * i + tcol, PITCH_A, ASWZ);
 #pragma unroll
     for (int i = 0; i < 2; ++i) boff[i] = lds0 + ABYTES + tr_addr(wn + 32 * i + tcol, PITCH, 4);
-    const bool do_bias = (p.dbias != nullptr) && (blockIdx.x % tiles_n == 0);
+    const bool do_bias = (p.dbias != nullptr) && (tile_id % tiles_n == 0);
     float bsum = 0.f;                                             // thread tid < 128: column sum of dY over this block's rows
 
     for (int rt = rt_begin; rt < rt_end; ++rt) {
@@ -1432,6 +1438,61 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
             else p.dbias[co] = p.accumulate ? p.dbias[co] + bsum : bsum;
         }
     }
+}
+template <int BM>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[64 * BM * 2 + 64 * 256];
+    wgrad_tr_body<BM>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
+// ---- MANY weight gradients in ONE launch.  A 4.8-GFLOP policy-step gradient alone pays ~25-40 us of ramp-up / drain around ~48 us
+// of steady-state work (tools/wgrad_sweep.py: 61-70 TFLOP/s at every tile / split plan, against 104 on the video-training shapes with
+// the same kernels); grouped, the ramps of all problems but the first and the last overlap.  The descriptors travel in the kernel
+// arguments (no device table: a captured hipGraph keeps them in its kernel node), block -> (problem, split, tile) by a prefix scan.
+// variant 0: exact-f32 64x64 LDS-DMA body, 1 / 2: bf16 twin-fed 128- / 64-row body.
+#define WGM_MAX 16
+struct WgradMultiArgs {
+    int n;
+    int wg_end[WGM_MAX];      // exclusive prefix of workgroups per problem
+    int variant[WGM_MAX];
+    int tiles[WGM_MAX];       // output tiles per problem (workgroups = tiles * splits)
+    WgradDesc d[WGM_MAX];
+};
+static_assert(sizeof(WgradMultiArgs) <= 4096, "kernel arguments exceed the 4 KB segment");
+
+__global__ __launch_bounds__(256, 4) void conv_wgrad_multi_kernel(const WgradMultiArgs a) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[32768];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < a.n && bid >= a.wg_end[i]) ++i;
+    const int first = i ? a.wg_end[i - 1] : 0;
+    const int nwg = a.wg_end[i] - first, tiles = a.tiles[i];
+    // XCD-contiguous order inside a problem: consecutive slots of one XCD walk the tiles of one reduction slice (they share its dY
+    // and input rows through that XCD's L2)
+    const int lin = nwg >= 8 ? xcd_remap(bid - first, nwg) : bid - first;
+    const int split = lin / tiles, tile = lin - split * tiles;
+    const int v = a.variant[i];
+    if (v == 0) wgrad_dma_body<64, 64, 2>(a.d[i], tile, split, smem);
+    else if (v == 1) wgrad_tr_body<128>(a.d[i], tile, split, smem);
+    else wgrad_tr_body<64>(a.d[i], tile, split, smem);
+}
+
+// The same for the halo-tile body (3x3 / stride 1 / pad 1 layers, exact f32): a workgroup owns 64 output channels x (64 input
+// channels x 9 taps) and DMAs 2-4 x fewer bytes per FLOP than the 64x64 body -- with both camera encoders' chains on the chip the
+// L2 -> LDS path (about 25 GB/s per CU), not the matrix pipe, bounds the 64x64 tiles.  variant 3 / 4 / 5: patch width 32 / 16 / 8.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_multi_halo_kernel(const WgradMultiArgs a) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[wgrad_halo_lds<32>()];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < a.n && bid >= a.wg_end[i]) ++i;
+    const int first = i ? a.wg_end[i - 1] : 0;
+    const int nwg = a.wg_end[i] - first, tiles = a.tiles[i];
+    const int lin = nwg >= 8 ? xcd_remap(bid - first, nwg) : bid - first;
+    const int split = lin / tiles, tile = lin - split * tiles;
+    const int v = a.variant[i];
+    if (v == 3) wgrad_halo_body<32>(a.d[i], tile, split, smem);
+    else if (v == 4) wgrad_halo_body<16>(a.d[i], tile, split, smem);
+    else wgrad_halo_body<8>(a.d[i], tile, split, smem);
 }
 
 __device__ __forceinline__ void wgrad_reduce_body(const WgradDesc& p, const unsigned bid, const unsigned nblk) {
@@ -2099,6 +2160,104 @@ int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwor
     if (!items_dev || !work_dev || nwork < 0) return V2A_ERR_ARG;
     if (nwork == 0) return V2A_OK;
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nwork), dim3(256), 0, stream, (const WgradDesc*)items_dev, (const int4*)work_dev);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+
+// ---- grouped weight gradients (conv_wgrad_multi_kernel).  Step 1, v2a_conv2d_wgrad_describe: fill the descriptor of ONE gradient
+// for the grouped launch without launching anything.  want_splits = 0: planning call -- only *variant_out (0 exact-f32 64x64 LDS-DMA
+// body on the fp32 operands, 1 / 2 bf16 twin-fed 128- / 64-row body on x_h / dy_h, -1 not eligible: use v2a_conv2d_wgrad), *tiles_out
+// (output tiles) and *rtiles_out (reduction tiles: 32 rows for variant 0, 64 for the twin-fed bodies) are written.  want_splits >= 1:
+// `slabs` (the layer's own scratch, >= (splits * Cout * K + splits * Cout) * 4 bytes when splits > 1) is entered, item_out (HOST,
+// v2a_wgrad_item_bytes()) receives the main-kernel descriptor, *splits_out the split actually used (capped so that every slice keeps
+// work), and ritem_out / *rblocks_out / *rform_out the reduce item for v2a_wgrad_reduce_multi (rblocks 0: nothing to reduce).
+int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, const void* x_h, const void* x2_h, const void* dy_h, float* dw,
+                              float* dbias, int N, int H, int W, int C1, int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph,
+                              int pw, int idil, int ups, int accumulate, int want_splits, void* slabs, size_t slab_bytes, void* item_out,
+                              int* variant_out, int* tiles_out, int* rtiles_out, int* splits_out, void* ritem_out, int* rblocks_out,
+                              int* rform_out) {
+    if (!variant_out || !tiles_out || !rtiles_out) return V2A_ERR_ARG;
+    WgradDesc p;
+    __builtin_memset(&p, 0, sizeof(WgradDesc));
+    p.x = x; p.x2 = x2; p.dy = dy; p.xh = (const uint16_t*)x_h; p.x2h = (const uint16_t*)x2_h; p.dyh = (const uint16_t*)dy_h;
+    p.dw = dw; p.dbias = dbias; p.partial = (float*)slabs;
+    p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.idil = idil < 1 ? 1 : idil; p.ups = ups;
+    p.HL = ups ? 2 * H : (p.idil > 1 ? (H - 1) * p.idil + 1 : H);
+    p.WL = ups ? 2 * W : (p.idil > 1 ? (W - 1) * p.idil + 1 : W);
+    p.M = N * OH * OW;
+    const int Cin = C1 + C2;
+    p.K = KH * KW * Cin;
+    p.accumulate = accumulate;
+    p.fd_ow = make_fastdiv((uint32_t)OW);
+    p.fd_oh = make_fastdiv((uint32_t)OH);
+    int variant = -1;
+    const double big = (double)N * H * W * (C1 > C2 ? C1 : C2);
+    if (x_h && dy_h && (C2 == 0 || x2_h) && Cout >= 64 && p.K > 64 && C1 % 8 == 0 && C2 % 8 == 0 && Cout % 8 == 0 &&
+        (((uintptr_t)x_h | (uintptr_t)x2_h | (uintptr_t)dy_h) & 15) == 0 && big < 2147483648.0) {
+        variant = Cout <= 64 ? 2 : 1;
+    } else if (x && dy && (C2 == 0 || x2) && Cout % 4 == 0 && p.K % 4 == 0 && Cin % 4 == 0 && C1 % 4 == 0 &&
+               (((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)dy) & 15) == 0 && big < 4294967296.0) {
+        variant = 0;
+        // 3x3 / stride 1 / pad 1 over whole 32-pixel patches: the halo-tile body (V2A_WGRAD_HALO=0 keeps the 64x64 body)
+        if (wgrad_halo_on() && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && p.idil == 1 && C2 == 0 && OH == H &&
+            OW == W && C1 % 64 == 0 && Cout % 64 == 0 && p.M % 32 == 0 && (OW == 8 || OW == 16 || OW % 32 == 0) &&
+            OH % (OW >= 32 ? 1 : 32 / OW) == 0 && big < 2147483648.0)
+            variant = OW == 8 ? 5 : (OW == 16 ? 4 : 3);
+    }
+    *variant_out = variant;
+    if (variant < 0) { *tiles_out = 0; *rtiles_out = 0; return V2A_OK; }
+    const int rrows = (variant == 1 || variant == 2) ? 64 : 32;
+    const int tiles = variant == 0 ? cdiv(Cout, 64) * cdiv(p.K, 64)
+                      : (variant >= 3 ? (Cout / 64) * (C1 / 64) : cdiv(Cout, variant == 1 ? 128 : 64) * cdiv(p.K, 128));
+    const int nrt = cdiv(p.M, rrows);
+    *tiles_out = tiles;
+    *rtiles_out = nrt;
+    if (want_splits < 1) return V2A_OK;
+    if (!dw || !item_out || !splits_out || !ritem_out || !rblocks_out || !rform_out) return V2A_ERR_ARG;
+    int s = want_splits > nrt ? nrt : want_splits;
+    int per = cdiv(nrt, s);
+    s = cdiv(nrt, per);                               // no empty slices
+    if (s > 1 && (!slabs || ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > slab_bytes)) return V2A_ERR_WORKSPACE;
+    p.splits = s;
+    p.rtiles_per_split = per;
+    *splits_out = s;
+    *reinterpret_cast<WgradDesc*>(item_out) = p;
+    *rblocks_out = 0;
+    *rform_out = 0;
+    if (s > 1) {
+        WgradDeferred d;
+        tl_wgrad_defer = &d;
+        launch_wgrad_reduce(p, nullptr);
+        tl_wgrad_defer = nullptr;
+        *reinterpret_cast<WgradDesc*>(ritem_out) = d.desc;
+        *rblocks_out = d.blocks;
+        *rform_out = d.taps_form;
+    }
+    return V2A_OK;
+}
+int v2a_wgrad_multi_max(void) { return WGM_MAX; }
+// Step 2: launch n <= v2a_wgrad_multi_max() described gradients as one kernel.  items / variants / tiles: HOST arrays (items =
+// n * v2a_wgrad_item_bytes() bytes as written by v2a_conv2d_wgrad_describe); workgroups are issued in array order (put the deepest
+// reductions first).
+int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* tiles, int n, hipStream_t stream) {
+    if (!items || !variants || !tiles || n < 1 || n > WGM_MAX) return V2A_ERR_ARG;
+    WgradMultiArgs a;
+    __builtin_memset(&a, 0, sizeof(a));
+    a.n = n;
+    int tot = 0;
+    for (int i = 0; i < n; ++i) {
+        a.d[i] = reinterpret_cast<const WgradDesc*>(items)[i];
+        if (variants[i] < 0 || variants[i] > 5 || tiles[i] < 1 || a.d[i].splits < 1) return V2A_ERR_ARG;
+        if ((variants[i] >= 3) != (variants[0] >= 3)) return V2A_ERR_ARG;      // one kernel family per launch
+        a.variant[i] = variants[i];
+        a.tiles[i] = tiles[i];
+        tot += tiles[i] * a.d[i].splits;
+        a.wg_end[i] = tot;
+    }
+    for (int i = n; i < WGM_MAX; ++i) a.wg_end[i] = tot;
+    if (variants[0] >= 3) hipLaunchKernelGGL(conv_wgrad_multi_halo_kernel, dim3(tot), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3(tot), dim3(256), 0, stream, a);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

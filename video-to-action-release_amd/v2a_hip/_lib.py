@@ -34,6 +34,9 @@ SIGNATURES = {
     "v2a_conv2d_wgrad_deferred": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P, P, P, P]),
     "v2a_conv2d_wgrad_h_deferred": (I, [P, P, P, P, P] + [I] * 17 + [P, SZ, P, P, P, P]),
     "v2a_wgrad_reduce_multi": (I, [P, P, I, P]),
+    "v2a_conv2d_wgrad_describe": (I, [P] * 8 + [I] * 18 + [P, SZ, P, P, P, P, P, P, P, P]),
+    "v2a_wgrad_multi_max": (I, []),
+    "v2a_conv2d_wgrad_multi": (I, [P, P, P, I, P]),
     "v2a_pack_chunk_elems": (I, []),
     "v2a_debug_wgrad_dma": (I, [I]),
     "v2a_conv2d_plan": (I, [I, I, I, P, P, P]),
@@ -78,9 +81,15 @@ SIGNATURES = {
     "v2a_video_loss_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, SZ, P]),
     "v2a_video_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "v2a_video_denoise_step": (I, [P, P, P, P, P, I, I, I, F, F, F, F, F, F, F, F, I, I, I, P]),
+    "v2a_video_denoise_row_bytes": (I, []),
+    "v2a_video_denoise_step2": (I, [P, P, P, P, P, I, I, I, I, I, P, P, I, I, P]),
+    "v2a_video_sampler_advance": (I, [P, P, P, I, I, P]),
+    "v2a_emb_linear_multi_max": (I, []),
+    "v2a_emb_linear_multi": (I, [P, I, I, P, P, P, P, I, P]),
     "v2a_philox_normal": (I, [P, SZ, U64, P, U64, P]),
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
     "v2a_advance_counter": (I, [P, U64, P]),
+    "v2a_debug_timestamp": (I, [P, P]),
     "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),
     "v2a_perceiver_attention_bwd": (I, [P] * 9 + [I, I, I, I, I, F, P]),
     "v2a_layernorm_bwd": (I, [P, P, P, P, P, I, I, F, P]),

@@ -336,6 +336,96 @@ class WgradCollector:
         check(lib.v2a_wgrad_reduce_multi(ent[0].data_ptr(), ent[1].data_ptr(), ent[2], _stream()), "wgrad_reduce_multi")
 
 
+class WgradBatch:
+    """Weight gradients of SEVERAL layers as one launch (csrc/igemm.hip conv_wgrad_multi_kernel; descriptors in the kernel arguments,
+    so a captured hipGraph carries them in its kernel node).  `add` records a gradient (False: the grouped kernel cannot take it --
+    launch it alone); `launch` plans the reduction splits over the whole group (about TARGET_WG workgroups per launch, every slice at
+    least MIN_DEPTH reduction tiles), runs the main kernel(s) and hands the split-K reduces to the collector (one multi-tensor launch
+    at the collector's next flush).  Per-element summation order is fixed by the plan: bitwise reproducible."""
+    TARGET_WG = int(os.environ.get("V2A_WGRAD_MULTI_WG", "1280"))
+    MIN_DEPTH = int(os.environ.get("V2A_WGRAD_MULTI_DEPTH", "4"))
+    TARGET_WG_HALO = int(os.environ.get("V2A_WGRAD_MULTI_WG_HALO", "512"))
+    WEIGHT = {0: 1.0, 1: 2.0, 2: 1.5, 3: 1.0, 4: 1.0, 5: 1.0}   # relative cost of one (output tile, reduction tile) step per kernel body
+
+    def __init__(self, collector):
+        self.col = collector
+        self.calls = []
+
+    def __len__(self):
+        return len(self.calls)
+
+    def _describe(self, c, want, slab, slab_bytes, item, ritem):
+        import ctypes
+        v, t, rt, sp, rb, rf = (ctypes.c_int(0) for _ in range(6))
+        x, dy, x2 = c["x"], c["dy"], c["x2"]
+        N, H, W, C1 = x.shape
+        C2 = x2.shape[-1] if x2 is not None else 0
+        _, OH, OW, Cout = dy.shape
+        check(lib.v2a_conv2d_wgrad_describe(x.data_ptr(), _p(x2), dy.data_ptr(), _p(c["x_h"]), _p(c["x2_h"]), _p(c["dy_h"]), c["dw"].data_ptr(),
+                                            _p(c["dbias"]), N, H, W, C1, C2, OH, OW, Cout, c["KH"], c["KW"], c["stride"][0], c["stride"][1],
+                                            c["pad"][0], c["pad"][1], c["idil"], 1 if c["ups"] else 0, 1 if c["accumulate"] else 0, want,
+                                            slab, slab_bytes, item, ctypes.byref(v), ctypes.byref(t), ctypes.byref(rt), ctypes.byref(sp),
+                                            ritem, ctypes.byref(rb), ctypes.byref(rf)), "conv2d_wgrad_describe")
+        return v.value, t.value, rt.value, sp.value, rb.value, rf.value
+
+    def add(self, x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None,
+            x_h=None, dy_h=None, x2_h=None, slab_key=None):
+        if dw is None:
+            return False
+        _chk(x, "x"); _chk(dy, "dy")
+        twins = x_h is not None and dy_h is not None and (x2 is None or x2_h is not None) and lib.v2a_get_precision() == 1
+        c = dict(x=x, dy=dy, x2=x2, x_h=x_h if twins else None, dy_h=dy_h if twins else None, x2_h=x2_h if (twins and x2 is not None) else None,
+                 dw=dw, dbias=dbias, KH=KH, KW=KW, stride=stride, pad=pad, idil=idil, ups=ups, accumulate=accumulate, slab_key=slab_key)
+        v, t, rt, _, _, _ = self._describe(c, 0, None, 0, None, None)
+        if v < 0:
+            return False
+        c.update(variant=v, tiles=t, rtiles=rt)
+        self.calls.append(c)
+        return True
+
+    def launch(self):
+        import ctypes
+        allc, self.calls = self.calls, []
+        if not allc:
+            return
+        # two kernel families (csrc/igemm.hip): the halo-tile body (variants 3-5) and the 64x64 / twin-fed bodies (0-2)
+        for fam, target in ((False, self.TARGET_WG), (True, self.TARGET_WG_HALO)):
+            calls = [c for c in allc if (c["variant"] >= 3) == fam]
+            if calls:
+                self._launch_family(calls, target)
+        last_kernel[0] = "conv_wgrad_multi"
+
+    def _launch_family(self, calls, target_wg):
+        import ctypes
+        units = sum(c["tiles"] * c["rtiles"] * self.WEIGHT[c["variant"]] for c in calls)
+        per_wg = max(units / target_wg, 1.0)
+        ib = self.col.item_bytes
+        recs = []
+        for c in calls:
+            want = int(round(c["rtiles"] * self.WEIGHT[c["variant"]] / per_wg))
+            want = max(1, min(want, 128, c["rtiles"] // self.MIN_DEPTH if c["rtiles"] >= self.MIN_DEPTH else 1))
+            Cout = c["dy"].shape[-1]
+            K = c["KH"] * c["KW"] * (c["x"].shape[-1] + (c["x2"].shape[-1] if c["x2"] is not None else 0))
+            nbytes = (want * Cout * K + want * Cout) * 4 if want > 1 else 0
+            slab = None
+            if nbytes:
+                key = c["slab_key"] if c["slab_key"] is not None else c["dw"].data_ptr()
+                slab = self.col.slab((key, "multi", nbytes), nbytes)      # size in the key: a slab a captured graph points at never has to grow
+            item, ritem = ctypes.create_string_buffer(ib), ctypes.create_string_buffer(ib)
+            v, t, rt, sp, rb, rf = self._describe(c, want, _p(slab), nbytes, item, ritem)
+            recs.append((-(-rt // sp) * self.WEIGHT[v], item.raw, v, t, ritem.raw, rb, rf))
+        recs.sort(key=lambda r: -r[0])                     # deepest slices first (they are dispatched first)
+        mx = lib.v2a_wgrad_multi_max()
+        for i in range(0, len(recs), mx):
+            grp = recs[i:i + mx]
+            items = b"".join(r[1] for r in grp)
+            vs = (ctypes.c_int * len(grp))(*[r[2] for r in grp])
+            ts = (ctypes.c_int * len(grp))(*[r[3] for r in grp])
+            check(lib.v2a_conv2d_wgrad_multi(items, vs, ts, len(grp), _stream()), "conv2d_wgrad_multi")
+        for r in recs:
+            self.col.add(r[4], r[5], r[6])
+
+
 def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idil=1, ups=False, dw=None, accumulate=False, dbias=None,
                  x_h=None, dy_h=None, x2_h=None, collector=None, slab_key=None):
     """dW in torch layout (shape w_shape = [Cout, Cin, ...]) of the conv whose input was x (+x2) and output grad dy [N,OH,OW,Cout].
@@ -901,6 +991,40 @@ def spatial_softmax_bwd(att, kp, dkp):
     return dfeat
 
 
+_TS = {"on": os.environ.get("V2A_TSTAMP") == "1", "buf": None, "names": []}
+
+
+def tstamp(name):
+    """Measurement aid (V2A_TSTAMP=1): record the wall clock at this point of the CURRENT stream into the next slot (capturable: the
+    slot order is the call order of the first pass; replays overwrite the same slots).  Read with tstamp_table()."""
+    if not _TS["on"]:
+        return
+    if _TS["buf"] is None:
+        _TS["buf"] = torch.zeros(4096, dtype=torch.int64, device="cuda")
+    names = _TS["names"]
+    i = _TS.get("cursor", 0)
+    if i < len(names):
+        assert names[i] == name, (names[i], name)
+    else:
+        names.append(name)
+    _TS["cursor"] = i + 1
+    check(lib.v2a_debug_timestamp(_TS["buf"].data_ptr() + 8 * i, _stream()), "debug_timestamp")
+
+
+def tstamp_reset():
+    _TS["cursor"] = 0
+
+
+def tstamp_table():
+    """[(name, microseconds since the first slot)] of the last pass."""
+    if _TS["buf"] is None:
+        return []
+    torch.cuda.synchronize()
+    v = _TS["buf"][:len(_TS["names"])].cpu().tolist()
+    t0 = min(v) if v else 0
+    return [(n, (x - t0) / 100.0) for n, x in zip(_TS["names"], v)]
+
+
 def philox_normal(out, seed, offset_dev=None, offset_imm=0):
     check(lib.v2a_philox_normal(out.data_ptr(), out.numel(), seed, _p(offset_dev), offset_imm, _stream()), "philox_normal")
     return out
@@ -959,6 +1083,55 @@ def video_denoise_step(v, v_uncond, img, noise, coef, mode, final, f, HW, ci=3):
     check(lib.v2a_video_denoise_step(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, *[float(c) for c in coef],
                                      mode, 1 if final else 0, ci, _stream()), "video_denoise_step")
     return out
+
+
+def video_denoise_table(rows, device, out=None):
+    """rows: [(sa, s1, ra, rm, c1, c2, sigma, gw, mode, final, t)] per sampler step -> device table for video_denoise_step2."""
+    import numpy as np
+    n = len(rows)
+    host = np.zeros((n, 12), dtype=np.float32)
+    iv = host.view(np.int32)
+    for i, r in enumerate(rows):
+        host[i, :8] = [float(c) for c in r[:8]]
+        iv[i, 8:11] = [int(r[8]), 1 if r[9] else 0, int(r[10])]
+    t = torch.from_numpy(host)
+    if out is None:
+        return t.to(device)
+    assert out.shape[0] >= n
+    out[:n].copy_(t)
+    return out
+
+
+def video_denoise_step2(v, v_uncond, img, noise, table, objective, f, HW, ci=3, state=None, step=0, use_philox=False, out=None):
+    """One table-driven sampler step (csrc/elementwise.hip video_denoise_kernel2).  state: uint64[3] device tensor {row, seed, counter}
+    (row index and Philox state read on the device) or None (row `step`).  out=img updates the sampler state in place."""
+    if out is None:
+        out = torch.empty_like(img)
+    B = img.shape[0]
+    check(lib.v2a_video_denoise_step2(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, ci,
+                                      _OBJECTIVES[objective], table.data_ptr(), _p(state), int(step), 1 if use_philox else 0, _stream()),
+          "video_denoise_step2")
+    return out
+
+
+def video_sampler_advance(state, table, tt, nrows):
+    check(lib.v2a_video_sampler_advance(state.data_ptr(), table.data_ptr(), tt.data_ptr(), tt.numel(), nrows, _stream()), "video_sampler_advance")
+
+
+def emb_linear_multi(x, ws, bs):
+    """[x @ w.T + b for w, b in zip(ws, bs)] for weight matrices sharing x [B <= 16, K] in one launch (<= 32 per launch)."""
+    import ctypes
+    _chk(x, "x")
+    B, K = x.shape
+    outs = [torch.empty((B, w.shape[0]), dtype=torch.float32, device=x.device) for w in ws]
+    mx = lib.v2a_emb_linear_multi_max()
+    for i in range(0, len(ws), mx):
+        n = len(ws[i:i + mx])
+        arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+        check(lib.v2a_emb_linear_multi(x.data_ptr(), B, K, arr([w.data_ptr() for w in ws[i:i + n]]),
+                                       arr([_p(b) for b in bs[i:i + n]]), arr([o.data_ptr() for o in outs[i:i + n]]),
+                                       (ctypes.c_int * n)(*[w.shape[0] for w in ws[i:i + n]]), n, _stream()), "emb_linear_multi")
+    return outs
 
 
 # ---------------------------------------------------------------------------------------------- video-model training loss

@@ -150,6 +150,11 @@ class PolicyEngine:
         self._wgc_on = _os.environ.get("V2A_WGRAD_MULTI_REDUCE", "1") != "0"
         self._collect_wg = False
         self._wg_stream = None
+        # grouped weight-gradient launches: "stage" = one launch per ResNet stage (and per <= 16 ConditionalUnet1D layers), "enc" = one
+        # group per camera encoder at the end of its chain, "0" = every gradient its own launch (round-2 behaviour)
+        self._wgb_mode = _os.environ.get("V2A_WGRAD_BATCH", "enc")
+        self._wgb_side = _os.environ.get("V2A_WGRAD_BATCH_STREAM", "0") == "1"
+        self._wgb_streams = {}
         self._side = None
         self._keep = []
         self._build()
@@ -267,6 +272,11 @@ class PolicyEngine:
         if self.defer_unet_wgrad and self._collect_wg:
             self._deferred.append((a, k))
             return None
+        if self._wgb is not None and not immediate:
+            kb = dict(k, slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
+            if self._wgb.add(*a, **kb):
+                self._wgb_keep.append((a, k))
+                return None
         if self._wgc_active and not immediate:
             k = dict(k, collector=self._collector(), slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
         if not (self.async_wgrad or (self._wg_mode == "unet" and not self._in_enc)):
@@ -287,6 +297,49 @@ class PolicyEngine:
     _wgc_active = False
     _dw_names = None
     _tmp_seq = 0
+    _wgb = None            # the ops.WgradBatch weight gradients are being collected into (grouped launches), or None
+    _wgb_keep = ()
+    _wgb_stream = None     # side stream the current chain's grouped launches run on (None: the chain's own stream)
+
+    def _wgb_begin(self, side_key=None):
+        """Collect the weight gradients that follow into grouped launches (V2A_WGRAD_BATCH=0: off).  side_key: run those launches on
+        a side stream of their own (one per key), forked from / joined to the current stream."""
+        if self._wgb_mode == "0" or not self._wgc_active:
+            return
+        self._wgb = ops.WgradBatch(self._collector())
+        self._wgb_keep = []
+        self._wgb_stream = None
+        if side_key is not None and self._wgb_side:
+            st = self._wgb_streams.get(side_key)
+            if st is None:
+                st = self._wgb_streams[side_key] = torch.cuda.Stream(device=self.device)
+            self._wgb_stream = st
+
+    def _wgb_launch(self):
+        """Launch what has been collected so far (a stage boundary of the chain)."""
+        b = self._wgb
+        if b is None or not len(b):
+            return
+        st = self._wgb_stream
+        if st is None:
+            b.launch()
+            return
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            b.launch()
+        self._wgb_forked = True
+
+    def _wgb_end(self):
+        """Launch the rest, join the side stream (operands were kept alive until here)."""
+        if self._wgb is None:
+            return
+        self._wgb_launch()
+        if self._wgb_stream is not None and self._wgb_forked:
+            torch.cuda.current_stream().wait_stream(self._wgb_stream)
+        self._wgb_forked = False
+        self._wgb, self._wgb_keep, self._wgb_stream = None, (), None
+
+    _wgb_forked = False
 
     def _slab_key(self, dw):
         """Stable name of the layer a gradient view belongs to (its slab buffer is kept per layer, not per address: the autograd path
@@ -492,6 +545,7 @@ class PolicyEngine:
         e = self.enc[key]
         cfg = self.cfg
         w0 = cfg.widths[0]
+        ops.tstamp(f"enc_fwd[{key}] begin")
         x0 = ops.nchw_to_nhwc(img_nchw, normalize=True)
         c1 = ops.conv2d(x0, e["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3))
         a1, s_gn1 = self._gn(c1, e["bb"] + ".1", w0 // 16, "relu")
@@ -531,16 +585,22 @@ class PolicyEngine:
         st.update(feat=feat, kp=kp, att=att)
         if save is not None:
             save[key] = st
+        ops.tstamp(f"enc_fwd[{key}] end")
         return f
 
     def encode_bwd(self, key, df, st, grads):
         tok = self._gn_begin()
         self._wg_begin()
+        self._wgb_begin(side_key=key)
+        ops.tstamp(f"enc_bwd[{key}] begin")
         try:
             self._encode_bwd(key, df, st, grads)
         finally:
+            ops.tstamp(f"enc_bwd[{key}] chain done")
+            self._wgb_end()
             self._gn_flush(tok, grads)
             self._wg_flush()
+            ops.tstamp(f"enc_bwd[{key}] end")
 
     def _encode_bwd(self, key, df, st, grads):
         e = self.enc[key]
@@ -584,6 +644,10 @@ class PolicyEngine:
                 dh, dh_sl = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=res_in, x_h=do1h, defer=True)
             else:
                 dh, dh_sl = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=res_in, x_h=do1h), None
+            if bi % 2 == 1:
+                ops.tstamp(f"enc_bwd[{key}] stage {3 - bi // 2} dgrad done")
+            if self._wgb_mode == "stage" and bi % 2 == 1:           # both blocks of a ResNet stage are through: their gradients as one launch
+                self._wgb_launch()
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
         # RGB stem: 3 input channels make every 16-B piece of the gathered operand straddle pixels (scalar-gather kernel, 0.4 ms
@@ -720,6 +784,7 @@ class PolicyEngine:
         """sample [B,T,Da] fp32, t_long [B] int64, global_cond [B,G] -> eps prediction [B,T,Da]."""
         cfg = self.cfg
         B, T, Da = sample.shape
+        ops.tstamp("unet_fwd begin")
         temb = ops.sincos_embed(t_long, cfg.dsed, 0)
         e1 = ops.linear(temb, self.step1.pf(), self.step1.b)
         m1 = ops.act_fwd(e1, "mish")
@@ -923,6 +988,7 @@ class PolicyEngine:
         save = {}
         pred = self.unet_fwd(noisy, timesteps, gc, save)
         loss, dpred = ops.mse_loss(pred, noise, want_grad=True)
+        ops.tstamp("unet_bwd begin")
         names = list(names) if names is not None else self.trainable_names()
         if arena is None:
             arena = torch.zeros(self.grad_layout(names)[1], dtype=torch.float32, device=self.device)   # GN param grads accumulate
@@ -931,13 +997,17 @@ class PolicyEngine:
         self._collect_wg = True
         tok = self._gn_begin()
         self._wg_begin()
+        if not self.defer_unet_wgrad:          # (data parallel: the model.* slice is finished inside phase 1) grouped launches at its end
+            self._wgb_begin()
         try:
             dgc = self.unet_bwd(dpred, save, grads)
         finally:
             self._collect_wg = False
+            self._wgb_end()
             self._gn_flush(tok, grads)
             self._wg_flush()
         self._join_side()
+        ops.tstamp("unet_bwd end")
         return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc, keep=save)
 
     def backward_phase2(self, st):
@@ -959,11 +1029,19 @@ class PolicyEngine:
                 self._wg_stream = torch.cuda.Stream(device=self.device)
             self._wg_stream.wait_stream(main)
             with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
+                ops.tstamp("unet_wgrad begin")
                 col = self._collector() if self._wgc_on else None
+                batch = ops.WgradBatch(col) if (col is not None and self._wgb_mode != "0") else None
                 for a, k in deferred:
-                    ops.conv2d_wgrad(*a, **dict(k, collector=col, slab_key=k.get("slab_key") or self._slab_key(k.get("dw"))))
+                    kk = dict(k, slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
+                    if batch is not None and batch.add(*a, **kk):
+                        continue
+                    ops.conv2d_wgrad(*a, **dict(kk, collector=col))
+                if batch is not None:
+                    batch.launch()
                 if col is not None:
                     col.flush()
+                ops.tstamp("unet_wgrad end")
         self._in_enc = True
         try:
             self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])

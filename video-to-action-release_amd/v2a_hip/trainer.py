@@ -123,6 +123,8 @@ class PolicyTrainer:
     def _fwd_bwd(self):
         st = self.store
         B = self.B
+        ops.tstamp_reset()
+        ops.tstamp("step begin")
         o0 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
         o1 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
         oa = torch.empty((B, st.act_len, st.act_dim), dtype=torch.float32, device=self.device)
@@ -161,8 +163,11 @@ class PolicyTrainer:
             self.comm_events.append(ev)
 
     def _opt(self):
+        ops.tstamp("optimiser begin")
         self.opt.step(zero_grad=True)
+        ops.tstamp("optimiser done / packs begin")
         self.eng.refresh_packs()
+        ops.tstamp("step end")
 
     # ------------------------------------------------------------------ step
     def step(self):
