@@ -39,6 +39,8 @@ def _traffic(leg, kernel):
 
 # SURVEY.md 8d algorithmic bytes: sampler per UNet forward at B = 16 = W + 16 * A * s (W = 201,087,649 weights, A = 1.816 G activation
 # elements per sample, s bytes per element); policy per step at B = 64, fp32 = 64 B * 87,219,143 parameters + 3 * 3.326 M * 64 * 4
+TRAFFIC_SOURCE = ("profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a separate run (tools/profile_round.sh), "
+                  "NOT measured inside this bench run")
 ALGORITHMIC_BYTES = {"video": 201087649 * 4 + 16 * 1.816e9 * 4, "video_bf16": 201087649 * 2 + 16 * 1.816e9 * 2, "policy": 8.13e9}
 
 
@@ -109,6 +111,24 @@ def instrumented_pass(torch, trainer, steps):
     orig_axpy = ops.axpy
     ops.conv2d = timed("fwd", orig_fwd, f_fwd)
     ops.conv2d_wgrad = timed("wgrad", orig_wg, f_wg)
+    # grouped weight gradients (ops.WgradBatch -> conv_wgrad_multi_kernel / conv_wgrad_multi_halo_kernel): one event pair per launch family
+    orig_fam = ops.WgradBatch._launch_family
+
+    def fam(self, calls, target_wg):
+        fl = 0.0
+        for c in calls:
+            x, dy = c["x"], c["dy"]
+            c2 = c["x2"].shape[-1] if c["x2"] is not None else 0
+            fl += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * c["KH"] * c["KW"] * (x.shape[-1] + c2)
+        name = "conv_wgrad_multi_halo" if calls[0]["variant"] >= 3 else "conv_wgrad_multi"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        orig_axpy(blk_a, blk_b, 1.0, out=blk_b)
+        e0.record()
+        orig_fam(self, calls, target_wg)
+        e1.record()
+        recs.append(("wgrad", (name, fl, (len(calls), 0, 0, 0, 0, -2)), e0, e1))
+
+    ops.WgradBatch._launch_family = fam
     g_saved, a_saved, e_saved, m_saved = trainer.use_graph, trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode
     trainer.use_graph = False
     trainer.eng.async_wgrad = False          # measure every kernel alone on the main stream (the timed step overlaps the two
@@ -121,6 +141,7 @@ def instrumented_pass(torch, trainer, steps):
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.conv2d_wgrad = orig_fwd, orig_wg
+        ops.WgradBatch._launch_family = orig_fam
         trainer.use_graph = g_saved
         trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode = a_saved, e_saved, m_saved
         trainer.eng.defer_unet_wgrad = d_saved
@@ -245,73 +266,72 @@ def _cpu_collect(proc, hard_timeout):
 
 class CpuBaselines:
     """The CPU oracle (pinned bit-exact against the reference: tests/test_oracle_golden.py) timed on this box's host cores, as
-    SURVEY 8d asks: ONE thread (the reference's launch script pins OMP_NUM_THREADS=1, train_libero_dp.sh:11), 32 threads and all
-    usable cores.  Every run is a subprocess with a hard timeout; the one-thread runs are started at the beginning of the benchmark
-    and tick in the background on one core each while the GPU legs run, the many-thread runs execute alone."""
+    SURVEY 8d asks: ONE thread (the reference's launch script pins OMP_NUM_THREADS=1, train_libero_dp.sh:11) and 32 threads (all
+    256 SMT threads of this host do not finish one step in 100 s -- measured in round 2 -- so that setting is not run).  Every run
+    is a subprocess with a hard timeout.  `run_all()` BLOCKS and is called before any GPU leg is timed (and after the GPU has gone
+    idle): no CPU-oracle process is alive inside a GPU timed window.  The two one-thread runs share the wait with the 32-thread runs
+    (34 of this host's cores busy at once)."""
 
-    def __init__(self, batch, video_steps, enabled=True, video=True):
-        self.batch, self.video_steps, self.enabled = batch, video_steps, enabled
+    def __init__(self, batch, video_steps, video=True):
+        self.batch, self.video_steps, self.video_on = batch, video_steps, video
         self.usable = _usable_cores()
         self.model = _cpu_model()
-        self.bg = {}
-        if enabled:
-            self.bg["policy"] = (_cpu_spawn(f"_cpu_baseline_worker(8, 1, 25.0, 4)", 1), time.time())
-            if video:
-                self.bg["video"] = (_cpu_spawn(f"_cpu_video_worker(1, 1.0, 1, True)", 1), time.time())
+        self.results = {}
 
-    def _multi_settings(self):
-        out = [min(32, self.usable)]
-        if self.usable > 32:
-            out.append(self.usable)
-        return out
-
-    def policy(self):
-        settings = []
-        for th in self._multi_settings():
-            cap = 120.0 if th <= 32 else 45.0       # all 256 SMT threads: torch-CPU does not finish ONE step in 100 s on this host (128 threads: 0.2 steps/s)
-            last = _cpu_collect(_cpu_spawn(f"_cpu_baseline_worker({self.batch}, {th}, 12.0, 12)", th), cap)
-            if last and last["done"] >= 1:
-                settings.append({"threads": th, "value": last["done"] / last["t"],
-                                 "sample": f"{last['done']} timed B={self.batch} fp32 train steps (first untimed), {last['t']:.1f} s"})
-            elif last and last.get("first"):
-                settings.append({"threads": th, "value": 1.0 / last["first"],
-                                 "sample": f"1 cold B={self.batch} fp32 train step ({last['first']:.1f} s, includes allocator / oneDNN warm-up); "
-                                           f"no second step finished within the {cap:.0f} s cap"})
-            else:
-                settings.append({"threads": th, "value": None, "sample": f"no step finished within the {cap:.0f} s cap"})
-        proc, _ = self.bg.pop("policy")
-        last = _cpu_collect(proc, 60.0)
+    def run_all(self):
+        th = min(32, self.usable)
+        t0 = time.time()
+        bg = {"policy": _cpu_spawn("_cpu_baseline_worker(8, 1, 25.0, 4)", 1)}
+        if self.video_on:
+            bg["video"] = _cpu_spawn("_cpu_video_worker(1, 1.0, 1, True)", 1)
+        pol = [self._policy_multi(th)]
+        vid = [self._video_multi(th)] if self.video_on else []
+        last = _cpu_collect(bg["policy"], max(5.0, 90.0 - (time.time() - t0)))
         if last and last["done"] >= 1:
             per8 = last["t"] / last["done"]
-            settings.insert(0, {"threads": 1, "value": 1.0 / (per8 * self.batch / 8.0),
-                                "sample": f"{last['done']} timed B=8 steps (BASELINE configs[0] size; {per8:.2f} s each, first untimed), scaled "
-                                          f"linearly to B={self.batch} rows per step"})
+            pol.insert(0, {"threads": 1, "value": 1.0 / (per8 * self.batch / 8.0),
+                           "sample": f"{last['done']} timed B=8 steps (BASELINE configs[0] size; {per8:.2f} s each, first untimed), scaled "
+                                     f"linearly to B={self.batch} rows per step"})
         else:
-            settings.insert(0, {"threads": 1, "value": None, "sample": "no B=8 step finished on one thread within the cap"})
-        return self._pack(settings, "steps/s",
-                          f"CPU oracle of the same train step (fwd+bwd via torch-CPU autograd + clip/AdamW/EMA), fp32, B={self.batch}")
-
-    def video(self):
-        settings = []
-        for th in self._multi_settings():
-            last = _cpu_collect(_cpu_spawn(f"_cpu_video_worker({th}, 10.0, 4, False)", th), 90.0 if th <= 32 else 45.0)
+            pol.insert(0, {"threads": 1, "value": None, "sample": "no B=8 step finished on one thread within the cap"})
+        self.results["policy"] = self._pack(pol, "steps/s", f"CPU oracle of the same train step (fwd+bwd via torch-CPU autograd + "
+                                                            f"clip/AdamW/EMA), fp32, B={self.batch}")
+        if self.video_on:
+            last = _cpu_collect(bg["video"], max(5.0, 150.0 - (time.time() - t0)))
             if last and last["done"] >= 1:
                 per = last["t"] / last["done"]
-                settings.append({"threads": th, "value": 7.0 / (per * self.video_steps),
-                                 "sample": f"{last['done']} timed full-size Unet_Libero forwards at B=1 ({per:.2f} s each, first untimed)"})
+                vid.insert(0, {"threads": 1, "value": 7.0 / (per * self.video_steps),
+                               "sample": f"ONE full-size Unet_Libero forward at B=1, cold (no warm-up pass: {per:.1f} s)"})
             else:
-                settings.append({"threads": th, "value": None, "sample": f"no forward finished within the {90 if th <= 32 else 45} s cap"})
-        proc, t0 = self.bg.pop("video")
-        last = _cpu_collect(proc, max(5.0, 150.0 - (time.time() - t0)))
+                vid.insert(0, {"threads": 1, "value": None, "sample": "the one-thread forward did not finish within 150 s"})
+            self.results["video"] = self._pack(vid, "predicted frames/s",
+                                               f"CPU oracle UNet forwards, extrapolated linearly to {self.video_steps} denoise steps per sample "
+                                               f"(the sampler costs B x steps forwards; the elementwise DDIM update is ignored)")
+        self.results["wall_s"] = time.time() - t0
+
+    def _policy_multi(self, th):
+        last = _cpu_collect(_cpu_spawn(f"_cpu_baseline_worker({self.batch}, {th}, 12.0, 12)", th), 120.0)
+        if last and last["done"] >= 1:
+            return {"threads": th, "value": last["done"] / last["t"],
+                    "sample": f"{last['done']} timed B={self.batch} fp32 train steps (first untimed), {last['t']:.1f} s"}
+        if last and last.get("first"):
+            return {"threads": th, "value": 1.0 / last["first"],
+                    "sample": f"1 cold B={self.batch} fp32 train step ({last['first']:.1f} s, includes allocator / oneDNN warm-up)"}
+        return {"threads": th, "value": None, "sample": "no step finished within the 120 s cap"}
+
+    def _video_multi(self, th):
+        last = _cpu_collect(_cpu_spawn(f"_cpu_video_worker({th}, 10.0, 4, False)", th), 90.0)
         if last and last["done"] >= 1:
             per = last["t"] / last["done"]
-            settings.insert(0, {"threads": 1, "value": 7.0 / (per * self.video_steps),
-                                "sample": f"ONE full-size Unet_Libero forward at B=1, cold (no warm-up pass: {per:.1f} s)"})
-        else:
-            settings.insert(0, {"threads": 1, "value": None, "sample": "the one-thread forward did not finish within 150 s"})
-        return self._pack(settings, "predicted frames/s",
-                          f"CPU oracle UNet forwards, extrapolated linearly to {self.video_steps} denoise steps per sample (the sampler "
-                          f"costs B x steps forwards; the elementwise DDIM update is ignored)")
+            return {"threads": th, "value": 7.0 / (per * self.video_steps),
+                    "sample": f"{last['done']} timed full-size Unet_Libero forwards at B=1 ({per:.2f} s each, first untimed)"}
+        return {"threads": th, "value": None, "sample": "no forward finished within the 90 s cap"}
+
+    def policy(self):
+        return self.results.get("policy")
+
+    def video(self):
+        return self.results.get("video")
 
     def _pack(self, settings, unit, what):
         good = [s for s in settings if s["value"]]
@@ -319,42 +339,57 @@ class CpuBaselines:
         return {"value": best["value"] if best else None, "unit": unit, "cores": best["threads"] if best else 0, "kind": "port",
                 "cpu_model": self.model, "usable_cores": self.usable,
                 "sample": (what + "; best of the settings below: " + best["sample"]) if best else what + "; nothing finished",
-                "settings": settings}
-
-    def abandon(self):
-        for proc, _ in self.bg.values():
-            try:
-                proc.kill()
-            except Exception:
-                pass
-        self.bg = {}
+                "settings": settings, "isolation": "run to completion before the first GPU leg is timed (no CPU-oracle process alive "
+                                                   "inside a GPU timed window)"}
 
 
-def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video"):
-    """BASELINE.json configs[2]: AVDC sampler, Unet_Libero (201 M params, random init), 8-frame 128x128 (1 cond + 7 predicted),
-    B=16, 50 sampling steps (sampling_timesteps=50 < 100 => the reference's DDIM path, goal_diffusion.py:405,647), CLIP-free
-    synthetic task tokens [B,10,512].  frames/s = B * 7 / wall time of one sample() with inputs resident in HBM."""
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+# algorithmic FLOPs per sample per denoise step of Unet_Libero (FlopCounterMode on the reference)
+VIDEO_TFLOP = {(128, 7): 2.130, (256, 15): 18.379}
+
+
+def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", size=128, frames=7, reps=3, roofline=True, workload=None):
+    """AVDC sampler, Unet_Libero (201 M parameters, random init), `frames` predicted frames + 1 conditioning frame at size x size,
+    CLIP-free synthetic task tokens [B,10,512].  sampling_steps < 100 = the reference's DDIM branch (goal_diffusion.py:405,647),
+    100 = its released configuration (ancestral, config/libero/lb_tk8_65to72.py:40-47).  One untimed call first (weight packs,
+    workspaces, hipGraph capture), then `reps` sample() calls, each bracketed by HIP events on the launch stream; value = B * frames /
+    MEDIAN call time, inputs resident in HBM."""
     from flowdiffusion.flowdiffusion.unet import Unet_Libero
     from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
     from v2a_hip import ops
     torch.manual_seed(0)
     unet = Unet_Libero().to(device).eval()
-    d = GoalGaussianDiffusion(unet, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=sampling_steps, loss_type="l2",
+    C = 3 * frames
+    d = GoalGaussianDiffusion(unet, image_size=(size, size), channels=C, timesteps=100, sampling_timesteps=sampling_steps, loss_type="l2",
                               objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to(device)
     g = torch.Generator(device=device).manual_seed(1)
-    x_cond = torch.rand(batch, 3, 128, 128, device=device, generator=g)
+    x_cond = torch.rand(batch, 3, size, size, device=device, generator=g)
     te = torch.randn(batch, 10, 512, device=device, generator=g)
-    # warm-up: 2 steps (weight packs, workspace, allocator)
-    d.sampling_timesteps, d.is_ddim_sampling = 2, True
-    d.sample(x_cond, te, batch_size=batch)
-    d.sampling_timesteps = sampling_steps
-    d.is_ddim_sampling = sampling_steps < d.num_timesteps
+    out = d.sample(x_cond, te, batch_size=batch)                    # warm-up: packs, workspace, allocator, graph capture
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = d.sample(x_cond, te, batch_size=batch)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    flops = 2.130e12 * batch * sampling_steps                       # SURVEY.md 8d: 2.130 TFLOP per sample per denoise step
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = d.sample(x_cond, te, batch_size=batch)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3)
+    dt = _median(times)
+    flops = VIDEO_TFLOP[(size, frames)] * 1e12 * batch * sampling_steps
+    res = {"metric": "video_frames_per_sec", "value": batch * frames / dt, "unit": "predicted frames/s (x(f+1)/f incl. the conditioning frame)",
+           "seconds_per_sample_call": dt, "timing": f"median of {reps} sample() calls, HIP events on the launch stream", "call_seconds": times,
+           "config": {"workload": workload or f"AVDC sampler Unet_Libero {size}x{size}, 1+{frames} frames", "batch": batch,
+                      "sampling_steps": sampling_steps, "sampler": "ddim" if sampling_steps < 100 else "ddpm (ancestral)", "guidance_weight": 0,
+                      "hip_graph": True, "noise": "in-kernel Philox"},
+           "dtype": "f32", "algorithmic_tflops": flops / dt / 1e12, "output_range": [float(out.min()), float(out.max())]}
+    if not roofline:
+        return res
     # instrumented single UNet forward: per-variant conv timing with HIP events
     recs = []
     orig = ops.conv2d
@@ -380,7 +415,7 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video"):
     try:
         eng = unet._engine()
         lab = eng.label_embedding(te)
-        xin = ops.video_pack2(torch.randn(batch, 21, 128, 128, device=device), x_cond, 7, 128, 128)
+        xin = ops.video_pack2(torch.randn(batch, C, size, size, device=device), x_cond, frames, size, size)
         eng.forward_cl(xin, torch.full((batch,), 50, dtype=torch.long, device=device), lab)
         torch.cuda.synchronize()
     finally:
@@ -392,18 +427,26 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video"):
         v[0] += fl; v[1] += e0.elapsed_time(e1) * 1e-3; v[2] += 1
     name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
     ach = fl / sec / 1e12
-    return {"metric": "video_frames_per_sec", "value": batch * 7 / dt, "unit": "predicted frames/s (x8/7 incl. the conditioning frame)",
-            "seconds_per_sample_call": dt, "config": {"workload": "AVDC sampler Unet_Libero 128x128, 1+7 frames (BASELINE.json configs[2])",
-                                                       "batch": batch, "sampling_steps": sampling_steps, "sampler": "ddim" if sampling_steps < 100 else "ddpm",
-                                                       "guidance_weight": 0},
-            "dtype": "f32", "algorithmic_tflops": flops / dt / 1e12, "output_range": [float(out.min()), float(out.max())],
-            "unet_forwards": sampling_steps + 3,
-            "roofline": {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(traffic_leg, name),
-                         "traffic_vs_algorithmic": _leg_traffic(traffic_leg) if batch == 16 else None, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
-                         "share_of_conv_time": sec / sum(v[1] for v in agg.values()),
-                         "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]}
-                                               for k, v in sorted(agg.items())}}}
+    std = batch == 16 and size == 128
+    res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(traffic_leg, name) if std else None,
+                       "traffic_source": TRAFFIC_SOURCE if std else None,
+                       "traffic_vs_algorithmic": _leg_traffic(traffic_leg) if std else None, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                       "share_of_conv_time": sec / sum(v[1] for v in agg.values()),
+                       "end_to_end_frac": flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                       "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]}
+                                             for k, v in sorted(agg.items())}}
+    return res
+
+
+def _as_bf16(vb, note):
+    if "roofline" in vb:
+        vb["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
+        vb["roofline"]["frac"] = vb["roofline"]["achieved"] / BF16_MFMA_PEAK_TFLOPS
+        vb["roofline"]["end_to_end_frac"] = vb["algorithmic_tflops"] / BF16_MFMA_PEAK_TFLOPS
+    vb["dtype"] = "bf16 activations / weights in HBM, bf16 MFMA, f32 accumulate / norm statistics / softmax"
+    vb["note"] = note
+    return vb
 
 
 def video_train_leg(torch, device, batch=2, steps=4, warmup=2):
@@ -442,6 +485,49 @@ def video_train_leg(torch, device, batch=2, steps=4, warmup=2):
     return res
 
 
+def _timed_policy_steps(torch, tr, steps, barrier):
+    """The driver contract: K steps bracketed by barrier + synchronize on both sides (wall clock), plus one HIP event per step on the
+    launch stream -> the median step interval."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        evs[i].record()
+        tr.step()
+    evs[steps].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    iv = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return dt, _median(iv)
+
+
+def _rccl_algo(path):
+    """What RCCL logged about the all-reduce (NCCL_DEBUG=INFO, subsystems INIT + TUNING): the `-> Algo a proto p` decisions by message
+    size and the ring / tree channel lines."""
+    import glob
+    import re
+    names = {0: "tree", 1: "ring", 2: "collnet_direct", 3: "collnet_chain", 4: "nvls", 5: "nvls_tree"}
+    out = {"log": path, "decisions": [], "channels": None}
+    try:
+        txt = ""
+        for f in sorted(glob.glob(path.replace("%h", "*").replace("%p", "*")))[:1]:
+            txt = open(f, errors="replace").read()
+        for m in re.finditer(r"AllReduce:?\s*(\d+)\s*Bytes\s*->\s*Algo\s*(\d+)\s*proto\s*(\d+)", txt):
+            d = {"bytes": int(m.group(1)), "algo": names.get(int(m.group(2)), m.group(2)), "proto": int(m.group(3))}
+            if d not in out["decisions"]:
+                out["decisions"].append(d)
+        out["decisions"] = out["decisions"][:8]
+        ch = re.findall(r"(\d+) coll channels", txt)
+        out["channels"] = int(ch[0]) if ch else None
+        out["rings_logged"] = len(re.findall(r"Ring \d+ :", txt)) or len(re.findall(r"Channel \d+/\d+ :", txt))
+        out["trees_logged"] = len(re.findall(r"Trees? \[", txt))
+        if not txt:
+            out["note"] = "no RCCL log found (NCCL_DEBUG_FILE)"
+    except Exception as e:
+        out["note"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -450,7 +536,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-video", action="store_true", help="skip the video-sampler leg (BASELINE.json configs[2])")
+    ap.add_argument("--no-video", action="store_true", help="skip the video-sampler legs (BASELINE.json configs[2], released config, C5, B=1)")
     ap.add_argument("--no-video-train", action="store_true", help="skip the video-model training-step leg")
     ap.add_argument("--no-predict", action="store_true", help="skip the predict_action latency leg")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented eager pass (profiling runs)")
@@ -460,6 +546,7 @@ def main():
     ap.add_argument("--no-bf16-extra", action="store_true", help="skip the additional bf16-mode measurements appended to the fp32 run")
     ap.add_argument("--video-batch", type=int, default=16)
     ap.add_argument("--video-steps", type=int, default=50)
+    ap.add_argument("--video-reps", type=int, default=3)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -474,12 +561,26 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))))
 
-    import numpy as np
-    import random
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dp = os.environ.get("V2A_FORCE_DP") == "1"      # one rank through the N > 1 step structure + RCCL (validation on a 1-GPU box)
+    rccl_log = None
+    if world > 1 or force_dp:
+        # what RCCL decides for the gradient all-reduce is part of the result (comm.algo): have it log its tuning decisions to a file
+        rccl_log = os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/v2a_rccl_{os.getpid()}_%h_%p.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+
+    # ---- CPU baseline FIRST (rank 0, N = 1): the GPU is idle and nothing is being timed on it while the CPU oracle runs
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = CpuBaselines(args.batch, args.video_steps, video=not args.no_video)
+        cpu.run_all()
+
+    import numpy as np
+    import random
+    import torch
     if args.gpus != world and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -490,7 +591,6 @@ def main():
     device = f"cuda:{dev_index}"
     pg = None
     backend = None
-    force_dp = os.environ.get("V2A_FORCE_DP") == "1"      # one rank through the N > 1 step structure + RCCL (validation on a 1-GPU box)
     if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -521,25 +621,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = CpuBaselines(args.batch, args.video_steps, video=not args.no_video)      # one-thread runs tick in the background from here on
+    def max_over_ranks(x):
+        if world <= 1:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(max(args.warmup, 3)):       # >= 3: two eager steps + the capture step
         tr.step()
     if tr.dp:
         tr.comm_events = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, med_ms = _timed_policy_steps(torch, tr, args.steps, barrier)
+    dt = max_over_ranks(dt)
     comm = None
     if tr.dp:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # exposed communication: how long the compute stream sat in its wait on the communicator, per step (HIP events recorded on
         # the launch stream right before / after GradReducer.finish)
         exposed = [a.elapsed_time(b) for a, b in tr.comm_events]
@@ -557,18 +655,22 @@ def main():
             torch.cuda.synchronize()
             iso.append(e0.elapsed_time(e1))
         tr.arena.zero_()
+        nbytes = tr.reducer.bytes_per_step()
+        iso_ms = _median(iso)
         comm = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else "gloo (ranks share a GPU: RCCL needs one device per rank)",
                 "rccl_ranks": world if backend == "nccl" else 0, "ranks": world, "physical_gpus": min(world, ndev),
-                "allreduce_bytes_per_step": tr.reducer.bytes_per_step(), "slices": [hi - lo for lo, hi in tr.reducer.slices],
-                "allreduce_ms_isolated": sorted(iso)[len(iso) // 2],
+                "allreduce_bytes_per_step": nbytes, "slices": [hi - lo for lo, hi in tr.reducer.slices],
+                "allreduce_ms_isolated": iso_ms,
+                "allreduce_busbw_GBps": (nbytes * 2.0 * (world - 1) / max(world, 1) / (iso_ms * 1e-3) / 1e9) if world > 1 else None,
                 "exposed_comm_ms_per_step": sum(exposed) / max(len(exposed), 1),
+                "algo": _rccl_algo(rccl_log) if (backend == "nccl" and rccl_log) else None,
                 "note": "slice 0 (ConditionalUnet1D gradients) is launched after backward phase 1 and travels under the image-encoder "
                         "backward; exposed = compute-stream wait on the communicator, measured with HIP events inside the timed steps"}
     loss = float(tr.loss.item())
 
     out = None
+    ms = dt / args.steps * 1e3
     if rank == 0:
-        ms = dt / args.steps * 1e3
         value = world * args.steps / dt
         P = 87219143
         flops_step = 8.722e9 * args.batch                  # fwd+bwd algorithmic FLOPs per sample
@@ -579,53 +681,84 @@ def main():
                                       "compute_loss fwd/bwd -> clip -> AdamW -> EMA", "batch_per_gpu": args.batch,
                           "global_batch": args.batch * world, "image": "128x128x3 uint8 start+goal", "action": "16x7",
                           "params": P, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+               "ms_per_step_median_hip_events": med_ms,
                "samples_per_sec": value * args.batch, "final_loss": loss,
                "step_algorithmic_tflops": flops_step / (ms * 1e-3) / 1e12}
         if comm is not None:
             out["comm"] = comm
+
+    # ---- N > 1: the sampler sharded by batch rows and the joint loop (BASELINE configs[3]); every rank takes part
+    if world > 1 and not args.no_video:
+        try:
+            v2a_hip.set_video_storage("bf16")
+            rows = max(1, -(-args.video_batch // world))
+            barrier()
+            vs = video_leg(torch, device, rows, args.video_steps, traffic_leg="video_bf16", reps=args.video_reps, roofline=False,
+                           workload="BASELINE configs[2] sharded by batch rows over the ranks")
+            t_call = max_over_ranks(vs["seconds_per_sample_call"])
+            # per-task exploration rollouts of the released config (lb_online_trainer_v7.py:871,888-891: 8 tasks, bs = 1, 100 ancestral
+            # steps): tasks r, r + N, ... on rank r
+            tasks = len(range(rank, 8, world))
+            barrier()
+            vr = video_leg(torch, device, 1, 100, reps=1, roofline=False) if tasks else None
+            t_roll = max_over_ranks((vr["seconds_per_sample_call"] * tasks) if vr else 0.0)
+            if rank == 0:
+                out["video_bf16"] = _as_bf16({"metric": "video_frames_per_sec", "value": rows * world * 7 / t_call,
+                                              "unit": "predicted frames/s, all ranks", "rows_per_rank": rows, "seconds_per_sample_call": t_call,
+                                              "config": vs["config"], "timing": vs["timing"] + "; MAX over ranks",
+                                              "algorithmic_tflops": 2.130 * rows * world * args.video_steps / t_call},
+                                             "weak-free: the B rows of one sample() call are split over the ranks, no collective")
+                every = 200                                      # config/libero/lb_tk8_65to72.py:84-90: one exploration round per 200 steps
+                out["joint"] = {"workload": "BASELINE configs[3]: policy train steps + one video-guided exploration round (8 tasks, bs 1, 100 "
+                                            "ancestral steps, tasks split over the ranks) every 200 steps", "rollout_every_steps": every,
+                                "sampler_seconds_per_round": t_roll, "tasks_per_rank_max": -(-8 // world),
+                                "steps_per_sec_incl_sampling": world * every / (every * ms * 1e-3 + t_roll),
+                                "note": "the policy rollouts inside a round run in the simulator (out of scope); only the video sampler's share is timed"}
+            v2a_hip.set_video_storage("f32")
+        except Exception as e:
+            if rank == 0:
+                out["video_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- roofline of the dominant kernel (rank 0, N=1 only): instrumented eager pass
-    if rank == 0 and world == 1 and not args.no_roofline_pass:
-        agg = instrumented_pass(torch, tr, 3)
-        tot = sum(v[1] for v in agg.values())
-        name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
-        achieved = fl / sec / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("policy", {}).get(name)
-            except Exception:
-                traffic = None
-        out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                           "traffic_vs_algorithmic": _leg_traffic("policy") if (args.batch == 64 and args.precision == "fp32") else None,
-                           "launches": cnt,
-                           "avg_launch_us": sec / cnt * 1e6, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
-                           "share_of_conv_time": sec / tot,
-                           "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 3 * 1e3, "launches_per_step": v[2] // 3}
-                                                 for k, v in sorted(agg.items())}}
+    if rank == 0 and world == 1:
+        if not args.no_roofline_pass:
+            agg = instrumented_pass(torch, tr, 3)
+            tot = sum(v[1] for v in agg.values())
+            name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+            achieved = fl / sec / 1e12
+            peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                               "frac": achieved / peak, "traffic": _traffic("policy", name), "traffic_source": TRAFFIC_SOURCE,
+                               "traffic_vs_algorithmic": _leg_traffic("policy") if (args.batch == 64 and args.precision == "fp32") else None,
+                               "launches": cnt, "avg_launch_us": sec / cnt * 1e6, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
+                               "share_of_conv_time": sec / tot, "whole_step_frac_of_mfma_floor": flops_step / (ms * 1e-3) / 1e12 / peak,
+                               "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 3 * 1e3, "launches_per_step": v[2] / 3}
+                                                     for k, v in sorted(agg.items())}}
         if cpu is not None:
             out["cpu_baseline"] = cpu.policy()
-        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
-        out["roofline"]["peak"] = peak
-        out["roofline"]["frac"] = out["roofline"]["achieved"] / peak
         if args.precision == "fp32" and not args.no_bf16_extra:
-            # the same step in the bf16-MFMA performance configuration (fresh trainer: new hipGraph), reported beside the parity run
+            # the same step in the bf16-MFMA performance configuration (fresh trainer: new hipGraph), reported beside the parity run.
+            # BASELINE configs[1] names bf16: this leg is HBM-bound (64 B x 87.2 M parameters + 3 x 3.326 M x B x 4 B of
+            # activations = 8.13 GB per step against a 0.22 ms MFMA floor), so its roofline is bytes / time against 8 TB/s.
             v2a_hip.set_precision("bf16")
             torch.manual_seed(0)
             pol2 = build_policy(DEFAULT_CONF).to(device)
             tr2 = PolicyTrainer(pol2, store, batch_size=args.batch, seed=rank, use_graph=not args.no_graph)
             for _ in range(max(args.warmup, 3)):
                 tr2.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                tr2.step()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            out["bf16"] = {"metric": "policy_train_steps_per_sec", "value": args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+            dt2, med2 = _timed_policy_steps(torch, tr2, args.steps, barrier)
+            ms2 = dt2 / args.steps * 1e3
+            alg_bytes = 64.0 * 87219143 + 3 * 3.326e6 * args.batch * 4
+            out["bf16"] = {"metric": "policy_train_steps_per_sec", "value": args.steps / dt2, "ms_per_step": ms2,
+                           "ms_per_step_median_hip_events": med2,
                            "dtype": "bf16 MFMA inputs, f32 accumulate/storage/optimizer", "final_loss": float(tr2.loss.item()),
-                           "note": "performance configuration; parity (1e-4) is claimed for the fp32 run only"}
+                           "roofline": {"kernel": "whole captured step (HBM-bound leg: no single kernel dominates)", "bound": "hbm",
+                                        "achieved": alg_bytes / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": alg_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_bytes,
+                                        "traffic": None, "traffic_source": None,
+                                        "mfma_floor_ms": 8.722e9 * args.batch / (BF16_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
+                                        "hbm_floor_ms": alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3},
+                           "note": "performance configuration (what BASELINE configs[1] names); parity (1e-4) is claimed for the fp32 run only"}
             del tr2, pol2
             v2a_hip.set_precision("fp32")
         # predict_action latency (B=1, DDIM-8, EMA-style replica) under hipGraph replay
@@ -638,12 +771,15 @@ def main():
             obs1 = {k: torch.rand(1, 1, 3, 128, 128, device=device) for k in ("img_obs_1", "img_goal_1")}
             for _ in range(3):
                 gp(obs1)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
+            lat = []
             for _ in range(50):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 gp(obs1)
-            torch.cuda.synchronize()
-            out["predict_action"] = {"latency_ms": (time.perf_counter() - t2) / 50 * 1e3, "batch": 1, "sampler": "ddim-8",
+                e1.record()
+                torch.cuda.synchronize()
+                lat.append(e0.elapsed_time(e1))
+            out["predict_action"] = {"latency_ms": _median(lat), "batch": 1, "sampler": "ddim-8", "timing": "median of 50 HIP-event intervals",
                                      "note": "encoders + 8 ConditionalUnet1D steps + unnormalise, one hipGraph replay per call; "
                                              "reference CPU path 110 ms (SURVEY section 6)"}
         except KeyboardInterrupt:
@@ -653,19 +789,41 @@ def main():
         if not args.no_video:
             del tr, pol, store
             torch.cuda.empty_cache()
-            out["video"] = video_leg(torch, device, args.video_batch, args.video_steps)
-            if cpu is not None:
+            R = args.video_reps
+
+            def leg(key, fn):
+                try:
+                    torch.cuda.empty_cache()
+                    out[key] = fn()
+                except Exception as e:
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
+
+            leg("video", lambda: video_leg(torch, device, args.video_batch, args.video_steps, reps=R,
+                                           workload="AVDC sampler Unet_Libero 128x128, 1+7 frames (BASELINE.json configs[2])"))
+            if cpu is not None and "error" not in out["video"]:
                 out["video"]["cpu_baseline"] = cpu.video()
             if args.precision == "fp32" and not args.no_bf16_extra:
+                note16 = ("performance configuration (counterpart of the reference's fp16-autocast GPU path); 0.8 % relative L2 "
+                          "deviation from the fp32 parity path per UNet forward (tests/test_video_gpu.py)")
                 v2a_hip.set_video_storage("bf16")
-                torch.cuda.empty_cache()
-                vb = video_leg(torch, device, args.video_batch, args.video_steps, traffic_leg="video_bf16")
-                vb["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
-                vb["roofline"]["frac"] = vb["roofline"]["achieved"] / BF16_MFMA_PEAK_TFLOPS
-                vb["dtype"] = "bf16 activations / weights in HBM, bf16 MFMA, f32 accumulate / norm statistics / softmax"
-                vb["note"] = ("performance configuration (counterpart of the reference's fp16-autocast GPU path); 0.8 % relative L2 "
-                              "deviation from the fp32 parity path per UNet forward (tests/test_video_gpu.py)")
-                out["video_bf16"] = vb
+                leg("video_bf16", lambda: _as_bf16(video_leg(torch, device, args.video_batch, args.video_steps, traffic_leg="video_bf16", reps=R,
+                                                             workload="AVDC sampler Unet_Libero 128x128, 1+7 frames (BASELINE.json configs[2])"), note16))
+                # the RELEASED sampler configuration (SURVEY 8d "also report the reference-config variant"): 100 ancestral DDPM steps
+                leg("video_bf16_ddpm100", lambda: _as_bf16(video_leg(
+                    torch, device, args.video_batch, 100, traffic_leg="video_bf16", reps=R, roofline=False,
+                    workload="released sampler config (config/libero/lb_tk8_65to72.py:40-47): 100 ancestral steps, B=16"), note16))
+                # what the trainer actually issues: ONE task at bs = 1 (lb_online_trainer_v7.py:871,888-891) -> latency per rollout
+                def b1():
+                    r = _as_bf16(video_leg(torch, device, 1, 100, reps=R, roofline=False,
+                                           workload="per-task exploration rollout: bs = 1, 100 ancestral steps (lb_online_trainer_v7.py:871-891)"), note16)
+                    r["latency_ms_per_rollout"] = r["seconds_per_sample_call"] * 1e3
+                    r["ms_per_denoise_step"] = r["seconds_per_sample_call"] * 1e3 / 100
+                    return r
+                leg("video_b1", b1)
+                # BASELINE configs[4], video half at a 1-GPU slice: 256x256, 16-frame sequence (1 cond + 15 predicted), per-GPU batch 2
+                leg("video_c5", lambda: _as_bf16(video_leg(
+                    torch, device, 2, args.video_steps, size=256, frames=15, reps=R, roofline=False,
+                    workload="BASELINE configs[4] video half: 256x256, 1+15 frames, per-GPU sampler batch 2 (16 over 8 GPUs)"), note16))
                 v2a_hip.set_video_storage("f32")
             if not args.no_video_train:
                 try:
@@ -673,8 +831,6 @@ def main():
                     out["video_train"] = video_train_leg(torch, device)
                 except Exception as e:
                     out["video_train"] = {"error": f"{type(e).__name__}: {e}"}
-    if cpu is not None:
-        cpu.abandon()
     if rank == 0:
         print(json.dumps(out))
     sys.stdout.flush()

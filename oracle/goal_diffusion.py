@@ -2,8 +2,8 @@
 
 Follows /root/reference/flowdiffusion/flowdiffusion/goal_diffusion.py:
   cosine_beta_schedule :317-327, buffers :390-454, predict_start_from_v :484-488,
-  predict_noise_from_start :472-476, q_posterior :490-497, model_predictions :499-559 (pred_v,
-  both the guidance_weight==0 branch :549-553 and the CFG branch :501-514,:536-547),
+  predict_noise_from_start :472-476, q_posterior :490-497, model_predictions :499-559 (all three objectives: pred_noise :521-527,
+  pred_x0 :529-532, pred_v -- both the guidance_weight==0 branch :549-553 and the CFG branch :501-514,:536-547),
   p_sample :571-580, p_sample_loop :582-599, ddim_sample :601-641, sample :643-650.
 
 p_losses / forward :690-724 (training): `p_losses` below, differentiated by torch autograd exactly as the reference does.
@@ -53,8 +53,8 @@ def ddim_time_pairs(total=100, sampling=50):
     return list(zip(times[:-1], times[1:]))
 
 
-def _model_predictions(model_fn, T, x, t_int, x_cond, task_embed, gw):
-    """pred_v objective.  Returns (pred_noise, x_start)."""
+def _model_predictions(model_fn, T, x, t_int, x_cond, task_embed, gw, objective="pred_v"):
+    """Returns (pred_noise, x_start); clip_x_start = False as both sampling loops call it (:562, :617)."""
     B = x.shape[0]
     t = torch.full((B,), t_int, dtype=torch.long)
     sa, s1 = T["sqrt_alphas_cumprod"][t_int], T["sqrt_one_minus_alphas_cumprod"][t_int]
@@ -65,27 +65,38 @@ def _model_predictions(model_fn, T, x, t_int, x_cond, task_embed, gw):
         te2[B:] = 0.0
         out = model_fn(x_in.repeat(2, 1, 1, 1), t.repeat(2), te2)
         v_c, v_u = out[:B], out[B:]
-        x0_c = sa * x - s1 * v_c
-        x0_u = sa * x - s1 * v_u
-        n_u = (ra * x - x0_u) / rm
-        n_c = (ra * x - x0_c) / rm
-        pred_noise = (1 + gw) * n_c - gw * n_u
+        if objective != "pred_v":
+            model_output = (1 + gw) * v_c - gw * v_u                              # :514
+        else:
+            x0_c = sa * x - s1 * v_c
+            x0_u = sa * x - s1 * v_u
+            n_u = (ra * x - x0_u) / rm
+            n_c = (ra * x - x0_c) / rm
+            pred_noise = (1 + gw) * n_c - gw * n_u
+            x_start = ra * x - rm * pred_noise
+            return pred_noise, x_start
+    else:
+        model_output = model_fn(x_in, t, task_embed)
+    if objective == "pred_noise":
+        pred_noise = model_output
         x_start = ra * x - rm * pred_noise
-        return pred_noise, x_start
-    v = model_fn(x_in, t, task_embed)
-    x_start = sa * x - s1 * v
-    pred_noise = (ra * x - x_start) / rm
+    elif objective == "pred_x0":
+        x_start = model_output
+        pred_noise = (ra * x - x_start) / rm
+    else:
+        x_start = sa * x - s1 * model_output
+        pred_noise = (ra * x - x_start) / rm
     return pred_noise, x_start
 
 
 @torch.no_grad()
 def p_sample_loop(model_fn, T, noises, x_cond, task_embed, guidance_weight=0.0, var_temp=1.0,
-                  num_timesteps=100, record=None):
+                  num_timesteps=100, record=None, objective="pred_v"):
     """Ancestral DDPM loop.  noises[0]: initial x_T; noises[1+k]: noise used at the k-th step with t>0."""
     img = noises[0]
     k = 1
     for t in reversed(range(num_timesteps)):
-        _, x0 = _model_predictions(model_fn, T, img, t, x_cond, task_embed, guidance_weight)
+        _, x0 = _model_predictions(model_fn, T, img, t, x_cond, task_embed, guidance_weight, objective)
         x0 = x0.clamp(-1.0, 1.0)
         mean = T["posterior_mean_coef1"][t] * x0 + T["posterior_mean_coef2"][t] * img
         if t > 0:
@@ -101,12 +112,12 @@ def p_sample_loop(model_fn, T, noises, x_cond, task_embed, guidance_weight=0.0, 
 
 @torch.no_grad()
 def ddim_sample(model_fn, T, noises, x_cond, task_embed, guidance_weight=0.0, num_timesteps=100,
-                sampling_timesteps=50, eta=0.0, record=None):
+                sampling_timesteps=50, eta=0.0, record=None, objective="pred_v"):
     """DDIM loop; eta=0 so the drawn noise is multiplied by sigma=0 (still consumed: noises[1+k])."""
     img = noises[0]
     k = 1
     for time, time_next in ddim_time_pairs(num_timesteps, sampling_timesteps):
-        pred_noise, x_start = _model_predictions(model_fn, T, img, time, x_cond, task_embed, guidance_weight)
+        pred_noise, x_start = _model_predictions(model_fn, T, img, time, x_cond, task_embed, guidance_weight, objective)
         if time_next < 0:
             img = x_start
         else:
@@ -122,12 +133,12 @@ def ddim_sample(model_fn, T, noises, x_cond, task_embed, guidance_weight=0.0, nu
 
 
 def sample(model_fn, T, noises, x_cond, task_embed, guidance_weight=0.0, var_temp=1.0,
-           num_timesteps=100, sampling_timesteps=100, record=None):
+           num_timesteps=100, sampling_timesteps=100, record=None, objective="pred_v"):
     if sampling_timesteps < num_timesteps:
         return ddim_sample(model_fn, T, noises, x_cond, task_embed, guidance_weight, num_timesteps,
-                           sampling_timesteps, record=record)
+                           sampling_timesteps, record=record, objective=objective)
     return p_sample_loop(model_fn, T, noises, x_cond, task_embed, guidance_weight, var_temp, num_timesteps,
-                         record=record)
+                         record=record, objective=objective)
 
 
 def p_losses(model_fn, T, x_start, t, x_cond, task_embed, noise, objective="pred_v", loss_type="l2"):

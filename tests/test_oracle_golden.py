@@ -72,6 +72,42 @@ def test_oracle_unet_and_sampler_vs_reference(golden_dir):
         noises = [torch.randn(2, 9, 32, 32) for _ in range(steps + 1)]
         out = GD.sample(fn, T, noises, x_cond, te, guidance_weight=gw, num_timesteps=100, sampling_timesteps=steps)
         assert rel(out, g[f"sample_{name}"]) < 1e-5, name
+    # round 3: pred_noise / pred_x0 (model_predictions :521-532, with and without classifier-free guidance) -- reference-made fixtures
+    for name, steps, gw, obj in [("ddim50_pred_noise", 50, 0.0, "pred_noise"), ("ddim50_pred_x0", 50, 0.0, "pred_x0"),
+                                 ("ddim10_cfg_pred_x0", 10, 1.5, "pred_x0"), ("ddim10_cfg_pred_noise", 10, 1.5, "pred_noise")]:
+        torch.manual_seed(1234)
+        noises = [torch.randn(2, 9, 32, 32) for _ in range(steps + 1)]
+        out = GD.sample(fn, T, noises, x_cond, te, guidance_weight=gw, num_timesteps=100, sampling_timesteps=steps, objective=obj)
+        assert rel(out, g[f"sample_{name}"]) < 1e-5, name
+
+
+def test_oracle_unet_wrappers_vs_reference(golden_dir):
+    """UnetThor / UnetMWFlow / UnetBridge / UnetMW (reference flowdiffusion/flowdiffusion/unet.py:7-192): the oracle's UNet under the
+    wrappers' pack / unpack against forward outputs of the REFERENCE classes (tools/make_golden.py wrappers)."""
+    import flowdiffusion.flowdiffusion.unet as U
+    from oracle.param_fill import fill_module
+    from oracle.video_unet import UNetCfg, unet_forward
+    from tools_wsum import wsum
+    g = np.load(f"{golden_dir}/wrappers.npz")
+    for cls_name, ci, res, frames in [("UnetThor", 3, 16, 2), ("UnetMWFlow", 2, 32, 2), ("UnetBridge", 3, 16, 2), ("UnetMW", 3, 32, 2)]:
+        torch.manual_seed(0)
+        m = getattr(U, cls_name)()
+        sd = fill_module(m, seed=21)
+        assert abs(wsum(sd) - float(g[f"{cls_name}_wsum"])) < 1e-9 * float(g[f"{cls_name}_wsum"]), cls_name
+        cm = m.unet
+        cfg = UNetCfg(in_channels=cm.in_channels, model_channels=cm.model_channels, out_channels=cm.out_channels,
+                      num_res_blocks=cm.num_res_blocks, attention_resolutions=cm.attention_resolutions, channel_mult=cm.channel_mult,
+                      num_head_channels=32)
+        gen = torch.Generator().manual_seed(5)
+        x = torch.randn(1, frames * ci + 3, res, res, generator=gen)
+        t = torch.tensor([17])
+        te = torch.randn(1, 4, 512, generator=gen)
+        cond = x[:, -3:, None].expand(1, 3, frames, res, res)
+        xx = x[:, :-3].reshape(1, frames, ci, res, res).permute(0, 2, 1, 3, 4)
+        with torch.no_grad():
+            yo = unet_forward(sd, torch.cat([xx, cond], 1), t, te, cfg, pre="unet.")
+        yo = yo.permute(0, 2, 1, 3, 4).reshape(1, frames * cm.out_channels, res, res)
+        assert rel(yo, g[f"{cls_name}_y"]) < 1e-5, (cls_name, rel(yo, g[f"{cls_name}_y"]))
 
 
 def test_oracle_video_p_losses_vs_reference(golden_dir):
@@ -229,3 +265,56 @@ def test_oracle_optimiser_vs_torch():
         assert max((a - b).abs().max().item() for a, b in zip(ps, ref)) == 0.0
     # decay(step) = clamp(1 - (1 + step)^-0.75): in-tree statement diffuser/diffusion_policy/model/ema_model.py:44-54
     assert O.ema_decay(1) == 0.0 and abs(O.ema_decay(2) - (1 - 2 ** -0.75)) < 1e-12 and O.ema_decay(10 ** 9) == 0.9999
+
+
+def test_policy_schedulers_against_published_closed_forms():
+    """R7 (diffusers DDPMScheduler / DDIMScheduler, absent third party): the restatement is checked against answers that follow from
+    the PUBLISHED definitions by a different route than the restated loops (no network here: the sources are cited, the numbers
+    are derived in fp64 below, independently of oracle/schedulers.py's code path):
+      * squaredcos_cap_v2 = Nichol & Dhariwal 2021 (arXiv:2102.09672) eq. 17: alpha_bar(t) = f(t)/f(0), f(t) = cos^2((t/T + s)/(1 + s) pi/2),
+        s = 0.008, beta_t = min(1 - alpha_bar(t)/alpha_bar(t-1), 0.999).  While the cap is inactive the cumulative product telescopes:
+        alphas_cumprod[i] = f((i+1)/T)/f(0) in closed form; f(1) = 0, so only the LAST beta is capped: alphas_cumprod[T-1] =
+        alphas_cumprod[T-2] * 0.001.
+      * "leading" timestep spacing (Lin et al. 2023, arXiv:2305.08891 table 2; diffusers' default): t_i = i * floor(T / n), descending:
+        T = 100, n = 8 -> 84, 72, ..., 0.
+      * one ancestral step, Ho et al. 2020 (arXiv:2006.11239): the posterior mean of eq. 7 with x0 from eq. 15 equals eq. 11,
+        mu = (x_t - beta_t / sqrt(1 - alpha_bar_t) eps) / sqrt(alpha_t), whenever the x0 clip is inactive; "fixed_small" variance =
+        beta_t (1 - alpha_bar_{t-1}) / (1 - alpha_bar_t) (eq. 7's beta-tilde).
+      * one DDIM step, Song et al. 2021 (arXiv:2010.02502) eq. 12 with sigma = 0."""
+    import math
+    from oracle import schedulers as S
+    T = 100
+    f = lambda u: math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2
+    ac = S.squaredcos_alphas_cumprod(T).double().numpy()
+    closed = np.array([f((i + 1) / T) / f(0.0) for i in range(T)])
+    assert np.abs(ac[:T - 1] / closed[:T - 1] - 1).max() < 2e-5          # fp32 cumulative product of 99 factors vs the closed form
+    assert abs(ac[T - 1] / (ac[T - 2] * 0.001) - 1) < 2e-5               # the 0.999 cap on the last beta (1 - fp32(0.999) = 1.0000129e-3)
+    betas = S.squaredcos_betas(T).double().numpy()
+    assert abs(betas[T - 1] - 0.999) < 1e-7 and (betas[:T - 1] < 0.999).all() and (np.diff(betas[:T - 1]) > 0).all()
+    # three anchor values from the closed form (fp64), to 5 significant digits
+    for i, v in ((0, f(0.01) / f(0.0)), (49, f(0.5) / f(0.0)), (98, f(0.99) / f(0.0))):
+        assert abs(ac[i] / v - 1) < 2e-5, (i, ac[i], v)
+    assert S.ddim_timesteps(100, 8) == [84, 72, 60, 48, 36, 24, 12, 0]
+    assert S.ddim_timesteps(100, 10) == list(range(90, -1, -10))
+    g = torch.Generator().manual_seed(0)
+    act = S.squaredcos_alphas_cumprod(T)
+    x_t = torch.randn(4, 16, 7, generator=g) * 0.12
+    eps = torch.randn(4, 16, 7, generator=g) * 0.12
+    noise = torch.randn(4, 16, 7, generator=g)
+    for t in (7, 50):
+        a_bar, a_prev = float(act[t]), float(act[t - 1])
+        alpha_t = a_bar / a_prev
+        beta_t = 1 - alpha_t
+        x0 = (x_t.double() - math.sqrt(1 - a_bar) * eps.double()) / math.sqrt(a_bar)
+        assert float(x0.abs().max()) < 1.0                                 # clip inactive: eq. 11 applies
+        mu = (x_t.double() - beta_t / math.sqrt(1 - a_bar) * eps.double()) / math.sqrt(alpha_t)
+        sigma = math.sqrt(beta_t * (1 - a_prev) / (1 - a_bar))
+        got = S.ddpm_step(act, eps, t, x_t, noise, T)
+        assert rel(got, mu + sigma * noise.double()) < 2e-5
+    # DDIM (eta = 0): x_prev = sqrt(a_prev) x0 + sqrt(1 - a_prev) eps, previous step 12 below; the final step lands on alpha_bar = 1
+    for t in (84, 12, 0):
+        a_bar = float(act[t])
+        a_prev = float(act[t - 12]) if t >= 12 else 1.0
+        x0 = ((x_t.double() - math.sqrt(1 - a_bar) * eps.double()) / math.sqrt(a_bar)).clamp(-1, 1)
+        want = math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps.double()
+        assert rel(S.ddim_step(act, eps, t, x_t, T, 8), want) < 2e-5

@@ -76,6 +76,17 @@ def g_unet_tiny():
         with torch.no_grad():
             img = d.sample(x_cond, te, batch_size=B)
         out[f"sample_{name}"] = img.numpy()
+    # round 3: the other two objectives of model_predictions (:521-532), var_temp (:365,:578) -- all by the reference's own sampler
+    for name, steps, gw, obj, vt in [("ddpm100_pred_noise", 100, 0.0, "pred_noise", 1.0), ("ddim50_pred_noise", 50, 0.0, "pred_noise", 1.0),
+                                     ("ddim50_pred_x0", 50, 0.0, "pred_x0", 1.0), ("ddim10_cfg_pred_x0", 10, 1.5, "pred_x0", 1.0),
+                                     ("ddim10_cfg_pred_noise", 10, 1.5, "pred_noise", 1.0), ("ddpm100_vt06", 100, 0.0, "pred_v", 0.6)]:
+        d = GoalGaussianDiffusion(m, image_size=(H, W), channels=3 * f, timesteps=100, sampling_timesteps=steps,
+                                  loss_type="l2", objective=obj, beta_schedule="cosine",
+                                  min_snr_loss_weight=True, guidance_weight=gw, var_temp=vt).eval()
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            img = d.sample(x_cond, te, batch_size=B)
+        out[f"sample_{name}"] = img.numpy()
     np.savez_compressed(f"{OUT}/unet_tiny.npz", **out)
     print("unet_tiny ok", out["weights_abs_sum"])
 
@@ -397,7 +408,29 @@ def g_schedule():
     print("schedule ok", {k: v.shape for k, v in out.items()})
 
 
-GROUPS = {"tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer}
+def g_wrappers():
+    """The other AVDC wrappers (reference flowdiffusion/flowdiffusion/unet.py:7-192), forward outputs of the REFERENCE classes with
+    name-derived weights: full output (small resolutions), inputs regenerated from seeds on the test side."""
+    import flowdiffusion.flowdiffusion.unet as U
+    assert "/root/reference" in U.__file__
+    out = {}
+    for cls_name, ci, res, frames in [("UnetThor", 3, 16, 2), ("UnetMWFlow", 2, 32, 2), ("UnetBridge", 3, 16, 2), ("UnetMW", 3, 32, 2)]:
+        torch.manual_seed(0)
+        m = getattr(U, cls_name)().eval()
+        sd = fill_module(m, seed=21)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(1, frames * ci + 3, res, res, generator=g)
+        t = torch.tensor([17])
+        te = torch.randn(1, 4, 512, generator=g)
+        with torch.no_grad():
+            y = m(x, t, te)
+        out[f"{cls_name}_y"] = y.numpy()
+        out[f"{cls_name}_wsum"] = np.array(wsum(sd))
+        print(cls_name, tuple(y.shape), float(y.abs().max()))
+    np.savez_compressed(f"{OUT}/wrappers.npz", **out)
+
+
+GROUPS = {"wrappers": g_wrappers, "tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

@@ -18,4 +18,4 @@ a = ap.parse_args()
 import v2a_hip
 v2a_hip.set_precision(a.precision)
 v2a_hip.set_video_storage(a.storage)
-print(json.dumps(bench.video_leg(torch, "cuda:0", a.batch, a.steps, traffic_leg="video_bf16" if a.storage == "bf16" else "video")))
+print(json.dumps(bench.video_leg(torch, "cuda:0", a.batch, a.steps, traffic_leg="video_bf16" if a.storage == "bf16" else "video", reps=1)))

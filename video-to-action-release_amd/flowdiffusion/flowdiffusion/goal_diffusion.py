@@ -12,6 +12,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+import weakref
+
+_SGRAPHS = weakref.WeakKeyDictionary()      # GoalGaussianDiffusion -> its captured sampler step (kept out of the module: deepcopy / state_dict)
+
+
+def drop_sampler_graph(diffusion):
+    """Forget the captured sampler step of `diffusion` (its weights / packed operands changed behind torch's version counters)."""
+    _SGRAPHS.pop(diffusion, None)
+
+
 def exists(x):
     return x is not None
 
@@ -134,69 +144,156 @@ class GoalGaussianDiffusion(nn.Module):
                  "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped")
         return {n: getattr(self, n).detach().cpu() for n in names}
 
-    @torch.no_grad()
-    def _sample_loop(self, shape, x_cond, task_embed, return_all_timesteps=False):
-        from v2a_hip import ops
-        if self.objective != "pred_v":
-            raise NotImplementedError("the HIP sampler implements the v-prediction objective of the released AVDC checkpoints")
-        device = self.betas.device
-        if device.type != "cuda":
-            raise RuntimeError("GoalGaussianDiffusion.sample runs on a HIP device only (no CPU fallback)")
-        B, C, H, W = shape
-        ci = getattr(self.model, "frame_channels", 3)
-        f = C // ci
+    def _step_rows(self, return_all_timesteps=False):
+        """Per-step coefficient rows (sa, s1, ra, rm, c1, c2, sigma, gw, mode, final, t) of the sampling loop: ancestral
+        (reference :561-599: posterior mean coefficients, sigma = exp(0.5 * log-variance) * var_temp, nothing added at t = 0) or DDIM
+        (:601-641: sqrt(alpha_next), c, sigma; the last pair returns x_start)."""
         T = self._tables_host()
-        eng = self.model._engine()
-        x_cond = x_cond.to(device).float().contiguous()
-        task_embed = task_embed.to(device).float().contiguous()
         gw = float(self.guidance_weight)
-        label = eng.label_embedding(task_embed)                               # t-independent: once per call
-        label_u = eng.label_embedding(torch.zeros_like(task_embed)) if gw > 0.0 else None
-        img = self._noise(shape, device)
-        imgs = [img]
-
-        def unet(img_t, t_int, lab):
-            xin = ops.video_pack2(img_t, x_cond, f, H, W, ci)
-            tt = torch.full((B,), t_int, dtype=torch.long, device=device)
-            return eng.forward_cl(xin, tt, lab)
-
+        rows = []
         if not self.is_ddim_sampling:
             steps = list(reversed(range(self.num_timesteps)))
             for i, t in enumerate(steps):
-                v = unet(img, t, label)
-                vu = unet(img, t, label_u) if gw > 0.0 else None
-                noise = self._noise(shape, device) if t > 0 else None
-                sigma = float((0.5 * T["posterior_log_variance_clipped"][t]).exp()) * float(self.var_temp)
-                coef = (T["sqrt_alphas_cumprod"][t], T["sqrt_one_minus_alphas_cumprod"][t], T["sqrt_recip_alphas_cumprod"][t],
-                        T["sqrt_recipm1_alphas_cumprod"][t], T["posterior_mean_coef1"][t], T["posterior_mean_coef2"][t], sigma, gw)
+                sigma = float((0.5 * T["posterior_log_variance_clipped"][t]).exp()) * float(self.var_temp) if t > 0 else 0.0
                 last = (i == len(steps) - 1) and not return_all_timesteps
-                img = ops.video_denoise_step(v, vu, img, noise, coef, 0, last, f, H * W, ci)
-                imgs.append(img)
+                rows.append((T["sqrt_alphas_cumprod"][t], T["sqrt_one_minus_alphas_cumprod"][t], T["sqrt_recip_alphas_cumprod"][t],
+                             T["sqrt_recipm1_alphas_cumprod"][t], T["posterior_mean_coef1"][t], T["posterior_mean_coef2"][t], sigma, gw,
+                             0, last, t))
         else:
             times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)
             times = list(reversed(times.int().tolist()))
             pairs = list(zip(times[:-1], times[1:]))
             eta = self.ddim_sampling_eta
             for i, (t, tn) in enumerate(pairs):
-                v = unet(img, t, label)
-                vu = unet(img, t, label_u) if gw > 0.0 else None
                 base = (T["sqrt_alphas_cumprod"][t], T["sqrt_one_minus_alphas_cumprod"][t], T["sqrt_recip_alphas_cumprod"][t],
                         T["sqrt_recipm1_alphas_cumprod"][t])
                 last = (i == len(pairs) - 1) and not return_all_timesteps
                 if tn < 0:
-                    img = ops.video_denoise_step(v, vu, img, None, base + (0.0, 0.0, 0.0, gw), 2, last, f, H * W, ci)
+                    rows.append(base + (0.0, 0.0, 0.0, gw, 2, last, t))
                 else:
                     a, an = T["alphas_cumprod"][t], T["alphas_cumprod"][tn]
                     sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
                     c = (1 - an - sigma ** 2).sqrt()
-                    noise = self._noise(shape, device)                      # drawn even when eta = 0 (RNG stream parity)
-                    img = ops.video_denoise_step(v, vu, img, noise if float(sigma) != 0.0 else None,
-                                                 base + (float(an.sqrt()), float(c), float(sigma), gw), 1, last, f, H * W, ci)
+                    rows.append(base + (float(an.sqrt()), float(c), float(sigma), gw, 1, last, t))
+        return rows
+
+    def _weights_version(self):
+        return sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.buffers())
+
+    @torch.no_grad()
+    def _sample_loop(self, shape, x_cond, task_embed, return_all_timesteps=False):
+        """Both sampling loops of the reference (p_sample_loop :582-599, ddim_sample :601-641) for all three objectives
+        (model_predictions :499-559).  Per step: one HIP UNet forward (two with classifier-free guidance) + ONE table-driven denoise
+        kernel.  Default path: the step {pack, UNet, denoise, advance} is captured ONCE into a hipGraph and replayed for every step of
+        every call (time step, coefficients and the Philox noise counter live in device memory); parity tests that inject the
+        reference's noise stream (`_noise_hook`) and `return_all_timesteps` take the eager path over the same kernels."""
+        from v2a_hip import ops
+        import v2a_hip
+        device = self.betas.device
+        if device.type != "cuda":
+            raise RuntimeError("GoalGaussianDiffusion.sample runs on a HIP device only (no CPU fallback)")
+        B, C, H, W = shape
+        ci = getattr(self.model, "frame_channels", 3)
+        f = C // ci
+        eng = self.model._engine()
+        x_cond = x_cond.to(device).float().contiguous()
+        task_embed = task_embed.to(device).float().contiguous()
+        gw = float(self.guidance_weight)
+        rows = self._step_rows(return_all_timesteps)
+        hook = self.__dict__.get("_noise_hook")
+        use_graph = hook is None and not return_all_timesteps and self.__dict__.get("_use_graph", True) and v2a_hip.sampler_graphs_enabled()
+        nq = (B * C * H * W + 3) // 4
+        if hook is None:
+            # sampler noise = counter-based Philox, seeded from torch's generator (torch.manual_seed reproduces a call); the initial
+            # image uses counters [off0, off0 + nq), step s the next block -- drawn inside the denoise kernel
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            off0 = 0
+        if not use_graph:
+            label = eng.label_embedding(task_embed)                               # t-independent: once per call
+            label_u = eng.label_embedding(torch.zeros_like(task_embed)) if gw > 0.0 else None
+            table = ops.video_denoise_table(rows, device)
+            state = None
+            if hook is None:
+                img = torch.empty(shape, dtype=torch.float32, device=device)
+                ops.philox_normal(img, seed, offset_imm=off0)
+                state = torch.tensor([0, seed, off0], dtype=torch.int64, device=device)
+            else:
+                img = self._noise(shape, device)
+            imgs = [img]
+            for i, r in enumerate(rows):
+                t = r[10]
+                tt = torch.full((B,), t, dtype=torch.long, device=device)
+                xin = ops.video_pack2(img, x_cond, f, H, W, ci)
+                v = eng.forward_cl(xin, tt, label)
+                vu = eng.forward_cl(xin, tt, label_u) if gw > 0.0 else None
+                noise = None
+                if hook is not None:
+                    # reference RNG order: ancestral draws for t > 0 only; DDIM draws per pair (also when eta = 0), none for the last
+                    if (r[8] == 0 and t > 0) or r[8] == 1:
+                        noise = self._noise(shape, device)
+                        if float(r[6]) == 0.0:
+                            noise = None
+                if state is not None:
+                    state[0] = i
+                img = ops.video_denoise_step2(v, vu, img, noise, table, self.objective, f, H * W, ci, state=state, step=i,
+                                              use_philox=hook is None)
                 imgs.append(img)
-        if return_all_timesteps:
-            ret = torch.stack(imgs, dim=1)
-            return self.unnormalize(ret).clamp(min=0, max=1)
-        return img
+            if return_all_timesteps:
+                ret = torch.stack(imgs, dim=1)
+                return self.unnormalize(ret).clamp(min=0, max=1)
+            return img
+        # ---- whole-loop hipGraph
+        key = (B, C, H, W, ci, gw > 0.0, self.objective, getattr(eng, "storage", "f32"), v2a_hip.get_precision(), tuple(task_embed.shape),
+               id(eng), self._weights_version())
+        g = _SGRAPHS.get(self)
+        if g is None or g["key"] != key:
+            _SGRAPHS.pop(self, None)
+            g = self._build_sampler_graph(key, eng, shape, ci, f, task_embed.shape, gw)
+            _SGRAPHS[self] = g
+        g["x_cond"].copy_(x_cond)
+        if not torch.equal(g["task_embed"], task_embed):          # the text branch does not depend on t: recomputed only when it changes
+            g["task_embed"].copy_(task_embed)
+            g["label"].copy_(eng.label_embedding(task_embed))
+        ops.video_denoise_table(rows, device, out=g["table"])
+        g["state"].copy_(torch.tensor([0, seed, off0], dtype=torch.int64))
+        g["tt"].fill_(rows[0][10])
+        ops.philox_normal(g["img"], seed, offset_imm=off0)
+        g["nrows"][0] = len(rows)
+        for _ in range(len(rows)):
+            g["graph"].replay()
+        return g["img"].clone()
+
+    def _build_sampler_graph(self, key, eng, shape, ci, f, te_shape, gw):
+        from v2a_hip import ops
+        device = self.betas.device
+        B, C, H, W = shape
+        MAXR = 1024
+        assert self.num_timesteps <= MAXR
+        g = dict(key=key, img=torch.zeros(shape, dtype=torch.float32, device=device),
+                 x_cond=torch.zeros((B, 3, H, W), dtype=torch.float32, device=device),
+                 task_embed=torch.full(te_shape, float("nan"), dtype=torch.float32, device=device),
+                 table=torch.zeros((MAXR, 12), dtype=torch.float32, device=device), state=torch.zeros(3, dtype=torch.int64, device=device),
+                 tt=torch.zeros(B, dtype=torch.long, device=device), nrows=[MAXR])
+        te0 = torch.zeros(te_shape, dtype=torch.float32, device=device)
+        g["label"] = eng.label_embedding(te0).clone()
+        g["label_u"] = eng.label_embedding(te0).clone() if gw > 0.0 else None          # the unconditional branch embeds zeros (:504-506)
+
+        def step():
+            xin = ops.video_pack2(g["img"], g["x_cond"], f, H, W, ci)
+            v = eng.forward_cl(xin, g["tt"], g["label"])
+            vu = eng.forward_cl(xin, g["tt"], g["label_u"]) if gw > 0.0 else None
+            ops.video_denoise_step2(v, vu, g["img"], None, g["table"], self.objective, f, H * W, ci, state=g["state"], use_philox=True, out=g["img"])
+            ops.video_sampler_advance(g["state"], g["table"], g["tt"], MAXR)
+
+        rows = self._step_rows(False)
+        ops.video_denoise_table(rows, device, out=g["table"])
+        step()                                    # eager once: weight packs, workspaces, allocator warm
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        g["graph"] = graph
+        return g
 
     @torch.no_grad()
     def p_sample_loop(self, shape, x_cond, task_embed, return_all_timesteps=False):
@@ -336,6 +433,8 @@ class Trainer(object):
         for m in (self.model.model, self.ema.ema_model.model):          # parameters changed behind the engines' packed operands
             for key in ("_train_eng", "_eng"):
                 m.__dict__.pop(key, None)
+        for d in (self.model, self.ema.ema_model):
+            drop_sampler_graph(d)
         if "version" in data:
             print(f"loading from version {data['version']}")
 

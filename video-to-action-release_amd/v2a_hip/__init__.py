@@ -32,3 +32,9 @@ def set_video_storage(mode: str) -> str:
 
 def get_video_storage() -> str:
     return _video_storage[0]
+
+
+def sampler_graphs_enabled() -> bool:
+    """GoalGaussianDiffusion.sample replays one captured hipGraph per denoise step (V2A_SAMPLER_GRAPH=0: eager launches)."""
+    import os
+    return os.environ.get("V2A_SAMPLER_GRAPH", "1") != "0"

@@ -18,6 +18,7 @@ import torch
 from . import ops
 
 GN_SMALL_MAX = 16384
+_EMB_BATCH = os.environ.get("V2A_EMB_BATCH", "1") != "0"
 
 
 def build_program(cfg):
@@ -119,6 +120,8 @@ class UNetEngine:
         # "bf16": bf16 activations + bf16 weight packs, fp32 accumulation / normalisation statistics / softmax -- the counterpart of
         # the reference's fp16-autocast GPU path (lb_online_trainer_v7.py:889); needs every inner width to be a multiple of 64.
         self.storage = "f32"
+        self._eo = None
+        self._res_names = None
 
     def set_storage(self, mode):
         if mode not in ("f32", "bf16"):
@@ -275,7 +278,9 @@ class UNetEngine:
     def resblock(self, x, name, cin, cout, semb, x2=None):
         B = x.shape[0]
         a = self.gn_silu(x, name + ".in_layers.0", x2=x2, lazy=True)
-        eo = ops.linear(semb, self.p(name + ".emb_layers.1.weight"), self.p(name + ".emb_layers.1.bias"))      # [B,cout]
+        eo = self._eo.get(name) if self._eo is not None else None               # [B,cout], from the one-launch batch of forward_cl
+        if eo is None:
+            eo = ops.linear(semb, self.p(name + ".emb_layers.1.weight"), self.p(name + ".emb_layers.1.bias"))
         h = self.conv3d(a, name + ".in_layers.2", cout, rowvec=eo)
         a2 = self.gn_silu(h, name + ".out_layers.0", lazy=True)
         if self.has(name + ".skip_connection.spatial_conv.weight"):
@@ -378,6 +383,16 @@ class UNetEngine:
         """xin [B,F,H,W,Cin] channels-last, t [B] int64, label_emb [B,4mc] -> [B,F,H,W,Cout] channels-last."""
         emb = ops.axpy(self.time_embedding(t_long), label_emb)
         semb = ops.act_fwd(emb, "silu")                     # every ResBlock's emb_layers starts with the same SiLU
+        # ... so the 27 `emb_layers` Linears (unet.py:204-210,248-257) are ONE launch over the shared input (30 latency-bound GEMM
+        # launches per forward before: 0.6 ms at B = 16).  V2A_EMB_BATCH=0: one GEMM per ResBlock.
+        self._eo = None
+        B, K = semb.shape
+        if _EMB_BATCH and B <= 16 and K % 256 == 0 and K <= 1024:
+            if self._res_names is None:
+                self._res_names = [op[1] for blk in (self.inp + [self.mid] + self.out) for op in blk if op[0] == "res"]
+            outs = ops.emb_linear_multi(semb, [self.p(n + ".emb_layers.1.weight") for n in self._res_names],
+                                        [self.p(n + ".emb_layers.1.bias") for n in self._res_names])
+            self._eo = dict(zip(self._res_names, outs))
         hs = []
         h = xin
         for i, blk in enumerate(self.inp):

@@ -20,6 +20,11 @@ from . import ops
 from .unet_train import UNetTrainEngine
 
 
+def _drop_graph(diffusion):
+    from flowdiffusion.flowdiffusion.goal_diffusion import drop_sampler_graph
+    drop_sampler_graph(diffusion)
+
+
 def _train_engine(model):
     """UNetTrainEngine of a _HipUnetWrapper, rebuilt when the module moved; packs refreshed when torch changed any parameter."""
     params = dict(model.named_parameters())
@@ -162,6 +167,8 @@ class VideoTrainStep:
             seng = self.ema_model.model.__dict__.get("_eng")
             if seng is not None:
                 seng.packs._c.clear()
+            _drop_graph(self.ema_model)                     # ... and its captured sampler step points at those packs
+        _drop_graph(self.diffusion)
 
     def step(self, img, cond, tokens, t=None, noise=None, normalize=True):
         loss = self.loss_and_grads(img, cond, tokens, t, noise, normalize)
