@@ -194,3 +194,63 @@ def test_dp_layout_disagreement_fails_loudly_on_every_rank():
         assert p.exitcode == 0
     for rank in (0, 1):
         assert all(r.startswith("data-parallel ranks disagree") for r in res[rank]), res
+
+
+def _w4_worker(rank, world, port, out, wire):
+    """Four ranks, three slices launched in gradient-ready order at DIFFERENT host times per rank (uneven readiness: a rank that is
+    late with slice k must not let anybody's slice k+1 overtake it), fp32 or bf16 wire."""
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2a_hip.dp import GradReducer
+    from v2a_hip.video_train import gradient_ready_slices
+    names = ["unet.time_embed.0.weight", "unet.input_blocks.0.0.weight", "unet.middle_block.0.w", "unet.output_blocks.0.0.w", "unet.out.2.bias"]
+    numels = [1000, 5000, 3000, 7001, 13]
+    sl = gradient_ready_slices(names, numels)
+    assert sl == [(9000, 16014), (0, 9000)]
+    total = sum(numels)
+    arena = torch.zeros(total)
+    red = GradReducer(arena, [sl[0], (1000, 9000), (0, 1000)], dist.group.WORLD, world, wire=wire)
+    res = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(17 * rank + step)
+        vals = torch.randn(total, generator=g)
+        for k, (lo, hi) in enumerate(red.slices):
+            time.sleep(0.02 * ((rank + k + step) % 4))          # uneven readiness
+            arena[lo:hi] = vals[lo:hi]
+            red.launch(k)
+        assert red.pending() == {0, 1, 2}
+        red.finish()
+        res.append(arena.clone())
+    assert red.bytes_per_step() == (2 if wire == "bf16" else 4) * total
+    out.put((rank, [r.numpy() for r in res]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_dp4_uneven_slice_readiness_and_wire_format(wire):
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + os.getpid() % 500 + (7 if wire == "bf16" else 0)
+    procs = [ctx.Process(target=_w4_worker, args=(r, world, port, q, wire)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = 16014
+    for step in range(3):
+        want = sum(torch.randn(total, generator=torch.Generator().manual_seed(17 * r + step)) for r in range(world)) / world
+        for r in range(world):
+            got = torch.from_numpy(res[r][step])
+            assert np.array_equal(res[r][step], res[0][step])                 # every replica holds the same averaged gradient
+            if wire == "fp32":
+                assert torch.allclose(got, want, rtol=0, atol=1e-6)
+            else:                                                              # bf16 wire: inputs rounded to bf16, sums rounded per hop
+                tol = 4 * 2.0 ** -8 * float(want.abs().max() + 1)
+                assert float((got - want).abs().max()) <= tol and float((got - want).abs().max()) > 0

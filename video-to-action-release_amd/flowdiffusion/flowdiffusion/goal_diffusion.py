@@ -460,7 +460,8 @@ class Trainer(object):
                 emb = self.encode_batch_text(list(goal)).to(self.device).float()
                 keep = (torch.rand(emb.shape[0], 1, 1, device=emb.device) > self.cond_drop_chance).float()
                 emb = emb * keep
-            loss = self._step_fn.loss_and_grads(x, x_cond, emb, normalize=self.model.auto_normalize, accumulate=k > 0, scale=1.0 / acc)
+            loss = self._step_fn.loss_and_grads(x, x_cond, emb, normalize=self.model.auto_normalize, accumulate=k > 0, scale=1.0 / acc,
+                                                last=(k == acc - 1))
             total = loss / acc if total is None else total + loss / acc
         self._step_fn.apply()
         self.step += 1

@@ -14,11 +14,39 @@ import torch
 import torch.distributed as dist
 
 
+def _to_wire(src, dst):
+    """fp32 slice -> bf16 wire buffer (round to nearest even): the HIP cast kernel on the device, torch on CPU tensors (gloo tests)."""
+    if src.is_cuda:
+        from ._lib import lib, check
+        from . import ops
+        n = src.numel()
+        check(lib.v2a_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), n - n % 4, ops._stream()), "cast_f32_bf16")
+        if n % 4:
+            dst[n - n % 4:].copy_(src[n - n % 4:])
+    else:
+        dst.copy_(src)
+
+
+def _from_wire(src, dst):
+    if src.is_cuda:
+        from . import ops
+        dst.copy_(ops.cast_f(src))
+    else:
+        dst.copy_(src)
+
+
 class GradReducer:
-    def __init__(self, arena: torch.Tensor, slices, process_group=None, world_size=None):
+    def __init__(self, arena: torch.Tensor, slices, process_group=None, world_size=None, wire="fp32"):
         """arena: flat fp32 gradient buffer; slices: [(lo, hi), ...] element ranges in launch order (they must tile a prefix-free,
-        non-overlapping part of the arena; empty ranges are skipped on every rank alike)."""
+        non-overlapping part of the arena; empty ranges are skipped on every rank alike).
+        wire: "fp32" (default: the reference's DDP exchanges fp32 gradients) or "bf16" -- every slice is rounded to a bf16 staging
+        buffer, summed on the wire in bf16 and widened back into the arena: half the bytes per link (175 instead of 349 MB for the
+        policy), at bf16 resolution of the SUM (2^-9 relative per element); an opt-in performance mode, never the parity path."""
         assert arena.dim() == 1 and arena.is_contiguous()
+        if wire not in ("fp32", "bf16"):
+            raise ValueError(wire)
+        self.wire = wire
+        self._stage = {}
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if world_size is None else int(world_size)
@@ -62,7 +90,14 @@ class GradReducer:
         lo, hi = self.slices[which]
         if hi <= lo or not self.active:
             return
-        self._works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if self.wire == "bf16":
+            st = self._stage.get(which)
+            if st is None:
+                st = self._stage[which] = torch.empty(hi - lo, dtype=torch.bfloat16, device=self.arena.device)
+            _to_wire(self.arena[lo:hi], st)
+            self._works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), which))
+        else:
+            self._works.append((dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None))
         self.launches += 1
 
     def finish(self, scale_fn=None):
@@ -71,8 +106,11 @@ class GradReducer:
         if len(self._launched) != len(self.slices):
             missing = sorted(set(range(len(self.slices))) - self._launched)
             raise RuntimeError(f"finish() before slices {missing} were launched: ranks would issue different collectives")
-        for w in self._works:
+        for w, staged in self._works:
             w.wait()
+            if staged is not None:
+                lo, hi = self.slices[staged]
+                _from_wire(self._stage[staged], self.arena[lo:hi])
         self._works = []
         self._launched = set()
         if self.world > 1:
@@ -82,5 +120,9 @@ class GradReducer:
                 for lo, hi in self.slices:
                     self.arena[lo:hi].mul_(1.0 / self.world)
 
+    def pending(self):
+        """Slices launched since the last finish()."""
+        return set(self._launched)
+
     def bytes_per_step(self):
-        return 4 * sum(hi - lo for lo, hi in self.slices)
+        return (2 if self.wire == "bf16" else 4) * sum(hi - lo for lo, hi in self.slices)

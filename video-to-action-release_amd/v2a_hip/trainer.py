@@ -79,7 +79,9 @@ class PolicyTrainer:
         self._g_opt = None
         self._slices = self.eng.arena_slices(self.names)
         # the one collective of the path (v2a_hip/dp.py): slice 0 = ConditionalUnet1D gradients (final after phase 1), slice 1 = encoders
-        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size) if self.dp else None
+        # V2A_DP_WIRE=bf16: opt-in bf16 wire format (half the bytes per xGMI link; the sum is rounded to bf16 -- not the parity path)
+        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size,
+                                   wire=os.environ.get("V2A_DP_WIRE", "fp32")) if self.dp else None
         self.feed = None               # parity / test hook (eager mode): dict(rows=int64[B] pool offsets, noise=[B,T,Da], timesteps=int64[B])
         self.on_grads_ready = None     # diagnostics hook (eager mode): called with the arena right before the optimiser consumes it
         self.comm_events = None        # bench: [(before_wait, after_wait)] HIP event pairs bracketing the stream's wait on the communicator

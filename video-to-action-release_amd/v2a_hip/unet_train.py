@@ -425,7 +425,7 @@ class UNetTrainEngine(UNetEngine):
         tape["text"] = ttape
         return out, tape
 
-    def backward(self, tape, dout, grads):
+    def backward(self, tape, dout, grads, on_decoder_done=None):
         """dout [B,F,H,W,Cout] -> d(label_emb) [B,4mc]; parameter gradients land in grads[full parameter name] (including the
         text branch's when the tape came from forward_train_tokens)."""
         da, _ = self.conv3d_bwd(tape["out_c"], dout, grads)
@@ -437,8 +437,12 @@ class UNetTrainEngine(UNetEngine):
         pops = [pos for kind, pos in tape["marks"] if kind == "pop"]
         pushes = [pos for kind, pos in tape["marks"] if kind == "push"]
         pending = []                                     # skip gradients in the order the backward produces them
+        first_dec = min(pops) if pops else len(blocks)  # tape position of the first decoder block
         i = len(blocks) - 1
         while i >= 0:
+            if i == first_dec - 1 and on_decoder_done is not None:
+                on_decoder_done()                        # out.* and output_blocks.* gradients are final (data parallel: their slice leaves now)
+                on_decoder_done = None
             st = blocks[i]
             if st["kind"] == "conv":
                 first = (i == 0)

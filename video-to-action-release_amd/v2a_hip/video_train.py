@@ -57,6 +57,25 @@ class _GradArena:
             off += p.numel()
 
 
+def gradient_ready_slices(names, numels):
+    """Arena element ranges in the order the hand-written backward finishes them (UNetTrainEngine.backward walks out.* and
+    output_blocks.* first, then middle_block / input_blocks / time_embed / the text branch): [(decoder slice), (everything before it)].
+    named_parameters() registers output_blocks and out last (guided_diffusion/unet.py:435-632), so the decoder's gradients -- 58 % of
+    Unet_Libero's 201 M -- are one contiguous tail that can travel while the encoder half of the backward still runs."""
+    total = sum(numels)
+    off, first = 0, None
+    for n, k in zip(names, numels):
+        is_dec = ".output_blocks." in n or ".out." in n
+        if is_dec and first is None:
+            first = off
+        elif not is_dec and first is not None:
+            return [(0, total)]                          # decoder parameters are not a contiguous tail here: one slice
+        off += k
+    if first is None or first == 0:
+        return [(0, total)]
+    return [(first, total), (0, first)]
+
+
 def _loss_and_tape(diffusion, eng, img, cond, tokens, t, noise, normalize):
     B, C, H, W = img.shape
     ci = getattr(diffusion.model, "frame_channels", 3)
@@ -69,10 +88,10 @@ def _loss_and_tape(diffusion, eng, img, cond, tokens, t, noise, normalize):
     return loss, out, tape
 
 
-def _backward(diffusion, eng, tape, out, img, noise, t, normalize, grads, gscale=None):
+def _backward(diffusion, eng, tape, out, img, noise, t, normalize, grads, gscale=None, on_decoder_done=None):
     dout = ops.video_loss_bwd(out, img, noise, t, diffusion.sqrt_alphas_cumprod, diffusion.sqrt_one_minus_alphas_cumprod, diffusion.loss_weight,
                               diffusion.objective, diffusion.loss_type, normalize, gscale)
-    eng.backward(tape, dout, grads)
+    eng.backward(tape, dout, grads, on_decoder_done=on_decoder_done)
 
 
 class _VideoLossFn(torch.autograd.Function):
@@ -135,9 +154,17 @@ class VideoTrainStep:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
         self._acc = None
+        # data parallel: the one collective of the step as two asynchronous slice all-reduces in gradient-ready order (v2a_hip.dp):
+        # the decoder slice leaves as soon as the backward walk reaches the middle block and travels under the encoder half
+        self.reducer = None
+        if self.world > 1:
+            from .dp import GradReducer
+            numels = [self.params[n].numel() for n in self.arena.names]
+            self.reducer = GradReducer(self.arena.flat, gradient_ready_slices(self.arena.names, numels), process_group, self.world)
 
-    def loss_and_grads(self, img, cond, tokens, t=None, noise=None, normalize=True, accumulate=False, scale=1.0):
-        """Forward + backward of one micro-batch; gradients are written to (or, with `accumulate`, added into) the arena times `scale`."""
+    def loss_and_grads(self, img, cond, tokens, t=None, noise=None, normalize=True, accumulate=False, scale=1.0, last=True):
+        """Forward + backward of one micro-batch; gradients are written to (or, with `accumulate`, added into) the arena times `scale`.
+        last: no further micro-batch follows before apply() (then a data-parallel run starts the decoder slice's all-reduce mid-backward)."""
         d = self.diffusion
         if t is None:
             t = d._draw_t(img.shape[0])
@@ -151,14 +178,20 @@ class VideoTrainStep:
             _backward(d, eng, tape, out, img, noise, t, normalize, self._acc.views, g)
             ops.axpy(self._acc.flat, self.arena.flat, 1.0, out=self.arena.flat)
         else:
-            _backward(d, eng, tape, out, img, noise, t, normalize, self.arena.views, g)
+            early = None
+            if self.reducer is not None and last and len(self.reducer.slices) > 1:
+                early = lambda: self.reducer.launch(0)
+            _backward(d, eng, tape, out, img, noise, t, normalize, self.arena.views, g, on_decoder_done=early)
         return loss
 
     def apply(self):
         """All-reduce (mean over ranks) -> fused clip / Adam / zero / EMA -> refresh the packed operands."""
-        if self.world > 1:
-            torch.distributed.all_reduce(self.arena.flat, group=self.pg)
-            self.opt.scale_grads(1.0 / self.world)
+        if self.reducer is not None:
+            done = self.reducer.pending()
+            for i in range(len(self.reducer.slices)):
+                if i not in done:
+                    self.reducer.launch(i)
+            self.reducer.finish(self.opt.scale_grads)
         self.opt.step(zero_grad=True)
         eng = self.diffusion.model.__dict__.get("_train_eng")
         if eng is not None:
