@@ -439,6 +439,12 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
     return res
 
 
+def _as_fp16(vb, note):
+    vb = _as_bf16(vb, note)
+    vb["dtype"] = "fp16 (IEEE half) activations / weights in HBM, fp16 MFMA (v_mfma_f32_32x32x16_f16), f32 accumulate / norm statistics / softmax"
+    return vb
+
+
 def _as_bf16(vb, note):
     if "roofline" in vb:
         vb["roofline"]["peak"] = BF16_MFMA_PEAK_TFLOPS
@@ -824,6 +830,15 @@ def main():
                 leg("video_c5", lambda: _as_bf16(video_leg(
                     torch, device, 2, args.video_steps, size=256, frames=15, reps=R, roofline=False,
                     workload="BASELINE configs[4] video half: 256x256, 1+15 frames, per-GPU sampler batch 2 (16 over 8 GPUs)"), note16))
+                # BASELINE configs[4] says fp16 (and the reference's GPU path is fp16 autocast): the IEEE-half instances of the same kernels
+                v2a_hip.set_video_storage("fp16")
+                note_h = ("fp16 storage = the reference's own 16-bit type (lb_online_trainer_v7.py:72-76,889); 3 more mantissa bits than bf16, "
+                          "same MFMA rate; tests/test_video_gpu.py measures its deviation from the fp32 parity path")
+                leg("video_fp16", lambda: _as_fp16(video_leg(torch, device, args.video_batch, args.video_steps, reps=R, roofline=False,
+                                                             workload="AVDC sampler Unet_Libero 128x128, 1+7 frames (BASELINE.json configs[2]), fp16 storage"), note_h))
+                leg("video_c5_fp16", lambda: _as_fp16(video_leg(
+                    torch, device, 2, args.video_steps, size=256, frames=15, reps=R, roofline=False,
+                    workload="BASELINE configs[4] video half in fp16: 256x256, 1+15 frames, per-GPU sampler batch 2 (16 over 8 GPUs)"), note_h))
                 v2a_hip.set_video_storage("f32")
             if not args.no_video_train:
                 try:

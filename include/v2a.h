@@ -236,6 +236,12 @@ int v2a_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int N, i
 int v2a_spatial_softmax_fwd(const float* feat, float* kp, float* att, int B, int H, int W, int K, v2a_stream_t s);
 int v2a_spatial_softmax_bwd(const float* att, const float* kp, const float* dkp, float* dfeat, int B, int H, int W, int K, v2a_stream_t s);
 
+/* 16-bit format of every `_h` entry point (csrc/igemm_h.hip, igemm_h2.hip, igemm_h3.hip, norm_h.hip, v2a_attention_fwd_h, the f32 <-> 16-bit
+ * casts and packs): 0 = bf16 (default), 1 = IEEE fp16 -- the reference's own 16-bit type (fp16 autocast: lb_online_trainer_v7.py:72-76,889).
+ * Same kernels, instantiated with v_mfma_f32_32x32x16_f16 / v_cvt_f16_f32.  Process-wide; returns the previous value. */
+int v2a_set_half_format(int f16);
+int v2a_get_half_format(void);
+
 /* ------------------------------------------------------------------------------------- bf16-storage convolution (csrc/igemm_h.hip)
  * The reference's GPU path runs the video UNet under fp16 autocast (diffuser/libero/lb_online_trainer_v7.py:889,
  * guided_diffusion/guided_diffusion/nn.py:53-87 Conv3d); this is that configuration on gfx950: activations and packed weights are

@@ -867,3 +867,129 @@ def test_grouped_weight_gradients_one_launch_vs_torch(mode):
             assert torch.equal(a, b2) and (ab is None or torch.equal(ab, bb))
     finally:
         v2a_hip.set_precision(old)
+
+
+# ------------------------------------------------------------------------------------------------ fp16 instances of the 16-bit family
+def _conv_ref64(x16, w, b, k, pad, n, x2=None, rowvec=None, res=None, hdt=torch.float16):
+    """fp64 conv of sample n on exactly the 16-bit-rounded operands."""
+    xin = x16.float() if x2 is None else torch.cat([x16.float(), x2.float()], -1)
+    xin = xin.permute(0, 3, 1, 2).cpu().double()
+    wq = w.to(hdt).float().cpu().double()
+    ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=pad).permute(0, 2, 3, 1)[0]
+    if rowvec is not None:
+        ref = ref + rowvec[n].cpu().double()
+    if res is not None:
+        ref = ref + res[n].cpu().double()
+    return ref
+
+
+@pytest.mark.gpu
+def test_fp16_instances_of_the_16bit_kernels_match_fp64_on_fp16_rounded_operands():
+    """BASELINE configs[4] says fp16 and the reference's GPU path is fp16 autocast (lb_online_trainer_v7.py:72-76,889): every kernel of
+    the 16-bit video-storage family is instantiated for IEEE half as well (template flag F16: v_mfma_f32_32x32x16_f16, v_cvt_f16_f32),
+    selected by the tensors' dtype.  Each one against an fp64 reference on exactly the fp16-rounded operands: one fp16 rounding of the
+    exact result (2^-11 relative) plus accumulation noise -- 8x tighter than a bf16 result could be, so a kernel that silently ran its
+    bf16 instance on fp16 bits (or mixed the two conversions) cannot pass.  Covers casts / packs, the tap-by-tap conv (two sources,
+    split-K, fp32 output), the multi-stage 256-row conv, the halo-tile 3x3 conv plain and with GroupNorm + SiLU applied in its loader
+    (== apply-then-conv, bitwise), the frame-stack temporal conv, GroupNorm with own / conv-epilogue statistics, MFMA attention."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    dev, H16 = "cuda:0", torch.float16
+    g = torch.Generator().manual_seed(123)
+    r16 = lambda *s: torch.randn(*s, generator=g).to(H16).to(dev)
+    ulp = 2.0 ** -10                                                     # bound on one fp16 rounding (2^-11) with slack for subnormal steps
+    # casts / packs
+    x = torch.randn(4099 * 4, device=dev)
+    h = ops.cast_h(x, H16)
+    assert h.dtype == H16 and torch.equal(h, x.to(H16)) and torch.equal(ops.cast_f(h), h.float())
+    assert torch.equal(ops.cast_h(x), x.to(torch.bfloat16))              # the bf16 instance is still what a bf16 request gets
+    w5 = torch.randn(5, 64, 3, 3, device=dev)
+    assert torch.equal(ops.pack_weight_h(w5, dtype=H16).view(5, 3, 3, 64), w5.permute(0, 2, 3, 1).contiguous().to(H16))
+    xp = torch.randn(3, 5, 7, 6, device=dev)
+    pp = ops.pad_cast_h(xp, 32, H16)
+    assert pp.dtype == H16 and torch.equal(pp[..., :6], xp.to(H16)) and float(pp[..., 6:].abs().max()) == 0.0
+
+    def check(y, ref, what):
+        err = (y.cpu().double() - ref).abs()
+        assert (err <= ref.abs() * ulp + 2e-5 * ref.abs().max()).all(), (what, float(err.max()))
+
+    # tap-by-tap conv: two sources, bias / row vector / residual; split-K + fp32 output
+    N, Hh, W, C1, C2, Co = 2, 16, 16, 64, 128, 128
+    xa, xb = r16(N, Hh, W, C1), r16(N, Hh, W, C2)
+    w = (torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05).to(dev)
+    b, rv, res = torch.randn(Co, generator=g).to(dev), torch.randn(N, Co, generator=g).to(dev), r16(N, Hh, W, Co)
+    wp = ops.pack_weight_h(w, dtype=H16)
+    y = ops.conv2d_h(xa, wp, b, Co, 3, 3, (1, 1), (1, 1), x2=xb, rowvec=rv, rows_per_batch=Hh * W, residual=res)
+    assert y.dtype == H16 and ops.last_kernel[0].startswith("conv_igemm_h<")
+    for n in range(N):
+        check(y[n], _conv_ref64(xa, w, b, 3, 1, n, x2=xb, rowvec=rv, res=res), "conv_igemm_h fp16")
+    xd = r16(4, 8, 8, 1280)
+    wd = (torch.randn(640, 1280, 3, 3, generator=g) * 0.02).to(dev)
+    bd = torch.randn(640, generator=g).to(dev)
+    yd = ops.conv2d_h(xd, ops.pack_weight_h(wd, dtype=H16), bd, 640, 3, 3, (1, 1), (1, 1), out_f32=True)
+    refd = _conv_ref64(xd, wd, bd, 3, 1, 1)
+    assert yd.dtype == torch.float32 and float((yd[1].cpu().double() - refd).abs().max()) <= 3e-5 * float(refd.abs().max())
+    # halo-tile 3x3 (+ statistics), frame-stack temporal, multi-stage 256-row kernels
+    N, Hh, W, C, Co = 44, 32, 32, 128, 384
+    assert lib.v2a_conv2d_h3_eligible(N, Hh, W, C, Co, 3, 3, 1, 1, 1, 1, 0, 0) == 1
+    x = r16(N, Hh, W, C)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * 0.05).to(dev)
+    b, rv, res = torch.randn(Co, generator=g).to(dev), torch.randn(N, Co, generator=g).to(dev), r16(N, Hh, W, Co)
+    wp = ops.pack_weight_h(w, dtype=H16)
+    y, st = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rv, rows_per_batch=Hh * W, residual=res, want_stats=True)
+    assert ops.last_kernel[0].startswith("conv_halo_h3") and y.dtype == H16
+    for n in (0, N - 1):
+        check(y[n], _conv_ref64(x, w, b, 3, 1, n, rowvec=rv, res=res), "conv_halo_h3 fp16")
+    yf = y.float().view(N, Hh * W, Co)                        # blocks are numbered per (patch, 64-row group): compare per frame
+    nb = Hh * W // 64
+    assert torch.allclose(st[:, 0].view(N, nb, Co).sum(1), yf.sum(1), rtol=1e-4, atol=5e-2)
+    assert torch.allclose(st[:, 1].view(N, nb, Co).sum(1), (yf * yf).sum(1), rtol=1e-4, atol=5e-2)
+    # GroupNorm + SiLU applied inside the halo conv's loader == apply-then-conv, bitwise; statistics from the conv epilogue == own pass to 1 ulp
+    gamma, beta = torch.randn(Co, generator=g).to(dev), torch.randn(Co, generator=g).to(dev)
+    y3 = y.view(N, Hh * W, Co)
+    pg = ops.groupnorm_prep_h(y3, gamma, beta, 32, "silu", stats=st)
+    w2 = (torch.randn(384, Co, 3, 3, generator=g) * 0.03).to(dev)
+    wp2 = ops.pack_weight_h(w2, dtype=H16)
+    assert ops.gn_fusable(N, Hh, W, Co, 384, 3, 3, (1, 1), (1, 1), False)
+    fused = ops.conv2d_h(y, wp2, None, 384, 3, 3, (1, 1), (1, 1), pre_gn=pg)
+    assert ops.last_kernel[0].startswith("conv_halo_h3_gn")
+    applied = pg.apply().view(N, Hh, W, Co)
+    unfused = ops.conv2d_h(applied, wp2, None, 384, 3, 3, (1, 1), (1, 1))
+    assert fused.dtype == H16 and torch.equal(fused, unfused)
+    gn_ref = torch.nn.functional.group_norm(y3.float().double().permute(0, 2, 1).cpu(), 32, gamma.double().cpu(), beta.double().cpu(), eps=1e-5).permute(0, 2, 1)
+    gn_ref = gn_ref * torch.sigmoid(gn_ref)
+    own = ops.groupnorm_fwd_h(y3, gamma, beta, 32, "silu")
+    err = (own.cpu().double() - gn_ref).abs()
+    assert own.dtype == H16 and (err <= gn_ref.abs() * ulp + 1e-4 * gn_ref.abs().max()).all(), float(err.max())
+    d = (applied.view(N, Hh * W, Co).float() - own.float()).abs()
+    assert (d <= own.float().abs() * 2.0 ** -9 + 1e-5).all()
+    B, F, HW, C, Co = 16, 7, 1024, 128, 128
+    assert lib.v2a_conv2d_t3_eligible(B, F, HW, C, Co, 3, 1, 1, 1, 1, 0, 0, 0) == 1
+    x = r16(B, F, HW, C)
+    w = (torch.randn(Co, C, 3, 1, generator=g) * 0.08).to(dev)
+    b, rv, res = torch.randn(Co, generator=g).to(dev), torch.randn(B, Co, generator=g).to(dev), r16(B, F, HW, Co)
+    y = ops.conv2d_h(x, ops.pack_weight_h(w, dtype=H16), b, Co, 3, 1, (1, 1), (1, 0), rowvec=rv, rows_per_batch=F * HW, residual=res)
+    assert ops.last_kernel[0].startswith("conv_frames_h3") and y.dtype == H16
+    for n in (0, B - 1):
+        xin = x.float().permute(0, 3, 1, 2).cpu().double()
+        ref = torch.nn.functional.conv2d(xin[n:n + 1], w.to(H16).float().cpu().double(), b.cpu().double(), padding=(1, 0)).permute(0, 2, 3, 1)[0]
+        check(y[n], ref + rv[n].cpu().double() + res[n].cpu().double(), "conv_frames_h3 fp16")
+    N, Hh, W, C1, C2, Co = 5, 168, 168, 64, 64, 256
+    assert lib.v2a_conv2d_h2_eligible(N * Hh * W, Co, 9 * (C1 + C2), C1, C2) == 1
+    xa, xb = r16(N, Hh, W, C1), r16(N, Hh, W, C2)
+    w = (torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    y = ops.conv2d_h(xa, ops.pack_weight_h(w, dtype=H16), b, Co, 3, 3, (1, 1), (1, 1), x2=xb)
+    assert ops.last_kernel[0].startswith("conv_igemm_h2") and y.dtype == H16
+    check(y[4], _conv_ref64(xa, w, b, 3, 1, 4, x2=xb), "conv_igemm_h2 fp16")
+    # MFMA attention (head_ch 32), QKVAttentionLegacy semantics (guided_diffusion/unet.py:341-358)
+    n_fr, L, heads, ch = 3, 256, 16, 32
+    qkv = (torch.randn(n_fr * L, heads * 3 * ch, generator=g)).to(H16).to(dev)
+    out = ops.attention(qkv, n_fr, L, heads, ch)
+    assert out.dtype == H16
+    q, k, v = qkv.float().double().cpu().view(n_fr, L, heads, 3, ch).permute(3, 0, 2, 1, 4)      # [n, heads, L, ch]
+    sc = ch ** -0.25
+    wgt = torch.softmax((q * sc) @ (k * sc).transpose(-1, -2), dim=-1)
+    ref = (wgt @ v).permute(0, 2, 1, 3).reshape(n_fr * L, heads * ch)
+    err = (out.cpu().double() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -8 * float(ref.abs().max()), float(err.max())      # P is rounded to fp16 before P V (as the bf16 instance rounds to bf16)

@@ -415,6 +415,13 @@ def test_bf16_storage_full_unet_tracks_fp32(golden_dir):
     print('bf16-storage relative L2 error', rl2, 'max', rel(out, ref))
     assert rl2 < 3e-2, rl2
     assert (out - ref).abs().max().item() < 0.1 * ref.abs().max().item()
+    # fp16 storage (the reference's own 16-bit type): same kernels, IEEE-half instances -- closer to fp32 than bf16 (11 vs 8 bits)
+    m.storage = "fp16"
+    out16 = m(x, t, task_embed=emb)
+    m.storage = "f32"
+    rl16 = ((out16 - ref).norm() / ref.norm()).item()
+    print('fp16-storage relative L2 error', rl16, 'max', rel(out16, ref))
+    assert torch.isfinite(out16).all() and rl16 < 5e-3 and rl16 < 0.5 * rl2, (rl16, rl2)
     # process-wide default: models with narrow widths silently stay fp32, wide ones switch
     old = v2a_hip.set_video_storage("bf16")
     try:
@@ -448,3 +455,19 @@ def test_highres_256x256x16_frames_config_properties():
     m.storage = "bf16"
     half = m(x, t, task_embed=emb)
     assert ((half - both).norm() / both.norm()).item() < 3e-2
+    # configs[4] names fp16: the IEEE-half instances of the same kernels (3 more mantissa bits than bf16: a tighter track of fp32),
+    # row independence holds there too, and the 16-bit sampler runs end to end at this shape
+    m.storage = "fp16"
+    h16 = m(x, t, task_embed=emb)
+    e16 = ((h16 - both).norm() / both.norm()).item()
+    print(f"[C5 256x256x15f] relative L2 vs fp32: bf16 {((half - both).norm() / both.norm()).item():.2e}, fp16 {e16:.2e}")
+    assert torch.isfinite(h16).all() and e16 < 6e-3, e16
+    one16 = m(x[1:2], t[1:2], task_embed=emb[1:2])
+    assert rel(one16[0], h16[1]) < 2e-3
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    d = GoalGaussianDiffusion(m, image_size=(256, 256), channels=45, timesteps=100, sampling_timesteps=4, loss_type="l2", objective="pred_v",
+                              beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to("cuda:0")
+    torch.manual_seed(3)
+    smp = d.sample(torch.rand(1, 3, 256, 256, device="cuda:0"), emb[:1], batch_size=1)
+    assert smp.shape == (1, 45, 256, 256) and torch.isfinite(smp).all() and float(smp.min()) >= 0 and float(smp.max()) <= 1
+    m.storage = "f32"

@@ -14,6 +14,7 @@ cfgs = [a.split(":") for a in sys.argv[1:]] or [["bf16", "16", "50"], ["bf16", "
 for storage, B, steps in cfgs:
     B, steps = int(B), int(steps)
     v2a_hip.set_video_storage(storage)
+    unet.__dict__.pop("_eng", None)
     d = GoalGaussianDiffusion(unet, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=steps, loss_type="l2",
                               objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to(dev)
     g = torch.Generator(device=dev).manual_seed(1)

@@ -21,6 +21,17 @@ __device__ __forceinline__ void st4(uint16_t* p, f32x4 v) {
     uint2 o = {v2a_pack_bf16x2(v[0], v[1]), v2a_pack_bf16x2(v[2], v[3])};
     *reinterpret_cast<uint2*>(p) = o;
 }
+struct f16a { uint16_t v; };       // storage tag of the fp16 instances
+__device__ __forceinline__ float ld1(const f16a* p) { return v2a_h2f<true>(p->v); }
+__device__ __forceinline__ f32x4 ld4(const f16a* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    f32x4 v = {v2a_lo_h2<true>(u.x), v2a_hi_h2<true>(u.x), v2a_lo_h2<true>(u.y), v2a_hi_h2<true>(u.y)};
+    return v;
+}
+__device__ __forceinline__ void st4(f16a* p, f32x4 v) {
+    uint2 o = {v2a_pack_h2<true>(v[0], v[1]), v2a_pack_h2<true>(v[2], v[3])};
+    *reinterpret_cast<uint2*>(p) = o;
+}
 
 template <int CH, typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int heads) {
@@ -220,10 +231,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_a;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_a;
 
-__device__ __forceinline__ uint32_t pack_bf16_2(float a, float b) {
-    return v2a_pack_bf16x2(a, b);
-}
 
+template <bool F16>
 __global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int L, int heads) {
     constexpr int CH = 32, LDK = 40;                          // K row stride in bf16 (80 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __rest
                 f32x16 sacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], sacc, 0, 0, 0);
+                sacc = v2a_mfma_h<F16>(kf[0], qf[t][0], sacc);
+                sacc = v2a_mfma_h<F16>(kf[1], qf[t][1], sacc);
                 float cm = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -316,10 +325,10 @@ __global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __rest
                 m[t] = mn;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-                uint4 p0 = make_uint4(pack_bf16_2(pv[0], pv[1]), pack_bf16_2(pv[2], pv[3]), pack_bf16_2(pv[4], pv[5]), pack_bf16_2(pv[6], pv[7]));
-                uint4 p1 = make_uint4(pack_bf16_2(pv[8], pv[9]), pack_bf16_2(pv[10], pv[11]), pack_bf16_2(pv[12], pv[13]), pack_bf16_2(pv[14], pv[15]));
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], *reinterpret_cast<bf16x8_a*>(&p0), o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], *reinterpret_cast<bf16x8_a*>(&p1), o[t], 0, 0, 0);
+                uint4 p0 = make_uint4(v2a_pack_h2<F16>(pv[0], pv[1]), v2a_pack_h2<F16>(pv[2], pv[3]), v2a_pack_h2<F16>(pv[4], pv[5]), v2a_pack_h2<F16>(pv[6], pv[7]));
+                uint4 p1 = make_uint4(v2a_pack_h2<F16>(pv[8], pv[9]), v2a_pack_h2<F16>(pv[10], pv[11]), v2a_pack_h2<F16>(pv[12], pv[13]), v2a_pack_h2<F16>(pv[14], pv[15]));
+                o[t] = v2a_mfma_h<F16>(vf[0], *reinterpret_cast<bf16x8_a*>(&p0), o[t]);
+                o[t] = v2a_mfma_h<F16>(vf[1], *reinterpret_cast<bf16x8_a*>(&p1), o[t]);
             }
         }
         // O^T accumulator: lane -> query lr of tile t, channels d = (r & 3) + 8 (r >> 2) + 4 lk : four runs of 4 channels (8 B each)
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __rest
             uint16_t* dst = out + ((size_t)n * L + q) * C + (size_t)h * CH + 4 * lk;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint2 u = {pack_bf16_2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv), pack_bf16_2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv)};
+                uint2 u = {v2a_pack_h2<F16>(o[t][4 * g] * inv, o[t][4 * g + 1] * inv), v2a_pack_h2<F16>(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv)};
                 *reinterpret_cast<uint2*>(dst + 8 * g) = u;
             }
         }
@@ -788,9 +797,13 @@ int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int hea
     if (!qkv || !out) return V2A_ERR_ARG;
     if (head_ch == 32 && L % 32 == 0 && L >= 32 && L <= 1024 && (heads * 32) % 8 == 0) {      // MFMA path: K and V^T of a head fit in LDS
         const size_t lds_m = (size_t)L * 40 * 2 + (size_t)32 * (L + 4) * 2;
-        if (lds_m > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_mfma_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+        if (lds_m > 64 * 1024) {
+            (void)hipFuncSetAttribute((const void*)attn_mfma_h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            (void)hipFuncSetAttribute((const void*)attn_mfma_h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+        }
         const int waves = L >= 256 ? 4 : (L + 63) / 64;
-        hipLaunchKernelGGL(attn_mfma_h_kernel, dim3(n_frames * heads), dim3(waves * 64), lds_m, s, (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+        if (g_v2a_half_f16) hipLaunchKernelGGL(attn_mfma_h_kernel<true>, dim3(n_frames * heads), dim3(waves * 64), lds_m, s, (const uint16_t*)qkv, (uint16_t*)out, L, heads);
+        else hipLaunchKernelGGL(attn_mfma_h_kernel<false>, dim3(n_frames * heads), dim3(waves * 64), lds_m, s, (const uint16_t*)qkv, (uint16_t*)out, L, heads);
         V2A_CHECK_LAUNCH();
         return V2A_OK;
     }
@@ -800,7 +813,22 @@ int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int hea
     const uint16_t* q = (const uint16_t*)qkv;
     uint16_t* o = (uint16_t*)out;
     if (lds > 64 * 1024) {
-        if (head_ch == 64) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (head_ch == 64) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64, f16a>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
+    }
+    if (g_v2a_half_f16) {
+        const f16a* qf = (const f16a*)qkv;
+        f16a* of = (f16a*)out;
+        switch (head_ch) {
+            case 16: hipLaunchKernelGGL((attn_fwd_kernel<16, f16a>), grid, dim3(threads), lds, s, qf, of, L, heads); break;
+            case 32: hipLaunchKernelGGL((attn_fwd_kernel<32, f16a>), grid, dim3(threads), lds, s, qf, of, L, heads); break;
+            case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, f16a>), grid, dim3(threads), lds, s, qf, of, L, heads); break;
+            default: return V2A_ERR_ARG;
+        }
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
     }
     switch (head_ch) {
         case 16: hipLaunchKernelGGL((attn_fwd_kernel<16, uint16_t>), grid, dim3(threads), lds, s, q, o, L, heads); break;

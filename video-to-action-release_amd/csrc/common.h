@@ -31,6 +31,45 @@ __device__ __forceinline__ unsigned int v2a_pack_bf16x2(float lo, float hi) {
     v2a_f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, v2a_bf16x2));
 }
+// ---- the two 16-bit storage formats of the video-storage kernels: bf16 (default) and IEEE fp16 (the reference's GPU path is fp16
+// autocast: lb_online_trainer_v7.py:72-76,889).  Kernels carry the format as a template flag F16; tensors are uint16_t either way.
+// Conversions round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_f16_f32); the 32x32x16 MFMA exists for both at the same rate.
+typedef __attribute__((ext_vector_type(2))) _Float16 v2a_f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 v2a_f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 v2a_bf16x8;
+extern int g_v2a_half_f16;            // process-wide: 0 bf16, 1 fp16 (v2a_set_half_format; the host wrappers set it from the tensor dtype)
+template <bool F16> __device__ __forceinline__ unsigned short v2a_f2h(float f) {
+    if constexpr (F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
+    else return v2a_f2bf(f);
+}
+template <bool F16> __device__ __forceinline__ float v2a_h2f(unsigned short h) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, h);
+    else return __uint_as_float((unsigned int)h << 16);
+}
+template <bool F16> __device__ __forceinline__ unsigned int v2a_pack_h2(float lo, float hi) {
+    if constexpr (F16) {
+        v2a_f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, v2a_f16x2));
+    } else return v2a_pack_bf16x2(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ float v2a_lo_h2(unsigned int u) {      // element 0 of a packed pair
+    if constexpr (F16) return (float)__builtin_bit_cast(v2a_f16x2, u)[0];
+    else return __uint_as_float(u << 16);
+}
+template <bool F16> __device__ __forceinline__ float v2a_hi_h2(unsigned int u) {      // element 1
+    if constexpr (F16) return (float)__builtin_bit_cast(v2a_f16x2, u)[1];
+    else return __uint_as_float(u & 0xffff0000u);
+}
+template <bool F16> __device__ __forceinline__ void v2a_unpack_h8(const uint4 u, float* f) {
+    f[0] = v2a_lo_h2<F16>(u.x); f[1] = v2a_hi_h2<F16>(u.x); f[2] = v2a_lo_h2<F16>(u.y); f[3] = v2a_hi_h2<F16>(u.y);
+    f[4] = v2a_lo_h2<F16>(u.z); f[5] = v2a_hi_h2<F16>(u.z); f[6] = v2a_lo_h2<F16>(u.w); f[7] = v2a_hi_h2<F16>(u.w);
+}
+// D = A (32 x 16) * B (16 x 32) + C with 8 16-bit elements per lane and operand, fp32 accumulate
+template <bool F16, typename V8> __device__ __forceinline__ f32x16 v2a_mfma_h(const V8 a, const V8 b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v2a_f16x8, a), __builtin_bit_cast(v2a_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v2a_bf16x8, a), __builtin_bit_cast(v2a_bf16x8, b), c, 0, 0, 0);
+}
+
 // SiLU for outputs that are rounded to bf16 anyway: exp2 + reciprocal approximations (~2 ulp of fp32) instead of expf + IEEE division
 __device__ __forceinline__ float v2a_silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));

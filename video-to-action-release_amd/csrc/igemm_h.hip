@@ -22,6 +22,10 @@
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+struct f16s { uint16_t v; };      // storage tag of the fp16 instances (tensors are raw 16-bit words either way)
+int g_v2a_half_f16 = 0;           // process-wide 16-bit format of the video-storage kernels: 0 bf16, 1 fp16 (v2a_set_half_format)
+template <typename T> struct is_f16s { static constexpr bool value = false; };
+template <> struct is_f16s<f16s> { static constexpr bool value = true; };
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     constexpr int EPT = ROWB / (int)sizeof(T);      // elements per k tile
     constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-B chunk
     constexpr bool HALF = sizeof(T) == 2;
+    constexpr bool F16 = is_f16s<T>::value;
     constexpr int AL = BM / 32, BL = BN / 32;       // DMA pieces per thread per tile (32 rows x 8 chunks per 256-thread pass)
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int BUF = (BM + BN) * ROWB;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(a[i], b[j], acc[i][j]);
         } else {
             // one b128 fetch per operand row feeds FOUR exact-f32 MFMA k-steps: lanes with lk = 0 supply k = 8h + e, the others
             // k = 8h + 4 + e, for A and B alike (the order of an exact fp32 sum is free)
@@ -320,10 +325,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
                 if (p.residual) {
                     if constexpr (HALF) {
                         const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
-                        v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                        v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                        v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                        v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                        float rr[8];
+                        v2a_unpack_h8<F16>(u, rr);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rr[e];
                     } else {
                         const float* rp = reinterpret_cast<const float*>(p.residual) + o;
                         const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -344,8 +349,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
                     uint16_t h[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        h[e] = f2bf(v[e]);
-                        const float r = bf2f(h[e]);                   // statistics of what the consumer will read
+                        h[e] = v2a_f2h<F16>(v[e]);
+                        const float r = v2a_h2f<F16>(h[e]);           // statistics of what the consumer will read
                         ssum[e] += r;
                         ssq[e] += r * r;
                     }
@@ -360,11 +365,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
                 for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                     float t = v[e];
                     if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
-                    if (p.residual) t += HALF ? bf2f(reinterpret_cast<const uint16_t*>(p.residual)[o + e]) : reinterpret_cast<const float*>(p.residual)[o + e];
+                    if (p.residual) t += HALF ? v2a_h2f<F16>(reinterpret_cast<const uint16_t*>(p.residual)[o + e]) : reinterpret_cast<const float*>(p.residual)[o + e];
                     if (p.residual_f) t += p.residual_f[o + e];
                     if (!HALF) reinterpret_cast<float*>(p.y)[o + e] = t;
                     else if (p.yf) p.yf[o + e] = t;
-                    else reinterpret_cast<uint16_t*>(p.y)[o + e] = f2bf(t);
+                    else reinterpret_cast<uint16_t*>(p.y)[o + e] = v2a_f2h<F16>(t);
                 }
             }
         }
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
 template <typename T>
 __global__ void conv_splitk_reduce_h(const ConvDescH p) {
     constexpr bool HALF = sizeof(T) == 2;
+    constexpr bool F16 = is_f16s<T>::value;
     const size_t total = (size_t)p.M * p.Cout;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / p.Cout), n = (int)(idx - (size_t)m * p.Cout);
@@ -402,15 +408,16 @@ __global__ void conv_splitk_reduce_h(const ConvDescH p) {
         for (int s = 0; s < p.splitk; ++s) v += p.partial[(size_t)s * total + idx];
         if (p.bias) v += p.bias[n];
         if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
-        if (p.residual) v += HALF ? bf2f(reinterpret_cast<const uint16_t*>(p.residual)[idx]) : reinterpret_cast<const float*>(p.residual)[idx];
+        if (p.residual) v += HALF ? v2a_h2f<F16>(reinterpret_cast<const uint16_t*>(p.residual)[idx]) : reinterpret_cast<const float*>(p.residual)[idx];
         if (p.residual_f) v += p.residual_f[idx];
         if (!HALF) reinterpret_cast<float*>(p.y)[idx] = v;
         else if (p.yf) p.yf[idx] = v;
-        else reinterpret_cast<uint16_t*>(p.y)[idx] = f2bf(v);
+        else reinterpret_cast<uint16_t*>(p.y)[idx] = v2a_f2h<F16>(v);
     }
 }
 
 // torch [Cout][Cin][taps] fp32 -> [Cout][taps][Cin] bf16 (round to nearest even); taps == 1 is a plain cast
+template <bool F16>
 __global__ void pack_weight_h_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int taps) {
     const size_t total = (size_t)Cout * Cin * taps;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -418,21 +425,23 @@ __global__ void pack_weight_h_kernel(const float* __restrict__ w, uint16_t* __re
         const size_t t = idx / Cin;
         const int tap = (int)(t % taps);
         const int co = (int)(t / taps);
-        out[idx] = f2bf(w[((size_t)co * Cin + ci) * taps + tap]);
+        out[idx] = v2a_f2h<F16>(w[((size_t)co * Cin + ci) * taps + tap]);
     }
 }
 
+template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         uint2 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.x = v2a_pack_h2<F16>(v[0], v[1]);
+        o.y = v2a_pack_h2<F16>(v[2], v[3]);
         reinterpret_cast<uint2*>(y)[i] = o;
     }
 }
 // [M][Cin] fp32 -> [M][Cpad] bf16, channels Cin .. Cpad-1 zero: the 6-channel input of the sampler's stem padded to one 32-channel
 // chunk so that the stem conv runs on the halo kernel.  Thread = one 8-channel (16-B) piece of a row.
+template <bool F16>
 __global__ void pad_cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t M, int Cin, int Cpad) {
     const int pieces = Cpad >> 3;
     const size_t total = M * (size_t)pieces;
@@ -443,17 +452,18 @@ __global__ void pad_cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (c0 + e < Cin) ? x[m * Cin + c0 + e] : 0.f;
         uint4 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        o.x = v2a_pack_h2<F16>(v[0], v[1]);
+        o.y = v2a_pack_h2<F16>(v[2], v[3]);
+        o.z = v2a_pack_h2<F16>(v[4], v[5]);
+        o.w = v2a_pack_h2<F16>(v[6], v[7]);
         reinterpret_cast<uint4*>(y)[i] = o;
     }
 }
+template <bool F16>
 __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const uint2 u = reinterpret_cast<const uint2*>(x)[i];
-        f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        f32x4 v = {v2a_lo_h2<F16>(u.x), v2a_hi_h2<F16>(u.x), v2a_lo_h2<F16>(u.y), v2a_hi_h2<F16>(u.y)};
         reinterpret_cast<f32x4*>(y)[i] = v;
     }
 }
@@ -589,6 +599,16 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
 
 extern "C" {
 
+// 16-bit format of every `_h` entry point below and of csrc/igemm_h2.hip, igemm_h3.hip, norm_h.hip, the 16-bit attention: 0 = bf16
+// (default), 1 = IEEE fp16 (v_mfma_f32_32x32x16_f16, v_cvt_f16_f32).  Returns the old value.  Process-wide: the Python wrappers set it
+// from the dtype of the tensors they are handed before every call.
+int v2a_set_half_format(int f16) {
+    const int old = g_v2a_half_f16;
+    if (f16 == 0 || f16 == 1) g_v2a_half_f16 = f16;
+    return old;
+}
+int v2a_get_half_format(void) { return g_v2a_half_f16; }
+
 // bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
 // exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned pointers; zeros: >= 128 zero bytes.
 int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
@@ -596,6 +616,9 @@ int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const 
                      int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
                      float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!y == !y_f32) return V2A_ERR_ARG;
+    if (g_v2a_half_f16)
+        return conv_dma_launch<f16s>(x, x2, w_packed, bias, rowvec, residual, residual_f32, y, y_f32, zeros, N, H, W, C1, C2, Cout, KH, KW,
+                                     sh, sw, ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
     return conv_dma_launch<uint16_t>(x, x2, w_packed, bias, rowvec, residual, residual_f32, y, y_f32, zeros, N, H, W, C1, C2, Cout, KH, KW,
                                      sh, sw, ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
 }
@@ -610,9 +633,11 @@ int v2a_conv2d_fwd_h_d(const void* x, const void* x2, const void* w_packed, cons
     // the fp32 residual of the epilogue travels with the slabs (the consumer adds it): pass it through the `residual` slot of the
     // reduce-less path by clearing it here when the plan splits -- conv_dma_launch only defers when residual_f32 is null
     int ns = 0;
-    const int rc = conv_dma_launch<uint16_t>(x, x2, w_packed, bias, nullptr, nullptr, nullptr, nullptr, y_f32, zeros, N, H, W, C1, C2, Cout, KH,
-                                             KW, sh, sw, ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes,
-                                             stream, &ns);
+    const int rc = g_v2a_half_f16
+        ? conv_dma_launch<f16s>(x, x2, w_packed, bias, nullptr, nullptr, nullptr, nullptr, y_f32, zeros, N, H, W, C1, C2, Cout, KH, KW, sh, sw,
+                                ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes, stream, &ns)
+        : conv_dma_launch<uint16_t>(x, x2, w_packed, bias, nullptr, nullptr, nullptr, nullptr, y_f32, zeros, N, H, W, C1, C2, Cout, KH, KW, sh,
+                                    sw, ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes, stream, &ns);
     *nslab_out = ns;
     if (rc != V2A_OK || ns > 0 || !residual_f32) return rc;
     return V2A_ERR_ARG;      // unsplit plan with a residual: the caller must use v2a_conv2d_fwd_h (it asked v2a_conv2d_h_splits first)
@@ -654,7 +679,8 @@ int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, hi
     const size_t total = (size_t)Cout * Cin * taps;
     int g = (int)((total + 255) / 256);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(pack_weight_h_kernel, dim3(g), dim3(256), 0, stream, w, (uint16_t*)out, Cout, Cin, taps);
+    if (g_v2a_half_f16) hipLaunchKernelGGL(pack_weight_h_kernel<true>, dim3(g), dim3(256), 0, stream, w, (uint16_t*)out, Cout, Cin, taps);
+    else hipLaunchKernelGGL(pack_weight_h_kernel<false>, dim3(g), dim3(256), 0, stream, w, (uint16_t*)out, Cout, Cin, taps);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -665,7 +691,8 @@ int v2a_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
     if (n == 0) return V2A_OK;
     int g = (int)((n / 4 + 255) / 256);
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
+    if (g_v2a_half_f16) hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
+    else hipLaunchKernelGGL(cast_f32_bf16_kernel<false>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -676,7 +703,8 @@ int v2a_pad_cast_f32_bf16(const float* x, void* y, size_t M, int Cin, int Cpad, 
     const size_t total = M * (size_t)(Cpad / 8);
     int g = (int)((total + 255) / 256);
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(pad_cast_f32_bf16_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, M, Cin, Cpad);
+    if (g_v2a_half_f16) hipLaunchKernelGGL(pad_cast_f32_bf16_kernel<true>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, M, Cin, Cpad);
+    else hipLaunchKernelGGL(pad_cast_f32_bf16_kernel<false>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, M, Cin, Cpad);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -685,7 +713,8 @@ int v2a_cast_bf16_f32(const void* x, float* y, size_t n, hipStream_t stream) {
     if (n == 0) return V2A_OK;
     int g = (int)((n / 4 + 255) / 256);
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
+    if (g_v2a_half_f16) hipLaunchKernelGGL(cast_bf16_f32_kernel<true>, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
+    else hipLaunchKernelGGL(cast_bf16_f32_kernel<false>, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -61,10 +61,6 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nblk) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
 }
-__device__ __forceinline__ uint16_t f2bf2(float f) {
-    return v2a_f2bf(f);
-}
-__device__ __forceinline__ float bf2f2(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -72,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // WAVES_M x WAVES_N = 8 waves; each wave owns a (TM*32) x (TN*32) sub-tile.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int S>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int S, bool F16>
 __global__ __launch_bounds__(512, 1) void conv_igemm_h2(const ConvDescH2 p) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int ROWB = 64;                               // bytes per tile row: 32 bf16
@@ -194,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_h2(const ConvDescH2 p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(a[i], b[j], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's operand reads are done before it reaches the next barrier
         cbuf = (cbuf + 1 == S) ? 0 : cbuf + 1;
@@ -247,16 +243,16 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_h2(const ConvDescH2 p) {
                 }
                 if (p.residual) {
                     const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
-                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                    v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                    v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                    v[0] += v2a_lo_h2<F16>(u.x); v[1] += v2a_hi_h2<F16>(u.x);
+                    v[2] += v2a_lo_h2<F16>(u.y); v[3] += v2a_hi_h2<F16>(u.y);
+                    v[4] += v2a_lo_h2<F16>(u.z); v[5] += v2a_hi_h2<F16>(u.z);
+                    v[6] += v2a_lo_h2<F16>(u.w); v[7] += v2a_hi_h2<F16>(u.w);
                 }
                 uint16_t h[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    h[e] = f2bf2(v[e]);
-                    const float r = bf2f2(h[e]);
+                    h[e] = v2a_f2h<F16>(v[e]);
+                    const float r = v2a_h2f<F16>(h[e]);
                     ssum[e] += r;
                     ssq[e] += r * r;
                 }
@@ -270,8 +266,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_h2(const ConvDescH2 p) {
                 for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
                     float t = v[e];
                     if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
-                    if (p.residual) t += bf2f2(p.residual[o + e]);
-                    p.y[o + e] = f2bf2(t);
+                    if (p.residual) t += v2a_h2f<F16>(p.residual[o + e]);
+                    p.y[o + e] = v2a_f2h<F16>(t);
                 }
             }
         }
@@ -332,7 +328,8 @@ int v2a_conv2d_fwd_h2(const void* x, const void* x2, const void* w_packed, const
     p.fd_ow = make_fastdiv2((uint32_t)OW);
     p.fd_oh = make_fastdiv2((uint32_t)OH);
     const int tiles = cdiv(M, 256) * (Cout / 256);
-    hipLaunchKernelGGL((conv_igemm_h2<2, 4, 4, 2, 4>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, 4 stages x 32 KB
+    if (g_v2a_half_f16) hipLaunchKernelGGL((conv_igemm_h2<2, 4, 4, 2, 4, true>), dim3(tiles), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_h2<2, 4, 4, 2, 4, false>), dim3(tiles), dim3(512), 0, stream, p);      // 256 x 256, 4 stages x 32 KB
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -49,10 +49,6 @@ __device__ __forceinline__ int xcd_remap3(int bid, int nblk) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
 }
-__device__ __forceinline__ uint16_t f2bf3(float f) {
-    return v2a_f2bf(f);
-}
-__device__ __forceinline__ float bf2f3(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt3() {
@@ -83,7 +79,7 @@ struct HaloLater {
 };
 
 // BM = 256 (16 x 16 patch) or 512 (32 rows x 16 pixels: the 128-wide instance -- 12.3 KB of DMA per 512 x 128 x 32 step).
-template <int WAVES_M, int WAVES_N, int TM, int TN, int SB, int GN = 0>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int SB, int GN, bool F16>
 __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     static_assert((BM == 256 || BM == 512) && WAVES_M * WAVES_N == 8, "tile shape");
@@ -172,8 +168,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
         const int q = j * 512 + tid;
         uint4* slot = reinterpret_cast<uint4*>(smem + hb * HBUF + q * 16);
         const uint4 u = *slot;
-        float f[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
-                      __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+        float f[8];
+        v2a_unpack_h8<F16>(u, f);
         float o[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -182,8 +178,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
             o[e + 4] = p.act == ACT_SILU ? v2a_silu_fast(z1) : z1;
         }
         uint4 r;
-        r.x = v2a_pack_bf16x2(o[0], o[1]); r.y = v2a_pack_bf16x2(o[2], o[3]);
-        r.z = v2a_pack_bf16x2(o[4], o[5]); r.w = v2a_pack_bf16x2(o[6], o[7]);
+        r.x = v2a_pack_h2<F16>(o[0], o[1]); r.y = v2a_pack_h2<F16>(o[2], o[3]);
+        r.z = v2a_pack_h2<F16>(o[4], o[5]); r.w = v2a_pack_h2<F16>(o[6], o[7]);
         *slot = r;
     };
     auto issue_b = [&](int bc, int bt, int stage) {                 // weight tile of (chunk bc, tap bt); bc >= nchunks: the zero line
@@ -263,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][i], b[h][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(a[h][i], b[h][j], acc[i][j]);
     };
 
 #define V2A_H3_TAP(T)                                                                                                  \
@@ -338,16 +334,16 @@ __global__ __launch_bounds__(512, 1) void conv_halo_h3(const ConvDescH3 p) {
             }
             if (p.residual) {
                 const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
-                v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                v[0] += v2a_lo_h2<F16>(u.x); v[1] += v2a_hi_h2<F16>(u.x);
+                v[2] += v2a_lo_h2<F16>(u.y); v[3] += v2a_hi_h2<F16>(u.y);
+                v[4] += v2a_lo_h2<F16>(u.z); v[5] += v2a_hi_h2<F16>(u.z);
+                v[6] += v2a_lo_h2<F16>(u.w); v[7] += v2a_hi_h2<F16>(u.w);
             }
             uint16_t h[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                h[e] = f2bf3(v[e]);
-                const float r = bf2f3(h[e]);
+                h[e] = v2a_f2h<F16>(v[e]);
+                const float r = v2a_h2f<F16>(h[e]);
                 ssum[e] += r;
                 ssq[e] += r * r;
             }
@@ -413,7 +409,7 @@ struct ConvDescT3 {
     int B, HW, C, Cout, K, rows_per_batch, tiles_b;
 };
 
-template <int F>
+template <int F, bool F16>
 __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
     constexpr int PX = 64, BM = F * PX, BN = 128, ROWB = 64, NST = 3;
     constexpr int ABYTES = BM * ROWB, BBYTES = 3 * BN * ROWB, STAGE = ABYTES + BBYTES;
@@ -525,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
 #pragma unroll
                 for (int i = 0; i < F; ++i) {
                     const int src = i + t - 1;
-                    if (src >= 0 && src < F) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][src], bt[h][t], acc[i], 0, 0, 0);
+                    if (src >= 0 && src < F) acc[i] = v2a_mfma_h<F16>(a[h][src], bt[h][t], acc[i]);
                 }
             };
             load_half(0);
@@ -581,16 +577,16 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
                 }
                 if (p.residual) {
                     const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
-                    v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
-                    v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
-                    v[4] += __uint_as_float(u.z << 16); v[5] += __uint_as_float(u.z & 0xffff0000u);
-                    v[6] += __uint_as_float(u.w << 16); v[7] += __uint_as_float(u.w & 0xffff0000u);
+                    v[0] += v2a_lo_h2<F16>(u.x); v[1] += v2a_hi_h2<F16>(u.x);
+                    v[2] += v2a_lo_h2<F16>(u.y); v[3] += v2a_hi_h2<F16>(u.y);
+                    v[4] += v2a_lo_h2<F16>(u.z); v[5] += v2a_hi_h2<F16>(u.z);
+                    v[6] += v2a_lo_h2<F16>(u.w); v[7] += v2a_hi_h2<F16>(u.w);
                 }
                 uint16_t hh[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hh[e] = f2bf3(v[e]);
+                for (int e = 0; e < 8; ++e) hh[e] = v2a_f2h<F16>(v[e]);
                 if (p.stats) {                                        // the stored values go back into the staging rows for the column pass
-                    const f32x4 w0 = {bf2f3(hh[0]), bf2f3(hh[1]), bf2f3(hh[2]), bf2f3(hh[3])}, w1 = {bf2f3(hh[4]), bf2f3(hh[5]), bf2f3(hh[6]), bf2f3(hh[7])};
+                    const f32x4 w0 = {v2a_h2f<F16>(hh[0]), v2a_h2f<F16>(hh[1]), v2a_h2f<F16>(hh[2]), v2a_h2f<F16>(hh[3])}, w1 = {v2a_h2f<F16>(hh[4]), v2a_h2f<F16>(hh[5]), v2a_h2f<F16>(hh[6]), v2a_h2f<F16>(hh[7])};
                     *reinterpret_cast<f32x4*>(&cw[ml * LDC + (vcol ^ sx)]) = w0;
                     *reinterpret_cast<f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]) = w1;
                 }
@@ -675,8 +671,11 @@ static int conv_h3_launch(const void* x, const void* x2, int C1, const float* gn
     const bool gn = gn_ab != nullptr;
 #define V2A_H3_LAUNCH(...)                                                                                                   \
     do {                                                                                                                     \
-        if (gn) hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 1>), dim3(tiles), dim3(512), 0, stream, p);                    \
-        else hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 0>), dim3(tiles), dim3(512), 0, stream, p);                       \
+        if (g_v2a_half_f16) {                                                                                                \
+            if (gn) hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 1, true>), dim3(tiles), dim3(512), 0, stream, p);          \
+            else hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 0, true>), dim3(tiles), dim3(512), 0, stream, p);             \
+        } else if (gn) hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 1, false>), dim3(tiles), dim3(512), 0, stream, p);      \
+        else hipLaunchKernelGGL((conv_halo_h3<__VA_ARGS__, 0, false>), dim3(tiles), dim3(512), 0, stream, p);                \
     } while (0)
     if (Cout % 256 == 0) {
         const int tiles = N * p.tiles_img * (Cout / 256);
@@ -746,7 +745,8 @@ int v2a_conv2d_fwd_t3(const void* x, const void* w_packed, const float* bias, co
         if (ncu <= 0) ncu = 256;
     }
     const int total = B * p.tiles_b * (Cout / 128);
-    hipLaunchKernelGGL((conv_frames_h3<7>), dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);      // one persistent workgroup per CU
+    if (g_v2a_half_f16) hipLaunchKernelGGL((conv_frames_h3<7, true>), dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_frames_h3<7, false>), dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);      // one persistent workgroup per CU
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

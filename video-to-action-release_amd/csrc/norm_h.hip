@@ -26,16 +26,10 @@ struct GnDescH {
     float eps;
 };
 
-__device__ __forceinline__ void unpack8(const uint4 u, float* f) {
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
-}
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return v2a_pack_bf16x2(a, b); }
 // activation of the bf16-storage path: the result is rounded to 8 mantissa bits, so SiLU runs on the approximate exp2 / rcp units
 __device__ __forceinline__ float act_fwd_h(float x, int act) { return act == ACT_SILU ? v2a_silu_fast(x) : act_fwd(x, act); }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
     extern __shared__ __attribute__((aligned(16))) float bins[];   // [rpi][2][C]: one slot per (row lane, column), combined in lane order
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -64,14 +58,14 @@ __global__ __launch_bounds__(256) void gn_stats_h(const GnDescH p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float f[8];
-                unpack8(u[k], f);
+                v2a_unpack_h8<F16>(u[k], f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
         }
         for (; r < nrows; r += rpi) {
             float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(src + (size_t)r * stride), f);
+            v2a_unpack_h8<F16>(*reinterpret_cast<const uint4*>(src + (size_t)r * stride), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
         }
@@ -152,6 +146,7 @@ __global__ __launch_bounds__(64) void gn_finalize_h(const GnDescH p) {
 
 // grid (chunks, N): 32-bit indexing inside one sample, row / column split by a launch-invariant reciprocal (no 64-bit divides),
 // four independent 16-B loads in flight per thread.
+template <bool F16>
 __global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
     const int L8 = p.C >> 3;
     const uint32_t per_n = (uint32_t)p.S * (uint32_t)L8;
@@ -181,7 +176,7 @@ __global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
         for (int k = 0; k < 4; ++k) {
             if (!ok[k]) continue;
             float f[8];
-            unpack8(u[k], f);
+            v2a_unpack_h8<F16>(u[k], f);
             const float* a = ab + c[k];
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(a + p.C), b1 = *reinterpret_cast<const f32x4*>(a + p.C + 4);
@@ -191,7 +186,7 @@ __global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
                 o[e] = act_fwd_h(f[e] * a0[e] + b0[e], p.act);
                 o[e + 4] = act_fwd_h(f[e + 4] * a1[e] + b1[e], p.act);
             }
-            uint4 v = {pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            uint4 v = {v2a_pack_h2<F16>(o[0], o[1]), v2a_pack_h2<F16>(o[2], o[3]), v2a_pack_h2<F16>(o[4], o[5]), v2a_pack_h2<F16>(o[6], o[7])};
             *reinterpret_cast<uint4*>(yo + (size_t)row[k] * p.C + c[k]) = v;
         }
     }
@@ -236,7 +231,9 @@ static int gn_prep_h(GnDescH& p, const void* x, const void* x2, int C1, const fl
     if (!workspace || workspace_bytes < need) return V2A_ERR_WORKSPACE;
     p.partial = (float*)workspace;
     if (!stats1) {
-        hipLaunchKernelGGL(gn_stats_h, dim3(p.nchunk, N), dim3(256), (size_t)((C >> 3) >= 256 ? 1 : 256 / (C >> 3)) * 2 * C * sizeof(float), stream, p);
+        const size_t lds = (size_t)((C >> 3) >= 256 ? 1 : 256 / (C >> 3)) * 2 * C * sizeof(float);
+        if (g_v2a_half_f16) hipLaunchKernelGGL(gn_stats_h<true>, dim3(p.nchunk, N), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL(gn_stats_h<false>, dim3(p.nchunk, N), dim3(256), lds, stream, p);
         V2A_CHECK_LAUNCH();
     } else {
         const int nb = S >> 6;
@@ -269,7 +266,8 @@ static int gn_apply_launch_h(GnDescH& p, hipStream_t stream) {
     int cap = 8192 / N;
     if (cap < 32) cap = 32;
     if (g > cap) g = cap;
-    hipLaunchKernelGGL(gn_apply_h, dim3(g, N), dim3(256), 0, stream, p);
+    if (g_v2a_half_f16) hipLaunchKernelGGL(gn_apply_h<true>, dim3(g, N), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gn_apply_h<false>, dim3(g, N), dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -17,10 +17,10 @@ class _HipUnetWrapper(nn.Module):
             eng = UNetEngine(self.unet.engine_cfg(), {n: p for n, p in self.named_parameters()}, prefix="unet.")
             self.__dict__["_eng"] = eng
         import v2a_hip
-        want = getattr(self, "storage", None)          # per-model override ('f32' / 'bf16'); else the process-wide default
+        want = getattr(self, "storage", None)          # per-model override ('f32' / 'bf16' / 'fp16'); else the process-wide default
         if want is None:
             want = v2a_hip.get_video_storage()
-            if want == "bf16" and any((self.unet.model_channels * m) % 64 for m in self.unet.channel_mult):
+            if want != "f32" and any((self.unet.model_channels * m) % 64 for m in self.unet.channel_mult):
                 want = "f32"                           # widths the bf16 kernels cannot tile (e.g. the 32-channel test model)
         if eng.storage != want:
             eng.set_storage(want)

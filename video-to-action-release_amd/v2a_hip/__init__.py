@@ -23,7 +23,7 @@ def set_video_storage(mode: str) -> str:
     """HBM storage type of the video UNet's activations / weight packs: 'f32' (parity configuration, default) or 'bf16' (bf16
     tensors, fp32 accumulation and statistics: the counterpart of the reference's fp16-autocast GPU path).  Applies to every
     video UNet whose channel widths allow it (multiples of 64) and that has no `.storage` attribute of its own."""
-    if mode not in ("f32", "bf16"):
+    if mode not in ("f32", "bf16", "fp16"):      # "fp16": IEEE half instances of the same kernels (the reference's own 16-bit type)
         raise ValueError(mode)
     old = _video_storage[0]
     _video_storage[0] = mode

@@ -20,6 +20,8 @@ LL = ctypes.c_longlong
 # name -> (restype, argtypes).  Order/meaning mirrors include/v2a.h exactly.
 SIGNATURES = {
     "v2a_set_precision": (I, [I]),
+    "v2a_set_half_format": (I, [I]),
+    "v2a_get_half_format": (I, []),
     "v2a_get_precision": (I, []),
     "v2a_debug_force_tile": (I, [I, I]),
     "v2a_debug_force_wgrad_plan": (I, [I, I, I]),

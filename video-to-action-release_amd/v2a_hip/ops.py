@@ -501,35 +501,53 @@ def _zero_line(device):
     return z
 
 
+HALF_DTYPES = (torch.bfloat16, torch.float16)      # the two 16-bit storage formats (csrc/common.h: template flag F16 of the `_h` kernels)
+
+
 def _chk_h(t, name="tensor"):
-    assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), f"{name}: need contiguous bf16 CUDA tensor"
+    """16-bit storage tensor (bf16 or IEEE fp16).  The C side keeps ONE process-wide format flag for its `_h` entry points: it is set
+    here from the dtype of the tensor every wrapper checks first, so mixed use (bf16 policy twins, fp16 video storage) stays correct."""
+    assert t.is_cuda and t.dtype in HALF_DTYPES and t.is_contiguous(), f"{name}: need contiguous bf16 / fp16 CUDA tensor"
+    _set_fmt(t.dtype)
     return t
 
 
-def pack_weight_h(w: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """torch fp32 weight [Cout,Cin,*taps] -> bf16 [Cout][taps][Cin] (the K order of conv2d_h)."""
+_fmt_now = [None]
+
+
+def _set_fmt(dtype):
+    if _fmt_now[0] is not dtype:
+        lib.v2a_set_half_format(1 if dtype == torch.float16 else 0)
+        _fmt_now[0] = dtype
+
+
+def pack_weight_h(w: torch.Tensor, out: torch.Tensor = None, dtype=torch.bfloat16) -> torch.Tensor:
+    """torch fp32 weight [Cout,Cin,*taps] -> 16-bit [Cout][taps][Cin] (the K order of conv2d_h); dtype bf16 (default) or fp16."""
     _chk(w, "weight")
     co, ci = w.shape[0], w.shape[1]
     taps = w.numel() // (co * ci)
     if out is None:
-        out = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+        out = torch.empty(w.numel(), dtype=dtype, device=w.device)
+    _set_fmt(out.dtype)
     check(lib.v2a_pack_weight_h(w.data_ptr(), out.data_ptr(), co, ci, taps, _stream()), "pack_weight_h")
     return out
 
 
-def cast_h(x: torch.Tensor) -> torch.Tensor:
-    """fp32 -> bf16 (round to nearest even), same shape."""
+def cast_h(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """fp32 -> bf16 (default) or fp16, round to nearest even, same shape."""
     _chk(x, "x")
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _set_fmt(dtype)
     check(lib.v2a_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_f32_bf16")
     return y
 
 
-def pad_cast_h(x: torch.Tensor, cpad: int) -> torch.Tensor:
-    """fp32 [..., C] -> bf16 [..., cpad] with zero channels behind C (C <= cpad, cpad % 8 == 0)."""
+def pad_cast_h(x: torch.Tensor, cpad: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """fp32 [..., C] -> 16-bit [..., cpad] with zero channels behind C (C <= cpad, cpad % 8 == 0)."""
     _chk(x, "x")
     C = x.shape[-1]
-    y = torch.empty(x.shape[:-1] + (cpad,), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(x.shape[:-1] + (cpad,), dtype=dtype, device=x.device)
+    _set_fmt(dtype)
     check(lib.v2a_pad_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel() // C, C, cpad, _stream()), "pad_cast_f32_bf16")
     return y
 
@@ -561,7 +579,8 @@ class PendingGN:
         self.C = self.C1 + (x2.shape[-1] if x2 is not None else 0)
 
     def apply(self):
-        y = torch.empty((self.N, self.S, self.C), dtype=torch.bfloat16, device=self.x.device)
+        y = torch.empty((self.N, self.S, self.C), dtype=self.x.dtype, device=self.x.device)
+        _set_fmt(self.x.dtype)
         check(lib.v2a_groupnorm_apply_h(self.x.data_ptr(), _p(self.x2), self.C1, self.ab.data_ptr(), y.data_ptr(), self.N, self.S, self.C,
                                         ACT[self.act], _stream()), "groupnorm_apply_h")
         return y
@@ -596,7 +615,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
     if x2 is not None:
         _chk_h(x2, "x2")
         C2 = x2.shape[-1]
-    res_h = residual if (residual is not None and residual.dtype == torch.bfloat16) else None
+    res_h = residual if (residual is not None and residual.dtype in HALF_DTYPES) else None
     res_f = residual if (residual is not None and residual.dtype == torch.float32) else None
     sh, sw = stride
     ph, pw = pad
@@ -608,7 +627,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         OH, OW = out_hw
     M, K = N * OH * OW, KH * KW * (C1 + C2)
     if y is None:
-        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     else:
         out_f32 = y.dtype == torch.float32
     if pre_gn is not None:
@@ -619,7 +638,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
                                        rows_per_batch, _p(stats), _stream()), "conv2d_fwd_h3_gn")
         last_kernel[0] = f"conv_halo_h3_gn<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
         return (y, stats) if want_stats else y
-    if (idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16 and not defer and x2 is None
+    if (idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES and not defer and x2 is None
             and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
             and lib.v2a_conv2d_h3_eligible(N, H, W, C1, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, C2)):
         # 3x3 / stride 1: the halo-tile kernel (csrc/igemm_h3.hip) -- the nine taps share one DMA of the input patch
@@ -629,7 +648,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
               "conv2d_fwd_h3")
         last_kernel[0] = f"conv_halo_h3<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
         return (y, stats) if want_stats else y
-    if (idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16 and not defer and x2 is None and not ups
+    if (idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES and not defer and x2 is None and not ups
             and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
             and lib.v2a_conv2d_t3_eligible(N, H, W, C1, Cout, KH, KW, sh, sw, ph, pw, 0, C2)):
         # temporal 3x1 over [B, F, HW, C]: the frame-stack kernel (csrc/igemm_h3.hip) -- the three taps share one DMA of the frames
@@ -638,7 +657,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
                                     _zero_line(x.device).data_ptr(), N, H, W, C1, Cout, rows_per_batch, _p(stats), _stream()), "conv2d_fwd_t3")
         last_kernel[0] = "conv_frames_h3<448x128>"
         return (y, stats) if want_stats else y
-    if (_H2 and idil == 1 and not out_f32 and res_f is None and y.dtype == torch.bfloat16
+    if (_H2 and idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES
             and lib.v2a_conv2d_h2_eligible(M, Cout, K, C1, C2)):
         # large layer: the multi-stage 256-row kernel (csrc/igemm_h2.hip)
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
@@ -677,7 +696,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
 def linear(x2d, w, bias=None, residual=None, want_stats=False):
     """y = x @ w.T + b for x [M,K], torch weight [N,K] (already K-contiguous: no pack needed).  bf16 x takes a bf16 weight."""
     M, K = x2d.shape
-    if x2d.dtype == torch.bfloat16:
+    if x2d.dtype in HALF_DTYPES:
         r = conv2d_h(x2d.view(1, 1, M, K), w, bias, w.shape[0], 1, 1, residual=None if residual is None else residual.view(1, 1, M, -1),
                      want_stats=want_stats)
         return (r[0].view(M, w.shape[0]), r[1]) if want_stats else r.view(M, w.shape[0])
@@ -740,7 +759,7 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
     C = C1 + (x2.shape[-1] if x2 is not None else 0)
     if x2 is not None:
         _chk_h(x2, "x2")
-    y = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((N, S, C), dtype=x.dtype, device=x.device)
     wsb = lib.v2a_groupnorm_h_workspace_bytes(N, S, C)
     ws = workspace(wsb, x.device)
     if stats is None or S % 64 or (x2 is not None and stats2 is None):
@@ -868,8 +887,9 @@ def nhwc_to_nchw(src):
 
 # ------------------------------------------------------------------------------------------------ attention etc.
 def attention(qkv, n_frames, L, heads, head_ch):
-    if qkv.dtype == torch.bfloat16:
-        out = torch.empty((n_frames * L, heads * head_ch), dtype=torch.bfloat16, device=qkv.device)
+    if qkv.dtype in HALF_DTYPES:
+        _set_fmt(qkv.dtype)
+        out = torch.empty((n_frames * L, heads * head_ch), dtype=qkv.dtype, device=qkv.device)
         check(lib.v2a_attention_fwd_h(qkv.data_ptr(), out.data_ptr(), n_frames, L, heads, head_ch, _stream()), "attention_fwd_h")
         return out
     out = torch.empty((n_frames * L, heads * head_ch), dtype=torch.float32, device=qkv.device)

@@ -72,9 +72,12 @@ class _Packs:
         self._c = {}
 
     def get(self, name, half=False, pad_cin=0):
-        """pad_cin: bf16 pack with the input-channel axis zero-padded to `pad_cin` (the 6-channel stem on the 32-channel-chunk kernels)."""
+        """half: False (fp32 pack) or the 16-bit dtype of the pack (torch.bfloat16 / torch.float16).
+        pad_cin: 16-bit pack with the input-channel axis zero-padded to `pad_cin` (the 6-channel stem on the 32-channel-chunk kernels)."""
         w = self.P[name]
         key = (w.data_ptr(), w._version)
+        if half is True:
+            half = torch.bfloat16
         ck = (name, half, pad_cin)
         ent = self._c.get(ck)
         if ent is None or ent[0] != key:
@@ -88,7 +91,7 @@ class _Packs:
             for s in wd.shape[2:]:
                 taps *= s
             if half:
-                pk = ops.pack_weight_h(wd.contiguous(), None if ent is None else ent[1])
+                pk = ops.pack_weight_h(wd.contiguous(), None if ent is None else ent[1], dtype=half)
             else:
                 pk = wd if taps == 1 else ops.pack_weight(wd.contiguous(), 0, None if ent is None else ent[1])
             ent = (key, pk)
@@ -102,7 +105,7 @@ class _LazyGN:
 
     def __init__(self, pending, shape, frames_separate):
         self.pending, self.shape, self.frames_separate = pending, tuple(shape), frames_separate
-        self.dtype = torch.bfloat16
+        self.dtype = pending.x.dtype
 
     def materialize(self):
         return self.pending.apply().view(self.shape)
@@ -119,14 +122,17 @@ class UNetEngine:
         # "f32": fp32 tensors in HBM (parity configuration; the MFMA input type follows v2a_hip.set_precision).
         # "bf16": bf16 activations + bf16 weight packs, fp32 accumulation / normalisation statistics / softmax -- the counterpart of
         # the reference's fp16-autocast GPU path (lb_online_trainer_v7.py:889); needs every inner width to be a multiple of 64.
+        # "fp16": the same kernels instantiated for IEEE half (v_mfma_f32_32x32x16_f16): the reference's own 16-bit type.
         self.storage = "f32"
+        self.hdt = torch.bfloat16
         self._eo = None
         self._res_names = None
 
     def set_storage(self, mode):
-        if mode not in ("f32", "bf16"):
+        if mode not in ("f32", "bf16", "fp16"):
             raise ValueError(mode)
-        if mode == "bf16":
+        self.hdt = torch.float16 if mode == "fp16" else torch.bfloat16
+        if mode != "f32":
             c = self.cfg
             widths = [c.model_channels * m for m in c.channel_mult]
             if any(w % 64 for w in widths):
@@ -134,7 +140,7 @@ class UNetEngine:
         self.storage = mode
 
     def w(self, name, half=False, pad_cin=0):
-        return self.packs.get(self.pre + name, half, pad_cin)
+        return self.packs.get(self.pre + name, self.hdt if half else False, pad_cin)
 
     def p(self, name):
         return self.P[self.pre + name]
@@ -196,18 +202,18 @@ class UNetEngine:
     def conv3d(self, x, name, cout, stride=1, ups=False, x2=None, rowvec=None, residual=None, out_f32=False):
         """x [B,F,H,W,C] (+x2) -> [B,F,OH,OW,cout].  rowvec [B,cout] / residual [B,F,OH,OW,cout] land in the LAST kernel."""
         B, Fr, H, W, C = x.shape
-        if x.dtype == torch.bfloat16:                      # (a _LazyGN reports bf16)
+        if x.dtype in ops.HALF_DTYPES:                      # (a _LazyGN reports bf16)
             return self._conv3d_h(x, name, cout, stride, ups, x2, rowvec, residual, out_f32)
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
         x4 = x.view(B * Fr, H, W, C)
         x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
-        if (self.storage == "bf16" and has_t and cout % 128 == 0 and C < 32 and k == 3 and stride == 1 and x2 is None and not ups
+        if (self.storage != "f32" and has_t and cout % 128 == 0 and C < 32 and k == 3 and stride == 1 and x2 is None and not ups
                 and not os.environ.get("V2A_STEM_F32")):
             # stem (Cin = 6) in the bf16-storage configuration: input padded to one 32-channel chunk, so that the spatial conv runs on the
             # halo kernel (135 GFLOP of padded work at ~1 PFLOP/s instead of 25 GFLOP on the scalar-gather fp32 kernel at 33 TFLOP/s) and
             # its output is born bf16 (no cast launch in front of the temporal conv)
-            xh = ops.pad_cast_h(x4, 32)
+            xh = ops.pad_cast_h(x4, 32, self.hdt)
             y = ops.conv2d_h(xh, self.w(name + ".spatial_conv.weight", half=True, pad_cin=32), self.p(name + ".spatial_conv.bias"), cout, 3, 3,
                              (1, 1), (1, 1))
             z, stats = ops.conv2d_h(y.view(B, Fr, H * W, cout), self.w(name + ".temporal_conv.weight", half=True),
@@ -233,8 +239,8 @@ class UNetEngine:
             out = y.view(B, Fr, OH, OW, cout)
             out._gn_stats = stats
             return out
-        if self.storage == "bf16" and cout % 64 == 0:      # stem: fp32 spatial conv (Cin = 6), the 128-wide temporal conv on the bf16 kernel
-            z, stats = ops.conv2d_h(ops.cast_h(y).view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
+        if self.storage != "f32" and cout % 64 == 0:      # stem: fp32 spatial conv (Cin = 6), the 128-wide temporal conv on the bf16 kernel
+            z, stats = ops.conv2d_h(ops.cast_h(y, self.hdt).view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
                                     self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
                                     rows_per_batch=Fr * OH * OW, residual=None if residual is None else residual.view(B, Fr, OH * OW, cout),
                                     want_stats=True)
@@ -258,11 +264,11 @@ class UNetEngine:
         N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
         x3 = x.view(N, S, C1)
         x23 = None if x2 is None else x2.view(N, S, -1)
-        if lazy and x.dtype == torch.bfloat16 and ops._GN_FUSE:
+        if lazy and x.dtype in ops.HALF_DTYPES and ops._GN_FUSE:
             pg = ops.groupnorm_prep_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
                                       stats=getattr(x, "_gn_stats", None), stats2=None if x2 is None else getattr(x2, "_gn_stats", None))
             return _LazyGN(pg, (B, Fr, H, W, C), frames_separate)
-        if x.dtype == torch.bfloat16:
+        if x.dtype in ops.HALF_DTYPES:
             return ops.groupnorm_fwd_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
                                        stats=getattr(x, "_gn_stats", None),
                                        stats2=None if x2 is None else getattr(x2, "_gn_stats", None)).view(B, Fr, H, W, C)
@@ -296,7 +302,7 @@ class UNetEngine:
         hc = self.cfg.num_head_channels
         heads = C // hc
         n = self.gn_silu(x, name + ".norm", act="none", frames_separate=True)
-        half = x.dtype == torch.bfloat16
+        half = x.dtype in ops.HALF_DTYPES
         wq = self.w(name + ".qkv.weight", True).view(3 * C, C) if half else self.p(name + ".qkv.weight").view(3 * C, C)
         wo = self.w(name + ".proj_out.weight", True).view(C, C) if half else self.p(name + ".proj_out.weight").view(C, C)
         qkv = ops.linear(n.view(N * L, C), wq, self.p(name + ".qkv.bias"))
@@ -397,8 +403,8 @@ class UNetEngine:
         h = xin
         for i, blk in enumerate(self.inp):
             h = self._run(blk, h, semb)
-            if i == 0 and self.storage == "bf16" and h.dtype != torch.bfloat16:
-                h = ops.cast_h(h)          # the stem (Cin = 6) runs on the fp32 kernels; everything after it is bf16 in HBM
+            if i == 0 and self.storage != "f32" and h.dtype not in ops.HALF_DTYPES:
+                h = ops.cast_h(h, self.hdt)          # the stem (Cin = 6) runs on the fp32 kernels; everything after it is bf16 in HBM
             hs.append(h)
         h = self._run(self.mid, h, semb)
         for blk in self.out:
