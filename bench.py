@@ -388,6 +388,10 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
                       "sampling_steps": sampling_steps, "sampler": "ddim" if sampling_steps < 100 else "ddpm (ancestral)", "guidance_weight": 0,
                       "hip_graph": True, "noise": "in-kernel Philox"},
            "dtype": "f32", "algorithmic_tflops": flops / dt / 1e12, "output_range": [float(out.min()), float(out.max())]}
+    import v2a_hip as _v
+    # UNet forwards this leg ran in total (profiling scripts divide whole-run counters by it): the untimed call (+ the one eager step
+    # in front of the graph capture), the timed calls, the instrumented forward below
+    res["unet_forwards"] = sampling_steps * (1 + reps) + (1 if _v.sampler_graphs_enabled() else 0) + (1 if roofline else 0)
     if not roofline:
         return res
     # instrumented single UNet forward: per-variant conv timing with HIP events

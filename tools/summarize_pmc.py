@@ -11,6 +11,9 @@ from collections import defaultdict
 root = sys.argv[1]
 out = {}
 leg_totals = {}
+FROM_SUMMARY = None
+if os.path.isfile(root):          # re-derive roofline_traffic from a pmc_summary.json written earlier (the raw csv files do not travel)
+    FROM_SUMMARY = json.load(open(root))
 
 
 def _units(leg):
@@ -26,6 +29,11 @@ def _units(leg):
 
 
 for leg in ("policy", "video", "video_bf16"):
+    if FROM_SUMMARY is not None:
+        out[leg] = FROM_SUMMARY[leg]
+        if leg in FROM_SUMMARY.get("roofline_traffic", {}).get("legs", {}):
+            leg_totals[leg] = FROM_SUMMARY["roofline_traffic"]["legs"][leg]
+        continue
     res = defaultdict(lambda: {"n": 0})
     tot = {"fetch": 0.0, "write": 0.0}
     for ctr in ("fetch", "write"):
@@ -59,9 +67,16 @@ for leg_name in ("policy", "video", "video_bf16"):
     traffic = {}
     for k, v in out[leg_name].items():
         m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
-        mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short)(?:, \d+)?>", k)
-        m3 = re.match(r"(conv_halo_h3|conv_igemm_h2)<(\d+), (\d+), (\d+), (\d+), \d+(?:, (\d+))?>", k)      # <WAVES_M, WAVES_N, TM, TN, SB[, GN]> -> BM x BN
-        mf = re.match(r"conv_frames_h3<(\d+)>", k)
+        mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short|f16s)(?:, \d+)?>", k)
+        # <WAVES_M, WAVES_N, TM, TN, SB[, GN][, F16]> -> BM x BN (the trailing bool is the fp16 flag of round 3)
+        m3 = re.match(r"(conv_halo_h3|conv_igemm_h2)<(\d+), (\d+), (\d+), (\d+), \d+(?:, (\d+))?(?:, (?:true|false))?>", k)
+        mf = re.match(r"conv_frames_h3<(\d+)(?:, (?:true|false))?>", k)
+        mw = re.match(r"(conv_wgrad_multi(?:_halo)?)_kernel", k)
+        if mw:
+            a = traffic.setdefault(mw.group(1), [0.0, 0])
+            a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
+            a[1] += v["n"]
+            continue
         if m or mh or m3 or mf:
             if m3:
                 wm_, wn_, tm_, tn_ = (int(m3.group(i)) for i in (2, 3, 4, 5))
@@ -70,7 +85,7 @@ for leg_name in ("policy", "video", "video_bf16"):
                 key = f"conv_frames_h3<{int(mf.group(1)) * 64}x128>"
             else:
                 key = (f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else
-                       f"conv_igemm_h<{mh.group(1)},{mh.group(2)},{'float' if mh.group(3) == 'float' else 'bf16'}>")
+                       f"conv_igemm_h<{mh.group(1)},{mh.group(2)},{'float' if mh.group(3) == 'float' else ('fp16' if mh.group(3) == 'f16s' else 'bf16')}>")
             a = traffic.setdefault(key, [0.0, 0])     # template variants sharing a tile: launch-count weighted mean
             a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
             a[1] += v["n"]
