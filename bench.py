@@ -717,7 +717,7 @@ def main():
                                               "unit": "predicted frames/s, all ranks", "rows_per_rank": rows, "seconds_per_sample_call": t_call,
                                               "config": vs["config"], "timing": vs["timing"] + "; MAX over ranks",
                                               "algorithmic_tflops": 2.130 * rows * world * args.video_steps / t_call},
-                                             "weak-free: the B rows of one sample() call are split over the ranks, no collective")
+                                             "the B rows of one sample() call are split over the ranks (rows of a batch are independent): no collective")
                 every = 200                                      # config/libero/lb_tk8_65to72.py:84-90: one exploration round per 200 steps
                 out["joint"] = {"workload": "BASELINE configs[3]: policy train steps + one video-guided exploration round (8 tasks, bs 1, 100 "
                                             "ancestral steps, tasks split over the ranks) every 200 steps", "rollout_every_steps": every,
