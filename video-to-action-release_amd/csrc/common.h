@@ -75,6 +75,20 @@ __device__ __forceinline__ float v2a_silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
 }
 
+// GroupNorm affine + activation on one packed pair of 16-bit elements, two-wide fp32 VALU (v_pk_fma / v_pk_mul / v_pk_add):
+// z = x * a + b; SiLU: z * rcp(1 + exp2(-log2(e) * z)) -- the arithmetic of v2a_silu_fast.  Shared by gn_apply_h and the halo conv's
+// loader, which must agree bit for bit.
+template <bool F16> __device__ __forceinline__ unsigned int v2a_gn_act2(unsigned int u, v2a_f32x2 a, v2a_f32x2 b, bool silu) {
+    const v2a_f32x2 x = {v2a_lo_h2<F16>(u), v2a_hi_h2<F16>(u)};
+    v2a_f32x2 z = __builtin_elementwise_fma(x, a, b);
+    if (silu) {
+        const v2a_f32x2 t = z * -1.44269504088896340736f;
+        const v2a_f32x2 d = v2a_f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+        z = z * v2a_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    }
+    return v2a_pack_h2<F16>(z[0], z[1]);
+}
+
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
         case ACT_SILU: return x / (1.0f + expf(-x));

@@ -175,18 +175,26 @@ __global__ __launch_bounds__(256) void gn_apply_h(const GnDescH p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!ok[k]) continue;
-            float f[8];
-            v2a_unpack_h8<F16>(u[k], f);
             const float* a = ab + c[k];
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(a + p.C), b1 = *reinterpret_cast<const f32x4*>(a + p.C + 4);
-            float o[8];
+            uint4 v;
+            if (p.act == ACT_SILU || p.act == ACT_NONE) {
+                const bool silu = p.act == ACT_SILU;
+                v.x = v2a_gn_act2<F16>(u[k].x, v2a_f32x2{a0[0], a0[1]}, v2a_f32x2{b0[0], b0[1]}, silu);
+                v.y = v2a_gn_act2<F16>(u[k].y, v2a_f32x2{a0[2], a0[3]}, v2a_f32x2{b0[2], b0[3]}, silu);
+                v.z = v2a_gn_act2<F16>(u[k].z, v2a_f32x2{a1[0], a1[1]}, v2a_f32x2{b1[0], b1[1]}, silu);
+                v.w = v2a_gn_act2<F16>(u[k].w, v2a_f32x2{a1[2], a1[3]}, v2a_f32x2{b1[2], b1[3]}, silu);
+            } else {
+                float f[8], o[8];
+                v2a_unpack_h8<F16>(u[k], f);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = act_fwd_h(f[e] * a0[e] + b0[e], p.act);
-                o[e + 4] = act_fwd_h(f[e + 4] * a1[e] + b1[e], p.act);
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = act_fwd_h(f[e] * a0[e] + b0[e], p.act);
+                    o[e + 4] = act_fwd_h(f[e + 4] * a1[e] + b1[e], p.act);
+                }
+                v = uint4{v2a_pack_h2<F16>(o[0], o[1]), v2a_pack_h2<F16>(o[2], o[3]), v2a_pack_h2<F16>(o[4], o[5]), v2a_pack_h2<F16>(o[6], o[7])};
             }
-            uint4 v = {v2a_pack_h2<F16>(o[0], o[1]), v2a_pack_h2<F16>(o[2], o[3]), v2a_pack_h2<F16>(o[4], o[5]), v2a_pack_h2<F16>(o[6], o[7])};
             *reinterpret_cast<uint4*>(yo + (size_t)row[k] * p.C + c[k]) = v;
         }
     }
