@@ -592,13 +592,34 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
         float bv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
+        // Loads and stores share the vmcnt counter, so a load issued behind a frame's stores makes its consumer wait for those stores
+        // to be acknowledged -- seven store round trips in
+        // a row per tile (PMC: 3.2-3.5 TB/s on the C = 128 layers).  The row vector is one table row per tile when a tile lies inside one
+        // batch entry (rows_per_batch = F * HW, the only way the UNet calls it); the residual rows of frame i + 1 are requested before
+        // frame i's stores, so their wait leaves those stores in flight.
+        const bool rv_tile = p.rowvec && p.rows_per_batch == F * p.HW;
+        f32x4 rv0 = {0.f, 0.f, 0.f, 0.f}, rv1 = {0.f, 0.f, 0.f, 0.f};
+        if (rv_tile) {
+            const float* rv = p.rowvec + (size_t)b * p.Cout + n;
+            rv0 = *reinterpret_cast<const f32x4*>(rv);
+            rv1 = *reinterpret_cast<const f32x4*>(rv + 4);
+        }
+        uint4 rnext[2] = {uint4{0u, 0u, 0u, 0u}, uint4{0u, 0u, 0u, 0u}};
+        auto load_res = [&](int i) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                rnext[k] = *reinterpret_cast<const uint4*>(p.residual + (((size_t)(b * F + i) * p.HW) + p0 + w * 32 + k * (64 / V) + vrow) * p.Cout + n);
+        };
+        if (p.residual) load_res(0);
 #pragma unroll
         for (int i = 0; i < F; ++i) {
+            const uint4 rcur[2] = {rnext[0], rnext[1]};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
                 cw[row * LDC + (lr ^ ((row & 1) << 2))] = acc[i][r];
             }
+            if (p.residual && i + 1 < F) load_res(i + 1);          // ahead of this frame's stores
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const size_t m0 = ((size_t)(b * F + i) * p.HW) + p0 + w * 32;
 #pragma unroll
@@ -610,14 +631,17 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
                 const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
                 float v[8] = {c0[0] + bv[0], c0[1] + bv[1], c0[2] + bv[2], c0[3] + bv[3], c1[0] + bv[4], c1[1] + bv[5], c1[2] + bv[6], c1[3] + bv[7]};
                 const size_t o = m * p.Cout + n;
-                if (p.rowvec) {
+                if (rv_tile) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += rv0[e]; v[e + 4] += rv1[e]; }
+                } else if (p.rowvec) {
                     const float* rv = p.rowvec + (size_t)((uint32_t)m / (uint32_t)p.rows_per_batch) * p.Cout + n;
                     const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
                 }
                 if (p.residual) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(p.residual + o);
+                    const uint4 u = rcur[rr / (64 / V)];
                     v[0] += v2a_lo_h2<F16>(u.x); v[1] += v2a_hi_h2<F16>(u.x);
                     v[2] += v2a_lo_h2<F16>(u.y); v[3] += v2a_hi_h2<F16>(u.y);
                     v[4] += v2a_lo_h2<F16>(u.z); v[5] += v2a_hi_h2<F16>(u.z);
