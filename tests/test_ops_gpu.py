@@ -664,13 +664,16 @@ def test_fp32_groupnorm_takes_statistics_from_the_conv_epilogue(two):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("epi", ["residual", "rowvec", "bias"])
 @pytest.mark.parametrize("B,HW,C,Co", [(16, 1024, 128, 128), (4, 4096, 192, 256), (30, 512, 64, 128), (18, 256, 320, 384)])
-def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co):
+def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co, epi):
     """The frame-stack temporal kernel (csrc/igemm_h3.hip conv_frames_h3: all 7 frames of 64 pixels per workgroup, operand fragments
     kept in registers across the three taps, products against frames -1 / 7 not issued): first / last frame borders, several
     pixel tiles per sample, 2 .. 5 channel chunks (fewer than, equal to and more than the three LDS stages), bias + per-sample
     row vector + bf16 residual + statistics in natural 64-row blocks.  Within one bf16 ulp of an fp64 conv of the same rounded
-    operands, and equal to the tap-by-tap kernel up to summation order."""
+    operands, and equal to the tap-by-tap kernel up to summation order.  `epi` selects the epilogue: with a residual the tile is staged
+    in fp32; without one ("rowvec": bias + per-sample row vector, "bias": bias only) it is rounded and paired in registers
+    (pack_subtile3) and the statistics never touch LDS."""
     from v2a_hip import ops
     from v2a_hip._lib import lib
     dev, F = "cuda:0", 7
@@ -679,8 +682,8 @@ def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co):
     x = torch.randn(B, F, HW, C, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(Co, C, 3, 1, generator=g) * 0.08).to(dev)
     b = torch.randn(Co, generator=g).to(dev)
-    rowvec = torch.randn(B, Co, generator=g).to(dev)
-    res = torch.randn(B, F, HW, Co, generator=g).to(torch.bfloat16).to(dev)
+    rowvec = torch.randn(B, Co, generator=g).to(dev) if epi != "bias" else None
+    res = torch.randn(B, F, HW, Co, generator=g).to(torch.bfloat16).to(dev) if epi == "residual" else None
     wp = ops.pack_weight_h(w)
     y, st = ops.conv2d_h(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res, want_stats=True)
     assert ops.last_kernel[0].startswith("conv_frames_h3") and st is not None
@@ -696,7 +699,10 @@ def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co):
     wq = w.to(torch.bfloat16).float().cpu().double()
     for n in (0, B - 1):
         ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=(1, 0)).permute(0, 2, 3, 1)[0]
-        ref = ref + rowvec[n].cpu().double() + res[n].cpu().double()
+        if rowvec is not None:
+            ref = ref + rowvec[n].cpu().double()
+        if res is not None:
+            ref = ref + res[n].cpu().double()
         err = (y[n].cpu().double() - ref).abs()
         assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
     rows = y.float().view(-1, 64, Co)                                  # natural block numbering: rows / 64

@@ -67,6 +67,31 @@ __device__ __forceinline__ int lds_group_perm3(int m) {
 #endif
 }
 
+// value of the other lane of an (even, odd) lane pair
+__device__ __forceinline__ float pair_swap3(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+}
+
+// One 32 x 32 sub-tile of fp32 accumulators in the MFMA C layout (lane -> column lane & 31, register r -> row
+// (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) -> 16-bit values, two adjacent columns per dword, WITHOUT the fp32 round trip through
+// LDS: v = (acc + colb) + colr is rounded in registers; the lanes of an (even, odd) pair trade one value per register pair, after
+// which the even lane holds row rho(2q) and the odd lane row rho(2q + 1), columns (c & ~1, c | 1), in pk[q].  The per-column sums of
+// the ROUNDED values and of their squares accumulate into s2 / q2 (lane: its two columns over its eight rows).
+// LDS traffic of an epilogue sub-tile: 8 ds_write_b32 + 2 ds_read_b128 instead of 16 + 4 (+ 4 ds_write_b128 + 16 ds_read_b32 for the
+// statistics) -- the write path into LDS moves 64-85 B/clk and was what the epilogues of these kernels waited for.
+template <bool F16>
+__device__ __forceinline__ void pack_subtile3(const f32x16& acc, float colb, float colr, bool odd, uint32_t (&pk)[8], float (&s2)[2], float (&q2)[2]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float v0 = (acc[2 * q] + colb) + colr, v1 = (acc[2 * q + 1] + colb) + colr;
+        const float t = pair_swap3(odd ? v0 : v1);         // even lane: the odd lane's v0 (column c + 1, row rho(2q)); odd lane: the even lane's v1
+        pk[q] = v2a_pack_h2<F16>(odd ? t : v0, odd ? v1 : t);
+        const float a = v2a_lo_h2<F16>(pk[q]), b = v2a_hi_h2<F16>(pk[q]);
+        s2[0] += a; q2[0] += a * a;
+        s2[1] += b; q2[1] += b * b;
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt3() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -527,6 +552,7 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
 
     issue_next(0);
     issue_next(1);
+    wait_vmcnt3<0>();
     int cstage = 0, istage = 2;
     for (; lin < total; lin += G) {
         const int tmi = lin / tiles_n;
@@ -538,11 +564,15 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
         for (int c = 0; c < nchunks; ++c) {
-            // chunk c must have landed; chunk c+1 may stay in flight -- except at a tile's first chunk, where the previous tile's
-            // epilogue stores sit in the same counter (stores and loads do not retire in one order): drain it there
-            if (c == 0) wait_vmcnt3<0>();
-            else if (a_tail) wait_vmcnt3<AJ + 3>();
-            else wait_vmcnt3<AJ - 1 + 3>();
+            // chunk c must have landed; chunk c+1 may stay in flight.  The two chunks that were in flight when the previous tile's
+            // epilogue began were waited for THERE (below), so steps 0 and 1 need no wait; from step 2 on every DMA this counts was
+            // issued after the epilogue's stores.  (Loads and stores share vmcnt and do not retire in one order: a counted wait is
+            // exact only for loads with no YOUNGER store in the queue -- older stores can only prolong it.  Waiting for the
+            // prefetched chunks after the stores instead, with vmcnt(0), cost 2.5 us of store acknowledgements per tile.)
+            if (c >= 2) {
+                if (a_tail) wait_vmcnt3<AJ + 3>();
+                else wait_vmcnt3<AJ - 1 + 3>();
+            }
             __builtin_amdgcn_s_barrier();
             issue_next(istage);
             const unsigned char* sb = smem + cstage * STAGE;
@@ -582,6 +612,7 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
             istage = (istage + 1 == NST) ? 0 : istage + 1;
         }
 
+        wait_vmcnt3<0>();                                  // the next tile's first two chunks, ahead of this tile's stores
         // `istage` now names the stage consumed last: nothing is in flight to it until the next step's barrier, so -- once every wave
         // has read its last fragments -- it carries the epilogue's staging rows (private to each wave) and the statistics exchange
         __builtin_amdgcn_s_barrier();
@@ -589,6 +620,49 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
         float* st = reinterpret_cast<float*>(smem + istage * STAGE + ST_OFF);       // [2 (w)][F][4 (wn)][2][32]
         // ---- epilogue: sub-tile i of this wave = frame i, pixels p0 + w*32 .. +31 (staging rows private to the wave)
         const int n = n0 + wn + vcol;
+        if (!p.residual && (!p.rowvec || p.rows_per_batch == F * p.HW)) {
+            // no residual, and the row vector is one table row for the whole tile: the register path (pack_subtile3)
+            const int ncol = n0 + wn + lr;
+            const float colb = p.bias ? p.bias[ncol] : 0.f;
+            const float colr = p.rowvec ? p.rowvec[(size_t)b * p.Cout + ncol] : 0.f;
+            const bool odd = lane & 1;
+            uint32_t* ph = reinterpret_cast<uint32_t*>(smem + istage * STAGE) + wid * 32 * 16;    // [32 rows][16 dwords] per wave
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                uint32_t pk[8];
+                float s2[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+                pack_subtile3<F16>(acc[i], colb, colr, odd, pk, s2, q2);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 2 * q + (odd ? 1 : 0);
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    ph[row * 16 + (lr >> 1)] = pk[q];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const size_t m0 = ((size_t)(b * F + i) * p.HW) + p0 + w * 32;
+#pragma unroll
+                for (int rr = 0; rr < 32; rr += 64 / V) {
+                    const int ml = rr + vrow;
+                    const uint4 u = *reinterpret_cast<const uint4*>(ph + ml * 16 + (lane % V) * 4);
+                    *reinterpret_cast<uint4*>(p.y + (m0 + ml) * p.Cout + n) = u;
+                }
+                if (p.stats) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        s2[k] += pair_swap3(s2[k]);
+                        q2[k] += pair_swap3(q2[k]);
+                        s2[k] += __shfl_xor(s2[k], 32, 64);
+                        q2[k] += __shfl_xor(q2[k], 32, 64);
+                    }
+                    if (lane < 32 && !odd) {
+                        float* d = st + (((w * F + i) * 4 + (wid & 3)) * 2) * 32 + lr;
+                        d[0] = s2[0]; d[1] = s2[1];
+                        d[32] = q2[0]; d[33] = q2[1];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging rows are rewritten by the next frame
+            }
+        } else {
         float bv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[n + e] : 0.f;
@@ -684,6 +758,7 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
                     d[32] = q;
                 }
             }
+        }
         }
         if (p.stats) {
             __syncthreads();
