@@ -529,12 +529,14 @@ def test_conv2d_h2_multistage_kernel_matches_fp64_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("epi", ["residual", "rowvec"])
 @pytest.mark.parametrize("N,H,W,C,Co", [(34, 64, 64, 96, 256), (36, 48, 80, 64, 128), (44, 32, 32, 128, 384), (56, 64, 32, 64, 128)])
-def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
+def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co, epi):
     """The halo-tile 3x3 kernel (csrc/igemm_h3.hip: 16 x 16 output patches, the 18 x 18 input halo DMA-ed once per 32-channel chunk and
     read by the nine taps through shifted LDS windows, counted-vmcnt weight ring): both instances (256x256 / 256x128), image borders on
     every side of the patch grid, non-square frames, three chunk counts, bias + per-sample row vector + residual + statistics.  Within
-    one bf16 ulp of an fp64 conv of the same rounded operands, and equal to the tap-by-tap kernel up to summation order."""
+    one bf16 ulp of an fp64 conv of the same rounded operands, and equal to the tap-by-tap kernel up to summation order.  Both epilogues:
+    fp32 staging (with a residual) and the register path (pack_subtile3, without one)."""
     from v2a_hip import ops
     from v2a_hip._lib import lib
     dev = "cuda:0"
@@ -544,7 +546,7 @@ def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
     w = (torch.randn(Co, C, 3, 3, generator=g) * 0.05).to(dev)
     b = torch.randn(Co, generator=g).to(dev)
     rowvec = torch.randn(N, Co, generator=g).to(dev)
-    res = torch.randn(N, H, W, Co, generator=g).to(torch.bfloat16).to(dev)
+    res = torch.randn(N, H, W, Co, generator=g).to(torch.bfloat16).to(dev) if epi == "residual" else None
     wp = ops.pack_weight_h(w)
     y, st = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rowvec, rows_per_batch=H * W, residual=res, want_stats=True)
     assert ops.last_kernel[0].startswith("conv_halo_h3") and st is not None
@@ -560,7 +562,7 @@ def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co):
     wq = w.to(torch.bfloat16).float().cpu().double()
     for n in (0, N - 1):
         ref = torch.nn.functional.conv2d(xin[n:n + 1], wq, b.cpu().double(), padding=1).permute(0, 2, 3, 1)[0]
-        ref = ref + rowvec[n].cpu().double() + res[n].cpu().double()
+        ref = ref + rowvec[n].cpu().double() + (res[n].cpu().double() if res is not None else 0.0)
         err = (y[n].cpu().double() - ref).abs()
         assert (err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all(), float(err.max())
     # statistics: blocks are numbered per (patch, 64-row group), so compare per FRAME (what GroupNorm reduces over)
