@@ -1001,3 +1001,38 @@ def test_fp16_instances_of_the_16bit_kernels_match_fp64_on_fp16_rounded_operands
     ref = (wgt @ v).permute(0, 2, 1, 3).reshape(n_fr * L, heads * ch)
     err = (out.cpu().double() - ref).abs()
     assert float(err.max()) <= 2.0 ** -8 * float(ref.abs().max()), float(err.max())      # P is rounded to fp16 before P V (as the bf16 instance rounds to bf16)
+
+
+@pytest.mark.gpu
+def test_pack_weights_multi_forward_and_flipped_packs_vs_torch():
+    """v2a_pack_weights_multi: every pack of a model in two launches.  Mode 0 ([Cout][Cin][taps] -> [Cout][taps][Cin]) and mode 1
+    (tap-reversed transpose for the data gradient, through LDS tiles), fp32 + bf16 twins, for filters smaller and larger than a
+    chunk, odd and even tap counts, operands that do not fill their last chunk or tile.  Bit-exact against torch permutes."""
+    from v2a_hip._lib import lib, check
+    from v2a_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(9)
+    ce = lib.v2a_pack_chunk_elems()
+    shapes = [(64, 3, 49), (128, 64, 9), (96, 40, 5), (8, 2560, 9), (33, 17, 4), (256, 512, 1), (5, 7, 3)]
+    assert any(ci * t > ce for _, ci, t in shapes) and any(co * ci * t % ce for co, ci, t in shapes)
+    ws, rows, ch0, ch1, outs = [], [], [], [], []
+    for co, ci, taps in shapes:
+        w = torch.randn(co, ci, taps, generator=g).to(dev)
+        f32a, f32b = torch.zeros(w.numel(), device=dev), torch.zeros(w.numel(), device=dev)
+        ha, hb = torch.zeros(w.numel(), dtype=torch.bfloat16, device=dev), torch.zeros(w.numel(), dtype=torch.bfloat16, device=dev)
+        rows.append([w.data_ptr(), f32a.data_ptr(), co, ci, taps, 0, ha.data_ptr()])
+        ch0 += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
+        rows.append([w.data_ptr(), f32b.data_ptr(), co, ci, taps, 1, hb.data_ptr()])
+        ch1 += [[len(rows) - 1, t] for t in range(-(-co // 64) * -(-(ci * taps) // 64))]
+        ws.append(w)
+        outs.append((f32a, ha, f32b, hb))
+    tab = torch.tensor(rows, dtype=torch.int64).to(dev)
+    c0, c1 = torch.tensor(ch0, dtype=torch.int32).to(dev), torch.tensor(ch1, dtype=torch.int32).to(dev)
+    check(lib.v2a_pack_weights_multi(tab.data_ptr(), c0.data_ptr(), len(ch0), 0, ops._stream()), "pack0")
+    check(lib.v2a_pack_weights_multi(tab.data_ptr(), c1.data_ptr(), len(ch1), 1, ops._stream()), "pack1")
+    torch.cuda.synchronize()
+    for w, (f32a, ha, f32b, hb) in zip(ws, outs):
+        fwd = w.permute(0, 2, 1).contiguous().view(-1)                          # [Cout][taps][Cin]
+        flip = w.flip(2).permute(1, 2, 0).contiguous().view(-1)                 # [Cin][taps reversed][Cout]
+        assert torch.equal(f32a, fwd) and torch.equal(ha, fwd.to(torch.bfloat16))
+        assert torch.equal(f32b, flip) and torch.equal(hb, flip.to(torch.bfloat16))
