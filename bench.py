@@ -50,7 +50,9 @@ def _leg_traffic(leg, batch_scale=1.0):
     try:
         t = json.load(open(tpath)).get("legs", {}).get(leg)
         alg = ALGORITHMIC_BYTES[leg] * batch_scale
-        return {"hbm_bytes": t["hbm_bytes_per_unit"], "algorithmic_bytes": alg, "ratio": t["hbm_bytes_per_unit"] / alg,
+        # `steady` leaves out the set-up launches of the profiled run (parameter uploads, RNG fills, one-off packs: tools/summarize_pmc.py)
+        steady = t.get("steady_hbm_bytes_per_unit", t["hbm_bytes_per_unit"])
+        return {"hbm_bytes": steady, "algorithmic_bytes": alg, "ratio": steady / alg, "hbm_bytes_incl_setup_of_the_profiled_run": t["hbm_bytes_per_unit"],
                 "per": "UNet forward (B=16)" if leg.startswith("video") else "train step (B=64)", "source": "profiles/roofline_traffic.json"}
     except Exception:
         return None

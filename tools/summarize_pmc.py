@@ -28,11 +28,28 @@ def _units(leg):
     return None
 
 
+SETUP_NAMES = ("__amd_rocclr_", "at::native::", "pack_weight_kernel", "pack_weight_h_kernel")
+
+
+def _steady(kernels, units):
+    """HBM bytes per unit of the REPEATING part of a leg: a profiled run also holds the model set-up (parameter uploads, RNG fills,
+    one-off single-tensor packs, the first build of the pack tables), which `hbm_bytes_per_unit` = whole run / units charges to the
+    steps.  A kernel counts with floor(launches / units) launches per unit; kernels that only set up (by name) count zero."""
+    tot = 0.0
+    for k, v in kernels.items():
+        if any(k.startswith(n) for n in SETUP_NAMES):
+            continue
+        tot += v.get("hbm_bytes_per_launch_corrected", 0.0) * (v.get("n", 0) // units)
+    return tot
+
+
 for leg in ("policy", "video", "video_bf16"):
     if FROM_SUMMARY is not None:
         out[leg] = FROM_SUMMARY[leg]
         if leg in FROM_SUMMARY.get("roofline_traffic", {}).get("legs", {}):
-            leg_totals[leg] = FROM_SUMMARY["roofline_traffic"]["legs"][leg]
+            leg_totals[leg] = dict(FROM_SUMMARY["roofline_traffic"]["legs"][leg])
+            if "steady_hbm_bytes_per_unit" not in leg_totals[leg]:       # from the 40 largest kernels the summary kept
+                leg_totals[leg]["steady_hbm_bytes_per_unit"] = _steady(out[leg], leg_totals[leg]["units_in_run"])
         continue
     res = defaultdict(lambda: {"n": 0})
     tot = {"fetch": 0.0, "write": 0.0}
@@ -59,7 +76,8 @@ for leg in ("policy", "video", "video_bf16"):
     u = _units(leg)
     if u:       # whole-leg HBM bytes per step / per UNet forward: every kernel of the run, same correction
         leg_totals[leg] = {"units_in_run": u, "hbm_bytes_per_unit": (2.0 * tot["fetch"] + tot["write"]) * 1024.0 / u,
-                           "fetch_bytes_per_unit": 2.0 * tot["fetch"] * 1024.0 / u, "write_bytes_per_unit": tot["write"] * 1024.0 / u}
+                           "fetch_bytes_per_unit": 2.0 * tot["fetch"] * 1024.0 / u, "write_bytes_per_unit": tot["write"] * 1024.0 / u,
+                           "steady_hbm_bytes_per_unit": _steady(res, u)}
 # bench.py reads profiles/roofline_traffic.json: {"policy"|"video": {"<kernel><BM,BN>": corrected HBM bytes per launch}}
 import re
 rt = {}
