@@ -646,6 +646,20 @@ __global__ __launch_bounds__(64) void gn_wave_fwd(const GnDesc p) {
     const int n = wv / p.G, g = wv - n * p.G;
     const int C = p.C, epl = (p.S * CG) >> 6;
     const size_t base = (size_t)n * p.S * C + (size_t)g * CG;
+    // every load that does not depend on the statistics goes out BEFORE the gather (whose slab loop ends in a wait): the launch is a
+    // chain of memory round trips on one wave per SIMD, and this way the affine / residual / FiLM operands travel with the first of them
+    float gmv[MAXE], btv[MAXE], rsd[MAXE], f0[MAXE], f1[MAXE];
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        gmv[j] = btv[j] = rsd[j] = f0[j] = f1[j] = 0.f;
+        if (j < epl) {
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            gmv[j] = p.gamma[c];
+            btv[j] = p.beta[c];
+            if (p.residual) rsd[j] = p.residual[base + (size_t)row * C + cc];
+            if (p.film) { f0[j] = p.film[(size_t)n * p.film_ld + c]; f1[j] = p.film[(size_t)n * p.film_ld + C + c]; }
+        }
+    }
     float v[MAXE];
     gn_wave_gather<CG, MAXE>(p, p.x, base, g, lane, epl, v);
     float s = 0.f;
@@ -662,12 +676,12 @@ __global__ __launch_bounds__(64) void gn_wave_fwd(const GnDesc p) {
 #pragma unroll
     for (int j = 0; j < MAXE; ++j)
         if (j < epl) {
-            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG;
             const size_t off = base + (size_t)row * C + cc;
-            float z = (v[j] - mu) * rs * p.gamma[c] + p.beta[c];
-            if (p.residual) z += p.residual[off];
+            float z = (v[j] - mu) * rs * gmv[j] + btv[j];
+            if (p.residual) z += rsd[j];
             float a = act_fwd(z, p.act);
-            if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
+            if (p.film) a = f0[j] * a + f1[j];
             p.y[off] = a;
             if (p.yh) p.yh[off] = gn_f2bf(a);
         }
@@ -684,6 +698,21 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
     const float mu = p.mean[wv], rs = p.rstd[wv];
     const bool film = p.film != nullptr;
     float xh[MAXE], dz[MAXE], dov[MAXE];
+    // the saved input, the affine / residual / FiLM operands: requested ahead of the gather of dout (see gn_wave_fwd)
+    float xv[MAXE], gmv[MAXE], btv[MAXE], rsd[MAXE], f0[MAXE];
+#pragma unroll
+    for (int j = 0; j < MAXE; ++j) {
+        xv[j] = gmv[j] = btv[j] = rsd[j] = f0[j] = 0.f;
+        if (j < epl) {
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            const size_t off = base + (size_t)row * C + cc;
+            xv[j] = p.x[off];
+            gmv[j] = p.gamma[c];
+            btv[j] = p.beta[c];
+            if (p.residual) rsd[j] = p.residual[off];
+            if (film) f0[j] = p.film[(size_t)n * p.film_ld + c];
+        }
+    }
     gn_wave_gather<CG, MAXE>(p, p.dout, base, g, lane, epl, dov);
     float c0[NCOL], c1[NCOL], c2[NCOL], c3[NCOL];
 #pragma unroll
@@ -693,18 +722,16 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
     for (int j = 0; j < MAXE; ++j) {
         xh[j] = dz[j] = 0.f;
         if (j < epl) {
-            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
-            const size_t off = base + (size_t)row * C + cc;
-            const float h = (p.x[off] - mu) * rs;
-            const float gm = p.gamma[c];
-            float z = h * gm + p.beta[c];
-            if (p.residual) z += p.residual[off];
+            const float h = (xv[j] - mu) * rs;
+            const float gm = gmv[j];
+            float z = h * gm + btv[j];
+            if (p.residual) z += rsd[j];
             const float dout = dov[j];
             float da = dout;
             const int k = CG >= 64 ? (j % NCOL) : 0;
             if (film) {
                 const float a = act_fwd(z, p.act);
-                da = dout * p.film[(size_t)n * p.film_ld + c];
+                da = dout * f0[j];
                 c2[k] += dout * a;
                 c3[k] += dout;
             }
@@ -723,9 +750,9 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
 #pragma unroll
     for (int j = 0; j < MAXE; ++j)
         if (j < epl) {
-            const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
+            const int i = lane + 64 * j, row = i / CG, cc = i % CG;
             const size_t off = base + (size_t)row * C + cc;
-            const float dxv = rs * (p.gamma[c] * dz[j] - (A1 + xh[j] * A2) * inv);
+            const float dxv = rs * (gmv[j] * dz[j] - (A1 + xh[j] * A2) * inv);
             p.y[off] = dxv;
             if (p.yh) p.yh[off] = gn_f2bf(dxv);
             if (p.dres) p.dres[off] = dz[j];

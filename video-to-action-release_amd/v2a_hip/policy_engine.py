@@ -29,6 +29,8 @@ def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
     return torch.cumprod(1.0 - betas, dim=0)
 
 
+_GN_DEFER = __import__('os').environ.get('V2A_GN_DEFER', '1') != '0'      # 0: every conv runs its own split-K reduce (A/B)
+
 class _Conv:
     """One conv / linear / transposed-conv parameter pair and its packed operands."""
 
@@ -479,7 +481,7 @@ class PolicyEngine:
 
     def _defer_ok(self, rows, C, G):
         """May a conv whose [N, rows, C] output feeds GroupNorm(G) directly leave its split-K reduce to that launch?"""
-        return ops.gn_takes_slabs(rows, C, G)
+        return _GN_DEFER and ops.gn_takes_slabs(rows, C, G)
 
     def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None, dslabs=None, keep_dout=False, want_twin=False):
         """dslabs: dout4 is the not-yet-reduced output of a data-gradient conv (ops.Slabs); keep_dout: other launches read dout4 later,
