@@ -44,3 +44,21 @@ for N, S, C, G, act in SHAPES:
     tb = timeit(lambda: ops.groupnorm_bwd(x, g, b, G, dout, mean, rstd, act=act))
     mb = x.numel() * 4 / 1e6
     print(f"N={N} S={S:5d} C={C:5d} G={G:3d} E={S*C//G:6d} {act}: tensor {mb:6.2f} MB  fwd {tf:6.1f} us ({2*mb/tf/1e0:7.1f} GB/s... {2*mb/tf*1e-3:5.2f} TB/s)  bwd {tb:6.1f} us ({3*mb/tb*1e-3:5.2f} TB/s)", flush=True)
+
+print("--- backward with the producing conv's split-K slabs folded in (what the train step launches)")
+for N, S, C, G, act in [(64, 64, 256, 16, "relu"), (64, 16, 512, 32, "relu"), (64, 16, 256, 8, "mish"), (64, 256, 128, 8, "relu"), (64, 1024, 64, 4, "relu")]:
+    x = torch.randn(N, S, C, device=dev)
+    g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    res = torch.randn(N, S, C, device=dev)
+    y, mean, rstd = ops.groupnorm_fwd(x, g, b, G, act, residual=res)
+    cs = torch.empty((N, 2, C), device=dev)
+    for nslab in (0, 2, 4, 8):
+        ws = torch.randn(max(nslab, 1), N * S * C, device=dev)
+        dsum = torch.empty(N, S, C, device=dev)
+        sl = ops.Slabs(ws, nslab, N * S * C, None, None) if nslab else None
+        dout = ws[0].view(N, S, C)
+        for with_res in (False, True):
+            fn = lambda: ops.groupnorm_bwd(x, g, b, G, dout, mean, rstd, act, residual=res if with_res else None, want_dres=with_res,
+                                           colsum=cs, defer_params=True, dout_slabs=sl, dout_sum=dsum if sl is not None else None)
+            t = timeit(fn)
+            print(f"N={N} S={S:5d} C={C:5d} G={G:3d} nslab={nslab} residual={int(with_res)}: bwd {t:6.1f} us", flush=True)
