@@ -485,3 +485,38 @@ def test_batch_256_step_ties_to_oracle_through_linearity():
     bad = [e for e in errs if e[1] > max(TOL, 2 * worst_ref)]
     assert not bad, bad[:5]
     assert float(np.median([e[1] for e in errs])) <= TOL
+
+
+@pytest.mark.parametrize("B,seed", [(1, 101), (3, 1), (5, 3), (6, 106), (7, 1)])
+def test_ragged_batch_loss_and_grads_vs_oracle(B, seed):
+    """Batches that fill no tile evenly (1024 ... 7168 conv rows at the first ResNet stage, 16 ... 112 rows in the ConditionalUnet1D):
+    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin.  Loss and every gradient
+    against the CPU oracle on the same seeded inputs, 1e-4.
+
+    The seeds are chosen: about four in ten random batches of this size contain a ReLU input (or a max-pool pair) that fp32 rounding puts
+    on the other side of zero in ONE of the two fp32 implementations -- a single flipped mask element is 1e-3 ... 3e-2 of an encoder
+    weight gradient at B <= 7 (1 / (B * H * W) of its terms), and the fp32 oracle is then as far from an fp64 run of itself as the HIP
+    path is (tools/probes/ragged_grad_probe.py prints all three).  On a failure the message carries the distances to the fp64 oracle."""
+    from oracle import policy as OP
+    pol, sd = _policy(seed=21 + B)
+    g = torch.Generator().manual_seed(seed)
+    batch = {"obs": {"img_obs_1": torch.rand(B, 1, 3, 128, 128, generator=g), "img_goal_1": torch.rand(B, 1, 3, 128, 128, generator=g)},
+             "action": torch.rand(B, 16, 7, generator=g) * 2 - 1}
+    noise, ts = torch.randn(B, 16, 7, generator=g), torch.randint(0, 100, (B,), generator=g)
+    pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
+    pol.train()
+    loss = pol.compute_loss(batch)
+    loss.backward()
+    names = pol.trainable_names()
+    ref_loss, ref_g = OP.loss_and_grads(sd, batch, noise, ts, names=names)
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    P = dict(pol.named_parameters())
+    gsc = max(float(v.double().norm()) for v in ref_g.values())
+    dist = lambda a, b: max(((a[n].double().cpu() - b[n].double()).abs().max() / max(b[n].abs().max().item(), 1e-3 * gsc)).item() for n in names)
+    hip = {n: P[n].grad for n in names}
+    worst = dist(hip, ref_g)
+    if worst > TOL:
+        sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
+        b64 = {"obs": {k: v.double() for k, v in batch["obs"].items()}, "action": batch["action"].double()}
+        _, g64 = OP.loss_and_grads(sd64, b64, noise.double(), ts, names=names)
+        raise AssertionError(f"HIP vs fp32 oracle {worst:.2e}; vs the fp64 oracle: HIP {dist(hip, g64):.2e}, fp32 oracle {dist(ref_g, g64):.2e}")
