@@ -520,3 +520,21 @@ def test_ragged_batch_loss_and_grads_vs_oracle(B, seed):
         b64 = {"obs": {k: v.double() for k, v in batch["obs"].items()}, "action": batch["action"].double()}
         _, g64 = OP.loss_and_grads(sd64, b64, noise.double(), ts, names=names)
         raise AssertionError(f"HIP vs fp32 oracle {worst:.2e}; vs the fp64 oracle: HIP {dist(hip, g64):.2e}, fp32 oracle {dist(ref_g, g64):.2e}")
+
+
+@pytest.mark.parametrize("B", [1, 5, 9])
+def test_predict_action_ragged_batches_vs_oracle(B):
+    """DDIM-8 inference at batch sizes the fixture (B = 2) does not hold, through the graphed inference path when it applies: the action
+    trajectory against the CPU oracle on the same injected noise."""
+    from oracle import policy as OP
+    pol, sd = _policy(seed=31 + B)
+    pol.eval()
+    g = torch.Generator().manual_seed(200 + B)
+    obs = {"img_obs_1": torch.rand(B, 1, 3, 128, 128, generator=g), "img_goal_1": torch.rand(B, 1, 3, 128, 128, generator=g)}
+    init = torch.randn(B, 16, 7, generator=g)
+    pol.__dict__["_rng_hook"] = lambda shape, kind: init
+    out = pol.predict_action(obs, use_ddim=True)
+    ref = OP.predict_action(sd, obs, init, [], use_ddim=True)
+    assert out["action_pred"].shape == (B, 16, 7) and out["action"].shape == (B, 8, 7)
+    assert rel(out["action_pred"], ref["action_pred"]) <= TOL, rel(out["action_pred"], ref["action_pred"])
+    assert rel(out["action"], ref["action"]) <= TOL
