@@ -203,3 +203,16 @@ def test_capacity_eviction_before_max_episodes_warns():
             st.add_one_episode("t", "cam", i, imgs, acts)
     assert len(st) == 2 and st.capacity_evictions == 2
     assert sum(issubclass(x.category, RuntimeWarning) and "evicting the oldest by capacity" in str(x.message) for x in w) == 1
+
+
+def test_sampling_an_empty_buffer_raises_what_numpy_raises():
+    """Global_EnvReplayBuffer_Img.sample_random_batch_seq on an empty buffer fails inside np.random.randint(0, 0, size=B)
+    (env_img_replay_buffer.py:93) with ValueError; the index sampler raises the same error type and leaves the generators untouched."""
+    import random
+    from v2a_hip import replay
+    np.random.seed(5)
+    random.seed(5)
+    s0, p0 = np.random.get_state()[1].copy(), random.getstate()
+    with pytest.raises(ValueError):
+        replay.sample_indices(np.array([], dtype=np.int32), 4, 16)
+    assert (np.random.get_state()[1] == s0).all() and random.getstate() == p0

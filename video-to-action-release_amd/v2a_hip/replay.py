@@ -38,6 +38,8 @@ def _set_py_state(arr, st):
 
 def sample_indices(episode_len: np.ndarray, batch: int, act_len: int):
     """One sample_random_batch_seq worth of draws from the live generators.  Returns (episode[B], start[B]) int64."""
+    if len(episode_len) == 0:
+        raise ValueError("high <= 0")      # np.random.randint(0, 0, size=B) in the reference (env_img_replay_buffer.py:93): empty buffer
     npa, nps = _get_np_state()
     pya, pys = _get_py_state()
     el = np.ascontiguousarray(episode_len, dtype=np.int32)
