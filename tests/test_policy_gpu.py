@@ -138,8 +138,10 @@ def test_three_train_steps_vs_golden(golden_dir):
     assert np.max(np.abs(en - g["train_ema_norms"]) / (g["train_ema_norms"] + 1e-3)) <= 1e-4
 
 
-def test_trainer_graph_replay_matches_eager():
-    """PolicyTrainer: the captured hipGraph step must produce the same parameters as the eager step (same seeds)."""
+@pytest.mark.parametrize("batch", [8, 5])
+def test_trainer_graph_replay_matches_eager(batch):
+    """PolicyTrainer: the captured hipGraph step must produce the same parameters as the eager step (same seeds); also at a batch size
+    that fills no tile evenly."""
     import random
     from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
     from v2a_hip.replay import ReplayStore
@@ -155,7 +157,7 @@ def test_trainer_graph_replay_matches_eager():
             store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
                                   torch.rand(n - 1, 7, generator=gen) * 2 - 1)
         np.random.seed(5); random.seed(5)
-        tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=use_graph)
+        tr = PolicyTrainer(pol, store, batch_size=batch, seed=11, use_graph=use_graph)
         losses = [tr.step().item() for _ in range(5)]
         res.append((losses, [p.detach().double().norm().item() for p in pol.parameters()]))
     # every reduction of the step has a fixed summation order (no float atomics: csrc/norm.hip), and the captured graph launches the
