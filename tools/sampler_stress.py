@@ -10,7 +10,7 @@ import v2a_hip
 from flowdiffusion.flowdiffusion.unet import Unet_Libero
 from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
 
-v2a_hip.set_video_storage("bf16")
+v2a_hip.set_video_storage(sys.argv[2] if len(sys.argv) > 2 else "bf16")      # usage: sampler_stress.py [steps] [bf16|fp16|f32]
 dev = "cuda:0"
 torch.manual_seed(0)
 m = Unet_Libero().to(dev).eval()
