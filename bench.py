@@ -41,7 +41,8 @@ def _traffic(leg, kernel):
 # elements per sample, s bytes per element); policy per step at B = 64, fp32 = 64 B * 87,219,143 parameters + 3 * 3.326 M * 64 * 4
 TRAFFIC_SOURCE = ("profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a separate run (tools/profile_round.sh), "
                   "NOT measured inside this bench run")
-ALGORITHMIC_BYTES = {"video": 201087649 * 4 + 16 * 1.816e9 * 4, "video_bf16": 201087649 * 2 + 16 * 1.816e9 * 2, "policy": 8.13e9}
+ALGORITHMIC_BYTES = {"video": 201087649 * 4 + 16 * 1.816e9 * 4, "video_bf16": 201087649 * 2 + 16 * 1.816e9 * 2, "policy": 8.13e9,
+                     "policy_bf16": 8.13e9}          # the bf16-MFMA policy mode keeps fp32 tensors in HBM: same algorithmic bytes
 
 
 def _leg_traffic(leg, batch_scale=1.0):
@@ -767,7 +768,9 @@ def main():
                            "roofline": {"kernel": "whole captured step (HBM-bound leg: no single kernel dominates)", "bound": "hbm",
                                         "achieved": alg_bytes / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": alg_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_bytes,
-                                        "traffic": None, "traffic_source": None,
+                                        "traffic": (_leg_traffic("policy_bf16") or {}).get("hbm_bytes") if args.batch == 64 else None,
+                                        "traffic_source": TRAFFIC_SOURCE if (args.batch == 64 and _leg_traffic("policy_bf16")) else None,
+                                        "traffic_vs_algorithmic": _leg_traffic("policy_bf16") if args.batch == 64 else None,
                                         "mfma_floor_ms": 8.722e9 * args.batch / (BF16_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                                         "hbm_floor_ms": alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3},
                            "note": "performance configuration (what BASELINE configs[1] names); parity (1e-4) is claimed for the fp32 run only"}

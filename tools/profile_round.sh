@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/video_bf16 -o video
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/policy_bf16 -o policy -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --precision bf16 > $OUT/policy_bf16_bench.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_policy -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph > $OUT/pmc_fetch_policy.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_policy -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph > $OUT/pmc_write_policy.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_policy_bf16 -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph --precision bf16 > $OUT/pmc_fetch_policy_bf16.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_policy_bf16 -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph --precision bf16 > $OUT/pmc_write_policy_bf16.log 2>&1
 V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_video -o pmc -- python $R/tools/video_only.py --steps 1 > $OUT/pmc_fetch_video.log 2>&1
 V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_video -o pmc -- python $R/tools/video_only.py --steps 1 > $OUT/pmc_write_video.log 2>&1
 V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_video_bf16 -o pmc -- python $R/tools/video_only.py --steps 1 --storage bf16 > $OUT/pmc_fetch_video_bf16.log 2>&1

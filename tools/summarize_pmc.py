@@ -43,8 +43,11 @@ def _steady(kernels, units):
     return tot
 
 
-for leg in ("policy", "video", "video_bf16"):
+for leg in ("policy", "policy_bf16", "video", "video_bf16"):
     if FROM_SUMMARY is not None:
+        if leg not in FROM_SUMMARY:
+            out[leg] = {}
+            continue
         out[leg] = FROM_SUMMARY[leg]
         if leg in FROM_SUMMARY.get("roofline_traffic", {}).get("legs", {}):
             leg_totals[leg] = dict(FROM_SUMMARY["roofline_traffic"]["legs"][leg])
@@ -81,7 +84,7 @@ for leg in ("policy", "video", "video_bf16"):
 # bench.py reads profiles/roofline_traffic.json: {"policy"|"video": {"<kernel><BM,BN>": corrected HBM bytes per launch}}
 import re
 rt = {}
-for leg_name in ("policy", "video", "video_bf16"):
+for leg_name in ("policy", "policy_bf16", "video", "video_bf16"):
     traffic = {}
     for k, v in out[leg_name].items():
         m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
