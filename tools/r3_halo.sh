@@ -4,15 +4,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for cfg in ${CFGS:-base:}; do
   name=${cfg%%:*}; envs=${cfg#*:}
   echo "== $name ($envs)"
-  L=video-to-action-release_amd/v2a_hip
-  [ -f $L/libv2a_hip_main.so ] || cp $L/libv2a_hip.so $L/libv2a_hip_main.so
-  case "$envs" in *ALT=1*) cp $L/libv2a_hip_noperm.so $L/libv2a_hip.so;; *) cp $L/libv2a_hip_main.so $L/libv2a_hip.so;; esac
   env $(echo $envs | tr ',' ' ') timeout 300 python tools/probes/halo_probe.py 2>&1 | grep -v amdgpu.ids
 done
 if [ -n "$PMC" ]; then
   export TMPDIR=/tmp; cd /tmp
   OUT=$R/gpurun_out/pmc_halo; rm -rf $OUT; mkdir -p $OUT
-  case "$PMC_ENV" in *ALT=1*) cp $R/video-to-action-release_amd/v2a_hip/libv2a_hip_noperm.so $R/video-to-action-release_amd/v2a_hip/libv2a_hip.so;; esac
   env $(echo $PMC_ENV | tr ',' ' ') timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/a -o pmc -- python $R/tools/probes/halo_probe.py pmc > $OUT/a.log 2>&1
   python - <<PY
 import csv, glob, collections
