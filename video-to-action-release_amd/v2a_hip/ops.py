@@ -563,6 +563,16 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
 _GN_FUSE = os.environ.get('V2A_GN_FUSE', '1') != '0'
 
 
+_GN_FUSE_MAX_REPEAT = int(os.environ.get('V2A_GN_FUSE_MAX_REPEAT', '2'))
+
+
+def gn_fuse_pays(Cout):
+    """Is folding the GroupNorm into the halo conv's loader faster than apply pass + plain conv?  Every output-channel tile of the
+    kernel normalises the input halo again: with three or more 128-wide tiles (Cout = 384, 640 -> the 512 x 128 instance) it is not
+    (32 x 32 x 384: 289 vs 308 us; 768 -> 384: 548 vs 575 us; sampler +0.7 %)."""
+    return Cout % 256 == 0 or Cout // 128 <= _GN_FUSE_MAX_REPEAT
+
+
 def gn_fusable(N, H, W, C, Cout, KH, KW, stride, pad, ups):
     """True when a GroupNorm + activation in front of this conv can run inside the halo kernel (v2a_conv2d_fwd_h3_gn)."""
     return bool(_GN_FUSE and not ups and C <= 1024 and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")

@@ -161,6 +161,7 @@ class UNetEngine:
         if isinstance(x, _LazyGN):
             assert x2 is None
             if (not sp_f32 and not x.frames_separate
+                    and ops.gn_fuse_pays(cout)
                     and ops.gn_fusable(B * Fr, H, W, C, cout, k, k, (stride, stride), (k // 2, k // 2), ups)):
                 pre_gn = x.pending                       # normalised inside the halo conv: the GroupNorm apply pass never runs
                 x4 = pre_gn.x.view(B * Fr, H, W, pre_gn.C1)
