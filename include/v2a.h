@@ -206,6 +206,9 @@ int v2a_video_loss_bwd(const float* out_cl, const float* img, const float* noise
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
+int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
+int v2a_debug_f32p(int on, int s128, int s64);   /* tuning aid: pipelined exact-f32 conv kernel on/off (default on), LDS stages of its 128x128 / 64x64 tiles; returns the old `on` */
+int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words);   /* measurement aid: following conv_igemm_h launches stamp their phases per workgroup ([wg][8] x 100 MHz ticks), buf advances by stride_words per launch; null = off */
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */
 
 /* ---------------------------------------------------------------------------------------------- attention (csrc/attention.hip) */
@@ -313,11 +316,13 @@ int v2a_groupnorm_fwd_h(const void* x, const void* x2, int C1, const float* gamm
                         size_t workspace_bytes, v2a_stream_t s);
 int v2a_attention_fwd_h(const void* qkv, void* out, int n_frames, int L, int heads, int head_ch, v2a_stream_t s);
 int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, v2a_stream_t s);   /* [Cout][Cin][taps] f32 -> [Cout][taps][Cin] bf16 */
-int v2a_cast_f32_bf16(const float* x, void* y, size_t n, v2a_stream_t s);
+int v2a_cast_f32_bf16(const float* x, void* y, size_t n, v2a_stream_t s);   /* always bf16 (independent of v2a_set_half_format) */
+int v2a_cast_f32_h(const float* x, void* y, size_t n, int f16, v2a_stream_t s);   /* explicit 16-bit format: 0 bf16, 1 IEEE fp16 */
 /* fp32 [M][Cin] -> bf16 [M][Cpad] with zero channels behind Cin: the 6-channel stem input of Unet_Libero (unet.py:195-222) padded to
    one 32-channel chunk of the bf16 conv kernels */
 int v2a_pad_cast_f32_bf16(const float* x, void* y, size_t M, int Cin, int Cpad, v2a_stream_t s);
-int v2a_cast_bf16_f32(const void* x, float* y, size_t n, v2a_stream_t s);
+int v2a_cast_bf16_f32(const void* x, float* y, size_t n, v2a_stream_t s);   /* always bf16 */
+int v2a_cast_h_f32(const void* x, float* y, size_t n, int f16, v2a_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------- optimiser (csrc/optim.hip)
  * clip_grad_norm_(1.0) -> AdamW.step -> zero_grad -> EMA.update  (diffuser/libero/lb_online_trainer_v7.py:604-624;

@@ -3,7 +3,7 @@ V2A_TSTAMP=1 makes the engine drop wall-clock probes (one-lane kernels) at its p
 Usage (GPU box): V2A_TSTAMP=1 python tools/phase_clock.py [fp32|bf16] [batch]"""
 import os
 import sys
-os.environ["V2A_TSTAMP"] = "1"
+os.environ.setdefault("V2A_TSTAMP", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
@@ -25,6 +25,8 @@ dev = "cuda:0"
 pol = build_policy(DEFAULT_CONF).to(dev)
 store = bench.build_store(torch, dev, B, seed=100)
 tr = PolicyTrainer(pol, store, batch_size=B, seed=0, use_graph=True)
+if os.environ.get("V2A_PRIO") == "1":          # experiment: the whole step on a high-priority stream, weight-gradient branches at normal priority
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 for _ in range(6):
     tr.step()
 torch.cuda.synchronize()

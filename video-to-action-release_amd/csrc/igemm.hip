@@ -451,6 +451,181 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvDesc p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 by three bf16 planes
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): both differences are exact in fp32, so the three
+// planes carry 24 significant bits.  a * b is then summed from the six plane products whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi,
+// hi*lo, lo*hi, mid*mid; the three dropped ones are <= 2^-24 |a||b|, the size of one fp32 rounding), each exact in the bf16 MFMA's fp32
+// accumulation, smallest first.  Six v_mfma_f32_32x32x16_bf16 (192 cycles per 32x32x16 block) replace eight v_mfma_f32_32x32x2_f32 (512).
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = v2a_pack_bf16x2(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = v2a_pack_bf16x2(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = v2a_pack_bf16x2(s0, s1);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvDesc p) {
+    constexpr int BKT = 32, KC = 8, RPP = 32, LDH = 40;         // 40 halves = 80-B rows
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int AL = BM / RPP, BL = BN / RPP;
+    constexpr int PA = BM * LDH, PB = BN * LDH;                 // halves per plane
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 3 * (PA + PB)];
+    constexpr int STG = 3 * (PA + PB);                            // halves per stage: A planes (hi, mid, lo), then B planes
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nkt = (p.K + BKT - 1) / BKT;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    const int lrow = tid / KC, chunk = tid % KC;
+    int a_ihb[AL], a_iwb[AL], a_img[AL];
+    bool a_ok[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        int m = m0 + lrow + i * RPP;
+        a_ok[i] = m < p.M;
+        int mm = a_ok[i] ? m : 0;
+        int ow = mm % p.OW;
+        int t = mm / p.OW;
+        int oh = t % p.OH;
+        a_img[i] = t / p.OH;
+        a_ihb[i] = oh * p.sh - p.ph;
+        a_iwb[i] = ow * p.sw - p.pw;
+    }
+    f32x4 ra[AL], rb[BL];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BKT;
+        const int tap = k0 / Cin;
+        const int c = k0 - tap * Cin + chunk * 4;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
+            bool ok = a_ok[i] && ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+            if (p.idil > 1) {
+                ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                ih /= p.idil;
+                iw /= p.idil;
+            }
+            if (p.ups) { ih >>= 1; iw >>= 1; }
+            const size_t pix = ((size_t)a_img[i] * p.H + ih) * p.W + iw;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float* src = (c < p.C1) ? p.x + pix * p.C1 + c : p.x2 + pix * p.C2 + (c - p.C1);
+                v = *reinterpret_cast<const f32x4*>(src);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            int n = n0 + lrow + i * RPP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k0 + chunk * 4);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        uint16_t* A = smem + buf * STG;
+        uint16_t* B = A + 3 * PA;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair(ra[i][0], ra[i][1], h0, m0_, l0);
+            split3_pair(ra[i][2], ra[i][3], h1, m1, l1);
+            const int o = (lrow + i * RPP) * LDH + chunk * 4;
+            *reinterpret_cast<uint2*>(&A[o]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(&A[PA + o]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(&A[2 * PA + o]) = uint2{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair(rb[i][0], rb[i][1], h0, m0_, l0);
+            split3_pair(rb[i][2], rb[i][3], h1, m1, l1);
+            const int o = (lrow + i * RPP) * LDH + chunk * 4;
+            *reinterpret_cast<uint2*>(&B[o]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(&B[PB + o]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(&B[2 * PB + o]) = uint2{l0, l1};
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+        const uint16_t* A = smem + buf * STG;
+        const uint16_t* B = A + 3 * PA;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8*>(&A[q * PA + (wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8*>(&B[q * PB + (wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);     // lo  * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);     // hi  * lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // mid * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);     // mid * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);     // hi  * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);     // hi  * hi
+                    acc[i][j] = c;
+                }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 32 + lr;
+            if (n >= p.Cout) continue;
+            const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.splitk > 1) {
+                    p.partial[((size_t)split * p.M + m) * p.Cout + n] = v;
+                } else {
+                    v += bv;
+                    if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
+                    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                    if (p.y2 && n >= p.csplit) p.y2[(size_t)m * (p.Cout - p.csplit) + (n - p.csplit)] = v;
+                    else p.y[(size_t)m * (p.y2 ? p.csplit : p.Cout) + n] = v;
+                }
+            }
+        }
+}
+
 // y[m][n] = sum_s partial[s][m][n] + bias + rowvec + residual   (split-K second pass)
 __global__ void conv_splitk_reduce(const ConvDesc p) {
     const size_t total = (size_t)p.M * p.Cout;
@@ -1828,7 +2003,7 @@ extern "C" {
 // process-wide MFMA precision of the contraction kernels (0 = f32 exact, 1 = bf16 inputs / f32 accumulate); returns the old value
 int v2a_set_precision(int mode) {
     int old = g_precision;
-    if (mode == 0 || mode == 1) g_precision = mode;
+    if (mode == 0 || mode == 1 || mode == 2) g_precision = mode;      // 2: experiment -- fp32 products from three bf16 planes (conv_igemm_bf16x3)
     return old;
 }
 int v2a_get_precision(void) { return g_precision; }
@@ -1910,6 +2085,22 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     p.splitk = s;
     p.ktiles_per_split = cdiv(nkt, s);
     dim3 grid(tiles, s), block(256);
+    if (g_precision == 2 && vec && Cin % 32 == 0 && !p.bmode) {     // experiment: fp32 by three bf16 planes
+        p.splitk = s;
+        p.ktiles_per_split = cdiv(cdiv(p.K, 32), s);
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128>), grid, block, 0, stream, p);
+        else if (bm == 128) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 64>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64>), grid, block, 0, stream, p);
+        V2A_CHECK_LAUNCH();
+        if (s > 1) {
+            size_t total = (size_t)p.M * Cout;
+            int g = (int)((total + 255) / 256);
+            if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(conv_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
+            V2A_CHECK_LAUNCH();
+        }
+        return V2A_OK;
+    }
     if (g_precision == 1 && vec && Cin % 32 == 0 && !p.bmode) {     // bf16 MFMA (data gradients then use the flipped pack, bmode 0)
         p.splitk = s;
         p.ktiles_per_split = cdiv(cdiv(p.K, 32), s);

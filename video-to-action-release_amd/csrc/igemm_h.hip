@@ -67,7 +67,12 @@ struct ConvDescH {
     int idil;                 // input dilation 1 | 2 (strided data gradient / transposed conv): logical input = zero-interleaved x
     int frame_tiles;          // > 0: frame-interleaved tile order for (3 x 1) convs, = tiles per frame (OW / BM); 0: row order
     FastDivH fd_ow, fd_oh;
+    const void* w2;           // second weight set (rows >= m_split) or null       [conv_igemm_f32p only]
+    const float* bias2;       // second bias (rows >= m_split) or null
+    int m_split;              // first output row of the second set (a multiple of every row tile); INT_MAX: one set
+    unsigned long long* tstamps;   // measurement aid (v2a_debug_conv_stamps): [workgroup][8] wall-clock stamps of the kernel's phases, or null
 };
+#define V2A_STAMP(i) do { if (p.tstamps && threadIdx.x == 0) p.tstamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ int xcd_remap_h(int bid, int nblk) {
     int q = nblk >> 3, r = nblk & 7;
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * BUF];      // ONE LDS object (A0 B0 [A1 B1])
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    V2A_STAMP(0);
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
@@ -239,10 +245,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     };
     if constexpr (STAGES == 2) {
         if (kt_begin < kt_end) issue(0);
+        V2A_STAMP(1);
         int buf = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                        // tile kt landed everywhere; everyone is done reading the other buffer
+            if (kt == kt_begin) V2A_STAMP(2);
             if (kt + 1 < kt_end) issue(buf ^ 1);
             compute(smem + buf * BUF);
             buf ^= 1;
@@ -250,8 +258,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     } else {
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             issue(0);
+            if (kt == kt_begin) V2A_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                        // tile kt landed everywhere
+            if (kt == kt_begin) V2A_STAMP(2);
             compute(smem);
             __syncthreads();                        // everyone is done reading before the next tile overwrites the buffer
         }
@@ -262,6 +272,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     // bias / embedding vector / residual are applied on 8-wide vectors and the result leaves as one 16-B bf16 store (a full
     // 128-B line per row and wave) instead of 2-byte scatters.
     __syncthreads();
+    V2A_STAMP(3);
     constexpr int LDC = WN;                                       // floats per parked row; columns XOR-ed with 4 * (row & 1) so that
     static_assert(4 * 32 * LDC * 4 <= STAGES * BUF, "epilogue staging exceeds the operand buffers");   // the b128 read-back is conflict-free
     float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;  // one 32-row sub-tile of this wave at a time (wave-private region)
@@ -374,6 +385,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
             }
         }
     }
+    V2A_STAMP(4);
+    if (p.tstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); V2A_STAMP(5); }     // stores acknowledged
     if (p.stats && p.splitk == 1 && vec_ok) {
         // this wave's 64 rows x 64 channels: lanes with equal lane % V hold the same 8 channels for different rows
 #pragma unroll
@@ -395,6 +408,566 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
             *reinterpret_cast<f32x4*>(dst + p.Cout + 4) = q1;
         }
     }
+}
+
+// Epilogue of the fp32 instances (conv_igemm_f32p, conv_igemm_f32x3): each wave parks one 32-row sub-tile at a time in its own LDS
+// region (4 * 32 * BN/2 floats in all; the caller has drained every LDS user), then every lane owns 8 consecutive channels of a row --
+// split-K slab, or bias / row vector / residual and two 16-B stores -- and the per-64-row-block GroupNorm statistics.
+template <int BM, int BN>
+__device__ __forceinline__ void conv_f32_epilogue(const ConvDescH& p, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* smem, const int m0,
+                                                  const int n0, const int split, const float* bias_sel) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    constexpr int LDC = WN;
+    float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;
+    constexpr int V = WN / 8;
+    const int vrow = lane / V, vcol = (lane % V) * 8;
+    const int n = n0 + wn + vcol;
+    const bool vec_ok = (p.Cout % 8 == 0) && (n + 8 <= p.Cout);
+    float bv[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bv[e] = (bias_sel && p.splitk == 1 && n + e < p.Cout) ? bias_sel[n + e] : 0.f;
+        ssum[e] = 0.f;
+        ssq[e] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                cw[row * LDC + ((j * 32 + lr) ^ ((row & 1) << 2))] = acc[i][j][r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 64 / V) {
+            const int ml = rr + vrow;
+            const int m = m0 + wm + i * 32 + ml;
+            if (m >= p.M || n >= p.Cout) continue;
+            const int sx = (ml & 1) << 2;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + (vcol ^ sx)]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&cw[ml * LDC + ((vcol + 4) ^ sx)]);
+            float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            const size_t o = (size_t)m * p.Cout + n;
+            if (p.splitk > 1) {
+                float* dst = p.partial + (size_t)split * p.M * p.Cout + o;
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(dst) = c0;
+                    *reinterpret_cast<f32x4*>(dst + 4) = c1;
+                } else {
+                    for (int e = 0; e < 8 && n + e < p.Cout; ++e) dst[e] = v[e];
+                }
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            float* yo = reinterpret_cast<float*>(p.y);
+            if (vec_ok) {
+                if (p.rowvec) {
+                    const float* rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.Cout + n;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rv), r1 = *reinterpret_cast<const f32x4*>(rv + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                }
+                if (p.residual) {
+                    const float* rp = reinterpret_cast<const float*>(p.residual) + o;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[e + 4] += r1[e]; }
+                }
+                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(yo + o) = o0;
+                *reinterpret_cast<f32x4*>(yo + o + 4) = o1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+            } else {
+                for (int e = 0; e < 8 && n + e < p.Cout; ++e) {
+                    float t = v[e];
+                    if (p.rowvec) t += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n + e];
+                    if (p.residual) t += reinterpret_cast<const float*>(p.residual)[o + e];
+                    yo[o + e] = t;
+                }
+            }
+        }
+    }
+    V2A_STAMP(4);
+    if (p.tstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); V2A_STAMP(5); }
+    if (p.stats && p.splitk == 1 && vec_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = V; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
+        }
+        const int blk = (m0 + wm) >> 6;
+        if (lane < V && (m0 + wm) < p.M) {
+            float* dst = p.stats + (size_t)blk * 2 * p.Cout + n;
+            f32x4 a0 = {ssum[0], ssum[1], ssum[2], ssum[3]}, a1 = {ssum[4], ssum[5], ssum[6], ssum[7]};
+            f32x4 q0 = {ssq[0], ssq[1], ssq[2], ssq[3]}, q1 = {ssq[4], ssq[5], ssq[6], ssq[7]};
+            *reinterpret_cast<f32x4*>(dst) = a0;
+            *reinterpret_cast<f32x4*>(dst + 4) = a1;
+            *reinterpret_cast<f32x4*>(dst + p.Cout) = q0;
+            *reinterpret_cast<f32x4*>(dst + p.Cout + 4) = q1;
+        }
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_h() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- Pipelined exact-f32 instance (round 4).  In-kernel stamps of conv_igemm_h<.., float> (tools/probes/conv_stamp_probe.py) showed its
+// launches spend 1.3 us before the first DMA, 2.4 us in the epilogue -- and 45 us in a main loop whose MFMA work is 30.7 us: every k tile
+// (32 floats) pays `s_waitcnt vmcnt(0)` + `__syncthreads()` + a ~150-instruction DMA-issue block (address arithmetic, exec-masked selects,
+// scalar branches on p.ups / p.idil) during which the wave issues no MFMA, and co-resident workgroups fall into the same phase because they
+// alternate on the SIMD's matrix pipe.  v_mfma_f32_32x32x2_f32 occupies the pipe for 64 cycles per instruction, i.e. ~16 issue slots of
+// anything else are free per MFMA -- so here
+//   * the DMA of k tile t + S - 1 is issued IN PIECES between the MFMA groups of tile t (branch-free address arithmetic: the nearest-x2 /
+//     zero-interleave cases are a shift and a parity mask, the out-of-image select is a v_cndmask on the finished pointer),
+//   * S LDS stages with a COUNTED `s_waitcnt vmcnt((S-2) * pieces)` + one raw s_barrier per k tile (never drained: past the end of the
+//     slice the pieces read the zero line into a dead stage, so the count is a compile-time constant),
+//   * operand fragments of k-step h + 1 are read while the MFMAs of step h issue (register double buffer).
+// Same tiles, same LDS image (source-side swizzle), same k order per accumulator as conv_igemm_h<.., float>: results are bit-identical.
+// w2 / bias2 / m_split: output rows >= m_split use the second weight / bias set (the two camera encoders of the policy as ONE stacked
+// batch; m_split is a multiple of every row tile).
+// GEN = false: plain gather (no nearest-x2 upsample, no zero-interleaved input) -- a piece's offset is a per-thread constant plus a
+// per-tile SCALAR (no multiply in the loop); GEN = true: the general form.
+template <int BM, int BN, int S, int MINW, bool GEN>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) {
+    typedef float T;
+    constexpr int ROWB = 128, EPT = 32, EPC = 4;
+    constexpr int AL = BM / 32, BL = BN / 32, NL = AL + BL;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    static_assert((S - 2) * NL <= 63 && S >= 2, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(128))) unsigned char smem[S * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    V2A_STAMP(0);
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+    int tm = lin / tiles_n;
+    const int n0 = (lin % tiles_n) * BN;
+    if (p.frame_tiles > 0) {
+        const int per_sample = p.OH * p.frame_tiles;
+        const int img = tm / per_sample, rem = tm - img * per_sample;
+        const int pb = rem / p.OH, f = rem - pb * p.OH;
+        tm = img * per_sample + f * p.frame_tiles + pb;
+    }
+    const int m0 = tm * BM;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nkt = p.K / EPT;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    const bool second = m0 >= p.m_split;
+    const T* wsel = reinterpret_cast<const T*>(second ? p.w2 : p.w);
+    const float* bias_sel = second ? p.bias2 : p.bias;
+
+    const int lrow = tid >> 3;
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    int a_ihb[AL], a_iwb[AL], a_imgh[AL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int m = m0 + j * 32 + lrow;
+        const bool ok = m < p.M;
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t t = fdivh(mm, p.fd_ow);
+        const int ow = (int)(mm - t * p.OW);
+        const uint32_t img = fdivh(t, p.fd_oh);
+        const int oh = (int)(t - img * p.OH);
+        a_imgh[j] = (int)img * p.H;
+        a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);       // rows past M fail the bounds test below
+        a_iwb[j] = ow * p.sw - p.pw;
+    }
+    int a_lin1[AL], a_lin2[AL];                             // GEN = false: element offset of (row, tap (0,0), channel chunk) in source 1 / 2
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int pix = (a_imgh[j] + a_ihb[j]) * p.W + a_iwb[j];
+        a_lin1[j] = pix * p.C1 + chunk * EPC;
+        a_lin2[j] = pix * p.C2 + chunk * EPC;
+    }
+    const T* zsrc = reinterpret_cast<const T*>(p.zeros) + chunk * EPC;
+    const T* b_src[BL];
+    bool b_ok[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        b_ok[j] = n < p.Cout;
+        b_src[j] = wsel + (size_t)(b_ok[j] ? n : 0) * p.K + chunk * EPC;
+    }
+    const int shift = (p.ups || p.idil == 2) ? 1 : 0;       // logical -> stored pixel: nearest x2 upsample / zero-interleaved input
+    const int pmask = (p.idil == 2) ? 1 : 0;                // zero-interleaved input: odd logical positions are zeros
+
+    // (tap, channel) position of the next k tile to issue, and whether it still belongs to this slice
+    int ik0 = kt_begin * EPT;
+    int itap = ik0 / Cin;
+    int ic0 = ik0 - itap * Cin;
+    int ikh = itap / p.KW, ikw = itap - ikh * p.KW;
+    int it = kt_begin;
+
+    // pieces [q0, q1) of the pending k tile go to stage `buf`; a piece past the slice's end reads the zero line (keeps vmcnt counts fixed)
+    auto issue = [&](int buf, int q0, int q1) {
+        unsigned char* abase = smem + buf * STAGE;
+        unsigned char* bbase = abase + BM * ROWB;
+        const bool live = it < kt_end;
+        const bool first = ic0 < p.C1;
+        const T* src = reinterpret_cast<const T*>(first ? p.x : p.x2);
+        const uint32_t Cs = (uint32_t)(first ? p.C1 : p.C2);
+        const uint32_t cc = (uint32_t)((first ? ic0 : ic0 - p.C1) + chunk * EPC);
+        const int s_tap = (ikh * p.W + ikw) * (int)Cs + (first ? ic0 : ic0 - p.C1);      // scalar part of a GEN = false offset
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+            if (q < AL) {
+                const int j = q;
+                int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
+                bool ok;
+                uint32_t off;
+                if constexpr (GEN) {
+                    ok = live & ((unsigned)ih < (unsigned)p.HL) & ((unsigned)iw < (unsigned)p.WL) & (((ih | iw) & pmask) == 0);
+                    ih >>= shift; iw >>= shift;
+                    off = ((uint32_t)(a_imgh[j] + ih) * (uint32_t)p.W + (uint32_t)iw) * Cs + cc;
+                } else {
+                    ok = live & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+                    off = (uint32_t)((first ? a_lin1[j] : a_lin2[j]) + s_tap);
+                }
+                asm volatile("" : "+v"(off));               // keep the offset arithmetic out of an exec-masked region (plain select below)
+                const T* g = src + off;
+                g = ok ? g : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+            } else {
+                const int j = q - AL;
+                uint64_t gi = (uint64_t)(b_src[j] + ik0);
+                asm volatile("" : "+v"(gi));                // (a branch-free select: no scalar branch inside the MFMA stream)
+                const T* g = (live & b_ok[j]) ? reinterpret_cast<const T*>(gi) : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbase + (j * 256 + wid * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+    auto advance = [&]() {
+        ++it;
+        ik0 += EPT;
+        ic0 += EPT;
+        const bool wrap = ic0 >= Cin;
+        ic0 = wrap ? 0 : ic0;
+        const int kw1 = ikw + (wrap ? 1 : 0);
+        const bool wrap2 = kw1 == p.KW;
+        ikw = wrap2 ? 0 : kw1;
+        ikh += wrap2 ? 1 : 0;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int rswz = (lr >> 1) & 7;
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = (wm + i * 32 + lr) * ROWB;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j] = BM * ROWB + (wn + j * 32 + lr) * ROWB;
+    int pos[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) pos[h] = (((h << 1) | lk) ^ rswz) << 4;
+
+    // ---- prologue: S - 1 k tiles in flight
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) {
+        issue(s, 0, NL);
+        advance();
+    }
+    V2A_STAMP(1);
+    int cbuf = 0, ibuf = S - 1;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        wait_vmcnt_h<(S - 2) * NL>();                       // this wave's pieces of tile kt have landed; younger tiles stay in flight
+        __builtin_amdgcn_s_barrier();                       // ... everyone's have, and everyone is done reading the stage issued into next
+        if (kt == kt_begin) V2A_STAMP(2);
+        const unsigned char* base = smem + cbuf * STAGE;
+        f32x4_t a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4_t*>(base + a_off[i] + pos[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4_t*>(base + b_off[j] + pos[0]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int c = h & 1, nx = c ^ 1;
+            if (h < 3) {                                     // fragments of k-step h + 1: requested before this step's MFMAs issue
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nx][i] = *reinterpret_cast<const f32x4_t*>(base + a_off[i] + pos[h + 1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nx][j] = *reinterpret_cast<const f32x4_t*>(base + b_off[j] + pos[h + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue(ibuf, NL * h / 4, NL * (h + 1) / 4);       // its address arithmetic and DMA instructions go between the MFMAs below
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i][e], b[c][j][e], acc[i][j], 0, 0, 0);
+        }
+        advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's operand reads are done before it reaches the next barrier
+        cbuf = (cbuf + 1 == S) ? 0 : cbuf + 1;
+        ibuf = (ibuf + 1 == S) ? 0 : ibuf + 1;
+    }
+
+    // ---- epilogue: park each wave's sub-tiles in LDS, leave as 2 x 16-B stores per lane
+    wait_vmcnt_h<0>();                                       // the zero-line pieces past the end still land in the stages
+    __syncthreads();
+    V2A_STAMP(3);
+    static_assert(4 * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
+    conv_f32_epilogue<BM, BN>(p, acc, smem, m0, n0, split, bias_sel);
+}
+
+// ---- fp32 convolution by three bf16 planes (round 4).  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 matrix rate, so an exact-f32
+// conv is bound by 64 issue cycles per 4096 FLOP whatever the schedule (conv_igemm_f32p reaches the loop's floor at the clock the chip
+// sustains, tools/probes/conv_stamp_probe.py).  Here every fp32 operand value x is split while it is staged into LDS:
+//     hi = bf16(x),  mid = bf16(x - hi),  lo = bf16(x - hi - mid)        (both differences are exact in fp32: 24 significant bits)
+// and a product block is the sum of the six plane products of weight >= 2^-16 -- lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, smallest
+// first, each bf16 x bf16 product exact in the MFMA's fp32 accumulation; the three dropped products are <= 2^-24 |a||b|, one fp32 rounding.
+// Six v_mfma_f32_32x32x16_bf16 = 192 cycles per 32x32x16 block against 512 for eight v_mfma_f32_32x32x2_f32.  Measured error against an
+// fp64 reference on the same inputs: rms 3.6e-7 .. 7.3e-7 of the output's rms -- at or below the exact-f32 kernel's 4.2e-7 .. 8.5e-7
+// (tools/probes/emu_probe.py); NOT bit-equal to an fmaf chain, so `V2A_F32_CONV=exact` keeps the exact kernels selectable.
+// Structure: register-staged (the split needs the values in VGPRs): 16-B global loads two k tiles ahead (two register sets), split +
+// ds_write_b64 of tile t + 1 between the MFMA groups of tile t, two LDS stages of 3 x (BM + BN) rows x 64 B with the 16-B chunk swizzle
+// p ^ ((row >> 2) & 3) (conflict-free ds_read_b128 operand fetch), one barrier per k tile.
+__device__ __forceinline__ void split3_pair_h(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = v2a_pack_bf16x2(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = v2a_pack_bf16x2(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = v2a_pack_bf16x2(s0, s1);
+}
+
+template <int BM, int BN, int MINW, bool GEN>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p) {
+    constexpr int EPT = 32;
+    constexpr int AL = BM / 32, BL = BN / 32;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int ROWH = 64;                                    // bytes per plane row: 32 bf16
+    constexpr int PA = BM * ROWH, PB = BN * ROWH, STG = 3 * (PA + PB);
+    constexpr int S = 2, STAGE = STG;                           // (names the shared epilogue's size check uses)
+    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * STG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    V2A_STAMP(0);
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+    int tm = lin / tiles_n;
+    const int n0 = (lin % tiles_n) * BN;
+    if (p.frame_tiles > 0) {
+        const int per_sample = p.OH * p.frame_tiles;
+        const int img = tm / per_sample, rem = tm - img * per_sample;
+        const int pb = rem / p.OH, f = rem - pb * p.OH;
+        tm = img * per_sample + f * p.frame_tiles + pb;
+    }
+    const int m0 = tm * BM;
+    const int split = blockIdx.y;
+    const int Cin = p.C1 + p.C2;
+    const int nkt = p.K / EPT;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    const bool second = m0 >= p.m_split;
+    const float* wsel = reinterpret_cast<const float*>(second ? p.w2 : p.w);
+    const float* bias_sel = second ? p.bias2 : p.bias;
+
+    // loader: thread -> (row lrow + 32 j, float4 c4 of the 32-float k tile)
+    const int lrow = tid >> 3, c4 = tid & 7;
+    int a_ihb[AL], a_iwb[AL], a_imgh[AL], a_lin1[AL], a_lin2[AL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int m = m0 + j * 32 + lrow;
+        const bool ok = m < p.M;
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t t = fdivh(mm, p.fd_ow);
+        const int ow = (int)(mm - t * p.OW);
+        const uint32_t img = fdivh(t, p.fd_oh);
+        const int oh = (int)(t - img * p.OH);
+        a_imgh[j] = (int)img * p.H;
+        a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);
+        a_iwb[j] = ow * p.sw - p.pw;
+        const int pix = (a_imgh[j] + a_ihb[j]) * p.W + a_iwb[j];
+        a_lin1[j] = pix * p.C1 + c4 * 4;
+        a_lin2[j] = pix * p.C2 + c4 * 4;
+    }
+    const float* zsrc = reinterpret_cast<const float*>(p.zeros);
+    const float* b_src[BL];
+    bool b_ok[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        const int n = n0 + j * 32 + lrow;
+        b_ok[j] = n < p.Cout;
+        b_src[j] = wsel + (size_t)(b_ok[j] ? n : 0) * p.K + c4 * 4;
+    }
+    const int shift = (p.ups || p.idil == 2) ? 1 : 0;
+    const int pmask = (p.idil == 2) ? 1 : 0;
+    int ik0 = kt_begin * EPT;
+    int itap = ik0 / Cin;
+    int ic0 = ik0 - itap * Cin;
+    int ikh = itap / p.KW, ikw = itap - ikh * p.KW;
+    int it = kt_begin;
+
+    // request the next k tile (16-B loads into the given register set; past the slice's end: the zero line) and advance the position
+    auto load = [&](f32x4 (&ra)[AL], f32x4 (&rb)[BL]) {
+        const bool live = it < kt_end;
+        const bool first = ic0 < p.C1;
+        const float* src = reinterpret_cast<const float*>(first ? p.x : p.x2);
+        const uint32_t Cs = (uint32_t)(first ? p.C1 : p.C2);
+        const uint32_t cc = (uint32_t)((first ? ic0 : ic0 - p.C1) + c4 * 4);
+        const int s_tap = (ikh * p.W + ikw) * (int)Cs + (first ? ic0 : ic0 - p.C1);
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
+            bool ok;
+            uint32_t off;
+            if constexpr (GEN) {
+                ok = live & ((unsigned)ih < (unsigned)p.HL) & ((unsigned)iw < (unsigned)p.WL) & (((ih | iw) & pmask) == 0);
+                ih >>= shift; iw >>= shift;
+                off = ((uint32_t)(a_imgh[j] + ih) * (uint32_t)p.W + (uint32_t)iw) * Cs + cc;
+            } else {
+                ok = live & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+                off = (uint32_t)((first ? a_lin1[j] : a_lin2[j]) + s_tap);
+            }
+            asm volatile("" : "+v"(off));
+            const float* g = src + off;
+            g = ok ? g : zsrc;
+            ra[j] = *reinterpret_cast<const f32x4*>(g);
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            uint64_t gi = (uint64_t)(b_src[j] + ik0);
+            asm volatile("" : "+v"(gi));
+            const float* g = (live & b_ok[j]) ? reinterpret_cast<const float*>(gi) : zsrc;
+            rb[j] = *reinterpret_cast<const f32x4*>(g);
+        }
+        ++it;
+        ik0 += EPT;
+        ic0 += EPT;
+        const bool wrap = ic0 >= Cin;
+        ic0 = wrap ? 0 : ic0;
+        const int kw1 = ikw + (wrap ? 1 : 0);
+        const bool wrap2 = kw1 == p.KW;
+        ikw = wrap2 ? 0 : kw1;
+        ikh += wrap2 ? 1 : 0;
+    };
+    // LDS position of this thread's 8-B piece (4 bf16) of plane row r: 16-B chunk (c4 >> 1) ^ ((r >> 2) & 3), half c4 & 1
+    int w_off[AL > BL ? AL : BL];
+#pragma unroll
+    for (int j = 0; j < (AL > BL ? AL : BL); ++j) {
+        const int r = j * 32 + lrow;
+        w_off[j] = r * ROWH + ((((c4 >> 1) ^ ((r >> 2) & 3)) << 4) | ((c4 & 1) << 3));
+    }
+    auto split_store_a = [&](const f32x4 (&ra)[AL], unsigned char* stage) {
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair_h(ra[j][0], ra[j][1], h0, m0_, l0);
+            split3_pair_h(ra[j][2], ra[j][3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(stage + w_off[j]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(stage + PA + w_off[j]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(stage + 2 * PA + w_off[j]) = uint2{l0, l1};
+        }
+    };
+    auto split_store_b = [&](const f32x4 (&rb)[BL], unsigned char* stage) {
+        unsigned char* bb = stage + 3 * PA;
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair_h(rb[j][0], rb[j][1], h0, m0_, l0);
+            split3_pair_h(rb[j][2], rb[j][3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(bb + w_off[j]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(bb + PB + w_off[j]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(bb + 2 * PB + w_off[j]) = uint2{l0, l1};
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int rswz = (lr >> 2) & 3;                             // ((row >> 2) & 3) of every operand row this lane reads (wm, i * 32 are multiples of 16)
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = (wm + i * 32 + lr) * ROWH;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j] = 3 * PA + (wn + j * 32 + lr) * ROWH;
+    int pos[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pos[h] = (((h << 1) | lk) ^ rswz) << 4;
+
+    typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+    auto mfma6 = [&](const unsigned char* base, int h) {
+        bfx8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bfx8*>(base + q * PA + a_off[i] + pos[h]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bfx8*>(base + q * PB + b_off[j] + pos[h]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);     // lo  * hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);     // hi  * lo
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // mid * mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);     // mid * hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);     // hi  * mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);     // hi  * hi
+                acc[i][j] = c;
+            }
+    };
+
+    // ---- prologue: tile kt_begin staged, tile kt_begin + 1 requested
+    f32x4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
+    load(ra0, rb0);
+    load(ra1, rb1);
+    V2A_STAMP(1);
+    split_store_a(ra0, smem);
+    split_store_b(rb0, smem);
+    __syncthreads();
+    V2A_STAMP(2);
+    // one k tile: `cur` registers hold tile kt + 1 (requested one iteration ago), tile kt + 2 is requested into `nxt`
+    auto step = [&](f32x4 (&ra_c)[AL], f32x4 (&rb_c)[BL], f32x4 (&ra_n)[AL], f32x4 (&rb_n)[BL], int buf) {
+        unsigned char* cur = smem + buf * STG;
+        unsigned char* oth = smem + (buf ^ 1) * STG;
+        load(ra_n, rb_n);                                       // tile kt + 2 -> the register set consumed one step ago (1.5 steps of lead)
+        mfma6(cur, 0);
+        split_store_a(ra_c, oth);                               // (VALU of the split runs under the MFMAs around it)
+        mfma6(cur, 1);
+        split_store_b(rb_c, oth);
+        __syncthreads();
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        step(ra1, rb1, ra0, rb0, 0);
+        if (kt + 1 < kt_end) step(ra0, rb0, ra1, rb1, 1);
+    }
+    // (every wave passed the loop's last barrier after its last LDS access; the trailing register loads hit the zero line)
+    V2A_STAMP(3);
+    static_assert(4 * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
+    conv_f32_epilogue<BM, BN>(p, acc, smem, m0, n0, split, bias_sel);
 }
 
 template <typename T>
@@ -468,6 +1041,10 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
+static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact switches to the exact-f32 MFMA kernels
+static int g_f32p = -1, g_f32p_s128 = 2, g_f32p_s64 = 4;   // pipelined exact-f32 conv (conv_igemm_f32p): on / stages of the 128x128 and 64x64 tiles
+static unsigned long long* g_conv_stamps = nullptr;     // v2a_debug_conv_stamps: next launch's stamp block (advanced per launch)
+static size_t g_conv_stamp_stride = 0;
 static int g_stages_h = -1;       // 128x128 kernel on launches of >= 768 workgroups: 1 LDS buffer, 4 workgroups per CU (V2A_DMA_STAGES=2: always two buffers)
 static int g_small_tile_h = -1;   // 64x64 tiles for problems that 128-row tiles cannot spread over the chip (V2A_DMA_SMALL_TILE=0 disables)
 static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* tiles, int* s) {
@@ -548,6 +1125,8 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.ups = ups ? 1 : 0;
     p.stats = nullptr;
+    p.tstamps = g_conv_stamps;
+    if (g_conv_stamps) g_conv_stamps += (size_t)g_conv_stamp_stride;
     p.HL = ups ? 2 * H : (idil == 2 ? 2 * H - 1 : H);
     p.WL = ups ? 2 * W : (idil == 2 ? 2 * W - 1 : W);
     p.M = N * OH * OW;
@@ -578,10 +1157,55 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         const char* e = getenv("V2A_DMA_STAGES");
         g_stages_h = (e && e[0] == '2') ? 2 : 1;
     }
+    p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff;
+    if constexpr (sizeof(T) == 4) {
+        if (g_f32p < 0) {                            // V2A_F32P=0: the round-1..3 kernel (A/B); V2A_F32P_S128 / _S64: LDS stages per tile shape
+            const char* e = getenv("V2A_F32P");
+            g_f32p = (e && e[0] == '0') ? 0 : 1;
+            const char* e2 = getenv("V2A_F32P_S128");
+            if (e2 && e2[0] == '3') g_f32p_s128 = 3;
+            const char* e3 = getenv("V2A_F32P_S64");
+            if (e3 && e3[0] == '3') g_f32p_s64 = 3;
+        }
+        const int f32p = g_f32p, s128 = g_f32p_s128, s64 = g_f32p_s64;
+        if (g_f32x3 < 0) {
+            const char* e = getenv("V2A_F32_CONV");
+            g_f32x3 = (e && e[0] == 'e') ? 0 : 1;
+        }
+        if (g_f32x3) {
+            const bool gen = ups || idil == 2;
+            if (bm == 64) {
+                if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, true>), dim3(tiles, s), dim3(256), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, false>), dim3(tiles, s), dim3(256), 0, stream, p);
+            } else {
+                const int t64 = cdiv(p.M, 128) * cdiv(Cout, 64);      // 128 x 128 plans run as 128 x 64 tiles (two workgroups per CU)
+                if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<128, 64, 2, true>), dim3(t64, s), dim3(256), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_f32x3<128, 64, 2, false>), dim3(t64, s), dim3(256), 0, stream, p);
+            }
+            goto launched;
+        }
+        if (f32p) {
+            const bool gen = ups || idil == 2;
+#define V2A_F32P_LAUNCH(BM_, BN_, S_, W_)                                                                                       \
+    do {                                                                                                                          \
+        if (gen) hipLaunchKernelGGL((conv_igemm_f32p<BM_, BN_, S_, W_, true>), dim3(tiles, s), dim3(256), 0, stream, p);          \
+        else hipLaunchKernelGGL((conv_igemm_f32p<BM_, BN_, S_, W_, false>), dim3(tiles, s), dim3(256), 0, stream, p);            \
+    } while (0)
+            if (bm == 64) {
+                if (s64 == 3) V2A_F32P_LAUNCH(64, 64, 3, 3);
+                else V2A_F32P_LAUNCH(64, 64, 4, 2);
+            } else if (bn == 64) V2A_F32P_LAUNCH(128, 64, 3, 2);
+            else if (s128 == 3) V2A_F32P_LAUNCH(128, 128, 3, 1);
+            else V2A_F32P_LAUNCH(128, 128, 2, 2);
+#undef V2A_F32P_LAUNCH
+            goto launched;
+        }
+    }
     if (bm == 64) hipLaunchKernelGGL((conv_igemm_h<64, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
     else if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
     else if (g_stages_h == 1 && tiles * s >= 768) hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 1>), dim3(tiles, s), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
+launched:
     V2A_CHECK_LAUNCH();
     if (s > 1) {
         if (nslab_out && !rowvec && !residual_f32) {       // the consumer (a GroupNorm launch) sums the slabs itself: no reduce launch
@@ -608,6 +1232,29 @@ int v2a_set_half_format(int f16) {
     return old;
 }
 int v2a_get_half_format(void) { return g_v2a_half_f16; }
+// measurement aid: every following conv_igemm_h launch records, per workgroup, eight 100-MHz wall-clock stamps (entry, first DMA issued,
+// first k tile landed, main loop done, epilogue stores issued, stores acknowledged) into buf, which advances by `stride_words` 64-bit
+// words per launch.  buf = null switches the stamps off (the default: the kernels then skip them on a uniform branch).
+// tuning aid: on = 0 routes fp32 LDS-DMA convs to conv_igemm_h<.., float> (rounds 1-3), 1 to conv_igemm_f32p; s128 in {2, 3}, s64 in {3, 4}
+// = LDS stages of the 128 x 128 / 64 x 64 tiles (0 keeps the current value).  Returns the previous `on`.
+// fp32 LDS-DMA convs: 1 = by three bf16 planes (conv_igemm_f32x3, default), 0 = exact-f32 MFMA kernels.  Returns the old value.
+int v2a_set_f32_conv_mode(int x3) {
+    const int old = g_f32x3 < 0 ? 1 : g_f32x3;
+    g_f32x3 = x3 ? 1 : 0;
+    return old;
+}
+int v2a_debug_f32p(int on, int s128, int s64) {
+    const int old = g_f32p < 0 ? 1 : g_f32p;
+    g_f32p = on ? 1 : 0;
+    if (s128 == 2 || s128 == 3) g_f32p_s128 = s128;
+    if (s64 == 3 || s64 == 4) g_f32p_s64 = s64;
+    return old;
+}
+int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words) {
+    g_conv_stamps = (unsigned long long*)buf;
+    g_conv_stamp_stride = stride_words;
+    return V2A_OK;
+}
 
 // bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
 // exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned pointers; zeros: >= 128 zero bytes.
@@ -685,17 +1332,21 @@ int v2a_pack_weight_h(const float* w, void* out, int Cout, int Cin, int taps, hi
     return V2A_OK;
 }
 
-// elementwise casts between the two storage types (n % 4 == 0, 16-B / 8-B aligned)
-int v2a_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
-    if (!x || !y || n % 4) return V2A_ERR_ARG;
+// elementwise casts between the two storage types (n % 4 == 0, 16-B / 8-B aligned).  The 16-bit format is an ARGUMENT here
+// (f16: 0 bf16, 1 IEEE fp16), never the process-wide flag: callers that stage bf16 data (the data-parallel wire buffer, the policy's
+// weight twins) must not inherit the format an fp16 video forward selected before them.
+int v2a_cast_f32_h(const float* x, void* y, size_t n, int f16, hipStream_t stream) {
+    if (!x || !y || n % 4 || (f16 != 0 && f16 != 1)) return V2A_ERR_ARG;
     if (n == 0) return V2A_OK;
     int g = (int)((n / 4 + 255) / 256);
     if (g > 16384) g = 16384;
-    if (g_v2a_half_f16) hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
+    if (f16) hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
     else hipLaunchKernelGGL(cast_f32_bf16_kernel<false>, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y, n / 4);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
+// fp32 -> bf16, always (whatever v2a_set_half_format says)
+int v2a_cast_f32_bf16(const float* x, void* y, size_t n, hipStream_t stream) { return v2a_cast_f32_h(x, y, n, 0, stream); }
 // x fp32 [M][Cin] -> y bf16 [M][Cpad], zero-padded channels (Cpad % 8 == 0, Cin <= Cpad, y 16-B aligned)
 int v2a_pad_cast_f32_bf16(const float* x, void* y, size_t M, int Cin, int Cpad, hipStream_t stream) {
     if (!x || !y || Cin <= 0 || Cpad % 8 || Cin > Cpad || ((uintptr_t)y & 15)) return V2A_ERR_ARG;
@@ -708,15 +1359,17 @@ int v2a_pad_cast_f32_bf16(const float* x, void* y, size_t M, int Cin, int Cpad, 
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
-int v2a_cast_bf16_f32(const void* x, float* y, size_t n, hipStream_t stream) {
-    if (!x || !y || n % 4) return V2A_ERR_ARG;
+int v2a_cast_h_f32(const void* x, float* y, size_t n, int f16, hipStream_t stream) {
+    if (!x || !y || n % 4 || (f16 != 0 && f16 != 1)) return V2A_ERR_ARG;
     if (n == 0) return V2A_OK;
     int g = (int)((n / 4 + 255) / 256);
     if (g > 16384) g = 16384;
-    if (g_v2a_half_f16) hipLaunchKernelGGL(cast_bf16_f32_kernel<true>, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
+    if (f16) hipLaunchKernelGGL(cast_bf16_f32_kernel<true>, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
     else hipLaunchKernelGGL(cast_bf16_f32_kernel<false>, dim3(g), dim3(256), 0, stream, (const uint16_t*)x, y, n / 4);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
+// bf16 -> fp32, always
+int v2a_cast_bf16_f32(const void* x, float* y, size_t n, hipStream_t stream) { return v2a_cast_h_f32(x, y, n, 0, stream); }
 
 }  // extern "C"

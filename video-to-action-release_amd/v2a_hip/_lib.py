@@ -92,6 +92,9 @@ SIGNATURES = {
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
     "v2a_advance_counter": (I, [P, U64, P]),
     "v2a_debug_timestamp": (I, [P, P]),
+    "v2a_debug_conv_stamps": (I, [P, SZ]),
+    "v2a_debug_f32p": (I, [I, I, I]),
+    "v2a_set_f32_conv_mode": (I, [I]),
     "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),
     "v2a_perceiver_attention_bwd": (I, [P] * 9 + [I, I, I, I, I, F, P]),
     "v2a_layernorm_bwd": (I, [P, P, P, P, P, I, I, F, P]),
@@ -134,6 +137,8 @@ SIGNATURES = {
     "v2a_conv2d_fwd_h2": (I, [P, P, P, P, P, P, P, P] + [I] * 16 + [P, P]),
     "v2a_pack_weight_h": (I, [P, P, I, I, I, P]),
     "v2a_cast_f32_bf16": (I, [P, P, SZ, P]),
+    "v2a_cast_f32_h": (I, [P, P, SZ, I, P]),
+    "v2a_cast_h_f32": (I, [P, P, SZ, I, P]),
     "v2a_pad_cast_f32_bf16": (I, [P, P, SZ, I, I, P]),
     "v2a_cast_bf16_f32": (I, [P, P, SZ, P]),
     "v2a_opt_state_peek": (I, [P, P, P, P, P]),

@@ -516,9 +516,18 @@ _fmt_now = [None]
 
 
 def _set_fmt(dtype):
+    """Select the 16-bit format of the `_h` kernel families (process-wide C flag).  The cache only short-cuts repeated calls from
+    this module; set_half_format() below is the one public way to flip the flag, so the cache cannot go stale."""
     if _fmt_now[0] is not dtype:
         lib.v2a_set_half_format(1 if dtype == torch.float16 else 0)
         _fmt_now[0] = dtype
+
+
+def set_half_format(dtype):
+    """Public form of _set_fmt (torch.bfloat16 | torch.float16)."""
+    assert dtype in HALF_DTYPES
+    _fmt_now[0] = None
+    _set_fmt(dtype)
 
 
 def pack_weight_h(w: torch.Tensor, out: torch.Tensor = None, dtype=torch.bfloat16) -> torch.Tensor:
@@ -537,8 +546,7 @@ def cast_h(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     """fp32 -> bf16 (default) or fp16, round to nearest even, same shape."""
     _chk(x, "x")
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
-    _set_fmt(dtype)
-    check(lib.v2a_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_f32_bf16")
+    check(lib.v2a_cast_f32_h(x.data_ptr(), y.data_ptr(), x.numel(), 1 if dtype == torch.float16 else 0, _stream()), "cast_f32_h")
     return y
 
 
@@ -554,9 +562,9 @@ def pad_cast_h(x: torch.Tensor, cpad: int, dtype=torch.bfloat16) -> torch.Tensor
 
 def cast_f(x: torch.Tensor) -> torch.Tensor:
     """bf16 -> fp32, same shape."""
-    _chk_h(x, "x")
+    assert x.is_cuda and x.dtype in HALF_DTYPES and x.is_contiguous()
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    check(lib.v2a_cast_bf16_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "cast_bf16_f32")
+    check(lib.v2a_cast_h_f32(x.data_ptr(), y.data_ptr(), x.numel(), 1 if x.dtype == torch.float16 else 0, _stream()), "cast_h_f32")
     return y
 
 
@@ -1021,7 +1029,7 @@ def spatial_softmax_bwd(att, kp, dkp):
     return dfeat
 
 
-_TS = {"on": os.environ.get("V2A_TSTAMP") == "1", "buf": None, "names": []}
+_TS = {"on": os.environ.get("V2A_TSTAMP") in ("1", "2"), "fine": os.environ.get("V2A_TSTAMP") == "2", "buf": None, "names": []}
 
 
 def tstamp(name):
@@ -1039,6 +1047,12 @@ def tstamp(name):
         names.append(name)
     _TS["cursor"] = i + 1
     check(lib.v2a_debug_timestamp(_TS["buf"].data_ptr() + 8 * i, _stream()), "debug_timestamp")
+
+
+def tstamp_fine(name):
+    """Block-level probes (V2A_TSTAMP=2 only): one per ResNet block / residual block, forward and backward."""
+    if _TS["fine"]:
+        tstamp(name)
 
 
 def tstamp_reset():

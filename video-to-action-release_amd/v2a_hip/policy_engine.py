@@ -29,6 +29,7 @@ def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
     return torch.cumprod(1.0 - betas, dim=0)
 
 
+_PRIO = __import__('os').environ.get('V2A_PRIO') == '1'                    # experiment: chain streams at high priority
 _GN_DEFER = __import__('os').environ.get('V2A_GN_DEFER', '1') != '0'      # 0: every conv runs its own split-K reduce (A/B)
 
 class _Conv:
@@ -552,6 +553,7 @@ class PolicyEngine:
         c1 = ops.conv2d(x0, e["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3))
         a1, s_gn1 = self._gn(c1, e["bb"] + ".1", w0 // 16, "relu")
         h, pidx = ops.maxpool_fwd(a1)
+        ops.tstamp_fine(f"enc_fwd[{key}] stem done")
         st = dict(x0=x0, gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
         h_tw = None                                  # bf16 twin of the running activation (emitted by the GroupNorm launches)
         for blk in e["blocks"]:
@@ -579,6 +581,7 @@ class PolicyEngine:
             h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn, slabs=sl)
             h_tw = self._take_tw(h)
             st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd, inp_h=k1[0] if k1 else None, a_h=k2[0] if k2 else None))
+            ops.tstamp_fine(f"enc_fwd[{key}] block {len(st['blocks']) - 1} done")
         feat = h
         B, FH, FW, FC = feat.shape
         kl = ops.conv2d(feat, e["pool"].pf(), e["pool"].b, cfg.num_kp, 1, 1)
@@ -615,6 +618,7 @@ class PolicyEngine:
         feat = st["feat"]
         self._wg(feat, dkl, pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
         dh = _dgrad(dkl, pool, None, pool.ci, 1, 1)
+        ops.tstamp_fine(f"enc_bwd[{key}] head done")
         dh_sl = None
         nblk = len(e["blocks"])
         for bi, (blk, bs) in enumerate(zip(reversed(e["blocks"]), reversed(st["blocks"]))):
@@ -648,10 +652,13 @@ class PolicyEngine:
                 dh, dh_sl = _dgrad(do1, blk["conv1"], None, ci, 3, 3, (1, 1), (1, 1), idil=s, out_hw=(ih, iw), residual=res_in, x_h=do1h), None
             if bi % 2 == 1:
                 ops.tstamp(f"enc_bwd[{key}] stage {3 - bi // 2} dgrad done")
+            else:
+                ops.tstamp_fine(f"enc_bwd[{key}] block {nblk - 1 - bi} dgrad done")
             if self._wgb_mode == "stage" and bi % 2 == 1:           # both blocks of a ResNet stage are through: their gradients as one launch
                 self._wgb_launch()
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
+        ops.tstamp_fine(f"enc_bwd[{key}] stem gn done")
         # RGB stem: 3 input channels make every 16-B piece of the gathered operand straddle pixels (scalar-gather kernel, 0.4 ms
         # per encoder).  Pad the saved input to 4 channels once (zeros in the 4th), take the gradient of the 4-channel filter on
         # the vector / LDS-DMA kernel and keep its first three input channels.
@@ -712,6 +719,7 @@ class PolicyEngine:
             out = ops.axpy(a1, x)
         if save is not None:
             save.append(dict(r=r, x=x, x2=x2, a0=a0, s0=s0, s1=s1, a0_h=ka[0] if ka else None, x_h=x_h, x2_h=x2_h))
+        ops.tstamp_fine(f"unet_fwd {r['pre'][6:]} done")
         return out
 
     def _res_bwd(self, st, dout, grads, dmgf, extra=None, need_dx=True, dslabs=None, defer_dx=False):
@@ -893,6 +901,7 @@ class PolicyEngine:
                 defer_dx = (not first_block and nxt is not None and "r" in nxt and e["x2"] is None
                             and self._defer_ok(dx.shape[1], e["r"]["cin"], cfg.n_groups))
                 dx, dx2, dmgf = self._res_bwd(e, dx, grads, dmgf, extra=extra, need_dx=not first_block, dslabs=dx_sl, defer_dx=defer_dx)
+                ops.tstamp_fine(f"unet_bwd {e['r']['pre'][6:]} done")
                 dx_sl = None
                 if isinstance(dx, tuple):
                     dx, dx_sl = dx
@@ -932,7 +941,7 @@ class PolicyEngine:
             return [f() for f in fns]
         main = torch.cuda.current_stream()
         while len(self._enc_side) < len(fns) - 1:
-            self._enc_side.append(torch.cuda.Stream(device=self.device))
+            self._enc_side.append(torch.cuda.Stream(device=self.device, priority=-1 if _PRIO else 0))
         out = [None] * len(fns)
         for i, f in enumerate(fns[1:], 1):
             st = self._enc_side[i - 1]
