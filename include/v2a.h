@@ -207,6 +207,7 @@ int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offse
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
+int v2a_get_f32_conv_mode(void);
 int v2a_debug_f32p(int on, int s128, int s64);   /* tuning aid: pipelined exact-f32 conv kernel on/off (default on), LDS stages of its 128x128 / 64x64 tiles; returns the old `on` */
 int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words);   /* measurement aid: following conv_igemm_h launches stamp their phases per workgroup ([wg][8] x 100 MHz ticks), buf advances by stride_words per launch; null = off */
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */

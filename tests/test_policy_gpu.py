@@ -489,16 +489,33 @@ def test_batch_256_step_ties_to_oracle_through_linearity():
     assert float(np.median([e[1] for e in errs])) <= TOL
 
 
-@pytest.mark.parametrize("B,seed", [(1, 101), (3, 1), (5, 3), (6, 106), (7, 1)])
+def _grad_distances(hip, ref32, ref64, names):
+    """Per-tensor max |a - fp64| / max(|fp64|_inf, 1e-3 * largest gradient norm) of the HIP gradients and of the fp32 CPU oracle, both
+    against the fp64 run of the oracle (the yard-stick every > 1e-4 case of this suite uses), plus HIP against the fp32 oracle."""
+    gsc = max(float(ref64[n].norm()) for n in names)
+    rows = []
+    for n in names:
+        sc = max(float(ref64[n].abs().max()), 1e-3 * gsc)
+        rows.append((n, float((hip[n].double().cpu() - ref64[n]).abs().max()) / sc, float((ref32[n].double() - ref64[n]).abs().max()) / sc,
+                     float((hip[n].double().cpu() - ref32[n].double()).abs().max()) / sc))
+    return rows
+
+
+def _fp64_oracle_grads(OP, sd, batch, noise, ts, names):
+    sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
+    b64 = {"obs": {k: v.double() for k, v in batch["obs"].items()}, "action": batch["action"].double()}
+    return OP.loss_and_grads(sd64, b64, noise.double(), ts, names=names)
+
+
+@pytest.mark.parametrize("B,seed", [(1, 0), (3, 1), (5, 2), (6, 3), (7, 4)])
 def test_ragged_batch_loss_and_grads_vs_oracle(B, seed):
     """Batches that fill no tile evenly (1024 ... 7168 conv rows at the first ResNet stage, 16 ... 112 rows in the ConditionalUnet1D):
-    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin.  Loss and every gradient
-    against the CPU oracle on the same seeded inputs, 1e-4.
-
-    The seeds are chosen: about four in ten random batches of this size contain a ReLU input (or a max-pool pair) that fp32 rounding puts
-    on the other side of zero in ONE of the two fp32 implementations -- a single flipped mask element is 1e-3 ... 3e-2 of an encoder
-    weight gradient at B <= 7 (1 / (B * H * W) of its terms), and the fp32 oracle is then as far from an fp64 run of itself as the HIP
-    path is (tools/probes/ragged_grad_probe.py prints all three).  On a failure the message carries the distances to the fp64 oracle."""
+    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin.  Seeds are NOT selected
+    (0 .. 4): at B <= 7 one ReLU / max-pool mask element that fp32 rounding puts on the other side of zero is 1e-3 ... 3e-2 of an encoder
+    weight gradient, and it happens to one of two fp32 implementations in about four of ten random batches -- so the bound is the
+    yard-stick the other > 1e-4 cases use: against the fp64 run of the oracle no HIP gradient tensor may be further off than
+    max(1e-4, 2 x the fp32 CPU oracle's own distance to fp64 on its worst tensor); the loss must meet 1e-4 outright and the median
+    tensor too."""
     from oracle import policy as OP
     pol, sd = _policy(seed=21 + B)
     g = torch.Generator().manual_seed(seed)
@@ -513,15 +530,49 @@ def test_ragged_batch_loss_and_grads_vs_oracle(B, seed):
     ref_loss, ref_g = OP.loss_and_grads(sd, batch, noise, ts, names=names)
     assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item()), (loss.item(), ref_loss.item())
     P = dict(pol.named_parameters())
-    gsc = max(float(v.double().norm()) for v in ref_g.values())
-    dist = lambda a, b: max(((a[n].double().cpu() - b[n].double()).abs().max() / max(b[n].abs().max().item(), 1e-3 * gsc)).item() for n in names)
     hip = {n: P[n].grad for n in names}
-    worst = dist(hip, ref_g)
-    if worst > TOL:
-        sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
-        b64 = {"obs": {k: v.double() for k, v in batch["obs"].items()}, "action": batch["action"].double()}
-        _, g64 = OP.loss_and_grads(sd64, b64, noise.double(), ts, names=names)
-        raise AssertionError(f"HIP vs fp32 oracle {worst:.2e}; vs the fp64 oracle: HIP {dist(hip, g64):.2e}, fp32 oracle {dist(ref_g, g64):.2e}")
+    _, g64 = _fp64_oracle_grads(OP, sd, batch, noise, ts, names)
+    rows = _grad_distances(hip, ref_g, g64, names)
+    worst_hip, worst_ref = max(r[1] for r in rows), max(r[2] for r in rows)
+    print(f"[ragged B={B} seed={seed}] worst tensor vs fp64: HIP {worst_hip:.2e}, fp32 CPU oracle {worst_ref:.2e}; HIP vs fp32 oracle {max(r[3] for r in rows):.2e}")
+    bad = [r for r in rows if r[1] > max(TOL, 2 * worst_ref)]
+    assert not bad, bad[:5]
+    assert float(np.median([r[1] for r in rows])) <= TOL
+
+
+def test_c2_batch64_loss_and_grads_vs_oracle():
+    """BASELINE configs[1] at its own batch: compute_loss + every gradient at B = 64 directly against the CPU oracle on the same seeded
+    inputs (the fixtures pin B = 8; B = 256 is tied to the oracle through linearity).  Loss 1e-4; gradients by the fp64 yard-stick: with
+    64 x 4096-pixel sums the fp32 CPU oracle is itself off the fp64 truth on its worst tensor, no HIP tensor may be further off than twice
+    that (or 1e-4), the median tensor meets 1e-4."""
+    from oracle import policy as OP
+    B = 64
+    pol, sd = _policy(seed=64)
+    g = torch.Generator().manual_seed(64)
+    batch = {"obs": {"img_obs_1": torch.rand(B, 1, 3, 128, 128, generator=g), "img_goal_1": torch.rand(B, 1, 3, 128, 128, generator=g)},
+             "action": torch.rand(B, 16, 7, generator=g) * 2 - 1}
+    noise, ts = torch.randn(B, 16, 7, generator=g), torch.randint(0, 100, (B,), generator=g)
+    pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
+    pol.train()
+    loss = pol.compute_loss(batch)
+    loss.backward()
+    names = pol.trainable_names()
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    try:
+        ref_loss, ref_g = OP.loss_and_grads(sd, batch, noise, ts, names=names)
+        _, g64 = _fp64_oracle_grads(OP, sd, batch, noise, ts, names)
+    finally:
+        torch.set_num_threads(old)
+    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    P = dict(pol.named_parameters())
+    rows = _grad_distances({n: P[n].grad for n in names}, ref_g, g64, names)
+    worst_hip, worst_ref = max(r[1] for r in rows), max(r[2] for r in rows)
+    print(f"[C2 B=64] loss {loss.item():.7f} vs oracle {ref_loss.item():.7f}; worst tensor vs fp64: HIP {worst_hip:.2e}, fp32 CPU oracle {worst_ref:.2e}; "
+          f"HIP vs fp32 oracle {max(r[3] for r in rows):.2e}")
+    bad = [r for r in rows if r[1] > max(TOL, 2 * worst_ref)]
+    assert not bad, bad[:5]
+    assert float(np.median([r[1] for r in rows])) <= TOL
 
 
 @pytest.mark.parametrize("B", [1, 5, 9])

@@ -292,24 +292,26 @@ def test_full_size_sampler_multi_step_and_batch_rows():
     assert row_err <= 1e-5, row_err
 
 
-def test_c3_full_size_50_step_ddim_sampler_b16_row_vs_oracle():
-    """The exact BASELINE configs[2] workload: Unet_Libero (201 M parameters), 8-frame 128x128, B = 16, 50 DDIM
-    steps (reference ddim_sample, goal_diffusion.py:601-641) on the GPU with an injected initial image; row 0 recomputed by the CPU
-    oracle over all 50 sequential full-size UNet calls.  Bound: north_star's 1e-4; only if that is missed the same row is re-run in
-    fp64 and the bound widened to 4x the reference's own fp32-vs-exact deviation (the yard-stick costs twice the oracle's time)."""
+def test_c3_full_size_50_step_ddim_sampler_b16_row_vs_reference(golden_dir):
+    """The exact BASELINE configs[2] workload: Unet_Libero (201 M parameters), 8-frame 128x128, B = 16, 50 DDIM steps (reference
+    ddim_sample, goal_diffusion.py:601-641) on the GPU with an injected initial image; row 0 against tests/golden/c3_row.npz -- the same
+    row produced by the IMPORTED REFERENCE's own GoalGaussianDiffusion.sample at batch 1 (tools/make_golden.py g_c3_row; rows of a batch
+    are independent), every second pixel stored plus the sums of the whole row.  Bound: north_star's 1e-4.  (Round 3 recomputed the row
+    with the CPU oracle on the GPU box: 190 s of the suite; the oracle path remains as the diagnosis on a miss.)"""
     from flowdiffusion.flowdiffusion.unet import Unet_Libero
     from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
     from oracle.param_fill import fill_module
-    from oracle import goal_diffusion as OG
-    import oracle.video_unet as VU
+    g = np.load(f"{golden_dir}/c3_row.npz")
     torch.manual_seed(0)
     m = Unet_Libero()
     sd = fill_module(m, seed=12)
+    from tools_wsum import wsum
+    assert abs(wsum(sd) - float(g["weights_abs_sum"])) <= 1e-9 * float(g["weights_abs_sum"])
     m = m.to("cuda:0").eval()
-    steps, B = 50, 16
+    steps, B = int(g["steps"]), int(g["batch"])
     d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=steps, loss_type="l2",
                               objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to("cuda:0")
-    gen = torch.Generator().manual_seed(41)
+    gen = torch.Generator().manual_seed(int(g["seed"]))
     x_cond = torch.rand(B, 3, 128, 128, generator=gen)
     te = torch.randn(B, 10, 512, generator=gen)
     n0 = torch.randn(B, 21, 128, 128, generator=gen)
@@ -321,30 +323,21 @@ def test_c3_full_size_50_step_ddim_sampler_b16_row_vs_oracle():
 
     d.__dict__["_noise_hook"] = hook
     out = d.sample(x_cond.cuda(), te.cuda(), batch_size=B).cpu()
-    assert len(calls) == steps                    # randn(shape) + one randn_like per pair except the last (reference RNG order)
+    assert len(calls) == steps == int(g["n_noise_calls"])      # randn(shape) + one randn_like per pair except the last (reference RNG order)
     assert out.shape == (B, 21, 128, 128) and torch.isfinite(out).all() and float(out.min()) >= 0 and float(out.max()) <= 1
-    old = torch.get_num_threads()
-    torch.set_num_threads(min(32, max(old, 8)))
-    try:
-        nz = [n0[:1]]
-        ref = OG.sample(lambda x, t, e: VU.unet_libero_forward(sd, x, t, e, VU.LIBERO_CFG), OG.cosine_tables(), nz, x_cond[:1], te[:1],
+    ref_sub = torch.from_numpy(g["row0_sub"])
+    err = rel(out[0, :, ::2, ::2], ref_sub)
+    row = out[0].double()
+    e_sum = abs(float(row.sum()) - float(g["row0_sum"])) / float(g["row0_abs_sum"])
+    e_sq = abs(float((row ** 2).sum()) - float(g["row0_sq_sum"])) / float(g["row0_sq_sum"])
+    print(f"[C3 full-size 50-step DDIM, B=16] row 0 vs the reference's own sample: {err:.2e} (sum {e_sum:.1e}, sum of squares {e_sq:.1e})")
+    if err > TOL:                                 # diagnosis only: where do the oracle and an fp64 run of it stand?
+        from oracle import goal_diffusion as OG
+        import oracle.video_unet as VU
+        ref = OG.sample(lambda x, t, e: VU.unet_libero_forward(sd, x, t, e, VU.LIBERO_CFG), OG.cosine_tables(), [n0[:1]], x_cond[:1], te[:1],
                         sampling_timesteps=steps)
-        err = rel(out[:1], ref)
-        print(f"[C3 full-size 50-step DDIM, B=16] row 0: HIP vs CPU oracle {err:.2e}")
-        if err > TOL:
-            sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
-            T64 = {k: v.double() for k, v in OG.cosine_tables().items()}
-            VU.WORK_DTYPE = torch.float64
-            try:
-                exact = OG.sample(lambda x, t, e: VU.unet_libero_forward(sd64, x, t, e, VU.LIBERO_CFG), T64, [n0[:1].double()],
-                                  x_cond[:1].double(), te[:1].double(), sampling_timesteps=steps)
-            finally:
-                VU.WORK_DTYPE = torch.float32
-            ref_dev, err_exact = rel(ref, exact), rel(out[:1], exact)
-            print(f"    reference fp32 vs fp64 {ref_dev:.2e}; HIP vs fp64 {err_exact:.2e}")
-            assert err <= 4 * ref_dev and err_exact <= 4 * ref_dev, (err, err_exact, ref_dev)
-    finally:
-        torch.set_num_threads(old)
+        raise AssertionError(f"HIP vs reference fixture {err:.2e}; CPU oracle vs fixture {rel(ref[0, :, ::2, ::2], ref_sub):.2e}; HIP vs oracle {rel(out[:1], ref):.2e}")
+    assert e_sum <= TOL and e_sq <= TOL, (e_sum, e_sq)
 
 
 def test_full_unet_libero_forward_vs_golden(golden_dir):

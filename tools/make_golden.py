@@ -212,6 +212,45 @@ def g_unet_full():
     print("unet_full ok", float(y.double().abs().sum()))
 
 
+def g_c3_row():
+    """BASELINE configs[2] pinned on the REFERENCE: row 0 of the full-size 50-step DDIM sample (Unet_Libero, 8-frame 128 x 128) made by the
+    imported reference's own GoalGaussianDiffusion.sample at batch 1 with the inputs tests/test_video_gpu.py feeds row 0 of its B = 16
+    call (rows of a batch are independent).  ~5 minutes on 8 cores.  Stored: every second pixel of the row + sums of the whole row."""
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    torch.manual_seed(0)
+    m = build_ref_unet(tiny=False).eval()
+    sd = fill_module(m, seed=12)
+    steps, B = 50, 16
+    d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=steps, loss_type="l2",
+                              objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0)
+    gen = torch.Generator().manual_seed(41)
+    x_cond = torch.rand(B, 3, 128, 128, generator=gen)
+    te = torch.randn(B, 10, 512, generator=gen)
+    n0 = torch.randn(B, 21, 128, 128, generator=gen)
+    calls = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def fake_randn(*shape, **kw):                 # the reference draws its start image with torch.randn(shape, device=...)
+        calls.append(tuple(shape[0]) if isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape))
+        return n0[:1].clone()
+
+    def fake_randn_like(t, **kw):                 # eta = 0: sigma = 0 multiplies every later draw
+        calls.append(tuple(t.shape))
+        return torch.zeros_like(t)
+
+    torch.randn, torch.randn_like = fake_randn, fake_randn_like
+    try:
+        with torch.no_grad():
+            out = d.sample(x_cond[:1], te[:1], batch_size=1)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    assert out.shape == (1, 21, 128, 128), out.shape
+    np.savez_compressed(f"{OUT}/c3_row.npz", weights_abs_sum=wsum(sd), steps=steps, batch=B, seed=41, n_noise_calls=len(calls),
+                        row0_sub=out[0, :, ::2, ::2].numpy().astype(np.float32), row0_sum=float(out.double().sum()),
+                        row0_abs_sum=float(out.double().abs().sum()), row0_sq_sum=float((out.double() ** 2).sum()))
+    print("c3_row ok", out.shape, len(calls), float(out.double().abs().sum()))
+
+
 def g_policy():
     torch.manual_seed(0)
     pol = build_ref_policy()
@@ -430,7 +469,7 @@ def g_wrappers():
     np.savez_compressed(f"{OUT}/wrappers.npz", **out)
 
 
-GROUPS = {"wrappers": g_wrappers, "tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer}
+GROUPS = {"wrappers": g_wrappers, "tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer, "c3_row": g_c3_row}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)

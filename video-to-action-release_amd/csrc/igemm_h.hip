@@ -413,12 +413,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
 // Epilogue of the fp32 instances (conv_igemm_f32p, conv_igemm_f32x3): each wave parks one 32-row sub-tile at a time in its own LDS
 // region (4 * 32 * BN/2 floats in all; the caller has drained every LDS user), then every lane owns 8 consecutive channels of a row --
 // split-K slab, or bias / row vector / residual and two 16-B stores -- and the per-64-row-block GroupNorm statistics.
-template <int BM, int BN>
-__device__ __forceinline__ void conv_f32_epilogue(const ConvDescH& p, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* smem, const int m0,
-                                                  const int n0, const int split, const float* bias_sel) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+template <int BM, int BN, int WVM = 2, int WVN = 2>
+__device__ __forceinline__ void conv_f32_epilogue(const ConvDescH& p, f32x16 (&acc)[BM / WVM / 32][BN / WVN / 32], unsigned char* smem,
+                                                  const int m0, const int n0, const int split, const float* bias_sel) {
+    constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;      // WVM x WVN waves, each a (TM x 32) x (TN x 32) sub-tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int wm = (wid / WVN) * WM, wn = (wid % WVN) * WN;
     const int lr = lane & 31, lk = lane >> 5;
     constexpr int LDC = WN;
     float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;
@@ -744,6 +744,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) 
 // Structure: register-staged (the split needs the values in VGPRs): 16-B global loads two k tiles ahead (two register sets), split +
 // ds_write_b64 of tile t + 1 between the MFMA groups of tile t, two LDS stages of 3 x (BM + BN) rows x 64 B with the 16-B chunk swizzle
 // p ^ ((row >> 2) & 3) (conflict-free ds_read_b128 operand fetch), one barrier per k tile.
+typedef __attribute__((address_space(1))) f32x4 gf32x4_t;
 __device__ __forceinline__ void split3_pair_h(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
     h = v2a_pack_bf16x2(x0, x1);
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
@@ -752,11 +753,13 @@ __device__ __forceinline__ void split3_pair_h(float x0, float x1, uint32_t& h, u
     l = v2a_pack_bf16x2(s0, s1);
 }
 
-template <int BM, int BN, int MINW, bool GEN>
-__global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p) {
+template <int BM, int BN, int WVM, int WVN, int MINW, bool GEN>
+__global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const ConvDescH p) {
     constexpr int EPT = 32;
-    constexpr int AL = BM / 32, BL = BN / 32;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int NT = 64 * WVM * WVN, RP = NT / 8;             // threads; tile rows one loader pass covers (8 float4 per 32-float row)
+    constexpr int AL = BM / RP, BL = BN / RP;
+    constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
+    static_assert(AL >= 1 && BL >= 1 && TM >= 1 && TN >= 1, "tile shape");
     constexpr int ROWH = 64;                                    // bytes per plane row: 32 bf16
     constexpr int PA = BM * ROWH, PB = BN * ROWH, STG = 3 * (PA + PB);
     constexpr int S = 2, STAGE = STG;                           // (names the shared epilogue's size check uses)
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p)
     int a_ihb[AL], a_iwb[AL], a_imgh[AL], a_lin1[AL], a_lin2[AL];
 #pragma unroll
     for (int j = 0; j < AL; ++j) {
-        const int m = m0 + j * 32 + lrow;
+        const int m = m0 + j * RP + lrow;
         const bool ok = m < p.M;
         const uint32_t mm = ok ? (uint32_t)m : 0u;
         const uint32_t t = fdivh(mm, p.fd_ow);
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p)
     bool b_ok[BL];
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
-        const int n = n0 + j * 32 + lrow;
+        const int n = n0 + j * RP + lrow;
         b_ok[j] = n < p.Cout;
         b_src[j] = wsel + (size_t)(b_ok[j] ? n : 0) * p.K + c4 * 4;
     }
@@ -845,14 +848,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p)
             asm volatile("" : "+v"(off));
             const float* g = src + off;
             g = ok ? g : zsrc;
-            ra[j] = *reinterpret_cast<const f32x4*>(g);
+            ra[j] = *(const gf32x4_t*)(uint64_t)g;              // (address space 1: a global_load, never a flat_load -- flat loads also count on lgkmcnt)
         }
 #pragma unroll
         for (int j = 0; j < BL; ++j) {
             uint64_t gi = (uint64_t)(b_src[j] + ik0);
             asm volatile("" : "+v"(gi));
-            const float* g = (live & b_ok[j]) ? reinterpret_cast<const float*>(gi) : zsrc;
-            rb[j] = *reinterpret_cast<const f32x4*>(g);
+            gi = (live & b_ok[j]) ? gi : (uint64_t)zsrc;
+            rb[j] = *reinterpret_cast<const gf32x4_t*>(gi);
         }
         ++it;
         ik0 += EPT;
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p)
     int w_off[AL > BL ? AL : BL];
 #pragma unroll
     for (int j = 0; j < (AL > BL ? AL : BL); ++j) {
-        const int r = j * 32 + lrow;
+        const int r = j * RP + lrow;
         w_off[j] = r * ROWH + ((((c4 >> 1) ^ ((r >> 2) & 3)) << 4) | ((c4 & 1) << 3));
     }
     auto split_store_a = [&](const f32x4 (&ra)[AL], unsigned char* stage) {
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int wm = (wid / WVN) * WM, wn = (wid % WVN) * WN;
     const int lr = lane & 31, lk = lane >> 5;
     const int rswz = (lr >> 2) & 3;                             // ((row >> 2) & 3) of every operand row this lane reads (wm, i * 32 are multiples of 16)
     int a_off[TM], b_off[TN];
@@ -960,14 +963,16 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32x3(const ConvDescH p)
         split_store_b(rb_c, oth);
         __syncthreads();
     };
+    // always in pairs (the register sets keep fixed roles at the loop header: no copies of in-flight load results); an odd slice
+    // multiplies one all-zero tile at the end
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
         step(ra1, rb1, ra0, rb0, 0);
-        if (kt + 1 < kt_end) step(ra0, rb0, ra1, rb1, 1);
+        step(ra0, rb0, ra1, rb1, 1);
     }
     // (every wave passed the loop's last barrier after its last LDS access; the trailing register loads hit the zero line)
     V2A_STAMP(3);
-    static_assert(4 * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
-    conv_f32_epilogue<BM, BN>(p, acc, smem, m0, n0, split, bias_sel);
+    static_assert(WVM * WVN * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
+    conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, bias_sel);
 }
 
 template <typename T>
@@ -1041,6 +1046,7 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
+static void f32_conv_mode_init();
 static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact switches to the exact-f32 MFMA kernels
 static int g_f32p = -1, g_f32p_s128 = 2, g_f32p_s64 = 4;   // pipelined exact-f32 conv (conv_igemm_f32p): on / stages of the 128x128 and 64x64 tiles
 static unsigned long long* g_conv_stamps = nullptr;     // v2a_debug_conv_stamps: next launch's stamp block (advanced per launch)
@@ -1168,20 +1174,26 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
             if (e3 && e3[0] == '3') g_f32p_s64 = 3;
         }
         const int f32p = g_f32p, s128 = g_f32p_s128, s64 = g_f32p_s64;
-        if (g_f32x3 < 0) {
-            const char* e = getenv("V2A_F32_CONV");
-            g_f32x3 = (e && e[0] == 'e') ? 0 : 1;
-        }
+        f32_conv_mode_init();
         if (g_f32x3) {
+            // tiles: 64 x 64 (small problems, the plan's split), 128 x 64 / 256 x 64 for 64-wide layers, 128 x 128 on 8 waves otherwise --
+            // the wider the tile, the fewer fp32 -> plane conversions and LDS bytes per MFMA
             const bool gen = ups || idil == 2;
-            if (bm == 64) {
-                if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, true>), dim3(tiles, s), dim3(256), 0, stream, p);
-                else hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, false>), dim3(tiles, s), dim3(256), 0, stream, p);
-            } else {
-                const int t64 = cdiv(p.M, 128) * cdiv(Cout, 64);      // 128 x 128 plans run as 128 x 64 tiles (two workgroups per CU)
-                if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<128, 64, 2, true>), dim3(t64, s), dim3(256), 0, stream, p);
-                else hipLaunchKernelGGL((conv_igemm_f32x3<128, 64, 2, false>), dim3(t64, s), dim3(256), 0, stream, p);
-            }
+#define V2A_X3_LAUNCH(BM_, BN_, WM_, WN_, G_)                                                                                            \
+    do {                                                                                                                                   \
+        if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, true>), dim3(G_, s), dim3(64 * WM_ * WN_), 0, stream, p);      \
+        else hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, false>), dim3(G_, s), dim3(64 * WM_ * WN_), 0, stream, p);        \
+    } while (0)
+            static int big = -1;                             // V2A_X3_BIG=0: four-wave tiles only (A/B)
+            if (big < 0) { const char* e = getenv("V2A_X3_BIG"); big = (e && e[0] == '0') ? 0 : 1; }
+            if (bm == 64) V2A_X3_LAUNCH(64, 64, 2, 2, tiles);
+            else if (bn == 64) {
+                const int t256 = cdiv(p.M, 256) * cdiv(Cout, 64);
+                if (big && t256 >= 200 && p.M % 256 == 0 && p.frame_tiles == 0) V2A_X3_LAUNCH(256, 64, 4, 2, t256);
+                else V2A_X3_LAUNCH(128, 64, 2, 2, tiles);
+            } else if (big) V2A_X3_LAUNCH(128, 128, 2, 4, tiles);
+            else V2A_X3_LAUNCH(128, 64, 2, 2, cdiv(p.M, 128) * cdiv(Cout, 64));
+#undef V2A_X3_LAUNCH
             goto launched;
         }
         if (f32p) {
@@ -1238,10 +1250,21 @@ int v2a_get_half_format(void) { return g_v2a_half_f16; }
 // tuning aid: on = 0 routes fp32 LDS-DMA convs to conv_igemm_h<.., float> (rounds 1-3), 1 to conv_igemm_f32p; s128 in {2, 3}, s64 in {3, 4}
 // = LDS stages of the 128 x 128 / 64 x 64 tiles (0 keeps the current value).  Returns the previous `on`.
 // fp32 LDS-DMA convs: 1 = by three bf16 planes (conv_igemm_f32x3, default), 0 = exact-f32 MFMA kernels.  Returns the old value.
+static void f32_conv_mode_init() {
+    if (g_f32x3 < 0) {
+        const char* e = getenv("V2A_F32_CONV");
+        g_f32x3 = (e && e[0] == 'e') ? 0 : 1;
+    }
+}
 int v2a_set_f32_conv_mode(int x3) {
-    const int old = g_f32x3 < 0 ? 1 : g_f32x3;
+    f32_conv_mode_init();
+    const int old = g_f32x3;
     g_f32x3 = x3 ? 1 : 0;
     return old;
+}
+int v2a_get_f32_conv_mode(void) {
+    f32_conv_mode_init();
+    return g_f32x3;
 }
 int v2a_debug_f32p(int on, int s128, int s64) {
     const int old = g_f32p < 0 ? 1 : g_f32p;

@@ -207,8 +207,11 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     if x2 is not None:
         _chk(x2, "x2")
         C2 = x2.shape[-1]
+    # (with the three-plane fp32 products every eligible shape takes this route, however small: a layer must not change its
+    # arithmetic with the batch size -- the data-parallel equality test compares B rows on one rank with B/2 on two)
     if (bmode == 0 and y2 is None and not csplit and C1 % 32 == 0 and C2 % 32 == 0 and idil in (1, 2) and not (ups and idil > 1)
-            and N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] and lib.v2a_get_precision() == 0):
+            and (N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] or lib.v2a_get_f32_conv_mode() == 1)
+            and lib.v2a_get_precision() == 0):
         return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y,
                                defer=defer, want_stats=want_stats)
     if want_stats:     # only the LDS-DMA fp32 kernel emits statistics
