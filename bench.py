@@ -59,6 +59,81 @@ def _leg_traffic(leg, batch_scale=1.0):
         return None
 
 
+# ---------------------------------------------------------------------------------------------------------------- output line
+# The driver keeps the last 8 KB of stdout: the FULL record (every note, every conv variant) goes to bench_full_last.json + stderr, the
+# line on stdout is the same record with prose dropped, floats rounded to 5 significant digits and long strings cut -- so that the
+# bf16 leg, the sampler legs, predict_action and every cpu_baseline survive in the driver's copy.
+_DROP = {"note", "timing", "isolation", "traffic_source", "source", "settings", "all_conv_variants", "hbm_bytes_incl_setup_of_the_profiled_run",
+         "per", "cpu_model_detail", "image", "action"}
+_KEEP_STR = 110
+
+
+def _round5(x):
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.5g}")
+    return x
+
+
+def _compact(o, depth=0):
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if k in _DROP:
+                continue
+            out[k] = _compact(v, depth + 1)
+        return out
+    if isinstance(o, (list, tuple)):
+        return [_compact(v, depth + 1) for v in o][:12]
+    if isinstance(o, str):
+        return o if len(o) <= _KEEP_STR else o[:_KEEP_STR - 1] + "~"
+    return _round5(o)
+
+
+def _emit(out):
+    full = json.dumps(out)
+    try:
+        with open(os.path.join(ROOT, "bench_full_last.json"), "w") as f:
+            f.write(full + "\n")
+    except Exception:
+        pass
+    print("[bench full record] " + full, file=sys.stderr)
+    line = _compact(out)
+    if isinstance(out.get("roofline"), dict) and "all_conv_variants" in out["roofline"]:      # the three largest families, by time
+        top = sorted(out["roofline"]["all_conv_variants"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
+        line["roofline"]["top_conv_variants"] = {k: _compact(v) for k, v in top}
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > 7600:                          # last resort: shed the per-leg configs, then the per-leg rooflines of secondary legs
+        for leg in list(line):
+            if isinstance(line[leg], dict) and leg not in ("config", "roofline", "cpu_baseline"):
+                line[leg].pop("config", None)
+        txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > 7600:
+        for leg in ("video_bf16_ddpm100", "video_c5", "video_c5_fp16", "video_fp16", "video_round8"):
+            if isinstance(line.get(leg), dict):
+                line[leg] = {k: v for k, v in line[leg].items() if k in ("value", "unit", "seconds_per_sample_call", "algorithmic_tflops", "error")}
+        txt = json.dumps(line, separators=(",", ":"))
+    print(txt)
+
+
+def _graph_avg_us(kernel_prefix, csv_name="r04_policy_kernel_stats.csv"):
+    """Average duration (us) of the launches whose name starts with kernel_prefix in the committed rocprofv3 --kernel-trace --stats summary
+    of the captured step (profiles/): the figure INSIDE the replayed graph, next to the eager-pass figure this run measures."""
+    import csv
+    try:
+        tot, n = 0.0, 0
+        key = kernel_prefix.replace(" ", "")
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", csv_name))):
+            name = r["Name"].replace("void ", "").replace(" ", "")
+            if name.startswith(key):
+                tot += float(r["TotalDurationNs"])
+                n += int(r["Calls"])
+        return (tot / n / 1e3) if n else None
+    except Exception:
+        return None
+
+
 def build_store(torch, device, batch, seed):
     from v2a_hip.replay import ReplayStore
     n_eps, ep_len = 8 * 50, 121
@@ -123,7 +198,8 @@ def instrumented_pass(torch, trainer, steps):
             x, dy = c["x"], c["dy"]
             c2 = c["x2"].shape[-1] if c["x2"] is not None else 0
             fl += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * c["KH"] * c["KW"] * (x.shape[-1] + c2)
-        name = "conv_wgrad_multi_halo" if calls[0]["variant"] >= 3 else "conv_wgrad_multi"
+        v0 = calls[0]["variant"]
+        name = "conv_wgrad_multi_x3" if v0 >= 6 else ("conv_wgrad_multi_halo" if v0 >= 3 else "conv_wgrad_multi")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         orig_axpy(blk_a, blk_b, 1.0, out=blk_b)
         e0.record()
@@ -689,7 +765,10 @@ def main():
         flops_step = 8.722e9 * args.batch                  # fwd+bwd algorithmic FLOPs per sample
         out = {"metric": "policy_train_steps_per_sec", "value": value, "unit": f"steps/s (batch-{args.batch} steps, all ranks)", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 (MFMA inputs; f32 accumulate, f32 storage/optimizer)", "data": "synthetic",
+               "vs_baseline": None,
+               "dtype": ("f32 (f32 storage / accumulate / optimiser; conv products from three bf16 planes per operand = fp32-equivalent accuracy, "
+                         "V2A_F32_CONV=exact selects the exact-f32 MFMA kernels)") if args.precision == "fp32"
+               else "bf16 (MFMA inputs; f32 accumulate, f32 storage/optimizer)", "data": "synthetic",
                "config": {"workload": "Libero 8-task diffusion-policy train step (BASELINE.json configs[1]): R1 replay gather -> "
                                       "compute_loss fwd/bwd -> clip -> AdamW -> EMA", "batch_per_gpu": args.batch,
                           "global_batch": args.batch * world, "image": "128x128x3 uint8 start+goal", "action": "16x7",
@@ -739,9 +818,17 @@ def main():
             tot = sum(v[1] for v in agg.values())
             name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
             achieved = fl / sec / 1e12
-            peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+            x3 = "f32x3" in name                     # fp32 products from three bf16 planes: six bf16 MFMAs per product block
+            peak = (BF16_MFMA_PEAK_TFLOPS / 6.0) if x3 else (FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS)
+            g_us = _graph_avg_us(name.rstrip(">") + ",") or _graph_avg_us(name.rstrip(">") + ">")
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                               "frac": achieved / peak, "traffic": _traffic("policy", name), "traffic_source": TRAFFIC_SOURCE,
+                               "frac": achieved / peak,
+                               "peak_is": ("dense bf16 MFMA peak 2500 / 6 plane products per fp32 product (conv_igemm_f32x3)" if x3 else
+                                           "dense MFMA peak of the dtype"),
+                               "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else None,
+                               "frac_in_graph": ((fl / cnt) / (g_us * 1e-6) / 1e12 / peak) if g_us else None,
+                               "avg_launch_us_in_graph": g_us,
+                               "traffic": _traffic("policy", name), "traffic_source": TRAFFIC_SOURCE,
                                "traffic_vs_algorithmic": _leg_traffic("policy") if (args.batch == 64 and args.precision == "fp32") else None,
                                "launches": cnt, "avg_launch_us": sec / cnt * 1e6, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
                                "share_of_conv_time": sec / tot, "whole_step_frac_of_mfma_floor": flops_step / (ms * 1e-3) / 1e12 / peak,
@@ -801,6 +888,76 @@ def main():
             pass
         except Exception as e:                      # never let the secondary leg break the headline line
             out["predict_action"] = {"error": f"{type(e).__name__}: {e}"}
+        # ---- BASELINE configs[4], policy half at one GPU's share: B = 256 (fp32 and the 16-bit modes), with its rooflines
+        def policy_leg(prec, batch, steps=6, warm=3, dp=False):
+            v2a_hip.set_precision("bf16" if prec in ("bf16", "fp16") else "fp32")
+            if prec in ("bf16", "fp16") and hasattr(v2a_hip, "set_policy_half"):
+                v2a_hip.set_policy_half(prec)
+            torch.manual_seed(0)
+            polx = build_policy(DEFAULT_CONF).to(device)
+            stx = build_store(torch, device, batch, seed=100) if batch != args.batch else store
+            kw = {}
+            if dp:
+                import torch.distributed as dist
+                if not dist.is_initialized():
+                    import socket
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        port = sk.getsockname()[1]
+                    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(device))
+                os.environ["V2A_FORCE_DP"] = "1"
+                kw = dict(process_group=dist.group.WORLD, world_size=1)
+            try:
+                trx = PolicyTrainer(polx, stx, batch_size=batch, seed=0, use_graph=not args.no_graph, **kw)
+            finally:
+                os.environ.pop("V2A_FORCE_DP", None)
+            for _ in range(max(warm, 3)):
+                trx.step()
+            if dp:
+                trx.phase_events, trx.comm_events = [], []
+            dtx, medx = _timed_policy_steps(torch, trx, steps, barrier)
+            msx = dtx / steps * 1e3
+            r = {"ms_per_step": msx, "ms_per_step_median_hip_events": medx, "value": steps / dtx, "unit": f"steps/s (batch-{batch})",
+                 "samples_per_sec": steps / dtx * batch, "batch": batch, "precision": prec, "final_loss": float(trx.loss.item())}
+            flx = 8.722e9 * batch
+            if prec == "fp32":
+                r["whole_step_frac_of_f32_mfma_floor"] = flx / (msx * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS
+            else:
+                albytes = 64.0 * 87219143 + 3 * 3.326e6 * batch * 4
+                r["roofline"] = {"bound": "hbm", "achieved": albytes / (msx * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": albytes / (msx * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": albytes}
+            if dp:
+                torch.cuda.synchronize()
+                ph = [[a.elapsed_time(b) for a, b in zip(pe[:-1], pe[1:])] for pe in trx.phase_events]
+                med = [_median([p_[i] for p_ in ph]) for i in range(4)] if ph else [None] * 4
+                sl = [hi - lo for lo, hi in trx.reducer.slices]
+                r.update({"graph_phase1_ms": med[0], "graph_encoder_backward_ms": med[1], "reduce_wait_ms": med[2], "graph_optimiser_ms": med[3],
+                          "slice_elems": sl,
+                          "slice0_window_ms": med[1],
+                          "exposed_comm_estimate_ms_at_8_gpus": {
+                              w: max(0.0, 2 * 7 / 8 * sl[0] * b / 153e9 * 1e3 - (med[1] or 0.0)) + 2 * 7 / 8 * sl[1] * b / 153e9 * 1e3
+                              for w, b in (("fp32_wire", 4), ("bf16_wire", 2))},
+                          "estimate_assumes": "ring all-reduce bound by ONE xGMI link at 153 GB/s (2 (N-1)/N x bytes / link); slice 0 hides under the "
+                                              "encoder-backward graph, slice 1 is exposed"})
+            del trx, polx
+            v2a_hip.set_precision("fp32")
+            return r
+
+        def leg0(key, fn):
+            try:
+                torch.cuda.empty_cache()
+                out[key] = fn()
+            except Exception as e:
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
+
+        if not args.no_bf16_extra and args.batch == 64:
+            leg0("policy_b256", lambda: {"workload": "BASELINE configs[4] policy half at one GPU's share: batch 256",
+                                         "fp32": policy_leg("fp32", 256), "bf16": policy_leg("bf16", 256),
+                                         **({"fp16": policy_leg("fp16", 256)} if hasattr(v2a_hip, "set_policy_half") else {})})
+            # the data-parallel step STRUCTURE on one rank (three graphs + two slice all-reduces through RCCL with one rank): its cost
+            # per GPU against the one-graph step above, and the window the encoder backward leaves for slice 0
+            leg0("dp_structure", lambda: dict(policy_leg("fp32", args.batch, steps=10, dp=True), one_graph_ms_per_step=ms,
+                                              workload="V2A_FORCE_DP step structure, one rank, RCCL"))
         if not args.no_video:
             del tr, pol, store
             torch.cuda.empty_cache()
@@ -835,6 +992,27 @@ def main():
                     r["ms_per_denoise_step"] = r["seconds_per_sample_call"] * 1e3 / 100
                     return r
                 leg("video_b1", b1)
+                # an exploration round = 8 per-task rollouts (lb_online_trainer_v7.py:871,888-891): one after another (what the reference
+                # issues) against ONE B = 8 call of the same sampler
+                def round8():
+                    r = _as_bf16(video_leg(torch, device, 8, 100, reps=2, roofline=False,
+                                           workload="exploration round as ONE call: bs = 8, 100 ancestral steps"), note16)
+                    one = out.get("video_b1", {}).get("seconds_per_sample_call")
+                    r["seconds_8_rollouts_as_one_b8_call"] = r["seconds_per_sample_call"]
+                    r["seconds_8_rollouts_one_after_another"] = 8 * one if one else None
+                    return r
+                leg("video_round8", round8)
+                try:                                     # BASELINE configs[3] arithmetic at ONE GPU: policy steps + one round per 200 steps
+                    every = 200
+                    t8 = out["video_round8"]["seconds_per_sample_call"]
+                    t1 = out["video_b1"]["seconds_per_sample_call"] * 8
+                    out["joint"] = {"workload": "BASELINE configs[3] at one GPU: policy train steps + one video-guided exploration round (8 tasks, "
+                                                "100 ancestral steps) every 200 steps", "rollout_every_steps": every,
+                                    "steps_per_sec_incl_sampling_rollouts_one_by_one": every / (every * ms * 1e-3 + t1),
+                                    "steps_per_sec_incl_sampling_one_b8_call": every / (every * ms * 1e-3 + t8),
+                                    "sampler_seconds_per_round_one_by_one": t1, "sampler_seconds_per_round_b8": t8}
+                except Exception as e:
+                    out["joint"] = {"error": f"{type(e).__name__}: {e}"}
                 # BASELINE configs[4], video half at a 1-GPU slice: 256x256, 16-frame sequence (1 cond + 15 predicted), per-GPU batch 2
                 leg("video_c5", lambda: _as_bf16(video_leg(
                     torch, device, 2, args.video_steps, size=256, frames=15, reps=R, roofline=False,
@@ -856,9 +1034,14 @@ def main():
                 except Exception as e:
                     out["video_train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
-        print(json.dumps(out))
+        _emit(out)
     sys.stdout.flush()
-    if world > 1 or force_dp:
+    try:
+        import torch.distributed as _d
+        made_pg = _d.is_available() and _d.is_initialized()
+    except Exception:
+        made_pg = False
+    if world > 1 or force_dp or made_pg:
         import torch.distributed as dist
         try:                                   # the result line is out: never let communicator teardown turn into a failure
             torch.cuda.synchronize()

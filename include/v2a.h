@@ -163,8 +163,9 @@ int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* i
  * is replayed for every step of p_sample_loop / ddim_sample (:582-641).  table_dev: rows of v2a_video_denoise_row_bytes() bytes =
  * {sa, s1, ra, rm, c1, c2, sigma, gw: float; mode, final, t, pad: int32} (coefficient meaning as v2a_video_denoise_step).  state_dev:
  * uint64[3] = {current row, Philox seed, Philox counter of the initial image} or NULL (row step_imm).  noise: explicit tensor, or NULL
- * with use_philox = 1: drawn in the kernel (the values v2a_philox_normal(seed, state[2] + (row + 1) * ceil(total / 4)) would write), not
- * drawn at all where sigma = 0.  `out` may alias `img`. */
+ * with use_philox bit 0 set: drawn in the kernel (the values v2a_philox_normal(seed, state[2] + (row + 1) * ceil(total / 4)) would write),
+ * not drawn at all where sigma = 0.  use_philox bit 1: the table holds guided rows (gw > 0) -- v_uncond is then mandatory (V2A_ERR_ARG
+ * when null; without the bit the kernel never reads v_uncond).  `out` may alias `img`. */
 int v2a_video_denoise_row_bytes(void);
 int v2a_video_denoise_step2(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                             int frame_ch, int objective, const void* table_dev, const uint64_t* state_dev, int step_imm, int use_philox,
@@ -384,6 +385,7 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
                               int* variant_out, int* tiles_out, int* rtiles_out, int* splits_out, void* ritem_out, int* rblocks_out,
                               int* rform_out);
 int v2a_wgrad_multi_max(void);
+int v2a_wgrad_family(int variant);   /* kernel family of a described gradient (one family per v2a_conv2d_wgrad_multi launch): 0 exact 64x64 / twin-fed, 1 halo, 2 / 3 three-bf16-plane 64x64 / 128x128 */
 int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* tiles, int n, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- random-action episode file (csrc/h5read.hip)

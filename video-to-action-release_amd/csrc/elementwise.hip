@@ -392,7 +392,7 @@ __global__ void video_denoise_kernel2(const float* v, const float* v_u, const fl
             const float x = img[i];
             float x0, eps;
             if (objective == 2) {
-                if (k.gw > 0.f) {
+                if (k.gw > 0.f && v_u) {
                     const float x0c = k.sa * x - k.s1 * v[vi];
                     const float x0u = k.sa * x - k.s1 * v_u[vi];
                     const float nu = (k.ra * x - x0u) / k.rm;
@@ -405,7 +405,7 @@ __global__ void video_denoise_kernel2(const float* v, const float* v_u, const fl
                 }
             } else {
                 float mo = v[vi];
-                if (k.gw > 0.f) mo = (1.f + k.gw) * mo - k.gw * v_u[vi];
+                if (k.gw > 0.f && v_u) mo = (1.f + k.gw) * mo - k.gw * v_u[vi];
                 if (objective == 0) { eps = mo; x0 = k.ra * x - k.rm * eps; }
                 else { x0 = mo; eps = (k.ra * x - x0) / k.rm; }
             }
@@ -689,9 +689,12 @@ int v2a_video_denoise_step2(const float* v, const float* v_uncond, const float* 
                             int frame_ch, int objective, const void* table_dev, const uint64_t* state_dev, int step_imm, int use_philox,
                             hipStream_t s) {
     if (!v || !img || !out || !table_dev || objective < 0 || objective > 2) return V2A_ERR_ARG;
+    // use_philox: bit 0 = draw the noise in the kernel; bit 1 = the device table holds guided rows (gw > 0) -- the host cannot read
+    // the table, so the caller says so, and the unconditional half is then mandatory (the kernel would dereference null)
+    if ((use_philox & 2) && !v_uncond) return V2A_ERR_ARG;
     const size_t total = (size_t)B * f * frame_ch * HW;
-    hipLaunchKernelGGL(video_denoise_kernel2, GRID_FOR((total + 3) / 4), dim3(256), 0, s, v, v_uncond, img, noise, out, B, f, HW, frame_ch,
-                       objective, (const DenoiseRow*)table_dev, state_dev, step_imm, use_philox);
+    hipLaunchKernelGGL(video_denoise_kernel2, GRID_FOR((total + 3) / 4), dim3(256), 0, s, v, (use_philox & 2) ? v_uncond : nullptr, img, noise,
+                       out, B, f, HW, frame_ch, objective, (const DenoiseRow*)table_dev, state_dev, step_imm, use_philox & 1);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -706,12 +709,14 @@ int v2a_emb_linear_multi_max(void) { return EMB_MAX; }
 int v2a_emb_linear_multi(const float* x, int B, int K, const float* const* w, const float* const* bias, float* const* out, const int* couts,
                          int n, hipStream_t s) {
     if (!x || !w || !bias || !out || !couts || n < 1 || n > EMB_MAX || B < 1 || B > 16 || K % 256 || K < 256 || K > 1024) return V2A_ERR_ARG;
+    if (((uintptr_t)x & 15) != 0) return V2A_ERR_ARG;
     EmbMultiArgs a;
     __builtin_memset(&a, 0, sizeof(a));
     a.n = n; a.B = B; a.K = K;
     int tot = 0;
     for (int i = 0; i < n; ++i) {
         if (!w[i] || !out[i] || couts[i] < 1) return V2A_ERR_ARG;
+        if (((uintptr_t)w[i] & 15) != 0) return V2A_ERR_ARG;         // the kernel reads weight rows with 16-B loads (K % 256 == 0 keeps rows aligned)
         a.w[i] = w[i]; a.bias[i] = bias[i]; a.out[i] = out[i];
         tot += couts[i];
         a.col_end[i] = tot;

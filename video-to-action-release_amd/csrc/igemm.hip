@@ -1283,6 +1283,191 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
     }
 }
 
+// ---- fp32 weight gradient by three bf16 planes (round 4; the weight-gradient form of csrc/igemm_h.hip conv_igemm_f32x3).
+// dW[co][k'] = sum_r dY[r][co] * X[r][k']: both operands are k-major in HBM (rows = reduction index r), the bf16 MFMA wants 8 consecutive
+// r per lane -- the loader of conv_wgrad_bf16 above: a thread owns an 8 (rows) x 4 (channels) register block (8 coalesced 16-B loads),
+// here split into hi / mid / lo planes (x = hi + mid + lo exactly, see conv_igemm_f32x3) and written as 4 x 3 16-B LDS stores of 8 values
+// along r; a product block = the six plane products of weight >= 2^-16, smallest first.  fp32-equivalent accuracy (not bit-equal to the
+// exact-f32 kernels: V2A_F32_CONV=exact keeps those).  Row decode of the gathered operand is incremental (one division pair per 8 rows).
+template <int BM, int BN>
+__device__ __forceinline__ void wgrad_x3_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
+    constexpr int BKT = 32, LDH = 40;                           // 32 reduction rows per tile; 40 halves = 80-B LDS rows
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int PA = BM * LDH, PB = BN * LDH, STG = 3 * (PA + PB);      // halves per plane / per stage
+    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.K + BN - 1) / BN;
+    const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
+    const int Cin = p.C1 + p.C2;
+    const int nrt = (p.M + BKT - 1) / BKT;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    // loader roles: threads [0, BM) own dY columns, [BM, BM + BN) own gathered-input columns: 4 channels x 8 rows each (a 64 x 64 tile
+    // keeps half of the workgroup's threads out of the loads, as conv_wgrad_bf16 does)
+    const bool isA = tid < BM;
+    const bool isB = !isA && tid < BM + BN;
+    const int t2 = isA ? tid : tid - BM;
+    const int c4 = isA ? t2 % (BM / 4) : t2 % (BN / 4);
+    const int rgrp = isA ? t2 / (BM / 4) : t2 / (BN / 4);
+    int b_kh = 0, b_kw = 0, b_c = 0;
+    bool b_kok = false;
+    if (isB) {
+        const int k = n0 + c4 * 4;
+        b_kok = k < p.K;
+        const int kk = b_kok ? k : 0;
+        const int tap = kk / Cin;
+        b_c = kk - tap * Cin;
+        b_kh = tap / p.KW;
+        b_kw = tap - b_kh * p.KW;
+    }
+    const bool b_first = b_c < p.C1;
+    const float* b_base = b_first ? p.x + b_c : p.x2 + (b_c - p.C1);
+    const int b_Cs = b_first ? p.C1 : p.C2;
+    const int a_co = m0 + c4 * 4;
+    const bool a_cok = isA && a_co < p.Cout;
+    const bool do_bias = (p.dbias != nullptr) && (tile_id % tiles_n == 0);
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rv[8];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int rt) {
+        const int r0 = rt * BKT + rgrp * 8;
+        if (isA) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = r0 + e;
+                f32x4 v = zero4;
+                if (r < p.M && a_cok) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)r * p.Cout + a_co);
+                rv[e] = v;
+                if (do_bias) bsum += v;
+            }
+        } else if (isB) {
+            const uint32_t rr = r0 < p.M ? (uint32_t)r0 : 0u;
+            const uint32_t t = fdiv(rr, p.fd_ow);
+            int ow = (int)(rr - t * p.OW);
+            int img = (int)fdiv(t, p.fd_oh);
+            int oh = (int)t - img * p.OH;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = r0 + e;
+                f32x4 v = zero4;
+                int ih = oh * p.sh - p.ph + b_kh, iw = ow * p.sw - p.pw + b_kw;
+                bool ok = r < p.M && b_kok && ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
+                if (p.idil > 1) {
+                    ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
+                    ih /= p.idil;
+                    iw /= p.idil;
+                }
+                if (p.ups) { ih >>= 1; iw >>= 1; }
+                if (ok) v = *reinterpret_cast<const f32x4*>(b_base + ((size_t)(img * p.H + ih) * p.W + iw) * b_Cs);
+                rv[e] = v;
+                if (++ow == p.OW) {                             // next reduction row: (img, oh, ow) advance without a division
+                    ow = 0;
+                    if (++oh == p.OH) { oh = 0; ++img; }
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (isA || isB) {
+            uint16_t* dst = lds + buf * STG + (isA ? 0 : 3 * PA) + (c4 * 4) * LDH + rgrp * 8;
+            const int pl = isA ? PA : PB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t h[4], m[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split3_pair(rv[2 * q][j], rv[2 * q + 1][j], h[q], m[q], l[q]);
+                *reinterpret_cast<uint4*>(dst + j * LDH) = uint4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<uint4*>(dst + pl + j * LDH) = uint4{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<uint4*>(dst + 2 * pl + j * LDH) = uint4{l[0], l[1], l[2], l[3]};
+            }
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    if (rt_begin < rt_end) {
+        load_tile(rt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        const bool more = (rt + 1) < rt_end;
+        if (more) load_tile(rt + 1);
+        const uint16_t* A = lds + buf * STG;
+        const uint16_t* B = A + 3 * PA;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[3][TM], b[3][TN];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8*>(&A[q * PA + (wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8*>(&B[q * PB + (wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);     // lo  * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);     // hi  * lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // mid * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);     // mid * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);     // hi  * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);     // hi  * hi
+                    acc[i][j] = c;
+                }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int k = n0 + wn + j * 32 + lr;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co >= p.Cout) continue;
+                if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[i][j][r];
+                else wgrad_store(p, co, k, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);            // [4][BM] floats
+        if (isA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[rgrp * BM + c4 * 4 + j] = bsum[j];
+        }
+        __syncthreads();
+        if (tid < BM) {
+            const float t = red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid];
+            const int co = m0 + tid;
+            if (co < p.Cout) {
+                if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = t;
+                else p.dbias[co] = p.accumulate ? p.dbias[co] + t : t;
+            }
+        }
+    }
+}
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_x3(const WgradDesc p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * (BM + BN) * 40 * 2];
+    wgrad_x3_body<BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+
 // bf16-MFMA weight gradient fed from bf16 TWINS of the operands (x_h / dy_h: the rounded copies the bf16 forward / data-gradient convs
 // already made), instead of converting fp32 while staging: the kernel above is bound by operand traffic through the L2 fabric (32 KB
 // per workgroup per 256 MFMA cycles), so half the bytes is the lever.  Loader thread = 4 reduction rows x 8 channels (one 16-B load per
@@ -1668,6 +1853,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_multi_halo_kernel(const Wgr
     if (v == 3) wgrad_halo_body<32>(a.d[i], tile, split, smem);
     else if (v == 4) wgrad_halo_body<16>(a.d[i], tile, split, smem);
     else wgrad_halo_body<8>(a.d[i], tile, split, smem);
+}
+
+// The same for the three-bf16-plane body (variants 6: 64 x 64 tiles, 7: 128 x 128 tiles; one tile shape per launch).
+template <int BT>
+__global__ __launch_bounds__(256, BT == 64 ? 2 : 1) void conv_wgrad_multi_x3_kernel(const WgradMultiArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * (2 * BT) * 40 * 2];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < a.n && bid >= a.wg_end[i]) ++i;
+    const int first = i ? a.wg_end[i - 1] : 0;
+    const int nwg = a.wg_end[i] - first, tiles = a.tiles[i];
+    const int lin = nwg >= 8 ? xcd_remap(bid - first, nwg) : bid - first;
+    const int split = lin / tiles, tile = lin - split * tiles;
+    wgrad_x3_body<BT, BT>(a.d[i], tile, split, smem);
 }
 
 __device__ __forceinline__ void wgrad_reduce_body(const WgradDesc& p, const unsigned bid, const unsigned nblk) {
@@ -2362,6 +2561,18 @@ int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwor
 // `slabs` (the layer's own scratch, >= (splits * Cout * K + splits * Cout) * 4 bytes when splits > 1) is entered, item_out (HOST,
 // v2a_wgrad_item_bytes()) receives the main-kernel descriptor, *splits_out the split actually used (capped so that every slice keeps
 // work), and ritem_out / *rblocks_out / *rform_out the reduce item for v2a_wgrad_reduce_multi (rblocks 0: nothing to reduce).
+extern "C" int v2a_get_f32_conv_mode(void);
+static int g_wgrad_x3 = -1;
+static bool wgrad_x3_on() {
+    if (g_wgrad_x3 < 0) {
+        const char* e = getenv("V2A_WGRAD_X3");
+        g_wgrad_x3 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_wgrad_x3 == 1;
+}
+// kernel family of a grouped-launch variant: 0 = 64x64 exact / twin-fed bodies (0-2), 1 = halo body (3-5), 2 / 3 = three-plane bodies (6 / 7)
+static int wgrad_family(int v) { return v <= 2 ? 0 : (v <= 5 ? 1 : (v == 6 ? 2 : 3)); }
+int v2a_wgrad_family(int variant) { return wgrad_family(variant); }
 int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, const void* x_h, const void* x2_h, const void* dy_h, float* dw,
                               float* dbias, int N, int H, int W, int C1, int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph,
                               int pw, int idil, int ups, int accumulate, int want_splits, void* slabs, size_t slab_bytes, void* item_out,
@@ -2395,11 +2606,14 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
             OW == W && C1 % 64 == 0 && Cout % 64 == 0 && p.M % 32 == 0 && (OW == 8 || OW == 16 || OW % 32 == 0) &&
             OH % (OW >= 32 ? 1 : 32 / OW) == 0 && big < 2147483648.0)
             variant = OW == 8 ? 5 : (OW == 16 ? 4 : 3);
+        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on())         // fp32 products from three bf16 planes (V2A_WGRAD_X3=0: exact bodies)
+            variant = (Cout >= 128 && p.K >= 128) ? 7 : 6;
     }
     *variant_out = variant;
     if (variant < 0) { *tiles_out = 0; *rtiles_out = 0; return V2A_OK; }
     const int rrows = (variant == 1 || variant == 2) ? 64 : 32;
-    const int tiles = variant == 0 ? cdiv(Cout, 64) * cdiv(p.K, 64)
+    const int tiles = (variant == 0 || variant == 6) ? cdiv(Cout, 64) * cdiv(p.K, 64)
+                      : variant == 7 ? cdiv(Cout, 128) * cdiv(p.K, 128)
                       : (variant >= 3 ? (Cout / 64) * (C1 / 64) : cdiv(Cout, variant == 1 ? 128 : 64) * cdiv(p.K, 128));
     const int nrt = cdiv(p.M, rrows);
     *tiles_out = tiles;
@@ -2439,15 +2653,18 @@ int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* ti
     int tot = 0;
     for (int i = 0; i < n; ++i) {
         a.d[i] = reinterpret_cast<const WgradDesc*>(items)[i];
-        if (variants[i] < 0 || variants[i] > 5 || tiles[i] < 1 || a.d[i].splits < 1) return V2A_ERR_ARG;
-        if ((variants[i] >= 3) != (variants[0] >= 3)) return V2A_ERR_ARG;      // one kernel family per launch
+        if (variants[i] < 0 || variants[i] > 7 || tiles[i] < 1 || a.d[i].splits < 1) return V2A_ERR_ARG;
+        if (wgrad_family(variants[i]) != wgrad_family(variants[0])) return V2A_ERR_ARG;      // one kernel family per launch
         a.variant[i] = variants[i];
         a.tiles[i] = tiles[i];
         tot += tiles[i] * a.d[i].splits;
         a.wg_end[i] = tot;
     }
     for (int i = n; i < WGM_MAX; ++i) a.wg_end[i] = tot;
-    if (variants[0] >= 3) hipLaunchKernelGGL(conv_wgrad_multi_halo_kernel, dim3(tot), dim3(256), 0, stream, a);
+    const int fam = wgrad_family(variants[0]);
+    if (fam == 3) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<128>, dim3(tot), dim3(256), 0, stream, a);
+    else if (fam == 2) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<64>, dim3(tot), dim3(256), 0, stream, a);
+    else if (fam == 1) hipLaunchKernelGGL(conv_wgrad_multi_halo_kernel, dim3(tot), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3(tot), dim3(256), 0, stream, a);
     V2A_CHECK_LAUNCH();
     return V2A_OK;

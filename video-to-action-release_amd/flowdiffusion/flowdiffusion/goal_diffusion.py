@@ -14,6 +14,20 @@ import torch.nn.functional as F
 
 import weakref
 
+def _draw_philox_seed(device):
+    """62-bit Philox seed of one sample() call, taken from the DEVICE generator's (seed, offset) pair, which is then advanced:
+    torch.manual_seed / torch.cuda.manual_seed reproduce a call, consecutive calls differ, and the global CPU generator -- the replay
+    and data-sampling stream -- is left alone (round 3 drew one CPU torch.randint per call)."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    s0, off = int(gen.initial_seed()), int(gen.get_offset())
+    gen.set_offset(off + 4)                                  # Philox offsets advance in multiples of 4
+    z = (s0 ^ ((off + 0x9E3779B97F4A7C15) * 0xBF58476D1CE4E5B9)) & ((1 << 64) - 1)      # splitmix64 finaliser of (seed, offset)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & ((1 << 64) - 1)
+    return int((z ^ (z >> 31)) & ((1 << 62) - 1))
+
+
+_SGRAPH_KEEP = 4                           # captured sampler graphs kept per model (alternating batch sizes re-use theirs)
 _SGRAPHS = weakref.WeakKeyDictionary()      # GoalGaussianDiffusion -> its captured sampler step (kept out of the module: deepcopy / state_dict)
 
 
@@ -206,7 +220,7 @@ class GoalGaussianDiffusion(nn.Module):
         if hook is None:
             # sampler noise = counter-based Philox, seeded from torch's generator (torch.manual_seed reproduces a call); the initial
             # image uses counters [off0, off0 + nq), step s the next block -- drawn inside the denoise kernel
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            seed = _draw_philox_seed(device)
             off0 = 0
         if not use_graph:
             label = eng.label_embedding(task_embed)                               # t-independent: once per call
@@ -236,7 +250,7 @@ class GoalGaussianDiffusion(nn.Module):
                 if state is not None:
                     state[0] = i
                 img = ops.video_denoise_step2(v, vu, img, noise, table, self.objective, f, H * W, ci, state=state, step=i,
-                                              use_philox=hook is None)
+                                              use_philox=hook is None, guided=gw > 0.0)
                 imgs.append(img)
             if return_all_timesteps:
                 ret = torch.stack(imgs, dim=1)
@@ -244,12 +258,20 @@ class GoalGaussianDiffusion(nn.Module):
             return img
         # ---- whole-loop hipGraph
         key = (B, C, H, W, ci, gw > 0.0, self.objective, getattr(eng, "storage", "f32"), v2a_hip.get_precision(), tuple(task_embed.shape),
-               id(eng), self._weights_version())
-        g = _SGRAPHS.get(self)
-        if g is None or g["key"] != key:
-            _SGRAPHS.pop(self, None)
+               id(eng), len(rows), self._weights_version())
+        ent = _SGRAPHS.get(self)
+        if ent is None:
+            ent = _SGRAPHS[self] = {"lru": {}, "graph": None}
+        lru = ent["lru"]
+        g = lru.pop(key, None)
+        if g is None:
+            for k in [k for k in lru if k[-1] != key[-1]]:     # graphs captured over other weights can never match again
+                del lru[k]
+            while len(lru) >= _SGRAPH_KEEP:                    # least recently used first (dict order = use order)
+                del lru[next(iter(lru))]
             g = self._build_sampler_graph(key, eng, shape, ci, f, task_embed.shape, gw)
-            _SGRAPHS[self] = g
+        lru[key] = g
+        ent["graph"] = g["graph"]                              # the graph this call replays (tests look at it)
         g["x_cond"].copy_(x_cond)
         if not torch.equal(g["task_embed"], task_embed):          # the text branch does not depend on t: recomputed only when it changes
             g["task_embed"].copy_(task_embed)
@@ -258,7 +280,6 @@ class GoalGaussianDiffusion(nn.Module):
         g["state"].copy_(torch.tensor([0, seed, off0], dtype=torch.int64))
         g["tt"].fill_(rows[0][10])
         ops.philox_normal(g["img"], seed, offset_imm=off0)
-        g["nrows"][0] = len(rows)
         for _ in range(len(rows)):
             g["graph"].replay()
         return g["img"].clone()
@@ -273,7 +294,7 @@ class GoalGaussianDiffusion(nn.Module):
                  x_cond=torch.zeros((B, 3, H, W), dtype=torch.float32, device=device),
                  task_embed=torch.full(te_shape, float("nan"), dtype=torch.float32, device=device),
                  table=torch.zeros((MAXR, 12), dtype=torch.float32, device=device), state=torch.zeros(3, dtype=torch.int64, device=device),
-                 tt=torch.zeros(B, dtype=torch.long, device=device), nrows=[MAXR])
+                 tt=torch.zeros(B, dtype=torch.long, device=device))
         te0 = torch.zeros(te_shape, dtype=torch.float32, device=device)
         g["label"] = eng.label_embedding(te0).clone()
         g["label_u"] = eng.label_embedding(te0).clone() if gw > 0.0 else None          # the unconditional branch embeds zeros (:504-506)
@@ -282,10 +303,12 @@ class GoalGaussianDiffusion(nn.Module):
             xin = ops.video_pack2(g["img"], g["x_cond"], f, H, W, ci)
             v = eng.forward_cl(xin, g["tt"], g["label"])
             vu = eng.forward_cl(xin, g["tt"], g["label_u"]) if gw > 0.0 else None
-            ops.video_denoise_step2(v, vu, g["img"], None, g["table"], self.objective, f, H * W, ci, state=g["state"], use_philox=True, out=g["img"])
-            ops.video_sampler_advance(g["state"], g["table"], g["tt"], MAXR)
+            ops.video_denoise_step2(v, vu, g["img"], None, g["table"], self.objective, f, H * W, ci, state=g["state"], use_philox=True, out=g["img"],
+                                    guided=gw > 0.0)
+            ops.video_sampler_advance(g["state"], g["table"], g["tt"], nrows)        # the real row count: the last replay re-reads the last row
 
         rows = self._step_rows(False)
+        nrows = len(rows)
         ops.video_denoise_table(rows, device, out=g["table"])
         step()                                    # eager once: weight packs, workspaces, allocator warm
         torch.cuda.synchronize()

@@ -38,6 +38,7 @@ SIGNATURES = {
     "v2a_wgrad_reduce_multi": (I, [P, P, I, P]),
     "v2a_conv2d_wgrad_describe": (I, [P] * 8 + [I] * 18 + [P, SZ, P, P, P, P, P, P, P, P]),
     "v2a_wgrad_multi_max": (I, []),
+    "v2a_wgrad_family": (I, [I]),
     "v2a_conv2d_wgrad_multi": (I, [P, P, P, I, P]),
     "v2a_pack_chunk_elems": (I, []),
     "v2a_debug_wgrad_dma": (I, [I]),

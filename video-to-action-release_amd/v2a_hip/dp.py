@@ -120,6 +120,16 @@ class GradReducer:
                 for lo, hi in self.slices:
                     self.arena[lo:hi].mul_(1.0 / self.world)
 
+    def abort(self):
+        """Abandon the step in flight (a non-finite loss, an exception between launch and finish): wait for the collectives that were
+        already issued -- every rank issued the same ones up to here, so nothing hangs -- and forget them WITHOUT averaging or widening
+        into the arena, so that the next step can launch its slices again.  The decision to skip a step must be collective (all ranks
+        call abort() for the same step); a rank that finishes while another aborts would be one collective ahead."""
+        for w, _ in self._works:
+            w.wait()
+        self._works = []
+        self._launched = set()
+
     def pending(self):
         """Slices launched since the last finish()."""
         return set(self._launched)

@@ -105,6 +105,15 @@ def _plan_name(fn, prefix, M, Cout, K):
 
 def _plan_name_h(M, Cout, K, ept, tname):
     tiles128 = -(-M // 128) * -(-Cout // (64 if Cout <= 64 else 128))
+    if tname == "float":                          # fp32 instances: three-plane kernel (default) or the pipelined exact-f32 kernel
+        x3 = lib.v2a_get_f32_conv_mode() == 1
+        base = "conv_igemm_f32x3" if x3 else "conv_igemm_f32p"
+        if tiles128 < 128 and _SMALL_TILE_H:
+            return f"{base}<64,64>"
+        if Cout <= 64:
+            big = x3 and M % 256 == 0 and -(-M // 256) >= 200 and os.environ.get("V2A_X3_BIG", "1") != "0"
+            return f"{base}<{256 if big else 128},64>"
+        return f"{base}<128,{128 if (not x3 or os.environ.get('V2A_X3_BIG', '1') != '0') else 64}>"
     if tiles128 < 128 and _SMALL_TILE_H:          # mirrors conv_plan_h (csrc/igemm_h.hip)
         return f"conv_igemm_h<64,64,{tname}>"
     return f"conv_igemm_h<128,{64 if Cout <= 64 else 128},{tname}>"
@@ -348,7 +357,8 @@ class WgradBatch:
     TARGET_WG = int(os.environ.get("V2A_WGRAD_MULTI_WG", "1280"))
     MIN_DEPTH = int(os.environ.get("V2A_WGRAD_MULTI_DEPTH", "4"))
     TARGET_WG_HALO = int(os.environ.get("V2A_WGRAD_MULTI_WG_HALO", "512"))
-    WEIGHT = {0: 1.0, 1: 2.0, 2: 1.5, 3: 1.0, 4: 1.0, 5: 1.0}   # relative cost of one (output tile, reduction tile) step per kernel body
+    TARGET_WG_X3 = (int(os.environ.get("V2A_WGRAD_MULTI_WG_X3_64", "1024")), int(os.environ.get("V2A_WGRAD_MULTI_WG_X3_128", "512")))
+    WEIGHT = {0: 1.0, 1: 2.0, 2: 1.5, 3: 1.0, 4: 1.0, 5: 1.0, 6: 1.0, 7: 1.0}   # relative cost of one (output tile, reduction tile) step per kernel body
 
     def __init__(self, collector):
         self.col = collector
@@ -391,9 +401,10 @@ class WgradBatch:
         allc, self.calls = self.calls, []
         if not allc:
             return
-        # two kernel families (csrc/igemm.hip): the halo-tile body (variants 3-5) and the 64x64 / twin-fed bodies (0-2)
-        for fam, target in ((False, self.TARGET_WG), (True, self.TARGET_WG_HALO)):
-            calls = [c for c in allc if (c["variant"] >= 3) == fam]
+        # kernel families (csrc/igemm.hip): the 64x64 / twin-fed bodies (variants 0-2), the halo-tile body (3-5), the three-bf16-plane
+        # bodies (6: 64 x 64 tiles, 7: 128 x 128 tiles)
+        for fam, target in ((0, self.TARGET_WG), (1, self.TARGET_WG_HALO), (2, self.TARGET_WG_X3[0]), (3, self.TARGET_WG_X3[1])):
+            calls = [c for c in allc if lib.v2a_wgrad_family(c["variant"]) == fam]
             if calls:
                 self._launch_family(calls, target)
         last_kernel[0] = "conv_wgrad_multi"
@@ -1149,14 +1160,19 @@ def video_denoise_table(rows, device, out=None):
     return out
 
 
-def video_denoise_step2(v, v_uncond, img, noise, table, objective, f, HW, ci=3, state=None, step=0, use_philox=False, out=None):
+def video_denoise_step2(v, v_uncond, img, noise, table, objective, f, HW, ci=3, state=None, step=0, use_philox=False, out=None, guided=None):
     """One table-driven sampler step (csrc/elementwise.hip video_denoise_kernel2).  state: uint64[3] device tensor {row, seed, counter}
-    (row index and Philox state read on the device) or None (row `step`).  out=img updates the sampler state in place."""
+    (row index and Philox state read on the device) or None (row `step`).  out=img updates the sampler state in place.
+    guided: the table's rows carry a guidance weight > 0 (default: whether v_uncond was given) -- then v_uncond is mandatory and the C
+    side refuses a null pointer instead of dereferencing it."""
     if out is None:
         out = torch.empty_like(img)
     B = img.shape[0]
+    if guided is None:
+        guided = v_uncond is not None
+    flags = (1 if use_philox else 0) | (2 if guided else 0)
     check(lib.v2a_video_denoise_step2(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, ci,
-                                      _OBJECTIVES[objective], table.data_ptr(), _p(state), int(step), 1 if use_philox else 0, _stream()),
+                                      _OBJECTIVES[objective], table.data_ptr(), _p(state), int(step), flags, _stream()),
           "video_denoise_step2")
     return out
 

@@ -85,6 +85,7 @@ class PolicyTrainer:
         self.feed = None               # parity / test hook (eager mode): dict(rows=int64[B] pool offsets, noise=[B,T,Da], timesteps=int64[B])
         self.on_grads_ready = None     # diagnostics hook (eager mode): called with the arena right before the optimiser consumes it
         self.comm_events = None        # bench: [(before_wait, after_wait)] HIP event pairs bracketing the stream's wait on the communicator
+        self.phase_events = None       # bench (data-parallel step structure): [(e0 .. e4)] HIP events at the boundaries of the three graphs
         self._st = None
         self._warm = 0
         self.step_count = 0
@@ -206,13 +207,26 @@ class PolicyTrainer:
                     with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
                         self._opt()
                 # capture does not execute: run the step for real
+            pe = None
+            if self.dp and self.phase_events is not None:
+                pe = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                pe[0].record()
             self._g_fb.replay()
             if self.dp:
+                if pe:
+                    pe[1].record()
                 self._reduce_async(0)
                 self._g_enc.replay()
+                if pe:
+                    pe[2].record()
                 self._reduce_async(1)
                 self._reduce_wait()
+                if pe:
+                    pe[3].record()
                 self._g_opt.replay()
+                if pe:
+                    pe[4].record()
+                    self.phase_events.append(pe)
         self.step_count += 1
         return self.loss
 

@@ -15,6 +15,8 @@ Two entry points share the same kernels:
   * `VideoTrainStep` is what flowdiffusion's Trainer drives: gradients land in one arena (one RCCL all-reduce when world > 1), the fused
     optimiser consumes it, packed operands are refreshed afterwards.
 fp32 throughout (the reference trains under fp16 autocast; fp32 is the parity configuration)."""
+import sys
+import os
 import torch
 from . import ops
 from .unet_train import UNetTrainEngine
@@ -160,7 +162,13 @@ class VideoTrainStep:
         if self.world > 1:
             from .dp import GradReducer
             numels = [self.params[n].numel() for n in self.arena.names]
-            self.reducer = GradReducer(self.arena.flat, gradient_ready_slices(self.arena.names, numels), process_group, self.world)
+            slices = gradient_ready_slices(self.arena.names, numels)
+            # a parameter re-ordering that loses the decoder / encoder split would silently lose the overlap: say how many slices there are
+            self.n_gradient_slices = len(slices)
+            if len(slices) < 2 and os.environ.get("V2A_DP_QUIET") != "1":
+                print(f"[v2a_hip.video_train] gradient_ready_slices found {len(slices)} slice(s): the decoder slice's early all-reduce is OFF",
+                      file=sys.stderr)
+            self.reducer = GradReducer(self.arena.flat, slices, process_group, self.world)
 
     def loss_and_grads(self, img, cond, tokens, t=None, noise=None, normalize=True, accumulate=False, scale=1.0, last=True):
         """Forward + backward of one micro-batch; gradients are written to (or, with `accumulate`, added into) the arena times `scale`.
@@ -183,6 +191,13 @@ class VideoTrainStep:
                 early = lambda: self.reducer.launch(0)
             _backward(d, eng, tape, out, img, noise, t, normalize, self.arena.views, g, on_decoder_done=early)
         return loss
+
+    def abandon(self):
+        """Drop the gradients of the step in flight instead of apply() (e.g. a non-finite loss; in a data-parallel run EVERY rank must
+        take the same decision): outstanding slice all-reduces are completed and forgotten, the arena is zeroed."""
+        if self.reducer is not None:
+            self.reducer.abort()
+        self.arena.flat.zero_()
 
     def apply(self):
         """All-reduce (mean over ranks) -> fused clip / Adam / zero / EMA -> refresh the packed operands."""
