@@ -783,14 +783,16 @@ def main():
     if world > 1 and not args.no_video:
         try:
             v2a_hip.set_video_storage("bf16")
-            rows = max(1, -(-args.video_batch // world))
+            from v2a_hip.dp import shard_rows, shard_tasks
+            lo_r, hi_r = shard_rows(args.video_batch, world, rank)
+            rows = max(1, hi_r - lo_r)
             barrier()
             vs = video_leg(torch, device, rows, args.video_steps, traffic_leg="video_bf16", reps=args.video_reps, roofline=False,
                            workload="BASELINE configs[2] sharded by batch rows over the ranks")
             t_call = max_over_ranks(vs["seconds_per_sample_call"])
             # per-task exploration rollouts of the released config (lb_online_trainer_v7.py:871,888-891: 8 tasks, bs = 1, 100 ancestral
             # steps): tasks r, r + N, ... on rank r
-            tasks = len(range(rank, 8, world))
+            tasks = len(shard_tasks(8, world, rank))
             barrier()
             vr = video_leg(torch, device, 1, 100, reps=1, roofline=False) if tasks else None
             t_roll = max_over_ranks((vr["seconds_per_sample_call"] * tasks) if vr else 0.0)

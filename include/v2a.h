@@ -209,6 +209,11 @@ int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint6
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
 int v2a_get_f32_conv_mode(void);
+/* Two parameter sets over ONE stacked batch (the policy's two camera encoders as one launch sequence): the NEXT fp32 LDS-DMA conv launch
+ * (v2a_conv2d_fwd_dma_f32 / _d) computes output rows >= m_split with w2 / bias2 (m_split % 256 == 0); the NEXT fp32 GroupNorm launch
+ * (v2a_groupnorm_fwd* / _bwd*) uses gamma2 / beta2 for samples n >= n_split.  Host-side state, consumed by that launch. */
+int v2a_conv2d_set_second(const void* w2, const float* bias2, int m_split);
+int v2a_groupnorm_set_second(const float* gamma2, const float* beta2, int n_split);
 int v2a_debug_f32p(int on, int s128, int s64);   /* tuning aid: pipelined exact-f32 conv kernel on/off (default on), LDS stages of its 128x128 / 64x64 tiles; returns the old `on` */
 int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words);   /* measurement aid: following conv_igemm_h launches stamp their phases per workgroup ([wg][8] x 100 MHz ticks), buf advances by stride_words per launch; null = off */
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */

@@ -254,3 +254,59 @@ def test_dp4_uneven_slice_readiness_and_wire_format(wire):
             else:                                                              # bf16 wire: inputs rounded to bf16, sums rounded per hop
                 tol = 4 * 2.0 ** -8 * float(want.abs().max() + 1)
                 assert float((got - want).abs().max()) <= tol and float((got - want).abs().max()) > 0
+
+
+def _shard_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "video-to-action-release_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2a_hip.dp import shard_rows, shard_tasks, joint_steps_per_sec
+    lo, hi = shard_rows(16, world, rank)
+    tasks = shard_tasks(8, world, rank)
+    # every rank "samples" its rows and its tasks' rollouts: a row / task is represented by a value only its owner can produce
+    rows = torch.zeros(16)
+    rows[lo:hi] = torch.arange(lo, hi, dtype=torch.float32) + 1000.0
+    tk = torch.zeros(8)
+    for t in tasks:
+        tk[t] = 100.0 + t
+    owners_r, owners_t = torch.zeros(16), torch.zeros(8)
+    owners_r[lo:hi] = 1
+    for t in tasks:
+        owners_t[t] = 1
+    for v in (rows, tk, owners_r, owners_t):
+        dist.all_reduce(v)                                  # (test bookkeeping only: the product path has no collective here)
+    # the slowest rank decides the round (MAX over ranks, as bench.py does with its timings)
+    mine = torch.tensor([float(len(tasks)) * 0.63])         # 0.63 s per bs-1 rollout (round-3 measurement)
+    dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+    rate = joint_steps_per_sec(world, 10.0, 0.63)
+    if rank == 0:
+        out.put((rows.tolist(), tk.tolist(), owners_r.tolist(), owners_t.tolist(), float(mine), rate))
+    dist.destroy_process_group()
+
+
+def test_world8_sampler_rows_and_exploration_tasks_partition_without_a_collective():
+    """BASELINE configs[3] / [2] at 8 ranks: the B = 16 rows of a sample() call and the 8 per-task exploration rollouts are dealt by
+    v2a_hip.dp.shard_rows / shard_tasks (what bench.py --gpus 8 and the joint loop use): every row and every task has exactly one owner,
+    nothing is dropped, and the joint-loop rate is the arithmetic of the slowest rank's share."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 8
+    port = 29900 + os.getpid() % 50
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rows, tk, own_r, own_t, t_round, rate = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert own_r == [1.0] * 16 and own_t == [1.0] * 8
+    assert rows == [1000.0 + i for i in range(16)] and tk == [100.0 + t for t in range(8)]
+    assert abs(t_round - 0.63) < 1e-6                       # one rollout per rank at world 8
+    assert abs(rate - 8 * 200 / (200 * 10.0e-3 + 0.63)) < 1e-9
+    from v2a_hip.dp import shard_rows, shard_tasks
+    for w in (1, 2, 3, 4, 5, 8, 16, 32):                     # ragged worlds: still a partition
+        cover = sorted(i for r in range(w) for i in range(*shard_rows(16, w, r)))
+        assert cover == list(range(16)), (w, cover)
+        assert sorted(t for r in range(w) for t in shard_tasks(8, w, r)) == list(range(8))

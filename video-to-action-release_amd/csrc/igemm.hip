@@ -2566,9 +2566,9 @@ static int g_wgrad_x3 = -1;
 static bool wgrad_x3_on() {
     if (g_wgrad_x3 < 0) {
         const char* e = getenv("V2A_WGRAD_X3");
-        g_wgrad_x3 = (e && e[0] == '0') ? 0 : 1;
-    }
-    return g_wgrad_x3 == 1;
+        g_wgrad_x3 = (e && e[0] == '1') ? 1 : 0;      // default OFF: measured slower on the policy step than the exact halo / 64x64 bodies
+    }                                                  // (10.5 vs 9.6-9.8 ms): the transposing loader keeps half the workgroup idle on 64 x 64
+    return g_wgrad_x3 == 1;                            // tiles and the 128 x 128 tile runs one workgroup per CU
 }
 // kernel family of a grouped-launch variant: 0 = 64x64 exact / twin-fed bodies (0-2), 1 = halo body (3-5), 2 / 3 = three-plane bodies (6 / 7)
 static int wgrad_family(int v) { return v <= 2 ? 0 : (v <= 5 ? 1 : (v == 6 ? 2 : 3)); }
@@ -2606,7 +2606,7 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
             OW == W && C1 % 64 == 0 && Cout % 64 == 0 && p.M % 32 == 0 && (OW == 8 || OW == 16 || OW % 32 == 0) &&
             OH % (OW >= 32 ? 1 : 32 / OW) == 0 && big < 2147483648.0)
             variant = OW == 8 ? 5 : (OW == 16 ? 4 : 3);
-        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on())         // fp32 products from three bf16 planes (V2A_WGRAD_X3=0: exact bodies)
+        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on())         // fp32 products from three bf16 planes (V2A_WGRAD_X3=1; default: the exact bodies)
             variant = (Cout >= 128 && p.K >= 128) ? 7 : 6;
     }
     *variant_out = variant;

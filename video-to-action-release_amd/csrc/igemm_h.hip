@@ -984,7 +984,7 @@ __global__ void conv_splitk_reduce_h(const ConvDescH p) {
         const int m = (int)(idx / p.Cout), n = (int)(idx - (size_t)m * p.Cout);
         float v = 0.f;
         for (int s = 0; s < p.splitk; ++s) v += p.partial[(size_t)s * total + idx];
-        if (p.bias) v += p.bias[n];
+        if (p.bias) v += (m >= p.m_split ? p.bias2 : p.bias)[n];
         if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
         if (p.residual) v += HALF ? v2a_h2f<F16>(reinterpret_cast<const uint16_t*>(p.residual)[idx]) : reinterpret_cast<const float*>(p.residual)[idx];
         if (p.residual_f) v += p.residual_f[idx];
@@ -1047,6 +1047,10 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
 }
 
 static void f32_conv_mode_init();
+// second weight / bias set of the NEXT fp32 LDS-DMA conv launch (output rows >= m_split read it): host-side state, consumed by that launch
+static const void* g_conv_w2 = nullptr;
+static const float* g_conv_bias2 = nullptr;
+static int g_conv_msplit = 0x7fffffff;
 static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact switches to the exact-f32 MFMA kernels
 static int g_f32p = -1, g_f32p_s128 = 2, g_f32p_s64 = 4;   // pipelined exact-f32 conv (conv_igemm_f32p): on / stages of the 128x128 and 64x64 tiles
 static unsigned long long* g_conv_stamps = nullptr;     // v2a_debug_conv_stamps: next launch's stamp block (advanced per launch)
@@ -1165,6 +1169,12 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     }
     p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff;
     if constexpr (sizeof(T) == 4) {
+        if (g_conv_w2) {                             // second operand set of this launch (v2a_conv2d_set_second), consumed here
+            const int ms = g_conv_msplit;
+            p.w2 = g_conv_w2; p.bias2 = g_conv_bias2; p.m_split = ms;
+            g_conv_w2 = nullptr; g_conv_bias2 = nullptr; g_conv_msplit = 0x7fffffff;
+            if (ms < 1 || ms % 256 != 0 || (((uintptr_t)p.w2) & 15)) return V2A_ERR_ARG;      // a multiple of every row tile
+        }
         if (g_f32p < 0) {                            // V2A_F32P=0: the round-1..3 kernel (A/B); V2A_F32P_S128 / _S64: LDS stages per tile shape
             const char* e = getenv("V2A_F32P");
             g_f32p = (e && e[0] == '0') ? 0 : 1;
@@ -1261,6 +1271,12 @@ int v2a_set_f32_conv_mode(int x3) {
     const int old = g_f32x3;
     g_f32x3 = x3 ? 1 : 0;
     return old;
+}
+// The next v2a_conv2d_fwd_dma_f32 / _d launch computes output rows >= m_split with w2 / bias2 (same shapes as w / bias): two layers of
+// identical geometry over one stacked batch -- the policy's two camera encoders -- as ONE launch.  m_split % 256 == 0.  w2 = null clears.
+int v2a_conv2d_set_second(const void* w2, const float* bias2, int m_split) {
+    g_conv_w2 = w2; g_conv_bias2 = w2 ? bias2 : nullptr; g_conv_msplit = w2 ? m_split : 0x7fffffff;
+    return V2A_OK;
 }
 int v2a_get_f32_conv_mode(void) {
     f32_conv_mode_init();

@@ -45,7 +45,13 @@ struct GnDesc {
     float* sout;            // [N][S][C] or null
     int nslab;
     size_t slab_stride;
+    // two parameter sets over one stacked batch (the policy's two camera encoders as ONE chain): samples n >= n_split use gamma2 / beta2
+    const float* gamma2;
+    const float* beta2;
+    int n_split;            // INT_MAX: one set
 };
+#define GN_GAMMA(p, n) (((n) >= (p).n_split) ? (p).gamma2 : (p).gamma)
+#define GN_BETA(p, n) (((n) >= (p).n_split) ? (p).beta2 : (p).beta)
 
 __device__ __forceinline__ unsigned short gn_f2bf(float f) {      // round to nearest even, as v2a_cast_f32_bf16
     return v2a_f2bf(f);
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
                 const int g = (cc + j) / cg;          // per element: a float4 may straddle two groups when cg % 4 != 0
                 mu[j] = p.mean[n * p.G + g];
                 rs[j] = p.rstd[n * p.G + g];
-                gm[j] = p.gamma[cc + j];
-                bt[j] = p.beta[cc + j];
+                gm[j] = GN_GAMMA(p, n)[cc + j];
+                bt[j] = GN_BETA(p, n)[cc + j];
             }
         }
 // (manual prefetch below)
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
             float a = 0.f;
             for (int j = 0; j < cg; ++j) {
                 const float v = cg <= 64 ? cs_s[tid][j] : p.colsum[(size_t)n * 2 * C + tid * C + g * cg + j];
-                a += p.gamma[g * cg + j] * v;
+                a += GN_GAMMA(p, n)[g * cg + j] * v;
             }
             p.gsum[(size_t)(n * p.G + g) * 2 + tid] = a;
         }
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_rows(const GnDesc p) {
             if (!ok[k]) continue;
             const int c = cc[k], g = c / cg;
             const float mu = mean[g], rsd = rstd[g];
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c);
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
         for (int j = 0; j < 4; ++j) {
             const int c = c4 * 4 + j;
             const int g = c / cg;
-            float z = (v[j] - p.mean[n * p.G + g]) * p.rstd[n * p.G + g] * p.gamma[c] + p.beta[c] + r[j];
+            float z = (v[j] - p.mean[n * p.G + g]) * p.rstd[n * p.G + g] * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c] + r[j];
             float a = act_fwd(z, p.act);
             if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
             o[j] = a;
@@ -336,10 +342,10 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
                 A2 = p.gsum[(size_t)(n * p.G + g) * 2 + 1];
             }
             const float xh = (v[j] - mu) * rs;
-            const float z = xh * p.gamma[c] + p.beta[c] + r[j];
+            const float z = xh * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c] + r[j];
             const float dz = d[j] * act_bwd(z, p.act);
             dzv[j] = dz;
-            o[j] = rs * (p.gamma[c] * dz - (A1 + xh * A2) * inv_cnt);
+            o[j] = rs * (GN_GAMMA(p, n)[c] * dz - (A1 + xh * A2) * inv_cnt);
         }
         y4[i] = o;
         if (p.yh) gn_store_twin4(p.yh, i, o);
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(sm + i * 4);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
             f32x4 o;
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
     for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
-        float z = (sm[i] - mu) * rs * p.gamma[c] + p.beta[c];
+        float z = (sm[i] - mu) * rs * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c];
         if (p.residual) z += p.residual[off];
         float a = act_fwd(z, p.act);
         if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off), dv = gn_src4(p, p.dout, off, c);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
             f32x4 hv, zv;
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
         const float h = (p.x[off] - mu) * rs;
-        float z = h * p.gamma[c] + p.beta[c];
+        float z = h * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c];
         if (p.residual) z += p.residual[off];
         const float dout = gn_src1(p, p.dout, off, c);
         float da = dout;
@@ -524,8 +530,8 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
         const float dz = da * act_bwd(z, p.act);
         xh[i] = h;
         dzs[i] = dz;
-        A1 += dz * p.gamma[c];
-        A2 += dz * p.gamma[c] * h;
+        A1 += dz * GN_GAMMA(p, n)[c];
+        A2 += dz * GN_GAMMA(p, n)[c] * h;
     }
     }
     A1 = wave_sum(A1);
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 hv = *reinterpret_cast<const f32x4*>(xh + i * 4), zv = *reinterpret_cast<const f32x4*>(dzs + i * 4);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c);
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = rs * (gm[j] * zv[j] - (A1 + hv[j] * A2) * inv);
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
     for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
-        const float dxv = rs * (p.gamma[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
+        const float dxv = rs * (GN_GAMMA(p, n)[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
         p.y[off] = dxv;
         if (p.yh) p.yh[off] = gn_f2bf(dxv);
         if (p.dres) p.dres[off] = dzs[i];
@@ -654,8 +660,8 @@ __global__ __launch_bounds__(64) void gn_wave_fwd(const GnDesc p) {
         gmv[j] = btv[j] = rsd[j] = f0[j] = f1[j] = 0.f;
         if (j < epl) {
             const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
-            gmv[j] = p.gamma[c];
-            btv[j] = p.beta[c];
+            gmv[j] = GN_GAMMA(p, n)[c];
+            btv[j] = GN_BETA(p, n)[c];
             if (p.residual) rsd[j] = p.residual[base + (size_t)row * C + cc];
             if (p.film) { f0[j] = p.film[(size_t)n * p.film_ld + c]; f1[j] = p.film[(size_t)n * p.film_ld + C + c]; }
         }
@@ -707,8 +713,8 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
             const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
             const size_t off = base + (size_t)row * C + cc;
             xv[j] = p.x[off];
-            gmv[j] = p.gamma[c];
-            btv[j] = p.beta[c];
+            gmv[j] = GN_GAMMA(p, n)[c];
+            btv[j] = GN_BETA(p, n)[c];
             if (p.residual) rsd[j] = p.residual[off];
             if (film) f0[j] = p.film[(size_t)n * p.film_ld + c];
         }
@@ -910,14 +916,29 @@ int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* g
                        stats1, stats2, workspace, workspace_bytes, stream);
 }
 }  // extern "C"
+// Second parameter set of the NEXT fp32 GroupNorm launch (forward or backward; consumed by it): samples n >= n_split use gamma2 / beta2.
+// Host-side state of the launching thread's sequence -- the policy engine runs its two camera encoders as ONE stacked batch this way.
+static const float* g_gn_gamma2 = nullptr;
+static const float* g_gn_beta2 = nullptr;
+static int g_gn_nsplit = 0x7fffffff;
+extern "C" int v2a_groupnorm_set_second(const float* gamma2, const float* beta2, int n_split) {
+    if ((gamma2 == nullptr) != (beta2 == nullptr) || (gamma2 && n_split < 1)) return V2A_ERR_ARG;
+    g_gn_gamma2 = gamma2; g_gn_beta2 = beta2; g_gn_nsplit = gamma2 ? n_split : 0x7fffffff;
+    return V2A_OK;
+}
+static void gn_take_second(GnDesc& p) {
+    p.gamma2 = g_gn_gamma2; p.beta2 = g_gn_beta2; p.n_split = g_gn_gamma2 ? g_gn_nsplit : 0x7fffffff;
+    g_gn_gamma2 = nullptr; g_gn_beta2 = nullptr; g_gn_nsplit = 0x7fffffff;
+}
 static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
                        const float* stats2, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) { GnDesc t = {}; gn_take_second(t); return V2A_ERR_ARG; }
     if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
     if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
+    gn_take_second(p);
     p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
     p.yh = (unsigned short*)y_h;
@@ -1033,6 +1054,7 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     if (!x || !gamma || !beta || (!dout && nslab <= 0) || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
     if (nslab > 0 && (!slabs || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
     GnDesc p = {};
+    gn_take_second(p);
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
     p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.yh = (unsigned short*)dx_h; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;

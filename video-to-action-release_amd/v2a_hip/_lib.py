@@ -97,6 +97,8 @@ SIGNATURES = {
     "v2a_debug_f32p": (I, [I, I, I]),
     "v2a_set_f32_conv_mode": (I, [I]),
     "v2a_get_f32_conv_mode": (I, []),
+    "v2a_conv2d_set_second": (I, [P, P, I]),
+    "v2a_groupnorm_set_second": (I, [P, P, I]),
     "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),
     "v2a_perceiver_attention_bwd": (I, [P] * 9 + [I, I, I, I, I, F, P]),
     "v2a_layernorm_bwd": (I, [P, P, P, P, P, I, I, F, P]),

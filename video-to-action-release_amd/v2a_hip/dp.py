@@ -14,6 +14,29 @@ import torch
 import torch.distributed as dist
 
 
+# ---- how the path's independent units are dealt to the ranks (no data-path collective: rows of a sample() call, the per-task exploration
+# rollouts and the replay minibatches are independent; bench.py --gpus N and the trainer use exactly these functions)
+def shard_rows(batch: int, world: int, rank: int):
+    """[lo, hi) rows of one B-row sample() call that rank `rank` computes: ceil(B / world) rows per rank, the last ranks may get fewer
+    (or none when world > B) -- the reference samples whole batches, rows are independent (goal_diffusion.py:582-641)."""
+    per = -(-int(batch) // int(world))
+    lo = min(rank * per, batch)
+    return lo, min(lo + per, batch)
+
+
+def shard_tasks(n_tasks: int, world: int, rank: int):
+    """Task ids of one video-guided exploration round (8 Libero tasks, one bs-1 rollout each: lb_online_trainer_v7.py:871,888-891) that
+    rank `rank` samples: r, r + world, ..."""
+    return list(range(rank, int(n_tasks), int(world)))
+
+
+def joint_steps_per_sec(world: int, ms_per_step: float, seconds_per_rollout: float, n_tasks: int = 8, every: int = 200):
+    """BASELINE configs[3] arithmetic: `every` data-parallel train steps (all ranks step together: world batch-64 steps per step time)
+    plus one exploration round whose rollouts are dealt by shard_tasks (the slowest rank holds ceil(n_tasks / world) of them)."""
+    t_round = -(-n_tasks // world) * seconds_per_rollout
+    return world * every / (every * ms_per_step * 1e-3 + t_round)
+
+
 def _to_wire(src, dst):
     """fp32 slice -> bf16 wire buffer (round to nearest even): the HIP cast kernel on the device, torch on CPU tensors (gloo tests)."""
     if src.is_cuda:

@@ -164,7 +164,7 @@ _DEFER = os.environ.get('V2A_DEFER_REDUCE', '1') != '0'
 
 
 def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y, defer=False,
-                    want_stats=False):
+                    want_stats=False, second=None):
     """fp32 conv on the LDS-DMA kernel (exact-f32 MFMA): same results as the register-staged kernel up to summation order.
     defer: returns (y, Slabs | None) -- with Slabs the split-K reduce is left to the consuming GroupNorm launch.
     want_stats: returns (y, stats | None) -- per-64-row (sum, sum of squares) blocks of y for groupnorm_fwd(stats=...)."""
@@ -185,6 +185,10 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
     wsb = lib.v2a_conv2d_dma_f32_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
     last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
+    if second is not None:      # (w2_packed, bias2 | None, m_split): output rows >= m_split use the second operand set (this launch only)
+        w2, b2, ms = second
+        assert (b2 is None) == (bias is None) and w2.numel() == w_packed.numel()
+        check(lib.v2a_conv2d_set_second(w2.data_ptr(), _p(b2), int(ms)), "conv2d_set_second")
     if defer and _DEFER and wsb and rowvec is None:
         import ctypes
         ns = ctypes.c_int(0)
@@ -205,7 +209,7 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
            residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None, defer=False,
-           want_stats=False):
+           want_stats=False, second=None):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]; with defer=True
     (y, Slabs | None): when Slabs is returned, y is NOT written yet -- hand both to the GroupNorm that consumes the conv.
     bf16-MFMA mode: `x_h` = an existing bf16 twin of x (skips the cast launch); `keep_h` (a list) receives the twin that was used, so a
@@ -222,7 +226,9 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
             and (N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] or lib.v2a_get_f32_conv_mode() == 1)
             and lib.v2a_get_precision() == 0):
         return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y,
-                               defer=defer, want_stats=want_stats)
+                               defer=defer, want_stats=want_stats, second=second)
+    if second is not None:
+        raise ValueError("conv2d(second=...): only the fp32 LDS-DMA kernels take two operand sets (channels % 32 == 0, fp32 precision mode)")
     if want_stats:     # only the LDS-DMA fp32 kernel emits statistics
         assert not defer
         return conv2d(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
@@ -745,8 +751,15 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ group norm
+def _gn_second(second):
+    """second = (gamma2, beta2, n_split): samples n >= n_split of the NEXT GroupNorm launch use the second parameter set."""
+    if second is not None:
+        g2, b2, ns = second
+        check(lib.v2a_groupnorm_set_second(g2.data_ptr(), b2.data_ptr(), int(ns)), "groupnorm_set_second")
+
+
 def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None,
-                  stats=None, stats2=None):
+                  stats=None, stats2=None, second=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
     Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
     that consumes y takes it as x_h and skips its cast launch)."""
@@ -765,6 +778,7 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     if twin_out is not None and C % 4 == 0:
         yh = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
         twin_out.append(yh)
+    _gn_second(second)
     if slabs is not None:      # x is the (still unwritten) conv output: the kernel sums the conv's split-K slabs and stores x too
         assert slabs.residual is None
         check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), None, C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
@@ -803,7 +817,7 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
                   dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None, colsum=None, defer_params=False,
-                  dout_slabs=None, dout_sum=None):
+                  dout_slabs=None, dout_sum=None, second=None):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
     as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx.
     defer_params: only fill `colsum` [N,2,C] (per-sample sums); the caller reduces it over n for many layers at once
@@ -828,6 +842,8 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
+    assert second is None or defer_params, "two parameter sets: the per-set parameter gradients come from the colsum rows (defer_params)"
+    _gn_second(second)
     if dout_slabs is not None:      # dout = sum of the producing data-gradient conv's split-K slabs (+ its epilogue residual)
         sl = dout_slabs
         assert sl.bias is None

@@ -126,6 +126,11 @@ class PolicyEngine:
         # alone and cost 10 % on top of the encoder branches, so they stay on their chain's stream by default
         # ("unet": side stream for the ConditionalUnet1D weight gradients only).
         self.enc_streams = _os.environ.get("V2A_ENC_STREAMS", "1") != "0"
+        # both camera encoders as ONE chain over a stacked batch (fp32 precision mode, B % 16 == 0): V2A_ENC_STACK=1.  Built, parity-green
+        # (every policy test passes on it) and measured SLOWER than the two parallel chains with the three-plane convs: 9.92 / 9.97 ms
+        # against 9.77 / 9.89 ms per step on one box (forward 1.92 vs 1.77 ms, backward chain 2.97 vs 2.8, grouped weight gradients
+        # 1.78 vs 1.3: one stream loses the overlap of the two chains and gains less from the halved launch count) -- default off
+        self.stack_enc = _os.environ.get("V2A_ENC_STACK", "0") == "1"
         self._enc_side = []
         self._wg_mode = _os.environ.get("V2A_ASYNC_WGRAD", "0")
         self.async_wgrad = self._wg_mode == "1"
@@ -521,14 +526,17 @@ class PolicyEngine:
         chain, self._gn_chain = self._gn_chain, prev
         if not chain:
             return
-        key = (tuple(chain), tuple(grads[pre + ".weight"].data_ptr() for pre, _, _ in chain))
+        key = (tuple(chain), tuple(grads[ent[0] + ".weight"].data_ptr() for ent in chain))
         ent = self._gn_tables.get(key)
         if ent is None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("GroupNorm gradient table missing during graph capture; run one eager step first")
             rows, work = [], []
-            for i, (pre, N, C) in enumerate(chain):
-                rows.append([self._gn_cs[(pre, N, C)].data_ptr(), grads[pre + ".weight"].data_ptr(), grads[pre + ".bias"].data_ptr(), N, C])
+            for i, ent in enumerate(chain):
+                pre, N, C = ent[:3]
+                # (pre, N, C): the layer's own [N, 2, C] buffer; (pre, N, C, key, byte offset): N rows of a stacked buffer (two encoders)
+                cs_ptr = self._gn_cs[(pre, N, C)].data_ptr() if len(ent) == 3 else self._gn_cs[ent[3]].data_ptr() + ent[4]
+                rows.append([cs_ptr, grads[pre + ".weight"].data_ptr(), grads[pre + ".bias"].data_ptr(), N, C])
                 work += [[i, b] for b in range((C + 63) // 64)]
             for k in list(self._gn_tables):              # evict oldest-first, never a table a captured hipGraph points at
                 if len(self._gn_tables) <= 64:
@@ -677,6 +685,184 @@ class PolicyEngine:
             ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
         else:
             self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
+
+    # ------------------------------------------------------------------ both camera encoders as ONE stacked chain
+    # The two ResNet18-GN encoders have identical geometry and separate weights.  Stacked along the batch ([2B, H, W, C]: rows [0, B) first
+    # camera, [B, 2B) second) every conv / GroupNorm / pooling launch serves both: the LDS-DMA fp32 convs take a second operand set for
+    # output rows >= m_split (csrc/igemm_h.hip w2 / bias2 / m_split), the GroupNorm kernels a second (gamma, beta) for samples >= n_split;
+    # weight gradients and GroupNorm parameter gradients are per-encoder entries of the grouped launches (sub-batch pointers).  Half the
+    # launches of the encoder phases, each with twice the rows -- the per-launch skeleton (~10 us) is what these short kernels are made of.
+    def stack_ok(self, B):
+        from ._lib import lib
+        return (self.stack_enc and len(self.cfg.rgb_keys) == 2 and B >= 16 and B % 16 == 0 and lib.v2a_get_precision() == 0
+                and lib.v2a_get_f32_conv_mode() in (0, 1) and self.flip_dgrad)
+
+    def _gn2(self, x4, pa, pb, G, act, B, residual=None, slabs=None):
+        N = x4.shape[0]
+        C = x4.shape[-1]
+        x3 = x4.view(N, -1, C)
+        r3 = residual.view(N, -1, C) if residual is not None else None
+        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pa + ".weight"], self.P[pa + ".bias"], G, act, residual=r3, slabs=slabs,
+                                          second=(self.P[pb + ".weight"], self.P[pb + ".bias"], B))
+        return y.view(x4.shape), (x3, mean, rstd, r3, None, (pa, pb), G, act)
+
+    def _gn_bwd2(self, saved, dout4, want_dres=False, dslabs=None, keep_dout=False):
+        x3, mean, rstd, r3, _, (pa, pb), G, act = saved
+        d3 = dout4.view(x3.shape)
+        N, _, C = x3.shape
+        B = N // 2
+        ck = ("stack", pa, N, C)
+        cs = self._gn_cs.get(ck)
+        if cs is None:
+            cs = torch.empty((N, 2, C), dtype=torch.float32, device=self.device)
+            self._gn_cs[ck] = cs
+        self._gn_chain.append((pa, B, C, ck, 0))
+        self._gn_chain.append((pb, B, C, ck, B * 2 * C * 4))
+        dx, _, _, dres, _ = ops.groupnorm_bwd(x3, self.P[pa + ".weight"], self.P[pa + ".bias"], G, d3, mean, rstd, act, residual=r3,
+                                              want_dres=want_dres, colsum=cs, defer_params=True, dout_slabs=dslabs,
+                                              dout_sum=d3 if (dslabs is not None and keep_dout) else None,
+                                              second=(self.P[pb + ".weight"], self.P[pb + ".bias"], B))
+        return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None)
+
+    def _dgrad2(self, x, ca, cb, cout, kh, kw, stride, pad, ms, **kw_):
+        wa, bmode = ca.dg()
+        wb, _ = cb.dg()
+        assert bmode == 0
+        return ops.conv2d(x, wa, None, cout, kh, kw, stride, pad, second=(wb, None, ms), **kw_)
+
+    def encode_fwd2(self, keys, img_all, save):
+        """img_all [2B,3,H,W] (rows [0,B): camera keys[0], [B,2B): keys[1]) -> features [2B, feature_dim]."""
+        ea, eb = self.enc[keys[0]], self.enc[keys[1]]
+        cfg = self.cfg
+        w0 = cfg.widths[0]
+        B2 = img_all.shape[0]
+        B = B2 // 2
+        ops.tstamp("enc_fwd[stacked] begin")
+        x0 = ops.nchw_to_nhwc(img_all, normalize=True)
+        H0, W0 = x0.shape[1], x0.shape[2]
+        c1 = torch.empty((B2, (H0 + 6 - 7) // 2 + 1, (W0 + 6 - 7) // 2 + 1, w0), dtype=torch.float32, device=x0.device)
+        ops.conv2d(x0[:B], ea["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3), y=c1[:B])        # Cin = 3: the scalar-gather kernel, per camera
+        ops.conv2d(x0[B:], eb["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3), y=c1[B:])
+        a1, s_gn1 = self._gn2(c1, ea["bb"] + ".1", eb["bb"] + ".1", w0 // 16, "relu", B)
+        h, pidx = ops.maxpool_fwd(a1)
+        ops.tstamp_fine("enc_fwd[stacked] stem done")
+        st = dict(x0=x0, gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[], B=B)
+        for ba, bb in zip(ea["blocks"], eb["blocks"]):
+            s_, co = ba["stride"], ba["cout"]
+            g = co // 16
+            inp = h
+            oh, ow = inp.shape[1] // s_, inp.shape[2] // s_
+            ms = B * oh * ow
+            dfr = self._defer_ok(oh * ow, co, g)
+            cv = lambda x, ca, cb, kh, st_, pd: ops.conv2d(x, ca.pf(), None, co, kh, kh, (st_, st_), (pd, pd), defer=dfr,
+                                                            second=(cb.pf(), None, ms))
+            o1 = cv(inp, ba["conv1"], bb["conv1"], 3, s_, 1)
+            o1, sl = o1 if dfr else (o1, None)
+            a, s1 = self._gn2(o1, ba["pre"] + ".bn1", bb["pre"] + ".bn1", g, "relu", B, slabs=sl)
+            sd = None
+            if ba["down"] is not None:
+                idn = cv(inp, ba["down"], bb["down"], 1, s_, 0)
+                idn, sl = idn if dfr else (idn, None)
+                idn, sd = self._gn2(idn, ba["pre"] + ".downsample.1", bb["pre"] + ".downsample.1", g, "none", B, slabs=sl)
+            else:
+                idn = inp
+            o2 = cv(a, ba["conv2"], bb["conv2"], 3, 1, 1)
+            o2, sl = o2 if dfr else (o2, None)
+            h, s2 = self._gn2(o2, ba["pre"] + ".bn2", bb["pre"] + ".bn2", g, "relu", B, residual=idn, slabs=sl)
+            st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd))
+            ops.tstamp_fine(f"enc_fwd[stacked] block {len(st['blocks']) - 1} done")
+        feat = h
+        _, FH, FW, FC = feat.shape
+        kl = ops.conv2d(feat, ea["pool"].pf(), ea["pool"].b, cfg.num_kp, 1, 1, second=(eb["pool"].pf(), eb["pool"].b, B * FH * FW))
+        kp, att = ops.spatial_softmax_fwd(kl)
+        f = torch.empty((B2, cfg.feature_dim), dtype=torch.float32, device=feat.device)
+        for e_, lo in ((ea, 0), (eb, B)):                  # [B, 64] x [64, 64]: two tiny launches (rows per camera < a row tile)
+            ops.conv2d(kp[lo:lo + B].view(1, 1, B, -1), e_["fc"].pf(), e_["fc"].b, cfg.feature_dim, 1, 1, y=f[lo:lo + B].view(1, 1, B, -1))
+        st.update(feat=feat, kp=kp, att=att)
+        if save is not None:
+            save["_stacked"] = st
+        ops.tstamp("enc_fwd[stacked] end")
+        return f
+
+    def encode_bwd2(self, keys, df, st, grads):
+        tok = self._gn_begin()
+        self._wg_begin()
+        self._wgb_begin(side_key="stacked")
+        ops.tstamp("enc_bwd[stacked] begin")
+        try:
+            self._encode_bwd2(keys, df, st, grads)
+        finally:
+            ops.tstamp("enc_bwd[stacked] chain done")
+            self._wgb_end()
+            self._gn_flush(tok, grads)
+            self._wg_flush()
+            ops.tstamp("enc_bwd[stacked] end")
+
+    def _encode_bwd2(self, keys, df, st, grads):
+        ea, eb = self.enc[keys[0]], self.enc[keys[1]]
+        B = st["B"]
+        B2 = 2 * B
+        halves = ((ea, 0), (eb, B))
+        kp, att, feat = st["kp"], st["att"], st["feat"]
+        dkp = torch.empty_like(kp)
+        for e_, lo in halves:
+            fc = e_["fc"]
+            self._wg(kp[lo:lo + B].view(1, 1, B, -1), df[lo:lo + B].view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname], dbias=grads[fc.bname])
+            _dgrad(df[lo:lo + B].view(1, 1, B, -1), fc, None, fc.ci, 1, 1, (1, 1), (0, 0), y=dkp[lo:lo + B].view(1, 1, B, -1))
+        dkl = ops.spatial_softmax_bwd(att, kp, dkp)
+        for e_, lo in halves:
+            pool = e_["pool"]
+            self._wg(feat[lo:lo + B], dkl[lo:lo + B], pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
+        FH, FW = feat.shape[1], feat.shape[2]
+        dh = self._dgrad2(dkl, ea["pool"], eb["pool"], ea["pool"].ci, 1, 1, (1, 1), (0, 0), B * FH * FW)
+        ops.tstamp_fine("enc_bwd[stacked] head done")
+        dh_sl = None
+        nblk = len(ea["blocks"])
+        for bi, (ba, bb, bs) in enumerate(zip(reversed(ea["blocks"]), reversed(eb["blocks"]), reversed(st["blocks"]))):
+            s_, co, ci = ba["stride"], ba["cout"], ba["cin"]
+            inp = bs["inp"]
+            g = co // 16
+            oh, ow = bs["a"].shape[1], bs["a"].shape[2]
+            ih, iw = inp.shape[1], inp.shape[2]
+            dfr = self._defer_ok(oh * ow, co, g)
+            dfr_in = bi + 1 < nblk and self._defer_ok(ih * iw, ci, ci // 16)
+            do2, didn = self._gn_bwd2(bs["s2"], dh, want_dres=True, dslabs=dh_sl)
+            for (blk, lo) in ((ba, 0), (bb, B)):
+                self._wg(bs["a"][lo:lo + B], do2[lo:lo + B], blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
+            da = self._dgrad2(do2, ba["conv2"], bb["conv2"], co, 3, 3, (1, 1), (1, 1), B * oh * ow, defer=dfr)
+            da, sl = da if dfr else (da, None)
+            do1, _ = self._gn_bwd2(bs["s1"], da, dslabs=sl)
+            for (blk, lo) in ((ba, 0), (bb, B)):
+                self._wg(inp[lo:lo + B], do1[lo:lo + B], blk["conv1"].shape, 3, 3, (s_, s_), (1, 1), dw=grads[blk["conv1"].wname])
+            if ba["down"] is not None:
+                didn_raw, _ = self._gn_bwd2(bs["sd"], didn)
+                for (blk, lo) in ((ba, 0), (bb, B)):
+                    self._wg(inp[lo:lo + B], didn_raw[lo:lo + B], blk["down"].shape, 1, 1, (s_, s_), (0, 0), dw=grads[blk["down"].wname])
+                res_in = self._dgrad2(didn_raw, ba["down"], bb["down"], ci, 1, 1, (1, 1), (0, 0), B * ih * iw, idil=s_, out_hw=(ih, iw))
+            else:
+                res_in = didn
+            dh = self._dgrad2(do1, ba["conv1"], bb["conv1"], ci, 3, 3, (1, 1), (1, 1), B * ih * iw, idil=s_, out_hw=(ih, iw), residual=res_in,
+                              defer=dfr_in)
+            dh, dh_sl = dh if dfr_in else (dh, None)
+            if bi % 2 == 1:
+                ops.tstamp(f"enc_bwd[stacked] stage {3 - bi // 2} dgrad done")
+            else:
+                ops.tstamp_fine(f"enc_bwd[stacked] block {nblk - 1 - bi} dgrad done")
+        da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
+        dc1, _ = self._gn_bwd2(st["gn1"], da1)
+        ops.tstamp_fine("enc_bwd[stacked] stem gn done")
+        x0 = st["x0"]
+        N0, H0, W0, _ = x0.shape
+        xp = self._stem_pad.get("stacked")
+        if xp is None or xp.shape[:3] != x0.shape[:3]:
+            xp = torch.zeros((N0, H0, W0, 4), dtype=torch.float32, device=x0.device)
+            self._stem_pad["stacked"] = xp
+        ops.copy2d(x0, xp, N0 * H0 * W0, 3, 3, 4)
+        for e_, lo in halves:
+            c1 = e_["conv1"]
+            dw4 = torch.empty((c1.co, 4, 7, 7), dtype=torch.float32, device=x0.device)
+            self._wg(xp[lo:lo + B], dc1[lo:lo + B], (c1.co, 4, 7, 7), 7, 7, (2, 2), (3, 3), dw=dw4, immediate=True)
+            ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
 
     # ------------------------------------------------------------------ ConditionalUnet1D
     def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None, defer=False, x_h=None):
@@ -954,7 +1140,24 @@ class PolicyEngine:
         return out
 
     def global_cond(self, imgs: dict, save=None):
-        self._cur_batch = next(iter(imgs.values())).shape[0]
+        keys = list(self.cfg.rgb_keys)
+        self._cur_batch = imgs[keys[0]].shape[0]
+        if self.stack_ok(self._cur_batch):
+            B = self._cur_batch
+            img_all = imgs.get("_stacked")
+            if img_all is None:                       # separate tensors (compute_loss through the policy surface): one copy puts them side by side
+                a, b = imgs[keys[0]], imgs[keys[1]]
+                if a.dtype == b.dtype and a.shape == b.shape:
+                    img_all = torch.empty((2 * B,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+                    img_all[:B].copy_(a)
+                    img_all[B:].copy_(b)
+            if img_all is not None:
+                f = self.encode_fwd2(keys, img_all, save)
+                fd = f.shape[1]
+                gc = torch.empty((B, 2 * fd), dtype=torch.float32, device=f.device)
+                ops.copy2d(f[:B], gc, B, fd, fd, 2 * fd, dst_off=0)
+                ops.copy2d(f[B:], gc, B, fd, fd, 2 * fd, dst_off=fd)
+                return gc
         feats = self._enc_parallel([(lambda k=k: self.encode_fwd(k, imgs[k], save)) for k in self.cfg.rgb_keys])
         B = feats[0].shape[0]
         fd = feats[0].shape[1]
@@ -1055,7 +1258,14 @@ class PolicyEngine:
                 ops.tstamp("unet_wgrad end")
         self._in_enc = True
         try:
-            self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
+            if "_stacked" in st["save_enc"]:
+                keys = list(self.cfg.rgb_keys)
+                df = torch.empty((2 * B, fd), dtype=torch.float32, device=dgc.device)
+                ops.copy2d(dgc, df[:B], B, fd, fd * nk, fd, src_off=0)
+                ops.copy2d(dgc, df[B:], B, fd, fd * nk, fd, src_off=fd)
+                self.encode_bwd2(keys, df, st["save_enc"]["_stacked"], grads)
+            else:
+                self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
         finally:
             self._in_enc = False
         if deferred:

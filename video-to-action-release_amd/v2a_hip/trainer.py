@@ -128,8 +128,8 @@ class PolicyTrainer:
         B = self.B
         ops.tstamp_reset()
         ops.tstamp("step begin")
-        o0 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
-        o1 = torch.empty((B, 3, st.H, st.W), dtype=torch.float32, device=self.device)
+        oo = torch.empty((2 * B, 3, st.H, st.W), dtype=torch.float32, device=self.device)      # start | goal frames side by side: the
+        o0, o1 = oo[:B], oo[B:]                                                                 # two camera encoders run as one stacked chain
         oa = torch.empty((B, st.act_len, st.act_dim), dtype=torch.float32, device=self.device)
         check(lib.v2a_replay_gather(st.root_frames.data_ptr(), 1 if st.dtype == torch.uint8 else 0, st.root_acts.data_ptr(),
                                     self.frame_start.data_ptr(), o0.data_ptr(), o1.data_ptr(), oa.data_ptr(), B, st.H, st.W,
@@ -143,7 +143,7 @@ class PolicyTrainer:
             ops.philox_randint(self.timesteps, self.policy.noise_scheduler.config.num_train_timesteps, self.seed ^ 0x5DEECE66D,
                                offset_dev=self.counter)
             check(lib.v2a_advance_counter(self.counter.data_ptr(), (n_noise + 3) // 4 + B, ops._stream()), "advance_counter")
-        imgs = {"img_obs_1": o0, "img_goal_1": o1}
+        imgs = {"img_obs_1": o0, "img_goal_1": o1, "_stacked": oo}
         self._st = self.eng.backward_phase1(imgs, oa, self.noise, self.timesteps, names=self.names, arena=self.arena)
         ops.copy2d(self._st["loss"], self.loss, 1, 1, 1, 1)
 
