@@ -43,6 +43,8 @@ enum { V2A_ACT_NONE = 0, V2A_ACT_SILU = 1, V2A_ACT_RELU = 2, V2A_ACT_MISH = 3, V
  * accumulation and fp32 HBM storage (performance configuration; the reference's GPU path is fp16 autocast). Returns the old mode. */
 int v2a_set_precision(int mode);
 int v2a_get_precision(void);
+int v2a_set_policy_half(int f16);   /* 16-bit format of the policy's MFMA mode (v2a_set_precision(1)): 0 bf16 (default), 1 IEEE fp16; returns the old value */
+int v2a_get_policy_half(void);
 int v2a_debug_force_tile(int bm, int bn);   /* tuning aid: force the forward tile (128x128 | 128x64 | 64x64), 0,0 = heuristic */
 int v2a_debug_force_wgrad_plan(int bm, int bn, int split);   /* tuning aid: force the weight-gradient tile / split; 0,0,0 = heuristic */
 size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K);
@@ -141,6 +143,9 @@ int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const 
                   const float* act_min, const float* act_max, int act_dim, v2a_stream_t s);
 /* F.mse_loss(...).mean() and its gradient (diffusion_unet_image_policy.py:273-276) */
 int v2a_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int n, v2a_stream_t s);
+/* the same with the loss GRADIENT multiplied by *grad_scale_dev (device float, may be null): the dynamic loss scale of the fp16 policy mode
+ * (GradScaler's scale; lb_online_trainer_v7.py:72-76,604) -- the returned loss is unscaled */
+int v2a_mse_loss_scaled(const float* pred, const float* target, float* loss, float* dpred, int n, const float* grad_scale_dev, v2a_stream_t s);
 /* DDPMScheduler.step (mode 0) / DDIMScheduler.step (mode 1) on the action trajectory (diffusion_unet_image_policy.py:121-128) */
 int v2a_policy_sched_step(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb, float c_sa,
                           float c0, float c1, float sigma, int mode, v2a_stream_t s);
@@ -344,6 +349,13 @@ int v2a_opt_state_peek(const void* host_state, float* grad_norm, float* clip_coe
 /* step counters of a HOST copy of the state, for `trainer.save/load` (lb_online_trainer_v7.py:367-408); lr <= 0 keeps the rate */
 int v2a_opt_state_counters(const void* host_state, long long* step, long long* ema_step, int* ema_initted);
 int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_step, int ema_initted, double lr);
+/* dynamic loss scaling = torch.cuda.amp.GradScaler's contract inside the fused tail (reference: accelerate fp16 mixed precision,
+ * lb_online_trainer_v7.py:72-76,604-612): the gradients arrive multiplied by loss_scale; v2a_opt_step unscales inside the clip factor,
+ * skips the parameter / moment update (EMA and zero_grad still run) when their norm is inf / nan, halves the scale then, and grows it by
+ * growth_factor after growth_interval clean steps.  init_scale <= 0: off (default). */
+int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_factor, double backoff_factor, int growth_interval);
+int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps);
+size_t v2a_opt_state_loss_scale_offset(void);
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad, v2a_stream_t s);
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, v2a_stream_t s);  /* 1/world after the RCCL sum */
 

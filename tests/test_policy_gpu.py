@@ -224,6 +224,95 @@ def test_bf16_mode_policy_close_to_fp32(golden_dir):
     assert abs(float(flat.norm() / ref.norm()) - 1.0) <= 3e-2
 
 
+def test_fp16_mode_policy_close_to_fp32_and_loss_scaler_contract(golden_dir):
+    """precision='fp16' (BASELINE configs[4]; the reference's own GPU precision: accelerate mixed_precision='fp16' + GradScaler,
+    lb_online_trainer_v7.py:72-76,604-612): IEEE-half MFMA inputs, fp32 accumulate / storage.
+    (a) compute_loss / backward through the policy surface: loss within 1e-2 of the fp32 golden loss, gradient direction cos >= 0.995 of
+        the oracle's and CLOSER to it than the bf16 mode's (11 significand bits against 8);
+    (b) PolicyTrainer steps with dynamic loss scaling in the fused tail: the arena the optimiser sees is loss_scale x the fp32 run's
+        gradient, the clip sees the UNSCALED norm, parameters track the fp32 trainer's;
+    (c) GradScaler's overflow contract: a non-finite gradient makes the step a no-op for parameters / moments / the Adam step counter,
+        halves the scale, still zeroes the gradients; growth after `growth_interval` clean steps."""
+    import v2a_hip
+    from oracle import policy as OP
+    g = np.load(f"{golden_dir}/policy.npz", allow_pickle=True)
+    names = [str(n) for n in g["param_names"]]
+    noise, ts = torch.from_numpy(g["noise"]), torch.from_numpy(g["timesteps"])
+    res = {}
+    for mode in ("bf16", "fp16"):
+        pol, sd = _policy()
+        batch = _batch(g)
+        pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
+        old = v2a_hip.set_precision(mode)
+        try:
+            assert v2a_hip.get_precision() == mode
+            pol.engine.refresh_packs()
+            loss = pol.compute_loss(batch)
+            loss.backward()
+        finally:
+            v2a_hip.set_precision(old)
+        P = dict(pol.named_parameters())
+        res[mode] = (loss.item(), torch.cat([P[n].grad.flatten().cpu() for n in names]).double())
+    assert v2a_hip.get_precision() == "fp32"
+    _, og = OP.loss_and_grads(sd, batch, noise, ts, names=names)
+    ref = torch.cat([og[n].flatten() for n in names]).double()
+    err = {m: float((res[m][1] - ref).norm() / ref.norm()) for m in res}
+    cos = float((res["fp16"][1] * ref).sum() / (res["fp16"][1].norm() * ref.norm()))
+    print(f"[16-bit policy modes] gradient relative L2 distance to the fp32 oracle: bf16 {err['bf16']:.2e}, fp16 {err['fp16']:.2e}; fp16 cos {cos:.6f}")
+    assert abs(res["fp16"][0] - float(g["loss"])) <= 1e-2 * abs(float(g["loss"]))
+    assert cos >= 0.995 and err["fp16"] < err["bf16"], (cos, err)
+
+    # (b) + (c): the trainer with the scaler
+    from v2a_hip.trainer import PolicyTrainer
+    import bench
+    B = 8
+    store = bench.build_store(torch, "cuda:0", B, seed=5)
+    gen = torch.Generator().manual_seed(9)
+    feed = dict(rows=np.arange(B, dtype=np.int64) * 200 + 7, noise=torch.randn(B, 16, 7, generator=gen), timesteps=torch.randint(0, 100, (B,), generator=gen))
+    runs = {}
+    for mode in ("fp32", "fp16"):
+        pol, _ = _policy(seed=3)
+        old = v2a_hip.set_precision(mode)
+        try:
+            tr = PolicyTrainer(pol, store, batch_size=B, seed=1, use_graph=False)
+            assert tr.loss_scaling == (mode == "fp16")
+            snap = {}
+            tr.feed = feed
+            tr.on_grads_ready = lambda arena: snap.update(g=arena.detach().clone())
+            tr.step()
+            gn, cc, step, _ = tr.opt.peek()
+            p_after = torch.cat([p.detach().flatten() for p in pol.parameters()])[::499].cpu()
+            runs[mode] = dict(g=snap["g"].cpu().double(), gn=gn, cc=cc, step=step, p=p_after, scaler=tr.opt.scaler() if mode == "fp16" else None)
+            if mode == "fp16":
+                # (c) poison one gradient element on the way to the optimiser: the step must be skipped
+                p_before = torch.cat([p.detach().flatten() for p in pol.parameters()]).clone()
+                m_before = tr.opt.m.clone()
+                tr.on_grads_ready = lambda arena: arena[12345:12346].fill_(float("inf"))
+                tr.step()
+                ls, gt, skipped, nskip = tr.opt.scaler()
+                assert skipped and nskip == 1 and ls == 32768.0 and gt == 0, (ls, gt, skipped, nskip)
+                assert tr.opt.peek()[2] == 1                                      # Adam step counter did not advance
+                assert torch.equal(torch.cat([p.detach().flatten() for p in pol.parameters()]), p_before) and torch.equal(tr.opt.m, m_before)
+                assert float(tr.arena.abs().max()) == 0.0                         # zero_grad still ran
+                tr.on_grads_ready = None
+                tr.step()                                                         # and a clean step afterwards is taken
+                ls2, gt2, skipped2, _ = tr.opt.scaler()
+                assert not skipped2 and ls2 == 32768.0 and gt2 == 1 and tr.opt.peek()[2] == 2
+            del tr
+        finally:
+            v2a_hip.set_precision(old)
+    S = runs["fp16"]["scaler"][0]
+    assert S == 65536.0 and runs["fp16"]["scaler"][1] == 1 and not runs["fp16"]["scaler"][2]
+    gs, g32 = runs["fp16"]["g"] / S, runs["fp32"]["g"]
+    rel_g = float((gs - g32).norm() / g32.norm())
+    print(f"[fp16 trainer] loss scale {S:.0f}; unscaled gradient vs the fp32 trainer's: relative L2 {rel_g:.2e}; "
+          f"grad norm {runs['fp16']['gn']:.5f} vs {runs['fp32']['gn']:.5f}")
+    assert rel_g <= 2e-2
+    assert abs(runs["fp16"]["gn"] - runs["fp32"]["gn"]) <= 2e-2 * runs["fp32"]["gn"]          # the clip saw the unscaled norm
+    assert abs(runs["fp16"]["cc"] * S - runs["fp32"]["cc"]) <= 2e-2 * runs["fp32"]["cc"]      # its factor carries 1 / scale
+    assert float((runs["fp16"]["p"] - runs["fp32"]["p"]).abs().max()) <= 2.5e-4               # first Adam step is sign-like: +- lr
+
+
 def _dp_worker(rank, world, port, q):
     import os, sys, random
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -87,13 +87,17 @@ __global__ void add_noise_kernel(const float* act, const float* noise, const int
     out[i] = sqrtf(a) * na + sqrtf(1.0f - a) * noise[i];
 }
 // loss = mean((pred - target)^2) ; dpred = 2 (pred - target) / n      (single workgroup: n = B*16*7 is tiny)
-__global__ __launch_bounds__(256) void mse_loss_kernel(const float* pred, const float* target, float* loss, float* dpred, int n) {
+// grad_scale (device, optional): the loss gradient is multiplied by *grad_scale -- the dynamic loss scale of the fp16 mode (csrc/optim.hip
+// OptState.loss_scale; the reported loss stays unscaled)
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* pred, const float* target, float* loss, float* dpred, int n,
+                                                       const float* grad_scale) {
     __shared__ double sm[4];
     double s = 0.0;
+    const float gs = grad_scale ? *grad_scale : 1.0f;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float d = pred[i] - target[i];
         s += (double)d * d;
-        if (dpred) dpred[i] = 2.0f * d / (float)n;
+        if (dpred) dpred[i] = (2.0f * d / (float)n) * gs;
     }
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
@@ -600,10 +604,13 @@ int v2a_add_noise(const float* act, const float* noise, const int64_t* t, const 
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
-int v2a_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int n, hipStream_t s) {
-    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, s, pred, target, loss, dpred, n);
+int v2a_mse_loss_scaled(const float* pred, const float* target, float* loss, float* dpred, int n, const float* grad_scale_dev, hipStream_t s) {
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, s, pred, target, loss, dpred, n, grad_scale_dev);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
+}
+int v2a_mse_loss(const float* pred, const float* target, float* loss, float* dpred, int n, hipStream_t s) {
+    return v2a_mse_loss_scaled(pred, target, loss, dpred, n, nullptr, s);
 }
 int v2a_policy_sched_step(const float* eps, const float* sample, const float* noise, float* out, int n, float c_sb, float c_sa,
                           float c0, float c1, float sigma, int mode, hipStream_t s) {

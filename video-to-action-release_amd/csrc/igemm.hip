@@ -315,7 +315,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return v2a_pack_bf16x2(a, b);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvDesc p) {
     constexpr int BKT = 32, KC = 8, RPP = 32, LDH = 40;         // 40 halves = 80-B rows
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -382,12 +382,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvDesc p) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            uint2 u = {pack_bf16x2(ra[i][0], ra[i][1]), pack_bf16x2(ra[i][2], ra[i][3])};
+            uint2 u = {v2a_pack_h2<F16>(ra[i][0], ra[i][1]), v2a_pack_h2<F16>(ra[i][2], ra[i][3])};
             *reinterpret_cast<uint2*>(&As[buf][(lrow + i * RPP) * LDH + chunk * 4]) = u;
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
-            uint2 u = {pack_bf16x2(rb[i][0], rb[i][1]), pack_bf16x2(rb[i][2], rb[i][3])};
+            uint2 u = {v2a_pack_h2<F16>(rb[i][0], rb[i][1]), v2a_pack_h2<F16>(rb[i][2], rb[i][3])};
             *reinterpret_cast<uint2*>(&Bs[buf][(lrow + i * RPP) * LDH + chunk * 4]) = u;
         }
     };
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvDesc p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(a[i], b[j], acc[i][j]);
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
@@ -655,6 +655,7 @@ struct WgradDesc {
     int N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, ups, HL, WL, M, K;
     int splits, rtiles_per_split;
     int accumulate;                    // 1: dw += result
+    int f16;                           // twin-fed bodies: the 16-bit twins are IEEE fp16 (1) or bf16 (0)
     FastDiv fd_ow, fd_oh;
 };
 
@@ -1099,7 +1100,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo_f32(const WgradDesc p)
     __shared__ __attribute__((aligned(128))) unsigned char smem[wgrad_halo_lds<TW>()];
     wgrad_halo_body<TW>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
-static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: bf16 MFMA, fp32 storage / accumulate
+static int g_precision = 0;   // 0: exact-f32 MFMA (parity configuration)  1: 16-bit MFMA inputs, fp32 storage / accumulate
+int g_v2a_policy_f16 = 0;     // 16-bit format of the policy's MFMA mode: 0 bf16 (default), 1 IEEE fp16 (v2a_set_policy_half; the reference's GPU
+                              // path is fp16 autocast + GradScaler: lb_online_trainer_v7.py:72-76,593,604-612)
 static int g_wforce_bm = 0;   // experiments only (v2a_debug_force_wgrad_plan)
 // split of the halo kernel: ~512 workgroups (two resident per CU), at least 8 k tiles per slice
 static int wgrad_halo_split(int M, int Cout, int K) {
@@ -1130,7 +1133,7 @@ static bool wgrad_halo_shape_ok(int M, int Cout, int K) {
 // bf16-MFMA weight gradient.  The MFMA wants 8 consecutive reduction rows per lane while HBM is contiguous along the OTHER axis
 // (channels), so each loader thread owns a 8(rows) x 4(channels) register block: 8 coalesced float4 loads, then four b128 LDS
 // stores of 8 bf16 along the reduction axis ([channel][32 rows + pad] tiles).  Threads [0,BM) stage dY^T, [BM,BM+BN) the im2col.
-template <int BM, int BN>
+template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
     constexpr int BKT = 32, LDH = 40;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -1209,8 +1212,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
             uint16_t* dst = (isA ? &As[buf][0] : &Bs[buf][0]) + (c4 * 4) * LDH + rgrp * 8;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint4 u = {pack_bf16x2(rv[0][j], rv[1][j]), pack_bf16x2(rv[2][j], rv[3][j]), pack_bf16x2(rv[4][j], rv[5][j]),
-                           pack_bf16x2(rv[6][j], rv[7][j])};
+                uint4 u = {v2a_pack_h2<F16>(rv[0][j], rv[1][j]), v2a_pack_h2<F16>(rv[2][j], rv[3][j]), v2a_pack_h2<F16>(rv[4][j], rv[5][j]),
+                           v2a_pack_h2<F16>(rv[6][j], rv[7][j])};
                 *reinterpret_cast<uint4*>(dst + j * LDH) = u;
             }
         }
@@ -1244,7 +1247,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(a[i], b[j], acc[i][j]);
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
@@ -1472,7 +1475,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3(const WgradDesc p) {
 // already made), instead of converting fp32 while staging: the kernel above is bound by operand traffic through the L2 fabric (32 KB
 // per workgroup per 256 MFMA cycles), so half the bytes is the lever.  Loader thread = 4 reduction rows x 8 channels (one 16-B load per
 // row), transposed into the [channel][32 rows + pad] LDS image with eight 8-B stores; MFMA loop, split slabs and epilogue as above.
-template <int BM, int BN>
+template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
     constexpr int BKT = 32, LDH = 40;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -1591,7 +1594,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(a[i], b[j], acc[i][j]);
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
@@ -1641,7 +1644,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16h(const WgradDesc p) {
 // MFMA operand.  LDS image: [64 rows][128 columns] bf16 per operand (256-B rows), 16-B pieces XOR-swizzled by 4 * (row & 3) at the
 // DMA source so that the four rows of a block sit in different 64-B bank quarters.  Single buffer (32 KB, 4 workgroups per CU) like
 // the forward kernel; split slabs / bias partials / reduce kernel shared with the other weight-gradient kernels.
-template <int BM>
+template <int BM, bool F16>
 __device__ __forceinline__ void wgrad_tr_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
     // tile: BM (128 | 64) output channels x 128 k' columns, 64 reduction rows; BM = 64 serves the 64-channel layers (one wave row less
     // per workgroup column: waves 2 x 2 over 64 x 128, each 32 x 64)
@@ -1764,7 +1767,7 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradDesc& p, const int tile
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const uint4 ua = {al[i].x, al[i].y, ah[i].x, ah[i].y}, ub = {bl[j].x, bl[j].y, bh[j].x, bh[j].y};
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[i][j], 0, 0, 0);
+                    acc[i][j] = v2a_mfma_h<F16>(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[i][j]);
                 }
         }
         if (do_bias && tid < BM) {
@@ -1799,10 +1802,10 @@ __device__ __forceinline__ void wgrad_tr_body(const WgradDesc& p, const int tile
         }
     }
 }
-template <int BM>
+template <int BM, bool F16>
 __global__ __launch_bounds__(256, 4) void conv_wgrad_tr_h(const WgradDesc p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[64 * BM * 2 + 64 * 256];
-    wgrad_tr_body<BM>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+    wgrad_tr_body<BM, F16>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // ---- MANY weight gradients in ONE launch.  A 4.8-GFLOP policy-step gradient alone pays ~25-40 us of ramp-up / drain around ~48 us
@@ -1833,8 +1836,11 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_multi_kernel(const WgradMul
     const int split = lin / tiles, tile = lin - split * tiles;
     const int v = a.variant[i];
     if (v == 0) wgrad_dma_body<64, 64, 2>(a.d[i], tile, split, smem);
-    else if (v == 1) wgrad_tr_body<128>(a.d[i], tile, split, smem);
-    else wgrad_tr_body<64>(a.d[i], tile, split, smem);
+    else if (a.d[i].f16) {                                      // twin format of this problem (uniform): IEEE fp16 | bf16
+        if (v == 1) wgrad_tr_body<128, true>(a.d[i], tile, split, smem);
+        else wgrad_tr_body<64, true>(a.d[i], tile, split, smem);
+    } else if (v == 1) wgrad_tr_body<128, false>(a.d[i], tile, split, smem);
+    else wgrad_tr_body<64, false>(a.d[i], tile, split, smem);
 }
 
 // The same for the halo-tile body (3x3 / stride 1 / pad 1 layers, exact f32): a workgroup owns 64 output channels x (64 input
@@ -2047,10 +2053,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 // (contiguous along Cin*taps) and the global writes (contiguous along Cout) are full lines.
 // A non-zero 7th column also writes the bf16 twin of the operand (the LDS-DMA kernels' weight operand).
 #define PACK_CHUNK 16384
-__device__ __forceinline__ uint16_t f2bf_pack(float f) {
-    return v2a_f2bf(f);
+__device__ __forceinline__ uint16_t f2h_pack(float f, int f16) {
+    return f16 ? v2a_f2h<true>(f) : v2a_f2bf(f);
 }
-__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* table, const int* chunks) {
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* table, const int* chunks, const int f16) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
     const float* src = reinterpret_cast<const float*>(table[t * 7 + 0]);
     float* dst = reinterpret_cast<float*>(table[t * 7 + 1]);
@@ -2069,7 +2075,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
         const size_t idx = (size_t)start + i;
         const float v = src[((size_t)co * Cin + ci) * taps + tap];
         if (dst) dst[idx] = v;
-        if (dsth) dsth[idx] = f2bf_pack(v);
+        if (dsth) dsth[idx] = f2h_pack(v, f16);
         ci += 256;
         while (ci >= Cin) {
             ci -= Cin;
@@ -2077,7 +2083,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
         }
     }
 }
-__global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t* table, const int* chunks) {
+__global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t* table, const int* chunks, const int f16) {
     __shared__ float tile[64][65];
     const int t = chunks[2 * blockIdx.x], tl = chunks[2 * blockIdx.x + 1];
     const float* src = reinterpret_cast<const float*>(table[t * 7 + 0]);
@@ -2099,7 +2105,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t
             const size_t o = ((size_t)ci * taps + (taps - 1 - tap)) * Cout + co;
             const float v = tile[tx][r];
             if (dst) dst[o] = v;
-            if (dsth) dsth[o] = f2bf_pack(v);
+            if (dsth) dsth[o] = f2h_pack(v, f16);
         }
     }
 }
@@ -2206,6 +2212,14 @@ int v2a_set_precision(int mode) {
     return old;
 }
 int v2a_get_precision(void) { return g_precision; }
+// 16-bit format of the policy's MFMA mode (v2a_set_precision(1)): 0 bf16 (default), 1 IEEE fp16 -- the register-staged kernels round
+// fp32 operands to it, the twin-fed kernels read twins in it, GroupNorm / the weight packs emit twins in it.  Returns the old value.
+int v2a_set_policy_half(int f16) {
+    const int old = g_v2a_policy_f16;
+    if (f16 == 0 || f16 == 1) g_v2a_policy_f16 = f16;
+    return old;
+}
+int v2a_get_policy_half(void) { return g_v2a_policy_f16; }
 static int wgrad_dma_on() {
     if (g_wgrad_dma < 0) {
         const char* e = getenv("V2A_WGRAD_DMA");
@@ -2303,9 +2317,13 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     if (g_precision == 1 && vec && Cin % 32 == 0 && !p.bmode) {     // bf16 MFMA (data gradients then use the flipped pack, bmode 0)
         p.splitk = s;
         p.ktiles_per_split = cdiv(cdiv(p.K, 32), s);
-        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 128>), grid, block, 0, stream, p);
-        else if (bm == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 64>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_bf16<64, 64>), grid, block, 0, stream, p);
+        if (g_v2a_policy_f16) {
+            if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 128, true>), grid, block, 0, stream, p);
+            else if (bm == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 64, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm_bf16<64, 64, true>), grid, block, 0, stream, p);
+        } else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 128, false>), grid, block, 0, stream, p);
+        else if (bm == 128) hipLaunchKernelGGL((conv_igemm_bf16<128, 64, false>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_bf16<64, 64, false>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
             size_t total = (size_t)p.M * Cout;
@@ -2383,6 +2401,7 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* x2_h, const void* dy_h, floa
     p.K = KH * KW * (C + C2);
     if (p.K <= 64) return V2A_ERR_ARG;
     p.accumulate = accumulate;
+    p.f16 = g_v2a_policy_f16;
     p.fd_ow = make_fastdiv((uint32_t)OW);
     p.fd_oh = make_fastdiv((uint32_t)OH);
     const bool bm64 = Cout <= 64;                   // 64-channel layers: the 64 x 128 instance
@@ -2398,11 +2417,15 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* x2_h, const void* dy_h, floa
     if (!use_tr && (bm64 || C2 > 0)) return V2A_ERR_ARG;        // (the register-staged fallback has no 64-row / two-source instance)
     if (use_tr && (((uintptr_t)x_h | (uintptr_t)x2_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * (C > C2 ? C : C2) < 2147483648.0) {
         p.rtiles_per_split = cdiv(cdiv(p.M, 64), s);
-        if (bm64) hipLaunchKernelGGL(conv_wgrad_tr_h<64>, dim3(tiles, s), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL(conv_wgrad_tr_h<128>, dim3(tiles, s), dim3(256), 0, stream, p);
+        if (g_v2a_policy_f16) {
+            if (bm64) hipLaunchKernelGGL((conv_wgrad_tr_h<64, true>), dim3(tiles, s), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_wgrad_tr_h<128, true>), dim3(tiles, s), dim3(256), 0, stream, p);
+        } else if (bm64) hipLaunchKernelGGL((conv_wgrad_tr_h<64, false>), dim3(tiles, s), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_tr_h<128, false>), dim3(tiles, s), dim3(256), 0, stream, p);
     } else {
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
-        hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128>), dim3(tiles, s), dim3(256), 0, stream, p);
+        if (g_v2a_policy_f16) hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128, true>), dim3(tiles, s), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16h<128, 128, false>), dim3(tiles, s), dim3(256), 0, stream, p);
     }
     V2A_CHECK_LAUNCH();
     if (s > 1) {
@@ -2428,6 +2451,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     const int Cin = C1 + C2;
     p.K = KH * KW * Cin;
     p.accumulate = accumulate;
+    p.f16 = g_v2a_policy_f16;
     p.fd_ow = make_fastdiv((uint32_t)OW);
     p.fd_oh = make_fastdiv((uint32_t)OH);
     const bool veca = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
@@ -2464,9 +2488,13 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     if (g_precision == 1 && veca && vecb && !(bm == 64 && dma_ok)) {
         p.splits = s;
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
-        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128>), grid, block, 0, stream, p);
-        else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 64>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_bf16<64, 64>), grid, block, 0, stream, p);
+        if (g_v2a_policy_f16) {
+            if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128, true>), grid, block, 0, stream, p);
+            else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 64, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((conv_wgrad_bf16<64, 64, true>), grid, block, 0, stream, p);
+        } else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128, false>), grid, block, 0, stream, p);
+        else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_bf16<128, 64, false>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16<64, 64, false>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
             launch_wgrad_reduce(p, stream);
@@ -2591,6 +2619,7 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
     const int Cin = C1 + C2;
     p.K = KH * KW * Cin;
     p.accumulate = accumulate;
+    p.f16 = g_v2a_policy_f16;
     p.fd_ow = make_fastdiv((uint32_t)OW);
     p.fd_oh = make_fastdiv((uint32_t)OH);
     int variant = -1;
@@ -2675,8 +2704,8 @@ int v2a_pack_chunk_elems(void) { return PACK_CHUNK; }
 // transposed = 0: the mode-0 rows (chunks = {operand, start}); transposed = 1: the mode-1 rows (chunks = {operand, 64x64 tile}).
 int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, int transposed, hipStream_t stream) {
     if (!table_dev || !chunks_dev || nchunks <= 0) return V2A_ERR_ARG;
-    if (transposed) hipLaunchKernelGGL(pack_weights_multi_t_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev);
-    else hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev);
+    if (transposed) hipLaunchKernelGGL(pack_weights_multi_t_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev, g_v2a_policy_f16);
+    else hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nchunks), dim3(256), 0, stream, table_dev, chunks_dev, g_v2a_policy_f16);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -32,6 +32,7 @@ struct GnDesc {
     const float* st1;       // forward large path: per-64-row (sum, sum of squares) blocks of x from the producing conv's epilogue
     const float* st2;       // ... and of x2 ([N * S/64][2][C1] / [N * S/64][2][C - C1]); replaces the gn_colreduce pass over the tensor
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
+    int yh_f16;             // format of the twin `yh`: 0 bf16, 1 IEEE fp16 (the policy's 16-bit mode: v2a_set_policy_half)
     unsigned short* yh;     // optional bf16 twin of the output (forward: y, backward: dx), same shape: feeds the bf16-MFMA convs
     float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
     int film_ld;            // elements between the FiLM rows of consecutive samples (2*C when the [N][2][C] tensor is dense)
@@ -53,13 +54,13 @@ struct GnDesc {
 #define GN_GAMMA(p, n) (((n) >= (p).n_split) ? (p).gamma2 : (p).gamma)
 #define GN_BETA(p, n) (((n) >= (p).n_split) ? (p).beta2 : (p).beta)
 
-__device__ __forceinline__ unsigned short gn_f2bf(float f) {      // round to nearest even, as v2a_cast_f32_bf16
-    return v2a_f2bf(f);
+__device__ __forceinline__ unsigned short gn_f2h(float f, int f16) {      // round to nearest even, as v2a_cast_f32_h (bf16 | IEEE fp16)
+    return f16 ? v2a_f2h<true>(f) : v2a_f2bf(f);
 }
-__device__ __forceinline__ void gn_store_twin4(unsigned short* yh, size_t i4, const f32x4& o) {
+__device__ __forceinline__ void gn_store_twin4(unsigned short* yh, size_t i4, const f32x4& o, int f16) {
     uint2 u;
-    u.x = (unsigned int)gn_f2bf(o[0]) | ((unsigned int)gn_f2bf(o[1]) << 16);
-    u.y = (unsigned int)gn_f2bf(o[2]) | ((unsigned int)gn_f2bf(o[3]) << 16);
+    u.x = f16 ? v2a_pack_h2<true>(o[0], o[1]) : v2a_pack_h2<false>(o[0], o[1]);
+    u.y = f16 ? v2a_pack_h2<true>(o[2], o[3]) : v2a_pack_h2<false>(o[2], o[3]);
     reinterpret_cast<uint2*>(yh)[i4] = u;
 }
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_rows(const GnDesc p) {
             }
             const size_t off4 = ((size_t)row[k] * C + c) >> 2;
             reinterpret_cast<f32x4*>(yo)[off4] = o;
-            if (p.yh) gn_store_twin4(p.yh + (size_t)n * p.S * C, off4, o);
+            if (p.yh) gn_store_twin4(p.yh + (size_t)n * p.S * C, off4, o, p.yh_f16);
         }
     }
 }
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
             o[j] = a;
         }
         y4[i] = o;
-        if (p.yh) gn_store_twin4(p.yh, i, o);
+        if (p.yh) gn_store_twin4(p.yh, i, o, p.yh_f16);
     }
 }
 
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
             o[j] = rs * (GN_GAMMA(p, n)[c] * dz - (A1 + xh * A2) * inv_cnt);
         }
         y4[i] = o;
-        if (p.yh) gn_store_twin4(p.yh, i, o);
+        if (p.yh) gn_store_twin4(p.yh, i, o, p.yh_f16);
         if (dr4) dr4[i] = dzv;
     }
 }
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
                 o[j] = a;
             }
             *reinterpret_cast<f32x4*>(p.y + off) = o;
-            if (p.yh) gn_store_twin4(p.yh, off >> 2, o);
+            if (p.yh) gn_store_twin4(p.yh, off >> 2, o, p.yh_f16);
         }
         return;
     }
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
         float a = act_fwd(z, p.act);
         if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
         p.y[off] = a;
-        if (p.yh) p.yh[off] = gn_f2bf(a);
+        if (p.yh) p.yh[off] = gn_f2h(a, p.yh_f16);
     }
 }
 
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = rs * (gm[j] * zv[j] - (A1 + hv[j] * A2) * inv);
             *reinterpret_cast<f32x4*>(p.y + off) = o;
-            if (p.yh) gn_store_twin4(p.yh, off >> 2, o);
+            if (p.yh) gn_store_twin4(p.yh, off >> 2, o, p.yh_f16);
             if (p.dres) *reinterpret_cast<f32x4*>(p.dres + off) = zv;
         }
     } else {
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
         const size_t off = base + (size_t)row * C + cc;
         const float dxv = rs * (GN_GAMMA(p, n)[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
         p.y[off] = dxv;
-        if (p.yh) p.yh[off] = gn_f2bf(dxv);
+        if (p.yh) p.yh[off] = gn_f2h(dxv, p.yh_f16);
         if (p.dres) p.dres[off] = dzs[i];
     }
     }
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(64) void gn_wave_fwd(const GnDesc p) {
             float a = act_fwd(z, p.act);
             if (p.film) a = f0[j] * a + f1[j];
             p.y[off] = a;
-            if (p.yh) p.yh[off] = gn_f2bf(a);
+            if (p.yh) p.yh[off] = gn_f2h(a, p.yh_f16);
         }
 }
 
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
             const size_t off = base + (size_t)row * C + cc;
             const float dxv = rs * (gmv[j] * dz[j] - (A1 + xh[j] * A2) * inv);
             p.y[off] = dxv;
-            if (p.yh) p.yh[off] = gn_f2bf(dxv);
+            if (p.yh) p.yh[off] = gn_f2h(dxv, p.yh_f16);
             if (p.dres) p.dres[off] = dz[j];
         }
     if (CG < 64) {                       // lanes l, l + CG, l + 2 CG ... hold the same channel: fixed xor tree
@@ -926,7 +927,9 @@ extern "C" int v2a_groupnorm_set_second(const float* gamma2, const float* beta2,
     g_gn_gamma2 = gamma2; g_gn_beta2 = beta2; g_gn_nsplit = gamma2 ? n_split : 0x7fffffff;
     return V2A_OK;
 }
+extern int g_v2a_policy_f16;
 static void gn_take_second(GnDesc& p) {
+    p.yh_f16 = g_v2a_policy_f16;
     p.gamma2 = g_gn_gamma2; p.beta2 = g_gn_beta2; p.n_split = g_gn_gamma2 ? g_gn_nsplit : 0x7fffffff;
     g_gn_gamma2 = nullptr; g_gn_beta2 = nullptr; g_gn_nsplit = 0x7fffffff;
 }

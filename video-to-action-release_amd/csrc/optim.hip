@@ -22,6 +22,15 @@ struct OptState {           // device resident
     float step_size, inv_sqrt_bc2, decay_mul;   // decay_mul = 1 - lr*wd
     float ema_decay;
     int ema_mode;            // bit0 copy, bit1 lerp
+    // dynamic loss scaling of the fp16 policy mode = torch.cuda.amp.GradScaler's contract (the reference trains under accelerate's fp16
+    // mixed precision: lb_online_trainer_v7.py:72-76; backward of the scaled loss :604, clip_grad_norm_ on UNSCALED gradients :608,
+    // optimiser step skipped on inf / nan :612, ema.update() regardless :623).  scaler_on = 0: everything below is inert.
+    int scaler_on;
+    float loss_scale;        // S: the loss-gradient kernel multiplies by it (v2a_mse_loss reads it from here), the gradients carry it
+    int growth_tracker, growth_interval;
+    float growth_factor, backoff_factor;
+    int skip;                // this step found a non-finite gradient: parameters / moments / Adam step untouched
+    long long skipped_steps;
 };
 
 __global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, const int* chunks, double* partial) {
@@ -47,11 +56,28 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const double norm = sqrt(sm[0] + sm[1] + sm[2] + sm[3]);
+    double norm = sqrt(sm[0] + sm[1] + sm[2] + sm[3]);
+    double unscale = 1.0;
+    st->skip = 0;
+    if (st->scaler_on) {
+        // GradScaler.unscale_ + step + update: the sum of squares of the SCALED gradients overflows / is nan exactly when one of them is
+        const bool bad = !(norm == norm) || norm > 3.0e38;
+        unscale = 1.0 / (double)st->loss_scale;
+        if (bad) {
+            st->skip = 1;
+            st->skipped_steps += 1;
+            st->loss_scale *= st->backoff_factor;
+            st->growth_tracker = 0;
+        } else if (++st->growth_tracker >= st->growth_interval) {
+            st->loss_scale *= st->growth_factor;
+            st->growth_tracker = 0;
+        }
+        norm *= unscale;
+    }
     st->grad_norm = (float)norm;
     double coef = st->max_norm / ((double)(float)norm + 1e-6);
-    st->clip_coef = (float)(coef > 1.0 ? 1.0 : coef);
-    st->step += 1;
+    st->clip_coef = (float)((coef > 1.0 ? 1.0 : coef) * unscale);      // the update kernel multiplies every gradient by this: unscale is free
+    if (!st->skip) st->step += 1;
     const double bc1 = 1.0 - pow(st->b1, (double)st->step), bc2 = 1.0 - pow(st->b2, (double)st->step);
     st->step_size = (float)(st->lr / bc1);
     st->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -91,6 +117,18 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
     const float clip = st->clip_coef, b1 = (float)st->b1, b2 = (float)st->b2, eps = (float)st->eps;
     const float step_size = st->step_size, isb2 = st->inv_sqrt_bc2, dmul = st->decay_mul, dec = st->ema_decay;
     const int mode = st->ema_mode;
+    if (st->skip) {                                     // non-finite gradients: no parameter / moment update; EMA and zero_grad still run
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            if (zero_grad) g[i] = 0.f;
+            if (e && mode) {
+                const float pv = p[i];
+                float ev = (mode & 1) ? pv : e[i];
+                if (mode & 2) { const float d = (ev - pv) * (1.0f - dec); ev = ev - d; }
+                e[i] = ev;
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const float gr = g[i] * clip;
         float pv = p[i] * dmul;
@@ -156,6 +194,29 @@ int v2a_opt_state_counters(const void* host_state, long long* step, long long* e
     if (ema_initted) *ema_initted = s->ema_initted;
     return V2A_OK;
 }
+// dynamic loss scaling (fp16 policy mode): patch a HOST copy of the state.  init_scale <= 0 switches the scaler off.
+int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_factor, double backoff_factor, int growth_interval) {
+    OptState* s = reinterpret_cast<OptState*>(host_state);
+    if (!s) return V2A_ERR_ARG;
+    s->scaler_on = init_scale > 0 ? 1 : 0;
+    s->loss_scale = init_scale > 0 ? (float)init_scale : 1.0f;
+    s->growth_factor = (float)growth_factor; s->backoff_factor = (float)backoff_factor;
+    s->growth_interval = growth_interval < 1 ? 1 : growth_interval;
+    s->growth_tracker = 0; s->skip = 0; s->skipped_steps = 0;
+    return V2A_OK;
+}
+// {loss_scale, growth_tracker, skip flag of the last step, skipped steps so far} of a HOST copy
+int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps) {
+    const OptState* s = reinterpret_cast<const OptState*>(host_state);
+    if (!s) return V2A_ERR_ARG;
+    if (loss_scale) *loss_scale = s->loss_scale;
+    if (growth_tracker) *growth_tracker = s->growth_tracker;
+    if (skipped_last) *skipped_last = s->skip;
+    if (skipped_steps) *skipped_steps = s->skipped_steps;
+    return V2A_OK;
+}
+// byte offset of loss_scale inside the device state block (v2a_mse_loss reads the scale from there)
+size_t v2a_opt_state_loss_scale_offset(void) { return offsetof(OptState, loss_scale); }
 int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_step, int ema_initted, double lr) {
     OptState* s = reinterpret_cast<OptState*>(host_state);
     if (!s || step < 0 || ema_step < 0) return V2A_ERR_ARG;

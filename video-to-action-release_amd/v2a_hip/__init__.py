@@ -6,14 +6,31 @@ from ._lib import lib, V2AError, LIB_PATH  # noqa: F401
 
 
 def set_precision(mode: str) -> str:
-    """'fp32' (exact-f32 MFMA: the parity configuration, default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate / storage)."""
-    code = {"fp32": 0, "f32": 0, "bf16": 1}[mode]
-    old = lib.v2a_set_precision(code)
-    return "bf16" if old == 1 else "fp32"
+    """'fp32' (fp32 arithmetic: the parity configuration, default), 'bf16' or 'fp16' (16-bit MFMA inputs, fp32 accumulate / storage).
+    'fp16' = IEEE half inputs, the reference's own GPU precision (accelerate mixed_precision='fp16': lb_online_trainer_v7.py:72-76);
+    PolicyTrainer then runs its fused optimiser with dynamic loss scaling (GradScaler's contract)."""
+    code = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 1}[mode]
+    old = get_precision()
+    lib.v2a_set_precision(code)
+    if code == 1:
+        set_policy_half(mode)
+    return old
 
 
 def get_precision() -> str:
-    return "bf16" if lib.v2a_get_precision() == 1 else "fp32"
+    if lib.v2a_get_precision() != 1:
+        return "fp32"
+    return "fp16" if lib.v2a_get_policy_half() == 1 else "bf16"
+
+
+def set_policy_half(mode: str) -> str:
+    """16-bit format of the policy's MFMA mode: 'bf16' (default) or 'fp16'."""
+    import torch
+    from . import ops
+    f16 = {"bf16": 0, "fp16": 1}[mode]
+    old = lib.v2a_set_policy_half(f16)
+    ops.POLICY_HALF[0] = torch.float16 if f16 else torch.bfloat16
+    return "fp16" if old == 1 else "bf16"
 
 
 _video_storage = ["f32"]

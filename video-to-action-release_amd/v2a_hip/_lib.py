@@ -23,6 +23,8 @@ SIGNATURES = {
     "v2a_set_half_format": (I, [I]),
     "v2a_get_half_format": (I, []),
     "v2a_get_precision": (I, []),
+    "v2a_set_policy_half": (I, [I]),
+    "v2a_get_policy_half": (I, []),
     "v2a_debug_force_tile": (I, [I, I]),
     "v2a_debug_force_wgrad_plan": (I, [I, I, I]),
     "v2a_conv2d_workspace_bytes": (SZ, [I, I, I]),
@@ -59,6 +61,7 @@ SIGNATURES = {
     "v2a_sincos_embed": (I, [P, P, I, I, I, P]),
     "v2a_add_noise": (I, [P, P, P, P, P, I, I, P, P, I, P]),
     "v2a_mse_loss": (I, [P, P, P, P, I, P]),
+    "v2a_mse_loss_scaled": (I, [P, P, P, P, I, P, P]),
     "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
     "v2a_gn_param_grads_multi": (I, [P, P, I, P]),
     "v2a_groupnorm_takes_slabs": (I, [I, I, I]),
@@ -148,6 +151,9 @@ SIGNATURES = {
     "v2a_opt_state_peek": (I, [P, P, P, P, P]),
     "v2a_opt_state_counters": (I, [P, P, P, P]),
     "v2a_opt_state_set_counters": (I, [P, LL, LL, I, D]),
+    "v2a_opt_state_set_scaler": (I, [P, D, D, D, I]),
+    "v2a_opt_state_scaler": (I, [P, P, P, P, P]),
+    "v2a_opt_state_loss_scale_offset": (SZ, []),
     "v2a_opt_step": (I, [P, P, I, P, P, I, P]),
     "v2a_opt_scale_grads": (I, [P, P, I, F, P]),
     "v2a_replay_sample_indices": (I, [P, P, P, I, I, I, P, P]),

@@ -237,8 +237,8 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
             and not (ups and idil > 1) and N * H * W >= _H_ROUTE_MIN_ROWS[0] and lib.v2a_get_precision() == 1):
         wh = _twin_of(w_packed)
         if wh is not None:
-            xh = x_h.view(x.shape) if x_h is not None else cast_h(x)
-            x2h = None if x2 is None else cast_h(x2)
+            xh = x_h.view(x.shape) if x_h is not None else cast_h(x, POLICY_HALF[0])
+            x2h = None if x2 is None else cast_h(x2, POLICY_HALF[0])
             if keep_h is not None:
                 keep_h.append(xh)
                 if x2h is not None:
@@ -521,6 +521,7 @@ def _zero_line(device):
     return z
 
 
+POLICY_HALF = [torch.bfloat16]                     # dtype of the policy's 16-bit twins (v2a_hip.set_policy_half: bf16 | fp16)
 HALF_DTYPES = (torch.bfloat16, torch.float16)      # the two 16-bit storage formats (csrc/common.h: template flag F16 of the `_h` kernels)
 
 
@@ -776,7 +777,7 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
     yh = None
     if twin_out is not None and C % 4 == 0:
-        yh = torch.empty((N, S, C), dtype=torch.bfloat16, device=x.device)
+        yh = torch.empty((N, S, C), dtype=POLICY_HALF[0], device=x.device)
         twin_out.append(yh)
     _gn_second(second)
     if slabs is not None:      # x is the (still unwritten) conv output: the kernel sums the conv's split-K slabs and stores x too
@@ -826,7 +827,7 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
     dx = torch.empty_like(x)
     dxh = None
     if twin_out is not None and C % 4 == 0:
-        dxh = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        dxh = torch.empty(x.shape, dtype=POLICY_HALF[0], device=x.device)
         twin_out.append(dxh)
     dres = torch.empty_like(x) if want_dres else None
     dfilm = dfilm_out if dfilm_out is not None else (torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None)
@@ -907,10 +908,12 @@ def add_noise(act, noise, t_long, alphas_cumprod, limits=None):
     return out
 
 
-def mse_loss(pred, target, want_grad=True):
+def mse_loss(pred, target, want_grad=True, grad_scale_ptr=0):
+    """grad_scale_ptr: device address of a float the loss GRADIENT is multiplied by (the fp16 mode's dynamic loss scale), or 0."""
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
-    check(lib.v2a_mse_loss(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), _p(dpred), pred.numel(), _stream()), "mse_loss")
+    check(lib.v2a_mse_loss_scaled(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), _p(dpred), pred.numel(), grad_scale_ptr or None,
+                                  _stream()), "mse_loss")
     return loss, dpred
 
 

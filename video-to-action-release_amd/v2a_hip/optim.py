@@ -41,6 +41,29 @@ class FusedAdamWEMA:
         for p in params:
             self._offsets.append(self._offsets[-1] + p.numel())
 
+    # ------------------------------------------------------------------ dynamic loss scaling (fp16 mode)
+    def enable_loss_scaling(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        """torch.cuda.amp.GradScaler's defaults and contract, inside the fused tail (csrc/optim.hip): call before the first step.
+        init_scale <= 0 switches it off.  Returns the device address of the scale (the loss-gradient kernel multiplies by it)."""
+        host = self.state.cpu().numpy().tobytes()
+        buf = ctypes.create_string_buffer(host, len(host))
+        check(lib.v2a_opt_state_set_scaler(ctypes.addressof(buf), float(init_scale), float(growth_factor), float(backoff_factor),
+                                           int(growth_interval)), "opt_state_set_scaler")
+        self.state.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        return self.loss_scale_ptr() if init_scale > 0 else 0
+
+    def loss_scale_ptr(self):
+        return self.state.data_ptr() + lib.v2a_opt_state_loss_scale_offset()
+
+    def scaler(self):
+        """(loss scale, growth tracker, last step skipped?, skipped steps so far) -- synchronises."""
+        host = self.state.cpu().numpy().tobytes()
+        buf = ctypes.create_string_buffer(host, len(host))
+        ls, gt, sk, n = ctypes.c_float(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        check(lib.v2a_opt_state_scaler(ctypes.addressof(buf), ctypes.byref(ls), ctypes.byref(gt), ctypes.byref(sk), ctypes.byref(n)),
+              "opt_state_scaler")
+        return ls.value, gt.value, bool(sk.value), n.value
+
     def step(self, zero_grad=True):
         check(lib.v2a_opt_step(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
                                self.partial.data_ptr(), 1 if zero_grad else 0, ops._stream()), "opt_step")

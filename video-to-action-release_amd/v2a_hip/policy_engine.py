@@ -84,9 +84,10 @@ class _Conv:
         if self._pf_h is not None:                    # keep the bf16 twins in step with the fp32 operands
             from ._lib import lib, check
             for src, dst in ((self._pf, self._pf_h), (self._pd, self._pd_h)):
-                check(lib.v2a_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel() - src.numel() % 4, ops._stream()), "cast_f32_bf16")
+                check(lib.v2a_cast_f32_h(src.data_ptr(), dst.data_ptr(), src.numel() - src.numel() % 4, 1 if dst.dtype == torch.float16 else 0,
+                                         ops._stream()), "cast_f32_h")
                 if src.numel() % 4:
-                    dst[-(src.numel() % 4):] = src.reshape(-1)[-(src.numel() % 4):].to(torch.bfloat16)
+                    dst[-(src.numel() % 4):] = src.reshape(-1)[-(src.numel() % 4):].to(dst.dtype)
             ops.register_h_twin(self._pf, self._pf_h)
             ops.register_h_twin(self._pd, self._pd_h)
         self._ver = (self.w.data_ptr(), self.w._version)
@@ -146,6 +147,7 @@ class PolicyEngine:
         # of the N-major loader over the forward pack: the K-contiguous form is what the LDS-DMA kernels take
         self.flip_dgrad = _os.environ.get("V2A_FLIP_DGRAD", "1") != "0"
         self._deferred = []
+        self.loss_scale_ptr = 0      # device address of the dynamic loss scale (fp16 mode: PolicyTrainer points it at its optimiser state)
         # GroupNorm parameter gradients: every layer's backward leaves its per-sample column sums in a persistent [N,2,C] buffer; ONE
         # multi-tensor launch per chain (ConditionalUnet1D, each camera encoder) reduces them over n in a fixed order -- no atomics,
         # bitwise reproducible, and 60 reduction launches per step fewer
@@ -254,7 +256,7 @@ class PolicyEngine:
         tw = self._take_tw(dy)                       # left by the GroupNorm backward that produced dy (same storage: no cast launch)
         if tw is not None:
             return tw.view(dy.shape)
-        return ops.cast_h(dy)
+        return ops.cast_h(dy, ops.POLICY_HALF[0])
 
     _tw = None
     _tw_tag = 0
@@ -420,17 +422,17 @@ class PolicyEngine:
         bf16 kernel can take."""
         from ._lib import lib, check
         bf16 = lib.v2a_get_precision() == 1
-        if getattr(self, "_mp", None) is not None and self._mp["bf16"] != bf16:
-            self._mp = None
+        if getattr(self, "_mp", None) is not None and (self._mp["bf16"] != bf16 or self._mp.get("half") is not ops.POLICY_HALF[0]):
+            self._mp = None                            # precision mode or 16-bit format changed: new twins
         if getattr(self, "_mp", None) is None:
             rows, ch0, ch1 = [], [], []
             ce = lib.v2a_pack_chunk_elems()
             for c in self._convs.values():
                 w = c.w.detach()
                 taps = c.kh * c.kw
-                if bf16 and c._pf_h is None:
-                    c._pf_h = torch.empty(w.numel(), dtype=torch.bfloat16, device=self.device)
-                    c._pd_h = torch.empty(w.numel(), dtype=torch.bfloat16, device=self.device)
+                if bf16 and (c._pf_h is None or c._pf_h.dtype is not ops.POLICY_HALF[0]):
+                    c._pf_h = torch.empty(w.numel(), dtype=ops.POLICY_HALF[0], device=self.device)
+                    c._pd_h = torch.empty(w.numel(), dtype=ops.POLICY_HALF[0], device=self.device)
                 if taps == 1:
                     c._pf = w
                 elif c._pf is None or c._pf.data_ptr() == w.data_ptr():
@@ -458,7 +460,7 @@ class PolicyEngine:
             dev = self.device
             t = lambda a, dt: torch.tensor(a, dtype=dt).to(dev) if a else None
             self._mp = dict(tab=t(rows, torch.int64), ch0=t(ch0, torch.int32), n0=len(ch0), ch1=t(ch1, torch.int32), n1=len(ch1),
-                            ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16)
+                            ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16, half=ops.POLICY_HALF[0])
         mp = self._mp
         if mp["ptrs"] != [c.w.data_ptr() for c in self._convs.values()]:      # parameters were re-allocated (.to(), load): rebuild
             self._mp = None
@@ -1201,7 +1203,7 @@ class PolicyEngine:
         noisy = ops.add_noise(action, noise, timesteps, self.ac, self.act_limits)
         save = {}
         pred = self.unet_fwd(noisy, timesteps, gc, save)
-        loss, dpred = ops.mse_loss(pred, noise, want_grad=True)
+        loss, dpred = ops.mse_loss(pred, noise, want_grad=True, grad_scale_ptr=self.loss_scale_ptr)
         ops.tstamp("unet_bwd begin")
         names = list(names) if names is not None else self.trainable_names()
         if arena is None:

@@ -63,6 +63,12 @@ class PolicyTrainer:
                                  ema_power=ema_params["power"], ema_min_value=ema_params["min_value"],
                                  ema_beta=ema_params.get("beta", 0.9999), ema_update_after_step=ema_params["update_after_step"],
                                  ema_update_every=ema_params["update_every"])
+        # fp16 MFMA mode (v2a_hip.set_precision("fp16")): dynamic loss scaling inside the fused tail, GradScaler's contract -- the scaled loss
+        # gradient starts the backward, unscale rides on the clip factor, a non-finite gradient norm skips the update and halves the scale
+        import v2a_hip as _v
+        self.loss_scaling = _v.get_precision() == "fp16" and os.environ.get("V2A_LOSS_SCALE", "1") != "0"
+        if self.loss_scaling:
+            self.eng.loss_scale_ptr = self.opt.enable_loss_scaling(float(os.environ.get("V2A_LOSS_SCALE_INIT", "65536")))
         self.seed = int(seed) + 7919 * rank
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)       # Philox offset, advanced on device
         T, Da = policy.horizon, policy.action_dim
