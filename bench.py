@@ -932,6 +932,9 @@ def main():
                 albytes = 64.0 * 87219143 + 3 * 3.326e6 * batch * 4
                 r["roofline"] = {"bound": "hbm", "achieved": albytes / (msx * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": albytes / (msx * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": albytes}
+            if getattr(trx, "loss_scaling", False):
+                ls_, _, _, nskip_ = trx.opt.scaler()
+                r["loss_scale"], r["skipped_steps"] = ls_, nskip_      # GradScaler calibration: the first steps at 65536 overflow and are skipped
             if dp:
                 torch.cuda.synchronize()
                 ph = [[a.elapsed_time(b) for a, b in zip(pe[:-1], pe[1:])] for pe in trx.phase_events]

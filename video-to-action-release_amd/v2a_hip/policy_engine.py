@@ -147,6 +147,7 @@ class PolicyEngine:
         # of the N-major loader over the forward pack: the K-contiguous form is what the LDS-DMA kernels take
         self.flip_dgrad = _os.environ.get("V2A_FLIP_DGRAD", "1") != "0"
         self._deferred = []
+        self.split_deferred = False  # data parallel: backward_phase2 leaves the deferred weight gradients to run_deferred_wgrads()
         self.loss_scale_ptr = 0      # device address of the dynamic loss scale (fp16 mode: PolicyTrainer points it at its optimiser state)
         # GroupNorm parameter gradients: every layer's backward leaves its per-sample column sums in a persistent [N,2,C] buffer; ONE
         # multi-tensor launch per chain (ConditionalUnet1D, each camera encoder) reduces them over n in a fixed order -- no atomics,
@@ -1239,25 +1240,15 @@ class PolicyEngine:
             return df
 
         main = torch.cuda.current_stream()
-        deferred, self._deferred = self._deferred, []
+        deferred = []
+        if not self.split_deferred:                    # (data parallel: the trainer runs them itself -- run_deferred_wgrads -- on the stream
+            deferred, self._deferred = self._deferred, []      # its first slice all-reduce then leaves from)
         if deferred:                                   # third branch: every ConditionalUnet1D weight gradient
             if self._wg_stream is None:
                 self._wg_stream = torch.cuda.Stream(device=self.device)
             self._wg_stream.wait_stream(main)
             with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
-                ops.tstamp("unet_wgrad begin")
-                col = self._collector() if self._wgc_on else None
-                batch = ops.WgradBatch(col) if (col is not None and self._wgb_mode != "0") else None
-                for a, k in deferred:
-                    kk = dict(k, slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
-                    if batch is not None and batch.add(*a, **kk):
-                        continue
-                    ops.conv2d_wgrad(*a, **dict(kk, collector=col))
-                if batch is not None:
-                    batch.launch()
-                if col is not None:
-                    col.flush()
-                ops.tstamp("unet_wgrad end")
+                self._launch_deferred(deferred)
         self._in_enc = True
         try:
             if "_stacked" in st["save_enc"]:
@@ -1273,6 +1264,30 @@ class PolicyEngine:
         if deferred:
             main.wait_stream(self._wg_stream)
         self._join_side()
+
+    def _launch_deferred(self, deferred):
+        ops.tstamp("unet_wgrad begin")
+        col = self._collector() if self._wgc_on else None
+        batch = ops.WgradBatch(col) if (col is not None and self._wgb_mode != "0") else None
+        for a, k in deferred:
+            kk = dict(k, slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
+            if batch is not None and batch.add(*a, **kk):
+                continue
+            ops.conv2d_wgrad(*a, **dict(kk, collector=col))
+        if batch is not None:
+            batch.launch()
+        if col is not None:
+            col.flush()
+        ops.tstamp("unet_wgrad end")
+
+    def run_deferred_wgrads(self):
+        """Data-parallel step (split_deferred): the ConditionalUnet1D weight gradients collected by backward_phase1, launched on the CURRENT
+        stream (the trainer's side stream, as a graph of their own) -- after them the `model.*` arena slice is final and its all-reduce
+        starts from that stream, while the encoder backward runs on the main one."""
+        deferred, self._deferred = self._deferred, []
+        if deferred:
+            with ops.ws_lane(7):
+                self._launch_deferred(deferred)
 
     def arena_slices(self, names):
         """(start, end) element ranges of the `model.*` (ConditionalUnet1D) and the remaining (encoder) gradients in the arena."""

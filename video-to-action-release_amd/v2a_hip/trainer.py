@@ -41,8 +41,16 @@ class PolicyTrainer:
         # the data-parallel step structure (three graphs + two asynchronous slice all-reduces); V2A_FORCE_DP=1 selects it for a
         # single rank too, so that the RCCL path can be exercised on a one-GPU box
         self.dp = world_size > 1 or (process_group is not None and os.environ.get("V2A_FORCE_DP") == "1")
-        if self.dp:
+        # data parallel: the deferred ConditionalUnet1D weight-gradient branch stays alive (round 3 switched it off) -- it runs as a graph
+        # of its own on a side stream, the `model.*` slice's all-reduce leaves from that stream when it is done, and the encoder backward
+        # runs on the main stream meanwhile.  V2A_DP_DEFER=0: round-3 structure (weight gradients inside phase 1).
+        self.dp_defer = self.dp and os.environ.get("V2A_DP_DEFER", "1") != "0" and self.eng.defer_unet_wgrad
+        if self.dp and not self.dp_defer:
             self.eng.defer_unet_wgrad = False      # the model.* gradient slice must be final after phase 1 (its all-reduce starts there)
+        if self.dp_defer:
+            self.eng.split_deferred = True
+        self._side = None
+        self._g_wg = None
         opt_params = dict(lr=1e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6) if opt_params is None else dict(opt_params)
         ema_params = dict(update_after_step=0, inv_gamma=1.0, power=0.75, min_value=0.0, update_every=1) if ema_params is None else dict(ema_params)
         # ema_pytorch keeps the online model out of the EMA module tree (and out of its state_dict) when this is False -- the released
@@ -156,6 +164,24 @@ class PolicyTrainer:
     def _bwd_encoders(self):
         self.eng.backward_phase2(self._st)
 
+    def _slice0(self, graph=False):
+        """Start the all-reduce of slice 0 (`model.*`).  With the deferred weight-gradient branch: run that branch on the side stream
+        first (eagerly or as its captured graph) and launch the collective FROM the side stream; the main stream goes on with the
+        encoder backward and meets the side stream again in finish()."""
+        if not self.dp_defer:
+            self._reduce_async(0)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            if graph:
+                self._g_wg.replay()
+            else:
+                self.eng.run_deferred_wgrads()
+            self._reduce_async(0)
+
     def _reduce_async(self, which):
         """Sum all-reduce of one arena slice (RCCL over xGMI), asynchronous: the ConditionalUnet1D slice (74 % of the bytes) is
         final before the image-encoder backward starts and travels underneath it.  No fallback: a backend that cannot do this raises."""
@@ -166,6 +192,8 @@ class PolicyTrainer:
         if self.comm_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        if self.dp_defer and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # the weight-gradient branch (and the launch of slice 0) joins here
         self.reducer.finish(self.opt.scale_grads)           # averaging folded into the optimiser's gradient scale
         if ev is not None:
             ev[1].record()
@@ -185,7 +213,7 @@ class PolicyTrainer:
         if not self.use_graph or self._warm < 2:
             self._fwd_bwd()
             if self.dp:
-                self._reduce_async(0)
+                self._slice0()
             self._bwd_encoders()
             if self.dp:
                 self._reduce_async(1)
@@ -206,6 +234,10 @@ class PolicyTrainer:
                 else:                                     # three graphs with the two slice all-reduces launched between them
                     with torch.cuda.graph(self._g_fb):
                         self._fwd_bwd()
+                    if self.dp_defer:
+                        self._g_wg = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self._g_wg, pool=self._g_fb.pool()):
+                            self.eng.run_deferred_wgrads()
                     self._g_enc = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._g_enc, pool=self._g_fb.pool()):
                         self._bwd_encoders()
@@ -221,7 +253,7 @@ class PolicyTrainer:
             if self.dp:
                 if pe:
                     pe[1].record()
-                self._reduce_async(0)
+                self._slice0(graph=True)
                 self._g_enc.replay()
                 if pe:
                     pe[2].record()
