@@ -158,6 +158,9 @@ def test_sampler_vs_golden(golden_dir, name, steps, gw, obj, vt):
     out = d.sample(x_cond.cuda(), te.cuda(), batch_size=2)
     ref = g[f"sample_{name}"]
     assert out.shape == ref.shape and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    if rel(out, ref) <= TOL:                          # inside north_star's band against the reference's own sample: the fp64 yard-stick (up to
+        print(f"[sampler {name}] HIP vs reference {rel(out, ref):.2e}")      # a minute of host time per case) is only needed to justify a miss
+        return
     exact = _tiny_fp64_sample(sd, x_cond, te, steps, gw, objective=obj, var_temp=vt)
     ref_dev, err, err_exact = rel(ref, exact), rel(out, ref), rel(out, exact)
     print(f"[sampler {name}] HIP vs reference {err:.2e}; HIP vs fp64 {err_exact:.2e}; reference fp32 vs fp64 {ref_dev:.2e}")
