@@ -147,7 +147,6 @@ class PolicyEngine:
         # of the N-major loader over the forward pack: the K-contiguous form is what the LDS-DMA kernels take
         self.flip_dgrad = _os.environ.get("V2A_FLIP_DGRAD", "1") != "0"
         self._deferred = []
-        self.early_unet_wg = _os.environ.get("V2A_UNET_WG_EARLY", "0") == "1"
         self.split_deferred = False  # data parallel: backward_phase2 leaves the deferred weight gradients to run_deferred_wgrads()
         self.loss_scale_ptr = 0      # device address of the dynamic loss scale (fp16 mode: PolicyTrainer points it at its optimiser state)
         # GroupNorm parameter gradients: every layer's backward leaves its per-sample column sums in a persistent [N,2,C] buffer; ONE
@@ -1070,7 +1069,6 @@ class PolicyEngine:
                 self._wg(dy4, x4, us.shape, 1, 4, (1, 2), (0, 1), dw=grads[us.wname])
                 ops.colsum(dx.view(-1, us.ci), out=grads[us.bname])
                 dx = ops.conv2d(dy4, us.pf(), None, Cx, 1, 4, (1, 2), (0, 1)).view(Bx, Tx, Cx)
-                self._flush_deferred_early()
             elif "ds" in e:
                 ds, xin = e["ds"], e["x"]
                 Bx, Tx, Cx = xin.shape
@@ -1080,7 +1078,6 @@ class PolicyEngine:
                 skip = pending_skip.pop() if pending_skip else None
                 dx = _dgrad(dy4, ds, None, Cx, 1, 3, (1, 1), (0, 1), idil=2, out_hw=(1, Tx),
                                 residual=None if skip is None else skip.view(Bx, 1, Tx, Cx)).view(Bx, Tx, Cx)
-                self._flush_deferred_early()
             else:
                 n_res_seen += 1
                 first_block = (n_res_seen == total_res)          # down_modules.0.0: its input is data -> no dx
@@ -1264,9 +1261,8 @@ class PolicyEngine:
                 self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
         finally:
             self._in_enc = False
-        if deferred or self._wg_early_forked:
+        if deferred:
             main.wait_stream(self._wg_stream)
-            self._wg_early_forked = False
         self._join_side()
 
     def _launch_deferred(self, deferred):
@@ -1283,22 +1279,6 @@ class PolicyEngine:
         if col is not None:
             col.flush()
         ops.tstamp("unet_wgrad end")
-
-    def _flush_deferred_early(self):
-        """Experiment (V2A_UNET_WG_EARLY=1): launch the ConditionalUnet1D weight gradients collected SO FAR as a grouped launch on the side
-        stream while the latency-bound data-gradient chain of the UNet goes on (one fork per call, joined at the end of backward_phase2) --
-        instead of all of them next to the encoder backward, whose short kernels a 400-us weight-gradient launch starves."""
-        if not self.early_unet_wg or self.split_deferred or not self._deferred:
-            return
-        deferred, self._deferred = self._deferred, []
-        if self._wg_stream is None:
-            self._wg_stream = torch.cuda.Stream(device=self.device)
-        self._wg_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
-            self._launch_deferred(deferred)
-        self._wg_early_forked = True
-
-    _wg_early_forked = False
 
     def run_deferred_wgrads(self):
         """Data-parallel step (split_deferred): the ConditionalUnet1D weight gradients collected by backward_phase1, launched on the CURRENT
