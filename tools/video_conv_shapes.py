@@ -48,6 +48,6 @@ for key, fl, e0, e1 in recs:
     a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = sum(a[1] for a in agg.values())
 print(f"total conv time {tot*1e3:.1f} ms over {sum(a[2] for a in agg.values())} launches, {sum(a[0] for a in agg.values())/tot/1e12:.0f} TFLOP/s")
-for key, (fl, tt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+for key, (fl, tt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     M, Cin, Cout, kh, kw, name = key
     print(f"M={M:8d} Cin={Cin:5d} Cout={Cout:5d} k={kh}x{kw} {name:30s} n={n:3d} avg {tt/n*1e6:8.1f} us  {fl/tt/1e12:6.0f} TF  {tt*1e3:6.2f} ms ({100*tt/tot:4.1f} %)")
