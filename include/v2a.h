@@ -219,8 +219,7 @@ int v2a_get_f32_conv_mode(void);
  * (v2a_groupnorm_fwd* / _bwd*) uses gamma2 / beta2 for samples n >= n_split.  Host-side state, consumed by that launch. */
 int v2a_conv2d_set_second(const void* w2, const float* bias2, int m_split);
 int v2a_groupnorm_set_second(const float* gamma2, const float* beta2, int n_split);
-int v2a_debug_f32p(int on, int s128, int s64);
-int v2a_debug_x3_ablate(int bits);   /* measurement aid: bit 0 no A split, 1 no B split, 2 no LDS stores, 3 no MFMA in conv_igemm_f32x3 (results wrong while set); returns the old bits */   /* tuning aid: pipelined exact-f32 conv kernel on/off (default on), LDS stages of its 128x128 / 64x64 tiles; returns the old `on` */
+int v2a_debug_f32p(int on, int s128, int s64);   /* tuning aid: pipelined exact-f32 conv kernel on/off (default on), LDS stages of its 128x128 / 64x64 tiles; returns the old `on` */
 int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words);   /* measurement aid: following conv_igemm_h launches stamp their phases per workgroup ([wg][8] x 100 MHz ticks), buf advances by stride_words per launch; null = off */
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */
 

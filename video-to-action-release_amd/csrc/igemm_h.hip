@@ -70,7 +70,6 @@ struct ConvDescH {
     const void* w2;           // second weight set (rows >= m_split) or null       [conv_igemm_f32p only]
     const float* bias2;       // second bias (rows >= m_split) or null
     int m_split;              // first output row of the second set (a multiple of every row tile); INT_MAX: one set
-    int abl;                  // measurement aid (v2a_debug_x3_ablate): bit 0 no A split, bit 1 no B split, bit 2 no LDS stores, bit 3 no MFMA
     unsigned long long* tstamps;   // measurement aid (v2a_debug_conv_stamps): [workgroup][8] wall-clock stamps of the kernel's phases, or null
 };
 #define V2A_STAMP(i) do { if (p.tstamps && threadIdx.x == 0) p.tstamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
@@ -879,14 +878,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             uint32_t h0, m0_, l0, h1, m1, l1;
-            if (p.abl & 1) {
-                h0 = m0_ = l0 = __float_as_uint(ra[j][0]) ^ __float_as_uint(ra[j][1]);
-                h1 = m1 = l1 = __float_as_uint(ra[j][2]) ^ __float_as_uint(ra[j][3]);
-            } else {
-                split3_pair_h(ra[j][0], ra[j][1], h0, m0_, l0);
-                split3_pair_h(ra[j][2], ra[j][3], h1, m1, l1);
-            }
-            if (p.abl & 4) { asm volatile("" :: "v"(h0), "v"(m0_), "v"(l0), "v"(h1), "v"(m1), "v"(l1)); continue; }
+            split3_pair_h(ra[j][0], ra[j][1], h0, m0_, l0);
+            split3_pair_h(ra[j][2], ra[j][3], h1, m1, l1);
             *reinterpret_cast<uint2*>(stage + w_off[j]) = uint2{h0, h1};
             *reinterpret_cast<uint2*>(stage + PA + w_off[j]) = uint2{m0_, m1};
             *reinterpret_cast<uint2*>(stage + 2 * PA + w_off[j]) = uint2{l0, l1};
@@ -897,14 +890,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
 #pragma unroll
         for (int j = 0; j < BL; ++j) {
             uint32_t h0, m0_, l0, h1, m1, l1;
-            if (p.abl & 2) {
-                h0 = m0_ = l0 = __float_as_uint(rb[j][0]) ^ __float_as_uint(rb[j][1]);
-                h1 = m1 = l1 = __float_as_uint(rb[j][2]) ^ __float_as_uint(rb[j][3]);
-            } else {
-                split3_pair_h(rb[j][0], rb[j][1], h0, m0_, l0);
-                split3_pair_h(rb[j][2], rb[j][3], h1, m1, l1);
-            }
-            if (p.abl & 4) { asm volatile("" :: "v"(h0), "v"(m0_), "v"(l0), "v"(h1), "v"(m1), "v"(l1)); continue; }
+            split3_pair_h(rb[j][0], rb[j][1], h0, m0_, l0);
+            split3_pair_h(rb[j][2], rb[j][3], h1, m1, l1);
             *reinterpret_cast<uint2*>(bb + w_off[j]) = uint2{h0, h1};
             *reinterpret_cast<uint2*>(bb + PB + w_off[j]) = uint2{m0_, m1};
             *reinterpret_cast<uint2*>(bb + 2 * PB + w_off[j]) = uint2{l0, l1};
@@ -940,16 +927,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
             for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bfx8*>(base + q * PA + a_off[i] + pos[h]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bfx8*>(base + q * PB + b_off[j] + pos[h]);
-        }
-        if (p.abl & 8) {                                        // (measurement aid: operands stay live, the matrix pipe is skipped)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(a[q][i]));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(b[q][j]));
-            }
-            return;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1069,7 +1046,6 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
     }
 }
 
-static int g_x3_abl = 0;      // measurement aid: ablation bits of conv_igemm_f32x3 (v2a_debug_x3_ablate; results are WRONG while set)
 static void f32_conv_mode_init();
 // second weight / bias set of the NEXT fp32 LDS-DMA conv launch (output rows >= m_split read it): host-side state, consumed by that launch
 static const void* g_conv_w2 = nullptr;
@@ -1191,7 +1167,7 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         const char* e = getenv("V2A_DMA_STAGES");
         g_stages_h = (e && e[0] == '2') ? 2 : 1;
     }
-    p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff; p.abl = g_x3_abl;
+    p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff;
     if constexpr (sizeof(T) == 4) {
         if (g_conv_w2) {                             // second operand set of this launch (v2a_conv2d_set_second), consumed here
             const int ms = g_conv_msplit;
@@ -1302,7 +1278,6 @@ int v2a_conv2d_set_second(const void* w2, const float* bias2, int m_split) {
     g_conv_w2 = w2; g_conv_bias2 = w2 ? bias2 : nullptr; g_conv_msplit = w2 ? m_split : 0x7fffffff;
     return V2A_OK;
 }
-int v2a_debug_x3_ablate(int bits) { const int old = g_x3_abl; g_x3_abl = bits & 15; return old; }
 int v2a_get_f32_conv_mode(void) {
     f32_conv_mode_init();
     return g_f32x3;

@@ -98,7 +98,6 @@ SIGNATURES = {
     "v2a_debug_timestamp": (I, [P, P]),
     "v2a_debug_conv_stamps": (I, [P, SZ]),
     "v2a_debug_f32p": (I, [I, I, I]),
-    "v2a_debug_x3_ablate": (I, [I]),
     "v2a_set_f32_conv_mode": (I, [I]),
     "v2a_get_f32_conv_mode": (I, []),
     "v2a_conv2d_set_second": (I, [P, P, I]),
