@@ -1287,104 +1287,140 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16(const WgradDesc p) {
 }
 
 // ---- fp32 weight gradient by three bf16 planes (round 4; the weight-gradient form of csrc/igemm_h.hip conv_igemm_f32x3).
-// dW[co][k'] = sum_r dY[r][co] * X[r][k']: both operands are k-major in HBM (rows = reduction index r), the bf16 MFMA wants 8 consecutive
-// r per lane -- the loader of conv_wgrad_bf16 above: a thread owns an 8 (rows) x 4 (channels) register block (8 coalesced 16-B loads),
-// here split into hi / mid / lo planes (x = hi + mid + lo exactly, see conv_igemm_f32x3) and written as 4 x 3 16-B LDS stores of 8 values
-// along r; a product block = the six plane products of weight >= 2^-16, smallest first.  fp32-equivalent accuracy (not bit-equal to the
-// exact-f32 kernels: V2A_F32_CONV=exact keeps those).  Row decode of the gathered operand is incremental (one division pair per 8 rows).
-template <int BM, int BN>
+// dW[co][k'] = sum_r dY[r][co] * X[r][k']: both operands are contiguous along the NON-reduction axis in HBM while the bf16 MFMA wants 8
+// consecutive reduction rows r per lane.  The loader does no transposition at all: a thread takes one 16-B load (4 channels of one row),
+// splits it into hi / mid / lo planes (x = hi + mid + lo exactly, see conv_igemm_f32x3) and writes three 8-B pieces into k-major LDS
+// images [32 rows][BM | BN columns] (one image per plane, 16-B pieces XOR-swizzled by SWZ * (row & 3) like wgrad_tr_body below);
+// `ds_read_b64_tr_b16` delivers the MFMA operand from them (two reads = 8 reduction rows of the lane's column).  A product block = the
+// six plane products of weight >= 2^-16, smallest first.  Pipeline as in the forward kernel: global loads two reduction tiles ahead
+// (two register sets), split + ds_write_b64 of tile t + 1 between the two MFMA groups of tile t, two LDS stages, one barrier per tile;
+// every thread loads (no idle half as in the register-transposing first version).  fp32-equivalent accuracy (not bit-equal to the
+// exact-f32 kernels: V2A_F32_CONV=exact keeps those).
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(1))) f32x4 gf32x4w_t;
+typedef __attribute__((address_space(3))) bf16x4_t lbf16x4_t;
+template <int BM, int BN, int WVM, int WVN, bool GEN>
 __device__ __forceinline__ void wgrad_x3_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
-    constexpr int BKT = 32, LDH = 40;                           // 32 reduction rows per tile; 40 halves = 80-B LDS rows
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int PA = BM * LDH, PB = BN * LDH, STG = 3 * (PA + PB);      // halves per plane / per stage
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
+    constexpr int NT = 64 * WVM * WVN, BKR = 32;
+    constexpr int PITCH_A = BM * 2, PITCH_B = BN * 2;           // bytes per image row
+    constexpr int PA = BKR * PITCH_A, PB = BKR * PITCH_B, STG = 3 * (PA + PB);
+    constexpr int SWZ_A = BM == 128 ? 4 : 2, SWZ_B = BN == 128 ? 4 : 2;
+    constexpr int TPR_A = BM / 4, RP_A = NT / TPR_A, AL = BKR / RP_A;      // threads per image row, rows per loader pass, loads per thread
+    constexpr int TPR_B = BN / 4, RP_B = NT / TPR_B, BL = BKR / RP_B;
+    constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;
+    static_assert(AL >= 1 && BL >= 1 && TM >= 1 && TN >= 1 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile shape");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_n = (p.K + BN - 1) / BN;
     const int m0 = (tile_id / tiles_n) * BM, n0 = (tile_id % tiles_n) * BN;
     const int Cin = p.C1 + p.C2;
-    const int nrt = (p.M + BKT - 1) / BKT;
+    const int nrt = (p.M + BKR - 1) / BKR;
     const int rt_begin = split * p.rtiles_per_split;
     const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
-    // loader roles: threads [0, BM) own dY columns, [BM, BM + BN) own gathered-input columns: 4 channels x 8 rows each (a 64 x 64 tile
-    // keeps half of the workgroup's threads out of the loads, as conv_wgrad_bf16 does)
-    const bool isA = tid < BM;
-    const bool isB = !isA && tid < BM + BN;
-    const int t2 = isA ? tid : tid - BM;
-    const int c4 = isA ? t2 % (BM / 4) : t2 % (BN / 4);
-    const int rgrp = isA ? t2 / (BM / 4) : t2 / (BN / 4);
-    int b_kh = 0, b_kw = 0, b_c = 0;
-    bool b_kok = false;
-    if (isB) {
-        const int k = n0 + c4 * 4;
-        b_kok = k < p.K;
-        const int kk = b_kok ? k : 0;
-        const int tap = kk / Cin;
-        b_c = kk - tap * Cin;
-        b_kh = tap / p.KW;
-        b_kw = tap - b_kh * p.KW;
+    const float* zline = g_zero_line;
+
+    const int a_c4 = tid % TPR_A, a_r = tid / TPR_A;
+    const int a_co = m0 + a_c4 * 4;
+    const bool a_cok = a_co < p.Cout;
+    const float* a_src = p.dy + (a_cok ? a_co : 0);
+    const int b_c4 = tid % TPR_B, b_r = tid / TPR_B;
+    const int bk = n0 + b_c4 * 4;
+    const bool b_kok = bk < p.K;
+    const int btap = (b_kok ? bk : 0) / Cin;
+    const int bci = (b_kok ? bk : 0) - btap * Cin;
+    const int bkh = btap / p.KW, bkw = btap - bkh * p.KW;
+    const bool bfirst = bci < p.C1;                             // column from x or from x2 (channel concat [x | x2]; C1 % 4 == 0)
+    const float* b_src = bfirst ? p.x + bci : p.x2 + (bci - p.C1);
+    const int bCs = bfirst ? p.C1 : p.C2;
+    int it = rt_begin;
+    const int shift = (p.ups || p.idil == 2) ? 1 : 0;
+    const int pmask = (p.idil == 2) ? 1 : 0;
+    // loop-invariant descriptor fields pinned in SGPRs (readfirstlane: not re-loaded from the kernel arguments inside the loop, where an
+    // s_waitcnt lgkmcnt would also wait for the LDS reads); branch-free form of fdiv()
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int M_ = sgpr(p.M), Cout_ = sgpr(p.Cout), OW_ = sgpr(p.OW), OH_ = sgpr(p.OH), H_ = sgpr(p.H), W_ = sgpr(p.W), HL_ = sgpr(p.HL), WL_ = sgpr(p.WL);
+    const int sh_ = sgpr(p.sh), sw_ = sgpr(p.sw), ph_ = sgpr(p.ph - bkh * 0), pw_ = sgpr(p.pw);
+    const uint32_t ow_m = (uint32_t)sgpr((int)p.fd_ow.m), ow_s = (uint32_t)sgpr((int)((p.fd_ow.s - 1) & 31)), oh_m = (uint32_t)sgpr((int)p.fd_oh.m),
+                   oh_s = (uint32_t)sgpr((int)((p.fd_oh.s - 1) & 31));
+    const bool ow_one = OW_ <= 1, oh_one = OH_ <= 1;
+    auto fdivb = [](uint32_t n, uint32_t m, uint32_t sm1, bool one) -> uint32_t {
+        const uint32_t t = __umulhi(m, n);
+        const uint32_t q = (t + ((n - t) >> 1)) >> sm1;
+        return one ? n : q;
+    };
+
+    // request the next reduction tile (16-B loads into the given register set; past the slice's end: the zero line)
+    auto load = [&](f32x4 (&ra)[AL], f32x4 (&rb)[BL]) {
+        const bool live = it < rt_end;
+        const int r0 = it * BKR;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const int r = r0 + j * RP_A + a_r;
+            uint32_t off = (uint32_t)r * (uint32_t)Cout_;
+            asm volatile("" : "+v"(off));
+            const float* g = a_src + off;
+            g = (live & a_cok & (r < M_)) ? g : zline;
+            ra[j] = *(const gf32x4w_t*)(uint64_t)g;             // (address space 1: a global_load, never a flat_load)
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const int r = r0 + j * RP_B + b_r;
+            const uint32_t rr = r < M_ ? (uint32_t)r : 0u;
+            const uint32_t t = fdivb(rr, ow_m, ow_s, ow_one);
+            const int ow = (int)(rr - t * (uint32_t)OW_);
+            const uint32_t img = fdivb(t, oh_m, oh_s, oh_one);
+            const int oh = (int)(t - img * (uint32_t)OH_);
+            int ih = oh * sh_ - ph_ + bkh, iw = ow * sw_ - pw_ + bkw;
+            bool ok = live & b_kok & (r < M_) & ((unsigned)ih < (unsigned)HL_) & ((unsigned)iw < (unsigned)WL_);
+            if constexpr (GEN) {                                // folded nearest-x2 upsample / transposed conv (input dilation 2)
+                ok = ok & (((ih | iw) & pmask) == 0);
+                ih >>= shift;
+                iw >>= shift;
+            }
+            uint32_t off = ((uint32_t)((int)img * H_ + ih) * (uint32_t)W_ + (uint32_t)iw) * (uint32_t)bCs;
+            asm volatile("" : "+v"(off));
+            const float* g = b_src + off;
+            g = ok ? g : zline;
+            rb[j] = *(const gf32x4w_t*)(uint64_t)g;
+        }
+        ++it;
+    };
+    // LDS position of this thread's 8-B piece (4 bf16) in a plane image: row rr, columns 4 c4 .. + 3
+    int wa_off[AL], wb_off[BL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int rr = j * RP_A + a_r;
+        wa_off[j] = rr * PITCH_A + ((((a_c4 >> 1) ^ (SWZ_A * (rr & 3))) << 4) | ((a_c4 & 1) << 3));
     }
-    const bool b_first = b_c < p.C1;
-    const float* b_base = b_first ? p.x + b_c : p.x2 + (b_c - p.C1);
-    const int b_Cs = b_first ? p.C1 : p.C2;
-    const int a_co = m0 + c4 * 4;
-    const bool a_cok = isA && a_co < p.Cout;
-    const bool do_bias = (p.dbias != nullptr) && (tile_id % tiles_n == 0);
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 rv[8];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_tile = [&](int rt) {
-        const int r0 = rt * BKT + rgrp * 8;
-        if (isA) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int r = r0 + e;
-                f32x4 v = zero4;
-                if (r < p.M && a_cok) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)r * p.Cout + a_co);
-                rv[e] = v;
-                if (do_bias) bsum += v;
-            }
-        } else if (isB) {
-            const uint32_t rr = r0 < p.M ? (uint32_t)r0 : 0u;
-            const uint32_t t = fdiv(rr, p.fd_ow);
-            int ow = (int)(rr - t * p.OW);
-            int img = (int)fdiv(t, p.fd_oh);
-            int oh = (int)t - img * p.OH;
+    for (int j = 0; j < BL; ++j) {
+        const int rr = j * RP_B + b_r;
+        wb_off[j] = 3 * PA + rr * PITCH_B + ((((b_c4 >> 1) ^ (SWZ_B * (rr & 3))) << 4) | ((b_c4 & 1) << 3));
+    }
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                         // column sums of dY over this thread's rows (bias gradient)
+    auto split_store_a = [&](const f32x4 (&ra)[AL], unsigned char* stage) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int r = r0 + e;
-                f32x4 v = zero4;
-                int ih = oh * p.sh - p.ph + b_kh, iw = ow * p.sw - p.pw + b_kw;
-                bool ok = r < p.M && b_kok && ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
-                if (p.idil > 1) {
-                    ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
-                    ih /= p.idil;
-                    iw /= p.idil;
-                }
-                if (p.ups) { ih >>= 1; iw >>= 1; }
-                if (ok) v = *reinterpret_cast<const f32x4*>(b_base + ((size_t)(img * p.H + ih) * p.W + iw) * b_Cs);
-                rv[e] = v;
-                if (++ow == p.OW) {                             // next reduction row: (img, oh, ow) advance without a division
-                    ow = 0;
-                    if (++oh == p.OH) { oh = 0; ++img; }
-                }
-            }
+        for (int j = 0; j < AL; ++j) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            bsum += ra[j];
+            split3_pair(ra[j][0], ra[j][1], h0, m0_, l0);
+            split3_pair(ra[j][2], ra[j][3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(stage + wa_off[j]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(stage + PA + wa_off[j]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(stage + 2 * PA + wa_off[j]) = uint2{l0, l1};
         }
     };
-    auto store_tile = [&](int buf) {
-        if (isA || isB) {
-            uint16_t* dst = lds + buf * STG + (isA ? 0 : 3 * PA) + (c4 * 4) * LDH + rgrp * 8;
-            const int pl = isA ? PA : PB;
+    auto split_store_b = [&](const f32x4 (&rb)[BL], unsigned char* stage) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t h[4], m[4], l[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) split3_pair(rv[2 * q][j], rv[2 * q + 1][j], h[q], m[q], l[q]);
-                *reinterpret_cast<uint4*>(dst + j * LDH) = uint4{h[0], h[1], h[2], h[3]};
-                *reinterpret_cast<uint4*>(dst + pl + j * LDH) = uint4{m[0], m[1], m[2], m[3]};
-                *reinterpret_cast<uint4*>(dst + 2 * pl + j * LDH) = uint4{l[0], l[1], l[2], l[3]};
-            }
+        for (int j = 0; j < BL; ++j) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair(rb[j][0], rb[j][1], h0, m0_, l0);
+            split3_pair(rb[j][2], rb[j][3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(stage + wb_off[j]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(stage + PB + wb_off[j]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(stage + 2 * PB + wb_off[j]) = uint2{l0, l1};
         }
     };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1392,46 +1428,73 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradDesc& p, const int tile
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
+    const int wm = (wid / WVN) * WM, wn = (wid % WVN) * WN;
     const int lr = lane & 31, lk = lane >> 5;
-    if (rt_begin < rt_end) {
-        load_tile(rt_begin);
-        store_tile(0);
+    // transposing-read source address of this lane (see wgrad_tr_body): 16-lane group g = lane >> 4, segment s = lane & 15
+    const int grp = lane >> 4, seg = lane & 15;
+    const int trow = 8 * (grp >> 1) + (seg >> 2);               // + 16 for the second k step, + 4 for the second half of the operand
+    const int tcol = 16 * (grp & 1) + 4 * (seg & 3);
+    int a_tr[TM], b_tr[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int col = wm + 32 * i + tcol;
+        a_tr[i] = trow * PITCH_A + (((col >> 3) ^ (SWZ_A * (trow & 3))) << 4) + ((col & 7) << 1);
     }
-    __syncthreads();
-    int buf = 0;
-    for (int rt = rt_begin; rt < rt_end; ++rt) {
-        const bool more = (rt + 1) < rt_end;
-        if (more) load_tile(rt + 1);
-        const uint16_t* A = lds + buf * STG;
-        const uint16_t* B = A + 3 * PA;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8 a[3][TM], b[3][TN];
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn + 32 * j + tcol;
+        b_tr[j] = 3 * PA + trow * PITCH_B + (((col >> 3) ^ (SWZ_B * (trow & 3))) << 4) + ((col & 7) << 1);
+    }
+    auto tr8 = [&](const unsigned char* q, int pitch) -> bf16x8 {
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lbf16x4_t*)(q));
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lbf16x4_t*)(q + 4 * pitch));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto mfma6 = [&](const unsigned char* base, int h) {
+        bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 3; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8*>(&A[q * PA + (wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
+            for (int i = 0; i < TM; ++i) a[q][i] = tr8(base + q * PA + a_tr[i] + h * 16 * PITCH_A, PITCH_A);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8*>(&B[q * PB + (wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);     // lo  * hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);     // hi  * lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // mid * mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);     // mid * hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);     // hi  * mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);     // hi  * hi
-                    acc[i][j] = c;
-                }
+            for (int j = 0; j < TN; ++j) b[q][j] = tr8(base + q * PB + b_tr[j] + h * 16 * PITCH_B, PITCH_B);
         }
-        if (more) store_tile(buf ^ 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);     // lo  * hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);     // hi  * lo
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // mid * mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);     // mid * hi
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);     // hi  * mid
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);     // hi  * hi
+                acc[i][j] = c;
+            }
+    };
+
+    // ---- prologue: tile rt_begin staged, tile rt_begin + 1 requested
+    f32x4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
+    load(ra0, rb0);
+    load(ra1, rb1);
+    split_store_a(ra0, smem);
+    split_store_b(rb0, smem);
+    __syncthreads();
+    auto step = [&](f32x4 (&ra_c)[AL], f32x4 (&rb_c)[BL], f32x4 (&ra_n)[AL], f32x4 (&rb_n)[BL], int buf) {
+        unsigned char* cur = smem + buf * STG;
+        unsigned char* oth = smem + (buf ^ 1) * STG;
+        load(ra_n, rb_n);                                       // tile rt + 2 -> the register set consumed one step ago
+        mfma6(cur, 0);
+        split_store_a(ra_c, oth);                               // (VALU of the split runs under the MFMAs around it)
+        mfma6(cur, 1);
+        split_store_b(rb_c, oth);
         __syncthreads();
-        buf ^= 1;
+    };
+    // always in pairs (fixed register-set roles at the loop header); an odd slice multiplies one all-zero tile at the end
+    for (int rt = rt_begin; rt < rt_end; rt += 2) {
+        step(ra1, rb1, ra0, rb0, 0);
+        step(ra0, rb0, ra1, rb1, 1);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1447,16 +1510,15 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradDesc& p, const int tile
                 else wgrad_store(p, co, k, acc[i][j][r]);
             }
         }
-    if (do_bias) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);            // [4][BM] floats
-        if (isA) {
+    if ((p.dbias != nullptr) && (tile_id % tiles_n == 0)) {     // (every wave is past the loop's last barrier: the stages are free)
+        float* red = reinterpret_cast<float*>(smem);            // [RP_A][BM] floats
 #pragma unroll
-            for (int j = 0; j < 4; ++j) red[rgrp * BM + c4 * 4 + j] = bsum[j];
-        }
+        for (int j = 0; j < 4; ++j) red[a_r * BM + a_c4 * 4 + j] = bsum[j];
         __syncthreads();
         if (tid < BM) {
-            const float t = red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid];
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < RP_A; ++g) t += red[g * BM + tid];
             const int co = m0 + tid;
             if (co < p.Cout) {
                 if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = t;
@@ -1464,11 +1526,6 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradDesc& p, const int tile
             }
         }
     }
-}
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_wgrad_x3(const WgradDesc p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * (BM + BN) * 40 * 2];
-    wgrad_x3_body<BM, BN>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // bf16-MFMA weight gradient fed from bf16 TWINS of the operands (x_h / dy_h: the rounded copies the bf16 forward / data-gradient convs
@@ -1861,10 +1918,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_multi_halo_kernel(const Wgr
     else wgrad_halo_body<8>(a.d[i], tile, split, smem);
 }
 
-// The same for the three-bf16-plane body (variants 6: 64 x 64 tiles, 7: 128 x 128 tiles; one tile shape per launch).
+// The same for the three-bf16-plane body: variant 6 = 64 (output channels) x 128 (k') tiles, 4 waves of 64 x 32, two workgroups per
+// CU; variant 7 = 128 x 128 tiles, 8 waves of 64 x 32, one workgroup per CU (one tile shape per launch).
 template <int BT>
-__global__ __launch_bounds__(256, BT == 64 ? 2 : 1) void conv_wgrad_multi_x3_kernel(const WgradMultiArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * (2 * BT) * 40 * 2];
+__global__ __launch_bounds__(BT == 64 ? 256 : 512, BT == 64 ? 2 : 1) void conv_wgrad_multi_x3_kernel(const WgradMultiArgs a) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[2 * 3 * 32 * (BT + 128) * 2];
     const int bid = (int)blockIdx.x;
     int i = 0;
     while (i + 1 < a.n && bid >= a.wg_end[i]) ++i;
@@ -1872,7 +1930,14 @@ __global__ __launch_bounds__(256, BT == 64 ? 2 : 1) void conv_wgrad_multi_x3_ker
     const int nwg = a.wg_end[i] - first, tiles = a.tiles[i];
     const int lin = nwg >= 8 ? xcd_remap(bid - first, nwg) : bid - first;
     const int split = lin / tiles, tile = lin - split * tiles;
-    wgrad_x3_body<BT, BT>(a.d[i], tile, split, smem);
+    const bool gen = a.d[i].ups || a.d[i].idil > 1;
+    if constexpr (BT == 64) {
+        if (gen) wgrad_x3_body<64, 128, 1, 4, true>(a.d[i], tile, split, smem);
+        else wgrad_x3_body<64, 128, 1, 4, false>(a.d[i], tile, split, smem);
+    } else {
+        if (gen) wgrad_x3_body<128, 128, 2, 4, true>(a.d[i], tile, split, smem);
+        else wgrad_x3_body<128, 128, 2, 4, false>(a.d[i], tile, split, smem);
+    }
 }
 
 __device__ __forceinline__ void wgrad_reduce_body(const WgradDesc& p, const unsigned bid, const unsigned nblk) {
@@ -2594,9 +2659,9 @@ static int g_wgrad_x3 = -1;
 static bool wgrad_x3_on() {
     if (g_wgrad_x3 < 0) {
         const char* e = getenv("V2A_WGRAD_X3");
-        g_wgrad_x3 = (e && e[0] == '1') ? 1 : 0;      // default OFF: measured slower on the policy step than the exact halo / 64x64 bodies
-    }                                                  // (10.5 vs 9.6-9.8 ms): the transposing loader keeps half the workgroup idle on 64 x 64
-    return g_wgrad_x3 == 1;                            // tiles and the 128 x 128 tile runs one workgroup per CU
+        g_wgrad_x3 = (e && e[0] == '0') ? 0 : 1;      // default ON with the transposing-read body (policy step 9.75 -> 9.15 ms; the first,
+    }                                                  // register-transposing version was slower than the exact bodies: 10.5 ms)
+    return g_wgrad_x3 == 1;
 }
 // kernel family of a grouped-launch variant: 0 = 64x64 exact / twin-fed bodies (0-2), 1 = halo body (3-5), 2 / 3 = three-plane bodies (6 / 7)
 static int wgrad_family(int v) { return v <= 2 ? 0 : (v <= 5 ? 1 : (v == 6 ? 2 : 3)); }
@@ -2635,13 +2700,14 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
             OW == W && C1 % 64 == 0 && Cout % 64 == 0 && p.M % 32 == 0 && (OW == 8 || OW == 16 || OW % 32 == 0) &&
             OH % (OW >= 32 ? 1 : 32 / OW) == 0 && big < 2147483648.0)
             variant = OW == 8 ? 5 : (OW == 16 ? 4 : 3);
-        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on())         // fp32 products from three bf16 planes (V2A_WGRAD_X3=1; default: the exact bodies)
-            variant = (Cout >= 128 && p.K >= 128) ? 7 : 6;
+        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && p.idil <= 2 && big < 1073741824.0)         // fp32 products from three bf16 planes (V2A_WGRAD_X3=1; default: the exact bodies)
+            variant = Cout >= 128 ? 7 : 6;
     }
     *variant_out = variant;
     if (variant < 0) { *tiles_out = 0; *rtiles_out = 0; return V2A_OK; }
     const int rrows = (variant == 1 || variant == 2) ? 64 : 32;
-    const int tiles = (variant == 0 || variant == 6) ? cdiv(Cout, 64) * cdiv(p.K, 64)
+    const int tiles = variant == 0 ? cdiv(Cout, 64) * cdiv(p.K, 64)
+                      : variant == 6 ? cdiv(Cout, 64) * cdiv(p.K, 128)
                       : variant == 7 ? cdiv(Cout, 128) * cdiv(p.K, 128)
                       : (variant >= 3 ? (Cout / 64) * (C1 / 64) : cdiv(Cout, variant == 1 ? 128 : 64) * cdiv(p.K, 128));
     const int nrt = cdiv(p.M, rrows);
@@ -2691,7 +2757,7 @@ int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* ti
     }
     for (int i = n; i < WGM_MAX; ++i) a.wg_end[i] = tot;
     const int fam = wgrad_family(variants[0]);
-    if (fam == 3) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<128>, dim3(tot), dim3(256), 0, stream, a);
+    if (fam == 3) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<128>, dim3(tot), dim3(512), 0, stream, a);
     else if (fam == 2) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<64>, dim3(tot), dim3(256), 0, stream, a);
     else if (fam == 1) hipLaunchKernelGGL(conv_wgrad_multi_halo_kernel, dim3(tot), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3(tot), dim3(256), 0, stream, a);
