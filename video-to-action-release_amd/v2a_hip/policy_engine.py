@@ -49,6 +49,7 @@ class _Conv:
         self.co, self.ci = w.shape[0], w.shape[1]     # torch dims 0 / 1 (for transposed: [Cin][Cout])
         # data gradients read the forward pack directly (N-major loader) when the reduction channels are a multiple of 16
         self.nmaj = (self.co % 16 == 0) and (self.ci % 4 == 0)
+        self.group = "unet" if wname.startswith("model.") else "enc"      # refresh_packs(which)
         self._pf = None
         self._pd = None
         self._pf_h = None          # bf16 twins of the two operands (bf16 precision mode, see PolicyEngine.refresh_packs)
@@ -64,6 +65,8 @@ class _Conv:
         return self.eng.P[self.bname] if self.bname is not None else None
 
     def _fresh(self):
+        if self.eng._packs_pending is not None and self.group == self.eng._packs_pending:
+            self.eng.refresh_packs(self.eng._packs_pending)      # the trainer left this group's packs to the start of its next step
         w = self.w
         key = (w.data_ptr(), w._version)
         if key != self._ver:
@@ -415,18 +418,26 @@ class PolicyEngine:
         self._film_keep = (t0, t1, c0, c1)              # keep the tables alive until the launches ran
         self._film_ver = self._film_key()
 
-    def refresh_packs(self):
-        """Unconditionally re-pack every conv weight (call once per train step after the optimiser; capturable).
-        Two multi-tensor launches write everything: the forward packs (gather within a filter) and the flipped data-gradient
-        packs (tap-reversed transposes through LDS; odd-channel layers always, every layer in the bf16 precision mode).  In that
-        mode both launches also write the bf16 twin of each operand, which ops.conv2d picks up for the layers the LDS-DMA
+    _packs_pending = None      # "unet": the trainer postponed that group's re-pack to the start of its next step (see refresh_packs)
+    _pack_join = None          # stream the UNet forward has to wait for (the side stream that group's re-pack was launched on)
+
+    def refresh_packs(self, which="all"):
+        """Unconditionally re-pack conv weights (call once per train step after the optimiser; capturable).  which = "all" | "enc" |
+        "unet": the image encoders' (`obs_encoder.*`) or the ConditionalUnet1D's (`model.*`, 75 % of the parameters) operands only --
+        the trainer packs the encoders right after the optimiser and the UNet at the START of the next step on a side stream, under
+        the encoder forward that does not read them (0.33 of the 0.45 ms of pack launches leave the serial tail); until then
+        `_packs_pending` makes any other reader of a UNet operand refresh it first.
+        Two multi-tensor launches per group write everything: the forward packs (gather within a filter) and the flipped
+        data-gradient packs (tap-reversed transposes through LDS; odd-channel layers always, every layer in the bf16 precision mode).
+        In that mode both launches also write the bf16 twin of each operand, which ops.conv2d picks up for the layers the LDS-DMA
         bf16 kernel can take."""
         from ._lib import lib, check
         bf16 = lib.v2a_get_precision() == 1
         if getattr(self, "_mp", None) is not None and (self._mp["bf16"] != bf16 or self._mp.get("half") is not ops.POLICY_HALF[0]):
             self._mp = None                            # precision mode or 16-bit format changed: new twins
         if getattr(self, "_mp", None) is None:
-            rows, ch0, ch1 = [], [], []
+            rows = []
+            ch0, ch1 = {"enc": [], "unet": []}, {"enc": [], "unet": []}
             ce = lib.v2a_pack_chunk_elems()
             for c in self._convs.values():
                 w = c.w.detach()
@@ -440,39 +451,45 @@ class PolicyEngine:
                     c._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
                 if taps > 1 or bf16:                   # forward operand (1x1 weights are their own fp32 operand: twin only)
                     rows.append([w.data_ptr(), c._pf.data_ptr() if taps > 1 else 0, c.co, c.ci, taps, 0, c._pf_h.data_ptr() if bf16 else 0])
-                    ch0 += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
+                    ch0[c.group] += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
                 if not c.nmaj or bf16 or self.flip_dgrad:
                     if c._pd is None:
                         c._pd = torch.empty(w.numel(), dtype=torch.float32, device=self.device)
                     rows.append([w.data_ptr(), c._pd.data_ptr(), c.co, c.ci, taps, 1, c._pd_h.data_ptr() if bf16 else 0])
                     ntile = -(-c.co // 64) * -(-(c.ci * taps) // 64)
-                    ch1 += [[len(rows) - 1, t] for t in range(ntile)]
+                    ch1[c.group] += [[len(rows) - 1, t] for t in range(ntile)]
                 if bf16:
                     ops.register_h_twin(c._pf, c._pf_h)
                     ops.register_h_twin(c._pd, c._pd_h)
-            if self.batch_film:
+            if self.batch_film:                        # (FiLM tables: ConditionalUnet1D operands)
                 f0, f1 = self._film_rows()
                 for row in f0:
                     rows.append(row)
-                    ch0 += [[len(rows) - 1, s0] for s0 in range(0, row[2] * row[3], ce)]
+                    ch0["unet"] += [[len(rows) - 1, s0] for s0 in range(0, row[2] * row[3], ce)]
                 for row in f1:
                     rows.append(row)
-                    ch1 += [[len(rows) - 1, t_] for t_ in range(-(-row[2] // 64) * -(-row[3] // 64))]
+                    ch1["unet"] += [[len(rows) - 1, t_] for t_ in range(-(-row[2] // 64) * -(-row[3] // 64))]
             dev = self.device
             t = lambda a, dt: torch.tensor(a, dtype=dt).to(dev) if a else None
-            self._mp = dict(tab=t(rows, torch.int64), ch0=t(ch0, torch.int32), n0=len(ch0), ch1=t(ch1, torch.int32), n1=len(ch1),
-                            ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16, half=ops.POLICY_HALF[0])
+            self._mp = dict(tab=t(rows, torch.int64), ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16, half=ops.POLICY_HALF[0],
+                            ch0={g: t(v, torch.int32) for g, v in ch0.items()}, n0={g: len(v) for g, v in ch0.items()},
+                            ch1={g: t(v, torch.int32) for g, v in ch1.items()}, n1={g: len(v) for g, v in ch1.items()})
         mp = self._mp
         if mp["ptrs"] != [c.w.data_ptr() for c in self._convs.values()]:      # parameters were re-allocated (.to(), load): rebuild
             self._mp = None
-            return self.refresh_packs()
-        if mp["n0"]:
-            check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch0"].data_ptr(), mp["n0"], 0, ops._stream()), "pack_weights_multi")
-        if mp["n1"]:
-            check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"].data_ptr(), mp["n1"], 1, ops._stream()), "pack_weights_multi_t")
+            return self.refresh_packs(which)
+        groups = ("enc", "unet") if which == "all" else (which,)
+        for g in groups:
+            if mp["n0"][g]:
+                check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch0"][g].data_ptr(), mp["n0"][g], 0, ops._stream()), "pack_weights_multi")
+            if mp["n1"][g]:
+                check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"][g].data_ptr(), mp["n1"][g], 1, ops._stream()), "pack_weights_multi_t")
+        if self._packs_pending in groups:
+            self._packs_pending = None
         for c in self._convs.values():
-            c._ver = (c.w.data_ptr(), c.w._version)
-        if self.batch_film:
+            if c.group in groups:
+                c._ver = (c.w.data_ptr(), c.w._version)
+        if self.batch_film and "unet" in groups:
             self._film_ver = self._film_key()
 
     # ------------------------------------------------------------------ encoder
@@ -1203,6 +1220,9 @@ class PolicyEngine:
         gc = self.global_cond(imgs, save_enc)
         noisy = ops.add_noise(action, noise, timesteps, self.ac, self.act_limits)
         save = {}
+        if self._pack_join is not None:             # (trainer: the ConditionalUnet1D operands were re-packed on a side stream under the encoders)
+            torch.cuda.current_stream().wait_stream(self._pack_join)
+            self._pack_join = None
         pred = self.unet_fwd(noisy, timesteps, gc, save)
         loss, dpred = ops.mse_loss(pred, noise, want_grad=True, grad_scale_ptr=self.loss_scale_ptr)
         ops.tstamp("unet_bwd begin")
@@ -1288,6 +1308,7 @@ class PolicyEngine:
         if deferred:
             with ops.ws_lane(7):
                 self._launch_deferred(deferred)
+        return deferred        # the CALLER keeps the operands alive until this stream has been joined (the encoder backward allocates meanwhile)
 
     def arena_slices(self, names):
         """(start, end) element ranges of the `model.*` (ConditionalUnet1D) and the remaining (encoder) gradients in the arena."""

@@ -103,6 +103,11 @@ class PolicyTrainer:
         self._st = None
         self._warm = 0
         self.step_count = 0
+        # the ConditionalUnet1D re-pack (0.33 ms of HBM-bound launches) leaves the serial tail: it runs at the start of the NEXT step
+        # on a side stream, under the encoder forward (V2A_SPLIT_PACKS=0: everything right after the optimiser, as before)
+        self.split_packs = os.environ.get("V2A_SPLIT_PACKS", "1") != "0"
+        self._pack_side = None
+        self._wg_keep = None
 
     # ------------------------------------------------------------------ pieces
     def _draw_indices(self):
@@ -142,6 +147,13 @@ class PolicyTrainer:
         B = self.B
         ops.tstamp_reset()
         ops.tstamp("step begin")
+        if self.split_packs:                           # last step's ConditionalUnet1D weights -> packed operands, under the encoder forward
+            if self._pack_side is None:
+                self._pack_side = torch.cuda.Stream(device=self.device)
+            self._pack_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pack_side):
+                self.eng.refresh_packs("unet")
+            self.eng._pack_join = self._pack_side
         oo = torch.empty((2 * B, 3, st.H, st.W), dtype=torch.float32, device=self.device)      # start | goal frames side by side: the
         o0, o1 = oo[:B], oo[B:]                                                                 # two camera encoders run as one stacked chain
         oa = torch.empty((B, st.act_len, st.act_dim), dtype=torch.float32, device=self.device)
@@ -179,7 +191,7 @@ class PolicyTrainer:
             if graph:
                 self._g_wg.replay()
             else:
-                self.eng.run_deferred_wgrads()
+                self._wg_keep = self.eng.run_deferred_wgrads()      # operands stay referenced until the join in _reduce_wait()
             self._reduce_async(0)
 
     def _reduce_async(self, which):
@@ -194,6 +206,8 @@ class PolicyTrainer:
             ev[0].record()
         if self.dp_defer and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)      # the weight-gradient branch (and the launch of slice 0) joins here
+            if not (self.use_graph and self._g_fb is not None):
+                self._wg_keep = None
         self.reducer.finish(self.opt.scale_grads)           # averaging folded into the optimiser's gradient scale
         if ev is not None:
             ev[1].record()
@@ -203,7 +217,11 @@ class PolicyTrainer:
         ops.tstamp("optimiser begin")
         self.opt.step(zero_grad=True)
         ops.tstamp("optimiser done / packs begin")
-        self.eng.refresh_packs()
+        if self.split_packs:
+            self.eng.refresh_packs("enc")
+            self.eng._packs_pending = "unet"           # (re-armed on the host after every replay, see step())
+        else:
+            self.eng.refresh_packs()
         ops.tstamp("step end")
 
     # ------------------------------------------------------------------ step
@@ -235,9 +253,12 @@ class PolicyTrainer:
                     with torch.cuda.graph(self._g_fb):
                         self._fwd_bwd()
                     if self.dp_defer:
+                        # this graph runs NEXT TO the encoder-backward graph: a memory pool of its own, and its operands (activations
+                        # of the first graph) stay referenced for the graphs' lifetime -- a block freed here would be handed to the
+                        # graphs captured after it, which then overwrite it while this one still reads
                         self._g_wg = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self._g_wg, pool=self._g_fb.pool()):
-                            self.eng.run_deferred_wgrads()
+                        with torch.cuda.graph(self._g_wg):
+                            self._wg_keep = self.eng.run_deferred_wgrads()
                     self._g_enc = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._g_enc, pool=self._g_fb.pool()):
                         self._bwd_encoders()
@@ -265,6 +286,8 @@ class PolicyTrainer:
                 if pe:
                     pe[4].record()
                     self.phase_events.append(pe)
+        if self.split_packs:
+            self.eng._packs_pending = "unet"           # any reader of a UNet operand outside the next step refreshes it first
         self.step_count += 1
         return self.loss
 
