@@ -155,6 +155,9 @@ int v2a_unnormalize_action(const float* x, float* out, int n, const float* act_m
 int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);
 int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, v2a_stream_t s);
 int v2a_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int HW, v2a_stream_t s);
+/* NCHW RGB (float or uint8) -> the interior of a zero-bordered [N][H + 2 pad][W + 2 pad][4] image (channel 3 = 0), same normalisation:
+   the input layout of v2a_conv2d_fwd_window_f32 and of the stem's weight gradient.  The caller zeroes dst once. */
+int v2a_nchw_to_nhwc4p(const void* src, int is_u8, float* dst, int N, int H, int W, int pad, int normalize, v2a_stream_t s);
 /* Unet_Libero input pack 'b (f c) h w' + repeated cond image -> [B,f,H,W,6] (flowdiffusion/flowdiffusion/unet.py:217-220) */
 int v2a_video_pack(const float* img, const float* cond, float* xin, int B, int f, int HW, size_t img_bstride, size_t cond_bstride,
                    int frame_ch /* 3 RGB (Unet_Libero/MW/Thor/Bridge), 2 flow (UnetMWFlow) */, v2a_stream_t s);
@@ -276,6 +279,13 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
                            const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
                            int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, float* stats,
                            void* workspace, size_t workspace_bytes, v2a_stream_t s);
+/* "channel window" form for few-channel inputs (the RGB stem of the policy's ResNet-18 encoders: torchvision resnet18.conv1 7x7 / 2 behind
+   diffuser/diffusion_policy/common/vision_nets.py:29-39): pixel (ih, iw) = the C floats at x + ((n * H + ih) * W + iw) * xpitch, xpitch <= C
+   (overlapping windows); no padding (the buffer carries its zero border, v2a_nchw_to_nhwc4p); w_packed [Cout][KH][KW][C] (pack mode 2 of
+   v2a_pack_weights_multi for the 7x7x3 filter -> [Cout][7][8][4]).  fp32 three-plane conv mode only (V2A_ERR_ARG otherwise). */
+int v2a_conv2d_fwd_window_f32(const float* x, const float* w_packed, const float* bias, float* y, const void* zeros, int N, int H, int W,
+                              int xpitch, int C, int Cout, int KH, int KW, int sh, int sw, int OH, int OW, void* workspace,
+                              size_t workspace_bytes, v2a_stream_t stream);
 /* same, leaving the split-K reduce to the consuming GroupNorm launch (v2a_groupnorm_fwd_s / _bwd_s): *nslab_out (HOST) = number of
    fp32 slabs [M][Cout] left in `workspace` (bias / residual not applied, y untouched), or 0 when the conv finished y itself */
 int v2a_conv2d_fwd_dma_f32_d(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,

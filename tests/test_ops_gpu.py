@@ -1036,3 +1036,37 @@ def test_pack_weights_multi_forward_and_flipped_packs_vs_torch():
         flip = w.flip(2).permute(1, 2, 0).contiguous().view(-1)                 # [Cin][taps reversed][Cout]
         assert torch.equal(f32a, fwd) and torch.equal(ha, fwd.to(torch.bfloat16))
         assert torch.equal(f32b, flip) and torch.equal(hb, flip.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,u8", [(3, 32, 48, False), (64, 128, 128, True), (5, 18, 30, True)])
+def test_stem_channel_window_conv_and_weight_gradient_vs_torch(N, H, W, u8):
+    """RGB stem 7x7 / stride 2 / pad 3 (torchvision resnet18.conv1 behind vision_nets.py:29-39) as a channel-window conv over the
+    zero-bordered 4-channel image (v2a_nchw_to_nhwc4p + pack mode 2 + v2a_conv2d_fwd_window_f32), and its weight gradient on the
+    three-plane body fed from the same buffer: against torch fp32 on the CPU (fp64 yard-stick for the long reduction)."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("channel-window conv: fp32 three-plane mode only")
+    torch.manual_seed(5)
+    img = torch.randint(0, 256, (N, 3, H, W), dtype=torch.uint8) if u8 else torch.rand(N, 3, H, W)
+    w = torch.randn(64, 3, 7, 7) * 0.1
+    xn = (img.float() / 255.0 if u8 else img) * 2.0 - 1.0
+    ref = F.conv2d(xn, w, stride=2, padding=3)
+    xp = torch.zeros((N, H + 6, W + 6, 4), dtype=torch.float32, device=dev())
+    ops.nchw_to_nhwc4p(img.to(dev()), xp, 3, normalize=True)
+    close(xp[:, 3:-3, 3:-3, :3].permute(0, 3, 1, 2), xn, 1e-6, "padded NHWC4 interior")
+    assert float(xp[..., 3].abs().max()) == 0.0 and float(xp[:, :3].abs().max()) == 0.0 and float(xp[:, :, -3:].abs().max()) == 0.0
+    pw = torch.zeros(64 * 7 * 8 * 4, dtype=torch.float32, device=dev())
+    ops.pack_weight(w.to(dev()), 2, pw)
+    pw4 = pw.view(64, 7, 8, 4).cpu()
+    assert torch.equal(pw4[:, :, :7, :3], w.permute(0, 2, 3, 1)) and float(pw4[:, :, 7].abs().max()) == 0.0 and float(pw4[..., 3].abs().max()) == 0.0
+    y = ops.conv2d_window(xp, pw, 64, 7, 1, (2, 1), (H // 2, W // 2), xpitch=8, C=32)
+    close(nchw(y), ref, 1e-4, "window conv")
+    # weight gradient from the padded buffer (pad 0): the 4-channel filter's gradient, first three input channels kept
+    dy = torch.randn(N, H // 2, W // 2, 64)
+    dw4 = ops.conv2d_wgrad(xp, dy.to(dev()), (64, 4, 7, 7), 7, 7, (2, 2), (0, 0))
+    wd = w.double().requires_grad_(True)
+    F.conv2d(xn.double(), wd, stride=2, padding=3).backward(dy.permute(0, 3, 1, 2).double())
+    close(dw4[:, :3], wd.grad.float(), 1e-4, "stem weight gradient")
+    assert float(dw4[:, 3].abs().max()) == 0.0

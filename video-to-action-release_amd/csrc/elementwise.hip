@@ -236,6 +236,27 @@ __global__ void nchw_to_nhwc_kernel(const T* src, float* dst, int N, int C, int 
         dst[i] = v;
     }
 }
+// The same conversion into a zero-bordered 4-channel image [N][H + 2 pad][W + 2 pad][4] (channel 3 = 0): the layout the channel-window
+// stem conv (v2a_conv2d_fwd_window_f32) and its weight gradient read.  Only the interior is written; the caller zeroes the buffer once.
+template <typename T>
+__global__ void nchw_to_nhwc4p_kernel(const T* src, float* dst, int N, int H, int W, int pad, int normalize, float denom) {
+    const size_t total = (size_t)N * H * W;
+    const int HW = H * W, Wp = W + 2 * pad, Hp = H + 2 * pad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const int n = (int)(i / HW);
+        const int h = hw / W, w = hw - h * W;
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (float)src[((size_t)n * 3 + c) * HW + hw] / denom;
+            if (normalize) v = 2.0f * ((v - 0.0f) / (1.0f - 0.0f)) - 1.0f;
+            o[c] = v;
+        }
+        o[3] = 0.f;
+        *reinterpret_cast<f32x4*>(dst + (((size_t)n * Hp + h + pad) * Wp + w + pad) * 4) = o;
+    }
+}
 __global__ void nhwc_to_nchw_kernel(const float* src, float* dst, int N, int C, int HW) {
     const size_t total = (size_t)N * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -631,6 +652,13 @@ int v2a_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int HW, int
 }
 int v2a_nchw_to_nhwc_u8(const uint8_t* src, float* dst, int N, int C, int HW, int normalize, hipStream_t s) {
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<uint8_t>), GRID_FOR((size_t)N * C * HW), dim3(256), 0, s, src, dst, N, C, HW, normalize, 255.0f);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_nchw_to_nhwc4p(const void* src, int is_u8, float* dst, int N, int H, int W, int pad, int normalize, hipStream_t s) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || pad < 0 || (((uintptr_t)dst) & 15)) return V2A_ERR_ARG;
+    if (is_u8) hipLaunchKernelGGL((nchw_to_nhwc4p_kernel<uint8_t>), GRID_FOR((size_t)N * H * W), dim3(256), 0, s, (const uint8_t*)src, dst, N, H, W, pad, normalize, 255.0f);
+    else hipLaunchKernelGGL((nchw_to_nhwc4p_kernel<float>), GRID_FOR((size_t)N * H * W), dim3(256), 0, s, (const float*)src, dst, N, H, W, pad, normalize, 1.0f);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

@@ -2091,16 +2091,22 @@ static void launch_wgrad_reduce(const WgradDesc& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------ weight packs
 // mode 0 (forward pack):        dst[co][kh][kw][ci]    = src[co][ci][kh][kw]
 // mode 1 (data-gradient pack):  dst[ci][kh'][kw'][co]  = src[co][ci][KH-1-kh'][KW-1-kw']
+// mode 2 (channel-window pack): dst[co][kh][kw][ci] with KW + 1 columns of Cin + 1 channels (v2a_conv2d_fwd_window_f32; dst pre-zeroed)
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int KH, int KW, int mode) {
     const size_t total = (size_t)Cout * Cin * KH * KW;
     const int taps = KH * KW;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        if (mode == 0) {
+        if (mode == 0 || mode == 2) {
             int ci = (int)(idx % Cin);
             size_t t = idx / Cin;
             int tap = (int)(t % taps);
             int co = (int)(t / taps);
-            dst[idx] = src[((size_t)co * Cin + ci) * taps + tap];
+            const float v = src[((size_t)co * Cin + ci) * taps + tap];
+            if (mode == 0) dst[idx] = v;
+            else {                                   // channel-window pack: [Cout][KH][KW + 1][Cin + 1], added column / channel left as they are (zero)
+                const int kh = tap / KW, kw = tap - kh * KW;
+                dst[(((size_t)co * KH + kh) * (KW + 1) + kw) * (Cin + 1) + ci] = v;
+            }
         } else {
             int co = (int)(idx % Cout);
             size_t t = idx / Cout;
@@ -2112,7 +2118,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 }
 
 // all packs of a model in TWO launches.  table (int64) per operand: {src, dst, Cout, Cin, taps, mode, dst_bf16 or 0}.
-// mode 0 (forward pack [Cout][taps][Cin]): chunks (int32) {operand, start element}, PACK_CHUNK elements per workgroup.
+// mode 0 (forward pack [Cout][taps][Cin]) and mode 2 (its channel-window form): chunks (int32) {operand, start element}, PACK_CHUNK
+// elements per workgroup.
 // mode 1 (data-gradient pack [Cin][taps reversed][Cout] = a [Cout x Cin*taps] -> [Cin*taps x Cout] transpose with the taps of
 // each input channel reversed): chunks {operand, 64x64 tile index}; the tile goes through LDS so that both the global reads
 // (contiguous along Cin*taps) and the global writes (contiguous along Cout) are full lines.
@@ -2136,9 +2143,18 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
     int ci = (int)(idx0 - q * (unsigned)Cin);
     int co = (int)(q / (unsigned)taps);
     int tap = (int)(q - (unsigned)co * (unsigned)taps);
+    // mode 2 ("channel window" pack of a square filter, v2a_conv2d_fwd_window_f32): dst[co][kh][kw'][ci'] with KW + 1 columns and
+    // Cin + 1 channels per column -- the added column / channel stay zero (the caller zeroes dst once)
+    const int mode = (int)table[t * 7 + 5];
+    int kwn = 1;
+    while (kwn * kwn < taps) ++kwn;
     for (int i = threadIdx.x; i < cnt; i += 256) {
-        const size_t idx = (size_t)start + i;
+        size_t idx = (size_t)start + i;
         const float v = src[((size_t)co * Cin + ci) * taps + tap];
+        if (mode == 2) {
+            const int kh = tap / kwn, kw = tap - kh * kwn;
+            idx = (((size_t)co * kwn + kh) * (kwn + 1) + kw) * (Cin + 1) + ci;
+        }
         if (dst) dst[idx] = v;
         if (dsth) dsth[idx] = f2h_pack(v, f16);
         ci += 256;
@@ -2266,6 +2282,15 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
 }
 
 static int g_wgrad_stages64 = 2;  // LDS stages of the 64x64 DMA weight-gradient kernel (V2A_WGRAD_STAGES=4: the four-stage experiment)
+extern "C" int v2a_get_f32_conv_mode(void);
+static int g_wgrad_x3 = -1;
+static bool wgrad_x3_on() {
+    if (g_wgrad_x3 < 0) {
+        const char* e = getenv("V2A_WGRAD_X3");
+        g_wgrad_x3 = (e && e[0] == '0') ? 0 : 1;      // default ON with the transposing-read body (policy step 9.75 -> 9.15 ms; the first,
+    }                                                  // register-transposing version was slower than the exact bodies: 10.5 ms)
+    return g_wgrad_x3 == 1;
+}
 static int g_wgrad_dma = -1;  // fp32 weight gradients with 128-row output tiles on the LDS-DMA kernel (V2A_WGRAD_DMA=0 / v2a_debug_wgrad_dma)
 
 extern "C" {
@@ -2544,6 +2569,35 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     wgrad_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     const int nrt = cdiv(p.M, BK);
     if (s > 1 && ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    // few-channel inputs (the RGB stem padded to 4 channels: K = 196, a reduction over N * OH * OW = 262 144 rows) in the fp32
+    // three-plane mode: the three-plane body as a one-problem launch of the grouped kernel, with the plan's split (the exact LDS-DMA
+    // kernel it replaces: 173 us per encoder, at the tail of the step's weight-gradient branch)
+    if (g_precision == 0 && v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && veca && vecb && Cin <= 8 && !x2 && Cout % 4 == 0 &&
+        p.K % 4 == 0 && p.idil == 1 && !ups && (double)N * H * W * C1 < 1073741824.0) {
+        WgradMultiArgs a;
+        __builtin_memset(&a, 0, sizeof(a));
+        const int big = Cout >= 128 ? 1 : 0;
+        const int xt = cdiv(Cout, big ? 128 : 64) * cdiv(p.K, 128);
+        const int nrt32 = cdiv(p.M, 32);
+        int sx = s > nrt32 ? nrt32 : s;
+        const int per = cdiv(nrt32, sx);
+        sx = cdiv(nrt32, per);                        // no empty slices (sx <= s: the workspace check above covers it)
+        p.splits = sx;
+        p.rtiles_per_split = per;
+        a.n = 1;
+        a.d[0] = p;
+        a.variant[0] = big ? 7 : 6;
+        a.tiles[0] = xt;
+        for (int i = 0; i < WGM_MAX; ++i) a.wg_end[i] = xt * sx;
+        if (big) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<128>, dim3(xt * sx), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<64>, dim3(xt * sx), dim3(256), 0, stream, a);
+        V2A_CHECK_LAUNCH();
+        if (sx > 1) {
+            launch_wgrad_reduce(p, stream);
+            V2A_CHECK_LAUNCH();
+        }
+        return V2A_OK;
+    }
     p.splits = s;
     p.rtiles_per_split = cdiv(nrt, s);
     dim3 grid(tiles, s), block(256);
@@ -2654,15 +2708,6 @@ int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwor
 // `slabs` (the layer's own scratch, >= (splits * Cout * K + splits * Cout) * 4 bytes when splits > 1) is entered, item_out (HOST,
 // v2a_wgrad_item_bytes()) receives the main-kernel descriptor, *splits_out the split actually used (capped so that every slice keeps
 // work), and ritem_out / *rblocks_out / *rform_out the reduce item for v2a_wgrad_reduce_multi (rblocks 0: nothing to reduce).
-extern "C" int v2a_get_f32_conv_mode(void);
-static int g_wgrad_x3 = -1;
-static bool wgrad_x3_on() {
-    if (g_wgrad_x3 < 0) {
-        const char* e = getenv("V2A_WGRAD_X3");
-        g_wgrad_x3 = (e && e[0] == '0') ? 0 : 1;      // default ON with the transposing-read body (policy step 9.75 -> 9.15 ms; the first,
-    }                                                  // register-transposing version was slower than the exact bodies: 10.5 ms)
-    return g_wgrad_x3 == 1;
-}
 // kernel family of a grouped-launch variant: 0 = 64x64 exact / twin-fed bodies (0-2), 1 = halo body (3-5), 2 / 3 = three-plane bodies (6 / 7)
 static int wgrad_family(int v) { return v <= 2 ? 0 : (v <= 5 ? 1 : (v == 6 ? 2 : 3)); }
 int v2a_wgrad_family(int variant) { return wgrad_family(variant); }

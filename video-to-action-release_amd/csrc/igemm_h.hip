@@ -70,6 +70,8 @@ struct ConvDescH {
     const void* w2;           // second weight set (rows >= m_split) or null       [conv_igemm_f32p only]
     const float* bias2;       // second bias (rows >= m_split) or null
     int m_split;              // first output row of the second set (a multiple of every row tile); INT_MAX: one set
+    int xp1;                  // element pitch between consecutive pixels of source 1 (= C1; < C1: overlapping channel windows,
+                              // v2a_conv2d_fwd_window_f32)                                      [conv_igemm_f32x3, non-GEN path only]
     unsigned long long* tstamps;   // measurement aid (v2a_debug_conv_stamps): [workgroup][8] wall-clock stamps of the kernel's phases, or null
 };
 #define V2A_STAMP(i) do { if (p.tstamps && threadIdx.x == 0) p.tstamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
         a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);
         a_iwb[j] = ow * p.sw - p.pw;
         const int pix = (a_imgh[j] + a_ihb[j]) * p.W + a_iwb[j];
-        a_lin1[j] = pix * p.C1 + c4 * 4;
+        a_lin1[j] = pix * p.xp1 + c4 * 4;
         a_lin2[j] = pix * p.C2 + c4 * 4;
     }
     const float* zsrc = reinterpret_cast<const float*>(p.zeros);
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
         const float* src = reinterpret_cast<const float*>(first ? p.x : p.x2);
         const uint32_t Cs = (uint32_t)(first ? p.C1 : p.C2);
         const uint32_t cc = (uint32_t)((first ? ic0 : ic0 - p.C1) + c4 * 4);
-        const int s_tap = (ikh * p.W + ikw) * (int)Cs + (first ? ic0 : ic0 - p.C1);
+        const int s_tap = (ikh * p.W + ikw) * (first ? p.xp1 : p.C2) + (first ? ic0 : ic0 - p.C1);
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
@@ -1119,7 +1121,8 @@ template <typename T>
 static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,
                            const float* residual_f32, void* y, float* y_f32, const void* zeros, int N, int H, int W, int C1, int C2,
                            int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch,
-                           float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream, int* nslab_out = nullptr) {
+                           float* stats, void* workspace, size_t workspace_bytes, hipStream_t stream, int* nslab_out = nullptr,
+                           int xpitch = 0) {
     constexpr int ept = 128 / (int)sizeof(T);
     if (nslab_out) *nslab_out = 0;
     if (!x || !w_packed || !zeros || N <= 0 || Cout <= 0) return V2A_ERR_ARG;
@@ -1168,6 +1171,12 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         g_stages_h = (e && e[0] == '2') ? 2 : 1;
     }
     p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff;
+    p.xp1 = xpitch > 0 ? xpitch : C1;
+    if (xpitch > 0) {                                // channel windows: the three-plane kernel's plain loader only
+        if (sizeof(T) != 4 || x2 || C2 || ups || idil != 1 || xpitch > C1 || xpitch % 4) return V2A_ERR_ARG;
+        f32_conv_mode_init();
+        if (!g_f32x3) return V2A_ERR_ARG;
+    }
     if constexpr (sizeof(T) == 4) {
         if (g_conv_w2) {                             // second operand set of this launch (v2a_conv2d_set_second), consumed here
             const int ms = g_conv_msplit;
@@ -1345,6 +1354,22 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
     if (!y) return V2A_ERR_ARG;
     return conv_dma_launch<float>(x, x2, w_packed, bias, rowvec, residual, nullptr, y, nullptr, zeros, N, H, W, C1, C2, Cout, KH, KW, sh, sw,
                                   ph, pw, ups, idil, OH, OW, rows_per_batch, stats, workspace, workspace_bytes, stream);
+}
+
+// "Channel window" form of the conv above for few-channel inputs (the RGB stem of the policy's ResNet-18 encoders,
+// diffuser/diffusion_policy/common/vision_nets.py:29-39 -> torchvision resnet18 conv1 7x7 / stride 2): logical pixel (ih, iw) is the
+// C-channel window that starts at x + ((n * H + ih) * W + iw) * xpitch with xpitch <= C (windows overlap).  With the image stored
+// zero-padded as [N, Hp, Wp, 4] (RGB + a zero channel), a 7 x 8-pixel patch row is 32 contiguous floats: the 7x7x3 filter padded
+// to [Cout][7][8][4] is a KH = 7, KW = 1, C = 32 conv over windows of pitch sw * 4 floats -- every k tile one aligned 128-B line per
+// output pixel, on the vector loader of the three-plane kernel (the scalar-gather kernel this replaces: 166 us per encoder).
+// No padding (the caller's buffer carries the zero border), fp32 three-plane mode only (V2A_ERR_ARG otherwise).
+int v2a_conv2d_fwd_window_f32(const float* x, const float* w_packed, const float* bias, float* y, const void* zeros, int N, int H, int W,
+                              int xpitch, int C, int Cout, int KH, int KW, int sh, int sw, int OH, int OW, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
+    if (!y || xpitch <= 0) return V2A_ERR_ARG;
+    if ((OH - 1) * sh + KH > H || ((OW - 1) * sw + KW - 1) * xpitch + C > W * xpitch) return V2A_ERR_ARG;      // a window past its image row
+    return conv_dma_launch<float>(x, nullptr, w_packed, bias, nullptr, nullptr, nullptr, y, nullptr, zeros, N, H, W, C, 0, Cout, KH, KW, sh,
+                                  sw, 0, 0, 0, 1, OH, OW, 1, nullptr, workspace, workspace_bytes, stream, nullptr, xpitch);
 }
 
 // The same conv with the split-K reduce left to the consumer: when the plan splits K, the fp32 slabs [nslab][M][Cout] stay in

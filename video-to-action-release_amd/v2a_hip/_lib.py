@@ -77,6 +77,7 @@ SIGNATURES = {
     "v2a_unnormalize_action": (I, [P, P, I, P, P, I, P]),
     "v2a_nchw_to_nhwc_f32": (I, [P, P, I, I, I, I, P]),
     "v2a_nchw_to_nhwc_u8": (I, [P, P, I, I, I, I, P]),
+    "v2a_nchw_to_nhwc4p": (I, [P, I, P, I, I, I, I, I, P]),
     "v2a_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
     "v2a_video_pack": (I, [P, P, P, I, I, I, SZ, SZ, I, P]),
     "v2a_mha_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, F, U64, U64, P]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "v2a_conv2d_h_can_emit_stats": (I, [I, I, I]),
     "v2a_conv2d_fwd_dma_f32": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_fwd_dma_f32_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
+    "v2a_conv2d_fwd_window_f32": (I, [P, P, P, P, P] + [I] * 12 + [P, SZ, P]),
     "v2a_conv2d_h_splits": (I, [I, I, I]),
     "v2a_conv2d_fwd_h_d": (I, [P, P, P, P, P, P, P, P] + [I] * 17 + [P, P, SZ, P]),
     "v2a_conv2d_h2_eligible": (I, [I, I, I, I, I]),

@@ -929,6 +929,34 @@ def nchw_to_nhwc(src, normalize=False):
     return dst
 
 
+def nchw_to_nhwc4p(src, dst, pad, normalize=False):
+    """NCHW RGB batch -> the interior of the zero-bordered [N, H + 2 pad, W + 2 pad, 4] image `dst` (the caller zeroed it once)."""
+    N, C, H, W = src.shape
+    assert C == 3 and src.is_contiguous() and tuple(dst.shape) == (N, H + 2 * pad, W + 2 * pad, 4) and dst.dtype == torch.float32
+    if src.dtype != torch.uint8:
+        _chk(src)
+    check(lib.v2a_nchw_to_nhwc4p(src.data_ptr(), 1 if src.dtype == torch.uint8 else 0, dst.data_ptr(), N, H, W, pad, 1 if normalize else 0,
+                                 _stream()), "nchw_to_nhwc4p")
+    return dst
+
+
+def conv2d_window(xp, w_win, Cout, KH, KW, stride, out_hw, xpitch, C):
+    """Channel-window conv (lib.v2a_conv2d_fwd_window_f32): xp [N, Hp, Wp, c] zero-bordered few-channel image viewed as windows of C
+    floats every `xpitch` floats; w_win [Cout, KH, KW, C].  fp32 three-plane conv mode only."""
+    N, Hp, Wp, c = xp.shape
+    assert (Wp * c) % xpitch == 0
+    OH, OW = out_hw
+    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=xp.device)
+    M, K = N * OH * OW, KH * KW * C
+    wsb = lib.v2a_conv2d_dma_f32_workspace_bytes(M, Cout, K)
+    ws = workspace(wsb, xp.device) if wsb else None
+    last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
+    check(lib.v2a_conv2d_fwd_window_f32(xp.data_ptr(), w_win.data_ptr(), None, y.data_ptr(), _zero_line(xp.device).data_ptr(), N, Hp,
+                                        (Wp * c) // xpitch, xpitch, C, Cout, KH, KW, stride[0], stride[1], OH, OW, _p(ws), wsb, _stream()),
+          "conv2d_fwd_window_f32")
+    return y
+
+
 def nhwc_to_nchw(src):
     N, H, W, C = src.shape
     dst = torch.empty((N, C, H, W), dtype=torch.float32, device=src.device)

@@ -31,6 +31,7 @@ def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
 
 _PRIO = __import__('os').environ.get('V2A_PRIO') == '1'                    # experiment: chain streams at high priority
 _GN_DEFER = __import__('os').environ.get('V2A_GN_DEFER', '1') != '0'      # 0: every conv runs its own split-K reduce (A/B)
+_STEM_WINDOW = __import__('os').environ.get('V2A_STEM_WINDOW', '1') != '0'  # 0: RGB stem on the scalar-gather conv / padded-copy weight gradient (A/B)
 
 class _Conv:
     """One conv / linear / transposed-conv parameter pair and its packed operands."""
@@ -54,6 +55,9 @@ class _Conv:
         self._pd = None
         self._pf_h = None          # bf16 twins of the two operands (bf16 precision mode, see PolicyEngine.refresh_packs)
         self._pd_h = None
+        # RGB stem (7x7, 3 input channels): also the channel-window pack [Cout][7][8][4] of ops.conv2d_window (zero column / channel)
+        self.window = w.dim() == 4 and self.kh == 7 and self.kw == 7 and self.ci == 3
+        self._pw = None
         self._ver = (None, None)
 
     @property
@@ -80,6 +84,10 @@ class _Conv:
             if self._pf is None or self._pf is w:
                 self._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
             ops.pack_weight(w, 0, self._pf)
+        if self.window:
+            if self._pw is None:
+                self._pw = torch.zeros(self.co * self.kh * (self.kw + 1) * (self.ci + 1), dtype=torch.float32, device=w.device)
+            ops.pack_weight(w, 2, self._pw)
         if not self.nmaj or self._pd is not None:     # flipped pack: odd channel counts always, every layer once the bf16 mode used it
             if self._pd is None:
                 self._pd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
@@ -98,6 +106,10 @@ class _Conv:
     def pf(self):
         self._fresh()
         return self._pf
+
+    def pw(self):
+        self._fresh()
+        return self._pw
 
     def dg(self):
         """(operand, bmode) for the data-gradient / transposed-conv launch of this weight."""
@@ -141,6 +153,8 @@ class PolicyEngine:
         self._in_enc = False
         self._cur_batch = 0
         self._stem_pad = {}
+        self._stem_buf = {}        # (camera, N, H, W) -> zero-bordered [N, H + 6, W + 6, 4] stem input (_stem_fwd)
+        self._stem_ver = {}        # camera -> forwards written into its buffer so far
         # ConditionalUnet1D weight gradients feed nothing until the optimiser: with defer_unet_wgrad they are collected during the
         # data-gradient chain and launched as ONE extra branch next to the two encoder backward chains (one fork / one join).
         # The data-parallel trainer turns this off: there the `model.*` arena slice must be final after phase 1 so that its
@@ -452,6 +466,11 @@ class PolicyEngine:
                 if taps > 1 or bf16:                   # forward operand (1x1 weights are their own fp32 operand: twin only)
                     rows.append([w.data_ptr(), c._pf.data_ptr() if taps > 1 else 0, c.co, c.ci, taps, 0, c._pf_h.data_ptr() if bf16 else 0])
                     ch0[c.group] += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
+                if c.window:                           # RGB stem: the channel-window pack next to the plain one (mode 2 of the same launch)
+                    if c._pw is None:
+                        c._pw = torch.zeros(c.co * c.kh * (c.kw + 1) * (c.ci + 1), dtype=torch.float32, device=self.device)
+                    rows.append([w.data_ptr(), c._pw.data_ptr(), c.co, c.ci, taps, 2, 0])
+                    ch0[c.group] += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
                 if not c.nmaj or bf16 or self.flip_dgrad:
                     if c._pd is None:
                         c._pd = torch.empty(w.numel(), dtype=torch.float32, device=self.device)
@@ -571,18 +590,38 @@ class PolicyEngine:
             self._gn_pinned.add(key)
         ops.gn_param_grads_multi(*ent)
 
+    def _stem_fwd(self, key, img_nchw, conv1, w0):
+        """RGB stem conv 7x7 / stride 2 / pad 3 (torchvision resnet18.conv1 behind vision_nets.py:29-39).  fp32 three-plane mode: the image
+        goes into a persistent zero-bordered [N, H + 6, W + 6, 4] buffer and the conv runs as a channel-window conv on the vector loader
+        (ops.conv2d_window: one aligned 128-B line per output pixel and filter row); the same buffer is the weight gradient's input.
+        Otherwise: [N, H, W, 3] and the scalar-gather kernel.  Returns (saved input, conv output)."""
+        N, C, H, W = img_nchw.shape
+        if (_STEM_WINDOW and conv1.window and C == 3 and H % 2 == 0 and W % 2 == 0 and ops.lib.v2a_get_precision() == 0
+                and ops.lib.v2a_get_f32_conv_mode() == 1):
+            bk = (key, N, H, W)
+            xp = self._stem_buf.get(bk)
+            if xp is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("stem input buffer missing during graph capture; run one eager step first")
+                xp = self._stem_buf[bk] = torch.zeros((N, H + 6, W + 6, 4), dtype=torch.float32, device=img_nchw.device)
+            self._stem_ver[key] = self._stem_ver.get(key, 0) + 1      # (a backward over an overwritten buffer is refused, see _encode_bwd)
+            ops.nchw_to_nhwc4p(img_nchw, xp, 3, normalize=True)
+            c1 = ops.conv2d_window(xp, conv1.pw(), w0, 7, 1, (2, 1), (H // 2, W // 2), xpitch=8, C=32)
+            return xp, c1
+        x0 = ops.nchw_to_nhwc(img_nchw, normalize=True)
+        return x0, ops.conv2d(x0, conv1.pf(), None, w0, 7, 7, (2, 2), (3, 3))
+
     def encode_fwd(self, key, img_nchw, save):
         """img [B,3,H,W] in [0,1] (float or uint8) -> feature [B, feature_dim].  save: list collecting backward state (or None)."""
         e = self.enc[key]
         cfg = self.cfg
         w0 = cfg.widths[0]
         ops.tstamp(f"enc_fwd[{key}] begin")
-        x0 = ops.nchw_to_nhwc(img_nchw, normalize=True)
-        c1 = ops.conv2d(x0, e["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3))
+        x0, c1 = self._stem_fwd(key, img_nchw, e["conv1"], w0)
         a1, s_gn1 = self._gn(c1, e["bb"] + ".1", w0 // 16, "relu")
         h, pidx = ops.maxpool_fwd(a1)
         ops.tstamp_fine(f"enc_fwd[{key}] stem done")
-        st = dict(x0=x0, gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
+        st = dict(x0=x0, x0_ver=self._stem_ver.get(key, 0), gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
         h_tw = None                                  # bf16 twin of the running activation (emitted by the GroupNorm launches)
         for blk in e["blocks"]:
             s, co = blk["stride"], blk["cout"]
@@ -692,7 +731,13 @@ class PolicyEngine:
         # the vector / LDS-DMA kernel and keep its first three input channels.
         x0 = st["x0"]
         c1 = e["conv1"]
-        if x0.shape[-1] == 3:
+        if x0.shape[-1] == 4:                        # zero-bordered 4-channel stem input (_stem_fwd): no padding, no copy
+            if st.get("x0_ver") != self._stem_ver.get(key):
+                raise RuntimeError("the stem input of this forward was overwritten by a later forward of the same encoder and batch shape")
+            dw4 = torch.empty((c1.co, 4, 7, 7), dtype=torch.float32, device=x0.device)
+            self._wg(x0, dc1, (c1.co, 4, 7, 7), 7, 7, (2, 2), (0, 0), dw=dw4, immediate=True)
+            ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
+        elif x0.shape[-1] == 3:
             N0, H0, W0, _ = x0.shape
             xp = self._stem_pad.get(key)
             if xp is None or xp.shape[:3] != x0.shape[:3]:
