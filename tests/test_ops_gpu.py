@@ -164,7 +164,9 @@ GN_CASES = [
     (4, 257, 384, 32, "silu", False, False),             # large path, ragged rows, L4 not dividing 256
     (8, 16, 256, 8, "mish", False, True),                # small path + FiLM (conv1d block)
     (8, 4, 1024, 8, "mish", False, False),
-    (6, 16, 512, 32, "relu", True, False),               # resnet layer4 small path + residual
+    (6, 16, 512, 32, "relu", True, False),               # resnet layer4 small path + residual (float4 wave kernel, one row per lane)
+    (5, 64, 256, 16, "relu", True, False),               # resnet layer3: float4 wave kernel, four rows per lane
+    (3, 64, 256, 16, "relu", False, False),
     (5, 64, 640, 32, "none", False, False),              # attention norm (per frame)
 ]
 

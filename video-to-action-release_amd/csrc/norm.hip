@@ -786,6 +786,153 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
     }
 }
 
+// ---- CG = 16 slabs of S = 16 * NJ rows as float4 (round 4): the deep ResNet stages (8 x 8 x 256 channels: NJ = 4, 4 x 4 x 512: NJ = 1).
+// gn_wave_*<16, .> above reads them with 16 scalar loads per tensor and lane (4-B pieces of four 64-B row segments per instruction) and
+// keeps eight 16-element arrays per lane: 41 us per backward launch for 25 MB of traffic.  Here lane l owns the 16-B chunk l & 3 of rows
+// (l >> 2) + 16 j: one b128 load per tensor and row (every instruction covers 16 whole 64-B segments), per-channel operands once per lane,
+// the per-channel sums (dgamma / dbeta contributions) by four xor shuffles over the lanes of a chunk.  FiLM-free launches only.
+template <int NJ>
+__device__ __forceinline__ void gn_w16_gather(const GnDesc& p, const float* dense, const size_t (&off)[NJ], int c0, f32x4 (&v)[NJ]) {
+    if (p.nslab <= 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const f32x4*>(dense + off[j]);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < p.nslab; s0 += 4) {          // slab order, four slabs in flight (as gn_wave_gather)
+        f32x4 u[4][NJ];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                u[q][j] = (s0 + q < p.nslab) ? *reinterpret_cast<const f32x4*>(p.slabs + (size_t)(s0 + q) * p.slab_stride + off[j])
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[j] += u[q][j];
+    }
+    if (p.cbias) {
+        const f32x4 cb = *reinterpret_cast<const f32x4*>(p.cbias + c0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] += cb;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (p.sresid) v[j] += *reinterpret_cast<const f32x4*>(p.sresid + off[j]);
+        if (p.sout) *reinterpret_cast<f32x4*>(p.sout + off[j]) = v[j];
+    }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(64) void gn_wave16_fwd(const GnDesc p) {
+    const int lane = threadIdx.x, wv = blockIdx.x;
+    const int n = wv / p.G, g = wv - n * p.G;
+    const int C = p.C, c0 = g * 16 + (lane & 3) * 4;
+    size_t off[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane >> 2) + 16 * j) * C + c0;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c0), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c0);
+    f32x4 rsd[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rsd[j] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + off[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 v[NJ];
+    gn_w16_gather<NJ>(p, p.x, off, c0, v);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float inv = 1.0f / (float)(p.S * 16);
+    const float mu = wave_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * inv + p.eps);
+    if (lane == 0) { p.mean[wv] = mu; p.rstd[wv] = rs; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float z = (v[j][e] - mu) * rs * gm[e] + bt[e];
+            if (p.residual) z += rsd[j][e];
+            o[e] = act_fwd(z, p.act);
+        }
+        *reinterpret_cast<f32x4*>(p.y + off[j]) = o;
+        if (p.yh) gn_store_twin4(p.yh, off[j] >> 2, o, p.yh_f16);
+    }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(64) void gn_wave16_bwd(const GnDesc p) {
+    const int lane = threadIdx.x, wv = blockIdx.x;
+    const int n = wv / p.G, g = wv - n * p.G;
+    const int C = p.C, c0 = g * 16 + (lane & 3) * 4;
+    size_t off[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane >> 2) + 16 * j) * C + c0;
+    const float mu = p.mean[wv], rs = p.rstd[wv];
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c0), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c0);
+    f32x4 xv[NJ], rsd[NJ], dz[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        xv[j] = *reinterpret_cast<const f32x4*>(p.x + off[j]);
+        rsd[j] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + off[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    gn_w16_gather<NJ>(p, p.dout, off, c0, dz);
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    float A1 = 0.f, A2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = (xv[j][e] - mu) * rs;
+            float z = h * gm[e] + bt[e];
+            if (p.residual) z += rsd[j][e];
+            const float d = dz[j][e] * act_bwd(z, p.act);
+            xv[j][e] = h;
+            dz[j][e] = d;
+            cs0[e] += d;
+            cs1[e] += d * h;
+            A1 += d * gm[e];
+            A2 += d * gm[e] * h;
+        }
+    A1 = wave_sum(A1);
+    A2 = wave_sum(A2);
+    const float inv = 1.0f / (float)(p.S * 16);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gm[e] * dz[j][e] - (A1 + xv[j][e] * A2) * inv);
+        *reinterpret_cast<f32x4*>(p.y + off[j]) = o;
+        if (p.yh) gn_store_twin4(p.yh, off[j] >> 2, o, p.yh_f16);
+        if (p.dres) *reinterpret_cast<f32x4*>(p.dres + off[j]) = dz[j];
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)                  // lanes with equal lane & 3 hold the same four channels
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cs0[e] += __shfl_xor(cs0[e], o, 64);
+            cs1[e] += __shfl_xor(cs1[e], o, 64);
+        }
+    if (lane < 4) {
+        *reinterpret_cast<f32x4*>(p.colsum + (size_t)n * 2 * C + c0) = cs0;
+        *reinterpret_cast<f32x4*>(p.colsum + (size_t)n * 2 * C + C + c0) = cs1;
+    }
+}
+static bool gn_wave16_ok(const GnDesc& p, int cg) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2A_GN_WAVE16"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || cg != 16 || p.film || p.dfilm || (p.S != 16 && p.S != 64) || (p.C & 3)) return false;
+    const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.residual | (uintptr_t)p.dout | (uintptr_t)p.dres | (uintptr_t)p.gamma |
+                        (uintptr_t)p.beta | (uintptr_t)p.gamma2 | (uintptr_t)p.beta2 | (uintptr_t)p.slabs | (uintptr_t)p.cbias |
+                        (uintptr_t)p.sresid | (uintptr_t)p.sout | (uintptr_t)p.colsum | (uintptr_t)p.yh;
+    return (a & 15) == 0 && (p.slab_stride & 3) == 0;
+}
+
 static bool gn_wave_ok(int S, int cg) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("V2A_GN_WAVE"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -953,6 +1100,12 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
     if (!x2 && gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;             // 8 values per lane (the ConditionalUnet1D slabs) or 16
+        if (gn_wave16_ok(p, cg)) {
+            if (S == 64) hipLaunchKernelGGL((gn_wave16_fwd<4>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gn_wave16_fwd<1>), grid, block, 0, stream, p);
+            V2A_CHECK_LAUNCH();
+            return V2A_OK;
+        }
 #define V2A_GNW_F(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_fwd<CGV, 8>), grid, block, 0, stream, p); \
                             else hipLaunchKernelGGL((gn_wave_fwd<CGV, 16>), grid, block, 0, stream, p); } while (0)
         if (cg == 16) V2A_GNW_F(16);
@@ -1068,6 +1221,10 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     if (gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;
+        if (gn_wave16_ok(p, cg)) {
+            if (S == 64) hipLaunchKernelGGL((gn_wave16_bwd<4>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gn_wave16_bwd<1>), grid, block, 0, stream, p);
+        } else
 #define V2A_GNW_B(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_bwd<CGV, 8>), grid, block, 0, stream, p); \
                             else hipLaunchKernelGGL((gn_wave_bwd<CGV, 16>), grid, block, 0, stream, p); } while (0)
         if (cg == 16) V2A_GNW_B(16);
