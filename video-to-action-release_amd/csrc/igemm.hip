@@ -2572,7 +2572,9 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     // few-channel inputs (the RGB stem padded to 4 channels: K = 196, a reduction over N * OH * OW = 262 144 rows) in the fp32
     // three-plane mode: the three-plane body as a one-problem launch of the grouped kernel, with the plan's split (the exact LDS-DMA
     // kernel it replaces: 173 us per encoder, at the tail of the step's weight-gradient branch)
-    if (g_precision == 0 && v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && veca && vecb && Cin <= 8 && !x2 && Cout % 4 == 0 &&
+    static int stem_x3 = -1;
+    if (stem_x3 < 0) { const char* e = getenv("V2A_STEM_WGRAD_X3"); stem_x3 = (e && e[0] == '0') ? 0 : 1; }      // (in-step A/B: 8.86 vs 8.90 ms with the exact LDS-DMA kernel)
+    if (stem_x3 && g_precision == 0 && v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && veca && vecb && Cin <= 8 && !x2 && Cout % 4 == 0 &&
         p.K % 4 == 0 && p.idil == 1 && !ups && (double)N * H * W * C1 < 1073741824.0) {
         WgradMultiArgs a;
         __builtin_memset(&a, 0, sizeof(a));
