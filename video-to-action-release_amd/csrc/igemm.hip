@@ -1528,6 +1528,188 @@ __device__ __forceinline__ void wgrad_x3_body(const WgradDesc& p, const int tile
     }
 }
 
+// ---- three-plane weight gradient with a spatial halo tile in LDS (round 4): the halo idea of wgrad_halo_body with the products of
+// wgrad_x3_body, for the 3x3 / stride 1 / pad 1 layers (13 of a ResNet-18 encoder's 20 convs, 85 % of its weight-gradient FLOPs).
+// wgrad_x3_body splits every gathered operand value once per filter tap and output tile -- (BM + BN) * 32 conversions per 6 * BM * BN * 32
+// MACs, the conversion VALU and the LDS writes bound it at 75 TFLOP/s.  Here a workgroup owns 64 output channels x 64 input channels x
+// all 9 taps: per reduction tile of 32 output pixels (a TH x TW patch) it loads the 32 dY rows and the (TH + 2) x (TW + 2) x 64-channel
+// input halo ONCE, splits them ONCE into hi / mid / lo planes ([pixel][plane][64 channels] bf16, 384 B per pixel, 16-B pieces
+// XOR-swizzled by 2 * (pixel & 3)), and the nine taps read shifted windows of the halo planes with `ds_read_b64_tr_b16` (the halo row
+// pitch is padded to a multiple of 4 pixels, so a tap shift moves every lane's swizzle class alike and ONE address per tap serves
+// the tile's four transposing reads through immediate offsets): 108 bf16 MFMAs per wave and tile against ~9 global loads, ~200
+// conversion VALU and 27 ds_write_b64 per thread.  One LDS stage, two workgroups per CU (the other workgroup multiplies while this one
+// converts); the next tile's global loads fly under the MFMAs.  fp32-equivalent accuracy as wgrad_x3_body (same six products,
+// smallest first).
+template <int TW>
+struct X3H {
+    static constexpr int TH = 32 / TW, HWD = TW + 2, HHT = TH + 2, HP = HWD * HHT;
+    static constexpr int HWDP = (HWD + 3) & ~3;                  // halo row pitch in pixels (multiple of 4)
+    static constexpr int NB = (HP + 15) / 16;                    // loader passes over the halo (16 pixels x 16 float4 per pass)
+    static constexpr int PIX = 384;                              // bytes per pixel: 3 planes x 64 bf16
+    static constexpr int ABYTES = 32 * PIX, HBYTES = HHT * HWDP * PIX, LDS = ABYTES + HBYTES;
+    static constexpr int HOFF = (TW >= 16 ? (TW == 16 ? HWDP : 16) : 2 * HWDP) * PIX;      // byte step of 16 output pixels inside the halo image
+};
+template <int TW>
+__device__ __forceinline__ void wgrad_x3h_body(const WgradDesc& p, const int tile_id, const int split, unsigned char* smem) {
+    typedef X3H<TW> G;
+    constexpr int TH = G::TH, HWD = G::HWD, HP = G::HP, HWDP = G::HWDP, NB = G::NB, PIX = G::PIX;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Cin = p.C1;
+    const int cin_blocks = Cin >> 6;
+    const int m0 = (tile_id / cin_blocks) * 64, c0 = (tile_id % cin_blocks) * 64;
+    const int nrt = p.M >> 5;
+    const int rt_begin = split * p.rtiles_per_split;
+    const int rt_end = min(nrt, rt_begin + p.rtiles_per_split);
+    const int tiles_x = p.OW / TW, tiles_img = (p.OH / TH) * tiles_x;
+    const float* zline = g_zero_line;
+    const int c4 = tid & 15, prow = tid >> 4;                   // float4 within a 64-float row; row / pixel within a loader pass
+    unsigned char* As = smem;
+    unsigned char* Hs = smem + G::ABYTES;
+
+    // loader: 2 float4 of dY (rows prow, prow + 16) and NB float4 of the halo (pixels 16 q + prow) per thread and tile
+    int h_slot[NB];                                              // LDS pixel slot of the thread's halo pixels (-1: past the halo)
+    int h_dy[NB], h_dx[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int hp = q * 16 + prow;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        h_slot[q] = hp < HP ? hy * HWDP + hx : -1;
+        h_dy[q] = hy - 1;
+        h_dx[q] = hx - 1;
+    }
+    auto load = [&](int rt, f32x4 (&ra)[2], f32x4 (&rh)[NB]) {
+        const size_t r0 = (size_t)rt * 32;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            ra[j] = *(const gf32x4w_t*)(uint64_t)(p.dy + (r0 + prow + j * 16) * p.Cout + m0 + c4 * 4);
+        const int img = rt / tiles_img, t = rt - img * tiles_img;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int ih0 = ty * TH, iw0 = tx * TW;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int ih = ih0 + h_dy[q], iw = iw0 + h_dx[q];
+            const bool ok = h_slot[q] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const float* g = ok ? p.x + ((size_t)(img * p.H + ih) * p.W + iw) * Cin + c0 + c4 * 4 : zline;
+            rh[q] = *(const gf32x4w_t*)(uint64_t)g;
+        }
+    };
+    // LDS position of the thread's 8-B piece (4 bf16 of one plane) of pixel / row `ps`: + 128 per plane
+    auto piece = [&](int ps) { return ps * PIX + ((((c4 >> 1) ^ ((ps & 3) << 1)) << 4) | ((c4 & 1) << 3)); };
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    auto split_store = [&](const f32x4 (&ra)[2], const f32x4 (&rh)[NB]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            bsum += ra[j];
+            split3_pair(ra[j][0], ra[j][1], h0, m0_, l0);
+            split3_pair(ra[j][2], ra[j][3], h1, m1, l1);
+            unsigned char* d = As + piece(prow + j * 16);
+            *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(d + 128) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(d + 256) = uint2{l0, l1};
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            if (h_slot[q] < 0) continue;
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair(rh[q][0], rh[q][1], h0, m0_, l0);
+            split3_pair(rh[q][2], rh[q][3], h1, m1, l1);
+            unsigned char* d = Hs + piece(h_slot[q]);
+            *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(d + 128) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(d + 256) = uint2{l0, l1};
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int wm = (wid >> 1) * 32, wn = (wid & 1) * 32;
+    const int lr = lane & 31, lk = lane >> 5;
+    // transposing-read source of this lane (see wgrad_tr_body): 16-lane group grp, segment seg; the lane addresses reduction row
+    // 8 (grp >> 1) + (seg >> 2) (+ 4: second half, + 16: second k step) and the 4 columns 16 (grp & 1) + 4 (seg & 3) .. + 3
+    const int grp = lane >> 4, seg = lane & 15;
+    const int trow = 8 * (grp >> 1) + (seg >> 2);
+    const int tcol = 16 * (grp & 1) + 4 * (seg & 3);
+    const int acol = wm + tcol, bcol = wn + tcol;
+    const int a_addr = trow * PIX + ((((acol >> 3) ^ ((trow & 3) << 1)) << 4) + ((acol & 7) << 1));
+    // halo pixel (tap 0, 0) of reduction row trow: patch row trow / TW, patch column trow % TW
+    const int bpix0 = (trow / TW) * HWDP + (trow % TW);
+    const int bcch = bcol >> 3, bsub = (bcol & 7) << 1;
+    auto tr8 = [&](const unsigned char* q) -> bf16x8 {            // rows r .. r + 3 and r + 4 .. r + 7 of the lane's column
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lbf16x4_t*)(q));
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lbf16x4_t*)(q + 4 * PIX));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[q] = tr8(As + a_addr + h * 16 * PIX + q * 128);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int pix = bpix0 + kh * HWDP + kw;
+                    const unsigned char* bq = Hs + pix * PIX + (((bcch ^ ((pix & 3) << 1)) << 4) + bsub) + h * G::HOFF;
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[q] = tr8(bq + q * 128);
+                    f32x16 c = acc[kh * 3 + kw];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);     // lo  * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);     // hi  * lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);     // mid * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);     // mid * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);     // hi  * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);     // hi  * hi
+                    acc[kh * 3 + kw] = c;
+                }
+        }
+    };
+
+    f32x4 ra[2], rh[NB];
+    if (rt_begin < rt_end) {
+        load(rt_begin, ra, rh);
+        split_store(ra, rh);
+    }
+    __syncthreads();
+    for (int rt = rt_begin; rt < rt_end; ++rt) {
+        const bool more = rt + 1 < rt_end;
+        if (more) load(rt + 1, ra, rh);                        // in flight under the MFMAs of tile rt
+        compute();
+        __syncthreads();                                        // every wave is done reading tile rt
+        if (more) split_store(ra, rh);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int k = t * Cin + c0 + wn + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (p.splits > 1) p.partial[((size_t)split * p.Cout + co) * p.K + k] = acc[t][r];
+            else wgrad_store(p, co, k, acc[t][r]);
+        }
+    }
+    if ((p.dbias != nullptr) && c0 == 0) {                      // (past the loop's last barrier: the stage is free)
+        float* red = reinterpret_cast<float*>(smem);            // [16][64] floats
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[prow * 64 + c4 * 4 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * 64 + tid];
+            const int co = m0 + tid;
+            if (p.splits > 1) p.partial[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + co] = t;
+            else p.dbias[co] = p.accumulate ? p.dbias[co] + t : t;
+        }
+    }
+}
+
 // bf16-MFMA weight gradient fed from bf16 TWINS of the operands (x_h / dy_h: the rounded copies the bf16 forward / data-gradient convs
 // already made), instead of converting fp32 while staging: the kernel above is bound by operand traffic through the L2 fabric (32 KB
 // per workgroup per 256 MFMA cycles), so half the bytes is the lever.  Loader thread = 4 reduction rows x 8 channels (one 16-B load per
@@ -1938,6 +2120,22 @@ __global__ __launch_bounds__(BT == 64 ? 256 : 512, BT == 64 ? 2 : 1) void conv_w
         if (gen) wgrad_x3_body<128, 128, 2, 4, true>(a.d[i], tile, split, smem);
         else wgrad_x3_body<128, 128, 2, 4, false>(a.d[i], tile, split, smem);
     }
+}
+
+// The same for the three-plane halo body (3x3 / stride 1 / pad 1 layers): variant 8 / 9 / 10 = patch width 32 / 16 / 8.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_multi_x3h_kernel(const WgradMultiArgs a) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[X3H<32>::LDS];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < a.n && bid >= a.wg_end[i]) ++i;
+    const int first = i ? a.wg_end[i - 1] : 0;
+    const int nwg = a.wg_end[i] - first, tiles = a.tiles[i];
+    const int lin = nwg >= 8 ? xcd_remap(bid - first, nwg) : bid - first;
+    const int split = lin / tiles, tile = lin - split * tiles;
+    const int v = a.variant[i];
+    if (v == 8) wgrad_x3h_body<32>(a.d[i], tile, split, smem);
+    else if (v == 9) wgrad_x3h_body<16>(a.d[i], tile, split, smem);
+    else wgrad_x3h_body<8>(a.d[i], tile, split, smem);
 }
 
 __device__ __forceinline__ void wgrad_reduce_body(const WgradDesc& p, const unsigned bid, const unsigned nblk) {
@@ -2710,8 +2908,9 @@ int v2a_wgrad_reduce_multi(const void* items_dev, const void* work_dev, int nwor
 // `slabs` (the layer's own scratch, >= (splits * Cout * K + splits * Cout) * 4 bytes when splits > 1) is entered, item_out (HOST,
 // v2a_wgrad_item_bytes()) receives the main-kernel descriptor, *splits_out the split actually used (capped so that every slice keeps
 // work), and ritem_out / *rblocks_out / *rform_out the reduce item for v2a_wgrad_reduce_multi (rblocks 0: nothing to reduce).
-// kernel family of a grouped-launch variant: 0 = 64x64 exact / twin-fed bodies (0-2), 1 = halo body (3-5), 2 / 3 = three-plane bodies (6 / 7)
-static int wgrad_family(int v) { return v <= 2 ? 0 : (v <= 5 ? 1 : (v == 6 ? 2 : 3)); }
+// kernel family of a grouped-launch variant: 0 = 64x64 exact / twin-fed bodies (0-2), 1 = halo body (3-5), 2 / 3 = three-plane bodies (6 / 7),
+// 4 = three-plane halo body (8-10)
+static int wgrad_family(int v) { return v <= 2 ? 0 : (v <= 5 ? 1 : (v == 6 ? 2 : (v == 7 ? 3 : 4))); }
 int v2a_wgrad_family(int variant) { return wgrad_family(variant); }
 int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, const void* x_h, const void* x2_h, const void* dy_h, float* dw,
                               float* dbias, int N, int H, int W, int C1, int C2, int OH, int OW, int Cout, int KH, int KW, int sh, int sw, int ph,
@@ -2747,8 +2946,15 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
             OW == W && C1 % 64 == 0 && Cout % 64 == 0 && p.M % 32 == 0 && (OW == 8 || OW == 16 || OW % 32 == 0) &&
             OH % (OW >= 32 ? 1 : 32 / OW) == 0 && big < 2147483648.0)
             variant = OW == 8 ? 5 : (OW == 16 ? 4 : 3);
-        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && p.idil <= 2 && big < 1073741824.0)         // fp32 products from three bf16 planes (V2A_WGRAD_X3=1; default: the exact bodies)
-            variant = Cout >= 128 ? 7 : 6;
+        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && p.idil <= 2 && big < 1073741824.0) {       // fp32 products from three bf16 planes (V2A_WGRAD_X3=0: the exact bodies)
+            static int x3h = -1;                      // V2A_WGRAD_X3H=0: 3x3 layers on the plain three-plane body too (A/B)
+            if (x3h < 0) { const char* e = getenv("V2A_WGRAD_X3H"); x3h = (e && e[0] == '0') ? 0 : 1; }
+            const bool halo_geo = variant >= 3;       // (the exact halo body's geometry test above: 3x3 / stride 1 / pad 1, whole 32-pixel patches)
+            static int x3h_min_ow = -1;               // V2A_WGRAD_X3H_MIN_OW: narrower maps stay on the plain body (A/B)
+            if (x3h_min_ow < 0) { const char* e = getenv("V2A_WGRAD_X3H_MIN_OW"); x3h_min_ow = e ? atoi(e) : 8; }
+            if (x3h && halo_geo && OW >= x3h_min_ow) variant = OW == 8 ? 10 : (OW == 16 ? 9 : 8);
+            else variant = Cout >= 128 ? 7 : 6;
+        }
     }
     *variant_out = variant;
     if (variant < 0) { *tiles_out = 0; *rtiles_out = 0; return V2A_OK; }
@@ -2756,7 +2962,8 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
     const int tiles = variant == 0 ? cdiv(Cout, 64) * cdiv(p.K, 64)
                       : variant == 6 ? cdiv(Cout, 64) * cdiv(p.K, 128)
                       : variant == 7 ? cdiv(Cout, 128) * cdiv(p.K, 128)
-                      : (variant >= 3 ? (Cout / 64) * (C1 / 64) : cdiv(Cout, variant == 1 ? 128 : 64) * cdiv(p.K, 128));
+                      : (variant >= 8 ? (Cout / 64) * (C1 / 64)
+                      : (variant >= 3 ? (Cout / 64) * (C1 / 64) : cdiv(Cout, variant == 1 ? 128 : 64) * cdiv(p.K, 128)));
     const int nrt = cdiv(p.M, rrows);
     *tiles_out = tiles;
     *rtiles_out = nrt;
@@ -2795,7 +3002,7 @@ int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* ti
     int tot = 0;
     for (int i = 0; i < n; ++i) {
         a.d[i] = reinterpret_cast<const WgradDesc*>(items)[i];
-        if (variants[i] < 0 || variants[i] > 7 || tiles[i] < 1 || a.d[i].splits < 1) return V2A_ERR_ARG;
+        if (variants[i] < 0 || variants[i] > 10 || tiles[i] < 1 || a.d[i].splits < 1) return V2A_ERR_ARG;
         if (wgrad_family(variants[i]) != wgrad_family(variants[0])) return V2A_ERR_ARG;      // one kernel family per launch
         a.variant[i] = variants[i];
         a.tiles[i] = tiles[i];
@@ -2804,7 +3011,8 @@ int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* ti
     }
     for (int i = n; i < WGM_MAX; ++i) a.wg_end[i] = tot;
     const int fam = wgrad_family(variants[0]);
-    if (fam == 3) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<128>, dim3(tot), dim3(512), 0, stream, a);
+    if (fam == 4) hipLaunchKernelGGL(conv_wgrad_multi_x3h_kernel, dim3(tot), dim3(256), 0, stream, a);
+    else if (fam == 3) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<128>, dim3(tot), dim3(512), 0, stream, a);
     else if (fam == 2) hipLaunchKernelGGL(conv_wgrad_multi_x3_kernel<64>, dim3(tot), dim3(256), 0, stream, a);
     else if (fam == 1) hipLaunchKernelGGL(conv_wgrad_multi_halo_kernel, dim3(tot), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3(tot), dim3(256), 0, stream, a);

@@ -364,7 +364,8 @@ class WgradBatch:
     MIN_DEPTH = int(os.environ.get("V2A_WGRAD_MULTI_DEPTH", "4"))
     TARGET_WG_HALO = int(os.environ.get("V2A_WGRAD_MULTI_WG_HALO", "512"))
     TARGET_WG_X3 = (int(os.environ.get("V2A_WGRAD_MULTI_WG_X3_64", "1024")), int(os.environ.get("V2A_WGRAD_MULTI_WG_X3_128", "512")))
-    WEIGHT = {0: 1.0, 1: 2.0, 2: 1.5, 3: 1.0, 4: 1.0, 5: 1.0, 6: 1.0, 7: 1.0}   # relative cost of one (output tile, reduction tile) step per kernel body
+    TARGET_WG_X3H = int(os.environ.get("V2A_WGRAD_MULTI_WG_X3H", "512"))
+    WEIGHT = {0: 1.0, 1: 2.0, 2: 1.5, 3: 1.0, 4: 1.0, 5: 1.0, 6: 1.0, 7: 1.0, 8: 1.0, 9: 1.0, 10: 1.0}   # relative cost of one (output tile, reduction tile) step per kernel body
 
     def __init__(self, collector):
         self.col = collector
@@ -409,7 +410,9 @@ class WgradBatch:
             return
         # kernel families (csrc/igemm.hip): the 64x64 / twin-fed bodies (variants 0-2), the halo-tile body (3-5), the three-bf16-plane
         # bodies (6: 64 x 64 tiles, 7: 128 x 128 tiles)
-        for fam, target in ((0, self.TARGET_WG), (1, self.TARGET_WG_HALO), (2, self.TARGET_WG_X3[0]), (3, self.TARGET_WG_X3[1])):
+        # (8-10: the three-plane halo body)
+        for fam, target in ((0, self.TARGET_WG), (1, self.TARGET_WG_HALO), (2, self.TARGET_WG_X3[0]), (3, self.TARGET_WG_X3[1]),
+                            (4, self.TARGET_WG_X3H)):
             calls = [c for c in allc if lib.v2a_wgrad_family(c["variant"]) == fam]
             if calls:
                 self._launch_family(calls, target)
