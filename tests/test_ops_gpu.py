@@ -1072,3 +1072,31 @@ def test_stem_channel_window_conv_and_weight_gradient_vs_torch(N, H, W, u8):
     F.conv2d(xn.double(), wd, stride=2, padding=3).backward(dy.permute(0, 3, 1, 2).double())
     close(dw4[:, :3], wd.grad.float(), 1e-4, "stem weight gradient")
     assert float(dw4[:, 3].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,HW,Ci,Co,res", [(8, 32, 64, 64, False), (3, 32, 96, 128, True), (8, 16, 128, 128, True), (6, 8, 256, 256, False),
+                                             (16, 4, 512, 512, True), (40, 4, 64, 192, False), (2, 8, 32, 64, True)])
+def test_three_plane_halo_conv_vs_fp64(N, HW, Ci, Co, res):
+    """conv_halo_x3 (3x3 / stride 1 / pad 1 over square 32 / 16 / 8 / 4 maps, 128 output pixels x 64 channels per workgroup, halo split
+    once per 32-channel chunk): tiles of four map rows, eight map rows, two whole maps and eight whole maps; odd chunk counts; the fp32
+    residual of the data-gradient launches; split-K slabs.  Against fp64 torch, bound = the fp32 budget of the path (1e-4 of max |y|,
+    measured ~3e-7)."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    assert (N * HW * HW) % 128 == 0
+    g = torch.Generator().manual_seed(N * HW + Ci)
+    x = torch.randn(N, Ci, HW, HW, generator=g) * torch.rand(N, Ci, HW, HW, generator=g).mul(4).exp2()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    r = torch.randn(N, Co, HW, HW, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    wp = ops.pack_weight(w.to(dev()), 0)
+    y = ops.conv2d(nhwc(x), wp, None, Co, 3, 3, (1, 1), (1, 1), residual=nhwc(r) if res else None)
+    assert ops.last_kernel[0] is not None
+    close(nchw(y), ref.float(), 1e-4, "halo conv")
+    err = (nchw(y).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 5e-6, err

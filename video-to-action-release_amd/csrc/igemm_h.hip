@@ -977,6 +977,230 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, bias_sel);
 }
 
+// ---- three-plane 3x3 / stride 1 / pad 1 conv with a spatial halo tile in LDS (round 4): the forward / data-gradient counterpart of
+// csrc/igemm.hip wgrad_x3h_body, for the square maps of the policy's ResNet-18 encoders (32 x 32, 16 x 16, 8 x 8, 4 x 4).
+// conv_igemm_f32x3 gathers and splits the A tile once per filter tap and column tile: nine loads and nine fp32 -> plane conversions of
+// what is, up to a one-pixel shift, the same patch (its launches are bound by that traffic through the vector L1 and by the conversion
+// VALU, profiles/r04_x3_ablation.txt).  Here a workgroup owns 128 consecutive output pixels (whole map rows: 4 x 32, 8 x 16, two 8 x 8
+// maps, eight 4 x 4 maps) x 64 output channels and walks the reduction as (32-channel chunk) x (tap): per chunk the zero-padded halo of
+// its pixels is loaded and split ONCE into three bf16 plane images ([plane][slot][32 channels], 64-B rows, 16-B pieces XOR-swizzled by
+// (slot >> 2) & 3 as in conv_igemm_f32x3), the nine taps read shifted slot windows of it; per (chunk, tap) only the 64 x 32 weight tile
+// moves (registers -> split -> one of two LDS stages).  Conversions per MAC: 1/9 of the A side's; A bytes through L1: 1/9.
+// One halo buffer + two weight stages = 59 ... 80 KB: two workgroups per CU.  Epilogue, split-K slabs (over channel chunks) and their
+// consumers as conv_igemm_f32x3.  fp32-equivalent accuracy (the same six plane products per block, smallest first).
+template <int OWC>
+struct HX3 {
+    static constexpr int BM = 128, BN = 64, CK = 32;
+    static constexpr int PIXI = OWC * OWC;                            // pixels per (square) map
+    static constexpr int SP = PIXI >= BM ? 1 : BM / PIXI;             // maps per tile
+    static constexpr int PH = PIXI >= BM ? BM / OWC : OWC;            // map rows per tile and map
+    static constexpr int HWD = OWC + 2, HS = (PH + 2) * HWD, NS = SP * HS;   // halo row pitch, slots per map, slots per tile
+    static constexpr int NHP = (NS * 8 + 255) / 256;                  // halo loader passes (32 slots x 8 float4 per pass of 256 threads)
+    static constexpr int PHB = NS * 64;                               // bytes of one plane of the halo image
+    static constexpr int PB = BN * 64;                                // bytes of one plane of a weight tile
+    static constexpr int LDS = 3 * PHB + 2 * 3 * PB;
+};
+template <int OWC>
+__global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
+    typedef HX3<OWC> G;
+    constexpr int BM = G::BM, BN = G::BN, NHP = G::NHP, PHB = G::PHB, PB = G::PB, HWD = G::HWD, HS = G::HS, NS = G::NS;
+    constexpr int S = 1, STAGE = G::LDS;                        // (names of the shared epilogue's size check)
+    __shared__ __attribute__((aligned(128))) unsigned char smem[G::LDS];
+    unsigned char* Hs = smem;
+    unsigned char* Bs = smem + 3 * PHB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = p.Cout / BN, tiles_m = p.M / BM;
+    const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+    const int tm = lin / tiles_n;
+    const int n0 = (lin - tm * tiles_n) * BN, m0 = tm * BM;
+    const int split = blockIdx.y;
+    const int Cin = p.C1;
+    const int nchunks = Cin >> 5;
+    const int ck_begin = split * p.ktiles_per_split;
+    const int ck_end = min(nchunks, ck_begin + p.ktiles_per_split);
+    const int img0 = m0 / G::PIXI, row0 = (m0 % G::PIXI) / OWC;  // first map / first map row of the tile (row0 = 0 when a tile holds whole maps)
+    const float* xs = reinterpret_cast<const float*>(p.x);
+    const float* zsrc = reinterpret_cast<const float*>(p.zeros);
+    const int lrow = tid >> 3, c4 = tid & 7;
+
+    // halo loader: pass q of the 256 threads covers slots 32 q .. 32 q + 31 (thread: slot 32 q + lrow, float4 c4 of its 32 channels)
+    int h_src[NHP], h_dst[NHP];
+#pragma unroll
+    for (int q = 0; q < NHP; ++q) {
+        const int slot = q * 32 + lrow;
+        const int sp = slot / HS, rem = slot - sp * HS;
+        const int hy = rem / HWD, hx = rem - hy * HWD;
+        const int ih = row0 + hy - 1, iw = hx - 1;
+        const bool valid = slot < NS;
+        const bool ok = valid && (unsigned)ih < (unsigned)OWC && (unsigned)iw < (unsigned)OWC;
+        h_src[q] = ok ? (((img0 + sp) * OWC + ih) * OWC + iw) * Cin + c4 * 4 : -1;
+        h_dst[q] = valid ? slot * 64 + ((((c4 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c4 & 1) << 3)) : -1;
+    }
+    // (no branches around the loads, here and below: past the slice's end they read the zero line -- a conditional load makes the
+    // compiler's wait-count bookkeeping fall back to vmcnt(0) at the top of every step, which serialises the whole prefetch)
+    auto loadH = [&](int ck, bool live, f32x4 (&rh)[NHP]) {
+#pragma unroll
+        for (int q = 0; q < NHP; ++q) {
+            uint32_t off = (uint32_t)(h_src[q] + ck * 32);
+            asm volatile("" : "+v"(off));
+            const float* g = xs + off;
+            g = (live & (h_src[q] >= 0)) ? g : zsrc;
+            rh[q] = *(const gf32x4_t*)(uint64_t)g;
+        }
+    };
+    auto storeH = [&](const f32x4 (&rh)[NHP]) {
+#pragma unroll
+        for (int q = 0; q < NHP; ++q) {
+            if (h_dst[q] < 0) continue;
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair_h(rh[q][0], rh[q][1], h0, m0_, l0);
+            split3_pair_h(rh[q][2], rh[q][3], h1, m1, l1);
+            unsigned char* d = Hs + h_dst[q];
+            *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(d + PHB) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(d + 2 * PHB) = uint2{l0, l1};
+        }
+    };
+    // weight tile of (chunk, tap): rows n0 + lrow, n0 + lrow + 32 of the [Cout][tap][Cin] pack
+    const float* b_src[2];
+    int w_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 32 + lrow;
+        b_src[j] = reinterpret_cast<const float*>(p.w) + (size_t)(n0 + r) * p.K + c4 * 4;
+        w_off[j] = r * 64 + ((((c4 >> 1) ^ ((r >> 2) & 3)) << 4) | ((c4 & 1) << 3));
+    }
+    auto loadB = [&](int off, bool live, f32x4 (&rb)[2]) {      // off = tap * Cin + chunk * 32
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint64_t gi = (uint64_t)(b_src[j] + off);
+            asm volatile("" : "+v"(gi));
+            gi = live ? gi : (uint64_t)zsrc;
+            rb[j] = *reinterpret_cast<const gf32x4_t*>(gi);
+        }
+    };
+    auto storeB = [&](const f32x4 (&rb)[2], int stage) {
+        unsigned char* bb = Bs + stage * 3 * PB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            split3_pair_h(rb[j][0], rb[j][1], h0, m0_, l0);
+            split3_pair_h(rb[j][2], rb[j][3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(bb + w_off[j]) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(bb + PB + w_off[j]) = uint2{m0_, m1};
+            *reinterpret_cast<uint2*>(bb + 2 * PB + w_off[j]) = uint2{l0, l1};
+        }
+    };
+
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int wm = (wid >> 1) * 64, wn = (wid & 1) * 32;
+    const int lr = lane & 31, lk = lane >> 5;
+    int slot0[2];                                               // halo slot of tap (0, 0) of the lane's two output pixels
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pl = wm + i * 32 + lr;
+        const int sp = pl / (G::PH * OWC), q = pl - sp * (G::PH * OWC);
+        const int py = q / OWC, px = q - py * OWC;
+        slot0[i] = sp * HS + py * HWD + px;
+    }
+    const int b_off = (wn + lr) * 64, brs = (lr >> 2) & 3;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+    auto compute = [&](int stage, int toff) {
+        const unsigned char* bb = Bs + stage * 3 * PB;
+        int ab[2], as[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = slot0[i] + toff;
+            ab[i] = sl * 64;
+            as[i] = (sl >> 2) & 3;
+        }
+        // every operand fragment of the step is requested before its first MFMA (the fence keeps the compiler from sinking the
+        // reads back between the MFMAs, where each one waited out a full LDS round trip)
+        bfx8 a[2][3][2], b[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kp = (h << 1) | lk;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[h][q][i] = *reinterpret_cast<const bfx8*>(Hs + q * PHB + ab[i] + ((kp ^ as[i]) << 4));
+                b[h][q] = *reinterpret_cast<const bfx8*>(bb + q * PB + b_off + ((kp ^ brs) << 4));
+            }
+        }
+        asm volatile("" ::: "memory");
+        f32x16 c0 = acc[0][0], c1 = acc[1][0];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // the two accumulators' chains interleaved (a dependent MFMA waits 16 passes for its predecessor)
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][2][0], b[h][0], c0, 0, 0, 0);     // lo  * hi
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][2][1], b[h][0], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][0][0], b[h][2], c0, 0, 0, 0);     // hi  * lo
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][0][1], b[h][2], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][1][0], b[h][1], c0, 0, 0, 0);     // mid * mid
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][1][1], b[h][1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][1][0], b[h][0], c0, 0, 0, 0);     // mid * hi
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][1][1], b[h][0], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][0][0], b[h][1], c0, 0, 0, 0);     // hi  * mid
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][0][1], b[h][1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][0][0], b[h][0], c0, 0, 0, 0);     // hi  * hi
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[h][0][1], b[h][0], c1, 0, 0, 0);
+        }
+        acc[0][0] = c0;
+        acc[1][0] = c1;
+    };
+
+    // weight tiles travel three steps ahead in three register sets with fixed roles (9 taps per chunk = 0 mod 3: the tile of tap t
+    // always sits in set t % 3): tile u is requested at the start of step u - 3, split and stored into the free LDS stage during
+    // step u - 1, multiplied at step u -- the request has two and a half steps of MFMAs to land
+    f32x4 rh[NHP], rb0[2], rb1[2], rb2[2];
+    const int nsteps = (ck_end - ck_begin) * 9;
+    // running (chunk, tap) of the tile three steps ahead
+    int l_ck = ck_begin, l_tap = 0, l_step = 0;
+    auto loadB_next = [&](f32x4 (&rb)[2]) {
+        loadB(l_tap * Cin + l_ck * 32, l_step < nsteps, rb);
+        ++l_step;
+        const bool wrap = l_tap == 8;
+        l_tap = wrap ? 0 : l_tap + 1;
+        l_ck += wrap ? 1 : 0;
+    };
+    loadH(ck_begin, true, rh);
+    loadB_next(rb0);
+    loadB_next(rb1);
+    loadB_next(rb2);
+    storeH(rh);
+    storeB(rb0, 0);
+    __syncthreads();
+    int stage = 0;
+    for (int ck = ck_begin; ck < ck_end; ++ck) {
+        const bool more = ck + 1 < ck_end;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // set tap % 3 was stored during the previous step: request the tile three steps ahead into it
+            if (tap % 3 == 0) loadB_next(rb0);
+            else if (tap % 3 == 1) loadB_next(rb1);
+            else loadB_next(rb2);
+            if (tap == 4) loadH(ck + 1, more, rh);              // the next chunk's halo flies under taps 4 .. 8
+            compute(stage, (tap / 3) * HWD + (tap % 3));
+            // tile step + 1 -> the other stage (its readers passed the previous barrier; past the end: a zero tile nobody reads)
+            if ((tap + 1) % 3 == 0) storeB(rb0, stage ^ 1);
+            else if ((tap + 1) % 3 == 1) storeB(rb1, stage ^ 1);
+            else storeB(rb2, stage ^ 1);
+            if (tap == 8) {
+                __syncthreads();                                // every wave is done with this chunk's halo
+                storeH(rh);
+            }
+            __syncthreads();
+            stage ^= 1;
+        }
+    }
+    static_assert(4 * 32 * 32 * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
+    conv_f32_epilogue<BM, BN, 2, 2>(p, acc, smem, m0, n0, split, p.bias);
+}
+
 template <typename T>
 __global__ void conv_splitk_reduce_h(const ConvDescH p) {
     constexpr bool HALF = sizeof(T) == 2;
@@ -1089,6 +1313,25 @@ static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* 
     *s = sp;
 }
 
+// split (over 32-channel chunks) of the three-plane halo conv: about 512 workgroups, at most 8 slabs
+static int conv_halo_x3_split(int M, int Cout, int Cin) {
+    const int tiles = (M / 128) * (Cout / 64), nchunks = Cin / 32;
+    int s = 1;
+    if (tiles < 448) {
+        s = 512 / (tiles < 1 ? 1 : tiles);
+        if (s > 8) s = 8;
+        if (s > nchunks) s = nchunks;
+        if (s < 1) s = 1;
+    }
+    const int cps = cdiv(nchunks, s);
+    return cdiv(nchunks, cps);
+}
+static int g_conv_x3h = -1;       // V2A_CONV_X3H=0: 3x3 / stride-1 layers stay on conv_igemm_f32x3 (A/B)
+static bool conv_x3h_on() {
+    if (g_conv_x3h < 0) { const char* e = getenv("V2A_CONV_X3H"); g_conv_x3h = (e && e[0] == '0') ? 0 : 1; }
+    return g_conv_x3h == 1;
+}
+
 extern "C" {
 
 size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
@@ -1111,6 +1354,10 @@ int v2a_conv2d_dma_f32_can_emit_stats(int M, int Cout, int K) {
 size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K) {
     int bm, bn, tiles, s;
     conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);
+    if (K % 9 == 0 && (K / 9) % 32 == 0 && M % 128 == 0 && Cout % 64 == 0) {      // the halo kernel may take it (geometry permitting)
+        const int sh = conv_halo_x3_split(M, Cout, K / 9);
+        if (sh > s) s = sh;
+    }
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
 
@@ -1194,6 +1441,22 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         }
         const int f32p = g_f32p, s128 = g_f32p_s128, s64 = g_f32p_s64;
         f32_conv_mode_init();
+        if (g_f32x3 && conv_x3h_on() && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && idil == 1 &&
+            !x2 && C2 == 0 && H == W && OH == H && OW == W && (W == 4 || W == 8 || W == 16 || W == 32) && p.M % 128 == 0 && Cout % 64 == 0 &&
+            !stats && !p.w2 && (double)N * H * W * C1 < 2147483648.0) {
+            // 3x3 / stride 1 / pad 1 over the encoders' square maps: the halo kernel (its own split, over 32-channel chunks)
+            s = conv_halo_x3_split(p.M, Cout, C1);
+            if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+            p.splitk = s;
+            p.ktiles_per_split = cdiv(C1 / 32, s);
+            p.frame_tiles = 0;
+            const dim3 grid((p.M / 128) * (Cout / 64), s);
+            if (W == 32) hipLaunchKernelGGL(conv_halo_x3<32>, grid, dim3(256), 0, stream, p);
+            else if (W == 16) hipLaunchKernelGGL(conv_halo_x3<16>, grid, dim3(256), 0, stream, p);
+            else if (W == 8) hipLaunchKernelGGL(conv_halo_x3<8>, grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(conv_halo_x3<4>, grid, dim3(256), 0, stream, p);
+            goto launched;
+        }
         if (g_f32x3) {
             // tiles: 64 x 64 (small problems, the plan's split), 128 x 64 / 256 x 64 for 64-wide layers, 128 x 128 on 8 waves otherwise --
             // the wider the tile, the fewer fp32 -> plane conversions and LDS bytes per MFMA
