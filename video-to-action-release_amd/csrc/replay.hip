@@ -32,6 +32,42 @@ __global__ void replay_gather_kernel(const T* __restrict__ frames, const float* 
             out_acts[(size_t)b * act_len * act_dim + i] = acts[(size_t)f0 * act_dim + i];
 }
 
+// uint8 HWC store -> CHW fp32 batch, four pixels per thread: 12 contiguous bytes in (three dwords), one 16-B store per colour plane out
+// (a wave writes 1 KB runs; the element-per-thread kernel above writes 84-B runs and reads single bytes: 113 us per B = 64 batch).
+__global__ __launch_bounds__(256) void replay_gather_u8_chw4_kernel(const uint8_t* __restrict__ frames, const float* __restrict__ acts,
+                                                                   const int64_t* __restrict__ frame_start, float* __restrict__ out_start,
+                                                                   float* __restrict__ out_goal, float* __restrict__ out_acts, int frame_elems,
+                                                                   int act_len, int act_dim, int normalize, int HW) {
+    const int b = blockIdx.y;
+    const int64_t f0 = frame_start[b];
+    const uint8_t* src[2] = {frames + (size_t)f0 * frame_elems, frames + (size_t)(f0 + act_len) * frame_elems};
+    float* dst[2] = {out_start + (size_t)b * frame_elems, out_goal + (size_t)b * frame_elems};
+    const int q = blockIdx.x * 256 + threadIdx.x;               // pixels 4 q .. 4 q + 3
+    if (4 * q < HW) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(src[t] + 12 * (size_t)q);     // (frame_elems % 4 == 0: dword aligned)
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t bytes[12] = {w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255, w0 >> 24, w1 & 255, (w1 >> 8) & 255, (w1 >> 16) & 255, w1 >> 24,
+                                        w2 & 255, (w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                f32x4 o;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    float v = (float)bytes[3 * px + c] / 255.0f;      // true division, as images / 255.0 (img_utils.py:37)
+                    if (normalize) v = 2.0f * v - 1.0f;
+                    o[px] = v;
+                }
+                *reinterpret_cast<f32x4*>(dst[t] + (size_t)c * HW + 4 * q) = o;
+            }
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < act_len * act_dim; i += 256)
+            out_acts[(size_t)b * act_len * act_dim + i] = acts[(size_t)f0 * act_dim + i];
+}
+
 // ----------------------------------------------------------------------------------------- host sampler
 namespace {
 struct MT {
@@ -140,7 +176,10 @@ int v2a_replay_gather(const void* frames, int dtype_u8, const float* acts, const
     if (!frames || !acts || !frame_start || !out_start || !out_goal || !out_acts) return V2A_ERR_ARG;
     const int fe = H * W * 3;
     dim3 grid((fe + 256 * 8 - 1) / (256 * 8), B);
-    if (dtype_u8)
+    if (dtype_u8 && chw_out && (H * W) % 4 == 0 && ((((uintptr_t)out_start | (uintptr_t)out_goal | (uintptr_t)frames) & 15) == 0))
+        hipLaunchKernelGGL(replay_gather_u8_chw4_kernel, dim3((H * W / 4 + 255) / 256, B), dim3(256), 0, s, (const uint8_t*)frames, acts,
+                           frame_start, out_start, out_goal, out_acts, fe, act_len, act_dim, normalize, H * W);
+    else if (dtype_u8)
         hipLaunchKernelGGL((replay_gather_kernel<uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)frames, acts, frame_start, out_start,
                            out_goal, out_acts, B, fe, act_len, act_dim, 255.0f, normalize, chw_out, H * W);
     else

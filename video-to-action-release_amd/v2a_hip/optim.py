@@ -64,9 +64,21 @@ class FusedAdamWEMA:
               "opt_state_scaler")
         return ls.value, gt.value, bool(sk.value), n.value
 
-    def step(self, zero_grad=True):
-        check(lib.v2a_opt_step(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
-                               self.partial.data_ptr(), 1 if zero_grad else 0, ops._stream()), "opt_step")
+    def set_pack_rows(self, rows):
+        """rows[i] = (forward-pack address or 0, Cin, taps, channel-window-pack address or 0) of parameter i (PolicyEngine.opt_pack_rows):
+        step(packs=True) then writes those conv operands from the update kernel itself.  None clears."""
+        if rows is None:
+            self.pack_table = None
+            return
+        assert len(rows) == len(self.params)
+        self.pack_table = torch.tensor([[int(a), max(int(b), 1), max(int(c), 1), int(d)] for a, b, c, d in rows], dtype=torch.int64).to(self.device)
+
+    pack_table = None
+
+    def step(self, zero_grad=True, packs=False):
+        pk = self.pack_table.data_ptr() if (packs and self.pack_table is not None) else None
+        check(lib.v2a_opt_step_packed(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
+                                      self.partial.data_ptr(), 1 if zero_grad else 0, pk, ops._stream()), "opt_step")
 
     def scale_grads(self, scale: float):
         check(lib.v2a_opt_scale_grads(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, float(scale), ops._stream()),

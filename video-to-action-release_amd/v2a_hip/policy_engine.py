@@ -435,7 +435,28 @@ class PolicyEngine:
     _packs_pending = None      # "unet": the trainer postponed that group's re-pack to the start of its next step (see refresh_packs)
     _pack_join = None          # stream the UNet forward has to wait for (the side stream that group's re-pack was launched on)
 
-    def refresh_packs(self, which="all"):
+    _mp_serial = 0             # bumped whenever the pack tables are rebuilt (operand buffers may have moved): opt_pack_rows is stale then
+
+    def opt_pack_rows(self, tensors):
+        """For FusedAdamWEMA.set_pack_rows: per optimiser tensor (matched by address) the forward operand the update kernel should also
+        write -- the [Cout][taps][Cin] pack of a conv with more than one tap (+ the stem's channel-window pack), the slice of the
+        concatenated FiLM operand of a FiLM weight / bias -- or zeros.  fp32 precision mode only (the 16-bit modes' packs carry twins).
+        Returns (rows, serial)."""
+        self.refresh_packs()                          # allocates every operand; fixes the addresses the rows point at
+        by_ptr = {}
+        for c in self._convs.values():
+            taps = c.kh * c.kw
+            if taps > 1:
+                by_ptr[c.w.data_ptr()] = (c._pf.data_ptr(), c.ci, taps, c._pw.data_ptr() if c.window else 0)
+        if self.batch_film:
+            for r in self.film:
+                w, b = r["ce"].w.detach(), r["ce"].b.detach()
+                o = r["film_off"]
+                by_ptr[w.data_ptr()] = (self._film_w.data_ptr() + 4 * o * self.film_gd, w.numel(), 1, 0)
+                by_ptr[b.data_ptr()] = (self._film_b.data_ptr() + 4 * o, b.numel(), 1, 0)
+        return [by_ptr.get(t.data_ptr(), (0, 1, 1, 0)) for t in tensors], self._mp_serial
+
+    def refresh_packs(self, which="all", skip_fwd=False):
         """Unconditionally re-pack conv weights (call once per train step after the optimiser; capturable).  which = "all" | "enc" |
         "unet": the image encoders' (`obs_encoder.*`) or the ConditionalUnet1D's (`model.*`, 75 % of the parameters) operands only --
         the trainer packs the encoders right after the optimiser and the UNet at the START of the next step on a side stream, under
@@ -490,16 +511,18 @@ class PolicyEngine:
                     ch1["unet"] += [[len(rows) - 1, t_] for t_ in range(-(-row[2] // 64) * -(-row[3] // 64))]
             dev = self.device
             t = lambda a, dt: torch.tensor(a, dtype=dt).to(dev) if a else None
+            self._mp_serial += 1
             self._mp = dict(tab=t(rows, torch.int64), ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16, half=ops.POLICY_HALF[0],
                             ch0={g: t(v, torch.int32) for g, v in ch0.items()}, n0={g: len(v) for g, v in ch0.items()},
                             ch1={g: t(v, torch.int32) for g, v in ch1.items()}, n1={g: len(v) for g, v in ch1.items()})
         mp = self._mp
         if mp["ptrs"] != [c.w.data_ptr() for c in self._convs.values()]:      # parameters were re-allocated (.to(), load): rebuild
             self._mp = None
-            return self.refresh_packs(which)
+            return self.refresh_packs(which, skip_fwd)
         groups = ("enc", "unet") if which == "all" else (which,)
         for g in groups:
-            if mp["n0"][g]:
+            # skip_fwd: the optimiser's update kernel wrote the forward packs itself (FusedAdamWEMA.step(packs=True))
+            if mp["n0"][g] and not (skip_fwd and not bf16):
                 check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch0"][g].data_ptr(), mp["n0"][g], 0, ops._stream()), "pack_weights_multi")
             if mp["n1"][g]:
                 check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"][g].data_ptr(), mp["n1"][g], 1, ops._stream()), "pack_weights_multi_t")

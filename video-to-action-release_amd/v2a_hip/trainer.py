@@ -106,6 +106,9 @@ class PolicyTrainer:
         # the ConditionalUnet1D re-pack (0.33 ms of HBM-bound launches) leaves the serial tail: it runs at the start of the NEXT step
         # on a side stream, under the encoder forward (V2A_SPLIT_PACKS=0: everything right after the optimiser, as before)
         self.split_packs = os.environ.get("V2A_SPLIT_PACKS", "1") != "0"
+        self.fuse_packs = os.environ.get("V2A_FUSE_PACKS", "1") != "0"      # forward conv operands written by the optimiser's update kernel
+        self._pack_serial = -1
+        self._packs_fused = False
         self._pack_side = None
         self._wg_keep = None
 
@@ -152,7 +155,7 @@ class PolicyTrainer:
                 self._pack_side = torch.cuda.Stream(device=self.device)
             self._pack_side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._pack_side):
-                self.eng.refresh_packs("unet")
+                self.eng.refresh_packs("unet", skip_fwd=self._packs_fused)
             self.eng._pack_join = self._pack_side
         oo = torch.empty((2 * B, 3, st.H, st.W), dtype=torch.float32, device=self.device)      # start | goal frames side by side: the
         o0, o1 = oo[:B], oo[B:]                                                                 # two camera encoders run as one stacked chain
@@ -215,13 +218,22 @@ class PolicyTrainer:
 
     def _opt(self):
         ops.tstamp("optimiser begin")
-        self.opt.step(zero_grad=True)
+        # fp32 mode: the update kernel also writes the forward conv operands (no pack launch re-reads the parameters); the transposed
+        # data-gradient packs keep their launch
+        fused = self.fuse_packs and lib.v2a_get_precision() == 0
+        if fused and self._pack_serial != self.eng._mp_serial:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("optimiser pack table missing during graph capture; run one eager step first")
+            rows, self._pack_serial = self.eng.opt_pack_rows(self.opt.params)
+            self.opt.set_pack_rows(rows)
+        self._packs_fused = fused
+        self.opt.step(zero_grad=True, packs=fused)
         ops.tstamp("optimiser done / packs begin")
         if self.split_packs:
-            self.eng.refresh_packs("enc")
+            self.eng.refresh_packs("enc", skip_fwd=fused)
             self.eng._packs_pending = "unet"           # (re-armed on the host after every replay, see step())
         else:
-            self.eng.refresh_packs()
+            self.eng.refresh_packs(skip_fwd=fused)
         ops.tstamp("step end")
 
     # ------------------------------------------------------------------ step
