@@ -167,6 +167,9 @@ GN_CASES = [
     (6, 16, 512, 32, "relu", True, False),               # resnet layer4 small path + residual (float4 wave kernel, one row per lane)
     (5, 64, 256, 16, "relu", True, False),               # resnet layer3: float4 wave kernel, four rows per lane
     (3, 64, 256, 16, "relu", False, False),
+    (4, 8, 512, 8, "mish", False, True),                 # Conv1dBlock widths: 64 channels per group, two passes, FiLM
+    (3, 16, 512, 8, "mish", True, True),                 # ... four passes
+    (5, 8, 1024, 8, "mish", False, True),                # 128 channels per group, four passes
     (5, 64, 640, 32, "none", False, False),              # attention norm (per frame)
 ]
 

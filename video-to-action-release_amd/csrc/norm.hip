@@ -786,13 +786,14 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
     }
 }
 
-// ---- CG = 16 slabs of S = 16 * NJ rows as float4 (round 4): the deep ResNet stages (8 x 8 x 256 channels: NJ = 4, 4 x 4 x 512: NJ = 1).
-// gn_wave_*<16, .> above reads them with 16 scalar loads per tensor and lane (4-B pieces of four 64-B row segments per instruction) and
-// keeps eight 16-element arrays per lane: 41 us per backward launch for 25 MB of traffic.  Here lane l owns the 16-B chunk l & 3 of rows
-// (l >> 2) + 16 j: one b128 load per tensor and row (every instruction covers 16 whole 64-B segments), per-channel operands once per lane,
-// the per-channel sums (dgamma / dbeta contributions) by four xor shuffles over the lanes of a chunk.  FiLM-free launches only.
+// ---- float4 form of the wave path (round 4): slabs of E = S * CG = 256 * NJ elements, CG in {16, 32, 64, 128}, NJ in {1, 2, 4} -- the
+// deep ResNet stages (CG = 16: 8 x 8 x 256 channels, 4 x 4 x 512) and every Conv1dBlock of the ConditionalUnet1D (E = 512 / 1024).
+// gn_wave_*<CG, .> above reads them with E / 64 scalar loads per tensor and lane and keeps eight E/64-element arrays per lane.  Here a
+// row of the slab (CG floats) is CG / 4 lanes x one b128 load, a pass of the wave covers 256 / CG rows, NJ passes the slab: every
+// instruction moves whole 64 ... 512-B row segments, a lane owns four FIXED channels (gamma / beta / FiLM operands once per lane), and
+// the per-channel sums (dgamma / dbeta / dFiLM contributions) are xor shuffles over the lanes of a 16-B column.
 template <int NJ>
-__device__ __forceinline__ void gn_w16_gather(const GnDesc& p, const float* dense, const size_t (&off)[NJ], int c0, f32x4 (&v)[NJ]) {
+__device__ __forceinline__ void gn_wv_gather(const GnDesc& p, const float* dense, const size_t (&off)[NJ], int c0, f32x4 (&v)[NJ]) {
     if (p.nslab <= 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const f32x4*>(dense + off[j]);
@@ -825,24 +826,31 @@ __device__ __forceinline__ void gn_w16_gather(const GnDesc& p, const float* dens
     }
 }
 
-template <int NJ>
-__global__ __launch_bounds__(64) void gn_wave16_fwd(const GnDesc p) {
+template <int CG, int NJ>
+__global__ __launch_bounds__(64) void gn_wavev_fwd(const GnDesc p) {
+    constexpr int LPR = CG / 4, RPP = 64 / LPR;                 // lanes per row, rows per pass
     const int lane = threadIdx.x, wv = blockIdx.x;
     const int n = wv / p.G, g = wv - n * p.G;
-    const int C = p.C, c0 = g * 16 + (lane & 3) * 4;
+    const int C = p.C, c0 = g * CG + (lane % LPR) * 4;
     size_t off[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane >> 2) + 16 * j) * C + c0;
+    for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane / LPR) + RPP * j) * C + c0;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c0), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c0);
+    const bool film = p.film != nullptr;
+    f32x4 f0 = {1.f, 1.f, 1.f, 1.f}, f1 = {0.f, 0.f, 0.f, 0.f};
+    if (film) {
+        f0 = *reinterpret_cast<const f32x4*>(p.film + (size_t)n * p.film_ld + c0);
+        f1 = *reinterpret_cast<const f32x4*>(p.film + (size_t)n * p.film_ld + C + c0);
+    }
     f32x4 rsd[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) rsd[j] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + off[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 v[NJ];
-    gn_w16_gather<NJ>(p, p.x, off, c0, v);
+    gn_wv_gather<NJ>(p, p.x, off, c0, v);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-    const float inv = 1.0f / (float)(p.S * 16);
+    const float inv = 1.0f / (float)(p.S * CG);
     const float mu = wave_sum(s) * inv;
     float q = 0.f;
 #pragma unroll
@@ -858,31 +866,37 @@ __global__ __launch_bounds__(64) void gn_wave16_fwd(const GnDesc p) {
         for (int e = 0; e < 4; ++e) {
             float z = (v[j][e] - mu) * rs * gm[e] + bt[e];
             if (p.residual) z += rsd[j][e];
-            o[e] = act_fwd(z, p.act);
+            float a = act_fwd(z, p.act);
+            if (film) a = f0[e] * a + f1[e];
+            o[e] = a;
         }
         *reinterpret_cast<f32x4*>(p.y + off[j]) = o;
         if (p.yh) gn_store_twin4(p.yh, off[j] >> 2, o, p.yh_f16);
     }
 }
 
-template <int NJ>
-__global__ __launch_bounds__(64) void gn_wave16_bwd(const GnDesc p) {
+template <int CG, int NJ>
+__global__ __launch_bounds__(64) void gn_wavev_bwd(const GnDesc p) {
+    constexpr int LPR = CG / 4, RPP = 64 / LPR;
     const int lane = threadIdx.x, wv = blockIdx.x;
     const int n = wv / p.G, g = wv - n * p.G;
-    const int C = p.C, c0 = g * 16 + (lane & 3) * 4;
+    const int C = p.C, c0 = g * CG + (lane % LPR) * 4;
     size_t off[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane >> 2) + 16 * j) * C + c0;
+    for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane / LPR) + RPP * j) * C + c0;
     const float mu = p.mean[wv], rs = p.rstd[wv];
     const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c0), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c0);
+    const bool film = p.film != nullptr;
+    f32x4 f0 = {1.f, 1.f, 1.f, 1.f};
+    if (film) f0 = *reinterpret_cast<const f32x4*>(p.film + (size_t)n * p.film_ld + c0);
     f32x4 xv[NJ], rsd[NJ], dz[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         xv[j] = *reinterpret_cast<const f32x4*>(p.x + off[j]);
         rsd[j] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + off[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    gn_w16_gather<NJ>(p, p.dout, off, c0, dz);
-    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+    gn_wv_gather<NJ>(p, p.dout, off, c0, dz);
+    f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f}, cs2 = {0.f, 0.f, 0.f, 0.f}, cs3 = {0.f, 0.f, 0.f, 0.f};
     float A1 = 0.f, A2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -891,7 +905,14 @@ __global__ __launch_bounds__(64) void gn_wave16_bwd(const GnDesc p) {
             const float h = (xv[j][e] - mu) * rs;
             float z = h * gm[e] + bt[e];
             if (p.residual) z += rsd[j][e];
-            const float d = dz[j][e] * act_bwd(z, p.act);
+            const float dout = dz[j][e];
+            float da = dout;
+            if (film) {
+                da = dout * f0[e];
+                cs2[e] += dout * act_fwd(z, p.act);
+                cs3[e] += dout;
+            }
+            const float d = da * act_bwd(z, p.act);
             xv[j][e] = h;
             dz[j][e] = d;
             cs0[e] += d;
@@ -901,7 +922,7 @@ __global__ __launch_bounds__(64) void gn_wave16_bwd(const GnDesc p) {
         }
     A1 = wave_sum(A1);
     A2 = wave_sum(A2);
-    const float inv = 1.0f / (float)(p.S * 16);
+    const float inv = 1.0f / (float)(p.S * CG);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         f32x4 o;
@@ -912,26 +933,49 @@ __global__ __launch_bounds__(64) void gn_wave16_bwd(const GnDesc p) {
         if (p.dres) *reinterpret_cast<f32x4*>(p.dres + off[j]) = dz[j];
     }
 #pragma unroll
-    for (int o = 4; o < 64; o <<= 1)                  // lanes with equal lane & 3 hold the same four channels
+    for (int o = LPR; o < 64; o <<= 1)                // lanes with equal lane % LPR hold the same four channels
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             cs0[e] += __shfl_xor(cs0[e], o, 64);
             cs1[e] += __shfl_xor(cs1[e], o, 64);
+            if (film) { cs2[e] += __shfl_xor(cs2[e], o, 64); cs3[e] += __shfl_xor(cs3[e], o, 64); }
         }
-    if (lane < 4) {
+    if (lane < LPR) {
         *reinterpret_cast<f32x4*>(p.colsum + (size_t)n * 2 * C + c0) = cs0;
         *reinterpret_cast<f32x4*>(p.colsum + (size_t)n * 2 * C + C + c0) = cs1;
+        if (p.dfilm) {
+            *reinterpret_cast<f32x4*>(p.dfilm + (size_t)n * p.film_ld + c0) = cs2;
+            *reinterpret_cast<f32x4*>(p.dfilm + (size_t)n * p.film_ld + C + c0) = cs3;
+        }
     }
 }
-static bool gn_wave16_ok(const GnDesc& p, int cg) {
+// 1 / 2 / 4 passes of the float4 wave kernels (0: not eligible)
+static int gn_wavev_passes(const GnDesc& p, int cg) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("V2A_GN_WAVE16"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || cg != 16 || p.film || p.dfilm || (p.S != 16 && p.S != 64) || (p.C & 3)) return false;
+    if (on < 0) { const char* e = getenv("V2A_GN_WAVEV"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || !(cg == 16 || cg == 32 || cg == 64 || cg == 128) || (p.C & 3) || (p.film_ld & 3)) return 0;
+    const long E = (long)p.S * cg;
+    if (E != 256 && E != 512 && E != 1024) return 0;
     const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.residual | (uintptr_t)p.dout | (uintptr_t)p.dres | (uintptr_t)p.gamma |
                         (uintptr_t)p.beta | (uintptr_t)p.gamma2 | (uintptr_t)p.beta2 | (uintptr_t)p.slabs | (uintptr_t)p.cbias |
-                        (uintptr_t)p.sresid | (uintptr_t)p.sout | (uintptr_t)p.colsum | (uintptr_t)p.yh;
-    return (a & 15) == 0 && (p.slab_stride & 3) == 0;
+                        (uintptr_t)p.sresid | (uintptr_t)p.sout | (uintptr_t)p.colsum | (uintptr_t)p.yh | (uintptr_t)p.film | (uintptr_t)p.dfilm;
+    if ((a & 15) != 0 || (p.slab_stride & 3) != 0) return 0;
+    return (int)(E / 256);
 }
+#define V2A_GNWV_LAUNCH(KERN, CGV, NJV) hipLaunchKernelGGL((KERN<CGV, NJV>), grid, block, 0, stream, p)
+#define V2A_GNWV_NJ(KERN, CGV, NJ_)                                                                             \
+    do {                                                                                                          \
+        if ((NJ_) == 1) V2A_GNWV_LAUNCH(KERN, CGV, 1);                                                            \
+        else if ((NJ_) == 2) V2A_GNWV_LAUNCH(KERN, CGV, 2);                                                       \
+        else V2A_GNWV_LAUNCH(KERN, CGV, 4);                                                                       \
+    } while (0)
+#define V2A_GNWV(KERN, CG_, NJ_)                                                                                \
+    do {                                                                                                          \
+        if ((CG_) == 16) V2A_GNWV_NJ(KERN, 16, NJ_);                                                              \
+        else if ((CG_) == 32) V2A_GNWV_NJ(KERN, 32, NJ_);                                                         \
+        else if ((CG_) == 64) V2A_GNWV_NJ(KERN, 64, NJ_);                                                         \
+        else V2A_GNWV_NJ(KERN, 128, NJ_);                                                                         \
+    } while (0)
 
 static bool gn_wave_ok(int S, int cg) {
     static int on = -1;
@@ -1100,9 +1144,8 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
     if (!x2 && gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;             // 8 values per lane (the ConditionalUnet1D slabs) or 16
-        if (gn_wave16_ok(p, cg)) {
-            if (S == 64) hipLaunchKernelGGL((gn_wave16_fwd<4>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((gn_wave16_fwd<1>), grid, block, 0, stream, p);
+        if (const int nj = gn_wavev_passes(p, cg)) {
+            V2A_GNWV(gn_wavev_fwd, cg, nj);
             V2A_CHECK_LAUNCH();
             return V2A_OK;
         }
@@ -1221,9 +1264,8 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     if (gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;
-        if (gn_wave16_ok(p, cg)) {
-            if (S == 64) hipLaunchKernelGGL((gn_wave16_bwd<4>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((gn_wave16_bwd<1>), grid, block, 0, stream, p);
+        if (const int nj = gn_wavev_passes(p, cg)) {
+            V2A_GNWV(gn_wavev_bwd, cg, nj);
         } else
 #define V2A_GNW_B(CGV) do { if (small) hipLaunchKernelGGL((gn_wave_bwd<CGV, 8>), grid, block, 0, stream, p); \
                             else hipLaunchKernelGGL((gn_wave_bwd<CGV, 16>), grid, block, 0, stream, p); } while (0)
