@@ -199,7 +199,7 @@ def instrumented_pass(torch, trainer, steps):
             c2 = c["x2"].shape[-1] if c["x2"] is not None else 0
             fl += 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * c["KH"] * c["KW"] * (x.shape[-1] + c2)
         v0 = calls[0]["variant"]
-        name = "conv_wgrad_multi_x3" if v0 >= 6 else ("conv_wgrad_multi_halo" if v0 >= 3 else "conv_wgrad_multi")
+        name = "conv_wgrad_multi_x3h" if v0 >= 8 else ("conv_wgrad_multi_x3" if v0 >= 6 else ("conv_wgrad_multi_halo" if v0 >= 3 else "conv_wgrad_multi"))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         orig_axpy(blk_a, blk_b, 1.0, out=blk_b)
         e0.record()
@@ -825,12 +825,12 @@ def main():
             tot = sum(v[1] for v in agg.values())
             name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
             achieved = fl / sec / 1e12
-            x3 = "f32x3" in name                     # fp32 products from three bf16 planes: six bf16 MFMAs per product block
+            x3 = "x3" in name                        # fp32 products from three bf16 planes: six bf16 MFMAs per product block
             peak = (BF16_MFMA_PEAK_TFLOPS / 6.0) if x3 else (FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS)
-            g_us = _graph_avg_us(name.rstrip(">") + ",") or _graph_avg_us(name.rstrip(">") + ">")
+            g_us = _graph_avg_us(name.rstrip(">") + ",") or _graph_avg_us(name.rstrip(">") + ">") or _graph_avg_us(name + "_kernel")
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                                "frac": achieved / peak,
-                               "peak_is": ("dense bf16 MFMA peak 2500 / 6 plane products per fp32 product (conv_igemm_f32x3)" if x3 else
+                               "peak_is": ("dense bf16 MFMA peak 2500 / 6 plane products per fp32 product (three-plane kernels)" if x3 else
                                            "dense MFMA peak of the dtype"),
                                "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else None,
                                "frac_in_graph": ((fl / cnt) / (g_us * 1e-6) / 1e12 / peak) if g_us else None,
