@@ -87,12 +87,18 @@ rt = {}
 for leg_name in ("policy", "policy_bf16", "video", "video_bf16"):
     traffic = {}
     for k, v in out[leg_name].items():
-        m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32|bf16))<(\d+), (\d+)", k)
+        m = re.match(r"(conv_(?:igemm|wgrad)_(?:dma_f32|f32x3|f32p|f32|bf16))<(\d+), (\d+)", k)
+        mx = re.match(r"conv_halo_x3<(\d+)>", k)                  # round 4: three-plane halo conv, key = bench.py's ops.last_kernel name
+        if mx:
+            a = traffic.setdefault(f"conv_halo_x3<{mx.group(1)}>", [0.0, 0])
+            a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
+            a[1] += v["n"]
+            continue
         mh = re.match(r"conv_igemm_h<(\d+), (\d+), (float|unsigned short|f16s)(?:, \d+)?>", k)
         # <WAVES_M, WAVES_N, TM, TN, SB[, GN][, F16]> -> BM x BN (the trailing bool is the fp16 flag of round 3)
         m3 = re.match(r"(conv_halo_h3|conv_igemm_h2)<(\d+), (\d+), (\d+), (\d+), \d+(?:, (\d+))?(?:, (?:true|false))?>", k)
         mf = re.match(r"conv_frames_h3<(\d+)(?:, (?:true|false))?>", k)
-        mw = re.match(r"(conv_wgrad_multi(?:_halo)?)_kernel", k)
+        mw = re.match(r"(conv_wgrad_multi(?:_halo|_x3h|_x3)?)_kernel", k)
         if mw:
             a = traffic.setdefault(mw.group(1), [0.0, 0])
             a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
