@@ -114,6 +114,14 @@ def _emit(out):
             if isinstance(line.get(leg), dict):
                 line[leg] = {k: v for k, v in line[leg].items() if k in ("value", "unit", "seconds_per_sample_call", "algorithmic_tflops", "error")}
         txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > 7600:                          # still too long: explanatory strings and per-call lists of every leg (all of it is in the full record)
+        def shed(o):
+            if isinstance(o, dict):
+                return {k: shed(v) for k, v in o.items() if k not in ("peak_is", "output_range", "call_seconds", "cpu_model", "usable_cores",
+                                                                      "estimate_assumes", "frac_of_f32_mfma_peak", "end_to_end_frac_of_f32_mfma_peak")}
+            return o
+        line = shed(line)
+        txt = json.dumps(line, separators=(",", ":"))
     print(txt)
 
 

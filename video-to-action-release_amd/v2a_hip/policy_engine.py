@@ -619,8 +619,8 @@ class PolicyEngine:
         (ops.conv2d_window: one aligned 128-B line per output pixel and filter row); the same buffer is the weight gradient's input.
         Otherwise: [N, H, W, 3] and the scalar-gather kernel.  Returns (saved input, conv output)."""
         N, C, H, W = img_nchw.shape
-        if (_STEM_WINDOW and conv1.window and C == 3 and H % 2 == 0 and W % 2 == 0 and ops.lib.v2a_get_precision() == 0
-                and ops.lib.v2a_get_f32_conv_mode() == 1):
+        # (also in the 16-bit MFMA modes: the 3-channel stem never ran on the 16-bit kernels, it is an fp32 conv there too)
+        if (_STEM_WINDOW and conv1.window and C == 3 and H % 2 == 0 and W % 2 == 0 and ops.lib.v2a_get_f32_conv_mode() == 1):
             bk = (key, N, H, W)
             xp = self._stem_buf.get(bk)
             if xp is None:

@@ -262,20 +262,22 @@ class PolicyTrainer:
                         self._bwd_encoders()
                         self._opt()
                 else:                                     # three graphs with the two slice all-reduces launched between them
-                    with torch.cuda.graph(self._g_fb):
+                    # (thread-local capture mode: the communicator's watchdog thread polls the events of earlier collectives while these
+                    # graphs are captured -- in the default global mode its hipEventQuery is an illegal call and takes the process down)
+                    with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
                         self._fwd_bwd()
                     if self.dp_defer:
                         # this graph runs NEXT TO the encoder-backward graph: a memory pool of its own, and its operands (activations
                         # of the first graph) stay referenced for the graphs' lifetime -- a block freed here would be handed to the
                         # graphs captured after it, which then overwrite it while this one still reads
                         self._g_wg = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self._g_wg):
+                        with torch.cuda.graph(self._g_wg, capture_error_mode="thread_local"):
                             self._wg_keep = self.eng.run_deferred_wgrads()
                     self._g_enc = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._g_enc, pool=self._g_fb.pool()):
+                    with torch.cuda.graph(self._g_enc, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
                         self._bwd_encoders()
                     self._g_opt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+                    with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
                         self._opt()
                 # capture does not execute: run the step for real
             pe = None
