@@ -1291,7 +1291,14 @@ static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* 
     *bm = 128;
     *bn = Cout <= 64 ? 64 : 128;                   // 64-wide layers (ResNet layer1) would waste half of a 128-column tile
     *tiles = cdiv(M, 128) * cdiv(Cout, *bn);
-    if (g_small_tile_h && *tiles < 128) {          // few big tiles: quarter them (more workgroups, shallower split-K)
+    // few big tiles: quarter them (more workgroups, shallower split-K).  V2A_DEEP_SMALL_M=1 (experiment, default off) keeps 128-wide tiles
+    // for the deep small-M GEMMs of the ConditionalUnet1D (M <= 1024 rows, >= 1 G MACs), which are bound by operand bytes through the
+    // vector L1: the conv launches gain (45.6 -> 34.8 us, 25.6 -> 21.3 us, tools/probes/r4/unet_conv_time.py), the GroupNorm launches that
+    // sum their split-K slabs lose as much (twice the slabs) -- step 8.09 vs 8.07 ms.
+    static int deep_on = -1;
+    if (deep_on < 0) { const char* e = getenv("V2A_DEEP_SMALL_M"); deep_on = (e && e[0] == '1') ? 1 : 0; }
+    const bool deep_small_m = deep_on && ept == 32 && M <= 1024 && (double)M * Cout * K >= 1.0e9;
+    if (g_small_tile_h && *tiles < 128 && !deep_small_m) {
         *bm = 64;
         *bn = 64;
         *tiles = cdiv(M, 64) * cdiv(Cout, 64);

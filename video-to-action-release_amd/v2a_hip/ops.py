@@ -108,7 +108,7 @@ def _plan_name_h(M, Cout, K, ept, tname):
     if tname == "float":                          # fp32 instances: three-plane kernel (default) or the pipelined exact-f32 kernel
         x3 = lib.v2a_get_f32_conv_mode() == 1
         base = "conv_igemm_f32x3" if x3 else "conv_igemm_f32p"
-        if tiles128 < 128 and _SMALL_TILE_H:
+        if tiles128 < 128 and _SMALL_TILE_H and not (_DEEP_SMALL_M and M <= 1024 and float(M) * Cout * K >= 1.0e9):      # (mirrors conv_plan_h)
             return f"{base}<64,64>"
         if Cout <= 64:
             big = x3 and M % 256 == 0 and -(-M // 256) >= 200 and os.environ.get("V2A_X3_BIG", "1") != "0"
@@ -121,6 +121,7 @@ def _plan_name_h(M, Cout, K, ept, tname):
 
 _SMALL_TILE_H = os.environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
 _CONV_X3H = os.environ.get('V2A_CONV_X3H', '1') != '0'
+_DEEP_SMALL_M = os.environ.get('V2A_DEEP_SMALL_M', '0') == '1'
 _WGRAD_DMA = os.environ.get('V2A_WGRAD_DMA', '1') != '0'
 _h_twin_regs = 0
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
