@@ -70,6 +70,7 @@ struct ConvDescH {
     const void* w2;           // second weight set (rows >= m_split) or null       [conv_igemm_f32p only]
     const float* bias2;       // second bias (rows >= m_split) or null
     int m_split;              // first output row of the second set (a multiple of every row tile); INT_MAX: one set
+    int split_xcd;            // > 0: 1-D grid, split-K slices pinned to XCDs (slices per XCD)              [conv_igemm_f32x3 only]
     int xp1;                  // element pitch between consecutive pixels of source 1 (= C1; < C1: overlapping channel windows,
                               // v2a_conv2d_fwd_window_f32)                                      [conv_igemm_f32x3, non-GEN path only]
     unsigned long long* tstamps;   // measurement aid (v2a_debug_conv_stamps): [workgroup][8] wall-clock stamps of the kernel's phases, or null
@@ -771,7 +772,20 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     V2A_STAMP(0);
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+    int lin, split;
+    if (p.split_xcd > 0) {
+        // split-K slices pinned to XCDs (1-D grid of tiles x splits, splits = 8 x split_xcd): workgroup L runs on XCD L & 7, which owns
+        // slices (L & 7) * split_xcd .. + split_xcd - 1 and ALL their output tiles -- its L2 then holds one K slice of both operands
+        // (a few MB) and every byte is fetched over the fabric once; with slice = blockIdx.y each XCD streamed the WHOLE weight matrix
+        // for its share of the row tiles (the deep small-M GEMMs of the ConditionalUnet1D ran at the fabric's ~8 TB/s, not the L2's)
+        const int L = (int)blockIdx.x, xcd = L & 7, slot = L >> 3, tiles = tiles_m * tiles_n;
+        const int sl = slot / tiles;
+        split = xcd * p.split_xcd + sl;
+        lin = slot - sl * tiles;
+    } else {
+        lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+        split = blockIdx.y;
+    }
     int tm = lin / tiles_n;
     const int n0 = (lin % tiles_n) * BN;
     if (p.frame_tiles > 0) {
@@ -781,7 +795,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
         tm = img * per_sample + f * p.frame_tiles + pb;
     }
     const int m0 = tm * BM;
-    const int split = blockIdx.y;
     const int Cin = p.C1 + p.C2;
     const int nkt = p.K / EPT;
     const int kt_begin = split * p.ktiles_per_split;
@@ -1425,6 +1438,7 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         g_stages_h = (e && e[0] == '2') ? 2 : 1;
     }
     p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff;
+    p.split_xcd = 0;
     p.xp1 = xpitch > 0 ? xpitch : C1;
     if (xpitch > 0) {                                // channel windows: the three-plane kernel's plain loader only
         if (sizeof(T) != 4 || x2 || C2 || ups || idil != 1 || xpitch > C1 || xpitch % 4) return V2A_ERR_ARG;
@@ -1468,10 +1482,14 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
             // tiles: 64 x 64 (small problems, the plan's split), 128 x 64 / 256 x 64 for 64-wide layers, 128 x 128 on 8 waves otherwise --
             // the wider the tile, the fewer fp32 -> plane conversions and LDS bytes per MFMA
             const bool gen = ups || idil == 2;
+            static int sx_on = -1;                            // V2A_SPLIT_XCD=0: slice = blockIdx.y as before (A/B)
+            if (sx_on < 0) { const char* e = getenv("V2A_SPLIT_XCD"); sx_on = (e && e[0] == '0') ? 0 : 1; }
+            p.split_xcd = (sx_on && s >= 8 && s % 8 == 0 && p.frame_tiles == 0) ? s / 8 : 0;
 #define V2A_X3_LAUNCH(BM_, BN_, WM_, WN_, G_)                                                                                            \
     do {                                                                                                                                   \
-        if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, true>), dim3(G_, s), dim3(64 * WM_ * WN_), 0, stream, p);      \
-        else hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, false>), dim3(G_, s), dim3(64 * WM_ * WN_), 0, stream, p);        \
+        const dim3 grid_ = p.split_xcd > 0 ? dim3((G_) * s, 1) : dim3(G_, s);                                                              \
+        if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, true>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);           \
+        else hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, false>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);             \
     } while (0)
             static int big = -1;                             // V2A_X3_BIG=0: four-wave tiles only (A/B)
             if (big < 0) { const char* e = getenv("V2A_X3_BIG"); big = (e && e[0] == '0') ? 0 : 1; }
