@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
     unsigned char* Hs = smem;
     unsigned char* Bs = smem + 3 * PHB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    V2A_STAMP(0);
     const int tiles_n = p.Cout / BN, tiles_m = p.M / BM;
     const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
     const int tm = lin / tiles_n;
@@ -1184,9 +1185,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
     loadB_next(rb0);
     loadB_next(rb1);
     loadB_next(rb2);
+    V2A_STAMP(1);
     storeH(rh);
     storeB(rb0, 0);
     __syncthreads();
+    V2A_STAMP(2);
     int stage = 0;
     for (int ck = ck_begin; ck < ck_end; ++ck) {
         const bool more = ck + 1 < ck_end;
@@ -1210,6 +1213,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
             stage ^= 1;
         }
     }
+    V2A_STAMP(3);
     static_assert(4 * 32 * 32 * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
     conv_f32_epilogue<BM, BN, 2, 2>(p, acc, smem, m0, n0, split, p.bias);
 }

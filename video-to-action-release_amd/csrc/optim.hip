@@ -158,6 +158,51 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
         }
         return;
     }
+    // filters with more than one tap and a forward pack (the k = 5 Conv1d and 3 x 3 Conv2d weights: 85 M of the 87 M parameters): the
+    // updated values of a quarter chunk are parked in LDS and leave for the pack in DESTINATION order -- thread = filter row (co, ci),
+    // tap t of 64 consecutive rows = 64 consecutive floats of the pack.  (The element-order stores of the loop further down put a
+    // wave's 64 values on `taps` lines in 52-B / 28-B pieces and cost the kernel 0.12 ms; a row-per-thread loop over all five arrays
+    // fixed the stores and lost more on its strided loads.)  LDS reads at stride `taps` floats: conflict-free for odd tap counts.
+    if (pk && !pw && ptaps > 1) {
+        __shared__ float park[MT_CHUNK / 4];
+        constexpr int Q = MT_CHUNK / 4;
+        for (int base = 0; base < cnt; base += Q) {
+            const int qn = min(Q, cnt - base);
+            for (int i = base + threadIdx.x; i < base + qn; i += 256) {
+                const float gr = g[i] * clip;
+                float pv = p[i] * dmul;
+                float mv = m[i];
+                mv = mv + (gr - mv) * (1.0f - b1);
+                const float vv = v[i] * b2 + (1.0f - b2) * gr * gr;
+                const float denom = sqrtf(vv) * isb2 + eps;
+                pv = pv - step_size * (mv / denom);
+                p[i] = pv;
+                m[i] = mv;
+                v[i] = vv;
+                if (zero_grad) g[i] = 0.f;
+                if (e && mode) {
+                    float ev = (mode & 1) ? pv : e[i];
+                    if (mode & 2) { const float d = (ev - pv) * (1.0f - dec); ev = ev - d; }
+                    e[i] = ev;
+                }
+                park[i - base] = pv;
+            }
+            __syncthreads();
+            const int qs = start + base, qe = qs + qn;              // element range of this quarter in the tensor
+            const int r_lo = qs / ptaps, r_hi = (qe - 1) / ptaps;
+            for (int r = r_lo + threadIdx.x; r <= r_hi; r += 256) {
+                const int co = r / pCin, ci = r - co * pCin;
+                const int e0 = r * ptaps;
+                float* dst = pk + (size_t)co * ptaps * pCin + ci;
+                for (int tp = 0; tp < ptaps; ++tp) {
+                    const int el = e0 + tp;
+                    if (el >= qs && el < qe) dst[(size_t)tp * pCin] = park[el - qs];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const float gr = g[i] * clip;
         float pv = p[i] * dmul;
