@@ -1164,7 +1164,9 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
         const bool vec = cg % 4 == 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
         // 1024 threads per slab from 8 K elements up: with one 256-thread workgroup per (sample, group) a 64-KB slab was fetched in four
         // dependent rounds of loads by four waves per CU (19 us for the first ResNet stage); sixteen waves fetch it in one
-        const bool wide = vec && E >= 8192;
+        static int wide_min = -1;                        // V2A_GN_WIDE_MIN: smallest slab (elements) on the 1024-thread instance (tuning aid)
+        if (wide_min < 0) { const char* e = getenv("V2A_GN_WIDE_MIN"); wide_min = e ? atoi(e) : 8192; }
+        const bool wide = vec && E >= wide_min;
         if (lds > 64 * 1024) {
             (void)hipFuncSetAttribute((const void*)gn_small_fwd<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gn_small_fwd<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1278,7 +1280,9 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     } else if (E <= GN_SMALL_MAX) {
         const bool vec = cg % 4 == 0 && C % 4 == 0 &&
                          (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout | (uintptr_t)residual | (uintptr_t)dres | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
-        bool wide = vec && E >= 8192;
+        static int wide_min_b = -1;
+        if (wide_min_b < 0) { const char* e = getenv("V2A_GN_WIDE_MIN"); wide_min_b = e ? atoi(e) : 8192; }
+        bool wide = vec && E >= wide_min_b;
         int nt = wide ? 1024 : 256;
         int nsl = cg >= nt ? 1 : nt / cg;
         size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 32) * sizeof(float);
