@@ -197,6 +197,55 @@ def test_trainer_graph_replay_matches_eager(batch):
     assert all(np.isfinite(res[1][0]))
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_optimiser_written_operand_packs_equal_the_pack_launch(use_graph):
+    """Round 4: the fused update kernel (v2a_opt_step_packed) writes the forward conv operands itself -- [Cout][taps][Cin] packs in
+    destination order through LDS, the stem's channel-window pack, the concatenated FiLM operands -- and PolicyTrainer skips the pack
+    launch for them.  After a few steps every such operand must be bit-equal to what the pack kernels make of the live parameters
+    (mode 0 / mode 2 of v2a_pack_weight; plain copies for FiLM), eager and under graph replay, and equal to the V2A_FUSE_PACKS=0 run."""
+    import random
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    from v2a_hip.replay import ReplayStore
+    from v2a_hip.trainer import PolicyTrainer
+    if lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 mode only")
+    torch.manual_seed(1)
+    pol = build_policy(DEFAULT_CONF).to("cuda:0")
+    store = ReplayStore(64, 200, 30, capacity_frames=40 * 16)
+    gen = torch.Generator().manual_seed(3)
+    for e in range(16):
+        n = 30 + e
+        store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
+                              torch.rand(n - 1, 7, generator=gen) * 2 - 1)
+    np.random.seed(5); random.seed(5)
+    tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=use_graph)
+    assert tr.fuse_packs
+    for _ in range(4):
+        tr.step()
+    torch.cuda.synchronize()
+    assert tr._packs_fused and tr.opt.pack_table is not None
+    eng = tr.eng
+    checked = windows = 0
+    for c in eng._convs.values():
+        w = c.w.detach()
+        if c.kh * c.kw > 1:
+            assert torch.equal(c._pf, ops.pack_weight(w, 0)), c.wname
+            checked += 1
+        if c.window:
+            ref = torch.zeros_like(c._pw)
+            ops.pack_weight(w, 2, ref)
+            assert torch.equal(c._pw, ref), c.wname
+            windows += 1
+    assert checked > 60 and windows == 2
+    if eng.batch_film:
+        for r in eng.film:
+            o, n2 = r["film_off"], 2 * r["cout"]
+            assert torch.equal(eng._film_w[o:o + n2], r["ce"].w.detach().view(n2, -1))
+            assert torch.equal(eng._film_b[o:o + n2], r["ce"].b.detach())
+
+
 def test_policy_step_is_bitwise_reproducible():
     """two runs of the same seeded train steps give bitwise identical parameters, EMA weights and losses (graph
     replay included).  Replicas that stay bit-identical under data parallelism depend on exactly this."""
