@@ -367,8 +367,9 @@ int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_
 int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps);
 size_t v2a_opt_state_loss_scale_offset(void);
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad, v2a_stream_t s);
-/* same, and the update kernel also writes the conv operand packs of the updated parameters (packs_dev: [tensors][4] int64 = {forward pack
-   [Cout][taps][Cin] or 0, Cin, taps, channel-window pack (v2a_conv2d_fwd_window_f32) or 0}; the launch of v2a_pack_weights_multi that would
+/* same, and the update kernel also writes the conv operand packs of the updated parameters (packs_dev: [tensors][6] int64 = {forward pack
+   [Cout][taps][Cin] or 0, Cin, taps, channel-window pack (v2a_conv2d_fwd_window_f32) or 0, 16-bit twin of the forward pack or 0, 1 if that
+   twin is IEEE fp16}; the launch of v2a_pack_weights_multi that would
    read every parameter again is not needed for those operands) */
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad,
                         const int64_t* packs_dev, v2a_stream_t s);

@@ -197,8 +197,8 @@ def test_trainer_graph_replay_matches_eager(batch):
     assert all(np.isfinite(res[1][0]))
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_optimiser_written_operand_packs_equal_the_pack_launch(use_graph):
+@pytest.mark.parametrize("use_graph,prec", [(False, "fp32"), (True, "fp32"), (True, "bf16")])
+def test_optimiser_written_operand_packs_equal_the_pack_launch(use_graph, prec):
     """Round 4: the fused update kernel (v2a_opt_step_packed) writes the forward conv operands itself -- [Cout][taps][Cin] packs in
     destination order through LDS, the stem's channel-window pack, the concatenated FiLM operands -- and PolicyTrainer skips the pack
     launch for them.  After a few steps every such operand must be bit-equal to what the pack kernels make of the live parameters
@@ -209,8 +209,20 @@ def test_optimiser_written_operand_packs_equal_the_pack_launch(use_graph):
     from v2a_hip._lib import lib
     from v2a_hip.replay import ReplayStore
     from v2a_hip.trainer import PolicyTrainer
-    if lib.v2a_get_precision() != 0:
-        pytest.skip("fp32 mode only")
+    import v2a_hip
+    v2a_hip.set_precision(prec)
+    try:
+        _packs_check(use_graph, prec)
+    finally:
+        v2a_hip.set_precision("fp32")
+
+
+def _packs_check(use_graph, prec):
+    import random
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from v2a_hip import ops
+    from v2a_hip.replay import ReplayStore
+    from v2a_hip.trainer import PolicyTrainer
     torch.manual_seed(1)
     pol = build_policy(DEFAULT_CONF).to("cuda:0")
     store = ReplayStore(64, 200, 30, capacity_frames=40 * 16)
@@ -233,6 +245,9 @@ def test_optimiser_written_operand_packs_equal_the_pack_launch(use_graph):
         if c.kh * c.kw > 1:
             assert torch.equal(c._pf, ops.pack_weight(w, 0)), c.wname
             checked += 1
+        if prec != "fp32" and c._pf_h is not None:      # 16-bit twin of the forward operand = the rounded pack
+            ref_h = ops.cast_h(ops.pack_weight(w, 0) if c.kh * c.kw > 1 else w.reshape(-1).contiguous(), ops.POLICY_HALF[0])
+            assert torch.equal(c._pf_h.view(torch.int16), ref_h.reshape(-1).view(torch.int16)), c.wname
         if c.window:
             ref = torch.zeros_like(c._pw)
             ops.pack_weight(w, 2, ref)

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
     st->ema_mode = mode;
 }
 
-// `packs` (optional, int64 [tensor][4] = {dst, Cin, taps, dst_window}): the updated parameter also goes, re-laid, into the conv operand
+// `packs` (optional, int64 [tensor][6] = {dst, Cin, taps, dst_window, dst_16bit_twin, twin is fp16}): the updated parameter also goes, re-laid, into the conv operand
 // packs the next forward reads -- dst[co][tap][ci] (the forward pack of csrc/igemm.hip pack_weights_multi_kernel, mode 0; plain copies
 // are Cin = numel, taps = 1) and, for the RGB stem, dst_window[co][kh][kw'][ci'] (mode 2) -- instead of a pack launch that reads every
 // parameter again (0.36 ms of launches in the policy step's serial tail).  (co, ci, tap) of the thread's first element by one
@@ -123,12 +123,14 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
 __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table, const int* chunks, const OptState* st, int zero_grad,
                                                            const int64_t* packs) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
-    float* pk = packs ? reinterpret_cast<float*>(packs[t * 4 + 0]) : nullptr;
-    float* pw = packs ? reinterpret_cast<float*>(packs[t * 4 + 3]) : nullptr;
-    const int pCin = packs ? (int)packs[t * 4 + 1] : 1, ptaps = packs ? (int)packs[t * 4 + 2] : 1;
+    float* pk = packs ? reinterpret_cast<float*>(packs[t * 6 + 0]) : nullptr;
+    float* pw = packs ? reinterpret_cast<float*>(packs[t * 6 + 3]) : nullptr;
+    unsigned short* pkh = packs ? reinterpret_cast<unsigned short*>(packs[t * 6 + 4]) : nullptr;      // 16-bit twin of the forward pack (16-bit MFMA modes)
+    const int pf16 = packs ? (int)packs[t * 6 + 5] : 0;
+    const int pCin = packs ? (int)packs[t * 6 + 1] : 1, ptaps = packs ? (int)packs[t * 6 + 2] : 1;
     int kco = 0, kci = 0, ktap = 0, kwn = 1;
     const int step_tap = 256 % ptaps, step_ci = 256 / ptaps;
-    if (pk || pw) {
+    if (pk || pw || pkh) {
         const unsigned idx0 = (unsigned)start + threadIdx.x;    // torch layout [co][ci][tap]
         const unsigned q = idx0 / (unsigned)ptaps;
         ktap = (int)(idx0 - q * (unsigned)ptaps);
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
     // tap t of 64 consecutive rows = 64 consecutive floats of the pack.  (The element-order stores of the loop further down put a
     // wave's 64 values on `taps` lines in 52-B / 28-B pieces and cost the kernel 0.12 ms; a row-per-thread loop over all five arrays
     // fixed the stores and lost more on its strided loads.)  LDS reads at stride `taps` floats: conflict-free for odd tap counts.
-    if (pk && !pw && ptaps > 1) {
+    if ((pk || pkh) && !pw && ptaps > 1) {
         __shared__ float park[MT_CHUNK / 4];
         constexpr int Q = MT_CHUNK / 4;
         for (int base = 0; base < cnt; base += Q) {
@@ -193,10 +195,14 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
             for (int r = r_lo + threadIdx.x; r <= r_hi; r += 256) {
                 const int co = r / pCin, ci = r - co * pCin;
                 const int e0 = r * ptaps;
-                float* dst = pk + (size_t)co * ptaps * pCin + ci;
+                const size_t d0 = (size_t)co * ptaps * pCin + ci;
                 for (int tp = 0; tp < ptaps; ++tp) {
                     const int el = e0 + tp;
-                    if (el >= qs && el < qe) dst[(size_t)tp * pCin] = park[el - qs];
+                    if (el >= qs && el < qe) {
+                        const float x = park[el - qs];
+                        if (pk) pk[d0 + (size_t)tp * pCin] = x;
+                        if (pkh) pkh[d0 + (size_t)tp * pCin] = pf16 ? v2a_f2h<true>(x) : v2a_f2bf(x);
+                    }
                 }
             }
             __syncthreads();
@@ -220,8 +226,9 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
             if (mode & 2) { const float d = (ev - pv) * (1.0f - dec); ev = ev - d; }
             e[i] = ev;
         }
-        if (pk || pw) {
+        if (pk || pw || pkh) {
             if (pk) pk[((size_t)kco * ptaps + ktap) * pCin + kci] = pv;
+            if (pkh) pkh[((size_t)kco * ptaps + ktap) * pCin + kci] = pf16 ? v2a_f2h<true>(pv) : v2a_f2bf(pv);
             if (pw) {
                 const int kh = ktap / kwn, kw = ktap - kh * kwn;
                 pw[(((size_t)kco * kwn + kh) * (kwn + 1) + kw) * (pCin + 1) + kci] = pv;
@@ -313,7 +320,8 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
 }
 
 // One optimiser step over all tensors.  partial: nchunks doubles of scratch.
-// packs_dev: optional [tensors][4] int64 table {dst forward pack or 0, Cin, taps, dst channel-window pack or 0} -- the update kernel then
+// packs_dev: optional [tensors][6] int64 table {dst forward pack or 0, Cin, taps, dst channel-window pack or 0, dst 16-bit twin of the
+// forward pack or 0, 1 when that twin is IEEE fp16 (0: bf16)} -- the update kernel then
 // also writes the re-laid conv operands (see mt_adamw_ema_kernel); null: parameters only.
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
                         int zero_grad, const int64_t* packs_dev, hipStream_t s) {

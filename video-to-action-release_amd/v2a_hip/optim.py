@@ -65,13 +65,14 @@ class FusedAdamWEMA:
         return ls.value, gt.value, bool(sk.value), n.value
 
     def set_pack_rows(self, rows):
-        """rows[i] = (forward-pack address or 0, Cin, taps, channel-window-pack address or 0) of parameter i (PolicyEngine.opt_pack_rows):
+        """rows[i] = (forward-pack address or 0, Cin, taps, channel-window-pack address or 0, 16-bit twin address or 0, twin is fp16) of parameter i (PolicyEngine.opt_pack_rows):
         step(packs=True) then writes those conv operands from the update kernel itself.  None clears."""
         if rows is None:
             self.pack_table = None
             return
         assert len(rows) == len(self.params)
-        self.pack_table = torch.tensor([[int(a), max(int(b), 1), max(int(c), 1), int(d)] for a, b, c, d in rows], dtype=torch.int64).to(self.device)
+        self.pack_table = torch.tensor([[int(r[0]), max(int(r[1]), 1), max(int(r[2]), 1), int(r[3]), int(r[4]), int(r[5])] for r in rows],
+                                       dtype=torch.int64).to(self.device)
 
     pack_table = None
 

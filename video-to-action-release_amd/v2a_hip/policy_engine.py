@@ -440,21 +440,28 @@ class PolicyEngine:
     def opt_pack_rows(self, tensors):
         """For FusedAdamWEMA.set_pack_rows: per optimiser tensor (matched by address) the forward operand the update kernel should also
         write -- the [Cout][taps][Cin] pack of a conv with more than one tap (+ the stem's channel-window pack), the slice of the
-        concatenated FiLM operand of a FiLM weight / bias -- or zeros.  fp32 precision mode only (the 16-bit modes' packs carry twins).
+        concatenated FiLM operand of a FiLM weight / bias -- or zeros; in the 16-bit MFMA modes also the 16-bit twin of the forward operand.
         Returns (rows, serial)."""
         self.refresh_packs()                          # allocates every operand; fixes the addresses the rows point at
+        from ._lib import lib
+        bf16 = lib.v2a_get_precision() == 1
+        f16 = 1 if (bf16 and ops.POLICY_HALF[0] is torch.float16) else 0
         by_ptr = {}
         for c in self._convs.values():
             taps = c.kh * c.kw
+            tw = c._pf_h.data_ptr() if (bf16 and c._pf_h is not None) else 0
             if taps > 1:
-                by_ptr[c.w.data_ptr()] = (c._pf.data_ptr(), c.ci, taps, c._pw.data_ptr() if c.window else 0)
+                by_ptr[c.w.data_ptr()] = (c._pf.data_ptr(), c.ci, taps, c._pw.data_ptr() if c.window else 0, tw, f16)
+            elif tw:                                    # 1 x 1 / linear weights are their own fp32 operand: twin only
+                by_ptr[c.w.data_ptr()] = (0, c.w.numel(), 1, 0, tw, f16)
         if self.batch_film:
             for r in self.film:
                 w, b = r["ce"].w.detach(), r["ce"].b.detach()
                 o = r["film_off"]
-                by_ptr[w.data_ptr()] = (self._film_w.data_ptr() + 4 * o * self.film_gd, w.numel(), 1, 0)
-                by_ptr[b.data_ptr()] = (self._film_b.data_ptr() + 4 * o, b.numel(), 1, 0)
-        return [by_ptr.get(t.data_ptr(), (0, 1, 1, 0)) for t in tensors], self._mp_serial
+                tw = by_ptr.get(w.data_ptr(), (0, 0, 0, 0, 0, 0))[4]     # (its own 1 x 1 twin, if the 16-bit mode keeps one: same plain-copy indexing)
+                by_ptr[w.data_ptr()] = (self._film_w.data_ptr() + 4 * o * self.film_gd, w.numel(), 1, 0, tw, f16)
+                by_ptr[b.data_ptr()] = (self._film_b.data_ptr() + 4 * o, b.numel(), 1, 0, 0, 0)
+        return [by_ptr.get(t.data_ptr(), (0, 1, 1, 0, 0, 0)) for t in tensors], self._mp_serial
 
     def refresh_packs(self, which="all", skip_fwd=False):
         """Unconditionally re-pack conv weights (call once per train step after the optimiser; capturable).  which = "all" | "enc" |
@@ -522,7 +529,7 @@ class PolicyEngine:
         groups = ("enc", "unet") if which == "all" else (which,)
         for g in groups:
             # skip_fwd: the optimiser's update kernel wrote the forward packs itself (FusedAdamWEMA.step(packs=True))
-            if mp["n0"][g] and not (skip_fwd and not bf16):
+            if mp["n0"][g] and not skip_fwd:
                 check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch0"][g].data_ptr(), mp["n0"][g], 0, ops._stream()), "pack_weights_multi")
             if mp["n1"][g]:
                 check(lib.v2a_pack_weights_multi(mp["tab"].data_ptr(), mp["ch1"][g].data_ptr(), mp["n1"][g], 1, ops._stream()), "pack_weights_multi_t")

@@ -218,9 +218,9 @@ class PolicyTrainer:
 
     def _opt(self):
         ops.tstamp("optimiser begin")
-        # fp32 mode: the update kernel also writes the forward conv operands (no pack launch re-reads the parameters); the transposed
-        # data-gradient packs keep their launch
-        fused = self.fuse_packs and lib.v2a_get_precision() == 0
+        # the update kernel also writes the forward conv operands (and their 16-bit twins in the 16-bit MFMA modes): no pack launch re-reads
+        # the parameters; the transposed data-gradient packs keep their launch
+        fused = self.fuse_packs
         if fused and self._pack_serial != self.eng._mp_serial:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("optimiser pack table missing during graph capture; run one eager step first")
