@@ -372,7 +372,11 @@ int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, v
    twin is IEEE fp16}; the launch of v2a_pack_weights_multi that would
    read every parameter again is not needed for those operands) */
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad,
-                        const int64_t* packs_dev, v2a_stream_t s);
+                        const int64_t* packs_dev, int defer_ema, v2a_stream_t s);
+/* defer_ema = 1 above leaves the EMA replica (ema.update(), lb_online_trainer_v7.py:623) to this call: the same arithmetic on the same
+   values, launched where it overlaps other work (PolicyTrainer: under the next step's encoder forward).  A no-op when nothing is
+   pending.  mark_done = 1: an eager flush (the replica is being read between steps); the next optimiser step clears the flag otherwise. */
+int v2a_opt_apply_ema(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, int mark_done, v2a_stream_t s);
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, v2a_stream_t s);  /* 1/world after the RCCL sum */
 
 /* ---------------------------------------------------------------------------------------------- replay (csrc/replay.hip)

@@ -261,6 +261,43 @@ def _packs_check(use_graph, prec):
             assert torch.equal(eng._film_b[o:o + n2], r["ce"].b.detach())
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_deferred_ema_update_equals_the_inline_update(use_graph):
+    """PolicyTrainer defers the EMA replica's update of step n to the start of step n + 1 (under the encoder forward; `ema_policy`
+    flushes a pending update when read): after any number of steps -- read after every step, or only at the end -- the replica must be
+    bit-equal to the inline run (V2A_DEFER_EMA=0 = ema.update() right after opt.step(), lb_online_trainer_v7.py:623), parameters too."""
+    import random
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from v2a_hip.replay import ReplayStore
+    from v2a_hip.trainer import PolicyTrainer
+    runs = []
+    for defer, peek in ((False, False), (True, False), (True, True)):
+        torch.manual_seed(1)
+        pol = build_policy(DEFAULT_CONF).to("cuda:0")
+        store = ReplayStore(64, 200, 30, capacity_frames=40 * 16)
+        gen = torch.Generator().manual_seed(3)
+        for e in range(16):
+            n = 30 + e
+            store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
+                                  torch.rand(n - 1, 7, generator=gen) * 2 - 1)
+        np.random.seed(5); random.seed(5)
+        tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=use_graph)
+        tr.defer_ema = defer
+        mids = []
+        for it in range(5):
+            tr.step()
+            if peek and it in (1, 3):                  # reading the replica between steps flushes the pending update, once
+                mids.append([p.detach().clone() for p in tr.ema_policy.parameters()])
+        ema = [p.detach().clone() for p in tr.ema_policy.parameters()]
+        par = [p.detach().clone() for p in pol.parameters()]
+        assert tr._ema_dirty is False
+        runs.append((ema, par))
+    for k in (1, 2):
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[k][0])), "EMA replica differs from the inline update"
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[k][1]))
+    assert any(not torch.equal(a, b) for a, b in zip(runs[0][0], runs[0][1]))      # (the replica does lag the parameters)
+
+
 def test_policy_step_is_bitwise_reproducible():
     """two runs of the same seeded train steps give bitwise identical parameters, EMA weights and losses (graph
     replay included).  Replicas that stay bit-identical under data parallelism depend on exactly this."""

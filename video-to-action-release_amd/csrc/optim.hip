@@ -31,6 +31,10 @@ struct OptState {           // device resident
     float growth_factor, backoff_factor;
     int skip;                // this step found a non-finite gradient: parameters / moments / Adam step untouched
     long long skipped_steps;
+    // deferred EMA (v2a_opt_step_packed(defer_ema = 1)): this step's EMA update has NOT been applied by the update kernel; mt_ema_apply_kernel
+    // applies it (with this step's ema_mode / ema_decay, which stay valid until the next opt_advance) and the next opt_advance -- or
+    // v2a_opt_apply_ema(mark_done = 1) -- clears the flag
+    int ema_pending;
 };
 
 __global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, const int* chunks, double* partial) {
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, con
 }
 
 // one workgroup: finish the norm, advance step counters, derive this step's scalars
-__global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const double* partial, int nchunks) {
+__global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const double* partial, int nchunks, int defer_ema) {
     __shared__ double sm[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < nchunks; i += 256) s += partial[i];
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
     }
     st->ema_decay = (float)dec;
     st->ema_mode = mode;
+    st->ema_pending = (defer_ema && mode) ? 1 : 0;
 }
 
 // `packs` (optional, int64 [tensor][6] = {dst, Cin, taps, dst_window, dst_16bit_twin, twin is fp16}): the updated parameter also goes, re-laid, into the conv operand
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
 // parameter again (0.36 ms of launches in the policy step's serial tail).  (co, ci, tap) of the thread's first element by one
 // decomposition, then carried forward in steps of 256 elements.
 __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table, const int* chunks, const OptState* st, int zero_grad,
-                                                           const int64_t* packs) {
+                                                           const int64_t* packs, int defer_ema) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
     float* pk = packs ? reinterpret_cast<float*>(packs[t * 6 + 0]) : nullptr;
     float* pw = packs ? reinterpret_cast<float*>(packs[t * 6 + 3]) : nullptr;
@@ -142,7 +147,9 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
     float* g = reinterpret_cast<float*>(table[t * 6 + 1]) + start;
     float* m = reinterpret_cast<float*>(table[t * 6 + 2]) + start;
     float* v = reinterpret_cast<float*>(table[t * 6 + 3]) + start;
-    float* e = table[t * 6 + 4] ? reinterpret_cast<float*>(table[t * 6 + 4]) + start : nullptr;
+    // (defer_ema: the EMA replica is left to mt_ema_apply_kernel, which runs under the NEXT step's encoder forward: 12 of the 48 bytes
+    // this kernel moves per parameter leave the serial tail of the step)
+    float* e = (table[t * 6 + 4] && !defer_ema) ? reinterpret_cast<float*>(table[t * 6 + 4]) + start : nullptr;
     const long long n = table[t * 6 + 5];
     const int cnt = (int)min((long long)MT_CHUNK, n - start);
     const float clip = st->clip_coef, b1 = (float)st->b1, b2 = (float)st->b2, eps = (float)st->eps;
@@ -241,6 +248,28 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
     }
 }
 
+// The EMA update of the last optimiser step, when that step deferred it (OptState.ema_pending): ema = lerp(ema, p) / copy, exactly the
+// arithmetic of the inline path above on the same (p, ema) values -- p is not touched between the two points in time.
+__global__ __launch_bounds__(256) void mt_ema_apply_kernel(const int64_t* table, const int* chunks, const OptState* st) {
+    if (!st->ema_pending) return;
+    const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
+    if (!table[t * 6 + 4]) return;
+    const float* p = reinterpret_cast<const float*>(table[t * 6 + 0]) + start;
+    float* e = reinterpret_cast<float*>(table[t * 6 + 4]) + start;
+    const long long n = table[t * 6 + 5];
+    const int cnt = (int)min((long long)MT_CHUNK, n - start);
+    const float dec = st->ema_decay;
+    const int mode = st->ema_mode;
+    if (!mode) return;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const float pv = p[i];
+        float ev = (mode & 1) ? pv : e[i];
+        if (mode & 2) { const float d = (ev - pv) * (1.0f - dec); ev = ev - d; }
+        e[i] = ev;
+    }
+}
+__global__ void opt_ema_done_kernel(OptState* st) { st->ema_pending = 0; }
+
 // grads *= 1/world (after an RCCL sum all-reduce) -- folded into the clip by scaling the table's grads in place
 __global__ void mt_scale_grads_kernel(const int64_t* table, const int* chunks, float scale) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
@@ -315,6 +344,7 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
     s->step = step;
     s->ema_step = ema_step;
     s->ema_initted = ema_initted ? 1 : 0;
+    s->ema_pending = 0;
     if (lr > 0) s->lr = lr;
     return V2A_OK;
 }
@@ -323,21 +353,36 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
 // packs_dev: optional [tensors][6] int64 table {dst forward pack or 0, Cin, taps, dst channel-window pack or 0, dst 16-bit twin of the
 // forward pack or 0, 1 when that twin is IEEE fp16 (0: bf16)} -- the update kernel then
 // also writes the re-laid conv operands (see mt_adamw_ema_kernel); null: parameters only.
+// defer_ema = 1: the EMA replica is NOT updated here; v2a_opt_apply_ema applies this step's update later (before the next optimiser
+// step, on any stream ordered after this call and before that step) -- same values, off the serial tail.
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
-                        int zero_grad, const int64_t* packs_dev, hipStream_t s) {
+                        int zero_grad, const int64_t* packs_dev, int defer_ema, hipStream_t s) {
     if (!table_dev || !chunks_dev || !state_dev || !partial_dev || nchunks <= 0) return V2A_ERR_ARG;
     hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, partial_dev);
     V2A_CHECK_LAUNCH();
-    hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(256), 0, s, (OptState*)state_dev, partial_dev, nchunks);
+    hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(256), 0, s, (OptState*)state_dev, partial_dev, nchunks, defer_ema ? 1 : 0);
     V2A_CHECK_LAUNCH();
     hipLaunchKernelGGL(mt_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, (const OptState*)state_dev, zero_grad,
-                       packs_dev);
+                       packs_dev, defer_ema ? 1 : 0);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
                  int zero_grad, hipStream_t s) {
-    return v2a_opt_step_packed(table_dev, chunks_dev, nchunks, state_dev, partial_dev, zero_grad, nullptr, s);
+    return v2a_opt_step_packed(table_dev, chunks_dev, nchunks, state_dev, partial_dev, zero_grad, nullptr, 0, s);
+}
+// The EMA update a v2a_opt_step_packed(defer_ema = 1) call left pending (a no-op when none is: safe inside a replayed graph).
+// mark_done = 1 also clears the pending flag (an eager flush between steps: the next replay's apply launch then does nothing);
+// inside the step graph the next optimiser step clears it.
+int v2a_opt_apply_ema(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, int mark_done, hipStream_t s) {
+    if (!table_dev || !chunks_dev || !state_dev || nchunks <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(mt_ema_apply_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, (const OptState*)state_dev);
+    V2A_CHECK_LAUNCH();
+    if (mark_done) {
+        hipLaunchKernelGGL(opt_ema_done_kernel, dim3(1), dim3(1), 0, s, (OptState*)state_dev);
+        V2A_CHECK_LAUNCH();
+    }
+    return V2A_OK;
 }
 
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, hipStream_t s) {

@@ -76,10 +76,17 @@ class FusedAdamWEMA:
 
     pack_table = None
 
-    def step(self, zero_grad=True, packs=False):
+    def step(self, zero_grad=True, packs=False, defer_ema=False):
+        """defer_ema: the EMA replica is left to apply_ema() (same values; the caller launches it where it overlaps other work and
+        before the next step() -- PolicyTrainer does, and flushes whenever the replica is read)."""
         pk = self.pack_table.data_ptr() if (packs and self.pack_table is not None) else None
         check(lib.v2a_opt_step_packed(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
-                                      self.partial.data_ptr(), 1 if zero_grad else 0, pk, ops._stream()), "opt_step")
+                                      self.partial.data_ptr(), 1 if zero_grad else 0, pk, 1 if defer_ema else 0, ops._stream()), "opt_step")
+
+    def apply_ema(self, mark_done=False):
+        """Apply the EMA update a step(defer_ema=True) left pending (a no-op on the device when none is)."""
+        check(lib.v2a_opt_apply_ema(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
+                                    1 if mark_done else 0, ops._stream()), "opt_apply_ema")
 
     def scale_grads(self, scale: float):
         check(lib.v2a_opt_scale_grads(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, float(scale), ops._stream()),

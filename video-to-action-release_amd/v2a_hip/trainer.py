@@ -57,8 +57,9 @@ class PolicyTrainer:
         # config's setting; the checkpoint writer (_EMAHandle.state_dict) honours it
         self.ema_include_online_model = bool(ema_params.pop("include_online_model", True))
         # EMA replica (ema_pytorch deep-copies the online model: lb_online_trainer_v7.py:135)
-        self.ema_policy = copy.deepcopy(policy)
-        self.ema_policy.requires_grad_(False)
+        self._ema_policy = copy.deepcopy(policy)
+        self._ema_policy.requires_grad_(False)
+        self._ema_dirty = False
         self.names = policy.trainable_names()
         P = dict(policy.named_parameters())
         EP = dict(self.ema_policy.named_parameters())
@@ -107,10 +108,24 @@ class PolicyTrainer:
         # on a side stream, under the encoder forward (V2A_SPLIT_PACKS=0: everything right after the optimiser, as before)
         self.split_packs = os.environ.get("V2A_SPLIT_PACKS", "1") != "0"
         self.fuse_packs = os.environ.get("V2A_FUSE_PACKS", "1") != "0"      # forward conv operands written by the optimiser's update kernel
+        # Experiment, default off (V2A_DEFER_EMA=1 enables): the EMA replica is read at evaluation / checkpoint time only, yet its update
+        # is 12 of the 48 bytes per parameter the update kernel moves in the serial tail.  Deferred, that kernel skips it and the SAME
+        # update (same p, same decay; bit-equal, tests) runs at the start of the next step on the pack stream, under the encoder forward;
+        # `ema_policy` (a property) flushes a pending update before anyone sees the replica.  Measured: 8.21 vs 8.10 ms -- the extra
+        # launch competes with the encoder forward for what the tail saves, and re-reads the parameters.
+        self.defer_ema = os.environ.get("V2A_DEFER_EMA", "0") == "1"
         self._pack_serial = -1
         self._packs_fused = False
         self._pack_side = None
         self._wg_keep = None
+
+    @property
+    def ema_policy(self):
+        """The EMA replica (ema_pytorch's ema_model).  A deferred update of the last step is applied first (see defer_ema)."""
+        if self._ema_dirty:
+            self._ema_dirty = False
+            self.opt.apply_ema(mark_done=True)
+        return self._ema_policy
 
     # ------------------------------------------------------------------ pieces
     def _draw_indices(self):
@@ -150,12 +165,15 @@ class PolicyTrainer:
         B = self.B
         ops.tstamp_reset()
         ops.tstamp("step begin")
-        if self.split_packs:                           # last step's ConditionalUnet1D weights -> packed operands, under the encoder forward
-            if self._pack_side is None:
+        if self.split_packs or self.defer_ema:         # last step's ConditionalUnet1D weights -> packed operands, and its deferred EMA
+            if self._pack_side is None:                # update, under the encoder forward (joined before the ConditionalUnet1D forward)
                 self._pack_side = torch.cuda.Stream(device=self.device)
             self._pack_side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._pack_side):
-                self.eng.refresh_packs("unet", skip_fwd=self._packs_fused)
+                if self.split_packs:
+                    self.eng.refresh_packs("unet", skip_fwd=self._packs_fused)
+                if self.defer_ema:
+                    self.opt.apply_ema(mark_done=False)      # (a no-op on the device when nothing is pending: first step, after a flush)
             self.eng._pack_join = self._pack_side
         oo = torch.empty((2 * B, 3, st.H, st.W), dtype=torch.float32, device=self.device)      # start | goal frames side by side: the
         o0, o1 = oo[:B], oo[B:]                                                                 # two camera encoders run as one stacked chain
@@ -227,7 +245,7 @@ class PolicyTrainer:
             rows, self._pack_serial = self.eng.opt_pack_rows(self.opt.params)
             self.opt.set_pack_rows(rows)
         self._packs_fused = fused
-        self.opt.step(zero_grad=True, packs=fused)
+        self.opt.step(zero_grad=True, packs=fused, defer_ema=self.defer_ema)
         ops.tstamp("optimiser done / packs begin")
         if self.split_packs:
             self.eng.refresh_packs("enc", skip_fwd=fused)
@@ -302,6 +320,7 @@ class PolicyTrainer:
                     self.phase_events.append(pe)
         if self.split_packs:
             self.eng._packs_pending = "unet"           # any reader of a UNet operand outside the next step refreshes it first
+        self._ema_dirty = self.defer_ema               # (host-side mirror of OptState.ema_pending: set per step, also under graph replay)
         self.step_count += 1
         return self.loss
 
