@@ -116,6 +116,9 @@ for leg_name in ("policy", "policy_bf16", "video", "video_bf16"):
             a = traffic.setdefault(key, [0.0, 0])     # template variants sharing a tile: launch-count weighted mean
             a[0] += v["hbm_bytes_per_launch_corrected"] * v["n"]
             a[1] += v["n"]
+    hx = [(k, a) for k, a in traffic.items() if k.startswith("conv_halo_x3<")]       # + the family key bench.py's roofline uses
+    if hx:
+        traffic["conv_halo_x3"] = [sum(a[0] for _, a in hx), sum(a[1] for _, a in hx)]
     rt[leg_name] = {k: a[0] / max(a[1], 1) for k, a in traffic.items()}
 rt["legs"] = leg_totals
 out["roofline_traffic"] = rt
