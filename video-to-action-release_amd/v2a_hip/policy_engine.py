@@ -181,7 +181,9 @@ class PolicyEngine:
         # grouped weight-gradient launches: "stage" = one launch per ResNet stage (and per <= 16 ConditionalUnet1D layers), "enc" = one
         # group per camera encoder at the end of its chain, "0" = every gradient its own launch (round-2 behaviour)
         self._wgb_mode = _os.environ.get("V2A_WGRAD_BATCH", "enc")
-        self._wgb_side = _os.environ.get("V2A_WGRAD_BATCH_STREAM", "0") == "1"
+        # (the round-3 experiment that ran the grouped launches on per-encoder side streams -- V2A_WGRAD_BATCH_STREAM=1 -- was slower
+        # and, at the end of round 4, crashes the process in the first step; the switch is gone, the code path is kept off)
+        self._wgb_side = False
         self._wgb_streams = {}
         self._side = None
         self._keep = []
