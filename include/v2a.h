@@ -110,6 +110,12 @@ int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* g
                          int N, int S, int C, int G, float eps, int act, const float* stats1, const float* stats2, void* workspace,
                          size_t workspace_bytes, v2a_stream_t stream);
 int v2a_groupnorm_takes_slabs(int S, int C, int G);
+/* post-activation addend of the NEXT fp32 GroupNorm forward launch (consumed by it): out = act(gn(x) ...) + post, post dense or still the
+   split-K slabs (+ bias) of the conv that produces it -- the residual branch of ConditionalResidualBlock1D (conditional_unet1d.py:46-66:
+   `out = self.blocks[1](out); out = out + self.residual_conv(x)`) without an add / reduce launch of its own.  Only where
+   v2a_groupnorm_takes_post says 1 (slabs of 256 / 512 / 1024 elements, 16 ... 128 channels per group); V2A_ERR_ARG otherwise. */
+int v2a_groupnorm_set_post(const float* post, const float* post_slabs, int nslab, size_t slab_stride, const float* post_bias);
+int v2a_groupnorm_takes_post(int S, int C, int G);
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                         int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* reserved,

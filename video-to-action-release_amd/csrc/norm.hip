@@ -46,6 +46,14 @@ struct GnDesc {
     float* sout;            // [N][S][C] or null
     int nslab;
     size_t slab_stride;
+    // float4 wave forward only -- added to the OUTPUT (after activation / FiLM): the residual branch of a ConditionalResidualBlock1D
+    // (conditional_unet1d.py:46-66: out = blocks[1](out) + residual_conv(x)), either dense (the identity branch, or a finished 1x1 conv) or
+    // still the split-K slabs of the 1x1 residual conv (+ its bias): out = y + ((sum_s post_slabs[s] + post_bias) | post)
+    const float* post;
+    const float* post_slabs;
+    const float* post_bias;
+    int post_nslab;
+    size_t post_stride;
     // two parameter sets over one stacked batch (the policy's two camera encoders as ONE chain): samples n >= n_split use gamma2 / beta2
     const float* gamma2;
     const float* beta2;
@@ -870,6 +878,14 @@ __global__ __launch_bounds__(64) void gn_wavev_fwd(const GnDesc p) {
             if (film) a = f0[e] * a + f1[e];
             o[e] = a;
         }
+        if (p.post_nslab > 0) {                       // (the reduce kernel's order: slabs ascending from 0, then the bias, then the other addend)
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < p.post_nslab; ++sl) t += *reinterpret_cast<const f32x4*>(p.post_slabs + (size_t)sl * p.post_stride + off[j]);
+            if (p.post_bias) t += *reinterpret_cast<const f32x4*>(p.post_bias + c0);
+            o = t + o;
+        } else if (p.post) {
+            o = o + *reinterpret_cast<const f32x4*>(p.post + off[j]);
+        }
         *reinterpret_cast<f32x4*>(p.y + off[j]) = o;
         if (p.yh) gn_store_twin4(p.yh, off[j] >> 2, o, p.yh_f16);
     }
@@ -958,8 +974,9 @@ static int gn_wavev_passes(const GnDesc& p, int cg) {
     if (E != 256 && E != 512 && E != 1024) return 0;
     const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.residual | (uintptr_t)p.dout | (uintptr_t)p.dres | (uintptr_t)p.gamma |
                         (uintptr_t)p.beta | (uintptr_t)p.gamma2 | (uintptr_t)p.beta2 | (uintptr_t)p.slabs | (uintptr_t)p.cbias |
-                        (uintptr_t)p.sresid | (uintptr_t)p.sout | (uintptr_t)p.colsum | (uintptr_t)p.yh | (uintptr_t)p.film | (uintptr_t)p.dfilm;
-    if ((a & 15) != 0 || (p.slab_stride & 3) != 0) return 0;
+                        (uintptr_t)p.sresid | (uintptr_t)p.sout | (uintptr_t)p.colsum | (uintptr_t)p.yh | (uintptr_t)p.film | (uintptr_t)p.dfilm |
+                        (uintptr_t)p.post | (uintptr_t)p.post_slabs | (uintptr_t)p.post_bias;
+    if ((a & 15) != 0 || (p.slab_stride & 3) != 0 || (p.post_stride & 3) != 0) return 0;
     return (int)(E / 256);
 }
 #define V2A_GNWV_LAUNCH(KERN, CGV, NJV) hipLaunchKernelGGL((KERN<CGV, NJV>), grid, block, 0, stream, p)
@@ -1118,6 +1135,31 @@ extern "C" int v2a_groupnorm_set_second(const float* gamma2, const float* beta2,
     g_gn_gamma2 = gamma2; g_gn_beta2 = beta2; g_gn_nsplit = gamma2 ? n_split : 0x7fffffff;
     return V2A_OK;
 }
+// Post-activation addend of the NEXT fp32 GroupNorm FORWARD launch (consumed by it; float4 wave path only, V2A_ERR_ARG otherwise --
+// ask v2a_groupnorm_takes_post first): dense `post`, or `nslab` split-K slabs (+ bias) of the conv that produces it.
+static const float* g_gn_post = nullptr;
+static const float* g_gn_post_slabs = nullptr;
+static const float* g_gn_post_bias = nullptr;
+static int g_gn_post_nslab = 0;
+static size_t g_gn_post_stride = 0;
+extern "C" int v2a_groupnorm_set_post(const float* post, const float* post_slabs, int nslab, size_t slab_stride, const float* post_bias) {
+    if ((post && post_slabs) || (post_slabs && nslab < 1) || (!post_slabs && nslab > 0)) return V2A_ERR_ARG;
+    g_gn_post = post; g_gn_post_slabs = post_slabs; g_gn_post_bias = post_slabs ? post_bias : nullptr;
+    g_gn_post_nslab = post_slabs ? nslab : 0; g_gn_post_stride = slab_stride;
+    return V2A_OK;
+}
+extern "C" int v2a_groupnorm_takes_post(int S, int C, int G) {
+    if (G <= 0 || C % G != 0) return 0;
+    GnDesc t = {};
+    t.S = S; t.C = C;
+    return gn_wavev_passes(t, C / G) > 0 ? 1 : 0;
+}
+static bool gn_take_post(GnDesc& p) {
+    p.post = g_gn_post; p.post_slabs = g_gn_post_slabs; p.post_bias = g_gn_post_bias; p.post_nslab = g_gn_post_nslab; p.post_stride = g_gn_post_stride;
+    const bool any = g_gn_post || g_gn_post_slabs;
+    g_gn_post = nullptr; g_gn_post_slabs = nullptr; g_gn_post_bias = nullptr; g_gn_post_nslab = 0; g_gn_post_stride = 0;
+    return any;
+}
 extern int g_v2a_policy_f16;
 static void gn_take_second(GnDesc& p) {
     p.yh_f16 = g_v2a_policy_f16;
@@ -1128,11 +1170,12 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
                        const float* stats2, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) { GnDesc t = {}; gn_take_second(t); return V2A_ERR_ARG; }
-    if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
-    if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) { GnDesc t = {}; gn_take_second(t); gn_take_post(t); return V2A_ERR_ARG; }
+    if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) { GnDesc t = {}; gn_take_post(t); return V2A_ERR_ARG; }
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) { GnDesc t = {}; gn_take_post(t); return V2A_ERR_ARG; }
     GnDesc p = {};
     gn_take_second(p);
+    const bool has_post = gn_take_post(p);
     p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
     p.yh = (unsigned short*)y_h;
@@ -1141,6 +1184,7 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
     const int cg = C / G;
     const long E = (long)S * cg;
     if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.cbias = cbias; p.sout = (float*)x; }
+    if (has_post && (x2 || !gn_wave_ok(S, cg) || gn_wavev_passes(p, cg) == 0)) return V2A_ERR_ARG;      // only the float4 wave kernels add it
     if (!x2 && gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;             // 8 values per lane (the ConditionalUnet1D slabs) or 16

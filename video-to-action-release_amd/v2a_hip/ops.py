@@ -162,6 +162,10 @@ def gn_takes_slabs(S, C, G):
     return bool(lib.v2a_groupnorm_takes_slabs(S, C, G))
 
 
+def gn_takes_post(S, C, G):
+    return bool(lib.v2a_groupnorm_takes_post(S, C, G))
+
+
 _DEFER = os.environ.get('V2A_DEFER_REDUCE', '1') != '0'
 
 
@@ -770,7 +774,7 @@ def _gn_second(second):
 
 
 def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None,
-                  stats=None, stats2=None, second=None):
+                  stats=None, stats2=None, second=None, post=None, post_slabs=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
     Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
     that consumes y takes it as x_h and skips its cast launch)."""
@@ -790,6 +794,17 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
         yh = torch.empty((N, S, C), dtype=POLICY_HALF[0], device=x.device)
         twin_out.append(yh)
     _gn_second(second)
+    if post is not None or post_slabs is not None:
+        # added to the OUTPUT (after activation / FiLM): dense tensor, or the split-K slabs (+ bias) of the conv that produces it
+        # (conv2d(defer=True) on a scratch lane of its own); float4 wave kernels only -- ask gn_takes_post first
+        assert gn_takes_post(S, C, G) and x2 is None and not (post is not None and post_slabs is not None)
+        if post_slabs is not None:
+            assert post_slabs.residual is None and post_slabs.stride == N * S * C
+            check(lib.v2a_groupnorm_set_post(None, post_slabs.ws.data_ptr(), post_slabs.n, post_slabs.stride, _p(post_slabs.bias)), "groupnorm_set_post")
+        else:
+            _chk(post, "post")
+            assert post.numel() == N * S * C
+            check(lib.v2a_groupnorm_set_post(post.data_ptr(), None, 0, 0, None), "groupnorm_set_post")
     if slabs is not None:      # x is the (still unwritten) conv output: the kernel sums the conv's split-K slabs and stores x too
         assert slabs.residual is None
         check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), None, C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),

@@ -31,6 +31,7 @@ def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
 
 _PRIO = __import__('os').environ.get('V2A_PRIO') == '1'                    # experiment: chain streams at high priority
 _GN_DEFER = __import__('os').environ.get('V2A_GN_DEFER', '1') != '0'      # 0: every conv runs its own split-K reduce (A/B)
+_GN_POST = __import__('os').environ.get('V2A_GN_POST', '1') != '0'          # 0: the residual add of a ConditionalResidualBlock1D as its own launch (A/B)
 _STEM_WINDOW = __import__('os').environ.get('V2A_STEM_WINDOW', '1') != '0'  # 0: RGB stem on the scalar-gather conv / padded-copy weight gradient (A/B)
 
 class _Conv:
@@ -544,7 +545,7 @@ class PolicyEngine:
             self._film_ver = self._film_key()
 
     # ------------------------------------------------------------------ encoder
-    def _gn(self, x4, pre, G, act, residual=None, film=None, slabs=None):
+    def _gn(self, x4, pre, G, act, residual=None, film=None, slabs=None, post=None, post_slabs=None):
         """slabs: x4 is the not-yet-reduced output of a conv launched with defer=True (ops.Slabs); the GroupNorm launch finishes it."""
         N = x4.shape[0]
         C = x4.shape[-1]
@@ -552,7 +553,7 @@ class PolicyEngine:
         r3 = residual.view(N, -1, C) if residual is not None else None
         tw = [] if (C % 64 == 0 and ops.lib.v2a_get_precision() == 1) else None      # bf16-MFMA mode: the consuming conv's operand twin
         y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs,
-                                          twin_out=tw)
+                                          twin_out=tw, post=None if post is None else post.view(N, -1, C), post_slabs=post_slabs)
         self._set_tw(tw[0] if tw else None, y)       # taken by the caller right after (x_h of the next conv): no cast launch
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
@@ -989,14 +990,30 @@ class PolicyEngine:
         a0 = a0.view(B, T, co)
         a0_tw = self._take_tw(a0)
         ka = []
+        # the residual branch rides on the second GroupNorm launch (out = mish(gn(c1)) + residual_conv(x), conditional_unet1d.py:62-65): the
+        # identity branch as a dense addend, the 1 x 1 conv branch as its split-K slabs left on a scratch lane of their own -- no add / reduce
+        # launch on the serial chain (bit-equal: the kernel adds in the reduce kernel's order).  fp32 mode, float4 wave GroupNorm only.
+        fuse = _GN_POST and ops.lib.v2a_get_precision() == 0 and ops.gn_takes_post(T, co, G)
+        p_dense, p_slabs = None, None
+        if fuse:
+            if r["rc"] is None:
+                p_dense = x
+            else:
+                with ops.ws_lane(5):
+                    rcy, p_slabs = self._c1d(x, r["rc"], 1, x2=x2, pad=0, defer=True)
+                if p_slabs is None:
+                    p_dense = rcy                                  # (the plan did not split: a finished tensor)
         c1, sl = self._c1d(a0, r["c1"], k, keep_h=ka, defer=True, x_h=a0_tw) if dfr else (self._c1d(a0, r["c1"], k, keep_h=ka, x_h=a0_tw), None)
-        a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish", slabs=sl)
+        a1, s1 = self._gn(c1.view(B, 1, T, co), r["pre"] + ".blocks.1.block.1", G, "mish", slabs=sl,
+                          post=None if p_dense is None else p_dense.reshape(B, 1, T, co), post_slabs=p_slabs)
         a1 = a1.view(B, T, co)
         x_h = kx[0] if kx else None                              # the twins also serve rc's and both weight gradients
         x2_h = kx[1] if (len(kx) > 1 and x2 is not None) else None
         if x2 is not None and x2_h is None:
             x_h = None
-        if r["rc"] is not None:
+        if fuse:
+            out = a1
+        elif r["rc"] is not None:
             out = self._c1d(x, r["rc"], 1, x2=x2, residual=a1, pad=0)
         else:
             out = ops.axpy(a1, x)
