@@ -382,6 +382,9 @@ int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nch
 /* defer_ema = 1 above leaves the EMA replica (ema.update(), lb_online_trainer_v7.py:623) to this call: the same arithmetic on the same
    values, launched where it overlaps other work (PolicyTrainer: under the next step's encoder forward).  A no-op when nothing is
    pending.  mark_done = 1: an eager flush (the replica is being read between steps); the next optimiser step clears the flag otherwise. */
+/* gradient-norm partial sums of chunks [first, first + count) ahead of the step (those gradients are final earlier: the ConditionalUnet1D
+   slice, while the encoder backward runs); the next v2a_opt_step / _packed call on the same `partial` sums only the rest */
+int v2a_opt_presum(const int64_t* table_dev, const int* chunks_dev, int first, int count, double* partial_dev, v2a_stream_t s);
 int v2a_opt_apply_ema(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, int mark_done, v2a_stream_t s);
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, v2a_stream_t s);  /* 1/world after the RCCL sum */
 

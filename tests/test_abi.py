@@ -61,6 +61,8 @@ def test_argument_validation_returns_error_codes_without_touching_the_device():
     assert lib.v2a_nchw_to_nhwc4p(None, 0, None, 2, 128, 128, 3, 1, None) == ERR_ARG
     assert lib.v2a_opt_step_packed(None, None, 0, None, None, 1, None, 0, None) == ERR_ARG
     assert lib.v2a_opt_apply_ema(None, None, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_opt_presum(None, None, 0, 0, None, None) == ERR_ARG
+    assert lib.v2a_groupnorm_set_post(None, None, 3, 0, None) == ERR_ARG and lib.v2a_groupnorm_takes_post(16, 256, 8) in (0, 1)
     # host-side sizing of the split slabs / partials
     assert lib.v2a_conv2d_wgrad_workspace_bytes(65536, 64, 576) > 0
     assert lib.v2a_conv2d_wgrad_h_workspace_bytes(229376, 128, 1152) >= 128 * 1152 * 4 * 2

@@ -37,8 +37,10 @@ struct OptState {           // device resident
     int ema_pending;
 };
 
-__global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, const int* chunks, double* partial) {
+__global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, const int* chunks_all, double* partial_all, int chunk0) {
     __shared__ double sm[4];
+    const int* chunks = chunks_all + 2 * chunk0;       // (a launch may cover a sub-range of the chunk list: v2a_opt_presum)
+    double* partial = partial_all + chunk0;
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
     const float* g = reinterpret_cast<const float*>(table[t * 6 + 1]);
     const long long n = table[t * 6 + 5];
@@ -279,7 +281,24 @@ __global__ void mt_scale_grads_kernel(const int64_t* table, const int* chunks, f
     for (int i = threadIdx.x; i < cnt; i += 256) g[i] *= scale;
 }
 
+static int g_presummed = 0;       // chunks whose gradient sums of squares are already in `partial` for the NEXT v2a_opt_step* call ...
+static int g_presum_first = 0;
+static const double* g_presum_partial = nullptr;      // ... on THIS partial buffer (any other optimiser's step ignores and clears it)
+
 extern "C" {
+
+// Gradient-norm partial sums of chunks [first, first + count) ahead of the optimiser step: the ConditionalUnet1D slice (75 % of the
+// parameters) is final long before the encoders' -- PolicyTrainer sums it on the weight-gradient stream while the encoder backward runs;
+// the next v2a_opt_step / _packed call (same table, same `partial`, a stream ordered after this one) then sums only the remaining chunks.
+int v2a_opt_presum(const int64_t* table_dev, const int* chunks_dev, int first, int count, double* partial_dev, hipStream_t s) {
+    if (!table_dev || !chunks_dev || !partial_dev || first < 0 || count <= 0) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(count), dim3(256), 0, s, table_dev, chunks_dev, partial_dev, first);
+    V2A_CHECK_LAUNCH();
+    g_presum_first = first;
+    g_presummed = count;
+    g_presum_partial = partial_dev;
+    return V2A_OK;
+}
 
 int v2a_opt_chunk_elems(void) { return MT_CHUNK; }
 size_t v2a_opt_state_bytes(void) { return sizeof(OptState); }
@@ -358,8 +377,22 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
                         int zero_grad, const int64_t* packs_dev, int defer_ema, hipStream_t s) {
     if (!table_dev || !chunks_dev || !state_dev || !partial_dev || nchunks <= 0) return V2A_ERR_ARG;
-    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, partial_dev);
-    V2A_CHECK_LAUNCH();
+    // chunks [pf, pf + pc): summed earlier on this partial buffer (v2a_opt_presum); the rest in up to two launches here
+    int pf = 0, pc = 0;
+    if (g_presummed > 0 && g_presum_partial == partial_dev && g_presum_first >= 0 && g_presum_first + g_presummed <= nchunks) {
+        pf = g_presum_first;
+        pc = g_presummed;
+    }
+    g_presummed = 0;
+    g_presum_partial = nullptr;
+    if (pf > 0) {
+        hipLaunchKernelGGL(mt_sumsq_kernel, dim3(pf), dim3(256), 0, s, table_dev, chunks_dev, partial_dev, 0);
+        V2A_CHECK_LAUNCH();
+    }
+    if (pf + pc < nchunks) {
+        hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks - pf - pc), dim3(256), 0, s, table_dev, chunks_dev, partial_dev, pf + pc);
+        V2A_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(256), 0, s, (OptState*)state_dev, partial_dev, nchunks, defer_ema ? 1 : 0);
     V2A_CHECK_LAUNCH();
     hipLaunchKernelGGL(mt_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, (const OptState*)state_dev, zero_grad,

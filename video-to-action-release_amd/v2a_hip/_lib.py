@@ -161,6 +161,7 @@ SIGNATURES = {
     "v2a_opt_step": (I, [P, P, I, P, P, I, P]),
     "v2a_opt_step_packed": (I, [P, P, I, P, P, I, P, I, P]),
     "v2a_opt_apply_ema": (I, [P, P, I, P, I, P]),
+    "v2a_opt_presum": (I, [P, P, I, I, P, P]),
     "v2a_opt_scale_grads": (I, [P, P, I, F, P]),
     "v2a_replay_sample_indices": (I, [P, P, P, I, I, I, P, P]),
     "v2a_replay_count_uniform_below": (I, [P, I, D]),

@@ -83,6 +83,18 @@ class FusedAdamWEMA:
         check(lib.v2a_opt_step_packed(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
                                       self.partial.data_ptr(), 1 if zero_grad else 0, pk, 1 if defer_ema else 0, ops._stream()), "opt_step")
 
+    def chunk_range(self, t0, t1):
+        """(first chunk, number of chunks) covering tensors t0 .. t1 - 1 of the optimiser's list."""
+        chunk = lib.v2a_opt_chunk_elems()
+        nch = [-(-p.numel() // chunk) for p in self.params]
+        return sum(nch[:t0]), sum(nch[t0:t1])
+
+    def presum(self, first, count):
+        """Sum the squares of the gradients of chunks [first, first + count) now (current stream); the next step() sums the rest."""
+        if count > 0:
+            check(lib.v2a_opt_presum(self.table.data_ptr(), self.chunks.data_ptr(), int(first), int(count), self.partial.data_ptr(), ops._stream()),
+                  "opt_presum")
+
     def apply_ema(self, mark_done=False):
         """Apply the EMA update a step(defer_ema=True) left pending (a no-op on the device when none is)."""
         check(lib.v2a_opt_apply_ema(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),

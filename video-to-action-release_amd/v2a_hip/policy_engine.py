@@ -435,6 +435,7 @@ class PolicyEngine:
         self._film_keep = (t0, t1, c0, c1)              # keep the tables alive until the launches ran
         self._film_ver = self._film_key()
 
+    on_unet_wgrads_done = None     # optional callback, runs on the deferred weight-gradient stream right after those launches
     _packs_pending = None      # "unet": the trainer postponed that group's re-pack to the start of its next step (see refresh_packs)
     _pack_join = None          # stream the UNet forward has to wait for (the side stream that group's re-pack was launched on)
 
@@ -1363,6 +1364,8 @@ class PolicyEngine:
             self._wg_stream.wait_stream(main)
             with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
                 self._launch_deferred(deferred)
+                if self.on_unet_wgrads_done is not None:       # (trainer: the model.* slice of the arena is final -> its gradient-norm partial sums)
+                    self.on_unet_wgrads_done()
         self._in_enc = True
         try:
             if "_stacked" in st["save_enc"]:

@@ -114,10 +114,23 @@ class PolicyTrainer:
         # `ema_policy` (a property) flushes a pending update before anyone sees the replica.  Measured: 8.21 vs 8.10 ms -- the extra
         # launch competes with the encoder forward for what the tail saves, and re-reads the parameters.
         self.defer_ema = os.environ.get("V2A_DEFER_EMA", "0") == "1"
+        # gradient norm: the ConditionalUnet1D slice (one end of the arena, 75 % of the parameters) is summed on the deferred weight-gradient
+        # stream while the encoder backward runs (single GPU only: under data parallelism the slices are all-reduced first; not with a
+        # gradient hook, which may still edit the arena).  V2A_PRESUM=0: one sum-of-squares launch in the serial tail.
+        self._presum_range = (0, 0)
+        if os.environ.get("V2A_PRESUM", "1") != "0" and not self.dp:
+            mi = [i for i, n in enumerate(self.names) if n.startswith("model.")]
+            if mi and mi[-1] - mi[0] + 1 == len(mi):         # (the model.* group is contiguous in the arena, first or last)
+                self._presum_range = self.opt.chunk_range(mi[0], mi[-1] + 1)
+                self.eng.on_unet_wgrads_done = self._presum
         self._pack_serial = -1
         self._packs_fused = False
         self._pack_side = None
         self._wg_keep = None
+
+    def _presum(self):
+        if self._presum_range[1] and self.on_grads_ready is None:
+            self.opt.presum(*self._presum_range)
 
     @property
     def ema_policy(self):
