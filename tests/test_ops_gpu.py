@@ -1079,7 +1079,7 @@ def test_stem_channel_window_conv_and_weight_gradient_vs_torch(N, H, W, u8):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,HW,Ci,Co,res", [(8, 32, 64, 64, False), (3, 32, 96, 128, True), (8, 16, 128, 128, True), (6, 8, 256, 256, False),
-                                             (16, 4, 512, 512, True), (40, 4, 64, 192, False), (2, 8, 32, 64, True)])
+                                             (16, 4, 512, 512, True), (40, 4, 64, 192, False), (2, 8, 32, 64, True), (3, 64, 64, 128, True)])
 def test_three_plane_halo_conv_vs_fp64(N, HW, Ci, Co, res):
     """conv_halo_x3 (3x3 / stride 1 / pad 1 over square 32 / 16 / 8 / 4 maps, 128 output pixels x 64 channels per workgroup, halo split
     once per 32-channel chunk): tiles of four map rows, eight map rows, two whole maps and eight whole maps; odd chunk counts; the fp32

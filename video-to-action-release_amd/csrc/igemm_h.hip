@@ -1351,6 +1351,11 @@ static int conv_halo_x3_split(int M, int Cout, int Cin) {
     return cdiv(nchunks, cps);
 }
 static int g_conv_x3h = -1;       // V2A_CONV_X3H=0: 3x3 / stride-1 layers stay on conv_igemm_f32x3 (A/B)
+static bool conv_x3h_64() {        // V2A_CONV_X3H_64=0: 64-wide maps (the fp32 sampler's second level; two map rows per tile) stay on conv_igemm_f32x3
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("V2A_CONV_X3H_64"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
 static bool conv_x3h_on() {
     if (g_conv_x3h < 0) { const char* e = getenv("V2A_CONV_X3H"); g_conv_x3h = (e && e[0] == '0') ? 0 : 1; }
     return g_conv_x3h == 1;
@@ -1467,7 +1472,7 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         const int f32p = g_f32p, s128 = g_f32p_s128, s64 = g_f32p_s64;
         f32_conv_mode_init();
         if (g_f32x3 && conv_x3h_on() && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && idil == 1 &&
-            !x2 && C2 == 0 && H == W && OH == H && OW == W && (W == 4 || W == 8 || W == 16 || W == 32) && p.M % 128 == 0 && Cout % 64 == 0 &&
+            !x2 && C2 == 0 && H == W && OH == H && OW == W && (W == 4 || W == 8 || W == 16 || W == 32 || (W == 64 && conv_x3h_64())) && p.M % 128 == 0 && Cout % 64 == 0 &&
             !stats && !p.w2 && (double)N * H * W * C1 < 2147483648.0) {
             // 3x3 / stride 1 / pad 1 over the encoders' square maps: the halo kernel (its own split, over 32-channel chunks)
             s = conv_halo_x3_split(p.M, Cout, C1);
@@ -1476,7 +1481,8 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
             p.ktiles_per_split = cdiv(C1 / 32, s);
             p.frame_tiles = 0;
             const dim3 grid((p.M / 128) * (Cout / 64), s);
-            if (W == 32) hipLaunchKernelGGL(conv_halo_x3<32>, grid, dim3(256), 0, stream, p);
+            if (W == 64) hipLaunchKernelGGL(conv_halo_x3<64>, grid, dim3(256), 0, stream, p);
+            else if (W == 32) hipLaunchKernelGGL(conv_halo_x3<32>, grid, dim3(256), 0, stream, p);
             else if (W == 16) hipLaunchKernelGGL(conv_halo_x3<16>, grid, dim3(256), 0, stream, p);
             else if (W == 8) hipLaunchKernelGGL(conv_halo_x3<8>, grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL(conv_halo_x3<4>, grid, dim3(256), 0, stream, p);

@@ -121,6 +121,7 @@ def _plan_name_h(M, Cout, K, ept, tname):
 
 _SMALL_TILE_H = os.environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
 _CONV_X3H = os.environ.get('V2A_CONV_X3H', '1') != '0'
+_CONV_X3H_64 = os.environ.get('V2A_CONV_X3H_64', '1') != '0'
 _DEEP_SMALL_M = os.environ.get('V2A_DEEP_SMALL_M', '0') == '1'
 _WGRAD_DMA = os.environ.get('V2A_WGRAD_DMA', '1') != '0'
 _h_twin_regs = 0
@@ -193,7 +194,7 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
     last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
     # mirrors conv_dma_launch (csrc/igemm_h.hip): 3x3 / stride 1 / pad 1 over square 4 ... 32-wide maps -> the three-plane halo kernel
     if (_CONV_X3H and lib.v2a_get_f32_conv_mode() == 1 and KH == 3 and KW == 3 and (sh, sw, ph, pw) == (1, 1, 1, 1) and not ups and idil == 1
-            and x2 is None and H == W and (OH, OW) == (H, W) and W in (4, 8, 16, 32) and M % 128 == 0 and Cout % 64 == 0
+            and x2 is None and H == W and (OH, OW) == (H, W) and W in ((4, 8, 16, 32, 64) if _CONV_X3H_64 else (4, 8, 16, 32)) and M % 128 == 0 and Cout % 64 == 0
             and not want_stats and second is None):
         last_kernel[0] = f"conv_halo_x3<{W}>"
     if second is not None:      # (w2_packed, bias2 | None, m_split): output rows >= m_split use the second operand set (this launch only)
