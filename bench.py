@@ -103,6 +103,10 @@ def _emit(out):
     if isinstance(out.get("roofline"), dict) and "all_conv_variants" in out["roofline"]:      # the three largest families, by time
         top = sorted(out["roofline"]["all_conv_variants"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
         line["roofline"]["top_conv_variants"] = {k: _compact(v) for k, v in top}
+    for leg in ("policy_exact", "video_exact"):  # the strict-arithmetic legs: the numbers only (everything else is in the full record)
+        if isinstance(line.get(leg), dict):
+            line[leg] = {k: v for k, v in line[leg].items() if k in ("value", "unit", "ms_per_step", "seconds_per_sample_call", "f32_conv_mode",
+                                                                     "whole_step_frac_of_f32_mfma_floor", "algorithmic_tflops", "error")}
     txt = json.dumps(line, separators=(",", ":"))
     if len(txt) > 7600:                          # last resort: shed the per-leg configs, then the per-leg rooflines of secondary legs
         for leg in list(line):
@@ -638,6 +642,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="one rank through the data-parallel step structure and RCCL (PolicyTrainer(force_dp=True))")
     ap.add_argument("--no-video", action="store_true", help="skip the video-sampler legs (BASELINE.json configs[2], released config, C5, B=1)")
     ap.add_argument("--no-video-train", action="store_true", help="skip the video-model training-step leg")
     ap.add_argument("--no-predict", action="store_true", help="skip the predict_action latency leg")
@@ -666,7 +671,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    force_dp = os.environ.get("V2A_FORCE_DP") == "1"      # one rank through the N > 1 step structure + RCCL (validation on a 1-GPU box)
+    force_dp = args.force_dp                              # one rank through the N > 1 step structure + RCCL (validation on a 1-GPU box)
     rccl_log = None
     if world > 1 or force_dp:
         # what RCCL decides for the gradient all-reduce is part of the result (comm.algo): have it log its tuning decisions to a file
@@ -715,7 +720,7 @@ def main():
     random.seed(rank)
     store = build_store(torch, device, args.batch, seed=100 + rank)
     tr = PolicyTrainer(pol, store, batch_size=args.batch, seed=rank, use_graph=not args.no_graph, process_group=pg,
-                       world_size=world, rank=rank)
+                       world_size=world, rank=rank, force_dp=force_dp)
 
     def barrier():
         if world > 1:
@@ -927,12 +932,8 @@ def main():
                         sk.bind(("127.0.0.1", 0))
                         port = sk.getsockname()[1]
                     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(device))
-                os.environ["V2A_FORCE_DP"] = "1"
-                kw = dict(process_group=dist.group.WORLD, world_size=1)
-            try:
-                trx = PolicyTrainer(polx, stx, batch_size=batch, seed=0, use_graph=not args.no_graph, **kw)
-            finally:
-                os.environ.pop("V2A_FORCE_DP", None)
+                kw = dict(process_group=dist.group.WORLD, world_size=1, force_dp=True)
+            trx = PolicyTrainer(polx, stx, batch_size=batch, seed=0, use_graph=not args.no_graph, **kw)
             for _ in range(max(warm, 3)):
                 trx.step()
             if dp:
@@ -975,14 +976,28 @@ def main():
             except Exception as e:
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
 
+        def exact_mode(fn):
+            """Run fn with the exact-f32 MFMA conv kernels (V2A_F32_CONV=exact / v2a_set_f32_conv_mode(0)): the configuration that is bit-equal
+            to an fmaf chain per accumulator -- the cost of strict fp32 arithmetic next to the three-plane headline."""
+            from v2a_hip._lib import lib as _lib
+            old_mode = _lib.v2a_set_f32_conv_mode(0)
+            try:
+                r = fn()
+            finally:
+                _lib.v2a_set_f32_conv_mode(old_mode)
+            r["f32_conv_mode"] = "exact (v_mfma_f32_32x32x2_f32)"
+            return r
+
         if not args.no_bf16_extra and args.batch == 64:
+            leg0("policy_exact", lambda: exact_mode(lambda: dict(policy_leg("fp32", args.batch, steps=10),
+                                                                 workload="the headline step on the exact-f32 MFMA conv kernels")))
             leg0("policy_b256", lambda: {"workload": "BASELINE configs[4] policy half at one GPU's share: batch 256",
                                          "fp32": policy_leg("fp32", 256), "bf16": policy_leg("bf16", 256),
                                          **({"fp16": policy_leg("fp16", 256)} if hasattr(v2a_hip, "set_policy_half") else {})})
             # the data-parallel step STRUCTURE on one rank (three graphs + two slice all-reduces through RCCL with one rank): its cost
             # per GPU against the one-graph step above, and the window the encoder backward leaves for slice 0
             leg0("dp_structure", lambda: dict(policy_leg("fp32", args.batch, steps=10, dp=True), one_graph_ms_per_step=ms,
-                                              workload="V2A_FORCE_DP step structure, one rank, RCCL"))
+                                              workload="force_dp step structure, one rank, RCCL"))
         if not args.no_video:
             del tr, pol, store
             torch.cuda.empty_cache()
@@ -999,6 +1014,10 @@ def main():
                                            workload="AVDC sampler Unet_Libero 128x128, 1+7 frames (BASELINE.json configs[2])"))
             if cpu is not None and "error" not in out["video"]:
                 out["video"]["cpu_baseline"] = cpu.video()
+            if args.precision == "fp32" and not args.no_bf16_extra:
+                leg("video_exact", lambda: exact_mode(lambda: video_leg(
+                    torch, device, args.video_batch, args.video_steps, reps=1, roofline=False,
+                    workload="AVDC sampler (BASELINE.json configs[2]) on the exact-f32 MFMA conv kernels")))
             if args.precision == "fp32" and not args.no_bf16_extra:
                 note16 = ("performance configuration (counterpart of the reference's fp16-autocast GPU path); 0.8 % relative L2 "
                           "deviation from the fp32 parity path per UNet forward (tests/test_video_gpu.py)")

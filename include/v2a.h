@@ -110,15 +110,16 @@ int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* g
                          int N, int S, int C, int G, float eps, int act, const float* stats1, const float* stats2, void* workspace,
                          size_t workspace_bytes, v2a_stream_t stream);
 int v2a_groupnorm_takes_slabs(int S, int C, int G);
-/* post-activation addend of the NEXT fp32 GroupNorm forward launch (consumed by it): out = act(gn(x) ...) + post, post dense or still the
-   split-K slabs (+ bias) of the conv that produces it -- the residual branch of ConditionalResidualBlock1D (conditional_unet1d.py:46-66:
-   `out = self.blocks[1](out); out = out + self.residual_conv(x)`) without an add / reduce launch of its own.  Only where
-   v2a_groupnorm_takes_post says 1 (slabs of 256 / 512 / 1024 elements, 16 ... 128 channels per group); V2A_ERR_ARG otherwise. */
-int v2a_groupnorm_set_post(const float* post, const float* post_slabs, int nslab, size_t slab_stride, const float* post_bias);
+/* v2a_groupnorm_fwd_s also takes a post-activation addend as explicit operands: out = act(gn(x) ...) + post, with `post` dense, or
+   `post_slabs` = the still unreduced split-K slabs (post_nslab of them, post_stride floats apart, + post_bias) of the conv that produces
+   it -- the residual branch of ConditionalResidualBlock1D (conditional_unet1d.py:46-66: `out = self.blocks[1](out); out = out +
+   self.residual_conv(x)`) without an add / reduce launch of its own.  Only where v2a_groupnorm_takes_post says 1 (slabs of 256 / 512 /
+   1024 elements, 16 ... 128 channels per group); V2A_ERR_ARG otherwise.  All null / 0: no addend. */
 int v2a_groupnorm_takes_post(int S, int C, int G);
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
-                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* reserved,
+                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
+                        const float* post_slabs, int post_nslab, size_t post_stride, const float* post_bias,
                         void* workspace, size_t workspace_bytes, v2a_stream_t s);
 int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
@@ -223,13 +224,6 @@ int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint6
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
 int v2a_get_f32_conv_mode(void);
-/* Two parameter sets over ONE stacked batch (the policy's two camera encoders as one launch sequence): the NEXT fp32 LDS-DMA conv launch
- * (v2a_conv2d_fwd_dma_f32 / _d) computes output rows >= m_split with w2 / bias2 (m_split % 256 == 0); the NEXT fp32 GroupNorm launch
- * (v2a_groupnorm_fwd* / _bwd*) uses gamma2 / beta2 for samples n >= n_split.  Host-side state, consumed by that launch. */
-int v2a_conv2d_set_second(const void* w2, const float* bias2, int m_split);
-int v2a_groupnorm_set_second(const float* gamma2, const float* beta2, int n_split);
-int v2a_debug_f32p(int on, int s128, int s64);   /* tuning aid: pipelined exact-f32 conv kernel on/off (default on), LDS stages of its 128x128 / 64x64 tiles; returns the old `on` */
-int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words);   /* measurement aid: following conv_igemm_h launches stamp their phases per workgroup ([wg][8] x 100 MHz ticks), buf advances by stride_words per launch; null = off */
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */
 
 /* ---------------------------------------------------------------------------------------------- attention (csrc/attention.hip) */
@@ -262,7 +256,9 @@ int v2a_spatial_softmax_bwd(const float* att, const float* kp, const float* dkp,
 
 /* 16-bit format of every `_h` entry point (csrc/igemm_h.hip, igemm_h2.hip, igemm_h3.hip, norm_h.hip, v2a_attention_fwd_h, the f32 <-> 16-bit
  * casts and packs): 0 = bf16 (default), 1 = IEEE fp16 -- the reference's own 16-bit type (fp16 autocast: lb_online_trainer_v7.py:72-76,889).
- * Same kernels, instantiated with v_mfma_f32_32x32x16_f16 / v_cvt_f16_f32.  Process-wide; returns the previous value. */
+ * Same kernels, instantiated with v_mfma_f32_32x32x16_f16 / v_cvt_f16_f32.  PER HOST THREAD (thread_local): the flag is the format of the
+ * 16-bit tensors the calling thread hands to its next `_h` launches (the Python wrappers set it from the tensor dtype before every call), so
+ * two threads driving bf16 and fp16 tensors do not disturb each other.  Returns the thread's previous value. */
 int v2a_set_half_format(int f16);
 int v2a_get_half_format(void);
 
@@ -369,23 +365,24 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
  * lb_online_trainer_v7.py:72-76,604-612): the gradients arrive multiplied by loss_scale; v2a_opt_step unscales inside the clip factor,
  * skips the parameter / moment update (EMA and zero_grad still run) when their norm is inf / nan, halves the scale then, and grows it by
  * growth_factor after growth_interval clean steps.  init_scale <= 0: off (default). */
-int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_factor, double backoff_factor, int growth_interval);
-int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps);
+int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_factor, double backoff_factor, int growth_interval,
+                             int growth_tracker);   /* growth_tracker: 0 for a fresh scaler; a resumed checkpoint's `_growth_tracker` */
+int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps,
+                         float* growth_factor, float* backoff_factor, int* growth_interval, int* scaler_on);   /* every out pointer optional */
 size_t v2a_opt_state_loss_scale_offset(void);
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad, v2a_stream_t s);
 /* same, and the update kernel also writes the conv operand packs of the updated parameters (packs_dev: [tensors][6] int64 = {forward pack
    [Cout][taps][Cin] or 0, Cin, taps, channel-window pack (v2a_conv2d_fwd_window_f32) or 0, 16-bit twin of the forward pack or 0, 1 if that
    twin is IEEE fp16}; the launch of v2a_pack_weights_multi that would
    read every parameter again is not needed for those operands) */
+   presum_first / presum_count: chunks [first, first + count) of partial_dev already hold this step's sums of squares (written by
+   v2a_opt_presum with the same range on a stream ordered before this call); 0 / 0: every chunk is summed here.  Explicit operands: nothing
+   is remembered between the two calls. */
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad,
-                        const int64_t* packs_dev, int defer_ema, v2a_stream_t s);
-/* defer_ema = 1 above leaves the EMA replica (ema.update(), lb_online_trainer_v7.py:623) to this call: the same arithmetic on the same
-   values, launched where it overlaps other work (PolicyTrainer: under the next step's encoder forward).  A no-op when nothing is
-   pending.  mark_done = 1: an eager flush (the replica is being read between steps); the next optimiser step clears the flag otherwise. */
+                        const int64_t* packs_dev, int presum_first, int presum_count, v2a_stream_t s);
 /* gradient-norm partial sums of chunks [first, first + count) ahead of the step (those gradients are final earlier: the ConditionalUnet1D
-   slice, while the encoder backward runs); the next v2a_opt_step / _packed call on the same `partial` sums only the rest */
+   slice, while the encoder backward runs).  Stateless: the caller hands the same range to v2a_opt_step_packed. */
 int v2a_opt_presum(const int64_t* table_dev, const int* chunks_dev, int first, int count, double* partial_dev, v2a_stream_t s);
-int v2a_opt_apply_ema(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, int mark_done, v2a_stream_t s);
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, v2a_stream_t s);  /* 1/world after the RCCL sum */
 
 /* ---------------------------------------------------------------------------------------------- replay (csrc/replay.hip)

@@ -81,26 +81,63 @@ def _gn(P, pre, x, groups):
     return F.group_norm(x, groups, P[pre + ".weight"], P[pre + ".bias"], eps=1e-5)
 
 
-def _basic_block(P, pre, x, stride, cout):
+# The encoders' only DISCRETE decisions are the ReLU masks and the max-pool winners.  Two correct fp32 implementations can take one of
+# them differently where a pre-activation is within rounding of zero / two window elements are within rounding of each other, and one
+# flipped decision moves a small weight gradient by 1 / (B H W) of its terms (tests/test_policy_gpu.py).  `dec` lets a test take that
+# out of a gradient comparison:  dec = {"record": {}}  stores this run's decisions (masks as NCHW bool, pool winners as window taps 0..8
+# int64) and the pre-activations they were taken on;  dec = {"use": {...}}  routes forward and backward through GIVEN decisions
+# (y = z * mask, y = the window element the given tap names) instead of taking its own.
+def _relu(z, name, dec):
+    if dec is None:
+        return F.relu(z)
+    if "record" in dec:
+        dec["record"][name] = (z > 0).detach()
+        dec["record"][name + ":z"] = z.detach()
+        return F.relu(z)
+    return z * dec["use"][name].to(z.dtype)
+
+
+def _maxpool3x3s2(z, name, dec):
+    if dec is None:
+        return F.max_pool2d(z, 3, 2, 1)
+    N, C, H, W = z.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    if "record" in dec:
+        y, flat = F.max_pool2d(z, 3, 2, 1, return_indices=True)          # flat = ih * W + iw of the winner
+        ih, iw = flat // W, flat % W
+        oh = torch.arange(OH).view(1, 1, OH, 1)
+        ow = torch.arange(OW).view(1, 1, 1, OW)
+        dec["record"][name] = ((ih - (2 * oh - 1)) * 3 + (iw - (2 * ow - 1))).detach()
+        dec["record"][name + ":z"] = z.detach()
+        return y
+    tap = dec["use"][name].long()
+    oh = torch.arange(OH).view(1, 1, OH, 1)
+    ow = torch.arange(OW).view(1, 1, 1, OW)
+    ih, iw = 2 * oh - 1 + tap // 3, 2 * ow - 1 + tap % 3
+    assert bool(((ih >= 0) & (ih < H) & (iw >= 0) & (iw < W)).all()), "a given max-pool winner lies in the padding"
+    return z.flatten(2).gather(2, (ih * W + iw).flatten(2)).view(N, C, OH, OW)
+
+
+def _basic_block(P, pre, x, stride, cout, dec=None):
     g = cout // 16
     out = F.conv2d(x, P[pre + ".conv1.weight"], None, stride=stride, padding=1)
-    out = F.relu(_gn(P, pre + ".bn1", out, g))
+    out = _relu(_gn(P, pre + ".bn1", out, g), pre + ".relu1", dec)
     out = F.conv2d(out, P[pre + ".conv2.weight"], None, stride=1, padding=1)
     out = _gn(P, pre + ".bn2", out, g)
     if (pre + ".downsample.0.weight") in P:
         x = _gn(P, pre + ".downsample.1", F.conv2d(x, P[pre + ".downsample.0.weight"], None, stride=stride), g)
-    return F.relu(out + x)
+    return _relu(out + x, pre + ".relu2", dec)
 
 
-def resnet18_gn(P, pre, x, widths=(64, 128, 256, 512)):
+def resnet18_gn(P, pre, x, widths=(64, 128, 256, 512), dec=None):
     """children()[:-2] of resnet18 with BatchNorm2d -> GroupNorm(C//16, C).  pre = '...backbone.nets'."""
     x = F.conv2d(x, P[pre + ".0.weight"], None, stride=2, padding=3)
-    x = F.relu(_gn(P, pre + ".1", x, widths[0] // 16))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _relu(_gn(P, pre + ".1", x, widths[0] // 16), pre + ".relu0", dec)
+    x = _maxpool3x3s2(x, pre + ".pool", dec)
     for li, c in enumerate(widths):
         for bi in range(2):
             stride = 2 if (li > 0 and bi == 0) else 1
-            x = _basic_block(P, f"{pre}.{4 + li}.{bi}", x, stride, c)
+            x = _basic_block(P, f"{pre}.{4 + li}.{bi}", x, stride, c, dec)
     return x
 
 
@@ -118,14 +155,14 @@ def spatial_softmax(P, pre, feat):
     return torch.cat([ex, ey], 1).view(-1, K, 2)
 
 
-def visual_core(P, pre, img, cfg: PolicyCfg):
-    feat = resnet18_gn(P, pre + ".backbone.nets", img, cfg.widths)
+def visual_core(P, pre, img, cfg: PolicyCfg, dec=None):
+    feat = resnet18_gn(P, pre + ".backbone.nets", img, cfg.widths, dec)
     kp = spatial_softmax(P, pre + ".pool", feat).flatten(1)
     return F.linear(kp, P[pre + ".nets.3.weight"], P[pre + ".nets.3.bias"])
 
 
-def obs_encoder(P, nobs: dict, cfg: PolicyCfg, pre="obs_encoder."):
-    feats = [visual_core(P, f"{pre}key_model_map.{k}", nobs[k], cfg) for k in cfg.rgb_keys]
+def obs_encoder(P, nobs: dict, cfg: PolicyCfg, pre="obs_encoder.", dec=None):
+    feats = [visual_core(P, f"{pre}key_model_map.{k}", nobs[k], cfg, dec) for k in cfg.rgb_keys]
     return torch.cat(feats, dim=-1)
 
 
@@ -191,11 +228,11 @@ def cond_unet1d(P, sample, t, global_cond, cfg: PolicyCfg, pre="model."):
 
 
 # ----------------------------------------------------------------------------- policy level
-def compute_loss(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY):
-    """compute_loss with the two RNG draws (randn then randint, :246-252) injected."""
+def compute_loss(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY, dec=None):
+    """compute_loss with the two RNG draws (randn then randint, :246-252) injected.  dec: see _relu / _maxpool3x3s2 (tests only)."""
     nobs = {k: normalize_img(v)[:, 0] for k, v in batch["obs"].items()}
     nact = normalize_act(batch["action"], cfg)
-    gc = obs_encoder(P, nobs, cfg).reshape(nact.shape[0], -1)
+    gc = obs_encoder(P, nobs, cfg, dec=dec).reshape(nact.shape[0], -1)
     ac = S.squaredcos_alphas_cumprod(cfg.num_train_timesteps)
     noisy = S.add_noise(ac, nact, noise, timesteps)
     pred = cond_unet1d(P, noisy, timesteps, gc, cfg)
@@ -203,7 +240,7 @@ def compute_loss(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY):
     return loss.reshape(loss.shape[0], -1).mean(dim=1).mean()
 
 
-def loss_and_grads(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY, names=None):
+def loss_and_grads(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY, names=None, dec=None):
     """Loss + dLoss/dparam for every (deduplicated) floating tensor in `names` (default: all of P)."""
     names = list(names) if names is not None else [k for k, v in P.items() if torch.is_floating_point(v)]
     Q = dict(P)
@@ -211,7 +248,7 @@ def loss_and_grads(P, batch, noise, timesteps, cfg: PolicyCfg = LIBERO_POLICY, n
     for n in names:
         leaves[n] = P[n].detach().clone().requires_grad_(True)
         Q[n] = leaves[n]
-    loss = compute_loss(Q, batch, noise, timesteps, cfg)
+    loss = compute_loss(Q, batch, noise, timesteps, cfg, dec=dec)
     grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
     return loss.detach(), {n: (g if g is not None else torch.zeros_like(P[n])) for n, g in zip(names, grads)}
 

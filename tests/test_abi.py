@@ -59,10 +59,12 @@ def test_argument_validation_returns_error_codes_without_touching_the_device():
     # round-4 entry points: channel-window stem conv, padded NHWC4 converter, optimiser step that also writes the operand packs
     assert lib.v2a_conv2d_fwd_window_f32(None, None, None, None, None, 2, 134, 67, 8, 32, 64, 7, 1, 2, 1, 64, 64, None, 0, None) == ERR_ARG
     assert lib.v2a_nchw_to_nhwc4p(None, 0, None, 2, 128, 128, 3, 1, None) == ERR_ARG
-    assert lib.v2a_opt_step_packed(None, None, 0, None, None, 1, None, 0, None) == ERR_ARG
-    assert lib.v2a_opt_apply_ema(None, None, 0, None, 0, None) == ERR_ARG
+    assert lib.v2a_opt_step_packed(None, None, 0, None, None, 1, None, 0, 0, None) == ERR_ARG
     assert lib.v2a_opt_presum(None, None, 0, 0, None, None) == ERR_ARG
-    assert lib.v2a_groupnorm_set_post(None, None, 3, 0, None) == ERR_ARG and lib.v2a_groupnorm_takes_post(16, 256, 8) in (0, 1)
+    assert lib.v2a_groupnorm_takes_post(16, 256, 8) in (0, 1)
+    # round 5: the post-activation addend of a GroupNorm launch is an explicit operand set of v2a_groupnorm_fwd_s (slabs without a count: rejected)
+    assert lib.v2a_groupnorm_fwd_s(None, None, 0, None, None, None, None, 0, None, None, None, None, 1, 16, 64, 8, 1e-5, 0, None, 0, 0, None,
+                                   None, None, 3, 0, None, None, 0, None) == ERR_ARG
     # host-side sizing of the split slabs / partials
     assert lib.v2a_conv2d_wgrad_workspace_bytes(65536, 64, 576) > 0
     assert lib.v2a_conv2d_wgrad_h_workspace_bytes(229376, 128, 1152) >= 128 * 1152 * 4 * 2

@@ -555,11 +555,11 @@ def test_conv2d_halo_h3_kernel_matches_fp64_reference(N, H, W, C, Co, epi):
     wp = ops.pack_weight_h(w)
     y, st = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rowvec, rows_per_batch=H * W, residual=res, want_stats=True)
     assert ops.last_kernel[0].startswith("conv_halo_h3") and st is not None
-    os.environ["V2A_CONV_H3_OFF_FOR_TEST"] = "1"
+    ops.CONV_H3[0] = False          # test hook: the same layer on the tap-by-tap kernel
     try:
         y1 = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), rowvec=rowvec, rows_per_batch=H * W, residual=res)
     finally:
-        os.environ.pop("V2A_CONV_H3_OFF_FOR_TEST")
+        ops.CONV_H3[0] = True
     assert not ops.last_kernel[0].startswith("conv_halo_h3")
     d = (y.float() - y1.float()).abs()
     assert (d <= y1.float().abs() * 2.0 ** -7 + 1e-5).all() and (d > 0).float().mean().item() < 0.01
@@ -694,11 +694,11 @@ def test_conv2d_temporal_frames_kernel_matches_fp64_reference(B, HW, C, Co, epi)
     wp = ops.pack_weight_h(w)
     y, st = ops.conv2d_h(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res, want_stats=True)
     assert ops.last_kernel[0].startswith("conv_frames_h3") and st is not None
-    os.environ["V2A_CONV_H3_OFF_FOR_TEST"] = "1"
+    ops.CONV_H3[0] = False          # test hook: the same layer on the tap-by-tap kernel
     try:
         y1 = ops.conv2d_h(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res)
     finally:
-        os.environ.pop("V2A_CONV_H3_OFF_FOR_TEST")
+        ops.CONV_H3[0] = True
     assert not ops.last_kernel[0].startswith("conv_frames_h3")
     d = (y.float() - y1.float()).abs()
     assert (d <= y1.float().abs() * 2.0 ** -7 + 1e-5).all() and (d > 0).float().mean().item() < 0.01
@@ -1103,3 +1103,64 @@ def test_three_plane_halo_conv_vs_fp64(N, HW, Ci, Co, res):
     close(nchw(y), ref.float(), 1e-4, "halo conv")
     err = (nchw(y).double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 5e-6, err
+
+
+def test_two_host_threads_two_streams_do_not_disturb_each_other():
+    """SURVEY 8b / VERDICT r4 next #5: the C ABI is "thread-safe for distinct streams ... no hidden global state".  Two host threads, each
+    on a stream and a scratch lane of its own, run DIFFERENT operands through the entry points that used to hand operands over in process
+    globals (fp32 conv with deferred split-K slabs -> GroupNorm that sums them and adds a post-activation addend) and through the 16-bit
+    convs in DIFFERENT formats (bf16 in one thread, IEEE fp16 in the other: the format flag is per host thread).  ctypes releases the GIL
+    inside every call, so the launches interleave at the C level.  Every result must be bit-equal to the same sequence run alone."""
+    import threading
+    from v2a_hip import ops
+    dev = "cuda:0"
+
+    def work(seed, half, out):
+        g = torch.Generator().manual_seed(seed)
+        B, T, C = 64, 4, 1024                                        # a deep small-M Conv1d: the plan splits K, the GroupNorm sums the slabs
+        x = torch.randn(B, 1, T, C, generator=g).to(dev)
+        w = (torch.randn(C, 5 * C, generator=g) * 0.02).to(dev)
+        bias = torch.randn(C, generator=g).to(dev)
+        gamma, beta = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+        post = torch.randn(B, T, C, generator=g).to(dev)
+        xh = torch.randn(2, 16, 16, 128, generator=g).to(half).to(dev)
+        wh = ops.pack_weight_h((torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(dev), dtype=half)
+        res = []
+        for it in range(12):
+            y, sl = ops.conv2d(x, w, bias, C, 1, 5, (1, 1), (0, 2), defer=True)
+            assert sl is not None and sl.n > 1
+            a, mean, rstd = ops.groupnorm_fwd(y.view(B, T, C), gamma, beta, 8, "mish", slabs=sl, post=post)
+            yh = ops.conv2d_h(xh, wh, None, 128, 3, 3, (1, 1), (1, 1))
+            assert yh.dtype == half
+            if it in (0, 11):
+                res.append((a.clone(), mean.clone(), yh.clone()))
+        out.append(res)
+
+    def run(seed, half, lane, out, err):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st), ops.ws_lane(lane):
+                work(seed, half, out)
+            st.synchronize()
+        except BaseException as e:      # noqa: a failure in a thread must fail the test
+            err.append(e)
+
+    alone = {}
+    for seed, half, lane in ((1, torch.bfloat16, 31), (2, torch.float16, 32)):
+        out, err = [], []
+        run(seed, half, lane, out, err)
+        assert not err, err
+        alone[seed] = out[0]
+    outs, errs = {1: [], 2: []}, []
+    th = [threading.Thread(target=run, args=(1, torch.bfloat16, 31, outs[1], errs)),
+          threading.Thread(target=run, args=(2, torch.float16, 32, outs[2], errs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for seed in (1, 2):
+        for (a0, m0, h0), (a1, m1, h1) in zip(alone[seed], outs[seed][0]):
+            assert torch.equal(a0, a1) and torch.equal(m0, m1) and torch.equal(h0.view(torch.int16), h1.view(torch.int16)), seed
+    assert not torch.equal(alone[1][0][0], alone[2][0][0])

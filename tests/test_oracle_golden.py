@@ -205,6 +205,58 @@ def test_oracle_policy_vs_reference(golden_dir):
     assert rel(o["action_pred"], g["ddim_action_pred"]) < 1e-6 and rel(o["action"], g["ddim_action"]) < 1e-6
 
 
+def test_oracle_decision_routing_is_neutral_and_the_tie_check_bites(golden_dir):
+    """The flip-aware machinery of the GPU gradient tests (oracle.policy `dec`, tests/flip_aware.py), checked without a GPU: recording the
+    encoders' ReLU / max-pool decisions changes nothing; routing forward and backward through the RECORDED decisions reproduces the free
+    run's loss and gradients (so a comparison through another forward's decisions only differs where that forward decided differently);
+    a decision flipped on a genuine tie passes check_routing, one flipped on a clear pre-activation does not."""
+    from oracle import policy as OP
+    from oracle.param_fill import fill_module
+    from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+    from flip_aware import check_routing
+    g = np.load(f"{golden_dir}/policy.npz", allow_pickle=True)
+    torch.manual_seed(0)
+    pol = build_policy(DEFAULT_CONF)
+    sd = fill_module(pol, seed=13)
+    batch = {"obs": {"img_obs_1": torch.from_numpy(g["img_obs"]), "img_goal_1": torch.from_numpy(g["img_goal"])},
+             "action": torch.from_numpy(g["action"])}
+    noise, ts = torch.from_numpy(g["noise"]), torch.from_numpy(g["timesteps"])
+    names = [str(n) for n in g["param_names"]]
+    loss0, g0 = OP.loss_and_grads(sd, batch, noise, ts, names=names)
+    rec = {"record": {}}
+    loss1, g1 = OP.loss_and_grads(sd, batch, noise, ts, names=names, dec=rec)
+    assert loss1.item() == loss0.item() and all(torch.equal(g0[n], g1[n]) for n in names)
+    own = {k: v for k, v in rec["record"].items() if not k.endswith(":z")}
+    assert len(own) == 2 * (2 + 2 * 8) and sum(v.numel() for v in own.values()) > 2_000_000
+    loss2, g2 = OP.loss_and_grads(sd, batch, noise, ts, names=names, dec={"use": own})
+    assert abs(loss2.item() - loss0.item()) <= 1e-7 * abs(loss0.item())
+    gsc = max(float(g0[n].norm()) for n in names)
+    assert max(float((g2[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-3 * gsc) for n in names) <= 1e-6
+    assert check_routing(rec["record"], own)[0] == 0
+    # one flipped ReLU decision: on the pre-activation closest to zero (a tie: accepted), then on the largest one (rejected)
+    key = next(k for k in own if k.endswith(".4.0.relu1"))
+    z = rec["record"][key + ":z"]
+    for pick, ok in ((z.abs().argmin(), z.abs().min() <= 3e-5 * z.abs().max()), (z.abs().argmax(), False)):
+        flipped = dict(own)
+        m = own[key].clone()
+        m.view(-1)[pick] = ~m.view(-1)[pick]
+        flipped[key] = m
+        if ok:
+            assert check_routing(rec["record"], flipped)[0] == 1
+        else:
+            with pytest.raises(AssertionError):
+                check_routing(rec["record"], flipped)
+    # one max-pool winner (an interior window: all nine taps lie inside the map) moved to the smallest element of its window: rejected
+    key = next(k for k in own if k.endswith(".pool"))
+    zz = rec["record"][key + ":z"]
+    win = zz[0, 0, 2 * 5 - 1:2 * 5 + 2, 2 * 5 - 1:2 * 5 + 2].reshape(-1)
+    assert float(win.max() - win.min()) > 1e-3 * float(zz.abs().max())
+    t = own[key].clone()
+    t[0, 0, 5, 5] = int(win.argmin())
+    with pytest.raises(AssertionError):
+        check_routing(rec["record"], dict(own, **{key: t}))
+
+
 def test_oracle_policy_action_limits_vs_reference(golden_dir):
     """Non-identity action limits (lb_action_minmax_orn01, diffuser/datasets/__init__.py:30-37): the oracle's normalise /
     unnormalise against the reference run with that normaliser; the product shell accepts the limits and rejects what the HIP

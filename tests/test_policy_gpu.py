@@ -38,54 +38,44 @@ def test_compute_loss_and_grads_vs_golden_and_oracle(golden_dir):
     noise, ts = torch.from_numpy(g["noise"]), torch.from_numpy(g["timesteps"])
     pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
     pol.train()
+    hip_dec = pol.engine.debug_decisions = {}
     loss = pol.compute_loss(batch)
     loss.backward()
+    pol.engine.debug_decisions = None
     assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
     names = [str(n) for n in g["param_names"]]
     P = dict(pol.named_parameters())
-    # golden: per-parameter gradient norms and 8 sampled elements each, from the reference's autograd
+    # golden (the reference's autograd): per-parameter gradient norms and 8 sampled elements each.  The ConditionalUnet1D has no discrete
+    # decision, so its tensors are compared outright; an encoder tensor is compared outright unless this forward took one of that
+    # encoder's decisions the other way (a genuine tie, checked below) -- the flip-aware oracle comparison below covers every tensor.
     gsc = float(np.max(g["grad_norms"]))
+    from flip_aware import hip_decisions, check_routing
+    dec_hip = hip_decisions(hip_dec)
+    rec = {"record": {}}
+    l2 = OP.compute_loss(sd, batch, noise, ts, dec=rec)          # the oracle's own forward: its loss, its decisions
+    assert abs(l2.item() - float(g["loss"])) < 1e-6
+    flipped = {k.split(".backbone")[0] for k in dec_hip if not torch.equal(dec_hip[k], rec["record"][k])}
     for i, n in enumerate(names):
         gr = P[n].grad
         assert gr is not None, n
+        if any(n.startswith(f) for f in flipped):
+            continue
         gn = float(gr.double().norm())
         assert abs(gn - g["grad_norms"][i]) <= TOL * max(g["grad_norms"][i], 1e-3 * gsc), (n, gn, g["grad_norms"][i])
         idx = torch.randint(0, gr.numel(), (8,), generator=torch.Generator().manual_seed(9))
         got = gr.flatten()[idx.to(gr.device)].cpu().numpy()
         assert np.max(np.abs(got - g["grad_samples"][i])) <= TOL * max(gr.abs().max().item(), 1e-3 * gsc), n
-    # oracle: full-tensor comparison of every gradient
-    l2, og = OP.loss_and_grads(sd, batch, noise, ts, names=names)
-    assert abs(l2.item() - float(g["loss"])) < 1e-6
+    # oracle: full-tensor comparison of every gradient, flip-aware (tests/flip_aware.py): the oracle's own decisions pin the HIP forward's
+    # routing, the oracle's backward THROUGH the HIP forward's decisions pins the arithmetic -- every tensor to 1e-4, none excused
+    nd, nt, tie = check_routing(rec["record"], dec_hip, "[golden B=2] ")
+    _, og = OP.loss_and_grads(sd, batch, noise, ts, names=names, dec={"use": dec_hip})
     # parameters whose true gradient is zero by symmetry (e.g. the keypoint-logit bias under a softmax) carry only
     # rounding noise: measure every tensor against max(|its gradient|, 1e-3 x the largest gradient norm)
     dist = {n: ((P[n].grad.double().cpu() - og[n].double()).abs().max() / max(og[n].abs().max().item(), 1e-3 * gsc)).item() for n in names}
     worst = max(dist.values())
-    if worst <= TOL:
-        return
-    # A tensor outside the band.  The one legitimate cause (measured: tools/probes/r4/stem_flip_check.py, and the docstring of
-    # test_ragged_batch_loss_and_grads_vs_oracle): the fp32 conv products from three bf16 planes are fp32-EQUIVALENT, not bit-equal to
-    # an fmaf chain, and ONE max-pool / ReLU decision between two values 3e-6 apart taken the other way moves the small stem gradient
-    # (here: 1 of 131 072 pooling windows of one encoder, 5e-3 of that tensor's largest element).  Held to:
-    #   * only image-encoder tensors, at most two of them, none further than 5e-2, the median tensor inside the band;
-    #   * the SAME engine with the exact-f32 MFMA kernels (v2a_set_f32_conv_mode(0): bit-equal to an fmaf chain) meets 1e-4 on
-    #     every tensor -- so no launch, tile edge or split-K slab is at fault, only which way fp32 rounding broke a tie.
-    off = {n: d for n, d in dist.items() if d > TOL}
-    print(f"[golden B=2] tensors outside 1e-4 vs the fp32 CPU oracle: {off}")
-    assert all("obs_encoder" in n for n in off) and len(off) <= 2 and worst <= 5e-2, off
-    assert float(np.median(list(dist.values()))) <= TOL
-    from v2a_hip._lib import lib
-    old = lib.v2a_set_f32_conv_mode(0)
-    try:
-        pol2, _ = _policy()
-        pol2.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
-        pol2.train()
-        pol2.compute_loss(batch).backward()
-        P2 = dict(pol2.named_parameters())
-        worst2 = max(((P2[n].grad.double().cpu() - og[n].double()).abs().max() / max(og[n].abs().max().item(), 1e-3 * gsc)).item()
-                     for n in names)
-    finally:
-        lib.v2a_set_f32_conv_mode(old)
-    assert worst2 <= TOL, worst2
+    print(f"[golden B=2] {nd} of {nt} encoder decisions differ from the CPU oracle's (largest tie distance {tie:.1e}); worst gradient tensor "
+          f"vs the oracle routed through the HIP decisions {worst:.2e}")
+    assert worst <= TOL, {n: d for n, d in dist.items() if d > TOL}
 
 
 @pytest.mark.parametrize("use_ddim,seed,key", [(True, 70, "ddim_action_pred"), (False, 71, "ddpm_action_pred")])
@@ -202,7 +192,7 @@ def test_optimiser_written_operand_packs_equal_the_pack_launch(use_graph, prec):
     """Round 4: the fused update kernel (v2a_opt_step_packed) writes the forward conv operands itself -- [Cout][taps][Cin] packs in
     destination order through LDS, the stem's channel-window pack, the concatenated FiLM operands -- and PolicyTrainer skips the pack
     launch for them.  After a few steps every such operand must be bit-equal to what the pack kernels make of the live parameters
-    (mode 0 / mode 2 of v2a_pack_weight; plain copies for FiLM), eager and under graph replay, and equal to the V2A_FUSE_PACKS=0 run."""
+    (mode 0 / mode 2 of v2a_pack_weight; plain copies for FiLM), eager and under graph replay."""
     import random
     from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
     from v2a_hip import ops
@@ -262,16 +252,18 @@ def _packs_check(use_graph, prec):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_deferred_ema_update_equals_the_inline_update(use_graph):
-    """PolicyTrainer defers the EMA replica's update of step n to the start of step n + 1 (under the encoder forward; `ema_policy`
-    flushes a pending update when read): after any number of steps -- read after every step, or only at the end -- the replica must be
-    bit-equal to the inline run (V2A_DEFER_EMA=0 = ema.update() right after opt.step(), lb_online_trainer_v7.py:623), parameters too."""
+def test_presummed_gradient_norm_is_stateless_and_bit_equal(use_graph):
+    """the ConditionalUnet1D slice's gradient-norm partial sums run ahead of the optimiser tail (v2a_opt_presum on the deferred
+    weight-gradient stream) and the tail is TOLD which chunks are done (presum_first / presum_count of v2a_opt_step_packed) -- no state
+    survives between the two calls.  grad_norm, clip coefficient, parameters and the EMA replica must be bit-equal with the pre-sum on and
+    off, eager and under graph replay, and a stray backward through the same engine between two steps (policy.compute_loss(...).backward()
+    fires the engine's weight-gradient hook too) must not change the next step."""
     import random
     from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
     from v2a_hip.replay import ReplayStore
     from v2a_hip.trainer import PolicyTrainer
     runs = []
-    for defer, peek in ((False, False), (True, False), (True, True)):
+    for presum, stray in ((False, False), (True, False), (True, True)):
         torch.manual_seed(1)
         pol = build_policy(DEFAULT_CONF).to("cuda:0")
         store = ReplayStore(64, 200, 30, capacity_frames=40 * 16)
@@ -281,20 +273,27 @@ def test_deferred_ema_update_equals_the_inline_update(use_graph):
             store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
                                   torch.rand(n - 1, 7, generator=gen) * 2 - 1)
         np.random.seed(5); random.seed(5)
-        tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=use_graph)
-        tr.defer_ema = defer
-        mids = []
+        tr = PolicyTrainer(pol, store, batch_size=8, seed=11, use_graph=use_graph, presum=presum)
+        assert (tr._presum_range[1] > 0) == presum
+        peeks = []
         for it in range(5):
             tr.step()
-            if peek and it in (1, 3):                  # reading the replica between steps flushes the pending update, once
-                mids.append([p.detach().clone() for p in tr.ema_policy.parameters()])
+            peeks.append(tr.opt.peek()[:3])
+            if stray and it in (1, 3):                 # a backward of the policy's autograd surface between two steps (its own arena)
+                g2 = torch.Generator().manual_seed(100 + it)
+                batch = {"obs": {"img_obs_1": torch.rand(2, 1, 3, 128, 128, generator=g2).cuda(),
+                                 "img_goal_1": torch.rand(2, 1, 3, 128, 128, generator=g2).cuda()},
+                         "action": (torch.rand(2, 16, 7, generator=g2) * 2 - 1).cuda()}
+                pol.compute_loss(batch).backward()
+                for p_ in pol.parameters():
+                    p_.grad = None
         ema = [p.detach().clone() for p in tr.ema_policy.parameters()]
         par = [p.detach().clone() for p in pol.parameters()]
-        assert tr._ema_dirty is False
-        runs.append((ema, par))
+        runs.append((ema, par, peeks))
     for k in (1, 2):
-        assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[k][0])), "EMA replica differs from the inline update"
-        assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[k][1]))
+        assert runs[0][2] == runs[k][2], ("grad_norm / clip_coef / step differ", runs[0][2], runs[k][2])
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[k][1])), "parameters differ from the run without the pre-sum"
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[k][0]))
     assert any(not torch.equal(a, b) for a, b in zip(runs[0][0], runs[0][1]))      # (the replica does lag the parameters)
 
 
@@ -510,7 +509,8 @@ def test_graphed_predict_action_matches_eager(golden_dir):
 
 def test_dp_step_structure_on_rccl_single_rank():
     """The N > 1 step (three hipGraphs, two asynchronous slice all-reduces through torch.distributed 'nccl' = RCCL, averaging in the
-    optimiser) driven by one rank (V2A_FORCE_DP=1): same loss trajectory as the single-graph step, clean exit."""
+    optimiser) driven by one rank (bench.py --force-dp = PolicyTrainer(force_dp=True)): same loss trajectory as the single-graph step,
+    clean exit."""
     import json
     import os
     import subprocess
@@ -519,9 +519,9 @@ def test_dp_step_structure_on_rccl_single_rank():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-video", "--no-predict",
            "--no-roofline-pass", "--no-bf16-extra"]
     losses = {}
-    for tag, extra in (("single", {}), ("dp", {"V2A_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"})):
+    for tag, flags, extra in (("single", [], {}), ("dp", ["--force-dp"], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"})):
         env = dict(os.environ, **extra)
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd + flags, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         # the unrounded record (the one-line summary on stdout keeps five significant digits: a 1e-5 bound on it would flip on a
         # rounding boundary)
@@ -680,58 +680,31 @@ def test_batch_256_step_ties_to_oracle_through_linearity():
     e_l, e_g = abs(L - acc_l) / abs(acc_l), float((G - acc_g).abs().max()) / gmax
     print(f"[B=256] loss {L:.6f} vs mean of 32 chunks {acc_l:.6f} (rel {e_l:.1e}); gradient max err {e_g:.1e} of max |g|")
     assert e_l <= 1e-5 and e_g <= 1e-4
-    # chunk 0 against the CPU oracle.  Yard-stick: the oracle's own fp32 run against its fp64 run on the same rows -- some gradients
-    # (sums of large cancelling terms over 8 x 4096 pixels) carry 1e-3 relative rounding noise in ANY fp32 implementation.
+    # chunk 0 against the CPU oracle, flip-aware (tests/flip_aware.py).  Yard-stick for the arithmetic: the oracle's own fp32 run against
+    # its fp64 run on the same rows AND the same decisions -- some gradients (sums of large cancelling terms over 8 x 4096 pixels) carry
+    # 1e-3 relative rounding noise in ANY fp32 implementation; no HIP tensor may be further from fp64 than twice the fp32 CPU oracle's worst.
     batch0 = {"obs": {k: v[:8, None] for k, v in imgs.items()}, "action": act[:8]}
+    eng.debug_decisions = {}
+    l0, gr0 = run(0, 8)
+    hip_dec, eng.debug_decisions = eng.debug_decisions, None
+    assert l0 == first[0] and torch.equal(gr0, first[1])           # (the export changes nothing)
+    off, hip = 0, {}
+    for n in names:
+        k = sd[n].numel()
+        hip[n] = gr0[off:off + k].view(sd[n].shape)
+        off += k
     old = torch.get_num_threads()
     torch.set_num_threads(min(32, old))
     try:
-        ol, og = OP.loss_and_grads(sd, batch0, noise[:8], ts[:8], names=names)
-        sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
-        b64 = {"obs": {k: v.double() for k, v in batch0["obs"].items()}, "action": batch0["action"].double()}
-        _, og64 = OP.loss_and_grads(sd64, b64, noise[:8].double(), ts[:8], names=names)
+        rows, ol = _flip_aware_rows(OP, sd, batch0, noise[:8], ts[:8], names, hip, hip_dec, "[B=256 chunk 0] ")
     finally:
         torch.set_num_threads(old)
-    assert abs(first[0] - ol.item()) <= TOL * abs(ol.item())
-    gsc = max(float(og64[n].norm()) for n in names)
-    off, errs = 0, []
-    for n in names:
-        k = og[n].numel()
-        scale = max(float(og64[n].abs().max()), 1e-3 * gsc)
-        e_hip = float((first[1][off:off + k] - og64[n].flatten()).abs().max()) / scale
-        e_ref = float((og[n].flatten().double() - og64[n].flatten()).abs().max()) / scale
-        errs.append((n, e_hip, e_ref))
-        off += k
-    worst, worst_ref = max(e[1] for e in errs), max(e[2] for e in errs)
-    print(f"[B=256] chunk 0 vs fp64 oracle: worst per-tensor gradient error HIP {worst:.2e}, CPU fp32 oracle {worst_ref:.2e}")
-    # with 8 x 4096-pixel sums the fp32 CPU run itself is 2.5e-3 off the fp64 truth on its worst tensor (cancelling sums); no tensor
-    # of the HIP gradient may be further off than twice that, and the typical tensor must meet north_star's 1e-4
-    bad = [e for e in errs if e[1] > max(TOL, 2 * worst_ref)]
-    assert float(np.median([e[1] for e in errs])) <= TOL
-    if not bad:
-        return
-    # A tensor beyond twice the CPU oracle's own distance.  With the three-plane (fp32-EQUIVALENT, not fmaf-bit-equal) conv products this
-    # is the rounding-decision effect documented at test_ragged_batch_loss_and_grads_vs_oracle: one ReLU / max-pool tie taken the other way
-    # moves an encoder tensor by 1e-3 ... 4e-2.  Held to that test's rule (encoder tensors only, none beyond 5e-2) AND to a cross-check
-    # that rules out the kernels' launch logic: the same chunk on the exact-f32 MFMA kernels (bit-equal to an fmaf chain) must meet the
-    # strict bound on every tensor.
-    print(f"[B=256] chunk 0: tensors beyond 2 x the CPU oracle's distance: {bad[:5]}")
-    assert all("obs_encoder" in e[0] and e[1] <= 5e-2 for e in bad) and len(bad) <= 2, bad[:5]
-    from v2a_hip._lib import lib
-    mode = lib.v2a_set_f32_conv_mode(0)
-    try:
-        _, gr0 = run(0, 8)
-    finally:
-        lib.v2a_set_f32_conv_mode(mode)
-    off, bad0 = 0, []
-    for n in names:
-        k = og[n].numel()
-        scale = max(float(og64[n].abs().max()), 1e-3 * gsc)
-        e0 = float((gr0[off:off + k] - og64[n].flatten()).abs().max()) / scale
-        if e0 > max(TOL, 2 * worst_ref):
-            bad0.append((n, e0))
-        off += k
-    assert not bad0, bad0[:5]
+    assert abs(first[0] - ol) <= TOL * abs(ol)
+    worst, worst_ref = max(r[1] for r in rows), max(r[2] for r in rows)
+    print(f"[B=256] chunk 0 vs fp64 oracle (HIP routing): worst per-tensor gradient error HIP {worst:.2e}, CPU fp32 oracle {worst_ref:.2e}")
+    bad = [r for r in rows if r[1] > max(TOL, 2 * worst_ref)]
+    assert not bad, bad[:5]
+    assert float(np.median([r[1] for r in rows])) <= TOL
 
 
 def _grad_distances(hip, ref32, ref64, names):
@@ -746,10 +719,27 @@ def _grad_distances(hip, ref32, ref64, names):
     return rows
 
 
-def _fp64_oracle_grads(OP, sd, batch, noise, ts, names):
+def _fp64_oracle_grads(OP, sd, batch, noise, ts, names, dec=None):
     sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
     b64 = {"obs": {k: v.double() for k, v in batch["obs"].items()}, "action": batch["action"].double()}
-    return OP.loss_and_grads(sd64, b64, noise.double(), ts, names=names)
+    return OP.loss_and_grads(sd64, b64, noise.double(), ts, names=names, dec=dec)
+
+
+def _flip_aware_rows(OP, sd, batch, noise, ts, names, hip_grads, eng_dec, tag):
+    """The flip-aware comparison of tests/flip_aware.py for one batch: (1) the HIP forward's encoder decisions against the CPU oracle's own
+    (few differ, every differing one a genuine tie); (2) _grad_distances rows of the HIP gradients and of the fp32 CPU oracle, both against
+    the fp64 oracle, all three backward passes routed through the HIP forward's decisions.  Returns (rows, the oracle's own loss)."""
+    from flip_aware import hip_decisions, check_routing
+    dec_hip = hip_decisions(eng_dec)
+    rec = {"record": {}}
+    with torch.no_grad():
+        ref_loss = float(OP.compute_loss(sd, batch, noise, ts, dec=rec))
+    nd, nt, tie = check_routing(rec["record"], dec_hip, tag)
+    del rec
+    _, g32 = OP.loss_and_grads(sd, batch, noise, ts, names=names, dec={"use": dec_hip})
+    _, g64 = _fp64_oracle_grads(OP, sd, batch, noise, ts, names, dec={"use": dec_hip})
+    print(f"{tag}{nd} of {nt} encoder decisions differ from the CPU oracle's own (largest tie distance {tie:.1e} of max |z|)")
+    return _grad_distances(hip_grads, g32, g64, names), ref_loss
 
 
 RAGGED_CASES = [(1, 0), (3, 1), (5, 2), (6, 3), (7, 4), (6, 1)]      # (B, generator seed): NOT selected
@@ -758,20 +748,17 @@ RAGGED_CASES = [(1, 0), (3, 1), (5, 2), (6, 3), (7, 4), (6, 1)]      # (B, gener
 def test_ragged_batch_loss_and_grads_vs_oracle():
     """Batches that fill no tile evenly (1024 ... 7168 conv rows at the first ResNet stage, 16 ... 112 rows in the ConditionalUnet1D):
     partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin; six unselected
-    (batch size, seed) pairs, every gradient tensor against the fp64 run of the oracle -- with the fp32 CPU oracle (the reference's own
-    arithmetic) measured against the same fp64 run beside it.
+    (batch size, seed) pairs, the loss and EVERY gradient tensor.
 
-    What is and is not bounded by 1e-4 (measured: tools/probes/ragged_grad_probe.py, gpurun_out/r4_ragged.txt -- 14 random batches, both
-    conv modes): the loss and the MEDIAN gradient tensor always are.  The WORST tensor is not, for ANY fp32 implementation: the encoder
-    gradients at B <= 7 are cancelling sums, and one ReLU / max-pool decision that fp32 rounding takes the other way moves a stem or
-    bn tensor by 1e-3 ... 4e-2 of its largest element -- it happens to the fp32 CPU oracle in 7 of those 14 batches (up to 4.1e-2 off
-    its own fp64 run) and to the HIP path in 7 (exact-f32 MFMA) / 9 (three-plane products) of them, on different batches.  So the worst
-    tensor is held to the yard-stick where it applies and to a comparison of the two fp32 implementations where it does not:
-      * a batch on which the CPU oracle is itself off fp64: HIP <= max(1e-4, 2 x the oracle's distance)  [the rule of the B = 256 test];
-      * over the six batches: HIP leaves the 1e-4 band at most 3 times more often than the CPU oracle does, and never further than
-        max(5e-2, 3 x the oracle's worst distance) -- a kernel bug (a wrong tile edge, a lost split-K slab) is orders above that."""
+    Round 3 found that two correct fp32 implementations of this step do not always agree to 1e-4 on the encoder gradients at B <= 7:
+    one ReLU / max-pool decision that fp32 rounding takes the other way moves a stem or bn tensor by 1e-3 ... 4e-2 of its largest element
+    (profiles/r04_ragged_fp64_yardstick.txt: the fp32 CPU oracle itself in 7 of 14 batches).  Round 4 answered with a loose bound; this
+    is the strict form (tests/flip_aware.py): the HIP forward's decisions are compared with the oracle's own (at most 1e-5 of them may
+    differ, each one a genuine tie), and all gradients are compared with the oracle's backward ROUTED THROUGH THE HIP DECISIONS -- then
+    every tensor of every batch must meet max(1e-4, 2 x the fp32 CPU oracle's own distance to its fp64 run), the rule of the B = 256
+    test, with no other allowance."""
     from oracle import policy as OP
-    rows_out = []
+    worst_all = 0.0
     for B, seed in RAGGED_CASES:
         pol, sd = _policy(seed=21 + B)
         g = torch.Generator().manual_seed(seed)
@@ -780,37 +767,31 @@ def test_ragged_batch_loss_and_grads_vs_oracle():
         noise, ts = torch.randn(B, 16, 7, generator=g), torch.randint(0, 100, (B,), generator=g)
         pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
         pol.train()
+        hip_dec = pol.engine.debug_decisions = {}
         loss = pol.compute_loss(batch)
         loss.backward()
+        pol.engine.debug_decisions = None
         names = pol.trainable_names()
-        ref_loss, ref_g = OP.loss_and_grads(sd, batch, noise, ts, names=names)
-        assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item()), (B, seed, loss.item(), ref_loss.item())
         P = dict(pol.named_parameters())
-        _, g64 = _fp64_oracle_grads(OP, sd, batch, noise, ts, names)
-        rows = _grad_distances({n: P[n].grad for n in names}, ref_g, g64, names)
+        rows, ref_loss = _flip_aware_rows(OP, sd, batch, noise, ts, names, {n: P[n].grad for n in names}, hip_dec, f"[ragged B={B} seed={seed}] ")
+        assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss), (B, seed, loss.item(), ref_loss)
         worst_hip, worst_ref = max(r[1] for r in rows), max(r[2] for r in rows)
         med = float(np.median([r[1] for r in rows]))
-        print(f"[ragged B={B} seed={seed}] worst tensor vs fp64: HIP {worst_hip:.2e}, fp32 CPU oracle {worst_ref:.2e}; median tensor HIP {med:.2e}")
+        print(f"[ragged B={B} seed={seed}] worst tensor vs fp64 (HIP routing): HIP {worst_hip:.2e}, fp32 CPU oracle {worst_ref:.2e}; median tensor HIP {med:.2e}")
         assert med <= TOL, (B, seed, med)
-        if worst_ref > TOL:
-            assert worst_hip <= max(TOL, 2 * worst_ref) or worst_hip <= 5e-2, (B, seed, worst_hip, worst_ref)
-        rows_out.append((worst_hip, worst_ref))
+        bad = [r for r in rows if r[1] > max(TOL, 2 * worst_ref)]
+        assert not bad, (B, seed, bad[:5])
+        worst_all = max(worst_all, worst_hip)
         del pol
         torch.cuda.empty_cache()
-    n_hip = sum(1 for h, _ in rows_out if h > TOL)
-    n_ref = sum(1 for _, r in rows_out if r > TOL)
-    mx_hip, mx_ref = max(h for h, _ in rows_out), max(r for _, r in rows_out)
-    print(f"[ragged] batches outside 1e-4 on their worst tensor: HIP {n_hip} / {len(rows_out)}, fp32 CPU oracle {n_ref} / {len(rows_out)}; "
-          f"largest distance HIP {mx_hip:.2e}, oracle {mx_ref:.2e}")
-    assert n_hip <= n_ref + 3, (n_hip, n_ref)
-    assert mx_hip <= max(5e-2, 3 * mx_ref), (mx_hip, mx_ref)
+    print(f"[ragged] largest per-tensor distance over the six batches: {worst_all:.2e}")
 
 
 def test_c2_batch64_loss_and_grads_vs_oracle():
     """BASELINE configs[1] at its own batch: compute_loss + every gradient at B = 64 directly against the CPU oracle on the same seeded
-    inputs (the fixtures pin B = 8; B = 256 is tied to the oracle through linearity).  Loss 1e-4; gradients by the fp64 yard-stick: with
-    64 x 4096-pixel sums the fp32 CPU oracle is itself off the fp64 truth on its worst tensor, no HIP tensor may be further off than twice
-    that (or 1e-4), the median tensor meets 1e-4."""
+    inputs (the fixtures pin B = 8; B = 256 is tied to the oracle through linearity).  Loss 1e-4; gradients flip-aware (tests/flip_aware.py)
+    and by the fp64 yard-stick: with 64 x 4096-pixel sums the fp32 CPU oracle is itself off the fp64 truth on its worst tensor, no HIP
+    tensor may be further off than twice that (or 1e-4), the median tensor meets 1e-4."""
     from oracle import policy as OP
     B = 64
     pol, sd = _policy(seed=64)
@@ -820,21 +801,21 @@ def test_c2_batch64_loss_and_grads_vs_oracle():
     noise, ts = torch.randn(B, 16, 7, generator=g), torch.randint(0, 100, (B,), generator=g)
     pol.__dict__["_rng_hook"] = lambda shape, kind: {"noise": noise, "timesteps": ts}[kind]
     pol.train()
+    hip_dec = pol.engine.debug_decisions = {}
     loss = pol.compute_loss(batch)
     loss.backward()
+    pol.engine.debug_decisions = None
     names = pol.trainable_names()
+    P = dict(pol.named_parameters())
     old = torch.get_num_threads()
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     try:
-        ref_loss, ref_g = OP.loss_and_grads(sd, batch, noise, ts, names=names)
-        _, g64 = _fp64_oracle_grads(OP, sd, batch, noise, ts, names)
+        rows, ref_loss = _flip_aware_rows(OP, sd, batch, noise, ts, names, {n: P[n].grad for n in names}, hip_dec, "[C2 B=64] ")
     finally:
         torch.set_num_threads(old)
-    assert abs(loss.item() - ref_loss.item()) <= TOL * abs(ref_loss.item()), (loss.item(), ref_loss.item())
-    P = dict(pol.named_parameters())
-    rows = _grad_distances({n: P[n].grad for n in names}, ref_g, g64, names)
+    assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss), (loss.item(), ref_loss)
     worst_hip, worst_ref = max(r[1] for r in rows), max(r[2] for r in rows)
-    print(f"[C2 B=64] loss {loss.item():.7f} vs oracle {ref_loss.item():.7f}; worst tensor vs fp64: HIP {worst_hip:.2e}, fp32 CPU oracle {worst_ref:.2e}; "
+    print(f"[C2 B=64] loss {loss.item():.7f} vs oracle {ref_loss:.7f}; worst tensor vs fp64 (HIP routing): HIP {worst_hip:.2e}, fp32 CPU oracle {worst_ref:.2e}; "
           f"HIP vs fp32 oracle {max(r[3] for r in rows):.2e}")
     bad = [r for r in rows if r[1] > max(TOL, 2 * worst_ref)]
     assert not bad, bad[:5]

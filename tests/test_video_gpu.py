@@ -94,9 +94,9 @@ def test_bf16_unet_with_fused_groupnorm_equals_the_unfused_forward():
     xb, tb = torch.randn(4, 24, 128, 128, device="cuda:0"), torch.tensor([3, 40, 77, 99], device="cuda:0")
     teb = torch.randn(4, 10, 512, device="cuda:0")
     v2a_hip.set_video_storage("bf16")
-    old = ops._GN_FUSE
+    old = ops.GN_FUSE[0]
     try:
-        ops._GN_FUSE = True
+        ops.GN_FUSE[0] = True
         seen = []
         orig = ops.conv2d_h
 
@@ -110,11 +110,11 @@ def test_bf16_unet_with_fused_groupnorm_equals_the_unfused_forward():
         finally:
             ops.conv2d_h = orig
         assert any(n.startswith("conv_halo_h3_gn") for n in seen)
-        ops._GN_FUSE = False
+        ops.GN_FUSE[0] = False
         z0 = big(xb, tb, task_embed=teb)
         assert torch.isfinite(z0).all() and torch.equal(z0, z1)
     finally:
-        ops._GN_FUSE = old
+        ops.GN_FUSE[0] = old
         v2a_hip.set_video_storage("f32")
 
 

@@ -25,8 +25,6 @@ dev = "cuda:0"
 pol = build_policy(DEFAULT_CONF).to(dev)
 store = bench.build_store(torch, dev, B, seed=100)
 tr = PolicyTrainer(pol, store, batch_size=B, seed=0, use_graph=True)
-if os.environ.get("V2A_PRIO") == "1":          # experiment: the whole step on a high-priority stream, weight-gradient branches at normal priority
-    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 for _ in range(6):
     tr.step()
 torch.cuda.synchronize()

@@ -16,16 +16,16 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_policy -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph > $OUT/pmc_write_policy.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_policy_bf16 -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph --precision bf16 > $OUT/pmc_fetch_policy_bf16.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_policy_bf16 -o pmc -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph --precision bf16 > $OUT/pmc_write_policy_bf16.log 2>&1
-V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_video -o pmc -- python $R/tools/video_only.py --steps 1 > $OUT/pmc_fetch_video.log 2>&1
-V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_video -o pmc -- python $R/tools/video_only.py --steps 1 > $OUT/pmc_write_video.log 2>&1
-V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_video_bf16 -o pmc -- python $R/tools/video_only.py --steps 1 --storage bf16 > $OUT/pmc_fetch_video_bf16.log 2>&1
-V2A_SAMPLER_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_video_bf16 -o pmc -- python $R/tools/video_only.py --steps 1 --storage bf16 > $OUT/pmc_write_video_bf16.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_video -o pmc -- python $R/tools/video_only.py --steps 1 --no-graph > $OUT/pmc_fetch_video.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_video -o pmc -- python $R/tools/video_only.py --steps 1 --no-graph > $OUT/pmc_write_video.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_video_bf16 -o pmc -- python $R/tools/video_only.py --steps 1 --no-graph --storage bf16 > $OUT/pmc_fetch_video_bf16.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_video_bf16 -o pmc -- python $R/tools/video_only.py --steps 1 --no-graph --storage bf16 > $OUT/pmc_write_video_bf16.log 2>&1
 # MFMA utilisation (matrix-pipe busy cycles vs active clock), one pass per leg
 for leg in policy video video_bf16; do
   case $leg in
     policy) CMD="python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-video --no-bf16-extra --no-predict --no-roofline-pass --no-graph";;
-    video) CMD="env V2A_SAMPLER_GRAPH=0 python $R/tools/video_only.py --steps 1";;
-    video_bf16) CMD="env V2A_SAMPLER_GRAPH=0 python $R/tools/video_only.py --steps 1 --storage bf16";;
+    video) CMD="python $R/tools/video_only.py --steps 1 --no-graph";;
+    video_bf16) CMD="python $R/tools/video_only.py --steps 1 --storage bf16 --no-graph";;
   esac
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_$leg -o pmc -- $CMD > $OUT/pmc_mfma_$leg.log 2>&1
   python $R/tools/mfma_util.py $OUT/pmc_mfma_$leg > $OUT/mfma_util_$leg.json 2>> $OUT/pmc_summary.err

@@ -14,8 +14,11 @@ ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--precision", default="fp32")
 ap.add_argument("--storage", default="f32", choices=["f32", "bf16"])
+ap.add_argument("--no-graph", action="store_true", help="eager launches (PMC passes: rocprofv3 counters do not see kernels inside a replayed hipGraph)")
 a = ap.parse_args()
 import v2a_hip
+if a.no_graph:
+    v2a_hip.set_sampler_graphs(False)
 v2a_hip.set_precision(a.precision)
 v2a_hip.set_video_storage(a.storage)
 print(json.dumps(bench.video_leg(torch, "cuda:0", a.batch, a.steps, traffic_leg="video_bf16" if a.storage == "bf16" else "video", reps=1)))

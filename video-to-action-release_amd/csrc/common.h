@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned int v2a_pack_bf16x2(float lo, float hi) {
 typedef __attribute__((ext_vector_type(2))) _Float16 v2a_f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 v2a_f16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 v2a_bf16x8;
-extern int g_v2a_half_f16;            // process-wide: 0 bf16, 1 fp16 (v2a_set_half_format; the host wrappers set it from the tensor dtype)
+extern thread_local int g_v2a_half_f16;   // per host thread: 0 bf16, 1 fp16 (v2a_set_half_format; the host wrappers set it from the tensor dtype)
 template <bool F16> __device__ __forceinline__ unsigned short v2a_f2h(float f) {
     if constexpr (F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
     else return v2a_f2bf(f);

@@ -464,167 +464,6 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uin
     l = v2a_pack_bf16x2(s0, s1);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_bf16x3(const ConvDesc p) {
-    constexpr int BKT = 32, KC = 8, RPP = 32, LDH = 40;         // 40 halves = 80-B rows
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int AL = BM / RPP, BL = BN / RPP;
-    constexpr int PA = BM * LDH, PB = BN * LDH;                 // halves per plane
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * 3 * (PA + PB)];
-    constexpr int STG = 3 * (PA + PB);                            // halves per stage: A planes (hi, mid, lo), then B planes
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tiles_n = (p.Cout + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int lin = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (lin / tiles_n) * BM, n0 = (lin % tiles_n) * BN;
-    const int split = blockIdx.y;
-    const int Cin = p.C1 + p.C2;
-    const int nkt = (p.K + BKT - 1) / BKT;
-    const int kt_begin = split * p.ktiles_per_split;
-    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
-    const int lrow = tid / KC, chunk = tid % KC;
-    int a_ihb[AL], a_iwb[AL], a_img[AL];
-    bool a_ok[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-        int m = m0 + lrow + i * RPP;
-        a_ok[i] = m < p.M;
-        int mm = a_ok[i] ? m : 0;
-        int ow = mm % p.OW;
-        int t = mm / p.OW;
-        int oh = t % p.OH;
-        a_img[i] = t / p.OH;
-        a_ihb[i] = oh * p.sh - p.ph;
-        a_iwb[i] = ow * p.sw - p.pw;
-    }
-    f32x4 ra[AL], rb[BL];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BKT;
-        const int tap = k0 / Cin;
-        const int c = k0 - tap * Cin + chunk * 4;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            int ih = a_ihb[i] + kh, iw = a_iwb[i] + kw;
-            bool ok = a_ok[i] && ih >= 0 && ih < p.HL && iw >= 0 && iw < p.WL;
-            if (p.idil > 1) {
-                ok = ok && (ih % p.idil == 0) && (iw % p.idil == 0);
-                ih /= p.idil;
-                iw /= p.idil;
-            }
-            if (p.ups) { ih >>= 1; iw >>= 1; }
-            const size_t pix = ((size_t)a_img[i] * p.H + ih) * p.W + iw;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const float* src = (c < p.C1) ? p.x + pix * p.C1 + c : p.x2 + pix * p.C2 + (c - p.C1);
-                v = *reinterpret_cast<const f32x4*>(src);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            int n = n0 + lrow + i * RPP;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k0 + chunk * 4);
-            rb[i] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        uint16_t* A = smem + buf * STG;
-        uint16_t* B = A + 3 * PA;
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            uint32_t h0, m0_, l0, h1, m1, l1;
-            split3_pair(ra[i][0], ra[i][1], h0, m0_, l0);
-            split3_pair(ra[i][2], ra[i][3], h1, m1, l1);
-            const int o = (lrow + i * RPP) * LDH + chunk * 4;
-            *reinterpret_cast<uint2*>(&A[o]) = uint2{h0, h1};
-            *reinterpret_cast<uint2*>(&A[PA + o]) = uint2{m0_, m1};
-            *reinterpret_cast<uint2*>(&A[2 * PA + o]) = uint2{l0, l1};
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            uint32_t h0, m0_, l0, h1, m1, l1;
-            split3_pair(rb[i][0], rb[i][1], h0, m0_, l0);
-            split3_pair(rb[i][2], rb[i][3], h1, m1, l1);
-            const int o = (lrow + i * RPP) * LDH + chunk * 4;
-            *reinterpret_cast<uint2*>(&B[o]) = uint2{h0, h1};
-            *reinterpret_cast<uint2*>(&B[PB + o]) = uint2{m0_, m1};
-            *reinterpret_cast<uint2*>(&B[2 * PB + o]) = uint2{l0, l1};
-        }
-    };
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int wm = (wid >> 1) * WM, wn = (wid & 1) * WN;
-    const int lr = lane & 31, lk = lane >> 5;
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);
-        const uint16_t* A = smem + buf * STG;
-        const uint16_t* B = A + 3 * PA;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8 a[3][TM], b[3][TN];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bf16x8*>(&A[q * PA + (wm + i * 32 + lr) * LDH + 16 * h + 8 * lk]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bf16x8*>(&B[q * PB + (wn + j * 32 + lr) * LDH + 16 * h + 8 * lk]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);     // lo  * hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);     // hi  * lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);     // mid * mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);     // mid * hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);     // hi  * mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);     // hi  * hi
-                    acc[i][j] = c;
-                }
-        }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn + j * 32 + lr;
-            if (n >= p.Cout) continue;
-            const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (p.splitk > 1) {
-                    p.partial[((size_t)split * p.M + m) * p.Cout + n] = v;
-                } else {
-                    v += bv;
-                    if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
-                    if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-                    if (p.y2 && n >= p.csplit) p.y2[(size_t)m * (p.Cout - p.csplit) + (n - p.csplit)] = v;
-                    else p.y[(size_t)m * (p.y2 ? p.csplit : p.Cout) + n] = v;
-                }
-            }
-        }
-}
 
 // y[m][n] = sum_s partial[s][m][n] + bias + rowvec + residual   (split-K second pass)
 __global__ void conv_splitk_reduce(const ConvDesc p) {
@@ -1113,20 +952,12 @@ static int wgrad_halo_split(int M, int Cout, int K) {
     if (s > deep) s = deep;
     return s < 1 ? 1 : s;
 }
-static int g_wgrad_halo = -1;      // V2A_WGRAD_HALO=0 disables the halo kernel
-static bool wgrad_halo_on() {
-    if (g_wgrad_halo < 0) {
-        const char* e = getenv("V2A_WGRAD_HALO");
-        g_wgrad_halo = (e && e[0] == '0') ? 0 : 1;
-    }
-    return g_wgrad_halo == 1;
-}
 // geometry-free part of the eligibility test (what the workspace query can know)
 static bool wgrad_halo_shape_ok(int M, int Cout, int K) {
     // small problems lose: every workgroup writes a 64 x 576 slab, and with few (Cout, Cin) blocks all parallelism has to come from
     // the split (64 -> 64 channels at 32x32x128 images: 115 us against 88 us on the generic kernel); from ~8 GFLOP and >= 4 blocks up
     // the halo kernel wins by 20-40 % (tools/wgrad_sweep.py)
-    if (!(g_precision == 0 && wgrad_halo_on() && !g_wforce_bm && K % 9 == 0 && (K / 9) % 64 == 0 && Cout % 64 == 0 && M % 32 == 0)) return false;
+    if (!(g_precision == 0 && !g_wforce_bm && K % 9 == 0 && (K / 9) % 64 == 0 && Cout % 64 == 0 && M % 32 == 0)) return false;
     return (Cout / 64) * (K / 9 / 64) >= 4 && 2.0 * (double)M * (double)K * (double)Cout >= 8e9;
 }
 
@@ -2431,12 +2262,7 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
         const bool big = Cout > 64 && K > 64 && flops >= 30e9 && tiles128 >= 8;
         *bm = *bn = big ? 128 : 64;
         *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
-        static int target = -1;                     // workgroups aimed at per launch (V2A_WGRAD_TARGET: tuning aid)
-        if (target < 0) {
-            const char* e = getenv("V2A_WGRAD_TARGET");
-            target = e ? atoi(e) : 1024;
-            if (target < 64) target = 1024;
-        }
+        const int target = 1024;                    // workgroups aimed at per launch (tools/wgrad_sweep.py: flat between 512 and 1536)
         int sp = target / *tiles;
         const int cap = big ? 128 : 64, deep = cdiv(M, 32) / 8;
         if (sp > cap) sp = cap;
@@ -2461,13 +2287,8 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
     *bn = (K > 64 && *bm == 128) ? 128 : 64;
     *tiles = cdiv(Cout, *bm) * cdiv(K, *bn);
     // very few big tiles mean a very deep split (9 tiles -> 56 slices): the fp32 slabs (write + re-read) then cost as much as the
-    // contraction.  Quartering the tiles quarters the split depth at nearly the same MFMA efficiency (V2A_WGRAD_SMALL_TILES=0: off)
-    static int small_mode = -1;
-    if (small_mode < 0) {
-        const char* e = getenv("V2A_WGRAD_SMALL_TILES");
-        small_mode = e ? atoi(e) : 96;
-    }
-    if (small_mode > 0 && *tiles < small_mode && *bm == 128) {
+    // contraction.  Quartering the tiles quarters the split depth at nearly the same MFMA efficiency
+    if (*tiles < 96 && *bm == 128) {
         *bm = 64;
         *bn = 64;
         *tiles = cdiv(Cout, 64) * cdiv(K, 64);
@@ -2479,16 +2300,7 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
     *s = (*tiles >= 192) ? 1 : pick_split(*tiles, cdiv(M, BK), 4);
 }
 
-static int g_wgrad_stages64 = 2;  // LDS stages of the 64x64 DMA weight-gradient kernel (V2A_WGRAD_STAGES=4: the four-stage experiment)
 extern "C" int v2a_get_f32_conv_mode(void);
-static int g_wgrad_x3 = -1;
-static bool wgrad_x3_on() {
-    if (g_wgrad_x3 < 0) {
-        const char* e = getenv("V2A_WGRAD_X3");
-        g_wgrad_x3 = (e && e[0] == '0') ? 0 : 1;      // default ON with the transposing-read body (policy step 9.75 -> 9.15 ms; the first,
-    }                                                  // register-transposing version was slower than the exact bodies: 10.5 ms)
-    return g_wgrad_x3 == 1;
-}
 static int g_wgrad_dma = -1;  // fp32 weight gradients with 128-row output tiles on the LDS-DMA kernel (V2A_WGRAD_DMA=0 / v2a_debug_wgrad_dma)
 
 extern "C" {
@@ -2496,7 +2308,7 @@ extern "C" {
 // process-wide MFMA precision of the contraction kernels (0 = f32 exact, 1 = bf16 inputs / f32 accumulate); returns the old value
 int v2a_set_precision(int mode) {
     int old = g_precision;
-    if (mode == 0 || mode == 1 || mode == 2) g_precision = mode;      // 2: experiment -- fp32 products from three bf16 planes (conv_igemm_bf16x3)
+    if (mode == 0 || mode == 1) g_precision = mode;
     return old;
 }
 int v2a_get_precision(void) { return g_precision; }
@@ -2510,10 +2322,7 @@ int v2a_set_policy_half(int f16) {
 int v2a_get_policy_half(void) { return g_v2a_policy_f16; }
 static int wgrad_dma_on() {
     if (g_wgrad_dma < 0) {
-        const char* e = getenv("V2A_WGRAD_DMA");
-        g_wgrad_dma = (e && e[0] == '0') ? 0 : 1;
-        const char* st = getenv("V2A_WGRAD_STAGES");
-        if (st && st[0] == '4') g_wgrad_stages64 = 4;
+        g_wgrad_dma = 1;
     }
     return g_wgrad_dma;
 }
@@ -2586,22 +2395,6 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
     p.splitk = s;
     p.ktiles_per_split = cdiv(nkt, s);
     dim3 grid(tiles, s), block(256);
-    if (g_precision == 2 && vec && Cin % 32 == 0 && !p.bmode) {     // experiment: fp32 by three bf16 planes
-        p.splitk = s;
-        p.ktiles_per_split = cdiv(cdiv(p.K, 32), s);
-        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128>), grid, block, 0, stream, p);
-        else if (bm == 128) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 64>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64>), grid, block, 0, stream, p);
-        V2A_CHECK_LAUNCH();
-        if (s > 1) {
-            size_t total = (size_t)p.M * Cout;
-            int g = (int)((total + 255) / 256);
-            if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(conv_splitk_reduce, dim3(g), dim3(256), 0, stream, p);
-            V2A_CHECK_LAUNCH();
-        }
-        return V2A_OK;
-    }
     if (g_precision == 1 && vec && Cin % 32 == 0 && !p.bmode) {     // bf16 MFMA (data gradients then use the flipped pack, bmode 0)
         p.splitk = s;
         p.ktiles_per_split = cdiv(cdiv(p.K, 32), s);
@@ -2658,12 +2451,7 @@ size_t v2a_conv2d_wgrad_workspace_bytes(int M, int Cout, int K) {
 // Weight gradient from the bf16 twins of the operands (bf16 MFMA, fp32 accumulate, dw in the torch layout as v2a_conv2d_wgrad).
 // For layers the 128-row bf16 tiles take: Cout > 64, K > 64, Cin % 8 == 0, Cout % 8 == 0, single input source.
 static int wgrad_h_split(int M, int Cout, int K) {
-    static int target = -1;                         // workgroups aimed at (V2A_WGRAD_H_TARGET: tuning aid)
-    if (target < 0) {
-        const char* e = getenv("V2A_WGRAD_H_TARGET");
-        target = e ? atoi(e) : 768;
-        if (target < 64) target = 768;
-    }
+    const int target = 768;                         // workgroups aimed at (swept 384 ... 1536: tools/wgrad_sweep.py --bf16)
     const int tiles = cdiv(Cout, Cout <= 64 ? 64 : 128) * cdiv(K, 128);
     int s = target / tiles, deep = cdiv(M, 32) / 8;
     if (deep > 256) deep = 256;
@@ -2697,13 +2485,7 @@ int v2a_conv2d_wgrad_h(const void* x_h, const void* x2_h, const void* dy_h, floa
     const int s = wgrad_h_split(p.M, Cout, p.K);
     if (s > 1 && ((size_t)s * Cout * p.K + (size_t)s * Cout) * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splits = s;
-    static int use_tr = -1;                         // V2A_WGRAD_TR=0: the register-staged twin kernel instead of the LDS-DMA / tr-read one
-    if (use_tr < 0) {
-        const char* e = getenv("V2A_WGRAD_TR");
-        use_tr = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (!use_tr && (bm64 || C2 > 0)) return V2A_ERR_ARG;        // (the register-staged fallback has no 64-row / two-source instance)
-    if (use_tr && (((uintptr_t)x_h | (uintptr_t)x2_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * (C > C2 ? C : C2) < 2147483648.0) {
+    if ((((uintptr_t)x_h | (uintptr_t)x2_h | (uintptr_t)dy_h) & 15) == 0 && (double)N * H * W * (C > C2 ? C : C2) < 2147483648.0) {
         p.rtiles_per_split = cdiv(cdiv(p.M, 64), s);
         if (g_v2a_policy_f16) {
             if (bm64) hipLaunchKernelGGL((conv_wgrad_tr_h<64, true>), dim3(tiles, s), dim3(256), 0, stream, p);
@@ -2770,9 +2552,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
     // few-channel inputs (the RGB stem padded to 4 channels: K = 196, a reduction over N * OH * OW = 262 144 rows) in the fp32
     // three-plane mode: the three-plane body as a one-problem launch of the grouped kernel, with the plan's split (the exact LDS-DMA
     // kernel it replaces: 173 us per encoder, at the tail of the step's weight-gradient branch)
-    static int stem_x3 = -1;
-    if (stem_x3 < 0) { const char* e = getenv("V2A_STEM_WGRAD_X3"); stem_x3 = (e && e[0] == '0') ? 0 : 1; }      // (in-step A/B: 8.86 vs 8.90 ms with the exact LDS-DMA kernel)
-    if (stem_x3 && g_precision == 0 && v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && veca && vecb && Cin <= 8 && !x2 && Cout % 4 == 0 &&
+    if (g_precision == 0 && v2a_get_f32_conv_mode() == 1 && veca && vecb && Cin <= 8 && !x2 && Cout % 4 == 0 &&
         p.K % 4 == 0 && p.idil == 1 && !ups && (double)N * H * W * C1 < 1073741824.0) {
         WgradMultiArgs a;
         __builtin_memset(&a, 0, sizeof(a));
@@ -2826,8 +2606,7 @@ int v2a_conv2d_wgrad(const float* x, const float* x2, const float* dy, float* dw
         p.rtiles_per_split = cdiv(cdiv(p.M, 32), s);
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 128>), grid, block, 0, stream, p);
         else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_dma_f32<128, 64>), grid, block, 0, stream, p);
-        else if (g_wgrad_stages64 == 2) hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64, 2>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64, 4>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_dma_f32<64, 64, 2>), grid, block, 0, stream, p);
         V2A_CHECK_LAUNCH();
         if (s > 1) {
             launch_wgrad_reduce(p, stream);
@@ -2942,17 +2721,13 @@ int v2a_conv2d_wgrad_describe(const float* x, const float* x2, const float* dy, 
                (((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)dy) & 15) == 0 && big < 4294967296.0) {
         variant = 0;
         // 3x3 / stride 1 / pad 1 over whole 32-pixel patches: the halo-tile body (V2A_WGRAD_HALO=0 keeps the 64x64 body)
-        if (wgrad_halo_on() && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && p.idil == 1 && C2 == 0 && OH == H &&
+        if (KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && p.idil == 1 && C2 == 0 && OH == H &&
             OW == W && C1 % 64 == 0 && Cout % 64 == 0 && p.M % 32 == 0 && (OW == 8 || OW == 16 || OW % 32 == 0) &&
             OH % (OW >= 32 ? 1 : 32 / OW) == 0 && big < 2147483648.0)
             variant = OW == 8 ? 5 : (OW == 16 ? 4 : 3);
-        if (v2a_get_f32_conv_mode() == 1 && wgrad_x3_on() && p.idil <= 2 && big < 1073741824.0) {       // fp32 products from three bf16 planes (V2A_WGRAD_X3=0: the exact bodies)
-            static int x3h = -1;                      // V2A_WGRAD_X3H=0: 3x3 layers on the plain three-plane body too (A/B)
-            if (x3h < 0) { const char* e = getenv("V2A_WGRAD_X3H"); x3h = (e && e[0] == '0') ? 0 : 1; }
+        if (v2a_get_f32_conv_mode() == 1 && p.idil <= 2 && big < 1073741824.0) {       // fp32 products from three bf16 planes (V2A_WGRAD_X3=0: the exact bodies)
             const bool halo_geo = variant >= 3;       // (the exact halo body's geometry test above: 3x3 / stride 1 / pad 1, whole 32-pixel patches)
-            static int x3h_min_ow = -1;               // V2A_WGRAD_X3H_MIN_OW: narrower maps stay on the plain body (A/B)
-            if (x3h_min_ow < 0) { const char* e = getenv("V2A_WGRAD_X3H_MIN_OW"); x3h_min_ow = e ? atoi(e) : 8; }
-            if (x3h && halo_geo && OW >= x3h_min_ow) variant = OW == 8 ? 10 : (OW == 16 ? 9 : 8);
+            if (halo_geo && OW >= 8) variant = OW == 8 ? 10 : (OW == 16 ? 9 : 8);
             else variant = Cout >= 128 ? 7 : 6;
         }
     }

@@ -23,7 +23,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 struct f16s { uint16_t v; };      // storage tag of the fp16 instances (tensors are raw 16-bit words either way)
-int g_v2a_half_f16 = 0;           // process-wide 16-bit format of the video-storage kernels: 0 bf16, 1 fp16 (v2a_set_half_format)
+thread_local int g_v2a_half_f16 = 0;   // 16-bit format of the calling host thread's `_h` launches: 0 bf16, 1 fp16 (v2a_set_half_format)
 template <typename T> struct is_f16s { static constexpr bool value = false; };
 template <> struct is_f16s<f16s> { static constexpr bool value = true; };
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -67,15 +67,10 @@ struct ConvDescH {
     int idil;                 // input dilation 1 | 2 (strided data gradient / transposed conv): logical input = zero-interleaved x
     int frame_tiles;          // > 0: frame-interleaved tile order for (3 x 1) convs, = tiles per frame (OW / BM); 0: row order
     FastDivH fd_ow, fd_oh;
-    const void* w2;           // second weight set (rows >= m_split) or null       [conv_igemm_f32p only]
-    const float* bias2;       // second bias (rows >= m_split) or null
-    int m_split;              // first output row of the second set (a multiple of every row tile); INT_MAX: one set
     int split_xcd;            // > 0: 1-D grid, split-K slices pinned to XCDs (slices per XCD)              [conv_igemm_f32x3 only]
     int xp1;                  // element pitch between consecutive pixels of source 1 (= C1; < C1: overlapping channel windows,
                               // v2a_conv2d_fwd_window_f32)                                      [conv_igemm_f32x3, non-GEN path only]
-    unsigned long long* tstamps;   // measurement aid (v2a_debug_conv_stamps): [workgroup][8] wall-clock stamps of the kernel's phases, or null
 };
-#define V2A_STAMP(i) do { if (p.tstamps && threadIdx.x == 0) p.tstamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ int xcd_remap_h(int bid, int nblk) {
     int q = nblk >> 3, r = nblk & 7;
@@ -108,7 +103,6 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     __shared__ __attribute__((aligned(128))) unsigned char smem[STAGES * BUF];      // ONE LDS object (A0 B0 [A1 B1])
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    V2A_STAMP(0);
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
@@ -248,12 +242,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     };
     if constexpr (STAGES == 2) {
         if (kt_begin < kt_end) issue(0);
-        V2A_STAMP(1);
         int buf = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                        // tile kt landed everywhere; everyone is done reading the other buffer
-            if (kt == kt_begin) V2A_STAMP(2);
             if (kt + 1 < kt_end) issue(buf ^ 1);
             compute(smem + buf * BUF);
             buf ^= 1;
@@ -261,10 +253,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     } else {
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             issue(0);
-            if (kt == kt_begin) V2A_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                        // tile kt landed everywhere
-            if (kt == kt_begin) V2A_STAMP(2);
             compute(smem);
             __syncthreads();                        // everyone is done reading before the next tile overwrites the buffer
         }
@@ -275,7 +265,6 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
     // bias / embedding vector / residual are applied on 8-wide vectors and the result leaves as one 16-B bf16 store (a full
     // 128-B line per row and wave) instead of 2-byte scatters.
     __syncthreads();
-    V2A_STAMP(3);
     constexpr int LDC = WN;                                       // floats per parked row; columns XOR-ed with 4 * (row & 1) so that
     static_assert(4 * 32 * LDC * 4 <= STAGES * BUF, "epilogue staging exceeds the operand buffers");   // the b128 read-back is conflict-free
     float* cw = reinterpret_cast<float*>(smem) + wid * 32 * LDC;  // one 32-row sub-tile of this wave at a time (wave-private region)
@@ -388,8 +377,6 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void conv_igemm_h(const C
             }
         }
     }
-    V2A_STAMP(4);
-    if (p.tstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); V2A_STAMP(5); }     // stores acknowledged
     if (p.stats && p.splitk == 1 && vec_ok) {
         // this wave's 64 rows x 64 channels: lanes with equal lane % V hold the same 8 channels for different rows
 #pragma unroll
@@ -497,8 +484,6 @@ __device__ __forceinline__ void conv_f32_epilogue(const ConvDescH& p, f32x16 (&a
             }
         }
     }
-    V2A_STAMP(4);
-    if (p.tstamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); V2A_STAMP(5); }
     if (p.stats && p.splitk == 1 && vec_ok) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -535,8 +520,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_h() { asm volatile("
 //     slice the pieces read the zero line into a dead stage, so the count is a compile-time constant),
 //   * operand fragments of k-step h + 1 are read while the MFMAs of step h issue (register double buffer).
 // Same tiles, same LDS image (source-side swizzle), same k order per accumulator as conv_igemm_h<.., float>: results are bit-identical.
-// w2 / bias2 / m_split: output rows >= m_split use the second weight / bias set (the two camera encoders of the policy as ONE stacked
-// batch; m_split is a multiple of every row tile).
 // GEN = false: plain gather (no nearest-x2 upsample, no zero-interleaved input) -- a piece's offset is a per-thread constant plus a
 // per-tile SCALAR (no multiply in the loop); GEN = true: the general form.
 template <int BM, int BN, int S, int MINW, bool GEN>
@@ -550,7 +533,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) 
     __shared__ __attribute__((aligned(128))) unsigned char smem[S * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    V2A_STAMP(0);
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
@@ -568,9 +550,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) 
     const int nkt = p.K / EPT;
     const int kt_begin = split * p.ktiles_per_split;
     const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
-    const bool second = m0 >= p.m_split;
-    const T* wsel = reinterpret_cast<const T*>(second ? p.w2 : p.w);
-    const float* bias_sel = second ? p.bias2 : p.bias;
+    const T* wsel = reinterpret_cast<const T*>(p.w);
+    const float* bias_sel = p.bias;
 
     const int lrow = tid >> 3;
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
@@ -690,12 +671,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) 
         issue(s, 0, NL);
         advance();
     }
-    V2A_STAMP(1);
     int cbuf = 0, ibuf = S - 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         wait_vmcnt_h<(S - 2) * NL>();                       // this wave's pieces of tile kt have landed; younger tiles stay in flight
         __builtin_amdgcn_s_barrier();                       // ... everyone's have, and everyone is done reading the stage issued into next
-        if (kt == kt_begin) V2A_STAMP(2);
         const unsigned char* base = smem + cbuf * STAGE;
         f32x4_t a[2][TM], b[2][TN];
 #pragma unroll
@@ -730,7 +709,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) 
     // ---- epilogue: park each wave's sub-tiles in LDS, leave as 2 x 16-B stores per lane
     wait_vmcnt_h<0>();                                       // the zero-line pieces past the end still land in the stages
     __syncthreads();
-    V2A_STAMP(3);
     static_assert(4 * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
     conv_f32_epilogue<BM, BN>(p, acc, smem, m0, n0, split, bias_sel);
 }
@@ -769,7 +747,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     __shared__ __attribute__((aligned(128))) unsigned char smem[2 * STG];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    V2A_STAMP(0);
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     int lin, split;
@@ -799,9 +776,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     const int nkt = p.K / EPT;
     const int kt_begin = split * p.ktiles_per_split;
     const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
-    const bool second = m0 >= p.m_split;
-    const float* wsel = reinterpret_cast<const float*>(second ? p.w2 : p.w);
-    const float* bias_sel = second ? p.bias2 : p.bias;
+    const float* wsel = reinterpret_cast<const float*>(p.w);
+    const float* bias_sel = p.bias;
 
     // loader: thread -> (row lrow + 32 j, float4 c4 of the 32-float k tile)
     const int lrow = tid >> 3, c4 = tid & 7;
@@ -962,11 +938,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     f32x4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
     load(ra0, rb0);
     load(ra1, rb1);
-    V2A_STAMP(1);
     split_store_a(ra0, smem);
     split_store_b(rb0, smem);
     __syncthreads();
-    V2A_STAMP(2);
     // one k tile: `cur` registers hold tile kt + 1 (requested one iteration ago), tile kt + 2 is requested into `nxt`
     auto step = [&](f32x4 (&ra_c)[AL], f32x4 (&rb_c)[BL], f32x4 (&ra_n)[AL], f32x4 (&rb_n)[BL], int buf) {
         unsigned char* cur = smem + buf * STG;
@@ -985,7 +959,6 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
         step(ra0, rb0, ra1, rb1, 1);
     }
     // (every wave passed the loop's last barrier after its last LDS access; the trailing register loads hit the zero line)
-    V2A_STAMP(3);
     static_assert(WVM * WVN * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
     conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, bias_sel);
 }
@@ -1022,7 +995,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
     unsigned char* Hs = smem;
     unsigned char* Bs = smem + 3 * PHB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    V2A_STAMP(0);
     const int tiles_n = p.Cout / BN, tiles_m = p.M / BM;
     const int lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
     const int tm = lin / tiles_n;
@@ -1185,11 +1157,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
     loadB_next(rb0);
     loadB_next(rb1);
     loadB_next(rb2);
-    V2A_STAMP(1);
     storeH(rh);
     storeB(rb0, 0);
     __syncthreads();
-    V2A_STAMP(2);
     int stage = 0;
     for (int ck = ck_begin; ck < ck_end; ++ck) {
         const bool more = ck + 1 < ck_end;
@@ -1213,7 +1183,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3(const ConvDescH p) {
             stage ^= 1;
         }
     }
-    V2A_STAMP(3);
     static_assert(4 * 32 * 32 * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
     conv_f32_epilogue<BM, BN, 2, 2>(p, acc, smem, m0, n0, split, p.bias);
 }
@@ -1227,7 +1196,7 @@ __global__ void conv_splitk_reduce_h(const ConvDescH p) {
         const int m = (int)(idx / p.Cout), n = (int)(idx - (size_t)m * p.Cout);
         float v = 0.f;
         for (int s = 0; s < p.splitk; ++s) v += p.partial[(size_t)s * total + idx];
-        if (p.bias) v += (m >= p.m_split ? p.bias2 : p.bias)[n];
+        if (p.bias) v += p.bias[n];
         if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + n];
         if (p.residual) v += HALF ? v2a_h2f<F16>(reinterpret_cast<const uint16_t*>(p.residual)[idx]) : reinterpret_cast<const float*>(p.residual)[idx];
         if (p.residual_f) v += p.residual_f[idx];
@@ -1290,45 +1259,23 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
 }
 
 static void f32_conv_mode_init();
-// second weight / bias set of the NEXT fp32 LDS-DMA conv launch (output rows >= m_split read it): host-side state, consumed by that launch
-static const void* g_conv_w2 = nullptr;
-static const float* g_conv_bias2 = nullptr;
-static int g_conv_msplit = 0x7fffffff;
-static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact switches to the exact-f32 MFMA kernels
-static int g_f32p = -1, g_f32p_s128 = 2, g_f32p_s64 = 4;   // pipelined exact-f32 conv (conv_igemm_f32p): on / stages of the 128x128 and 64x64 tiles
-static unsigned long long* g_conv_stamps = nullptr;     // v2a_debug_conv_stamps: next launch's stamp block (advanced per launch)
-static size_t g_conv_stamp_stride = 0;
-static int g_stages_h = -1;       // 128x128 kernel on launches of >= 768 workgroups: 1 LDS buffer, 4 workgroups per CU (V2A_DMA_STAGES=2: always two buffers)
-static int g_small_tile_h = -1;   // 64x64 tiles for problems that 128-row tiles cannot spread over the chip (V2A_DMA_SMALL_TILE=0 disables)
+static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact / v2a_set_f32_conv_mode(0) select the exact-f32 MFMA kernels
+// Tile / split plan shared by the LDS-DMA conv families.  128-row tiles (64 output columns for 64-wide layers); problems that 128-row
+// tiles cannot spread over the chip (< 128 tiles) take 64 x 64 tiles; K is split so that one round of about 512 workgroups covers the
+// launch, every slice at least 6 k tiles deep, at most 16 slices.
 static void conv_plan_h(int M, int Cout, int K, int ept, int* bm, int* bn, int* tiles, int* s) {
-    if (g_small_tile_h < 0) {
-        const char* e = getenv("V2A_DMA_SMALL_TILE");
-        g_small_tile_h = (e && e[0] == '0') ? 0 : 1;
-    }
     *bm = 128;
     *bn = Cout <= 64 ? 64 : 128;                   // 64-wide layers (ResNet layer1) would waste half of a 128-column tile
     *tiles = cdiv(M, 128) * cdiv(Cout, *bn);
-    // few big tiles: quarter them (more workgroups, shallower split-K).  V2A_DEEP_SMALL_M=1 (experiment, default off) keeps 128-wide tiles
-    // for the deep small-M GEMMs of the ConditionalUnet1D (M <= 1024 rows, >= 1 G MACs), which are bound by operand bytes through the
-    // vector L1: the conv launches gain (45.6 -> 34.8 us, 25.6 -> 21.3 us, tools/probes/r4/unet_conv_time.py), the GroupNorm launches that
-    // sum their split-K slabs lose as much (twice the slabs) -- step 8.09 vs 8.07 ms.
-    static int deep_on = -1;
-    if (deep_on < 0) { const char* e = getenv("V2A_DEEP_SMALL_M"); deep_on = (e && e[0] == '1') ? 1 : 0; }
-    const bool deep_small_m = deep_on && ept == 32 && M <= 1024 && (double)M * Cout * K >= 1.0e9;
-    if (g_small_tile_h && *tiles < 128 && !deep_small_m) {
+    if (*tiles < 128) {
         *bm = 64;
         *bn = 64;
         *tiles = cdiv(M, 64) * cdiv(Cout, 64);
     }
     int sp = 1;
     const int nkt = K / ept;                       // k tiles of 128 B: 64 bf16 or 32 fp32
-    static int slots = -1;                         // workgroups aimed at per launch (V2A_CONV_SLOTS: tuning aid)
-    if (slots < 0) {
-        const char* e = getenv("V2A_CONV_SLOTS");
-        slots = e ? atoi(e) : 512;
-        if (slots < 256) slots = 512;
-    }
-    if (*tiles < slots - slots / 8) {              // one round over the workgroup slots, >= 6 k tiles per slice, <= 16 slices
+    const int slots = 512;                         // workgroups aimed at per launch
+    if (*tiles < slots - slots / 8) {
         sp = slots / *tiles;
         const int smax = nkt / 6 < 16 ? nkt / 6 : 16;
         if (sp > smax) sp = smax;
@@ -1350,17 +1297,6 @@ static int conv_halo_x3_split(int M, int Cout, int Cin) {
     const int cps = cdiv(nchunks, s);
     return cdiv(nchunks, cps);
 }
-static int g_conv_x3h = -1;       // V2A_CONV_X3H=0: 3x3 / stride-1 layers stay on conv_igemm_f32x3 (A/B)
-static bool conv_x3h_64() {        // V2A_CONV_X3H_64=0: 64-wide maps (the fp32 sampler's second level; two map rows per tile) stay on conv_igemm_f32x3
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("V2A_CONV_X3H_64"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on == 1;
-}
-static bool conv_x3h_on() {
-    if (g_conv_x3h < 0) { const char* e = getenv("V2A_CONV_X3H"); g_conv_x3h = (e && e[0] == '0') ? 0 : 1; }
-    return g_conv_x3h == 1;
-}
-
 extern "C" {
 
 size_t v2a_conv2d_h_workspace_bytes(int M, int Cout, int K) {
@@ -1414,8 +1350,6 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
     p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.ups = ups ? 1 : 0;
     p.stats = nullptr;
-    p.tstamps = g_conv_stamps;
-    if (g_conv_stamps) g_conv_stamps += (size_t)g_conv_stamp_stride;
     p.HL = ups ? 2 * H : (idil == 2 ? 2 * H - 1 : H);
     p.WL = ups ? 2 * W : (idil == 2 ? 2 * W - 1 : W);
     p.M = N * OH * OW;
@@ -1428,13 +1362,8 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(p.K / ept, s);
-    static int frame_order = -1;                    // V2A_FRAME_TILES=0: row order for the temporal convs too
-    if (frame_order < 0) {
-        const char* e = getenv("V2A_FRAME_TILES");
-        frame_order = (e && e[0] == '0') ? 0 : 1;
-    }
     p.frame_tiles = 0;
-    if (frame_order && KH == 3 && KW == 1 && sh == 1 && sw == 1 && ph == 1 && pw == 0 && !ups && idil == 1 && OH == H && OW == W &&
+    if (KH == 3 && KW == 1 && sh == 1 && sw == 1 && ph == 1 && pw == 0 && !ups && idil == 1 && OH == H && OW == W &&
         OH > 1 && OW % bm == 0 && s == 1)
         p.frame_tiles = OW / bm;
     // fused GroupNorm statistics need the single-pass epilogue, an output in the storage type and whole 8-channel vectors
@@ -1442,11 +1371,6 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         if (s > 1 || !y || Cout % 8 || bm != 128) return V2A_ERR_ARG;
         p.stats = stats;
     }
-    if (g_stages_h < 0) {
-        const char* e = getenv("V2A_DMA_STAGES");
-        g_stages_h = (e && e[0] == '2') ? 2 : 1;
-    }
-    p.w2 = nullptr; p.bias2 = nullptr; p.m_split = 0x7fffffff;
     p.split_xcd = 0;
     p.xp1 = xpitch > 0 ? xpitch : C1;
     if (xpitch > 0) {                                // channel windows: the three-plane kernel's plain loader only
@@ -1455,25 +1379,10 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         if (!g_f32x3) return V2A_ERR_ARG;
     }
     if constexpr (sizeof(T) == 4) {
-        if (g_conv_w2) {                             // second operand set of this launch (v2a_conv2d_set_second), consumed here
-            const int ms = g_conv_msplit;
-            p.w2 = g_conv_w2; p.bias2 = g_conv_bias2; p.m_split = ms;
-            g_conv_w2 = nullptr; g_conv_bias2 = nullptr; g_conv_msplit = 0x7fffffff;
-            if (ms < 1 || ms % 256 != 0 || (((uintptr_t)p.w2) & 15)) return V2A_ERR_ARG;      // a multiple of every row tile
-        }
-        if (g_f32p < 0) {                            // V2A_F32P=0: the round-1..3 kernel (A/B); V2A_F32P_S128 / _S64: LDS stages per tile shape
-            const char* e = getenv("V2A_F32P");
-            g_f32p = (e && e[0] == '0') ? 0 : 1;
-            const char* e2 = getenv("V2A_F32P_S128");
-            if (e2 && e2[0] == '3') g_f32p_s128 = 3;
-            const char* e3 = getenv("V2A_F32P_S64");
-            if (e3 && e3[0] == '3') g_f32p_s64 = 3;
-        }
-        const int f32p = g_f32p, s128 = g_f32p_s128, s64 = g_f32p_s64;
         f32_conv_mode_init();
-        if (g_f32x3 && conv_x3h_on() && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && idil == 1 &&
-            !x2 && C2 == 0 && H == W && OH == H && OW == W && (W == 4 || W == 8 || W == 16 || W == 32 || (W == 64 && conv_x3h_64())) && p.M % 128 == 0 && Cout % 64 == 0 &&
-            !stats && !p.w2 && (double)N * H * W * C1 < 2147483648.0) {
+        if (g_f32x3 && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && !ups && idil == 1 &&
+            !x2 && C2 == 0 && H == W && OH == H && OW == W && (W == 4 || W == 8 || W == 16 || W == 32 || W == 64) && p.M % 128 == 0 && Cout % 64 == 0 &&
+            !stats && (double)N * H * W * C1 < 2147483648.0) {
             // 3x3 / stride 1 / pad 1 over the encoders' square maps: the halo kernel (its own split, over 32-channel chunks)
             s = conv_halo_x3_split(p.M, Cout, C1);
             if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
@@ -1492,48 +1401,42 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
             // tiles: 64 x 64 (small problems, the plan's split), 128 x 64 / 256 x 64 for 64-wide layers, 128 x 128 on 8 waves otherwise --
             // the wider the tile, the fewer fp32 -> plane conversions and LDS bytes per MFMA
             const bool gen = ups || idil == 2;
-            static int sx_on = -1;                            // V2A_SPLIT_XCD=0: slice = blockIdx.y as before (A/B)
-            if (sx_on < 0) { const char* e = getenv("V2A_SPLIT_XCD"); sx_on = (e && e[0] == '0') ? 0 : 1; }
-            p.split_xcd = (sx_on && s >= 8 && s % 8 == 0 && p.frame_tiles == 0) ? s / 8 : 0;
+            p.split_xcd = (s >= 8 && s % 8 == 0 && p.frame_tiles == 0) ? s / 8 : 0;
 #define V2A_X3_LAUNCH(BM_, BN_, WM_, WN_, G_)                                                                                            \
     do {                                                                                                                                   \
         const dim3 grid_ = p.split_xcd > 0 ? dim3((G_) * s, 1) : dim3(G_, s);                                                              \
         if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, true>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);           \
         else hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, false>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);             \
     } while (0)
-            static int big = -1;                             // V2A_X3_BIG=0: four-wave tiles only (A/B)
-            if (big < 0) { const char* e = getenv("V2A_X3_BIG"); big = (e && e[0] == '0') ? 0 : 1; }
             if (bm == 64) V2A_X3_LAUNCH(64, 64, 2, 2, tiles);
             else if (bn == 64) {
                 const int t256 = cdiv(p.M, 256) * cdiv(Cout, 64);
-                if (big && t256 >= 200 && p.M % 256 == 0 && p.frame_tiles == 0) V2A_X3_LAUNCH(256, 64, 4, 2, t256);
+                if (t256 >= 200 && p.M % 256 == 0 && p.frame_tiles == 0) V2A_X3_LAUNCH(256, 64, 4, 2, t256);
                 else V2A_X3_LAUNCH(128, 64, 2, 2, tiles);
-            } else if (big) V2A_X3_LAUNCH(128, 128, 2, 4, tiles);
-            else V2A_X3_LAUNCH(128, 64, 2, 2, cdiv(p.M, 128) * cdiv(Cout, 64));
+            } else V2A_X3_LAUNCH(128, 128, 2, 4, tiles);
 #undef V2A_X3_LAUNCH
             goto launched;
         }
-        if (f32p) {
+        {   // exact-f32 MFMA mode (V2A_F32_CONV=exact): the pipelined kernel, bit-equal to an fmaf chain per accumulator
             const bool gen = ups || idil == 2;
 #define V2A_F32P_LAUNCH(BM_, BN_, S_, W_)                                                                                       \
     do {                                                                                                                          \
         if (gen) hipLaunchKernelGGL((conv_igemm_f32p<BM_, BN_, S_, W_, true>), dim3(tiles, s), dim3(256), 0, stream, p);          \
         else hipLaunchKernelGGL((conv_igemm_f32p<BM_, BN_, S_, W_, false>), dim3(tiles, s), dim3(256), 0, stream, p);            \
     } while (0)
-            if (bm == 64) {
-                if (s64 == 3) V2A_F32P_LAUNCH(64, 64, 3, 3);
-                else V2A_F32P_LAUNCH(64, 64, 4, 2);
-            } else if (bn == 64) V2A_F32P_LAUNCH(128, 64, 3, 2);
-            else if (s128 == 3) V2A_F32P_LAUNCH(128, 128, 3, 1);
+            if (bm == 64) V2A_F32P_LAUNCH(64, 64, 4, 2);
+            else if (bn == 64) V2A_F32P_LAUNCH(128, 64, 3, 2);
             else V2A_F32P_LAUNCH(128, 128, 2, 2);
 #undef V2A_F32P_LAUNCH
             goto launched;
         }
+    } else {
+        // 16-bit storage: one LDS buffer (4 workgroups per CU) on launches of >= 768 workgroups, two buffers below
+        if (bm == 64) hipLaunchKernelGGL((conv_igemm_h<64, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
+        else if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
+        else if (tiles * s >= 768) hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 1>), dim3(tiles, s), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
     }
-    if (bm == 64) hipLaunchKernelGGL((conv_igemm_h<64, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_h<128, 64, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
-    else if (g_stages_h == 1 && tiles * s >= 768) hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 1>), dim3(tiles, s), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_h<128, 128, T, 2>), dim3(tiles, s), dim3(256), 0, stream, p);
 launched:
     V2A_CHECK_LAUNCH();
     if (s > 1) {
@@ -1561,11 +1464,6 @@ int v2a_set_half_format(int f16) {
     return old;
 }
 int v2a_get_half_format(void) { return g_v2a_half_f16; }
-// measurement aid: every following conv_igemm_h launch records, per workgroup, eight 100-MHz wall-clock stamps (entry, first DMA issued,
-// first k tile landed, main loop done, epilogue stores issued, stores acknowledged) into buf, which advances by `stride_words` 64-bit
-// words per launch.  buf = null switches the stamps off (the default: the kernels then skip them on a uniform branch).
-// tuning aid: on = 0 routes fp32 LDS-DMA convs to conv_igemm_h<.., float> (rounds 1-3), 1 to conv_igemm_f32p; s128 in {2, 3}, s64 in {3, 4}
-// = LDS stages of the 128 x 128 / 64 x 64 tiles (0 keeps the current value).  Returns the previous `on`.
 // fp32 LDS-DMA convs: 1 = by three bf16 planes (conv_igemm_f32x3, default), 0 = exact-f32 MFMA kernels.  Returns the old value.
 static void f32_conv_mode_init() {
     if (g_f32x3 < 0) {
@@ -1579,29 +1477,10 @@ int v2a_set_f32_conv_mode(int x3) {
     g_f32x3 = x3 ? 1 : 0;
     return old;
 }
-// The next v2a_conv2d_fwd_dma_f32 / _d launch computes output rows >= m_split with w2 / bias2 (same shapes as w / bias): two layers of
-// identical geometry over one stacked batch -- the policy's two camera encoders -- as ONE launch.  m_split % 256 == 0.  w2 = null clears.
-int v2a_conv2d_set_second(const void* w2, const float* bias2, int m_split) {
-    g_conv_w2 = w2; g_conv_bias2 = w2 ? bias2 : nullptr; g_conv_msplit = w2 ? m_split : 0x7fffffff;
-    return V2A_OK;
-}
 int v2a_get_f32_conv_mode(void) {
     f32_conv_mode_init();
     return g_f32x3;
 }
-int v2a_debug_f32p(int on, int s128, int s64) {
-    const int old = g_f32p < 0 ? 1 : g_f32p;
-    g_f32p = on ? 1 : 0;
-    if (s128 == 2 || s128 == 3) g_f32p_s128 = s128;
-    if (s64 == 3 || s64 == 4) g_f32p_s64 = s64;
-    return old;
-}
-int v2a_debug_conv_stamps(uint64_t* buf, size_t stride_words) {
-    g_conv_stamps = (unsigned long long*)buf;
-    g_conv_stamp_stride = stride_words;
-    return V2A_OK;
-}
-
 // bf16-storage convolution forward.  x / x2 / residual / y: bf16; w_packed: bf16 [Cout][KH][KW][C1+C2]; bias / rowvec: fp32;
 // exactly one of y (bf16) / y_f32 is non-null.  Requires C1 % 64 == 0, C2 % 64 == 0, 16-B aligned pointers; zeros: >= 128 zero bytes.
 int v2a_conv2d_fwd_h(const void* x, const void* x2, const void* w_packed, const float* bias, const float* rowvec, const void* residual,

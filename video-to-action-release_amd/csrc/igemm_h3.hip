@@ -775,11 +775,9 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
 extern "C" {
 
 // 1 when v2a_conv2d_fwd_h3 takes this problem: 3x3 / stride 1 / pad 1, one bf16 source, frames that tile into 16 x 16 patches,
-// 128-multiple output width, enough tiles to fill the chip.  V2A_CONV_H3=0 disables the path.
+// 128-multiple output width, enough tiles to fill the chip.
 int v2a_conv2d_h3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("V2A_CONV_H3"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || KH != 3 || KW != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || C2) return 0;
+    if (KH != 3 || KW != 3 || sh != 1 || sw != 1 || ph != 1 || pw != 1 || C2) return 0;
     if (ups) { H *= 2; W *= 2; }                          // H, W: the SOURCE frame; the conv runs over the upsampled one
     if (C % 32 || Cout % 128 || H % 16 || W % 16) return 0;
     const bool wide = Cout % 256 == 0;                    // 256 x 256 tiles; otherwise 512 x 128 (needs H % 32 == 0) or 256 x 128
@@ -857,9 +855,7 @@ int v2a_conv2d_fwd_h3_gn(const void* x, const void* x2, int C1, const float* gn_
 // 1 when v2a_conv2d_fwd_t3 takes this problem: the temporal tap of the factorised Conv3d seen as a 2-d conv over [B, F, HW, C] with
 // a 3 x 1 filter, stride 1, pad (1, 0); F = 7 (Libero: seven predicted frames), HW % 64 == 0, C % 32 == 0, Cout % 128 == 0.
 int v2a_conv2d_t3_eligible(int N, int H, int W, int C, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int ups, int C2) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("V2A_CONV_T3"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || KH != 3 || KW != 1 || sh != 1 || sw != 1 || ph != 1 || pw != 0 || C2 || ups) return 0;
+    if (KH != 3 || KW != 1 || sh != 1 || sw != 1 || ph != 1 || pw != 0 || C2 || ups) return 0;
     if (H != 7 || W % 64 || C % 32 || Cout % 128) return 0;
     if ((long)N * (W / 64) * (Cout / 128) < 208) return 0;
     if ((double)N * H * W * C >= 4294967296.0 || (double)H * W * C >= 1073741824.0 || (double)Cout * 3 * C >= 1073741824.0) return 0;

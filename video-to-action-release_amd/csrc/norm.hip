@@ -54,13 +54,7 @@ struct GnDesc {
     const float* post_bias;
     int post_nslab;
     size_t post_stride;
-    // two parameter sets over one stacked batch (the policy's two camera encoders as ONE chain): samples n >= n_split use gamma2 / beta2
-    const float* gamma2;
-    const float* beta2;
-    int n_split;            // INT_MAX: one set
 };
-#define GN_GAMMA(p, n) (((n) >= (p).n_split) ? (p).gamma2 : (p).gamma)
-#define GN_BETA(p, n) (((n) >= (p).n_split) ? (p).beta2 : (p).beta)
 
 __device__ __forceinline__ unsigned short gn_f2h(float f, int f16) {      // round to nearest even, as v2a_cast_f32_h (bf16 | IEEE fp16)
     return f16 ? v2a_f2h<true>(f) : v2a_f2bf(f);
@@ -109,8 +103,8 @@ __global__ __launch_bounds__(256) void gn_colreduce(const GnDesc p) {
                 const int g = (cc + j) / cg;          // per element: a float4 may straddle two groups when cg % 4 != 0
                 mu[j] = p.mean[n * p.G + g];
                 rs[j] = p.rstd[n * p.G + g];
-                gm[j] = GN_GAMMA(p, n)[cc + j];
-                bt[j] = GN_BETA(p, n)[cc + j];
+                gm[j] = p.gamma[cc + j];
+                bt[j] = p.beta[cc + j];
             }
         }
 // (manual prefetch below)
@@ -225,7 +219,7 @@ __global__ __launch_bounds__(256) void gn_finalize(const GnDesc p) {
             float a = 0.f;
             for (int j = 0; j < cg; ++j) {
                 const float v = cg <= 64 ? cs_s[tid][j] : p.colsum[(size_t)n * 2 * C + tid * C + g * cg + j];
-                a += GN_GAMMA(p, n)[g * cg + j] * v;
+                a += p.gamma[g * cg + j] * v;
             }
             p.gsum[(size_t)(n * p.G + g) * 2 + tid] = a;
         }
@@ -269,7 +263,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_rows(const GnDesc p) {
             if (!ok[k]) continue;
             const int c = cc[k], g = c / cg;
             const float mu = mean[g], rsd = rstd[g];
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -310,7 +304,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd(const GnDesc p) {
         for (int j = 0; j < 4; ++j) {
             const int c = c4 * 4 + j;
             const int g = c / cg;
-            float z = (v[j] - p.mean[n * p.G + g]) * p.rstd[n * p.G + g] * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c] + r[j];
+            float z = (v[j] - p.mean[n * p.G + g]) * p.rstd[n * p.G + g] * p.gamma[c] + p.beta[c] + r[j];
             float a = act_fwd(z, p.act);
             if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
             o[j] = a;
@@ -351,10 +345,10 @@ __global__ __launch_bounds__(256) void gn_apply_bwd(const GnDesc p) {
                 A2 = p.gsum[(size_t)(n * p.G + g) * 2 + 1];
             }
             const float xh = (v[j] - mu) * rs;
-            const float z = xh * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c] + r[j];
+            const float z = xh * p.gamma[c] + p.beta[c] + r[j];
             const float dz = d[j] * act_bwd(z, p.act);
             dzv[j] = dz;
-            o[j] = rs * (GN_GAMMA(p, n)[c] * dz - (A1 + xh * A2) * inv_cnt);
+            o[j] = rs * (p.gamma[c] * dz - (A1 + xh * A2) * inv_cnt);
         }
         y4[i] = o;
         if (p.yh) gn_store_twin4(p.yh, i, o, p.yh_f16);
@@ -448,7 +442,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(sm + i * 4);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
             f32x4 o;
@@ -467,7 +461,7 @@ __global__ __launch_bounds__(NT) void gn_small_fwd(const GnDesc p) {
     for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
-        float z = (sm[i] - mu) * rs * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c];
+        float z = (sm[i] - mu) * rs * p.gamma[c] + p.beta[c];
         if (p.residual) z += p.residual[off];
         float a = act_fwd(z, p.act);
         if (p.film) a = p.film[(size_t)n * p.film_ld + c] * a + p.film[(size_t)n * p.film_ld + C + c];
@@ -503,7 +497,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off), dv = gn_src4(p, p.dout, off, c);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c), bt = *reinterpret_cast<const f32x4*>(p.beta + c);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (p.residual) r = *reinterpret_cast<const f32x4*>(p.residual + off);
             f32x4 hv, zv;
@@ -526,7 +520,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
         const float h = (p.x[off] - mu) * rs;
-        float z = h * GN_GAMMA(p, n)[c] + GN_BETA(p, n)[c];
+        float z = h * p.gamma[c] + p.beta[c];
         if (p.residual) z += p.residual[off];
         const float dout = gn_src1(p, p.dout, off, c);
         float da = dout;
@@ -539,8 +533,8 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
         const float dz = da * act_bwd(z, p.act);
         xh[i] = h;
         dzs[i] = dz;
-        A1 += dz * GN_GAMMA(p, n)[c];
-        A2 += dz * GN_GAMMA(p, n)[c] * h;
+        A1 += dz * p.gamma[c];
+        A2 += dz * p.gamma[c] * h;
     }
     }
     A1 = wave_sum(A1);
@@ -557,7 +551,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
             const int row = i / cg4, c4 = i - row * cg4, c = g * cg + c4 * 4;
             const size_t off = base + (size_t)row * C + c4 * 4;
             const f32x4 hv = *reinterpret_cast<const f32x4*>(xh + i * 4), zv = *reinterpret_cast<const f32x4*>(dzs + i * 4);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c);
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = rs * (gm[j] * zv[j] - (A1 + hv[j] * A2) * inv);
@@ -570,7 +564,7 @@ __global__ __launch_bounds__(NT) void gn_small_bwd(const GnDesc p) {
     for (int i = tid; i < E; i += NT) {
         const int row = i / cg, cc = i - row * cg, c = g * cg + cc;
         const size_t off = base + (size_t)row * C + cc;
-        const float dxv = rs * (GN_GAMMA(p, n)[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
+        const float dxv = rs * (p.gamma[c] * dzs[i] - (A1 + xh[i] * A2) * inv);
         p.y[off] = dxv;
         if (p.yh) p.yh[off] = gn_f2h(dxv, p.yh_f16);
         if (p.dres) p.dres[off] = dzs[i];
@@ -669,8 +663,8 @@ __global__ __launch_bounds__(64) void gn_wave_fwd(const GnDesc p) {
         gmv[j] = btv[j] = rsd[j] = f0[j] = f1[j] = 0.f;
         if (j < epl) {
             const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
-            gmv[j] = GN_GAMMA(p, n)[c];
-            btv[j] = GN_BETA(p, n)[c];
+            gmv[j] = p.gamma[c];
+            btv[j] = p.beta[c];
             if (p.residual) rsd[j] = p.residual[base + (size_t)row * C + cc];
             if (p.film) { f0[j] = p.film[(size_t)n * p.film_ld + c]; f1[j] = p.film[(size_t)n * p.film_ld + C + c]; }
         }
@@ -722,8 +716,8 @@ __global__ __launch_bounds__(64) void gn_wave_bwd(const GnDesc p) {
             const int i = lane + 64 * j, row = i / CG, cc = i % CG, c = g * CG + cc;
             const size_t off = base + (size_t)row * C + cc;
             xv[j] = p.x[off];
-            gmv[j] = GN_GAMMA(p, n)[c];
-            btv[j] = GN_BETA(p, n)[c];
+            gmv[j] = p.gamma[c];
+            btv[j] = p.beta[c];
             if (p.residual) rsd[j] = p.residual[off];
             if (film) f0[j] = p.film[(size_t)n * p.film_ld + c];
         }
@@ -843,7 +837,7 @@ __global__ __launch_bounds__(64) void gn_wavev_fwd(const GnDesc p) {
     size_t off[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane / LPR) + RPP * j) * C + c0;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c0), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c0);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c0), bt = *reinterpret_cast<const f32x4*>(p.beta + c0);
     const bool film = p.film != nullptr;
     f32x4 f0 = {1.f, 1.f, 1.f, 1.f}, f1 = {0.f, 0.f, 0.f, 0.f};
     if (film) {
@@ -901,7 +895,7 @@ __global__ __launch_bounds__(64) void gn_wavev_bwd(const GnDesc p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) off[j] = ((size_t)n * p.S + (lane / LPR) + RPP * j) * C + c0;
     const float mu = p.mean[wv], rs = p.rstd[wv];
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(GN_GAMMA(p, n) + c0), bt = *reinterpret_cast<const f32x4*>(GN_BETA(p, n) + c0);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c0), bt = *reinterpret_cast<const f32x4*>(p.beta + c0);
     const bool film = p.film != nullptr;
     f32x4 f0 = {1.f, 1.f, 1.f, 1.f};
     if (film) f0 = *reinterpret_cast<const f32x4*>(p.film + (size_t)n * p.film_ld + c0);
@@ -967,13 +961,11 @@ __global__ __launch_bounds__(64) void gn_wavev_bwd(const GnDesc p) {
 }
 // 1 / 2 / 4 passes of the float4 wave kernels (0: not eligible)
 static int gn_wavev_passes(const GnDesc& p, int cg) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("V2A_GN_WAVEV"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || !(cg == 16 || cg == 32 || cg == 64 || cg == 128) || (p.C & 3) || (p.film_ld & 3)) return 0;
+    if (!(cg == 16 || cg == 32 || cg == 64 || cg == 128) || (p.C & 3) || (p.film_ld & 3)) return 0;
     const long E = (long)p.S * cg;
     if (E != 256 && E != 512 && E != 1024) return 0;
     const uintptr_t a = (uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.residual | (uintptr_t)p.dout | (uintptr_t)p.dres | (uintptr_t)p.gamma |
-                        (uintptr_t)p.beta | (uintptr_t)p.gamma2 | (uintptr_t)p.beta2 | (uintptr_t)p.slabs | (uintptr_t)p.cbias |
+                        (uintptr_t)p.beta | (uintptr_t)p.slabs | (uintptr_t)p.cbias |
                         (uintptr_t)p.sresid | (uintptr_t)p.sout | (uintptr_t)p.colsum | (uintptr_t)p.yh | (uintptr_t)p.film | (uintptr_t)p.dfilm |
                         (uintptr_t)p.post | (uintptr_t)p.post_slabs | (uintptr_t)p.post_bias;
     if ((a & 15) != 0 || (p.slab_stride & 3) != 0 || (p.post_stride & 3) != 0) return 0;
@@ -995,9 +987,7 @@ static int gn_wavev_passes(const GnDesc& p, int cg) {
     } while (0)
 
 static bool gn_wave_ok(int S, int cg) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("V2A_GN_WAVE"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || !(cg == 16 || cg == 32 || cg == 64 || cg == 128)) return false;
+    if (!(cg == 16 || cg == 32 || cg == 64 || cg == 128)) return false;
     const long E = (long)S * cg;
     return E % 64 == 0 && E / 64 <= 16;
 }
@@ -1061,6 +1051,8 @@ static void gn_chunks(int N, int S, int C, int* nchunk, int* rows) {
     *nchunk = (S + r - 1) / r;
 }
 
+// post-activation addend of a GroupNorm forward launch (explicit operands of v2a_groupnorm_fwd_s; all null / 0: none)
+struct GnPost { const float* dense; const float* slabs; const float* bias; int nslab; size_t stride; };
 extern "C" {
 
 size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
@@ -1072,7 +1064,8 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
 
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
-                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* unused_resid,
+                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
+                        const float* post_slabs, int post_nslab, size_t post_stride, const float* post_bias,
                         void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
@@ -1095,7 +1088,7 @@ int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* ga
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                         int act, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return v2a_groupnorm_fwd_s(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, mean, rstd, N, S, C, G, eps, act, nullptr, 0, 0,
-                               nullptr, nullptr, workspace, workspace_bytes, stream);
+                               nullptr, nullptr, nullptr, 0, 0, nullptr, workspace, workspace_bytes, stream);
 }
 // 1 when a GroupNorm over [N, S, C] with G groups runs on the wave path, i.e. accepts its input as split-K slabs (v2a_groupnorm_*_s)
 int v2a_groupnorm_takes_slabs(int S, int C, int G) {
@@ -1106,14 +1099,16 @@ int v2a_groupnorm_takes_slabs(int S, int C, int G) {
 static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
-                       const float* stats2, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                       const float* stats2, const GnPost& post, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
-                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* unused_resid,
+                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
+                        const float* post_slabs, int post_nslab, size_t post_stride, const float* post_bias,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    (void)unused_resid;
+    if ((post && post_slabs) || (post_slabs && post_nslab < 1) || (!post_slabs && post_nslab > 0)) return V2A_ERR_ARG;
+    const GnPost po = {post, post_slabs, post_slabs ? post_bias : nullptr, post_slabs ? post_nslab : 0, post_stride};
     return gn_fwd_impl(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, mean, rstd, N, S, C, G, eps, act, slabs, nslab, slab_stride,
-                       cbias, nullptr, nullptr, workspace, workspace_bytes, stream);
+                       cbias, nullptr, nullptr, po, workspace, workspace_bytes, stream);
 }
 // v2a_groupnorm_fwd with the statistics pass replaced by the producing convs' epilogue sums: stats1 [N * S/64][2][C1] (x) and, for a
 // virtual concat, stats2 [N * S/64][2][C - C1] (x2), as v2a_conv2d_fwd_dma_f32(..., stats, ...) writes them.  Needs S % 64 == 0 and the
@@ -1122,60 +1117,27 @@ int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* g
                          int N, int S, int C, int G, float eps, int act, const float* stats1, const float* stats2, void* workspace,
                          size_t workspace_bytes, hipStream_t stream) {
     return gn_fwd_impl(x, x2, C1, gamma, beta, nullptr, nullptr, 0, y, nullptr, mean, rstd, N, S, C, G, eps, act, nullptr, 0, 0, nullptr,
-                       stats1, stats2, workspace, workspace_bytes, stream);
+                       stats1, stats2, GnPost{}, workspace, workspace_bytes, stream);
 }
 }  // extern "C"
-// Second parameter set of the NEXT fp32 GroupNorm launch (forward or backward; consumed by it): samples n >= n_split use gamma2 / beta2.
-// Host-side state of the launching thread's sequence -- the policy engine runs its two camera encoders as ONE stacked batch this way.
-static const float* g_gn_gamma2 = nullptr;
-static const float* g_gn_beta2 = nullptr;
-static int g_gn_nsplit = 0x7fffffff;
-extern "C" int v2a_groupnorm_set_second(const float* gamma2, const float* beta2, int n_split) {
-    if ((gamma2 == nullptr) != (beta2 == nullptr) || (gamma2 && n_split < 1)) return V2A_ERR_ARG;
-    g_gn_gamma2 = gamma2; g_gn_beta2 = beta2; g_gn_nsplit = gamma2 ? n_split : 0x7fffffff;
-    return V2A_OK;
-}
-// Post-activation addend of the NEXT fp32 GroupNorm FORWARD launch (consumed by it; float4 wave path only, V2A_ERR_ARG otherwise --
-// ask v2a_groupnorm_takes_post first): dense `post`, or `nslab` split-K slabs (+ bias) of the conv that produces it.
-static const float* g_gn_post = nullptr;
-static const float* g_gn_post_slabs = nullptr;
-static const float* g_gn_post_bias = nullptr;
-static int g_gn_post_nslab = 0;
-static size_t g_gn_post_stride = 0;
-extern "C" int v2a_groupnorm_set_post(const float* post, const float* post_slabs, int nslab, size_t slab_stride, const float* post_bias) {
-    if ((post && post_slabs) || (post_slabs && nslab < 1) || (!post_slabs && nslab > 0)) return V2A_ERR_ARG;
-    g_gn_post = post; g_gn_post_slabs = post_slabs; g_gn_post_bias = post_slabs ? post_bias : nullptr;
-    g_gn_post_nslab = post_slabs ? nslab : 0; g_gn_post_stride = slab_stride;
-    return V2A_OK;
-}
 extern "C" int v2a_groupnorm_takes_post(int S, int C, int G) {
     if (G <= 0 || C % G != 0) return 0;
     GnDesc t = {};
     t.S = S; t.C = C;
     return gn_wavev_passes(t, C / G) > 0 ? 1 : 0;
 }
-static bool gn_take_post(GnDesc& p) {
-    p.post = g_gn_post; p.post_slabs = g_gn_post_slabs; p.post_bias = g_gn_post_bias; p.post_nslab = g_gn_post_nslab; p.post_stride = g_gn_post_stride;
-    const bool any = g_gn_post || g_gn_post_slabs;
-    g_gn_post = nullptr; g_gn_post_slabs = nullptr; g_gn_post_bias = nullptr; g_gn_post_nslab = 0; g_gn_post_stride = 0;
-    return any;
-}
 extern int g_v2a_policy_f16;
-static void gn_take_second(GnDesc& p) {
-    p.yh_f16 = g_v2a_policy_f16;
-    p.gamma2 = g_gn_gamma2; p.beta2 = g_gn_beta2; p.n_split = g_gn_gamma2 ? g_gn_nsplit : 0x7fffffff;
-    g_gn_gamma2 = nullptr; g_gn_beta2 = nullptr; g_gn_nsplit = 0x7fffffff;
-}
 static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
-                       const float* stats2, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) { GnDesc t = {}; gn_take_second(t); gn_take_post(t); return V2A_ERR_ARG; }
-    if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) { GnDesc t = {}; gn_take_post(t); return V2A_ERR_ARG; }
-    if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) { GnDesc t = {}; gn_take_post(t); return V2A_ERR_ARG; }
+                       const float* stats2, const GnPost& post, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || C % G != 0) return V2A_ERR_ARG;
+    if (nslab > 0 && (!slabs || x2 || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % 4 != 0 || (long)S * (C / G) <= GN_SMALL_MAX)) return V2A_ERR_ARG;
     GnDesc p = {};
-    gn_take_second(p);
-    const bool has_post = gn_take_post(p);
+    p.yh_f16 = g_v2a_policy_f16;
+    p.post = post.dense; p.post_slabs = post.slabs; p.post_bias = post.bias; p.post_nslab = post.nslab; p.post_stride = post.stride;
+    const bool has_post = post.dense || post.slabs;
     p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
     p.yh = (unsigned short*)y_h;
@@ -1208,9 +1170,7 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
         const bool vec = cg % 4 == 0 && C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
         // 1024 threads per slab from 8 K elements up: with one 256-thread workgroup per (sample, group) a 64-KB slab was fetched in four
         // dependent rounds of loads by four waves per CU (19 us for the first ResNet stage); sixteen waves fetch it in one
-        static int wide_min = -1;                        // V2A_GN_WIDE_MIN: smallest slab (elements) on the 1024-thread instance (tuning aid)
-        if (wide_min < 0) { const char* e = getenv("V2A_GN_WIDE_MIN"); wide_min = e ? atoi(e) : 8192; }
-        const bool wide = vec && E >= wide_min;
+        const bool wide = vec && E >= 8192;
         if (lds > 64 * 1024) {
             (void)hipFuncSetAttribute((const void*)gn_small_fwd<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gn_small_fwd<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1299,7 +1259,7 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     if (!x || !gamma || !beta || (!dout && nslab <= 0) || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
     if (nslab > 0 && (!slabs || !v2a_groupnorm_takes_slabs(S, C, G))) return V2A_ERR_ARG;
     GnDesc p = {};
-    gn_take_second(p);
+    p.yh_f16 = g_v2a_policy_f16;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
     p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.yh = (unsigned short*)dx_h; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;
@@ -1324,9 +1284,7 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     } else if (E <= GN_SMALL_MAX) {
         const bool vec = cg % 4 == 0 && C % 4 == 0 &&
                          (((uintptr_t)x | (uintptr_t)dx | (uintptr_t)dout | (uintptr_t)residual | (uintptr_t)dres | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
-        static int wide_min_b = -1;
-        if (wide_min_b < 0) { const char* e = getenv("V2A_GN_WIDE_MIN"); wide_min_b = e ? atoi(e) : 8192; }
-        bool wide = vec && E >= wide_min_b;
+        bool wide = vec && E >= 8192;
         int nt = wide ? 1024 : 256;
         int nsl = cg >= nt ? 1 : nt / cg;
         size_t lds = ((film ? 4 : 2) * E + (size_t)nsl * 4 * cg + 32) * sizeof(float);

@@ -31,10 +31,6 @@ struct OptState {           // device resident
     float growth_factor, backoff_factor;
     int skip;                // this step found a non-finite gradient: parameters / moments / Adam step untouched
     long long skipped_steps;
-    // deferred EMA (v2a_opt_step_packed(defer_ema = 1)): this step's EMA update has NOT been applied by the update kernel; mt_ema_apply_kernel
-    // applies it (with this step's ema_mode / ema_decay, which stay valid until the next opt_advance) and the next opt_advance -- or
-    // v2a_opt_apply_ema(mark_done = 1) -- clears the flag
-    int ema_pending;
 };
 
 __global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, const int* chunks_all, double* partial_all, int chunk0) {
@@ -64,7 +60,7 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(const int64_t* table, con
 }
 
 // one workgroup: finish the norm, advance step counters, derive this step's scalars
-__global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const double* partial, int nchunks, int defer_ema) {
+__global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const double* partial, int nchunks) {
     __shared__ double sm[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < nchunks; i += 256) s += partial[i];
@@ -119,7 +115,6 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
     }
     st->ema_decay = (float)dec;
     st->ema_mode = mode;
-    st->ema_pending = (defer_ema && mode) ? 1 : 0;
 }
 
 // `packs` (optional, int64 [tensor][6] = {dst, Cin, taps, dst_window, dst_16bit_twin, twin is fp16}): the updated parameter also goes, re-laid, into the conv operand
@@ -128,7 +123,7 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
 // parameter again (0.36 ms of launches in the policy step's serial tail).  (co, ci, tap) of the thread's first element by one
 // decomposition, then carried forward in steps of 256 elements.
 __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table, const int* chunks, const OptState* st, int zero_grad,
-                                                           const int64_t* packs, int defer_ema) {
+                                                           const int64_t* packs) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
     float* pk = packs ? reinterpret_cast<float*>(packs[t * 6 + 0]) : nullptr;
     float* pw = packs ? reinterpret_cast<float*>(packs[t * 6 + 3]) : nullptr;
@@ -149,9 +144,7 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
     float* g = reinterpret_cast<float*>(table[t * 6 + 1]) + start;
     float* m = reinterpret_cast<float*>(table[t * 6 + 2]) + start;
     float* v = reinterpret_cast<float*>(table[t * 6 + 3]) + start;
-    // (defer_ema: the EMA replica is left to mt_ema_apply_kernel, which runs under the NEXT step's encoder forward: 12 of the 48 bytes
-    // this kernel moves per parameter leave the serial tail of the step)
-    float* e = (table[t * 6 + 4] && !defer_ema) ? reinterpret_cast<float*>(table[t * 6 + 4]) + start : nullptr;
+    float* e = table[t * 6 + 4] ? reinterpret_cast<float*>(table[t * 6 + 4]) + start : nullptr;
     const long long n = table[t * 6 + 5];
     const int cnt = (int)min((long long)MT_CHUNK, n - start);
     const float clip = st->clip_coef, b1 = (float)st->b1, b2 = (float)st->b2, eps = (float)st->eps;
@@ -250,28 +243,6 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
     }
 }
 
-// The EMA update of the last optimiser step, when that step deferred it (OptState.ema_pending): ema = lerp(ema, p) / copy, exactly the
-// arithmetic of the inline path above on the same (p, ema) values -- p is not touched between the two points in time.
-__global__ __launch_bounds__(256) void mt_ema_apply_kernel(const int64_t* table, const int* chunks, const OptState* st) {
-    if (!st->ema_pending) return;
-    const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
-    if (!table[t * 6 + 4]) return;
-    const float* p = reinterpret_cast<const float*>(table[t * 6 + 0]) + start;
-    float* e = reinterpret_cast<float*>(table[t * 6 + 4]) + start;
-    const long long n = table[t * 6 + 5];
-    const int cnt = (int)min((long long)MT_CHUNK, n - start);
-    const float dec = st->ema_decay;
-    const int mode = st->ema_mode;
-    if (!mode) return;
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-        const float pv = p[i];
-        float ev = (mode & 1) ? pv : e[i];
-        if (mode & 2) { const float d = (ev - pv) * (1.0f - dec); ev = ev - d; }
-        e[i] = ev;
-    }
-}
-__global__ void opt_ema_done_kernel(OptState* st) { st->ema_pending = 0; }
-
 // grads *= 1/world (after an RCCL sum all-reduce) -- folded into the clip by scaling the table's grads in place
 __global__ void mt_scale_grads_kernel(const int64_t* table, const int* chunks, float scale) {
     const int t = chunks[2 * blockIdx.x], start = chunks[2 * blockIdx.x + 1];
@@ -281,22 +252,16 @@ __global__ void mt_scale_grads_kernel(const int64_t* table, const int* chunks, f
     for (int i = threadIdx.x; i < cnt; i += 256) g[i] *= scale;
 }
 
-static int g_presummed = 0;       // chunks whose gradient sums of squares are already in `partial` for the NEXT v2a_opt_step* call ...
-static int g_presum_first = 0;
-static const double* g_presum_partial = nullptr;      // ... on THIS partial buffer (any other optimiser's step ignores and clears it)
-
 extern "C" {
 
 // Gradient-norm partial sums of chunks [first, first + count) ahead of the optimiser step: the ConditionalUnet1D slice (75 % of the
 // parameters) is final long before the encoders' -- PolicyTrainer sums it on the weight-gradient stream while the encoder backward runs;
-// the next v2a_opt_step / _packed call (same table, same `partial`, a stream ordered after this one) then sums only the remaining chunks.
+// the caller then passes the SAME (first, count) as presum_first / presum_count to v2a_opt_step_packed (same table, same `partial`, a
+// stream ordered after this one), which sums only the remaining chunks.  Stateless: nothing is remembered between the two calls.
 int v2a_opt_presum(const int64_t* table_dev, const int* chunks_dev, int first, int count, double* partial_dev, hipStream_t s) {
     if (!table_dev || !chunks_dev || !partial_dev || first < 0 || count <= 0) return V2A_ERR_ARG;
     hipLaunchKernelGGL(mt_sumsq_kernel, dim3(count), dim3(256), 0, s, table_dev, chunks_dev, partial_dev, first);
     V2A_CHECK_LAUNCH();
-    g_presum_first = first;
-    g_presummed = count;
-    g_presum_partial = partial_dev;
     return V2A_OK;
 }
 
@@ -334,25 +299,33 @@ int v2a_opt_state_counters(const void* host_state, long long* step, long long* e
     if (ema_initted) *ema_initted = s->ema_initted;
     return V2A_OK;
 }
-// dynamic loss scaling (fp16 policy mode): patch a HOST copy of the state.  init_scale <= 0 switches the scaler off.
-int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_factor, double backoff_factor, int growth_interval) {
+// dynamic loss scaling (fp16 policy mode): patch a HOST copy of the state.  init_scale <= 0 switches the scaler off.  growth_tracker:
+// steps since the last growth / back-off (0 for a fresh scaler; a resumed checkpoint restores GradScaler's `_growth_tracker` here).
+int v2a_opt_state_set_scaler(void* host_state, double init_scale, double growth_factor, double backoff_factor, int growth_interval,
+                             int growth_tracker) {
     OptState* s = reinterpret_cast<OptState*>(host_state);
     if (!s) return V2A_ERR_ARG;
     s->scaler_on = init_scale > 0 ? 1 : 0;
     s->loss_scale = init_scale > 0 ? (float)init_scale : 1.0f;
     s->growth_factor = (float)growth_factor; s->backoff_factor = (float)backoff_factor;
     s->growth_interval = growth_interval < 1 ? 1 : growth_interval;
-    s->growth_tracker = 0; s->skip = 0; s->skipped_steps = 0;
+    s->growth_tracker = growth_tracker > 0 ? growth_tracker : 0; s->skip = 0; s->skipped_steps = 0;
     return V2A_OK;
 }
-// {loss_scale, growth_tracker, skip flag of the last step, skipped steps so far} of a HOST copy
-int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps) {
+// {loss_scale, growth_tracker, skip flag of the last step, skipped steps so far, growth factor, back-off factor, growth interval, on} of a
+// HOST copy (every out pointer optional)
+int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_tracker, int* skipped_last, long long* skipped_steps,
+                         float* growth_factor, float* backoff_factor, int* growth_interval, int* scaler_on) {
     const OptState* s = reinterpret_cast<const OptState*>(host_state);
     if (!s) return V2A_ERR_ARG;
     if (loss_scale) *loss_scale = s->loss_scale;
     if (growth_tracker) *growth_tracker = s->growth_tracker;
     if (skipped_last) *skipped_last = s->skip;
     if (skipped_steps) *skipped_steps = s->skipped_steps;
+    if (growth_factor) *growth_factor = s->growth_factor;
+    if (backoff_factor) *backoff_factor = s->backoff_factor;
+    if (growth_interval) *growth_interval = s->growth_interval;
+    if (scaler_on) *scaler_on = s->scaler_on;
     return V2A_OK;
 }
 // byte offset of loss_scale inside the device state block (v2a_mse_loss reads the scale from there)
@@ -363,7 +336,6 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
     s->step = step;
     s->ema_step = ema_step;
     s->ema_initted = ema_initted ? 1 : 0;
-    s->ema_pending = 0;
     if (lr > 0) s->lr = lr;
     return V2A_OK;
 }
@@ -372,19 +344,13 @@ int v2a_opt_state_set_counters(void* host_state, long long step, long long ema_s
 // packs_dev: optional [tensors][6] int64 table {dst forward pack or 0, Cin, taps, dst channel-window pack or 0, dst 16-bit twin of the
 // forward pack or 0, 1 when that twin is IEEE fp16 (0: bf16)} -- the update kernel then
 // also writes the re-laid conv operands (see mt_adamw_ema_kernel); null: parameters only.
-// defer_ema = 1: the EMA replica is NOT updated here; v2a_opt_apply_ema applies this step's update later (before the next optimiser
-// step, on any stream ordered after this call and before that step) -- same values, off the serial tail.
+// presum_first / presum_count: chunks [first, first + count) of `partial` already hold this step's sums of squares (v2a_opt_presum with
+// the same range, ordered before this call); 0 / 0: everything is summed here.
 int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
-                        int zero_grad, const int64_t* packs_dev, int defer_ema, hipStream_t s) {
+                        int zero_grad, const int64_t* packs_dev, int presum_first, int presum_count, hipStream_t s) {
     if (!table_dev || !chunks_dev || !state_dev || !partial_dev || nchunks <= 0) return V2A_ERR_ARG;
-    // chunks [pf, pf + pc): summed earlier on this partial buffer (v2a_opt_presum); the rest in up to two launches here
-    int pf = 0, pc = 0;
-    if (g_presummed > 0 && g_presum_partial == partial_dev && g_presum_first >= 0 && g_presum_first + g_presummed <= nchunks) {
-        pf = g_presum_first;
-        pc = g_presummed;
-    }
-    g_presummed = 0;
-    g_presum_partial = nullptr;
+    if (presum_first < 0 || presum_count < 0 || presum_first + presum_count > nchunks) return V2A_ERR_ARG;
+    const int pf = presum_count > 0 ? presum_first : 0, pc = presum_count;
     if (pf > 0) {
         hipLaunchKernelGGL(mt_sumsq_kernel, dim3(pf), dim3(256), 0, s, table_dev, chunks_dev, partial_dev, 0);
         V2A_CHECK_LAUNCH();
@@ -393,31 +359,17 @@ int v2a_opt_step_packed(const int64_t* table_dev, const int* chunks_dev, int nch
         hipLaunchKernelGGL(mt_sumsq_kernel, dim3(nchunks - pf - pc), dim3(256), 0, s, table_dev, chunks_dev, partial_dev, pf + pc);
         V2A_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(256), 0, s, (OptState*)state_dev, partial_dev, nchunks, defer_ema ? 1 : 0);
+    hipLaunchKernelGGL(opt_advance_kernel, dim3(1), dim3(256), 0, s, (OptState*)state_dev, partial_dev, nchunks);
     V2A_CHECK_LAUNCH();
     hipLaunchKernelGGL(mt_adamw_ema_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, (const OptState*)state_dev, zero_grad,
-                       packs_dev, defer_ema ? 1 : 0);
+                       packs_dev);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev,
                  int zero_grad, hipStream_t s) {
-    return v2a_opt_step_packed(table_dev, chunks_dev, nchunks, state_dev, partial_dev, zero_grad, nullptr, 0, s);
+    return v2a_opt_step_packed(table_dev, chunks_dev, nchunks, state_dev, partial_dev, zero_grad, nullptr, 0, 0, s);
 }
-// The EMA update a v2a_opt_step_packed(defer_ema = 1) call left pending (a no-op when none is: safe inside a replayed graph).
-// mark_done = 1 also clears the pending flag (an eager flush between steps: the next replay's apply launch then does nothing);
-// inside the step graph the next optimiser step clears it.
-int v2a_opt_apply_ema(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, int mark_done, hipStream_t s) {
-    if (!table_dev || !chunks_dev || !state_dev || nchunks <= 0) return V2A_ERR_ARG;
-    hipLaunchKernelGGL(mt_ema_apply_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, (const OptState*)state_dev);
-    V2A_CHECK_LAUNCH();
-    if (mark_done) {
-        hipLaunchKernelGGL(opt_ema_done_kernel, dim3(1), dim3(1), 0, s, (OptState*)state_dev);
-        V2A_CHECK_LAUNCH();
-    }
-    return V2A_OK;
-}
-
 int v2a_opt_scale_grads(const int64_t* table_dev, const int* chunks_dev, int nchunks, float scale, hipStream_t s) {
     hipLaunchKernelGGL(mt_scale_grads_kernel, dim3(nchunks), dim3(256), 0, s, table_dev, chunks_dev, scale);
     V2A_CHECK_LAUNCH();

@@ -376,7 +376,7 @@ class LB_Online_Trainer_V7(object):
             return
         data = {k: getattr(self, k) for k in self._CKPT_SCALARS}
         data.update(gcp_model=self.accelerator.get_state_dict(self.gcp_model), opt=self.opt.state_dict(), ema=self.ema.state_dict(),
-                    scaler=None, version=__version__)
+                    scaler=self.ptrainer.opt.scaler_state_dict(), version=__version__)      # GradScaler layout (reference :377), None outside fp16
         savepath = str(self.results_folder / f'model-{milestone}.pt')
         torch.save(data, savepath)
         utils.print_color(f'[ utils/training ] Saved model to {savepath}', c='y')
@@ -388,6 +388,8 @@ class LB_Online_Trainer_V7(object):
         self.num_steps_in_env = data['num_steps_in_env']
         self.opt.load_state_dict(data['opt'])
         self.ema.load_state_dict(data['ema'])
+        if data.get('scaler') and self.ptrainer.loss_scaling:      # fp16 mode: resume the loss scale and its growth tracker (reference :406-407)
+            self.gcp_model.engine.loss_scale_ptr = self.ptrainer.opt.load_scaler_state_dict(data['scaler'])
         self.gcp_model.engine.refresh_packs()            # parameters changed behind the packed copies
         if 'version' in data:
             print(f"loading from version {data['version']}")

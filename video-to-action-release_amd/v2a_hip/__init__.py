@@ -51,7 +51,15 @@ def get_video_storage() -> str:
     return _video_storage[0]
 
 
+_sampler_graphs = [True]
+
+
 def sampler_graphs_enabled() -> bool:
-    """GoalGaussianDiffusion.sample replays one captured hipGraph per denoise step (V2A_SAMPLER_GRAPH=0: eager launches)."""
-    import os
-    return os.environ.get("V2A_SAMPLER_GRAPH", "1") != "0"
+    """GoalGaussianDiffusion.sample replays one captured hipGraph per denoise step (set_sampler_graphs(False): eager launches)."""
+    return _sampler_graphs[0]
+
+
+def set_sampler_graphs(on: bool) -> bool:
+    old = _sampler_graphs[0]
+    _sampler_graphs[0] = bool(on)
+    return old

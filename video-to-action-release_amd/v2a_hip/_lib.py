@@ -65,9 +65,8 @@ SIGNATURES = {
     "v2a_policy_sched_step": (I, [P, P, P, P, I, F, F, F, F, F, I, P]),
     "v2a_gn_param_grads_multi": (I, [P, P, I, P]),
     "v2a_groupnorm_takes_slabs": (I, [I, I, I]),
-    "v2a_groupnorm_set_post": (I, [P, P, I, SZ, P]),
     "v2a_groupnorm_takes_post": (I, [I, I, I]),
-    "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, SZ, P]),
+    "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, I, SZ, P, P, SZ, P]),
     "v2a_groupnorm_bwd_s": (I, [P] * 5 + [I] + [P] * 10 + [I, I, I, I, I, I, P, I, SZ, P, P, P, SZ, P]),
     "v2a_h5_open": (I, [ctypes.c_char_p, P]),
     "v2a_h5_close": (None, [P]),
@@ -99,12 +98,8 @@ SIGNATURES = {
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
     "v2a_advance_counter": (I, [P, U64, P]),
     "v2a_debug_timestamp": (I, [P, P]),
-    "v2a_debug_conv_stamps": (I, [P, SZ]),
-    "v2a_debug_f32p": (I, [I, I, I]),
     "v2a_set_f32_conv_mode": (I, [I]),
     "v2a_get_f32_conv_mode": (I, []),
-    "v2a_conv2d_set_second": (I, [P, P, I]),
-    "v2a_groupnorm_set_second": (I, [P, P, I]),
     "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),
     "v2a_perceiver_attention_bwd": (I, [P] * 9 + [I, I, I, I, I, F, P]),
     "v2a_layernorm_bwd": (I, [P, P, P, P, P, I, I, F, P]),
@@ -155,12 +150,11 @@ SIGNATURES = {
     "v2a_opt_state_peek": (I, [P, P, P, P, P]),
     "v2a_opt_state_counters": (I, [P, P, P, P]),
     "v2a_opt_state_set_counters": (I, [P, LL, LL, I, D]),
-    "v2a_opt_state_set_scaler": (I, [P, D, D, D, I]),
-    "v2a_opt_state_scaler": (I, [P, P, P, P, P]),
+    "v2a_opt_state_set_scaler": (I, [P, D, D, D, I, I]),
+    "v2a_opt_state_scaler": (I, [P, P, P, P, P, P, P, P, P]),
     "v2a_opt_state_loss_scale_offset": (SZ, []),
     "v2a_opt_step": (I, [P, P, I, P, P, I, P]),
-    "v2a_opt_step_packed": (I, [P, P, I, P, P, I, P, I, P]),
-    "v2a_opt_apply_ema": (I, [P, P, I, P, I, P]),
+    "v2a_opt_step_packed": (I, [P, P, I, P, P, I, P, I, I, P]),
     "v2a_opt_presum": (I, [P, P, I, I, P, P]),
     "v2a_opt_scale_grads": (I, [P, P, I, F, P]),
     "v2a_replay_sample_indices": (I, [P, P, P, I, I, I, P, P]),

@@ -5,6 +5,7 @@ libv2a_hip.so launched on torch's current stream with raw pointers.
 All activations are channels-last fp32: images [N,H,W,C], sequences [N,T,C], video [B,F,H,W,C].
 """
 import os
+import threading
 import weakref
 import torch
 from ._lib import lib, check
@@ -13,7 +14,7 @@ ACT = {"none": 0, "silu": 1, "relu": 2, "mish": 3, "gelu": 4}
 
 _ws = {}
 _ws_retired = []        # outgrown scratch buffers stay allocated: captured hipGraphs hold their raw pointers (see workspace)
-_lane = [0]
+_tls = threading.local()      # per host thread: the current scratch lane (ws_lane), the 16-bit format last handed to the C side (_set_fmt)
 
 
 class ws_lane:
@@ -23,11 +24,11 @@ class ws_lane:
         self.lane = lane
 
     def __enter__(self):
-        self.prev = _lane[0]
-        _lane[0] = self.lane
+        self.prev = getattr(_tls, "lane", 0)
+        _tls.lane = self.lane
 
     def __exit__(self, *a):
-        _lane[0] = self.prev
+        _tls.lane = self.prev
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -52,7 +53,7 @@ def workspace(nbytes: int, device=None) -> torch.Tensor:
     caching allocator, every replay would keep writing partial sums into memory that now belongs to some other tensor."""
     device = torch.device(device if device is not None else torch.cuda.current_device())
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _lane[0])          # one scratch buffer per (device, lane): a side-stream launch sequence sets lane 1 (see ws_lane)
+    key = (idx, getattr(_tls, "lane", 0))          # one scratch buffer per (device, lane): a side-stream launch sequence sets lane 1 (see ws_lane)
     cur = _ws.get(key)
     if cur is None or cur.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -90,9 +91,9 @@ def pack_weight(w: torch.Tensor, mode: int = 0, out: torch.Tensor = None) -> tor
     return out
 
 
-_H_ROUTE_MIN_ROWS = [int(os.environ.get('V2A_H_ROUTE_MIN_ROWS', '256'))]
+_H_ROUTE_MIN_ROWS = [256]
 # fp32 convs whose im2col matrix (rows x K) has at least this many elements run on the LDS-DMA kernel (tools/conv_dma_f32_bench.py)
-_DMA_F32_MIN_WORK = [int(os.environ.get('V2A_DMA_F32_MIN_WORK', '300000'))]
+_DMA_F32_MIN_WORK = [300000]
 last_kernel = [None]    # rocprof-style name of the contraction kernel the most recent conv2d / conv2d_wgrad / conv2d_h call launched
 
 
@@ -108,22 +109,17 @@ def _plan_name_h(M, Cout, K, ept, tname):
     if tname == "float":                          # fp32 instances: three-plane kernel (default) or the pipelined exact-f32 kernel
         x3 = lib.v2a_get_f32_conv_mode() == 1
         base = "conv_igemm_f32x3" if x3 else "conv_igemm_f32p"
-        if tiles128 < 128 and _SMALL_TILE_H and not (_DEEP_SMALL_M and M <= 1024 and float(M) * Cout * K >= 1.0e9):      # (mirrors conv_plan_h)
+        if tiles128 < 128:                        # (mirrors conv_plan_h)
             return f"{base}<64,64>"
         if Cout <= 64:
-            big = x3 and M % 256 == 0 and -(-M // 256) >= 200 and os.environ.get("V2A_X3_BIG", "1") != "0"
+            big = x3 and M % 256 == 0 and -(-M // 256) >= 200
             return f"{base}<{256 if big else 128},64>"
-        return f"{base}<128,{128 if (not x3 or os.environ.get('V2A_X3_BIG', '1') != '0') else 64}>"
-    if tiles128 < 128 and _SMALL_TILE_H:          # mirrors conv_plan_h (csrc/igemm_h.hip)
+        return f"{base}<128,128>"
+    if tiles128 < 128:                            # mirrors conv_plan_h (csrc/igemm_h.hip)
         return f"conv_igemm_h<64,64,{tname}>"
     return f"conv_igemm_h<128,{64 if Cout <= 64 else 128},{tname}>"
 
 
-_SMALL_TILE_H = os.environ.get('V2A_DMA_SMALL_TILE', '1') != '0'
-_CONV_X3H = os.environ.get('V2A_CONV_X3H', '1') != '0'
-_CONV_X3H_64 = os.environ.get('V2A_CONV_X3H_64', '1') != '0'
-_DEEP_SMALL_M = os.environ.get('V2A_DEEP_SMALL_M', '0') == '1'
-_WGRAD_DMA = os.environ.get('V2A_WGRAD_DMA', '1') != '0'
 _h_twin_regs = 0
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 
@@ -167,11 +163,8 @@ def gn_takes_post(S, C, G):
     return bool(lib.v2a_groupnorm_takes_post(S, C, G))
 
 
-_DEFER = os.environ.get('V2A_DEFER_REDUCE', '1') != '0'
-
-
 def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y, defer=False,
-                    want_stats=False, second=None):
+                    want_stats=False):
     """fp32 conv on the LDS-DMA kernel (exact-f32 MFMA): same results as the register-staged kernel up to summation order.
     defer: returns (y, Slabs | None) -- with Slabs the split-K reduce is left to the consuming GroupNorm launch.
     want_stats: returns (y, stats | None) -- per-64-row (sum, sum of squares) blocks of y for groupnorm_fwd(stats=...)."""
@@ -193,15 +186,11 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
     ws = workspace(wsb, x.device) if wsb else None
     last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
     # mirrors conv_dma_launch (csrc/igemm_h.hip): 3x3 / stride 1 / pad 1 over square 4 ... 32-wide maps -> the three-plane halo kernel
-    if (_CONV_X3H and lib.v2a_get_f32_conv_mode() == 1 and KH == 3 and KW == 3 and (sh, sw, ph, pw) == (1, 1, 1, 1) and not ups and idil == 1
-            and x2 is None and H == W and (OH, OW) == (H, W) and W in ((4, 8, 16, 32, 64) if _CONV_X3H_64 else (4, 8, 16, 32)) and M % 128 == 0 and Cout % 64 == 0
-            and not want_stats and second is None):
+    if (lib.v2a_get_f32_conv_mode() == 1 and KH == 3 and KW == 3 and (sh, sw, ph, pw) == (1, 1, 1, 1) and not ups and idil == 1
+            and x2 is None and H == W and (OH, OW) == (H, W) and W in (4, 8, 16, 32, 64) and M % 128 == 0 and Cout % 64 == 0
+            and not want_stats):
         last_kernel[0] = f"conv_halo_x3<{W}>"
-    if second is not None:      # (w2_packed, bias2 | None, m_split): output rows >= m_split use the second operand set (this launch only)
-        w2, b2, ms = second
-        assert (b2 is None) == (bias is None) and w2.numel() == w_packed.numel()
-        check(lib.v2a_conv2d_set_second(w2.data_ptr(), _p(b2), int(ms)), "conv2d_set_second")
-    if defer and _DEFER and wsb and rowvec is None:
+    if defer and wsb and rowvec is None:
         import ctypes
         ns = ctypes.c_int(0)
         check(lib.v2a_conv2d_fwd_dma_f32_d(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), None, _p(residual), y.data_ptr(),
@@ -221,7 +210,7 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
            residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None, defer=False,
-           want_stats=False, second=None):
+           want_stats=False):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]; with defer=True
     (y, Slabs | None): when Slabs is returned, y is NOT written yet -- hand both to the GroupNorm that consumes the conv.
     bf16-MFMA mode: `x_h` = an existing bf16 twin of x (skips the cast launch); `keep_h` (a list) receives the twin that was used, so a
@@ -238,9 +227,7 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
             and (N * H * W * KH * KW * (C1 + C2) >= _DMA_F32_MIN_WORK[0] or lib.v2a_get_f32_conv_mode() == 1)
             and lib.v2a_get_precision() == 0):
         return _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, rows_per_batch, residual, idil, ups, out_hw, y,
-                               defer=defer, want_stats=want_stats, second=second)
-    if second is not None:
-        raise ValueError("conv2d(second=...): only the fp32 LDS-DMA kernels take two operand sets (channels % 32 == 0, fp32 precision mode)")
+                               defer=defer, want_stats=want_stats)
     if want_stats:     # only the LDS-DMA fp32 kernel emits statistics
         assert not defer
         return conv2d(x, w_packed, bias, Cout, KH, KW, stride, pad, x2=x2, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual,
@@ -372,11 +359,7 @@ class WgradBatch:
     launch it alone); `launch` plans the reduction splits over the whole group (about TARGET_WG workgroups per launch, every slice at
     least MIN_DEPTH reduction tiles), runs the main kernel(s) and hands the split-K reduces to the collector (one multi-tensor launch
     at the collector's next flush).  Per-element summation order is fixed by the plan: bitwise reproducible."""
-    TARGET_WG = int(os.environ.get("V2A_WGRAD_MULTI_WG", "1280"))
-    MIN_DEPTH = int(os.environ.get("V2A_WGRAD_MULTI_DEPTH", "4"))
-    TARGET_WG_HALO = int(os.environ.get("V2A_WGRAD_MULTI_WG_HALO", "512"))
-    TARGET_WG_X3 = (int(os.environ.get("V2A_WGRAD_MULTI_WG_X3_64", "1024")), int(os.environ.get("V2A_WGRAD_MULTI_WG_X3_128", "512")))
-    TARGET_WG_X3H = int(os.environ.get("V2A_WGRAD_MULTI_WG_X3H", "512"))
+    TARGET_WG, MIN_DEPTH, TARGET_WG_HALO, TARGET_WG_X3, TARGET_WG_X3H = 1280, 4, 512, (1024, 512), 512
     WEIGHT = {0: 1.0, 1: 2.0, 2: 1.5, 3: 1.0, 4: 1.0, 5: 1.0, 6: 1.0, 7: 1.0, 8: 1.0, 9: 1.0, 10: 1.0}   # relative cost of one (output tile, reduction tile) step per kernel body
 
     def __init__(self, collector):
@@ -515,7 +498,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
     if lib.v2a_get_precision() == 1:
         kn = "conv_wgrad_bf16"
     else:       # mirrors the dispatch in v2a_conv2d_wgrad: whole 16-B pieces -> the LDS-DMA kernel
-        dma = _WGRAD_DMA and Cout % 4 == 0 and K % 4 == 0 and C1 % 4 == 0 and (C1 + C2) % 4 == 0
+        dma = Cout % 4 == 0 and K % 4 == 0 and C1 % 4 == 0 and (C1 + C2) % 4 == 0
         kn = "conv_wgrad_dma_f32" if dma else "conv_wgrad_f32"
     last_kernel[0] = _plan_name(lib.v2a_conv2d_wgrad_plan, kn, M, Cout, K)
     return dw
@@ -523,8 +506,7 @@ def conv2d_wgrad(x, dy, w_shape, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, idi
 
 # ---- bf16-storage family (csrc/igemm_h.hip): activations / packed weights are torch.bfloat16 tensors, accumulation fp32
 _zeros_h = {}
-_FUSED_STATS = os.environ.get('V2A_GN_FUSED_STATS', '1') != '0'
-_H2 = os.environ.get('V2A_CONV_H2', '1') != '0'
+_FUSED_STATS = True      # GroupNorm statistics from the producing conv's epilogue
 
 
 def _zero_line(device):
@@ -541,28 +523,29 @@ HALF_DTYPES = (torch.bfloat16, torch.float16)      # the two 16-bit storage form
 
 
 def _chk_h(t, name="tensor"):
-    """16-bit storage tensor (bf16 or IEEE fp16).  The C side keeps ONE process-wide format flag for its `_h` entry points: it is set
-    here from the dtype of the tensor every wrapper checks first, so mixed use (bf16 policy twins, fp16 video storage) stays correct."""
+    """16-bit storage tensor (bf16 or IEEE fp16).  The C side keeps one format flag PER HOST THREAD for its `_h` entry points: it is set
+    here from the dtype of the tensor every wrapper checks first, so mixed use (bf16 policy twins, fp16 video storage, several threads)
+    stays correct."""
     assert t.is_cuda and t.dtype in HALF_DTYPES and t.is_contiguous(), f"{name}: need contiguous bf16 / fp16 CUDA tensor"
     _set_fmt(t.dtype)
     return t
 
 
-_fmt_now = [None]
+_fmt_now = _tls                    # (the C flag is thread_local too: csrc/igemm_h.hip g_v2a_half_f16)
 
 
 def _set_fmt(dtype):
-    """Select the 16-bit format of the `_h` kernel families (process-wide C flag).  The cache only short-cuts repeated calls from
-    this module; set_half_format() below is the one public way to flip the flag, so the cache cannot go stale."""
-    if _fmt_now[0] is not dtype:
+    """Select the 16-bit format of this thread's `_h` launches.  The cache only short-cuts repeated calls from this module;
+    set_half_format() below is the one public way to flip the flag, so the cache cannot go stale."""
+    if getattr(_fmt_now, "v", None) is not dtype:
         lib.v2a_set_half_format(1 if dtype == torch.float16 else 0)
-        _fmt_now[0] = dtype
+        _fmt_now.v = dtype
 
 
 def set_half_format(dtype):
     """Public form of _set_fmt (torch.bfloat16 | torch.float16)."""
     assert dtype in HALF_DTYPES
-    _fmt_now[0] = None
+    _fmt_now.v = None
     _set_fmt(dtype)
 
 
@@ -604,10 +587,11 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-_GN_FUSE = os.environ.get('V2A_GN_FUSE', '1') != '0'
-
-
-_GN_FUSE_MAX_REPEAT = int(os.environ.get('V2A_GN_FUSE_MAX_REPEAT', '2'))
+# test hooks (flipped by tests/test_ops_gpu.py / test_video_gpu.py to run the unfused / tap-by-tap forms of the same layers beside the
+# default ones; not configuration): GroupNorm folded into the halo conv's loader, the halo / frame-stack conv kernels themselves
+GN_FUSE = [True]
+CONV_H3 = [True]
+_GN_FUSE_MAX_REPEAT = 2
 
 
 def gn_fuse_pays(Cout):
@@ -619,7 +603,7 @@ def gn_fuse_pays(Cout):
 
 def gn_fusable(N, H, W, C, Cout, KH, KW, stride, pad, ups):
     """True when a GroupNorm + activation in front of this conv can run inside the halo kernel (v2a_conv2d_fwd_h3_gn)."""
-    return bool(_GN_FUSE and not ups and C <= 1024 and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
+    return bool(GN_FUSE[0] and CONV_H3[0] and not ups and C <= 1024
                 and lib.v2a_conv2d_h3_eligible(N, H, W, C, Cout, KH, KW, stride[0], stride[1], pad[0], pad[1], 0, 0))
 
 
@@ -693,7 +677,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         last_kernel[0] = f"conv_halo_h3_gn<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
         return (y, stats) if want_stats else y
     if (idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES and not defer and x2 is None
-            and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
+            and CONV_H3[0]
             and lib.v2a_conv2d_h3_eligible(N, H, W, C1, Cout, KH, KW, sh, sw, ph, pw, 1 if ups else 0, C2)):
         # 3x3 / stride 1: the halo-tile kernel (csrc/igemm_h3.hip) -- the nine taps share one DMA of the input patch
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
@@ -703,7 +687,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
         last_kernel[0] = f"conv_halo_h3<{'256x256' if Cout % 256 == 0 else ('512x128' if OH % 32 == 0 else '256x128')}>"
         return (y, stats) if want_stats else y
     if (idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES and not defer and x2 is None and not ups
-            and not os.environ.get("V2A_CONV_H3_OFF_FOR_TEST")
+            and CONV_H3[0]
             and lib.v2a_conv2d_t3_eligible(N, H, W, C1, Cout, KH, KW, sh, sw, ph, pw, 0, C2)):
         # temporal 3x1 over [B, F, HW, C]: the frame-stack kernel (csrc/igemm_h3.hip) -- the three taps share one DMA of the frames
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
@@ -711,7 +695,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
                                     _zero_line(x.device).data_ptr(), N, H, W, C1, Cout, rows_per_batch, _p(stats), _stream()), "conv2d_fwd_t3")
         last_kernel[0] = "conv_frames_h3<448x128>"
         return (y, stats) if want_stats else y
-    if (_H2 and idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES
+    if (idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES
             and lib.v2a_conv2d_h2_eligible(M, Cout, K, C1, C2)):
         # large layer: the multi-stage 256-row kernel (csrc/igemm_h2.hip)
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None
@@ -724,7 +708,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
     ws = workspace(wsb, x.device) if wsb else None
     if defer:        # fp32 output, split-K plan: leave the reduce (and bias / residual) to the consuming GroupNorm launch
         assert out_f32 and res_h is None and not want_stats
-        if _DEFER and wsb and rowvec is None and lib.v2a_conv2d_h_splits(M, Cout, K) > 1:
+        if wsb and rowvec is None and lib.v2a_conv2d_h_splits(M, Cout, K) > 1:
             import ctypes
             ns = ctypes.c_int(0)
             check(lib.v2a_conv2d_fwd_h_d(x.data_ptr(), _p(x2), w_packed.data_ptr(), _p(bias), None, _p(res_f), y.data_ptr(),
@@ -767,15 +751,8 @@ def colsum(x2d, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ group norm
-def _gn_second(second):
-    """second = (gamma2, beta2, n_split): samples n >= n_split of the NEXT GroupNorm launch use the second parameter set."""
-    if second is not None:
-        g2, b2, ns = second
-        check(lib.v2a_groupnorm_set_second(g2.data_ptr(), b2.data_ptr(), int(ns)), "groupnorm_set_second")
-
-
 def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None,
-                  stats=None, stats2=None, second=None, post=None, post_slabs=None):
+                  stats=None, stats2=None, post=None, post_slabs=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
     Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
     that consumes y takes it as x_h and skips its cast launch)."""
@@ -794,23 +771,25 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     if twin_out is not None and C % 4 == 0:
         yh = torch.empty((N, S, C), dtype=POLICY_HALF[0], device=x.device)
         twin_out.append(yh)
-    _gn_second(second)
+    po = (None, None, 0, 0, None)      # explicit operands of the launch: (dense post, post slabs, their number, their stride, their bias)
     if post is not None or post_slabs is not None:
         # added to the OUTPUT (after activation / FiLM): dense tensor, or the split-K slabs (+ bias) of the conv that produces it
         # (conv2d(defer=True) on a scratch lane of its own); float4 wave kernels only -- ask gn_takes_post first
         assert gn_takes_post(S, C, G) and x2 is None and not (post is not None and post_slabs is not None)
         if post_slabs is not None:
             assert post_slabs.residual is None and post_slabs.stride == N * S * C
-            check(lib.v2a_groupnorm_set_post(None, post_slabs.ws.data_ptr(), post_slabs.n, post_slabs.stride, _p(post_slabs.bias)), "groupnorm_set_post")
+            po = (None, post_slabs.ws.data_ptr(), post_slabs.n, post_slabs.stride, _p(post_slabs.bias))
         else:
             _chk(post, "post")
             assert post.numel() == N * S * C
-            check(lib.v2a_groupnorm_set_post(post.data_ptr(), None, 0, 0, None), "groupnorm_set_post")
-    if slabs is not None:      # x is the (still unwritten) conv output: the kernel sums the conv's split-K slabs and stores x too
-        assert slabs.residual is None
-        check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), None, C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
-                                      _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], slabs.ws.data_ptr(), slabs.n,
-                                      slabs.stride, _p(slabs.bias), None, None, 0, _stream()), "groupnorm_fwd_s")
+            po = (post.data_ptr(), None, 0, 0, None)
+    if slabs is not None or po[0] is not None or po[1] is not None:
+        # slabs: x is the (still unwritten) conv output -- the kernel sums the conv's split-K slabs and stores x too
+        assert slabs is None or slabs.residual is None
+        sl = (slabs.ws.data_ptr(), slabs.n, slabs.stride, _p(slabs.bias)) if slabs is not None else (None, 0, 0, None)
+        check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
+                                      _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], sl[0], sl[1], sl[2], sl[3],
+                                      po[0], po[1], po[2], po[3], po[4], _p(ws), wsb, _stream()), "groupnorm_fwd_s")
         return y, mean, rstd
     if (stats is not None and (x2 is None or stats2 is not None) and S % 64 == 0 and residual is None and film is None and yh is None):
         # statistics from the producing convs' epilogues (conv2d(want_stats=True)): the tensor is read once, by the apply pass
@@ -844,7 +823,7 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
                   dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None, colsum=None, defer_params=False,
-                  dout_slabs=None, dout_sum=None, second=None):
+                  dout_slabs=None, dout_sum=None):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
     as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx.
     defer_params: only fill `colsum` [N,2,C] (per-sample sums); the caller reduces it over n for many layers at once
@@ -869,8 +848,6 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     wsb = lib.v2a_groupnorm_workspace_bytes(N, S, C, G)
     ws = workspace(wsb, x.device) if wsb else None
-    assert second is None or defer_params, "two parameter sets: the per-set parameter gradients come from the colsum rows (defer_params)"
-    _gn_second(second)
     if dout_slabs is not None:      # dout = sum of the producing data-gradient conv's split-K slabs (+ its epilogue residual)
         sl = dout_slabs
         assert sl.bias is None
@@ -1116,7 +1093,8 @@ def spatial_softmax_bwd(att, kp, dkp):
     return dfeat
 
 
-_TS = {"on": os.environ.get("V2A_TSTAMP") in ("1", "2"), "fine": os.environ.get("V2A_TSTAMP") == "2", "buf": None, "names": []}
+_TSTAMP = os.environ.get("V2A_TSTAMP", "0")      # measurement aid (tools/phase_clock.py): "1" phase stamps, "2" also per-block stamps
+_TS = {"on": _TSTAMP in ("1", "2"), "fine": _TSTAMP == "2", "buf": None, "names": []}
 
 
 def tstamp(name):

@@ -42,13 +42,14 @@ class FusedAdamWEMA:
             self._offsets.append(self._offsets[-1] + p.numel())
 
     # ------------------------------------------------------------------ dynamic loss scaling (fp16 mode)
-    def enable_loss_scaling(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
-        """torch.cuda.amp.GradScaler's defaults and contract, inside the fused tail (csrc/optim.hip): call before the first step.
-        init_scale <= 0 switches it off.  Returns the device address of the scale (the loss-gradient kernel multiplies by it)."""
+    def enable_loss_scaling(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, growth_tracker=0):
+        """torch.cuda.amp.GradScaler's defaults and contract, inside the fused tail (csrc/optim.hip): call before the first step (or to
+        restore a checkpointed scaler: growth_tracker = its `_growth_tracker`).  init_scale <= 0 switches it off.  Returns the device
+        address of the scale (the loss-gradient kernel multiplies by it)."""
         host = self.state.cpu().numpy().tobytes()
         buf = ctypes.create_string_buffer(host, len(host))
         check(lib.v2a_opt_state_set_scaler(ctypes.addressof(buf), float(init_scale), float(growth_factor), float(backoff_factor),
-                                           int(growth_interval)), "opt_state_set_scaler")
+                                           int(growth_interval), int(growth_tracker)), "opt_state_set_scaler")
         self.state.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
         return self.loss_scale_ptr() if init_scale > 0 else 0
 
@@ -60,9 +61,32 @@ class FusedAdamWEMA:
         host = self.state.cpu().numpy().tobytes()
         buf = ctypes.create_string_buffer(host, len(host))
         ls, gt, sk, n = ctypes.c_float(), ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
-        check(lib.v2a_opt_state_scaler(ctypes.addressof(buf), ctypes.byref(ls), ctypes.byref(gt), ctypes.byref(sk), ctypes.byref(n)),
-              "opt_state_scaler")
+        check(lib.v2a_opt_state_scaler(ctypes.addressof(buf), ctypes.byref(ls), ctypes.byref(gt), ctypes.byref(sk), ctypes.byref(n),
+                                       None, None, None, None), "opt_state_scaler")
         return ls.value, gt.value, bool(sk.value), n.value
+
+    def scaler_state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict()'s layout ({'scale', 'growth_factor', 'backoff_factor', 'growth_interval',
+        '_growth_tracker'}: what the reference checkpoints as accelerator.scaler.state_dict(), lb_online_trainer_v7.py:377), or None
+        when loss scaling is off -- synchronises."""
+        host = self.state.cpu().numpy().tobytes()
+        buf = ctypes.create_string_buffer(host, len(host))
+        ls, gt, gf, bf = ctypes.c_float(), ctypes.c_int(), ctypes.c_float(), ctypes.c_float()
+        gi, on = ctypes.c_int(), ctypes.c_int()
+        check(lib.v2a_opt_state_scaler(ctypes.addressof(buf), ctypes.byref(ls), ctypes.byref(gt), None, None, ctypes.byref(gf),
+                                       ctypes.byref(bf), ctypes.byref(gi), ctypes.byref(on)), "opt_state_scaler")
+        if not on.value:
+            return None
+        return {"scale": float(ls.value), "growth_factor": float(gf.value), "backoff_factor": float(bf.value),
+                "growth_interval": int(gi.value), "_growth_tracker": int(gt.value)}
+
+    def load_scaler_state_dict(self, sd):
+        """Restore a GradScaler state dict (see scaler_state_dict); None / empty: leave the scaler as it is.  Only meaningful when loss
+        scaling is on (fp16 mode); returns the device address of the scale."""
+        if not sd:
+            return 0
+        return self.enable_loss_scaling(float(sd["scale"]), float(sd.get("growth_factor", 2.0)), float(sd.get("backoff_factor", 0.5)),
+                                        int(sd.get("growth_interval", 2000)), int(sd.get("_growth_tracker", 0)))
 
     def set_pack_rows(self, rows):
         """rows[i] = (forward-pack address or 0, Cin, taps, channel-window-pack address or 0, 16-bit twin address or 0, twin is fp16) of parameter i (PolicyEngine.opt_pack_rows):
@@ -76,12 +100,13 @@ class FusedAdamWEMA:
 
     pack_table = None
 
-    def step(self, zero_grad=True, packs=False, defer_ema=False):
-        """defer_ema: the EMA replica is left to apply_ema() (same values; the caller launches it where it overlaps other work and
-        before the next step() -- PolicyTrainer does, and flushes whenever the replica is read)."""
+    def step(self, zero_grad=True, packs=False, presum=(0, 0)):
+        """presum = (first, count): those chunks' gradient sums of squares were taken by presum(first, count) earlier in THIS step (a
+        stream ordered before this call); the step sums only the rest.  (0, 0): everything here."""
         pk = self.pack_table.data_ptr() if (packs and self.pack_table is not None) else None
         check(lib.v2a_opt_step_packed(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
-                                      self.partial.data_ptr(), 1 if zero_grad else 0, pk, 1 if defer_ema else 0, ops._stream()), "opt_step")
+                                      self.partial.data_ptr(), 1 if zero_grad else 0, pk, int(presum[0]), int(presum[1]), ops._stream()),
+              "opt_step")
 
     def chunk_range(self, t0, t1):
         """(first chunk, number of chunks) covering tensors t0 .. t1 - 1 of the optimiser's list."""
@@ -90,15 +115,10 @@ class FusedAdamWEMA:
         return sum(nch[:t0]), sum(nch[t0:t1])
 
     def presum(self, first, count):
-        """Sum the squares of the gradients of chunks [first, first + count) now (current stream); the next step() sums the rest."""
+        """Sum the squares of the gradients of chunks [first, first + count) now (current stream); hand the same range to step(presum=...)."""
         if count > 0:
             check(lib.v2a_opt_presum(self.table.data_ptr(), self.chunks.data_ptr(), int(first), int(count), self.partial.data_ptr(), ops._stream()),
                   "opt_presum")
-
-    def apply_ema(self, mark_done=False):
-        """Apply the EMA update a step(defer_ema=True) left pending (a no-op on the device when none is)."""
-        check(lib.v2a_opt_apply_ema(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.state.data_ptr(),
-                                    1 if mark_done else 0, ops._stream()), "opt_apply_ema")
 
     def scale_grads(self, scale: float):
         check(lib.v2a_opt_scale_grads(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, float(scale), ops._stream()),

@@ -29,10 +29,13 @@ def squaredcos_alphas_cumprod(n=100, max_beta=0.999):
     return torch.cumprod(1.0 - betas, dim=0)
 
 
-_PRIO = __import__('os').environ.get('V2A_PRIO') == '1'                    # experiment: chain streams at high priority
-_GN_DEFER = __import__('os').environ.get('V2A_GN_DEFER', '1') != '0'      # 0: every conv runs its own split-K reduce (A/B)
-_GN_POST = __import__('os').environ.get('V2A_GN_POST', '1') != '0'          # 0: the residual add of a ConditionalResidualBlock1D as its own launch (A/B)
-_STEM_WINDOW = __import__('os').environ.get('V2A_STEM_WINDOW', '1') != '0'  # 0: RGB stem on the scalar-gather conv / padded-copy weight gradient (A/B)
+
+# scratch lanes (ops.ws_lane: launches that may run concurrently must not share split-K slabs): 0 = the main chain, 1 + i = camera
+# encoder i on its side stream (any number of rgb keys), and two fixed lanes far outside that range
+_LANE_ENC0 = 1
+_LANE_RC = 1001        # slabs of a ConditionalResidualBlock1D's 1 x 1 residual conv, consumed by the block's second GroupNorm launch
+_LANE_WG = 1002        # deferred ConditionalUnet1D weight gradients (their own stream)
+
 
 class _Conv:
     """One conv / linear / transposed-conv parameter pair and its packed operands."""
@@ -137,35 +140,28 @@ class PolicyEngine:
         self.act_limits = None if lim is None else tuple(torch.as_tensor(v, dtype=torch.float32).reshape(-1).contiguous().to(self.device)
                                                         for v in lim)
         self._convs = {}
-        import os as _os
         # the two camera encoders (separate weights, no shared state) run as parallel branches of the step graph: +17 % steps/s
-        # at B=64 (their small-grid kernels fill each other's idle CUs).  Weight gradients on a third stream used to give ~1 %
-        # alone and cost 10 % on top of the encoder branches, so they stay on their chain's stream by default
-        # ("unet": side stream for the ConditionalUnet1D weight gradients only).
-        self.enc_streams = _os.environ.get("V2A_ENC_STREAMS", "1") != "0"
-        # both camera encoders as ONE chain over a stacked batch (fp32 precision mode, B % 16 == 0): V2A_ENC_STACK=1.  Built, parity-green
-        # (every policy test passes on it) and measured SLOWER than the two parallel chains with the three-plane convs: 9.92 / 9.97 ms
-        # against 9.77 / 9.89 ms per step on one box (forward 1.92 vs 1.77 ms, backward chain 2.97 vs 2.8, grouped weight gradients
-        # 1.78 vs 1.3: one stream loses the overlap of the two chains and gains less from the halved launch count) -- default off
-        self.stack_enc = _os.environ.get("V2A_ENC_STACK", "0") == "1"
+        # at B=64 (their small-grid kernels fill each other's idle CUs); their weight gradients stay on their chain's stream
         self._enc_side = []
-        self._wg_mode = _os.environ.get("V2A_ASYNC_WGRAD", "0")
-        self.async_wgrad = self._wg_mode == "1"
         self._in_enc = False
         self._cur_batch = 0
         self._stem_pad = {}
         self._stem_buf = {}        # (camera, N, H, W) -> zero-bordered [N, H + 6, W + 6, 4] stem input (_stem_fwd)
-        self._stem_ver = {}        # camera -> forwards written into its buffer so far
+        self._stem_ver = {}        # (camera, N, H, W) -> forwards written into that buffer so far
         # ConditionalUnet1D weight gradients feed nothing until the optimiser: with defer_unet_wgrad they are collected during the
         # data-gradient chain and launched as ONE extra branch next to the two encoder backward chains (one fork / one join).
         # The data-parallel trainer turns this off: there the `model.*` arena slice must be final after phase 1 so that its
         # all-reduce can travel under the encoder backward.
-        self.defer_unet_wgrad = _os.environ.get("V2A_DEFER_UNET_WGRAD", "1") != "0"
-        # data gradients as ordinary convs over a flipped, K-contiguous pack (written by the transposing multi-pack launch) instead
-        # of the N-major loader over the forward pack: the K-contiguous form is what the LDS-DMA kernels take
-        self.flip_dgrad = _os.environ.get("V2A_FLIP_DGRAD", "1") != "0"
+        self.defer_unet_wgrad = True
+        # data gradients are ordinary convs over a flipped, K-contiguous pack (written by the transposing multi-pack launch): the
+        # K-contiguous form is what the LDS-DMA kernels take
+        self.flip_dgrad = True
         self._deferred = []
         self.split_deferred = False  # data parallel: backward_phase2 leaves the deferred weight gradients to run_deferred_wgrads()
+        # debug export for the parity tests (None: off): when a dict, encode_fwd records the forward's DISCRETE decisions of each camera
+        # encoder -- the ReLU masks (NHWC bool) and the max-pool winners (int8 window tap 0..8) -- under "<module prefix>.relu0 / .pool /
+        # <block prefix>.relu1 / .relu2", so that a reference backward can be routed through the same decisions (tests/test_policy_gpu.py)
+        self.debug_decisions = None
         self.loss_scale_ptr = 0      # device address of the dynamic loss scale (fp16 mode: PolicyTrainer points it at its optimiser state)
         # GroupNorm parameter gradients: every layer's backward leaves its per-sample column sums in a persistent [N,2,C] buffer; ONE
         # multi-tensor launch per chain (ConditionalUnet1D, each camera encoder) reduces them over n in a fixed order -- no atomics,
@@ -176,18 +172,10 @@ class PolicyEngine:
         self._gn_pinned = set()
         # weight gradients: split-K reduces postponed to one multi-tensor launch per chain (ops.WgradCollector)
         self._wgc = None
-        self._wgc_on = _os.environ.get("V2A_WGRAD_MULTI_REDUCE", "1") != "0"
+        self._wgc_on = True
         self._collect_wg = False
         self._wg_stream = None
-        # grouped weight-gradient launches: "stage" = one launch per ResNet stage (and per <= 16 ConditionalUnet1D layers), "enc" = one
-        # group per camera encoder at the end of its chain, "0" = every gradient its own launch (round-2 behaviour)
-        self._wgb_mode = _os.environ.get("V2A_WGRAD_BATCH", "enc")
-        # (the round-3 experiment that ran the grouped launches on per-encoder side streams -- V2A_WGRAD_BATCH_STREAM=1 -- was slower
-        # and, at the end of round 4, crashes the process in the first step; the switch is gone, the code path is kept off)
-        self._wgb_side = False
-        self._wgb_streams = {}
-        self._side = None
-        self._keep = []
+        # grouped weight-gradient launches: one group per camera encoder at the end of its chain (and per <= 16 ConditionalUnet1D layers)
         self._build()
 
     # ------------------------------------------------------------------ structure
@@ -266,8 +254,7 @@ class PolicyEngine:
         self._film_w = self._film_b = self._film_wd = None
         self._film_ver = None
         self._dfilm_all = None
-        import os as _os2
-        self.batch_film = _os2.environ.get("V2A_BATCH_FILM", "1") != "0"
+        self.batch_film = True
 
     def _twin_dy(self, dy, x_h, cout):
         """bf16 twin of an output gradient, made once when the twin-fed weight-gradient kernel will take the layer (bf16-MFMA mode,
@@ -310,15 +297,7 @@ class PolicyEngine:
                 return None
         if self._wgc_active and not immediate:
             k = dict(k, collector=self._collector(), slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
-        if not (self.async_wgrad or (self._wg_mode == "unet" and not self._in_enc)):
-            return ops.conv2d_wgrad(*a, **k)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        self._keep.append((a, k))
-        with torch.cuda.stream(self._side), ops.ws_lane(1):
-            ops.conv2d_wgrad(*a, **k)
+        return ops.conv2d_wgrad(*a, **k)
 
     def _collector(self):
         if self._wgc is None:
@@ -330,47 +309,21 @@ class PolicyEngine:
     _tmp_seq = 0
     _wgb = None            # the ops.WgradBatch weight gradients are being collected into (grouped launches), or None
     _wgb_keep = ()
-    _wgb_stream = None     # side stream the current chain's grouped launches run on (None: the chain's own stream)
 
-    def _wgb_begin(self, side_key=None):
-        """Collect the weight gradients that follow into grouped launches (V2A_WGRAD_BATCH=0: off).  side_key: run those launches on
-        a side stream of their own (one per key), forked from / joined to the current stream."""
-        if self._wgb_mode == "0" or not self._wgc_active:
+    def _wgb_begin(self):
+        """Collect the weight gradients that follow into grouped launches."""
+        if not self._wgc_active:
             return
         self._wgb = ops.WgradBatch(self._collector())
         self._wgb_keep = []
-        self._wgb_stream = None
-        if side_key is not None and self._wgb_side:
-            st = self._wgb_streams.get(side_key)
-            if st is None:
-                st = self._wgb_streams[side_key] = torch.cuda.Stream(device=self.device)
-            self._wgb_stream = st
-
-    def _wgb_launch(self):
-        """Launch what has been collected so far (a stage boundary of the chain)."""
-        b = self._wgb
-        if b is None or not len(b):
-            return
-        st = self._wgb_stream
-        if st is None:
-            b.launch()
-            return
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            b.launch()
-        self._wgb_forked = True
 
     def _wgb_end(self):
-        """Launch the rest, join the side stream (operands were kept alive until here)."""
+        """Launch what was collected (operands were kept alive until here)."""
         if self._wgb is None:
             return
-        self._wgb_launch()
-        if self._wgb_stream is not None and self._wgb_forked:
-            torch.cuda.current_stream().wait_stream(self._wgb_stream)
-        self._wgb_forked = False
-        self._wgb, self._wgb_keep, self._wgb_stream = None, (), None
-
-    _wgb_forked = False
+        if len(self._wgb):
+            self._wgb.launch()
+        self._wgb, self._wgb_keep = None, ()
 
     def _slab_key(self, dw):
         """Stable name of the layer a gradient view belongs to (its slab buffer is kept per layer, not per address: the autograd path
@@ -385,18 +338,13 @@ class PolicyEngine:
 
     def _wg_begin(self):
         """From here on weight gradients only run their main kernels; _wg_flush sums all their split slabs in one launch."""
-        self._wgc_active = self._wgc_on and not self.async_wgrad and self._wg_mode != "unet"
+        self._wgc_active = self._wgc_on
         self._tmp_seq = 0
 
     def _wg_flush(self):
         if self._wgc_active:
             self._collector().flush()
         self._wgc_active = False
-
-    def _join_side(self):
-        if self._side is not None and self._keep:
-            torch.cuda.current_stream().wait_stream(self._side)
-        self._keep = []
 
     def _film_key(self):
         return tuple((r["ce"].w.data_ptr(), r["ce"].w._version, r["ce"].b._version) for r in self.film)
@@ -560,7 +508,7 @@ class PolicyEngine:
 
     def _defer_ok(self, rows, C, G):
         """May a conv whose [N, rows, C] output feeds GroupNorm(G) directly leave its split-K reduce to that launch?"""
-        return _GN_DEFER and ops.gn_takes_slabs(rows, C, G)
+        return ops.gn_takes_slabs(rows, C, G)
 
     def _gn_bwd(self, saved, dout4, grads, want_dres=False, want_dfilm=False, dfilm_out=None, dslabs=None, keep_dout=False, want_twin=False):
         """dslabs: dout4 is the not-yet-reduced output of a data-gradient conv (ops.Slabs); keep_dout: other launches read dout4 later,
@@ -606,10 +554,8 @@ class PolicyEngine:
                 raise RuntimeError("GroupNorm gradient table missing during graph capture; run one eager step first")
             rows, work = [], []
             for i, ent in enumerate(chain):
-                pre, N, C = ent[:3]
-                # (pre, N, C): the layer's own [N, 2, C] buffer; (pre, N, C, key, byte offset): N rows of a stacked buffer (two encoders)
-                cs_ptr = self._gn_cs[(pre, N, C)].data_ptr() if len(ent) == 3 else self._gn_cs[ent[3]].data_ptr() + ent[4]
-                rows.append([cs_ptr, grads[pre + ".weight"].data_ptr(), grads[pre + ".bias"].data_ptr(), N, C])
+                pre, N, C = ent          # the layer's own [N, 2, C] column-sum buffer
+                rows.append([self._gn_cs[(pre, N, C)].data_ptr(), grads[pre + ".weight"].data_ptr(), grads[pre + ".bias"].data_ptr(), N, C])
                 work += [[i, b] for b in range((C + 63) // 64)]
             for k in list(self._gn_tables):              # evict oldest-first, never a table a captured hipGraph points at
                 if len(self._gn_tables) <= 64:
@@ -631,14 +577,14 @@ class PolicyEngine:
         Otherwise: [N, H, W, 3] and the scalar-gather kernel.  Returns (saved input, conv output)."""
         N, C, H, W = img_nchw.shape
         # (also in the 16-bit MFMA modes: the 3-channel stem never ran on the 16-bit kernels, it is an fp32 conv there too)
-        if (_STEM_WINDOW and conv1.window and C == 3 and H % 2 == 0 and W % 2 == 0 and ops.lib.v2a_get_f32_conv_mode() == 1):
+        if (conv1.window and C == 3 and H % 2 == 0 and W % 2 == 0 and ops.lib.v2a_get_f32_conv_mode() == 1):
             bk = (key, N, H, W)
             xp = self._stem_buf.get(bk)
             if xp is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("stem input buffer missing during graph capture; run one eager step first")
                 xp = self._stem_buf[bk] = torch.zeros((N, H + 6, W + 6, 4), dtype=torch.float32, device=img_nchw.device)
-            self._stem_ver[key] = self._stem_ver.get(key, 0) + 1      # (a backward over an overwritten buffer is refused, see _encode_bwd)
+            self._stem_ver[bk] = self._stem_ver.get(bk, 0) + 1        # (a backward over an overwritten buffer is refused, see _encode_bwd)
             ops.nchw_to_nhwc4p(img_nchw, xp, 3, normalize=True)
             c1 = ops.conv2d_window(xp, conv1.pw(), w0, 7, 1, (2, 1), (H // 2, W // 2), xpitch=8, C=32)
             return xp, c1
@@ -655,7 +601,11 @@ class PolicyEngine:
         a1, s_gn1 = self._gn(c1, e["bb"] + ".1", w0 // 16, "relu")
         h, pidx = ops.maxpool_fwd(a1)
         ops.tstamp_fine(f"enc_fwd[{key}] stem done")
-        st = dict(x0=x0, x0_ver=self._stem_ver.get(key, 0), gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
+        dec = self.debug_decisions
+        if dec is not None:
+            dec[e["bb"] + ".relu0"] = a1 > 0
+            dec[e["bb"] + ".pool"] = pidx.clone()
+        st = dict(x0=x0, x0_ver=self._stem_ver.get((key,) + tuple(img_nchw.shape[:1]) + tuple(img_nchw.shape[2:]), 0), gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[])
         h_tw = None                                  # bf16 twin of the running activation (emitted by the GroupNorm launches)
         for blk in e["blocks"]:
             s, co = blk["stride"], blk["cout"]
@@ -681,6 +631,9 @@ class PolicyEngine:
                 (ops.conv2d(a, blk["conv2"].pf(), None, co, 3, 3, (1, 1), (1, 1), keep_h=k2, x_h=a_tw), None)
             h, s2 = self._gn(o2, blk["pre"] + ".bn2", g, "relu", residual=idn, slabs=sl)
             h_tw = self._take_tw(h)
+            if dec is not None:
+                dec[blk["pre"] + ".relu1"] = a > 0
+                dec[blk["pre"] + ".relu2"] = h > 0
             st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd, inp_h=k1[0] if k1 else None, a_h=k2[0] if k2 else None))
             ops.tstamp_fine(f"enc_fwd[{key}] block {len(st['blocks']) - 1} done")
         feat = h
@@ -697,7 +650,7 @@ class PolicyEngine:
     def encode_bwd(self, key, df, st, grads):
         tok = self._gn_begin()
         self._wg_begin()
-        self._wgb_begin(side_key=key)
+        self._wgb_begin()
         ops.tstamp(f"enc_bwd[{key}] begin")
         try:
             self._encode_bwd(key, df, st, grads)
@@ -755,8 +708,6 @@ class PolicyEngine:
                 ops.tstamp(f"enc_bwd[{key}] stage {3 - bi // 2} dgrad done")
             else:
                 ops.tstamp_fine(f"enc_bwd[{key}] block {nblk - 1 - bi} dgrad done")
-            if self._wgb_mode == "stage" and bi % 2 == 1:           # both blocks of a ResNet stage are through: their gradients as one launch
-                self._wgb_launch()
         da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
         dc1, _, _ = self._gn_bwd(st["gn1"], da1, grads)
         ops.tstamp_fine(f"enc_bwd[{key}] stem gn done")
@@ -766,7 +717,7 @@ class PolicyEngine:
         x0 = st["x0"]
         c1 = e["conv1"]
         if x0.shape[-1] == 4:                        # zero-bordered 4-channel stem input (_stem_fwd): no padding, no copy
-            if st.get("x0_ver") != self._stem_ver.get(key):
+            if st.get("x0_ver") != self._stem_ver.get((key, x0.shape[0], x0.shape[1] - 6, x0.shape[2] - 6)):
                 raise RuntimeError("the stem input of this forward was overwritten by a later forward of the same encoder and batch shape")
             dw4 = torch.empty((c1.co, 4, 7, 7), dtype=torch.float32, device=x0.device)
             self._wg(x0, dc1, (c1.co, 4, 7, 7), 7, 7, (2, 2), (0, 0), dw=dw4, immediate=True)
@@ -784,184 +735,6 @@ class PolicyEngine:
             ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
         else:
             self._wg(x0, dc1, c1.shape, 7, 7, (2, 2), (3, 3), dw=grads[c1.wname])
-
-    # ------------------------------------------------------------------ both camera encoders as ONE stacked chain
-    # The two ResNet18-GN encoders have identical geometry and separate weights.  Stacked along the batch ([2B, H, W, C]: rows [0, B) first
-    # camera, [B, 2B) second) every conv / GroupNorm / pooling launch serves both: the LDS-DMA fp32 convs take a second operand set for
-    # output rows >= m_split (csrc/igemm_h.hip w2 / bias2 / m_split), the GroupNorm kernels a second (gamma, beta) for samples >= n_split;
-    # weight gradients and GroupNorm parameter gradients are per-encoder entries of the grouped launches (sub-batch pointers).  Half the
-    # launches of the encoder phases, each with twice the rows -- the per-launch skeleton (~10 us) is what these short kernels are made of.
-    def stack_ok(self, B):
-        from ._lib import lib
-        return (self.stack_enc and len(self.cfg.rgb_keys) == 2 and B >= 16 and B % 16 == 0 and lib.v2a_get_precision() == 0
-                and lib.v2a_get_f32_conv_mode() in (0, 1) and self.flip_dgrad)
-
-    def _gn2(self, x4, pa, pb, G, act, B, residual=None, slabs=None):
-        N = x4.shape[0]
-        C = x4.shape[-1]
-        x3 = x4.view(N, -1, C)
-        r3 = residual.view(N, -1, C) if residual is not None else None
-        y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pa + ".weight"], self.P[pa + ".bias"], G, act, residual=r3, slabs=slabs,
-                                          second=(self.P[pb + ".weight"], self.P[pb + ".bias"], B))
-        return y.view(x4.shape), (x3, mean, rstd, r3, None, (pa, pb), G, act)
-
-    def _gn_bwd2(self, saved, dout4, want_dres=False, dslabs=None, keep_dout=False):
-        x3, mean, rstd, r3, _, (pa, pb), G, act = saved
-        d3 = dout4.view(x3.shape)
-        N, _, C = x3.shape
-        B = N // 2
-        ck = ("stack", pa, N, C)
-        cs = self._gn_cs.get(ck)
-        if cs is None:
-            cs = torch.empty((N, 2, C), dtype=torch.float32, device=self.device)
-            self._gn_cs[ck] = cs
-        self._gn_chain.append((pa, B, C, ck, 0))
-        self._gn_chain.append((pb, B, C, ck, B * 2 * C * 4))
-        dx, _, _, dres, _ = ops.groupnorm_bwd(x3, self.P[pa + ".weight"], self.P[pa + ".bias"], G, d3, mean, rstd, act, residual=r3,
-                                              want_dres=want_dres, colsum=cs, defer_params=True, dout_slabs=dslabs,
-                                              dout_sum=d3 if (dslabs is not None and keep_dout) else None,
-                                              second=(self.P[pb + ".weight"], self.P[pb + ".bias"], B))
-        return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None)
-
-    def _dgrad2(self, x, ca, cb, cout, kh, kw, stride, pad, ms, **kw_):
-        wa, bmode = ca.dg()
-        wb, _ = cb.dg()
-        assert bmode == 0
-        return ops.conv2d(x, wa, None, cout, kh, kw, stride, pad, second=(wb, None, ms), **kw_)
-
-    def encode_fwd2(self, keys, img_all, save):
-        """img_all [2B,3,H,W] (rows [0,B): camera keys[0], [B,2B): keys[1]) -> features [2B, feature_dim]."""
-        ea, eb = self.enc[keys[0]], self.enc[keys[1]]
-        cfg = self.cfg
-        w0 = cfg.widths[0]
-        B2 = img_all.shape[0]
-        B = B2 // 2
-        ops.tstamp("enc_fwd[stacked] begin")
-        x0 = ops.nchw_to_nhwc(img_all, normalize=True)
-        H0, W0 = x0.shape[1], x0.shape[2]
-        c1 = torch.empty((B2, (H0 + 6 - 7) // 2 + 1, (W0 + 6 - 7) // 2 + 1, w0), dtype=torch.float32, device=x0.device)
-        ops.conv2d(x0[:B], ea["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3), y=c1[:B])        # Cin = 3: the scalar-gather kernel, per camera
-        ops.conv2d(x0[B:], eb["conv1"].pf(), None, w0, 7, 7, (2, 2), (3, 3), y=c1[B:])
-        a1, s_gn1 = self._gn2(c1, ea["bb"] + ".1", eb["bb"] + ".1", w0 // 16, "relu", B)
-        h, pidx = ops.maxpool_fwd(a1)
-        ops.tstamp_fine("enc_fwd[stacked] stem done")
-        st = dict(x0=x0, gn1=s_gn1, pidx=pidx, a1_shape=tuple(a1.shape), blocks=[], B=B)
-        for ba, bb in zip(ea["blocks"], eb["blocks"]):
-            s_, co = ba["stride"], ba["cout"]
-            g = co // 16
-            inp = h
-            oh, ow = inp.shape[1] // s_, inp.shape[2] // s_
-            ms = B * oh * ow
-            dfr = self._defer_ok(oh * ow, co, g)
-            cv = lambda x, ca, cb, kh, st_, pd: ops.conv2d(x, ca.pf(), None, co, kh, kh, (st_, st_), (pd, pd), defer=dfr,
-                                                            second=(cb.pf(), None, ms))
-            o1 = cv(inp, ba["conv1"], bb["conv1"], 3, s_, 1)
-            o1, sl = o1 if dfr else (o1, None)
-            a, s1 = self._gn2(o1, ba["pre"] + ".bn1", bb["pre"] + ".bn1", g, "relu", B, slabs=sl)
-            sd = None
-            if ba["down"] is not None:
-                idn = cv(inp, ba["down"], bb["down"], 1, s_, 0)
-                idn, sl = idn if dfr else (idn, None)
-                idn, sd = self._gn2(idn, ba["pre"] + ".downsample.1", bb["pre"] + ".downsample.1", g, "none", B, slabs=sl)
-            else:
-                idn = inp
-            o2 = cv(a, ba["conv2"], bb["conv2"], 3, 1, 1)
-            o2, sl = o2 if dfr else (o2, None)
-            h, s2 = self._gn2(o2, ba["pre"] + ".bn2", bb["pre"] + ".bn2", g, "relu", B, residual=idn, slabs=sl)
-            st["blocks"].append(dict(inp=inp, a=a, s1=s1, s2=s2, sd=sd))
-            ops.tstamp_fine(f"enc_fwd[stacked] block {len(st['blocks']) - 1} done")
-        feat = h
-        _, FH, FW, FC = feat.shape
-        kl = ops.conv2d(feat, ea["pool"].pf(), ea["pool"].b, cfg.num_kp, 1, 1, second=(eb["pool"].pf(), eb["pool"].b, B * FH * FW))
-        kp, att = ops.spatial_softmax_fwd(kl)
-        f = torch.empty((B2, cfg.feature_dim), dtype=torch.float32, device=feat.device)
-        for e_, lo in ((ea, 0), (eb, B)):                  # [B, 64] x [64, 64]: two tiny launches (rows per camera < a row tile)
-            ops.conv2d(kp[lo:lo + B].view(1, 1, B, -1), e_["fc"].pf(), e_["fc"].b, cfg.feature_dim, 1, 1, y=f[lo:lo + B].view(1, 1, B, -1))
-        st.update(feat=feat, kp=kp, att=att)
-        if save is not None:
-            save["_stacked"] = st
-        ops.tstamp("enc_fwd[stacked] end")
-        return f
-
-    def encode_bwd2(self, keys, df, st, grads):
-        tok = self._gn_begin()
-        self._wg_begin()
-        self._wgb_begin(side_key="stacked")
-        ops.tstamp("enc_bwd[stacked] begin")
-        try:
-            self._encode_bwd2(keys, df, st, grads)
-        finally:
-            ops.tstamp("enc_bwd[stacked] chain done")
-            self._wgb_end()
-            self._gn_flush(tok, grads)
-            self._wg_flush()
-            ops.tstamp("enc_bwd[stacked] end")
-
-    def _encode_bwd2(self, keys, df, st, grads):
-        ea, eb = self.enc[keys[0]], self.enc[keys[1]]
-        B = st["B"]
-        B2 = 2 * B
-        halves = ((ea, 0), (eb, B))
-        kp, att, feat = st["kp"], st["att"], st["feat"]
-        dkp = torch.empty_like(kp)
-        for e_, lo in halves:
-            fc = e_["fc"]
-            self._wg(kp[lo:lo + B].view(1, 1, B, -1), df[lo:lo + B].view(1, 1, B, -1), fc.shape, 1, 1, dw=grads[fc.wname], dbias=grads[fc.bname])
-            _dgrad(df[lo:lo + B].view(1, 1, B, -1), fc, None, fc.ci, 1, 1, (1, 1), (0, 0), y=dkp[lo:lo + B].view(1, 1, B, -1))
-        dkl = ops.spatial_softmax_bwd(att, kp, dkp)
-        for e_, lo in halves:
-            pool = e_["pool"]
-            self._wg(feat[lo:lo + B], dkl[lo:lo + B], pool.shape, 1, 1, dw=grads[pool.wname], dbias=grads[pool.bname])
-        FH, FW = feat.shape[1], feat.shape[2]
-        dh = self._dgrad2(dkl, ea["pool"], eb["pool"], ea["pool"].ci, 1, 1, (1, 1), (0, 0), B * FH * FW)
-        ops.tstamp_fine("enc_bwd[stacked] head done")
-        dh_sl = None
-        nblk = len(ea["blocks"])
-        for bi, (ba, bb, bs) in enumerate(zip(reversed(ea["blocks"]), reversed(eb["blocks"]), reversed(st["blocks"]))):
-            s_, co, ci = ba["stride"], ba["cout"], ba["cin"]
-            inp = bs["inp"]
-            g = co // 16
-            oh, ow = bs["a"].shape[1], bs["a"].shape[2]
-            ih, iw = inp.shape[1], inp.shape[2]
-            dfr = self._defer_ok(oh * ow, co, g)
-            dfr_in = bi + 1 < nblk and self._defer_ok(ih * iw, ci, ci // 16)
-            do2, didn = self._gn_bwd2(bs["s2"], dh, want_dres=True, dslabs=dh_sl)
-            for (blk, lo) in ((ba, 0), (bb, B)):
-                self._wg(bs["a"][lo:lo + B], do2[lo:lo + B], blk["conv2"].shape, 3, 3, (1, 1), (1, 1), dw=grads[blk["conv2"].wname])
-            da = self._dgrad2(do2, ba["conv2"], bb["conv2"], co, 3, 3, (1, 1), (1, 1), B * oh * ow, defer=dfr)
-            da, sl = da if dfr else (da, None)
-            do1, _ = self._gn_bwd2(bs["s1"], da, dslabs=sl)
-            for (blk, lo) in ((ba, 0), (bb, B)):
-                self._wg(inp[lo:lo + B], do1[lo:lo + B], blk["conv1"].shape, 3, 3, (s_, s_), (1, 1), dw=grads[blk["conv1"].wname])
-            if ba["down"] is not None:
-                didn_raw, _ = self._gn_bwd2(bs["sd"], didn)
-                for (blk, lo) in ((ba, 0), (bb, B)):
-                    self._wg(inp[lo:lo + B], didn_raw[lo:lo + B], blk["down"].shape, 1, 1, (s_, s_), (0, 0), dw=grads[blk["down"].wname])
-                res_in = self._dgrad2(didn_raw, ba["down"], bb["down"], ci, 1, 1, (1, 1), (0, 0), B * ih * iw, idil=s_, out_hw=(ih, iw))
-            else:
-                res_in = didn
-            dh = self._dgrad2(do1, ba["conv1"], bb["conv1"], ci, 3, 3, (1, 1), (1, 1), B * ih * iw, idil=s_, out_hw=(ih, iw), residual=res_in,
-                              defer=dfr_in)
-            dh, dh_sl = dh if dfr_in else (dh, None)
-            if bi % 2 == 1:
-                ops.tstamp(f"enc_bwd[stacked] stage {3 - bi // 2} dgrad done")
-            else:
-                ops.tstamp_fine(f"enc_bwd[stacked] block {nblk - 1 - bi} dgrad done")
-        da1 = ops.maxpool_bwd(dh, st["pidx"], st["a1_shape"])
-        dc1, _ = self._gn_bwd2(st["gn1"], da1)
-        ops.tstamp_fine("enc_bwd[stacked] stem gn done")
-        x0 = st["x0"]
-        N0, H0, W0, _ = x0.shape
-        xp = self._stem_pad.get("stacked")
-        if xp is None or xp.shape[:3] != x0.shape[:3]:
-            xp = torch.zeros((N0, H0, W0, 4), dtype=torch.float32, device=x0.device)
-            self._stem_pad["stacked"] = xp
-        ops.copy2d(x0, xp, N0 * H0 * W0, 3, 3, 4)
-        for e_, lo in halves:
-            c1 = e_["conv1"]
-            dw4 = torch.empty((c1.co, 4, 7, 7), dtype=torch.float32, device=x0.device)
-            self._wg(xp[lo:lo + B], dc1[lo:lo + B], (c1.co, 4, 7, 7), 7, 7, (2, 2), (3, 3), dw=dw4, immediate=True)
-            ops.copy2d(dw4, grads[c1.wname], c1.co, 3 * 49, 4 * 49, 3 * 49)
 
     # ------------------------------------------------------------------ ConditionalUnet1D
     def _c1d(self, x, cv, k, x2=None, residual=None, stride=1, pad=None, keep_h=None, defer=False, x_h=None):
@@ -994,13 +767,13 @@ class PolicyEngine:
         # the residual branch rides on the second GroupNorm launch (out = mish(gn(c1)) + residual_conv(x), conditional_unet1d.py:62-65): the
         # identity branch as a dense addend, the 1 x 1 conv branch as its split-K slabs left on a scratch lane of their own -- no add / reduce
         # launch on the serial chain (bit-equal: the kernel adds in the reduce kernel's order).  fp32 mode, float4 wave GroupNorm only.
-        fuse = _GN_POST and ops.lib.v2a_get_precision() == 0 and ops.gn_takes_post(T, co, G)
+        fuse = ops.lib.v2a_get_precision() == 0 and ops.gn_takes_post(T, co, G)
         p_dense, p_slabs = None, None
         if fuse:
             if r["rc"] is None:
                 p_dense = x
             else:
-                with ops.ws_lane(5):
+                with ops.ws_lane(_LANE_RC):
                     rcy, p_slabs = self._c1d(x, r["rc"], 1, x2=x2, pad=0, defer=True)
                 if p_slabs is None:
                     p_dense = rcy                                  # (the plan did not split: a finished tensor)
@@ -1238,16 +1011,16 @@ class PolicyEngine:
     def _enc_parallel(self, fns):
         """Run the per-camera encoder chains (independent: separate weights, no shared state) as parallel branches: the first on
         the current stream, the others on side streams with their own scratch lanes; joined before returning."""
-        if not self.enc_streams or len(fns) < 2 or self._cur_batch < 8:      # B = 1 rollouts: fork / join costs more than it hides
+        if len(fns) < 2 or self._cur_batch < 8:      # B = 1 rollouts: fork / join costs more than it hides
             return [f() for f in fns]
         main = torch.cuda.current_stream()
         while len(self._enc_side) < len(fns) - 1:
-            self._enc_side.append(torch.cuda.Stream(device=self.device, priority=-1 if _PRIO else 0))
+            self._enc_side.append(torch.cuda.Stream(device=self.device))
         out = [None] * len(fns)
         for i, f in enumerate(fns[1:], 1):
             st = self._enc_side[i - 1]
             st.wait_stream(main)
-            with torch.cuda.stream(st), ops.ws_lane(1 + i):
+            with torch.cuda.stream(st), ops.ws_lane(_LANE_ENC0 + i):
                 out[i] = f()
         out[0] = fns[0]()
         for st in self._enc_side[:len(fns) - 1]:
@@ -1257,22 +1030,6 @@ class PolicyEngine:
     def global_cond(self, imgs: dict, save=None):
         keys = list(self.cfg.rgb_keys)
         self._cur_batch = imgs[keys[0]].shape[0]
-        if self.stack_ok(self._cur_batch):
-            B = self._cur_batch
-            img_all = imgs.get("_stacked")
-            if img_all is None:                       # separate tensors (compute_loss through the policy surface): one copy puts them side by side
-                a, b = imgs[keys[0]], imgs[keys[1]]
-                if a.dtype == b.dtype and a.shape == b.shape:
-                    img_all = torch.empty((2 * B,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
-                    img_all[:B].copy_(a)
-                    img_all[B:].copy_(b)
-            if img_all is not None:
-                f = self.encode_fwd2(keys, img_all, save)
-                fd = f.shape[1]
-                gc = torch.empty((B, 2 * fd), dtype=torch.float32, device=f.device)
-                ops.copy2d(f[:B], gc, B, fd, fd, 2 * fd, dst_off=0)
-                ops.copy2d(f[B:], gc, B, fd, fd, 2 * fd, dst_off=fd)
-                return gc
         feats = self._enc_parallel([(lambda k=k: self.encode_fwd(k, imgs[k], save)) for k in self.cfg.rgb_keys])
         B = feats[0].shape[0]
         fd = feats[0].shape[1]
@@ -1329,7 +1086,7 @@ class PolicyEngine:
         self._collect_wg = True
         tok = self._gn_begin()
         self._wg_begin()
-        if not self.defer_unet_wgrad:          # (data parallel: the model.* slice is finished inside phase 1) grouped launches at its end
+        if not self.defer_unet_wgrad:          # (weight gradients inside phase 1: grouped launches at its end)
             self._wgb_begin()
         try:
             dgc = self.unet_bwd(dpred, save, grads)
@@ -1338,7 +1095,6 @@ class PolicyEngine:
             self._wgb_end()
             self._gn_flush(tok, grads)
             self._wg_flush()
-        self._join_side()
         ops.tstamp("unet_bwd end")
         return dict(loss=loss, grads=grads, arena=arena, dgc=dgc, save_enc=save_enc, keep=save)
 
@@ -1362,30 +1118,22 @@ class PolicyEngine:
             if self._wg_stream is None:
                 self._wg_stream = torch.cuda.Stream(device=self.device)
             self._wg_stream.wait_stream(main)
-            with torch.cuda.stream(self._wg_stream), ops.ws_lane(7):
+            with torch.cuda.stream(self._wg_stream), ops.ws_lane(_LANE_WG):
                 self._launch_deferred(deferred)
                 if self.on_unet_wgrads_done is not None:       # (trainer: the model.* slice of the arena is final -> its gradient-norm partial sums)
                     self.on_unet_wgrads_done()
         self._in_enc = True
         try:
-            if "_stacked" in st["save_enc"]:
-                keys = list(self.cfg.rgb_keys)
-                df = torch.empty((2 * B, fd), dtype=torch.float32, device=dgc.device)
-                ops.copy2d(dgc, df[:B], B, fd, fd * nk, fd, src_off=0)
-                ops.copy2d(dgc, df[B:], B, fd, fd * nk, fd, src_off=fd)
-                self.encode_bwd2(keys, df, st["save_enc"]["_stacked"], grads)
-            else:
-                self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
+            self._enc_parallel([(lambda i=i, key=key: one(i, key)) for i, key in enumerate(self.cfg.rgb_keys)])
         finally:
             self._in_enc = False
         if deferred:
             main.wait_stream(self._wg_stream)
-        self._join_side()
 
     def _launch_deferred(self, deferred):
         ops.tstamp("unet_wgrad begin")
         col = self._collector() if self._wgc_on else None
-        batch = ops.WgradBatch(col) if (col is not None and self._wgb_mode != "0") else None
+        batch = ops.WgradBatch(col) if col is not None else None
         for a, k in deferred:
             kk = dict(k, slab_key=k.get("slab_key") or self._slab_key(k.get("dw")))
             if batch is not None and batch.add(*a, **kk):
@@ -1403,7 +1151,7 @@ class PolicyEngine:
         starts from that stream, while the encoder backward runs on the main one."""
         deferred, self._deferred = self._deferred, []
         if deferred:
-            with ops.ws_lane(7):
+            with ops.ws_lane(_LANE_WG):
                 self._launch_deferred(deferred)
         return deferred        # the CALLER keeps the operands alive until this stream has been joined (the encoder backward allocates meanwhile)
 

@@ -12,7 +12,6 @@ gradients per step (issued as two asynchronous slice all-reduces: the Conditiona
 backward), averaged by folding 1/world into the optimiser's gradient scale.
 """
 import copy
-import os
 import numpy as np
 import torch
 from . import ops
@@ -24,10 +23,15 @@ from ._lib import lib, check
 
 class PolicyTrainer:
     def __init__(self, policy, store: ReplayStore, batch_size=64, opt_params=None, ema_params=None, seed=0, use_graph=True,
-                 process_group=None, world_size=1, rank=0, store_vid: ReplayStore = None, rand_prob=0.3):
+                 process_group=None, world_size=1, rank=0, store_vid: ReplayStore = None, rand_prob=0.3, force_dp=False, dp_wire="fp32",
+                 loss_scale_init=65536.0, fuse_packs=True, presum=True):
         """`store_vid` (optional, same HBM pool as `store`: ReplayStore.pair) is the video-guided-rollout buffer; minibatches
         then follow sample_from_bufs' 'rand_prob' rule (lb_online_trainer_v7.py:787-851): all rows from `store` while `store_vid` is
-        empty, otherwise n_rand = #(U[0,1) < rand_prob) rows from `store` first and the rest from `store_vid`."""
+        empty, otherwise n_rand = #(U[0,1) < rand_prob) rows from `store` first and the rest from `store_vid`.
+        force_dp: the data-parallel step structure for a single rank too (exercises the RCCL path on a one-GPU box); dp_wire: "fp32" |
+        "bf16" wire format of the gradient all-reduce; loss_scale_init: initial dynamic loss scale of the fp16 mode (<= 0: no scaling);
+        fuse_packs / presum: the optimiser's update kernel writes the forward conv operands / the ConditionalUnet1D slice's gradient-norm
+        partial sums run ahead of the serial tail (both bit-equal to their separate-launch forms: tests/test_policy_gpu.py)."""
         self.policy = policy
         self.store = store
         self.store_vid = store_vid
@@ -38,15 +42,12 @@ class PolicyTrainer:
         self.eng = policy.engine
         self.device = self.eng.device
         self.world, self.rank, self.pg = world_size, rank, process_group
-        # the data-parallel step structure (three graphs + two asynchronous slice all-reduces); V2A_FORCE_DP=1 selects it for a
-        # single rank too, so that the RCCL path can be exercised on a one-GPU box
-        self.dp = world_size > 1 or (process_group is not None and os.environ.get("V2A_FORCE_DP") == "1")
-        # data parallel: the deferred ConditionalUnet1D weight-gradient branch stays alive (round 3 switched it off) -- it runs as a graph
-        # of its own on a side stream, the `model.*` slice's all-reduce leaves from that stream when it is done, and the encoder backward
-        # runs on the main stream meanwhile.  V2A_DP_DEFER=0: round-3 structure (weight gradients inside phase 1).
-        self.dp_defer = self.dp and os.environ.get("V2A_DP_DEFER", "1") != "0" and self.eng.defer_unet_wgrad
-        if self.dp and not self.dp_defer:
-            self.eng.defer_unet_wgrad = False      # the model.* gradient slice must be final after phase 1 (its all-reduce starts there)
+        # the data-parallel step structure (three + one graphs, two asynchronous slice all-reduces); force_dp selects it for a single
+        # rank too
+        self.dp = world_size > 1 or (process_group is not None and force_dp)
+        # data parallel: the deferred ConditionalUnet1D weight-gradient branch runs as a graph of its own on a side stream, the `model.*`
+        # slice's all-reduce leaves from that stream when it is done, and the encoder backward runs on the main stream meanwhile
+        self.dp_defer = self.dp
         if self.dp_defer:
             self.eng.split_deferred = True
         self._side = None
@@ -59,7 +60,6 @@ class PolicyTrainer:
         # EMA replica (ema_pytorch deep-copies the online model: lb_online_trainer_v7.py:135)
         self._ema_policy = copy.deepcopy(policy)
         self._ema_policy.requires_grad_(False)
-        self._ema_dirty = False
         self.names = policy.trainable_names()
         P = dict(policy.named_parameters())
         EP = dict(self.ema_policy.named_parameters())
@@ -75,9 +75,10 @@ class PolicyTrainer:
         # fp16 MFMA mode (v2a_hip.set_precision("fp16")): dynamic loss scaling inside the fused tail, GradScaler's contract -- the scaled loss
         # gradient starts the backward, unscale rides on the clip factor, a non-finite gradient norm skips the update and halves the scale
         import v2a_hip as _v
-        self.loss_scaling = _v.get_precision() == "fp16" and os.environ.get("V2A_LOSS_SCALE", "1") != "0"
+        self._loss_scale_init = float(loss_scale_init)
+        self.loss_scaling = _v.get_precision() == "fp16" and self._loss_scale_init > 0
         if self.loss_scaling:
-            self.eng.loss_scale_ptr = self.opt.enable_loss_scaling(float(os.environ.get("V2A_LOSS_SCALE_INIT", "65536")))
+            self.eng.loss_scale_ptr = self.opt.enable_loss_scaling(self._loss_scale_init)
         self.seed = int(seed) + 7919 * rank
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)       # Philox offset, advanced on device
         T, Da = policy.horizon, policy.action_dim
@@ -94,9 +95,8 @@ class PolicyTrainer:
         self._g_opt = None
         self._slices = self.eng.arena_slices(self.names)
         # the one collective of the path (v2a_hip/dp.py): slice 0 = ConditionalUnet1D gradients (final after phase 1), slice 1 = encoders
-        # V2A_DP_WIRE=bf16: opt-in bf16 wire format (half the bytes per xGMI link; the sum is rounded to bf16 -- not the parity path)
-        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size,
-                                   wire=os.environ.get("V2A_DP_WIRE", "fp32")) if self.dp else None
+        # dp_wire="bf16": opt-in bf16 wire format (half the bytes per xGMI link; the sum is rounded to bf16 -- not the parity path)
+        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size, wire=dp_wire) if self.dp else None
         self.feed = None               # parity / test hook (eager mode): dict(rows=int64[B] pool offsets, noise=[B,T,Da], timesteps=int64[B])
         self.on_grads_ready = None     # diagnostics hook (eager mode): called with the arena right before the optimiser consumes it
         self.comm_events = None        # bench: [(before_wait, after_wait)] HIP event pairs bracketing the stream's wait on the communicator
@@ -104,21 +104,16 @@ class PolicyTrainer:
         self._st = None
         self._warm = 0
         self.step_count = 0
-        # the ConditionalUnet1D re-pack (0.33 ms of HBM-bound launches) leaves the serial tail: it runs at the start of the NEXT step
-        # on a side stream, under the encoder forward (V2A_SPLIT_PACKS=0: everything right after the optimiser, as before)
-        self.split_packs = os.environ.get("V2A_SPLIT_PACKS", "1") != "0"
-        self.fuse_packs = os.environ.get("V2A_FUSE_PACKS", "1") != "0"      # forward conv operands written by the optimiser's update kernel
-        # Experiment, default off (V2A_DEFER_EMA=1 enables): the EMA replica is read at evaluation / checkpoint time only, yet its update
-        # is 12 of the 48 bytes per parameter the update kernel moves in the serial tail.  Deferred, that kernel skips it and the SAME
-        # update (same p, same decay; bit-equal, tests) runs at the start of the next step on the pack stream, under the encoder forward;
-        # `ema_policy` (a property) flushes a pending update before anyone sees the replica.  Measured: 8.21 vs 8.10 ms -- the extra
-        # launch competes with the encoder forward for what the tail saves, and re-reads the parameters.
-        self.defer_ema = os.environ.get("V2A_DEFER_EMA", "0") == "1"
+        # the ConditionalUnet1D's transposed data-gradient packs (HBM-bound launches) leave the serial tail: they run at the start of the
+        # NEXT step on a side stream, under the encoder forward
+        self.fuse_packs = bool(fuse_packs)             # forward conv operands written by the optimiser's update kernel
         # gradient norm: the ConditionalUnet1D slice (one end of the arena, 75 % of the parameters) is summed on the deferred weight-gradient
         # stream while the encoder backward runs (single GPU only: under data parallelism the slices are all-reduced first; not with a
-        # gradient hook, which may still edit the arena).  V2A_PRESUM=0: one sum-of-squares launch in the serial tail.
+        # gradient hook, which may still edit the arena).  The range is handed to the optimiser step EXPLICITLY, and only by a step whose
+        # own backward ran the pre-sum (_presummed): nothing is remembered across steps or optimisers.
         self._presum_range = (0, 0)
-        if os.environ.get("V2A_PRESUM", "1") != "0" and not self.dp:
+        self._presummed = False
+        if presum and not self.dp:
             mi = [i for i, n in enumerate(self.names) if n.startswith("model.")]
             if mi and mi[-1] - mi[0] + 1 == len(mi):         # (the model.* group is contiguous in the arena, first or last)
                 self._presum_range = self.opt.chunk_range(mi[0], mi[-1] + 1)
@@ -129,15 +124,17 @@ class PolicyTrainer:
         self._wg_keep = None
 
     def _presum(self):
-        if self._presum_range[1] and self.on_grads_ready is None:
+        """Hook on the deferred weight-gradient stream (PolicyEngine.on_unet_wgrads_done).  Only inside this trainer's own step (any other
+        backward through the engine, e.g. policy.compute_loss(...).backward(), fires the hook too and must not arm anything)."""
+        if self._in_step and self._presum_range[1] and self.on_grads_ready is None:
             self.opt.presum(*self._presum_range)
+            self._presummed = True
+
+    _in_step = False
 
     @property
     def ema_policy(self):
-        """The EMA replica (ema_pytorch's ema_model).  A deferred update of the last step is applied first (see defer_ema)."""
-        if self._ema_dirty:
-            self._ema_dirty = False
-            self.opt.apply_ema(mark_done=True)
+        """The EMA replica (ema_pytorch's ema_model)."""
         return self._ema_policy
 
     # ------------------------------------------------------------------ pieces
@@ -178,18 +175,16 @@ class PolicyTrainer:
         B = self.B
         ops.tstamp_reset()
         ops.tstamp("step begin")
-        if self.split_packs or self.defer_ema:         # last step's ConditionalUnet1D weights -> packed operands, and its deferred EMA
-            if self._pack_side is None:                # update, under the encoder forward (joined before the ConditionalUnet1D forward)
-                self._pack_side = torch.cuda.Stream(device=self.device)
-            self._pack_side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._pack_side):
-                if self.split_packs:
-                    self.eng.refresh_packs("unet", skip_fwd=self._packs_fused)
-                if self.defer_ema:
-                    self.opt.apply_ema(mark_done=False)      # (a no-op on the device when nothing is pending: first step, after a flush)
-            self.eng._pack_join = self._pack_side
-        oo = torch.empty((2 * B, 3, st.H, st.W), dtype=torch.float32, device=self.device)      # start | goal frames side by side: the
-        o0, o1 = oo[:B], oo[B:]                                                                 # two camera encoders run as one stacked chain
+        self._presummed = False
+        # last step's ConditionalUnet1D weights -> packed operands under the encoder forward (joined before the ConditionalUnet1D forward)
+        if self._pack_side is None:
+            self._pack_side = torch.cuda.Stream(device=self.device)
+        self._pack_side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._pack_side):
+            self.eng.refresh_packs("unet", skip_fwd=self._packs_fused)
+        self.eng._pack_join = self._pack_side
+        oo = torch.empty((2 * B, 3, st.H, st.W), dtype=torch.float32, device=self.device)      # start | goal frames, one allocation
+        o0, o1 = oo[:B], oo[B:]
         oa = torch.empty((B, st.act_len, st.act_dim), dtype=torch.float32, device=self.device)
         check(lib.v2a_replay_gather(st.root_frames.data_ptr(), 1 if st.dtype == torch.uint8 else 0, st.root_acts.data_ptr(),
                                     self.frame_start.data_ptr(), o0.data_ptr(), o1.data_ptr(), oa.data_ptr(), B, st.H, st.W,
@@ -203,7 +198,7 @@ class PolicyTrainer:
             ops.philox_randint(self.timesteps, self.policy.noise_scheduler.config.num_train_timesteps, self.seed ^ 0x5DEECE66D,
                                offset_dev=self.counter)
             check(lib.v2a_advance_counter(self.counter.data_ptr(), (n_noise + 3) // 4 + B, ops._stream()), "advance_counter")
-        imgs = {"img_obs_1": o0, "img_goal_1": o1, "_stacked": oo}
+        imgs = {"img_obs_1": o0, "img_goal_1": o1}
         self._st = self.eng.backward_phase1(imgs, oa, self.noise, self.timesteps, names=self.names, arena=self.arena)
         ops.copy2d(self._st["loss"], self.loss, 1, 1, 1, 1)
 
@@ -258,19 +253,31 @@ class PolicyTrainer:
             rows, self._pack_serial = self.eng.opt_pack_rows(self.opt.params)
             self.opt.set_pack_rows(rows)
         self._packs_fused = fused
-        self.opt.step(zero_grad=True, packs=fused, defer_ema=self.defer_ema)
+        self.opt.step(zero_grad=True, packs=fused, presum=self._presum_range if self._presummed else (0, 0))
+        self._presummed = False
         ops.tstamp("optimiser done / packs begin")
-        if self.split_packs:
-            self.eng.refresh_packs("enc", skip_fwd=fused)
-            self.eng._packs_pending = "unet"           # (re-armed on the host after every replay, see step())
-        else:
-            self.eng.refresh_packs(skip_fwd=fused)
+        self.eng.refresh_packs("enc", skip_fwd=fused)
+        self.eng._packs_pending = "unet"               # (re-armed on the host after every replay, see step())
         ops.tstamp("step end")
 
     # ------------------------------------------------------------------ step
     def step(self):
         """One optimisation step.  Returns the device tensor holding the loss (read it with .item() only when needed)."""
+        import v2a_hip as _v
+        if (_v.get_precision() == "fp16") != self.loss_scaling and self._loss_scale_init > 0:
+            raise RuntimeError("the precision mode changed after this PolicyTrainer was built (fp16 needs the loss scaler the constructor "
+                               "sets up, the other modes must not carry one): build a new trainer after v2a_hip.set_precision()")
         self._draw_indices()
+        self._in_step = True
+        try:
+            self._step_body()
+        finally:
+            self._in_step = False
+        self.eng._packs_pending = "unet"               # any reader of a UNet operand outside the next step refreshes it first
+        self.step_count += 1
+        return self.loss
+
+    def _step_body(self):
         if not self.use_graph or self._warm < 2:
             self._fwd_bwd()
             if self.dp:
@@ -331,11 +338,6 @@ class PolicyTrainer:
                 if pe:
                     pe[4].record()
                     self.phase_events.append(pe)
-        if self.split_packs:
-            self.eng._packs_pending = "unet"           # any reader of a UNet operand outside the next step refreshes it first
-        self._ema_dirty = self.defer_ema               # (host-side mirror of OptState.ema_pending: set per step, also under graph replay)
-        self.step_count += 1
-        return self.loss
 
     def ema_for_inference(self):
         """EMA weights are updated by the fused kernel behind torch's back: refresh its packed copies before use."""

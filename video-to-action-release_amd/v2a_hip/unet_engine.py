@@ -18,7 +18,7 @@ import torch
 from . import ops
 
 GN_SMALL_MAX = 16384
-_EMB_BATCH = os.environ.get("V2A_EMB_BATCH", "1") != "0"
+_EMB_BATCH = True       # all ResBlock embedding projections of a forward as one launch (v2a_emb_linear_multi)
 
 
 def build_program(cfg):
@@ -210,7 +210,7 @@ class UNetEngine:
         x4 = x.view(B * Fr, H, W, C)
         x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
         if (self.storage != "f32" and has_t and cout % 128 == 0 and C < 32 and k == 3 and stride == 1 and x2 is None and not ups
-                and not os.environ.get("V2A_STEM_F32")):
+                ):
             # stem (Cin = 6) in the bf16-storage configuration: input padded to one 32-channel chunk, so that the spatial conv runs on the
             # halo kernel (135 GFLOP of padded work at ~1 PFLOP/s instead of 25 GFLOP on the scalar-gather fp32 kernel at 33 TFLOP/s) and
             # its output is born bf16 (no cast launch in front of the temporal conv)
@@ -265,7 +265,7 @@ class UNetEngine:
         N, S = (B * Fr, H * W) if frames_separate else (B, Fr * H * W)
         x3 = x.view(N, S, C1)
         x23 = None if x2 is None else x2.view(N, S, -1)
-        if lazy and x.dtype in ops.HALF_DTYPES and ops._GN_FUSE:
+        if lazy and x.dtype in ops.HALF_DTYPES and ops.GN_FUSE[0]:
             pg = ops.groupnorm_prep_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
                                       stats=getattr(x, "_gn_stats", None), stats2=None if x2 is None else getattr(x2, "_gn_stats", None))
             return _LazyGN(pg, (B, Fr, H, W, C), frames_separate)

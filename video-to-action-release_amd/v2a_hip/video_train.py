@@ -165,7 +165,7 @@ class VideoTrainStep:
             slices = gradient_ready_slices(self.arena.names, numels)
             # a parameter re-ordering that loses the decoder / encoder split would silently lose the overlap: say how many slices there are
             self.n_gradient_slices = len(slices)
-            if len(slices) < 2 and os.environ.get("V2A_DP_QUIET") != "1":
+            if len(slices) < 2:
                 print(f"[v2a_hip.video_train] gradient_ready_slices found {len(slices)} slice(s): the decoder slice's early all-reduce is OFF",
                       file=sys.stderr)
             self.reducer = GradReducer(self.arena.flat, slices, process_group, self.world)
