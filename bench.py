@@ -220,11 +220,9 @@ def instrumented_pass(torch, trainer, steps):
         recs.append(("wgrad", (name, fl, (len(calls), 0, 0, 0, 0, -2)), e0, e1))
 
     ops.WgradBatch._launch_family = fam
-    g_saved, a_saved, e_saved, m_saved = trainer.use_graph, trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode
+    g_saved, e_saved = trainer.use_graph, trainer.eng.enc_streams
     trainer.use_graph = False
-    trainer.eng.async_wgrad = False          # measure every kernel alone on the main stream (the timed step overlaps the two
-    trainer.eng.enc_streams = False          # camera encoders as parallel graph branches)
-    trainer.eng._wg_mode = "0"
+    trainer.eng.enc_streams = False          # measure every kernel alone on the main stream (the timed step overlaps the two camera encoders)
     d_saved, trainer.eng.defer_unet_wgrad = trainer.eng.defer_unet_wgrad, False
     try:
         for _ in range(steps):
@@ -234,7 +232,7 @@ def instrumented_pass(torch, trainer, steps):
         ops.conv2d, ops.conv2d_wgrad = orig_fwd, orig_wg
         ops.WgradBatch._launch_family = orig_fam
         trainer.use_graph = g_saved
-        trainer.eng.async_wgrad, trainer.eng.enc_streams, trainer.eng._wg_mode = a_saved, e_saved, m_saved
+        trainer.eng.enc_streams = e_saved
         trainer.eng.defer_unet_wgrad = d_saved
     agg, shapes = {}, {}
     for kind, (name, fl, shape), e0, e1 in recs:

@@ -513,12 +513,11 @@ def test_conv2d_h2_multistage_kernel_matches_fp64_reference():
     wp = ops.pack_weight_h(w)
     y, st = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), x2=x2, rowvec=rowvec, rows_per_batch=H * W, residual=res, want_stats=True)
     assert ops.last_kernel[0].startswith("conv_igemm_h2") and st is not None
-    old = ops._H2
-    ops._H2 = False
+    ops.CONV_H2[0] = False           # test hook: the same layer on the 128 x 128 kernel
     try:
         y1 = ops.conv2d_h(x, wp, b, Co, 3, 3, (1, 1), (1, 1), x2=x2, rowvec=rowvec, rows_per_batch=H * W, residual=res)
     finally:
-        ops._H2 = old
+        ops.CONV_H2[0] = True
     d = (y.float() - y1.float()).abs()
     assert (d <= y1.float().abs() * 2.0 ** -7 + 1e-5).all() and (d > 0).float().mean().item() < 0.01
     # fp64 reference on a slab of rows (full conv on the host would take minutes): samples 0 and 4, all channels

@@ -734,8 +734,9 @@ __device__ __forceinline__ void split3_pair_h(float x0, float x1, uint32_t& h, u
     l = v2a_pack_bf16x2(s0, s1);
 }
 
-template <int BM, int BN, int WVM, int WVN, int MINW, bool GEN>
+template <int BM, int BN, int WVM, int WVN, int MINW, bool GEN, int PF = 2>
 __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const ConvDescH p) {
+    static_assert(PF == 2 || PF == 4, "register sets of k tiles in flight");
     constexpr int EPT = 32;
     constexpr int NT = 64 * WVM * WVN, RP = NT / 8;             // threads; tile rows one loader pass covers (8 float4 per 32-float row)
     constexpr int AL = BM / RP, BL = BN / RP;
@@ -934,29 +935,51 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
             }
     };
 
-    // ---- prologue: tile kt_begin staged, tile kt_begin + 1 requested
-    f32x4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
+    // ---- prologue: tile kt_begin staged, tiles kt_begin + 1 .. kt_begin + PF - 1 requested.  PF register sets of k tiles are in flight:
+    // these launches wait ~1 us for a k tile against ~0.2 us of MFMA work on it, and with two sets a workgroup had 32 KB in flight --
+    // 64 KB per CU at ~2 us of latency is the "8 TB/s load-path ceiling" the small-M GEMMs of the ConditionalUnet1D ran into (Little's
+    // law, not a bandwidth limit): four sets double it (PF = 4: the 64 x 64 tile, 64 staging VGPRs).
+    f32x4 ra0[AL], rb0[BL], ra1[AL], rb1[BL], ra2[PF == 4 ? AL : 1], rb2[PF == 4 ? BL : 1], ra3[PF == 4 ? AL : 1], rb3[PF == 4 ? BL : 1];
     load(ra0, rb0);
     load(ra1, rb1);
+    if constexpr (PF == 4) {
+        load(ra2, rb2);
+        load(ra3, rb3);
+    }
     split_store_a(ra0, smem);
     split_store_b(rb0, smem);
     __syncthreads();
-    // one k tile: `cur` registers hold tile kt + 1 (requested one iteration ago), tile kt + 2 is requested into `nxt`
+    // one k tile: `cur` registers hold tile kt + 1 (requested PF - 1 steps ago), tile kt + PF is requested into `nxt` (the set whose
+    // tile was split and stored one step ago)
     auto step = [&](f32x4 (&ra_c)[AL], f32x4 (&rb_c)[BL], f32x4 (&ra_n)[AL], f32x4 (&rb_n)[BL], int buf) {
         unsigned char* cur = smem + buf * STG;
         unsigned char* oth = smem + (buf ^ 1) * STG;
-        load(ra_n, rb_n);                                       // tile kt + 2 -> the register set consumed one step ago (1.5 steps of lead)
+        load(ra_n, rb_n);
         mfma6(cur, 0);
         split_store_a(ra_c, oth);                               // (VALU of the split runs under the MFMAs around it)
         mfma6(cur, 1);
         split_store_b(rb_c, oth);
         __syncthreads();
     };
-    // always in pairs (the register sets keep fixed roles at the loop header: no copies of in-flight load results); an odd slice
-    // multiplies one all-zero tile at the end
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
-        step(ra1, rb1, ra0, rb0, 0);
-        step(ra0, rb0, ra1, rb1, 1);
+    // the register sets keep fixed roles at the loop header (no copies of in-flight load results): the loop body is PF steps, left
+    // in the middle when the slice ends (a uniform forward branch; every wave has then passed that step's barrier after its last LDS
+    // access, the trailing register loads hit the zero line)
+    if constexpr (PF == 4) {
+        for (int kt = kt_begin; kt < kt_end; kt += 4) {
+            step(ra1, rb1, ra0, rb0, 0);
+            if (kt + 1 >= kt_end) break;
+            step(ra2, rb2, ra1, rb1, 1);
+            if (kt + 2 >= kt_end) break;
+            step(ra3, rb3, ra2, rb2, 0);
+            if (kt + 3 >= kt_end) break;
+            step(ra0, rb0, ra3, rb3, 1);
+        }
+    } else {
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            step(ra1, rb1, ra0, rb0, 0);
+            if (kt + 1 >= kt_end) break;
+            step(ra0, rb0, ra1, rb1, 1);
+        }
     }
     // (every wave passed the loop's last barrier after its last LDS access; the trailing register loads hit the zero line)
     static_assert(WVM * WVN * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
@@ -1259,6 +1282,8 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
 }
 
 static void f32_conv_mode_init();
+int g_x3_pf = 4;              // TEMPORARY A/B hook (v2a_tmp_x3_pf): register sets of the 64 x 64 three-plane tile
+extern "C" int v2a_tmp_x3_pf(int pf) { const int o = g_x3_pf; g_x3_pf = pf; return o; }
 static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact / v2a_set_f32_conv_mode(0) select the exact-f32 MFMA kernels
 // Tile / split plan shared by the LDS-DMA conv families.  128-row tiles (64 output columns for 64-wide layers); problems that 128-row
 // tiles cannot spread over the chip (< 128 tiles) take 64 x 64 tiles; K is split so that one round of about 512 workgroups covers the
@@ -1408,7 +1433,11 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, true>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);           \
         else hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, false>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);             \
     } while (0)
-            if (bm == 64) V2A_X3_LAUNCH(64, 64, 2, 2, tiles);
+            if (bm == 64 && g_x3_pf == 4) {
+                const dim3 grid_ = p.split_xcd > 0 ? dim3(tiles * s, 1) : dim3(tiles, s);
+                if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, 2, 2, true, 4>), grid_, dim3(256), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, 2, 2, false, 4>), grid_, dim3(256), 0, stream, p);
+            } else if (bm == 64) V2A_X3_LAUNCH(64, 64, 2, 2, tiles);
             else if (bn == 64) {
                 const int t256 = cdiv(p.M, 256) * cdiv(Cout, 64);
                 if (t256 >= 200 && p.M % 256 == 0 && p.frame_tiles == 0) V2A_X3_LAUNCH(256, 64, 4, 2, t256);

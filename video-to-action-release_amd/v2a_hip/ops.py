@@ -591,6 +591,7 @@ def cast_f(x: torch.Tensor) -> torch.Tensor:
 # default ones; not configuration): GroupNorm folded into the halo conv's loader, the halo / frame-stack conv kernels themselves
 GN_FUSE = [True]
 CONV_H3 = [True]
+CONV_H2 = [True]       # the multi-stage 256-row kernel (csrc/igemm_h2.hip)
 _GN_FUSE_MAX_REPEAT = 2
 
 
@@ -695,7 +696,7 @@ def conv2d_h(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None
                                     _zero_line(x.device).data_ptr(), N, H, W, C1, Cout, rows_per_batch, _p(stats), _stream()), "conv2d_fwd_t3")
         last_kernel[0] = "conv_frames_h3<448x128>"
         return (y, stats) if want_stats else y
-    if (idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES
+    if (CONV_H2[0] and idil == 1 and not out_f32 and res_f is None and y.dtype in HALF_DTYPES
             and lib.v2a_conv2d_h2_eligible(M, Cout, K, C1, C2)):
         # large layer: the multi-stage 256-row kernel (csrc/igemm_h2.hip)
         stats = torch.empty(((M + 63) // 64, 2, Cout), dtype=torch.float32, device=x.device) if (want_stats and _FUSED_STATS) else None

@@ -142,6 +142,7 @@ class PolicyEngine:
         self._convs = {}
         # the two camera encoders (separate weights, no shared state) run as parallel branches of the step graph: +17 % steps/s
         # at B=64 (their small-grid kernels fill each other's idle CUs); their weight gradients stay on their chain's stream
+        self.enc_streams = True    # (bench.py's instrumented pass sets False: every kernel alone on one stream)
         self._enc_side = []
         self._in_enc = False
         self._cur_batch = 0
@@ -1011,7 +1012,7 @@ class PolicyEngine:
     def _enc_parallel(self, fns):
         """Run the per-camera encoder chains (independent: separate weights, no shared state) as parallel branches: the first on
         the current stream, the others on side streams with their own scratch lanes; joined before returning."""
-        if len(fns) < 2 or self._cur_batch < 8:      # B = 1 rollouts: fork / join costs more than it hides
+        if not self.enc_streams or len(fns) < 2 or self._cur_batch < 8:      # B = 1 rollouts: fork / join costs more than it hides
             return [f() for f in fns]
         main = torch.cuda.current_stream()
         while len(self._enc_side) < len(fns) - 1:
