@@ -222,6 +222,19 @@ int v2a_video_loss_bwd(const float* out_cl, const float* img, const float* noise
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_philox_randint(int64_t* out, int n, int high, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, v2a_stream_t s);
 int v2a_advance_counter(uint64_t* ctr, uint64_t inc, v2a_stream_t s);
+/* fp32 convs over PRE-SPLIT operands (round 5): x3 / x2_3 / w3 point at the hi plane of three bf16 planes (hi = bf16(v), mid = bf16(v - hi),
+ * lo = bf16(v - hi - mid); `*_plane_stride` elements apart) of x [N,H,W,C1] / x2 [N,H,W,C2] / the packed weight [Cout][KH][KW][C1+C2].  The
+ * arithmetic, split plan, workspace (v2a_conv2d_dma_f32_workspace_bytes) and results -- bit for bit -- of v2a_conv2d_fwd_dma_f32_d in its
+ * three-plane mode, without the per-tile re-splitting: the ConditionalUnet1D's small-M / deep-K Conv1d GEMMs
+ * (diffuser/diffusion_policy/model/conditional_unet1d.py:46-66, conv1d_components.py:23-40).  Planes are written by v2a_groupnorm_fwd_s /
+ * _bwd_s (yh_plane_stride), v2a_opt_step_packed (twin format 2), v2a_pack_weights_multi (mode | 256) and v2a_split3_f32.  nslab_out as
+ * v2a_conv2d_fwd_dma_f32_d (null: the reduce launch runs inside).  Stateless; thread-safe for distinct streams and workspaces. */
+int v2a_conv2d_p3_eligible(int M, int Cout, int K, int C1, int C2);
+int v2a_conv2d_fwd_p3(const void* x3, size_t x_plane_stride, const void* x2_3, size_t x2_plane_stride, const void* w3, size_t w_plane_stride,
+                      const float* bias, const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
+                      int KH, int KW, int sh, int sw, int ph, int pw, int OH, int OW, int* nslab_out, void* workspace, size_t workspace_bytes,
+                      v2a_stream_t stream);
+int v2a_split3_f32(const float* x, void* y3, size_t n, size_t plane_stride, v2a_stream_t stream);   /* fp32 [n] -> three bf16 planes (n % 4 == 0) */
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
 int v2a_get_f32_conv_mode(void);
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */

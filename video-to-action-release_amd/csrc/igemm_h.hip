@@ -68,6 +68,7 @@ struct ConvDescH {
     int frame_tiles;          // > 0: frame-interleaved tile order for (3 x 1) convs, = tiles per frame (OW / BM); 0: row order
     FastDivH fd_ow, fd_oh;
     int split_xcd;            // > 0: 1-D grid, split-K slices pinned to XCDs (slices per XCD)              [conv_igemm_f32x3 only]
+    size_t xps, x2ps, wps;    // conv_p3 (pre-split operands): elements between the hi / mid / lo bf16 planes of x, x2, w
     int xp1;                  // element pitch between consecutive pixels of source 1 (= C1; < C1: overlapping channel windows,
                               // v2a_conv2d_fwd_window_f32)                                      [conv_igemm_f32x3, non-GEN path only]
 };
@@ -986,6 +987,198 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, bias_sel);
 }
 
+// ---- three-plane conv over PRE-SPLIT operands (round 5).  conv_igemm_f32x3<64, 64> on the ConditionalUnet1D's small-M /
+// deep-K GEMMs (M <= 1024 rows, K up to 10 240) spends a k tile's time on splitting: every one of the Cout / 64 column tiles splits the
+// same A rows again and every one of the M / 64 row tiles the same weights (per k tile and wave ~108 VALU + 6 ds_write2st64_b64 against
+// 12 MFMAs; the LDS store path and the conversion VALU, not the matrix pipe or the loads, set its ~0.9 us per k tile --
+// tools/probes/r5/ab_hook_probe.py: four register sets of k tiles in flight instead of two changed nothing).  Here the operands ARRIVE
+// split: x / x2 / w point at three bf16 planes (hi, mid, lo; `xps` / `x2ps` / `wps` elements apart) written once by the launches that
+// produce them -- the GroupNorm kernels for activations and gradients (v2a_groupnorm_fwd_s / _bwd_s, yh_plane_stride), the optimiser's
+// update kernel and the transposing pack launch for the weights -- and both operands move HBM / L2 -> LDS by LDS-DMA (no staging VGPRs,
+// no conversion, no ds_write): per k tile and thread six 16-B pieces.  Same tile, same LDS image (64-B plane rows, 16-B chunk swizzle
+// p ^ ((row >> 2) & 3), applied on the source side), same six plane products in the same order, same split plan and epilogue as
+// conv_igemm_f32x3<64, 64>: results are BIT-IDENTICAL to it (tests/test_ops_gpu.py).  S LDS stages of 24 KB with counted vmcnt + one raw
+// barrier per k tile (conv_igemm_f32p's scheme); pieces past the slice's end read the zero line.
+template <int BM, int BN, int S, int WVM = 2, int WVN = 2>
+__global__ __launch_bounds__(64 * WVM * WVN, (S * 3 * (BM + BN) * 64 <= 53 * 1024) ? 3 : ((S * 3 * (BM + BN) * 64 <= 80 * 1024) ? 2 : 1)) void conv_p3(const ConvDescH p) {
+    constexpr int EPT = 32, ROWH = 64;
+    constexpr int NT = 64 * WVM * WVN, RP = NT / 4;                    // threads; rows of a plane image one pass of the threads fills (4 chunks per row)
+    constexpr int AL = BM / RP, BL = BN / RP, NL = 3 * (AL + BL);      // DMA pieces per thread and k tile
+    static_assert(AL >= 1 && BL >= 1, "tile rows per pass");
+    constexpr int WM = BM / WVM, WN = BN / WVN, TM = WM / 32, TN = WN / 32;  // WVM x WVN waves, each TM x TN accumulators of 32 x 32
+    constexpr int PA = BM * ROWH, PB = BN * ROWH, STG = 3 * (PA + PB), STAGE = STG;
+    static_assert(S >= 2 && (S - 2) * NL <= 63, "vmcnt is a 6-bit counter");
+    static_assert(S * STG <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(128))) unsigned char smem[S * STG];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    int lin, split;
+    if (p.split_xcd > 0) {                                      // split-K slices pinned to XCDs (see conv_igemm_f32x3)
+        const int L = (int)blockIdx.x, xcd = L & 7, slot = L >> 3, tiles = tiles_m * tiles_n;
+        const int sl = slot / tiles;
+        split = xcd * p.split_xcd + sl;
+        lin = slot - sl * tiles;
+    } else {
+        lin = xcd_remap_h(blockIdx.x, tiles_m * tiles_n);
+        split = blockIdx.y;
+    }
+    const int tm = lin / tiles_n;
+    const int n0 = (lin % tiles_n) * BN, m0 = tm * BM;
+    const int Cin = p.C1 + p.C2;
+    const int nkt = p.K / EPT;
+    const int kt_begin = split * p.ktiles_per_split;
+    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    typedef unsigned short hT;
+    const hT* xs = reinterpret_cast<const hT*>(p.x);
+    const hT* x2s = reinterpret_cast<const hT*>(p.x2);
+    const hT* ws = reinterpret_cast<const hT*>(p.w);
+    const hT* zsrc = reinterpret_cast<const hT*>(p.zeros);
+
+    // DMA source state: pass j of the 256 threads fills rows 64 j .. 64 j + 63 of a plane image; this thread's piece is (row 64 j + tid / 4,
+    // position tid % 4) and carries the row's 16-B chunk (tid % 4) ^ ((row >> 2) & 3) -- 8 bf16 of the 32-element k tile -- for every j
+    const int lrow = tid >> 2;
+    const int chunk = (tid & 3) ^ ((lrow >> 2) & 3);
+    int a_ihb[AL], a_iwb[AL], a_lin1[AL], a_lin2[AL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int m = m0 + j * RP + lrow;
+        const bool ok = m < p.M;
+        const uint32_t mm = ok ? (uint32_t)m : 0u;
+        const uint32_t t = fdivh(mm, p.fd_ow);
+        const int ow = (int)(mm - t * p.OW);
+        const uint32_t img = fdivh(t, p.fd_oh);
+        const int oh = (int)(t - img * p.OH);
+        a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);          // rows past M fail the bounds test below
+        a_iwb[j] = ow * p.sw - p.pw;
+        const int pix = ((int)img * p.H + a_ihb[j]) * p.W + a_iwb[j];
+        a_lin1[j] = pix * p.C1 + chunk * 8;
+        a_lin2[j] = pix * p.C2 + chunk * 8;
+    }
+    bool b_ok[BL];
+    size_t b_row[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        const int n = n0 + j * RP + lrow;
+        b_ok[j] = n < p.Cout;
+        b_row[j] = (size_t)(b_ok[j] ? n : 0) * p.K + chunk * 8;
+    }
+    int ik0 = kt_begin * EPT;
+    int itap = ik0 / Cin;
+    int ic0 = ik0 - itap * Cin;
+    int ikh = itap / p.KW, ikw = itap - ikh * p.KW;
+    int it = kt_begin;
+
+    // pieces [q0, q1) of the pending k tile go to stage `buf`: piece = (plane, pass); first the 3 AL pieces of A, then the 3 BL of B
+    auto issue = [&](int buf, int q0, int q1) {
+        unsigned char* abase = smem + buf * STG + wid * 1024;
+        const bool live = it < kt_end;
+        const bool first = ic0 < p.C1;
+        const hT* src = first ? xs : x2s;
+        const size_t ps = first ? p.xps : p.x2ps;
+        const int s_tap = (ikh * p.W + ikw) * (first ? p.C1 : p.C2) + (first ? ic0 : ic0 - p.C1);
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+            if (q < 3 * AL) {
+                const int pl = q / AL, j = q % AL;
+                const int ih = a_ihb[j] + ikh, iw = a_iwb[j] + ikw;
+                const bool aok = live & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+                uint32_t aoff = (uint32_t)((first ? a_lin1[j] : a_lin2[j]) + s_tap);
+                asm volatile("" : "+v"(aoff));                  // keep the offset arithmetic out of an exec-masked region (plain select below)
+                const hT* g = src + (size_t)pl * ps + aoff;
+                g = aok ? g : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + pl * PA + j * RP * 64), 16, 0, 0);
+            } else {
+                const int pl = (q - 3 * AL) / BL, j = (q - 3 * AL) % BL;
+                uint64_t gi;
+                if (p.wps == 0)      // TILED weight planes: [Cout / BN][K / 32][plane][BN rows x 64 B, chunk-swizzled]: a k tile's plane image is one contiguous block
+                    gi = (uint64_t)(reinterpret_cast<const unsigned char*>(ws) + (((size_t)(n0 / BN) * nkt + it) * 3 + pl) * PB + j * RP * 64 + tid * 16);
+                else
+                    gi = (uint64_t)(ws + (size_t)pl * p.wps + b_row[j] + ik0);
+                asm volatile("" : "+v"(gi));
+                const hT* g = (live & b_ok[j]) ? reinterpret_cast<const hT*>(gi) : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + 3 * PA + pl * PB + j * RP * 64), 16, 0, 0);
+            }
+        }
+    };
+    auto advance = [&]() {
+        ++it;
+        ik0 += EPT;
+        ic0 += EPT;
+        const bool wrap = ic0 >= Cin;
+        ic0 = wrap ? 0 : ic0;
+        const int kw1 = ikw + (wrap ? 1 : 0);
+        const bool wrap2 = kw1 == p.KW;
+        ikw = wrap2 ? 0 : kw1;
+        ikh += wrap2 ? 1 : 0;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wid / WVN) * WM, wn = (wid % WVN) * WN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int rswz = (lr >> 2) & 3;
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_off[i] = (wm + i * 32 + lr) * ROWH;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_off[j] = 3 * PA + (wn + j * 32 + lr) * ROWH;
+    int pos[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pos[h] = (((h << 1) | lk) ^ rswz) << 4;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+    // one k half: every fragment first, then the six plane products of each accumulator (smallest first), the accumulators' dependent
+    // chains interleaved (a dependent MFMA waits 16 passes for its predecessor)
+    auto mfma6 = [&](const unsigned char* base, int h) {
+        bfx8 a[3][TM], b[3][TN];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const bfx8*>(base + q * PA + a_off[i] + pos[h]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[q][j] = *reinterpret_cast<const bfx8*>(base + q * PB + b_off[j] + pos[h]);
+        }
+        constexpr int PQ[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};      // (A plane, B plane): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PQ[t][0]][i], b[PQ[t][1]][j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: S - 1 k tiles in flight
+#pragma unroll
+    for (int s_ = 0; s_ < S - 1; ++s_) {
+        issue(s_, 0, NL);
+        advance();
+    }
+    int cbuf = 0, ibuf = S - 1;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        wait_vmcnt_h<(S - 2) * NL>();                           // this wave's pieces of tile kt have landed; younger tiles stay in flight
+        __builtin_amdgcn_s_barrier();                           // ... everyone's have, and everyone is done reading the stage issued into next
+        const unsigned char* base = smem + cbuf * STG;
+        issue(ibuf, 0, NL / 2);
+        mfma6(base, 0);
+        issue(ibuf, NL / 2, NL);
+        mfma6(base, 1);
+        advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's operand reads are done before it reaches the next barrier
+        cbuf = (cbuf + 1 == S) ? 0 : cbuf + 1;
+        ibuf = (ibuf + 1 == S) ? 0 : ibuf + 1;
+    }
+    wait_vmcnt_h<0>();                                          // the zero-line pieces past the end still land in the stages
+    __syncthreads();
+    static_assert(WVM * WVN * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
+    conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, p.bias);
+}
+
 // ---- three-plane 3x3 / stride 1 / pad 1 conv with a spatial halo tile in LDS (round 4): the forward / data-gradient counterpart of
 // csrc/igemm.hip wgrad_x3h_body, for the square maps of the policy's ResNet-18 encoders (32 x 32, 16 x 16, 8 x 8, 4 x 4).
 // conv_igemm_f32x3 gathers and splits the A tile once per filter tap and column tile: nine loads and nine fp32 -> plane conversions of
@@ -1242,6 +1435,17 @@ __global__ void pack_weight_h_kernel(const float* __restrict__ w, uint16_t* __re
     }
 }
 
+__global__ void split3_f32_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n4, size_t ps) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3_pair_h(v[0], v[1], h0, m0, l0);
+        split3_pair_h(v[2], v[3], h1, m1, l1);
+        *reinterpret_cast<uint2*>(y + 4 * i) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(y + ps + 4 * i) = uint2{m0, m1};
+        *reinterpret_cast<uint2*>(y + 2 * ps + 4 * i) = uint2{l0, l1};
+    }
+}
 template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -1588,6 +1792,92 @@ int v2a_conv2d_fwd_dma_f32_d(const float* x, const float* x2, const float* w_pac
     if (!y || !nslab_out) return V2A_ERR_ARG;
     return conv_dma_launch<float>(x, x2, w_packed, bias, rowvec, residual, nullptr, y, nullptr, zeros, N, H, W, C1, C2, Cout, KH, KW, sh, sw,
                                   ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes, stream, nslab_out);
+}
+
+static int g_p3_bm = 0, g_p3_bn = 0, g_p3_s = 1, g_p3_st = 3;
+int v2a_tmp_p3_plan(int bm, int bn, int s, int stages) { g_p3_bm = bm; g_p3_bn = bn; g_p3_s = s < 1 ? 1 : s; g_p3_st = stages; return 0; }
+// 1 when v2a_conv2d_fwd_p3 takes this problem: channel counts in 32N and a plan on 64 x 64 tiles (the small-M GEMMs the kernel is for)
+int v2a_conv2d_p3_eligible(int M, int Cout, int K, int C1, int C2) {
+    if (M <= 0 || Cout <= 0 || C1 <= 0 || C1 % 32 || C2 < 0 || C2 % 32 || K % 32) return 0;
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);
+    return bm == 64 ? 1 : 0;
+}
+// fp32 conv (three-plane products, the arithmetic of v2a_conv2d_fwd_dma_f32 in its default mode) whose operands are ALREADY split into
+// bf16 planes: x3 / x2_3 / w3 point at the hi plane of x [N,H,W,C1] / x2 [N,H,W,C2] / the packed weight [Cout][KH][KW][C1+C2]; the mid
+// and lo planes follow `*_plane_stride` ELEMENTS apart.  Who writes them: v2a_groupnorm_fwd_s / _bwd_s (yh_plane_stride), the
+// optimiser's update kernel (v2a_opt_step_packed, twin format 2), v2a_pack_weights_multi (mode bit 8), v2a_split3_f32.  Same split plan,
+// workspace (v2a_conv2d_dma_f32_workspace_bytes) and results -- bit for bit -- as v2a_conv2d_fwd_dma_f32_d on the unsplit tensors;
+// nslab_out as there (null: the reduce launch runs here).  Only where v2a_conv2d_p3_eligible says 1; stride >= 1, no upsample / dilation.
+int v2a_conv2d_fwd_p3(const void* x3, size_t x_plane_stride, const void* x2_3, size_t x2_plane_stride, const void* w3, size_t w_plane_stride,
+                      const float* bias, const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout,
+                      int KH, int KW, int sh, int sw, int ph, int pw, int OH, int OW, int* nslab_out, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream) {
+    if (nslab_out) *nslab_out = 0;
+    if (!x3 || !w3 || !y || !zeros || N <= 0 || (C2 > 0 && !x2_3) || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0) return V2A_ERR_ARG;
+    const int M = N * OH * OW, K = KH * KW * (C1 + C2);
+    if (!v2a_conv2d_p3_eligible(M, Cout, K, C1, C2)) return V2A_ERR_ARG;
+    if ((((uintptr_t)x3 | (uintptr_t)x2_3 | (uintptr_t)w3 | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual) & 15) != 0) return V2A_ERR_ARG;
+    if (((x_plane_stride | x2_plane_stride | w_plane_stride) & 7) != 0) return V2A_ERR_ARG;      // planes 16-B aligned
+    if (w_plane_stride == 0 && Cout % 128 != 0) return V2A_ERR_ARG;
+    if ((double)N * H * W * (C1 > C2 ? C1 : C2) >= 2147483648.0) return V2A_ERR_ARG;
+    ConvDescH p = {};
+    p.x = x3; p.x2 = x2_3; p.w = w3; p.xps = x_plane_stride; p.x2ps = x2_plane_stride; p.wps = w_plane_stride;
+    p.bias = bias; p.residual = residual; p.y = y; p.partial = (float*)workspace; p.zeros = zeros;
+    p.N = N; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.OH = OH; p.OW = OW; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.sh = sh; p.sw = sw; p.ph = ph; p.pw = pw; p.idil = 1;
+    p.HL = H; p.WL = W; p.M = M; p.K = K; p.rows_per_batch = 1;
+    p.fd_ow = make_fastdiv_h((uint32_t)OW);
+    p.fd_oh = make_fastdiv_h((uint32_t)OH);
+    p.xp1 = C1;
+    int bm, bn, tiles, s;
+    conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);
+    if (g_p3_bm) {                                   // TEMPORARY (v2a_tmp_p3_plan): forced tile / split / stages for the tile-shape A/B
+        bm = g_p3_bm; bn = g_p3_bn;
+        tiles = cdiv(M, bm) * cdiv(Cout, bn);
+        s = g_p3_s;
+        const int nkt = K / 32;
+        if (s > nkt) s = nkt;
+        s = cdiv(nkt, cdiv(nkt, s));
+    }
+    if (s > 1 && (size_t)s * M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    p.splitk = s;
+    p.ktiles_per_split = cdiv(K / 32, s);
+    p.split_xcd = (s >= 8 && s % 8 == 0) ? s / 8 : 0;
+    const dim3 grid = p.split_xcd > 0 ? dim3(tiles * s, 1) : dim3(tiles, s);
+    const int st = g_p3_bm ? g_p3_st : 3;
+    if (bm == 128 && bn == 128 && st == 8) hipLaunchKernelGGL((conv_p3<128, 128, 3, 2, 4>), grid, dim3(512), 0, stream, p);      // eight waves
+    else if (bm == 256 && bn == 128 && st == 8) hipLaunchKernelGGL((conv_p3<256, 128, 2, 4, 2>), grid, dim3(512), 0, stream, p);
+    else if (bm == 64 && bn == 64 && st == 2) hipLaunchKernelGGL((conv_p3<64, 64, 2>), grid, dim3(256), 0, stream, p);           // three workgroups per CU
+    else if (bm == 64 && bn == 64 && st == 3) hipLaunchKernelGGL((conv_p3<64, 64, 3>), grid, dim3(256), 0, stream, p);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_p3<64, 64, 6>), grid, dim3(256), 0, stream, p);
+    else if (bm == 128 && bn == 64 && st == 3) hipLaunchKernelGGL((conv_p3<128, 64, 3>), grid, dim3(256), 0, stream, p);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_p3<128, 64, 4>), grid, dim3(256), 0, stream, p);
+    else if (bm == 64 && bn == 128 && st == 3) hipLaunchKernelGGL((conv_p3<64, 128, 3>), grid, dim3(256), 0, stream, p);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_p3<64, 128, 4>), grid, dim3(256), 0, stream, p);
+    else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_p3<128, 128, 3>), grid, dim3(256), 0, stream, p);
+    else return V2A_ERR_ARG;
+    V2A_CHECK_LAUNCH();
+    if (s > 1) {
+        if (nslab_out) { *nslab_out = s; return V2A_OK; }
+        const size_t total = (size_t)M * Cout;
+        int g = (int)((total + 255) / 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce_h<float>, dim3(g), dim3(256), 0, stream, p);
+        V2A_CHECK_LAUNCH();
+    }
+    return V2A_OK;
+}
+// x fp32 [n] -> three bf16 planes hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) at y3, y3 + plane_stride, y3 + 2 plane_stride
+// (elements): the operand format of v2a_conv2d_fwd_p3, for tensors no fused producer writes (n % 4 == 0, 16-B / 8-B aligned)
+int v2a_split3_f32(const float* x, void* y3, size_t n, size_t plane_stride, hipStream_t stream) {
+    if (!x || !y3 || n % 4 || plane_stride < n || (plane_stride & 3) || (((uintptr_t)x & 15) | ((uintptr_t)y3 & 7))) return V2A_ERR_ARG;
+    if (n == 0) return V2A_OK;
+    int g = (int)((n / 4 + 255) / 256);
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(split3_f32_kernel, dim3(g), dim3(256), 0, stream, x, (uint16_t*)y3, n / 4, plane_stride);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
 }
 
 // torch-layout fp32 weight [Cout][Cin][taps] -> bf16 [Cout][taps][Cin]

@@ -98,6 +98,9 @@ SIGNATURES = {
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
     "v2a_advance_counter": (I, [P, U64, P]),
     "v2a_debug_timestamp": (I, [P, P]),
+    "v2a_conv2d_p3_eligible": (I, [I, I, I, I, I]),
+    "v2a_conv2d_fwd_p3": (I, [P, SZ, P, SZ, P, SZ, P, P, P, P] + [I] * 14 + [P, P, SZ, P]),
+    "v2a_split3_f32": (I, [P, P, SZ, SZ, P]),
     "v2a_set_f32_conv_mode": (I, [I]),
     "v2a_get_f32_conv_mode": (I, []),
     "v2a_attention_fwd": (I, [P, P, I, I, I, I, P]),

@@ -272,6 +272,48 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     return y
 
 
+def split3(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """fp32 tensor -> its three bf16 planes [3, *x.shape] (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)): the operand format
+    of conv2d_p3, for tensors no fused producer (GroupNorm launch, optimiser update kernel, pack launch) writes."""
+    _chk(x, "x")
+    if out is None:
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    check(lib.v2a_split3_f32(x.data_ptr(), out.data_ptr(), x.numel(), x.numel(), _stream()), "split3_f32")
+    return out
+
+
+def p3_eligible(M, Cout, K, C1, C2=0):
+    return bool(lib.v2a_conv2d_p3_eligible(M, Cout, K, C1, C2))
+
+
+def conv2d_p3(x3, w3, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2_3=None, residual=None, y=None, defer=False):
+    """fp32 conv over PRE-SPLIT operands (csrc/igemm_h.hip conv_p3): x3 [3, N, H, W, C1] / x2_3 [3, N, H, W, C2] / w3 [3, Cout * K] bf16
+    planes.  Bit-identical to conv2d(x, w, ...) on the unsplit tensors in the three-plane mode (same plan, same slabs).  defer: returns
+    (y, Slabs | None) like conv2d."""
+    assert x3.dtype == torch.bfloat16 and x3.is_contiguous() and x3.shape[0] == 3 and w3.dtype == torch.bfloat16 and w3.is_contiguous()
+    _, N, H, W, C1 = x3.shape
+    C2 = 0 if x2_3 is None else x2_3.shape[-1]
+    sh, sw = stride
+    ph, pw = pad
+    OH = (H + 2 * ph - KH) // sh + 1
+    OW = (W + 2 * pw - KW) // sw + 1
+    M, K = N * OH * OW, KH * KW * (C1 + C2)
+    assert w3.numel() == 3 * Cout * K
+    if y is None:
+        y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x3.device)
+    wsb = lib.v2a_conv2d_dma_f32_workspace_bytes(M, Cout, K)
+    ws = workspace(wsb, x3.device) if wsb else None
+    import ctypes
+    ns = ctypes.c_int(0)
+    last_kernel[0] = "conv_p3<64,64>"
+    check(lib.v2a_conv2d_fwd_p3(x3.data_ptr(), x3.numel() // 3, _p(x2_3), 0 if x2_3 is None else x2_3.numel() // 3, w3.data_ptr(), w3.numel() // 3,
+                                _p(bias), _p(residual), y.data_ptr(), _zero_line(x3.device).data_ptr(), N, H, W, C1, C2, Cout, KH, KW, sh, sw,
+                                ph, pw, OH, OW, ctypes.byref(ns) if defer else None, _p(ws), wsb, _stream()), "conv2d_fwd_p3")
+    if defer:
+        return y, (Slabs(ws, ns.value, M * Cout, bias, residual) if ns.value > 0 else None)
+    return y
+
+
 class WgradCollector:
     """Weight gradients whose split-K reduce is postponed: every layer keeps its slabs in a scratch buffer of its own (owned here,
     keyed by the gradient's address) and ONE multi-tensor launch (`flush`) finishes all of them -- 40-55 reduce launches per train
