@@ -72,7 +72,9 @@ int v2a_conv2d_wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* split);
 int v2a_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int mode, v2a_stream_t stream);
 /* every pack of a model in two launches: table_dev int64 [n][7] = {src, dst fp32 or 0, Cout, Cin, taps, mode, dst bf16 or 0};
  * transposed 0: mode-0 rows, chunks_dev int32 {operand, start} of v2a_pack_chunk_elems() elements; transposed 1: mode-1 rows
- * (data-gradient operand = tap-reversed transpose), chunks_dev {operand, 64x64 tile index over [Cout x Cin*taps]} */
+ * (data-gradient operand = tap-reversed transpose), chunks_dev {operand, 64x64 tile index over [Cout x Cin*taps]}.
+ * mode | 256: the 16-bit destination is the hi plane of THREE bf16 planes (hi, mid, lo of the fp32 value; Cout * Cin * taps elements apart)
+ * instead of one twin: the pre-split weight operand of v2a_conv2d_fwd_p3 */
 int v2a_pack_chunk_elems(void);
 int v2a_pack_weights_multi(const int64_t* table_dev, const int* chunks_dev, int nchunks, int transposed, v2a_stream_t stream);
 
@@ -116,13 +118,16 @@ int v2a_groupnorm_takes_slabs(int S, int C, int G);
    self.residual_conv(x)`) without an add / reduce launch of its own.  Only where v2a_groupnorm_takes_post says 1 (slabs of 256 / 512 /
    1024 elements, 16 ... 128 channels per group); V2A_ERR_ARG otherwise.  All null / 0: no addend. */
 int v2a_groupnorm_takes_post(int S, int C, int G);
+/* yh_plane_stride (both functions): 0 = y_h / dx_h is ONE 16-bit twin of the output in the policy's 16-bit format; > 0 = it is the hi plane of
+   THREE bf16 planes (hi, mid, lo of the fp32 value, that many elements apart): the pre-split operand of v2a_conv2d_fwd_p3 for the conv that
+   consumes this output.  Planes only on the float4 wave path (v2a_groupnorm_takes_post's shapes); V2A_ERR_ARG otherwise. */
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
-                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
-                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
+                        const float* film, int film_ld, float* y, void* y_h, size_t yh_plane_stride, float* mean, float* rstd, int N, int S, int C,
+                        int G, float eps, int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
                         const float* post_slabs, int post_nslab, size_t post_stride, const float* post_bias,
                         void* workspace, size_t workspace_bytes, v2a_stream_t s);
 int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
-                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, size_t yh_plane_stride, float* dres, float* dfilm,
                         float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
                         void* workspace, size_t workspace_bytes, v2a_stream_t s);
@@ -385,9 +390,10 @@ int v2a_opt_state_scaler(const void* host_state, float* loss_scale, int* growth_
 size_t v2a_opt_state_loss_scale_offset(void);
 int v2a_opt_step(const int64_t* table_dev, const int* chunks_dev, int nchunks, void* state_dev, double* partial_dev, int zero_grad, v2a_stream_t s);
 /* same, and the update kernel also writes the conv operand packs of the updated parameters (packs_dev: [tensors][6] int64 = {forward pack
-   [Cout][taps][Cin] or 0, Cin, taps, channel-window pack (v2a_conv2d_fwd_window_f32) or 0, 16-bit twin of the forward pack or 0, 1 if that
-   twin is IEEE fp16}; the launch of v2a_pack_weights_multi that would
-   read every parameter again is not needed for those operands) */
+   [Cout][taps][Cin] or 0, Cin, taps, channel-window pack (v2a_conv2d_fwd_window_f32) or 0, 16-bit side copy of the forward pack or 0, its
+   format: 0 bf16 twin, 1 IEEE fp16 twin, 2 = three bf16 planes hi / mid / lo of the fp32 value, the tensor's element count apart
+   (v2a_conv2d_fwd_p3's weight operand)}; the launch of v2a_pack_weights_multi that would read every parameter again is not needed for
+   those operands) */
    presum_first / presum_count: chunks [first, first + count) of partial_dev already hold this step's sums of squares (written by
    v2a_opt_presum with the same range on a stream ordered before this call); 0 / 0: every chunk is summed here.  Explicit operands: nothing
    is remembered between the two calls. */

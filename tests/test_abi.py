@@ -63,8 +63,12 @@ def test_argument_validation_returns_error_codes_without_touching_the_device():
     assert lib.v2a_opt_presum(None, None, 0, 0, None, None) == ERR_ARG
     assert lib.v2a_groupnorm_takes_post(16, 256, 8) in (0, 1)
     # round 5: the post-activation addend of a GroupNorm launch is an explicit operand set of v2a_groupnorm_fwd_s (slabs without a count: rejected)
-    assert lib.v2a_groupnorm_fwd_s(None, None, 0, None, None, None, None, 0, None, None, None, None, 1, 16, 64, 8, 1e-5, 0, None, 0, 0, None,
+    assert lib.v2a_groupnorm_fwd_s(None, None, 0, None, None, None, None, 0, None, None, 0, None, None, 1, 16, 64, 8, 1e-5, 0, None, 0, 0, None,
                                    None, None, 3, 0, None, None, 0, None) == ERR_ARG
+    # pre-split three-plane conv: null operands / a shape its 64 x 64 plan does not take
+    assert lib.v2a_conv2d_fwd_p3(None, 0, None, 0, None, 0, None, None, None, None, 64, 1, 4, 1024, 0, 1024, 1, 5, 1, 1, 0, 2, 1, 4, None, None, 0, None) == ERR_ARG
+    assert lib.v2a_conv2d_p3_eligible(256, 1024, 5120, 1024, 0) == 1 and lib.v2a_conv2d_p3_eligible(65536, 64, 576, 64, 0) == 0
+    assert lib.v2a_conv2d_p3_eligible(256, 1024, 35, 7, 0) == 0 and lib.v2a_split3_f32(None, None, 8, 8, None) == ERR_ARG
     # host-side sizing of the split slabs / partials
     assert lib.v2a_conv2d_wgrad_workspace_bytes(65536, 64, 576) > 0
     assert lib.v2a_conv2d_wgrad_h_workspace_bytes(229376, 128, 1152) >= 128 * 1152 * 4 * 2

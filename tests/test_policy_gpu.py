@@ -297,6 +297,47 @@ def test_presummed_gradient_norm_is_stateless_and_bit_equal(use_graph):
     assert any(not torch.equal(a, b) for a, b in zip(runs[0][0], runs[0][1]))      # (the replica does lag the parameters)
 
 
+@pytest.mark.parametrize("B", [64, 3])
+def test_presplit_operand_convs_equal_the_register_split_path_bitwise(B):
+    """Round 5: in the fp32 three-plane mode the ConditionalUnet1D's GroupNorm launches also write the hi / mid / lo
+    bf16 planes of their outputs, the optimiser / pack launches the planes of the weights, and the convs between them run on the pure
+    LDS-DMA kernel conv_p3 (no per-tile re-splitting).  Same planes, same tile, same split plan, same product order: loss and EVERY
+    gradient must be BIT-EQUAL to the run on the register-splitting kernels (engine.use_p3 = False), forward-only inference included,
+    and the new kernel must actually have run."""
+    from v2a_hip import ops
+    pol, sd = _policy(seed=5)
+    eng = pol.engine
+    assert eng.use_p3 is False          # default off: measured slower in the step (6 B per weight element from HBM instead of 4), see policy_engine.py
+    names = pol.trainable_names()
+    g = torch.Generator().manual_seed(300 + B)
+    imgs = {k: torch.rand(B, 3, 128, 128, generator=g).cuda() for k in ("img_obs_1", "img_goal_1")}
+    act = (torch.rand(B, 16, 7, generator=g) * 2 - 1).cuda()
+    noise, ts = torch.randn(B, 16, 7, generator=g).cuda(), torch.randint(0, 100, (B,), generator=g).cuda()
+    seen = []
+    orig = ops.conv2d_p3
+
+    def spy(*a, **k):
+        seen.append(1)
+        return orig(*a, **k)
+    out = {}
+    for use in (True, False):
+        eng.use_p3 = use
+        eng.refresh_packs()
+        ops.conv2d_p3 = spy
+        try:
+            loss, _, arena = eng.loss_fwd_bwd(imgs, act, noise, ts, need_grad=True, names=names)
+            l_inf, _, _ = eng.loss_fwd_bwd(imgs, act, noise, ts, need_grad=False)
+        finally:
+            ops.conv2d_p3 = orig
+        torch.cuda.synchronize()
+        out[use] = (loss.clone(), arena.clone(), l_inf.clone(), len(seen))
+        seen.clear()
+    eng.use_p3 = False
+    assert out[True][3] >= 60 and out[False][3] == 0, (out[True][3], out[False][3])      # 24 forward + 23 data-gradient convs, + the inference pass's 24
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
+    assert torch.equal(out[True][1], out[False][1]), float((out[True][1] - out[False][1]).abs().max())
+
+
 def test_policy_step_is_bitwise_reproducible():
     """two runs of the same seeded train steps give bitwise identical parameters, EMA weights and losses (graph
     replay included).  Replicas that stay bit-identical under data parallelism depend on exactly this."""

@@ -31,6 +31,21 @@ __device__ __forceinline__ unsigned int v2a_pack_bf16x2(float lo, float hi) {
     v2a_f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, v2a_bf16x2));
 }
+// fp32 -> three bf16 planes (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both differences are exact in fp32, the planes carry 24
+// significant bits): the operand format of the three-plane fp32 convs (csrc/igemm_h.hip conv_igemm_f32x3 / conv_halo_x3 / conv_p3)
+__device__ __forceinline__ void v2a_split3x2(float x0, float x1, unsigned int& h, unsigned int& m, unsigned int& l) {
+    h = v2a_pack_bf16x2(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = v2a_pack_bf16x2(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = v2a_pack_bf16x2(s0, s1);
+}
+__device__ __forceinline__ void v2a_split3x1(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = v2a_f2bf(x);
+    const float r = x - __uint_as_float((unsigned int)h << 16);
+    m = v2a_f2bf(r);
+    l = v2a_f2bf(r - __uint_as_float((unsigned int)m << 16));
+}
 // ---- the two 16-bit storage formats of the video-storage kernels: bf16 (default) and IEEE fp16 (the reference's GPU path is fp16
 // autocast: lb_online_trainer_v7.py:72-76,889).  Kernels carry the format as a template flag F16; tensors are uint16_t either way.
 // Conversions round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_f16_f32); the 32x32x16 MFMA exists for both at the same rate.

@@ -456,13 +456,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(const ConvDesc p) {
 // planes carry 24 significant bits.  a * b is then summed from the six plane products whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi,
 // hi*lo, lo*hi, mid*mid; the three dropped ones are <= 2^-24 |a||b|, the size of one fp32 rounding), each exact in the bf16 MFMA's fp32
 // accumulation, smallest first.  Six v_mfma_f32_32x32x16_bf16 (192 cycles per 32x32x16 block) replace eight v_mfma_f32_32x32x2_f32 (512).
-__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = v2a_pack_bf16x2(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = v2a_pack_bf16x2(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = v2a_pack_bf16x2(s0, s1);
-}
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) { v2a_split3x2(x0, x1, h, m, l); }
 
 
 // y[m][n] = sum_s partial[s][m][n] + bias + rowvec + residual   (split-K second pass)
@@ -2174,7 +2168,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
     int tap = (int)(q - (unsigned)co * (unsigned)taps);
     // mode 2 ("channel window" pack of a square filter, v2a_conv2d_fwd_window_f32): dst[co][kh][kw'][ci'] with KW + 1 columns and
     // Cin + 1 channels per column -- the added column / channel stay zero (the caller zeroes dst once)
-    const int mode = (int)table[t * 7 + 5];
+    const int mode = (int)table[t * 7 + 5] & 255;
+    const bool planes = ((int)table[t * 7 + 5] & 256) != 0;      // dsth = the hi plane of three bf16 planes, `total` elements apart (conv_p3 operands)
     int kwn = 1;
     while (kwn * kwn < taps) ++kwn;
     for (int i = threadIdx.x; i < cnt; i += 256) {
@@ -2185,7 +2180,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
             idx = (((size_t)co * kwn + kh) * (kwn + 1) + kw) * (Cin + 1) + ci;
         }
         if (dst) dst[idx] = v;
-        if (dsth) dsth[idx] = f2h_pack(v, f16);
+        if (dsth) {
+            if (planes) { unsigned short h, m, l; v2a_split3x1(v, h, m, l); dsth[idx] = h; dsth[total + idx] = m; dsth[2 * total + idx] = l; }
+            else dsth[idx] = f2h_pack(v, f16);
+        }
         ci += 256;
         while (ci >= Cin) {
             ci -= Cin;
@@ -2200,6 +2198,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t
     float* dst = reinterpret_cast<float*>(table[t * 7 + 1]);
     uint16_t* dsth = reinterpret_cast<uint16_t*>(table[t * 7 + 6]);
     const int Cout = (int)table[t * 7 + 2], Cin = (int)table[t * 7 + 3], taps = (int)table[t * 7 + 4];
+    const bool planes = ((int)table[t * 7 + 5] & 256) != 0;
+    const size_t total = (size_t)Cout * Cin * taps;
     const int J = Cin * taps, tj = (J + 63) >> 6;
     const int c0 = (tl / tj) << 6, j0 = (tl % tj) << 6;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -2215,7 +2215,10 @@ __global__ __launch_bounds__(256) void pack_weights_multi_t_kernel(const int64_t
             const size_t o = ((size_t)ci * taps + (taps - 1 - tap)) * Cout + co;
             const float v = tile[tx][r];
             if (dst) dst[o] = v;
-            if (dsth) dsth[o] = f2h_pack(v, f16);
+            if (dsth) {
+                if (planes) { unsigned short h, m, l; v2a_split3x1(v, h, m, l); dsth[o] = h; dsth[total + o] = m; dsth[2 * total + o] = l; }
+                else dsth[o] = f2h_pack(v, f16);
+            }
         }
     }
 }

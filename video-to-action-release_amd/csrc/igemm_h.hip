@@ -727,17 +727,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32p(const ConvDescH p) 
 // ds_write_b64 of tile t + 1 between the MFMA groups of tile t, two LDS stages of 3 x (BM + BN) rows x 64 B with the 16-B chunk swizzle
 // p ^ ((row >> 2) & 3) (conflict-free ds_read_b128 operand fetch), one barrier per k tile.
 typedef __attribute__((address_space(1))) f32x4 gf32x4_t;
-__device__ __forceinline__ void split3_pair_h(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = v2a_pack_bf16x2(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = v2a_pack_bf16x2(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = v2a_pack_bf16x2(s0, s1);
-}
+__device__ __forceinline__ void split3_pair_h(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) { v2a_split3x2(x0, x1, h, m, l); }
 
-template <int BM, int BN, int WVM, int WVN, int MINW, bool GEN, int PF = 2>
+template <int BM, int BN, int WVM, int WVN, int MINW, bool GEN>
 __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const ConvDescH p) {
-    static_assert(PF == 2 || PF == 4, "register sets of k tiles in flight");
+    constexpr int PF = 2;      // register sets of k tiles in flight (four were measured: no gain -- these launches are not load-latency-bound, tools/probes/r5)
     constexpr int EPT = 32;
     constexpr int NT = 64 * WVM * WVN, RP = NT / 8;             // threads; tile rows one loader pass covers (8 float4 per 32-float row)
     constexpr int AL = BM / RP, BL = BN / RP;
@@ -1090,11 +1084,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, (S * 3 * (BM + BN) * 64 <= 53 * 102
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + pl * PA + j * RP * 64), 16, 0, 0);
             } else {
                 const int pl = (q - 3 * AL) / BL, j = (q - 3 * AL) % BL;
-                uint64_t gi;
-                if (p.wps == 0)      // TILED weight planes: [Cout / BN][K / 32][plane][BN rows x 64 B, chunk-swizzled]: a k tile's plane image is one contiguous block
-                    gi = (uint64_t)(reinterpret_cast<const unsigned char*>(ws) + (((size_t)(n0 / BN) * nkt + it) * 3 + pl) * PB + j * RP * 64 + tid * 16);
-                else
-                    gi = (uint64_t)(ws + (size_t)pl * p.wps + b_row[j] + ik0);
+                uint64_t gi = (uint64_t)(ws + (size_t)pl * p.wps + b_row[j] + ik0);
                 asm volatile("" : "+v"(gi));
                 const hT* g = (live & b_ok[j]) ? reinterpret_cast<const hT*>(gi) : zsrc;
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abase + 3 * PA + pl * PB + j * RP * 64), 16, 0, 0);
@@ -1486,8 +1476,6 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
 }
 
 static void f32_conv_mode_init();
-int g_x3_pf = 4;              // TEMPORARY A/B hook (v2a_tmp_x3_pf): register sets of the 64 x 64 three-plane tile
-extern "C" int v2a_tmp_x3_pf(int pf) { const int o = g_x3_pf; g_x3_pf = pf; return o; }
 static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact / v2a_set_f32_conv_mode(0) select the exact-f32 MFMA kernels
 // Tile / split plan shared by the LDS-DMA conv families.  128-row tiles (64 output columns for 64-wide layers); problems that 128-row
 // tiles cannot spread over the chip (< 128 tiles) take 64 x 64 tiles; K is split so that one round of about 512 workgroups covers the
@@ -1637,11 +1625,7 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, true>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);           \
         else hipLaunchKernelGGL((conv_igemm_f32x3<BM_, BN_, WM_, WN_, 2, false>), grid_, dim3(64 * WM_ * WN_), 0, stream, p);             \
     } while (0)
-            if (bm == 64 && g_x3_pf == 4) {
-                const dim3 grid_ = p.split_xcd > 0 ? dim3(tiles * s, 1) : dim3(tiles, s);
-                if (gen) hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, 2, 2, true, 4>), grid_, dim3(256), 0, stream, p);
-                else hipLaunchKernelGGL((conv_igemm_f32x3<64, 64, 2, 2, 2, false, 4>), grid_, dim3(256), 0, stream, p);
-            } else if (bm == 64) V2A_X3_LAUNCH(64, 64, 2, 2, tiles);
+            if (bm == 64) V2A_X3_LAUNCH(64, 64, 2, 2, tiles);
             else if (bn == 64) {
                 const int t256 = cdiv(p.M, 256) * cdiv(Cout, 64);
                 if (t256 >= 200 && p.M % 256 == 0 && p.frame_tiles == 0) V2A_X3_LAUNCH(256, 64, 4, 2, t256);
@@ -1794,8 +1778,6 @@ int v2a_conv2d_fwd_dma_f32_d(const float* x, const float* x2, const float* w_pac
                                   ph, pw, ups, idil, OH, OW, rows_per_batch, nullptr, workspace, workspace_bytes, stream, nslab_out);
 }
 
-static int g_p3_bm = 0, g_p3_bn = 0, g_p3_s = 1, g_p3_st = 3;
-int v2a_tmp_p3_plan(int bm, int bn, int s, int stages) { g_p3_bm = bm; g_p3_bn = bn; g_p3_s = s < 1 ? 1 : s; g_p3_st = stages; return 0; }
 // 1 when v2a_conv2d_fwd_p3 takes this problem: channel counts in 32N and a plan on 64 x 64 tiles (the small-M GEMMs the kernel is for)
 int v2a_conv2d_p3_eligible(int M, int Cout, int K, int C1, int C2) {
     if (M <= 0 || Cout <= 0 || C1 <= 0 || C1 % 32 || C2 < 0 || C2 % 32 || K % 32) return 0;
@@ -1819,7 +1801,7 @@ int v2a_conv2d_fwd_p3(const void* x3, size_t x_plane_stride, const void* x2_3, s
     if (!v2a_conv2d_p3_eligible(M, Cout, K, C1, C2)) return V2A_ERR_ARG;
     if ((((uintptr_t)x3 | (uintptr_t)x2_3 | (uintptr_t)w3 | (uintptr_t)zeros | (uintptr_t)y | (uintptr_t)residual) & 15) != 0) return V2A_ERR_ARG;
     if (((x_plane_stride | x2_plane_stride | w_plane_stride) & 7) != 0) return V2A_ERR_ARG;      // planes 16-B aligned
-    if (w_plane_stride == 0 && Cout % 128 != 0) return V2A_ERR_ARG;
+    if (x_plane_stride == 0 || w_plane_stride == 0 || (C2 > 0 && x2_plane_stride == 0)) return V2A_ERR_ARG;
     if ((double)N * H * W * (C1 > C2 ? C1 : C2) >= 2147483648.0) return V2A_ERR_ARG;
     ConvDescH p = {};
     p.x = x3; p.x2 = x2_3; p.w = w3; p.xps = x_plane_stride; p.x2ps = x2_plane_stride; p.wps = w_plane_stride;
@@ -1832,31 +1814,15 @@ int v2a_conv2d_fwd_p3(const void* x3, size_t x_plane_stride, const void* x2_3, s
     p.xp1 = C1;
     int bm, bn, tiles, s;
     conv_plan_h(M, Cout, K, 32, &bm, &bn, &tiles, &s);
-    if (g_p3_bm) {                                   // TEMPORARY (v2a_tmp_p3_plan): forced tile / split / stages for the tile-shape A/B
-        bm = g_p3_bm; bn = g_p3_bn;
-        tiles = cdiv(M, bm) * cdiv(Cout, bn);
-        s = g_p3_s;
-        const int nkt = K / 32;
-        if (s > nkt) s = nkt;
-        s = cdiv(nkt, cdiv(nkt, s));
-    }
     if (s > 1 && (size_t)s * M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
     p.splitk = s;
     p.ktiles_per_split = cdiv(K / 32, s);
     p.split_xcd = (s >= 8 && s % 8 == 0) ? s / 8 : 0;
     const dim3 grid = p.split_xcd > 0 ? dim3(tiles * s, 1) : dim3(tiles, s);
-    const int st = g_p3_bm ? g_p3_st : 3;
-    if (bm == 128 && bn == 128 && st == 8) hipLaunchKernelGGL((conv_p3<128, 128, 3, 2, 4>), grid, dim3(512), 0, stream, p);      // eight waves
-    else if (bm == 256 && bn == 128 && st == 8) hipLaunchKernelGGL((conv_p3<256, 128, 2, 4, 2>), grid, dim3(512), 0, stream, p);
-    else if (bm == 64 && bn == 64 && st == 2) hipLaunchKernelGGL((conv_p3<64, 64, 2>), grid, dim3(256), 0, stream, p);           // three workgroups per CU
-    else if (bm == 64 && bn == 64 && st == 3) hipLaunchKernelGGL((conv_p3<64, 64, 3>), grid, dim3(256), 0, stream, p);
-    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_p3<64, 64, 6>), grid, dim3(256), 0, stream, p);
-    else if (bm == 128 && bn == 64 && st == 3) hipLaunchKernelGGL((conv_p3<128, 64, 3>), grid, dim3(256), 0, stream, p);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_p3<128, 64, 4>), grid, dim3(256), 0, stream, p);
-    else if (bm == 64 && bn == 128 && st == 3) hipLaunchKernelGGL((conv_p3<64, 128, 3>), grid, dim3(256), 0, stream, p);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_p3<64, 128, 4>), grid, dim3(256), 0, stream, p);
-    else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_p3<128, 128, 3>), grid, dim3(256), 0, stream, p);
-    else return V2A_ERR_ARG;
+    // 64 x 64 tiles, two LDS stages of 24 KB (three workgroups per CU): the best of the shapes / stage counts measured on the ConditionalUnet1D
+    // GEMMs (tools/probes/r5/conv_p3_tiles.py: 128 x 64, 64 x 128, 128 x 128 on four and eight waves, 3 ... 6 stages, a pre-tiled weight
+    // layout -- all within 10 %: what binds these launches is the LDS-DMA issue rate per wave, ~1 KB per ~300 cycles, not the tile)
+    hipLaunchKernelGGL((conv_p3<64, 64, 2>), grid, dim3(256), 0, stream, p);
     V2A_CHECK_LAUNCH();
     if (s > 1) {
         if (nslab_out) { *nslab_out = s; return V2A_OK; }

@@ -34,6 +34,7 @@ struct GnDesc {
     int N, S, C, G, act, nchunk, rows_per_chunk, C1;
     int yh_f16;             // format of the twin `yh`: 0 bf16, 1 IEEE fp16 (the policy's 16-bit mode: v2a_set_policy_half)
     unsigned short* yh;     // optional bf16 twin of the output (forward: y, backward: dx), same shape: feeds the bf16-MFMA convs
+    size_t yh3;             // > 0 (float4 wave kernels only): yh is the hi plane of THREE bf16 planes yh3 elements apart (v2a_split3x2): conv_p3 operands
     float* gsum;            // large backward path: [N*G][2] = sum over the group's channels of gamma_c * colsum{0,1}[n][c]
     int film_ld;            // elements between the FiLM rows of consecutive samples (2*C when the [N][2][C] tensor is dense)
     float eps;
@@ -64,6 +65,16 @@ __device__ __forceinline__ void gn_store_twin4(unsigned short* yh, size_t i4, co
     u.x = f16 ? v2a_pack_h2<true>(o[0], o[1]) : v2a_pack_h2<false>(o[0], o[1]);
     u.y = f16 ? v2a_pack_h2<true>(o[2], o[3]) : v2a_pack_h2<false>(o[2], o[3]);
     reinterpret_cast<uint2*>(yh)[i4] = u;
+}
+// the float4 wave kernels' 16-bit side output: one twin (16-bit MFMA modes), or the three bf16 planes of the fp32 value (conv_p3 operands)
+__device__ __forceinline__ void gn_store_twin_or_planes4(const GnDesc& p, size_t off, const f32x4& o) {
+    if (p.yh3 == 0) { gn_store_twin4(p.yh, off >> 2, o, p.yh_f16); return; }
+    unsigned int h0, m0, l0, h1, m1, l1;
+    v2a_split3x2(o[0], o[1], h0, m0, l0);
+    v2a_split3x2(o[2], o[3], h1, m1, l1);
+    *reinterpret_cast<uint2*>(p.yh + off) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(p.yh + p.yh3 + off) = uint2{m0, m1};
+    *reinterpret_cast<uint2*>(p.yh + 2 * p.yh3 + off) = uint2{l0, l1};
 }
 
 // -------------------------------------------------------------------------------------------- large path
@@ -881,7 +892,7 @@ __global__ __launch_bounds__(64) void gn_wavev_fwd(const GnDesc p) {
             o = o + *reinterpret_cast<const f32x4*>(p.post + off[j]);
         }
         *reinterpret_cast<f32x4*>(p.y + off[j]) = o;
-        if (p.yh) gn_store_twin4(p.yh, off[j] >> 2, o, p.yh_f16);
+        if (p.yh) gn_store_twin_or_planes4(p, off[j], o);
     }
 }
 
@@ -939,7 +950,7 @@ __global__ __launch_bounds__(64) void gn_wavev_bwd(const GnDesc p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gm[e] * dz[j][e] - (A1 + xv[j][e] * A2) * inv);
         *reinterpret_cast<f32x4*>(p.y + off[j]) = o;
-        if (p.yh) gn_store_twin4(p.yh, off[j] >> 2, o, p.yh_f16);
+        if (p.yh) gn_store_twin_or_planes4(p, off[j], o);
         if (p.dres) *reinterpret_cast<f32x4*>(p.dres + off[j]) = dz[j];
     }
 #pragma unroll
@@ -1052,7 +1063,7 @@ static void gn_chunks(int N, int S, int C, int* nchunk, int* rows) {
 }
 
 // post-activation addend of a GroupNorm forward launch (explicit operands of v2a_groupnorm_fwd_s; all null / 0: none)
-struct GnPost { const float* dense; const float* slabs; const float* bias; int nslab; size_t stride; };
+struct GnPost { const float* dense; const float* slabs; const float* bias; int nslab; size_t stride; size_t yh3; };
 extern "C" {
 
 size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
@@ -1063,13 +1074,13 @@ size_t v2a_groupnorm_workspace_bytes(int N, int S, int C, int G) {
 }
 
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
-                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
-                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
+                        const float* film, int film_ld, float* y, void* y_h, size_t yh_plane_stride, float* mean, float* rstd, int N, int S, int C,
+                        int G, float eps, int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
                         const float* post_slabs, int post_nslab, size_t post_stride, const float* post_bias,
                         void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
-                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
-                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, size_t yh_plane_stride, float* dres,
+                        float* dfilm, float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
                         void* workspace, size_t workspace_bytes, hipStream_t stream);
 // y = film(act(gn(x) + residual)); mean/rstd [N*G] are saved for the backward.
@@ -1087,7 +1098,7 @@ int v2a_groupnorm_fwd(const float* x, const float* x2, int C1, const float* gamm
 int v2a_groupnorm_fwd_t(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
                         const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
                         int act, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return v2a_groupnorm_fwd_s(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, mean, rstd, N, S, C, G, eps, act, nullptr, 0, 0,
+    return v2a_groupnorm_fwd_s(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, 0, mean, rstd, N, S, C, G, eps, act, nullptr, 0, 0,
                                nullptr, nullptr, nullptr, 0, 0, nullptr, workspace, workspace_bytes, stream);
 }
 // 1 when a GroupNorm over [N, S, C] with G groups runs on the wave path, i.e. accepts its input as split-K slabs (v2a_groupnorm_*_s)
@@ -1101,12 +1112,12 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* stats1,
                        const float* stats2, const GnPost& post, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int v2a_groupnorm_fwd_s(const float* x, const float* x2, int C1, const float* gamma, const float* beta, const float* residual,
-                        const float* film, int film_ld, float* y, void* y_h, float* mean, float* rstd, int N, int S, int C, int G, float eps,
-                        int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
+                        const float* film, int film_ld, float* y, void* y_h, size_t yh_plane_stride, float* mean, float* rstd, int N, int S, int C,
+                        int G, float eps, int act, const float* slabs, int nslab, size_t slab_stride, const float* cbias, const float* post,
                         const float* post_slabs, int post_nslab, size_t post_stride, const float* post_bias,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if ((post && post_slabs) || (post_slabs && post_nslab < 1) || (!post_slabs && post_nslab > 0)) return V2A_ERR_ARG;
-    const GnPost po = {post, post_slabs, post_slabs ? post_bias : nullptr, post_slabs ? post_nslab : 0, post_stride};
+    const GnPost po = {post, post_slabs, post_slabs ? post_bias : nullptr, post_slabs ? post_nslab : 0, post_stride, y_h ? yh_plane_stride : 0};
     return gn_fwd_impl(x, x2, C1, gamma, beta, residual, film, film_ld, y, y_h, mean, rstd, N, S, C, G, eps, act, slabs, nslab, slab_stride,
                        cbias, nullptr, nullptr, po, workspace, workspace_bytes, stream);
 }
@@ -1138,6 +1149,8 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
     p.yh_f16 = g_v2a_policy_f16;
     p.post = post.dense; p.post_slabs = post.slabs; p.post_bias = post.bias; p.post_nslab = post.nslab; p.post_stride = post.stride;
     const bool has_post = post.dense || post.slabs;
+    p.yh3 = post.yh3;
+    if (p.yh3 && ((p.yh3 & 3) || p.yh3 < (size_t)N * S * C)) return V2A_ERR_ARG;
     p.x2 = x2; p.C1 = x2 ? C1 : C;
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.y = y; p.mean = mean; p.rstd = rstd;
     p.yh = (unsigned short*)y_h;
@@ -1146,7 +1159,7 @@ static int gn_fwd_impl(const float* x, const float* x2, int C1, const float* gam
     const int cg = C / G;
     const long E = (long)S * cg;
     if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.cbias = cbias; p.sout = (float*)x; }
-    if (has_post && (x2 || !gn_wave_ok(S, cg) || gn_wavev_passes(p, cg) == 0)) return V2A_ERR_ARG;      // only the float4 wave kernels add it
+    if ((has_post || p.yh3) && (x2 || !gn_wave_ok(S, cg) || gn_wavev_passes(p, cg) == 0)) return V2A_ERR_ARG;      // only the float4 wave kernels add it / write planes
     if (!x2 && gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;             // 8 values per lane (the ConditionalUnet1D slabs) or 16
@@ -1246,14 +1259,14 @@ int v2a_groupnorm_bwd_t(const float* x, const float* gamma, const float* beta, c
                         const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
                         float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return v2a_groupnorm_bwd_s(x, gamma, beta, residual, film, film_ld, dout, mean, rstd, dx, dx_h, dres, dfilm, colsum, dgamma, dbeta,
+    return v2a_groupnorm_bwd_s(x, gamma, beta, residual, film, film_ld, dout, mean, rstd, dx, dx_h, 0, dres, dfilm, colsum, dgamma, dbeta,
                                accumulate_params, N, S, C, G, act, nullptr, 0, 0, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 // same; with nslab > 0 the incoming gradient is sum_s slabs[s][.] + sresid[.] (split-K partial sums and epilogue residual of the data-
 // gradient conv that produces it) and `dout_sum` (optional) receives that sum for its other readers; `dout` is then ignored.
 int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, const float* residual, const float* film, int film_ld,
-                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, float* dres, float* dfilm,
-                        float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
+                        const float* dout, const float* mean, const float* rstd, float* dx, void* dx_h, size_t yh_plane_stride, float* dres,
+                        float* dfilm, float* colsum, float* dgamma, float* dbeta, int accumulate_params, int N, int S, int C, int G, int act,
                         const float* slabs, int nslab, size_t slab_stride, const float* sresid, float* dout_sum,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !gamma || !beta || (!dout && nslab <= 0) || !mean || !rstd || !dx || !colsum || C % G != 0) return V2A_ERR_ARG;
@@ -1263,10 +1276,13 @@ int v2a_groupnorm_bwd_s(const float* x, const float* gamma, const float* beta, c
     p.x = x; p.gamma = gamma; p.beta = beta; p.residual = residual; p.film = film; p.dout = dout;
     p.film_ld = film_ld > 0 ? film_ld : 2 * C;
     p.mean = (float*)mean; p.rstd = (float*)rstd; p.y = dx; p.yh = (unsigned short*)dx_h; p.dres = dres; p.dfilm = dfilm; p.colsum = colsum;
+    p.yh3 = dx_h ? yh_plane_stride : 0;
+    if (p.yh3 && ((p.yh3 & 3) || p.yh3 < (size_t)N * S * C)) return V2A_ERR_ARG;
     p.N = N; p.S = S; p.C = C; p.G = G; p.act = act;
     const int cg = C / G;
     const long E = (long)S * cg;
     if (nslab > 0) { p.slabs = slabs; p.nslab = nslab; p.slab_stride = slab_stride; p.sresid = sresid; p.sout = dout_sum; }
+    if (p.yh3 && !(gn_wave_ok(S, cg) && gn_wavev_passes(p, cg))) return V2A_ERR_ARG;       // planes: the float4 wave kernels only
     if (gn_wave_ok(S, cg)) {
         const dim3 grid(N * G), block(64);
         const bool small = E <= 512;

@@ -117,6 +117,15 @@ __global__ __launch_bounds__(256) void opt_advance_kernel(OptState* st, const do
     st->ema_mode = mode;
 }
 
+// 16-bit side copy of a packed operand element: format 0 bf16, 1 IEEE fp16 (the twins of the 16-bit MFMA modes), 2 = the three bf16 planes
+// hi / mid / lo of the fp32 value, `n` (the tensor's element count) apart: conv_p3's pre-split weight operand
+__device__ __forceinline__ void opt_store_twin(unsigned short* pkh, size_t i, float x, int fmt, size_t n) {
+    if (fmt == 2) {
+        unsigned short h, m, l;
+        v2a_split3x1(x, h, m, l);
+        pkh[i] = h; pkh[n + i] = m; pkh[2 * n + i] = l;
+    } else pkh[i] = fmt ? v2a_f2h<true>(x) : v2a_f2bf(x);
+}
 // `packs` (optional, int64 [tensor][6] = {dst, Cin, taps, dst_window, dst_16bit_twin, twin is fp16}): the updated parameter also goes, re-laid, into the conv operand
 // packs the next forward reads -- dst[co][tap][ci] (the forward pack of csrc/igemm.hip pack_weights_multi_kernel, mode 0; plain copies
 // are Cin = numel, taps = 1) and, for the RGB stem, dst_window[co][kh][kw'][ci'] (mode 2) -- instead of a pack launch that reads every
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
                     if (el >= qs && el < qe) {
                         const float x = park[el - qs];
                         if (pk) pk[d0 + (size_t)tp * pCin] = x;
-                        if (pkh) pkh[d0 + (size_t)tp * pCin] = pf16 ? v2a_f2h<true>(x) : v2a_f2bf(x);
+                        if (pkh) opt_store_twin(pkh, d0 + (size_t)tp * pCin, x, pf16, (size_t)n);
                     }
                 }
             }
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256) void mt_adamw_ema_kernel(const int64_t* table,
         }
         if (pk || pw || pkh) {
             if (pk) pk[((size_t)kco * ptaps + ktap) * pCin + kci] = pv;
-            if (pkh) pkh[((size_t)kco * ptaps + ktap) * pCin + kci] = pf16 ? v2a_f2h<true>(pv) : v2a_f2bf(pv);
+            if (pkh) opt_store_twin(pkh, ((size_t)kco * ptaps + ktap) * pCin + kci, pv, pf16, (size_t)n);
             if (pw) {
                 const int kh = ktap / kwn, kw = ktap - kh * kwn;
                 pw[(((size_t)kco * kwn + kh) * (kwn + 1) + kw) * (pCin + 1) + kci] = pv;

@@ -66,8 +66,8 @@ SIGNATURES = {
     "v2a_gn_param_grads_multi": (I, [P, P, I, P]),
     "v2a_groupnorm_takes_slabs": (I, [I, I, I]),
     "v2a_groupnorm_takes_post": (I, [I, I, I]),
-    "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, I, SZ, P, P, SZ, P]),
-    "v2a_groupnorm_bwd_s": (I, [P] * 5 + [I] + [P] * 10 + [I, I, I, I, I, I, P, I, SZ, P, P, P, SZ, P]),
+    "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, SZ, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, I, SZ, P, P, SZ, P]),
+    "v2a_groupnorm_bwd_s": (I, [P] * 5 + [I] + [P] * 5 + [SZ] + [P] * 5 + [I, I, I, I, I, I, P, I, SZ, P, P, P, SZ, P]),
     "v2a_h5_open": (I, [ctypes.c_char_p, P]),
     "v2a_h5_close": (None, [P]),
     "v2a_h5_last_error": (ctypes.c_char_p, [P]),

@@ -146,6 +146,26 @@ def _twin_of(w_packed):
     return ent[1]
 
 
+_p3_reg = {}        # fp32 packed operand data_ptr -> (weakref, its three bf16 planes [3, numel]) (registered by the engine that keeps both fresh)
+
+
+def register_p3(w_f32: torch.Tensor, planes: torch.Tensor):
+    """Declare `planes` ([3, numel] bf16: hi / mid / lo) to hold the split of the packed fp32 operand `w_f32`: conv2d then runs eligible
+    layers whose input also arrives pre-split (x_p3) on the pure LDS-DMA kernel conv_p3 -- bit-identical results, no re-splitting."""
+    assert planes.dtype == torch.bfloat16 and planes.numel() == 3 * w_f32.numel()
+    if len(_p3_reg) % 64 == 63:
+        for k in [k for k, (ref, _) in _p3_reg.items() if ref() is None]:
+            del _p3_reg[k]
+    _p3_reg[w_f32.data_ptr()] = (weakref.ref(w_f32), planes)
+
+
+def _p3_of(w_packed):
+    ent = _p3_reg.get(w_packed.data_ptr())
+    if ent is None or ent[0]() is not w_packed:
+        return None
+    return ent[1]
+
+
 class Slabs:
     """Split-K partial sums a conv left for its consumer (conv2d(..., defer=True)): the tensor is sum_s ws[s] (+ bias) (+ residual).
     Only valid until the next launch that uses the same scratch lane -- the consumer must be the very next user."""
@@ -210,7 +230,7 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
 
 def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, rowvec=None, rows_per_batch=1,
            residual=None, idil=1, ups=False, out_hw=None, y=None, y2=None, csplit=0, bmode=0, x_h=None, keep_h=None, defer=False,
-           want_stats=False):
+           want_stats=False, x_p3=None, x2_p3=None):
     """Generic channels-last conv.  x [N,H,W,C1] (+ x2 [N,H,W,C2] concatenated along C).  Returns y [N,OH,OW,Cout]; with defer=True
     (y, Slabs | None): when Slabs is returned, y is NOT written yet -- hand both to the GroupNorm that consumes the conv.
     bf16-MFMA mode: `x_h` = an existing bf16 twin of x (skips the cast launch); `keep_h` (a list) receives the twin that was used, so a
@@ -221,6 +241,18 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
     if x2 is not None:
         _chk(x2, "x2")
         C2 = x2.shape[-1]
+    # operands that arrive pre-split (x_p3 / x2_p3: the [3, ...] bf16 planes a GroupNorm launch wrote next to x / x2; planes of the packed
+    # weight registered by the engine): the pure LDS-DMA three-plane kernel -- same plan, same slabs, bit-identical results
+    if (x_p3 is not None and (x2 is None or x2_p3 is not None) and bmode == 0 and y2 is None and not csplit and rowvec is None and not ups
+            and idil == 1 and out_hw is None and not want_stats and Cout % 64 == 0 and lib.v2a_get_precision() == 0
+            and lib.v2a_get_f32_conv_mode() == 1):
+        w3 = _p3_of(w_packed)
+        oh_ = (H + 2 * pad[0] - KH) // stride[0] + 1
+        ow_ = (W + 2 * pad[1] - KW) // stride[1] + 1
+        if w3 is not None and p3_eligible(N * oh_ * ow_, Cout, KH * KW * (C1 + C2), C1, C2):
+            assert x_p3.shape[1:] == x.shape and (x2 is None or x2_p3.shape[1:] == x2.shape)
+            return conv2d_p3(x_p3, w3, bias, Cout, KH, KW, stride, pad, x2_3=x2_p3 if x2 is not None else None, residual=residual, y=y,
+                             defer=defer)
     # (with the three-plane fp32 products every eligible shape takes this route, however small: a layer must not change its
     # arithmetic with the batch size -- the data-parallel equality test compares B rows on one rank with B/2 on two)
     if (bmode == 0 and y2 is None and not csplit and C1 % 32 == 0 and C2 % 32 == 0 and idil in (1, 2) and not (ups and idil > 1)
@@ -795,7 +827,7 @@ def colsum(x2d, out=None, accumulate=False):
 
 # ------------------------------------------------------------------------------------------------ group norm
 def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1e-5, y=None, x2=None, twin_out=None, slabs=None,
-                  stats=None, stats2=None, post=None, post_slabs=None):
+                  stats=None, stats2=None, post=None, post_slabs=None, planes_out=None):
     """x [N,S,C] (any leading/spatial shape flattened by the caller); x2 [N,S,C2]: virtual channel concat [x | x2].
     Returns (y [N,S,C(+C2)], mean, rstd).  twin_out (a list): also emit the bf16 twin of y and append it (bf16-MFMA mode: the conv
     that consumes y takes it as x_h and skips its cast launch)."""
@@ -811,9 +843,14 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     # film: [N, 2*C] rows (scale | shift); may be a column slice of a wider [N, NF] matrix (batched FiLM projections): row stride
     film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
     yh = None
+    yh3 = 0
     if twin_out is not None and C % 4 == 0:
         yh = torch.empty((N, S, C), dtype=POLICY_HALF[0], device=x.device)
         twin_out.append(yh)
+    elif planes_out is not None and x2 is None and gn_takes_post(S, C, G):      # three bf16 planes of y (conv_p3 operand), float4 wave path only
+        yh = torch.empty((3, N, S, C), dtype=torch.bfloat16, device=x.device)
+        yh3 = N * S * C
+        planes_out.append(yh)
     po = (None, None, 0, 0, None)      # explicit operands of the launch: (dense post, post slabs, their number, their stride, their bias)
     if post is not None or post_slabs is not None:
         # added to the OUTPUT (after activation / FiLM): dense tensor, or the split-K slabs (+ bias) of the conv that produces it
@@ -826,12 +863,12 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
             _chk(post, "post")
             assert post.numel() == N * S * C
             po = (post.data_ptr(), None, 0, 0, None)
-    if slabs is not None or po[0] is not None or po[1] is not None:
+    if slabs is not None or po[0] is not None or po[1] is not None or yh3:
         # slabs: x is the (still unwritten) conv output -- the kernel sums the conv's split-K slabs and stores x too
         assert slabs is None or slabs.residual is None
         sl = (slabs.ws.data_ptr(), slabs.n, slabs.stride, _p(slabs.bias)) if slabs is not None else (None, 0, 0, None)
         check(lib.v2a_groupnorm_fwd_s(x.data_ptr(), _p(x2), C1, gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, y.data_ptr(),
-                                      _p(yh), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], sl[0], sl[1], sl[2], sl[3],
+                                      _p(yh), yh3, mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ACT[act], sl[0], sl[1], sl[2], sl[3],
                                       po[0], po[1], po[2], po[3], po[4], _p(ws), wsb, _stream()), "groupnorm_fwd_s")
         return y, mean, rstd
     if (stats is not None and (x2 is None or stats2 is not None) and S % 64 == 0 and residual is None and film is None and yh is None):
@@ -866,7 +903,7 @@ def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None
 
 def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None, film=None, want_dres=False, want_dfilm=False,
                   dgamma=None, dbeta=None, accumulate_params=False, dfilm_out=None, twin_out=None, colsum=None, defer_params=False,
-                  dout_slabs=None, dout_sum=None):
+                  dout_slabs=None, dout_sum=None, planes_out=None):
     """Returns dx, dgamma, dbeta, dres (or None), dfilm [N,2,C] (or None).  dfilm_out: [N, 2*C] destination with the SAME row stride
     as `film` (a column slice of the batched [N, NF] gradient matrix).  twin_out (a list): also emit the bf16 twin of dx.
     defer_params: only fill `colsum` [N,2,C] (per-sample sums); the caller reduces it over n for many layers at once
@@ -874,9 +911,14 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
     N, S, C = x.shape
     dx = torch.empty_like(x)
     dxh = None
+    yh3 = 0
     if twin_out is not None and C % 4 == 0:
         dxh = torch.empty(x.shape, dtype=POLICY_HALF[0], device=x.device)
         twin_out.append(dxh)
+    elif planes_out is not None and gn_takes_post(S, C, G):      # three bf16 planes of dx (conv_p3 operand of the data gradient that follows)
+        dxh = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+        yh3 = x.numel()
+        planes_out.append(dxh)
     dres = torch.empty_like(x) if want_dres else None
     dfilm = dfilm_out if dfilm_out is not None else (torch.empty((N, 2, C), dtype=torch.float32, device=x.device) if want_dfilm else None)
     film_ld = 0 if film is None else (film.stride(0) if film.dim() >= 2 else 2 * C)
@@ -895,9 +937,15 @@ def groupnorm_bwd(x, gamma, beta, G, dout, mean, rstd, act="none", residual=None
         sl = dout_slabs
         assert sl.bias is None
         check(lib.v2a_groupnorm_bwd_s(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, None,
-                                      mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), _p(dres), _p(dfilm), colsum_.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), yh3, _p(dres), _p(dfilm), colsum_.data_ptr(),
                                       _p(dgamma), _p(dbeta), 1 if accumulate_params else 0, N, S, C, G, ACT[act], sl.ws.data_ptr(), sl.n,
                                       sl.stride, _p(sl.residual), _p(dout_sum), None, 0, _stream()), "groupnorm_bwd_s")
+        return dx, dgamma, dbeta, dres, dfilm
+    if yh3:
+        check(lib.v2a_groupnorm_bwd_s(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), yh3, _p(dres), _p(dfilm), colsum_.data_ptr(),
+                                      _p(dgamma), _p(dbeta), 1 if accumulate_params else 0, N, S, C, G, ACT[act], None, 0, 0, None, None,
+                                      _p(ws), wsb, _stream()), "groupnorm_bwd_s")
         return dx, dgamma, dbeta, dres, dfilm
     check(lib.v2a_groupnorm_bwd_t(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(residual), _p(film), film_ld, dout.data_ptr(),
                                   mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dxh), _p(dres), _p(dfilm), colsum_.data_ptr(),

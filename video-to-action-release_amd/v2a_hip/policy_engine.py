@@ -19,6 +19,9 @@ from . import ops
 def _dgrad(x, cv, bias, cout, kh, kw, stride=(1, 1), pad=(0, 0), **kw_):
     """conv2d launch that uses cv's data-gradient operand (forward pack + N-major loader, or the flipped pack)."""
     w, bmode = cv.dg()
+    x3 = cv.eng._planes_of(x)
+    if x3 is not None:
+        kw_ = dict(kw_, x_p3=x3.view((3,) + tuple(x.shape)))
     return ops.conv2d(x, w, bias, cout, kh, kw, stride, pad, bmode=bmode, **kw_)
 
 
@@ -59,6 +62,11 @@ class _Conv:
         self._pd = None
         self._pf_h = None          # bf16 twins of the two operands (bf16 precision mode, see PolicyEngine.refresh_packs)
         self._pd_h = None
+        # three-plane bf16 copies (hi / mid / lo) of the two operands: the ConditionalUnet1D convs whose inputs arrive pre-split run on the
+        # pure LDS-DMA kernel (ops.conv2d_p3); written by the optimiser's update kernel / the pack launches (PolicyEngine.refresh_packs)
+        self.want_p3 = False
+        self._pf_p3 = None
+        self._pd_p3 = None
         # RGB stem (7x7, 3 input channels): also the channel-window pack [Cout][7][8][4] of ops.conv2d_window (zero column / channel)
         self.window = w.dim() == 4 and self.kh == 7 and self.kw == 7 and self.ci == 3
         self._pw = None
@@ -105,6 +113,12 @@ class _Conv:
                     dst[-(src.numel() % 4):] = src.reshape(-1)[-(src.numel() % 4):].to(dst.dtype)
             ops.register_h_twin(self._pf, self._pf_h)
             ops.register_h_twin(self._pd, self._pd_h)
+        if self._pf_p3 is not None:                   # ... and the three-plane copies
+            ops.split3(self._pf.reshape(-1), out=self._pf_p3)
+            ops.register_p3(self._pf, self._pf_p3)
+            if self._pd is not None and self._pd_p3 is not None:
+                ops.split3(self._pd, out=self._pd_p3)
+                ops.register_p3(self._pd, self._pd_p3)
         self._ver = (self.w.data_ptr(), self.w._version)
 
     def pf(self):
@@ -157,6 +171,16 @@ class PolicyEngine:
         # data gradients are ordinary convs over a flipped, K-contiguous pack (written by the transposing multi-pack launch): the
         # K-contiguous form is what the LDS-DMA kernels take
         self.flip_dgrad = True
+        # Pre-split operands for the ConditionalUnet1D convs: built, bit-equal to the register-splitting path
+        # (tests/test_policy_gpu.py::test_presplit_operand_convs_equal_the_register_split_path_bitwise runs both) and measured SLOWER in the
+        # step -- 8.00 / 8.13 ms against 7.77 / 7.83 ms, alternating runs on one box -- although every conv launch alone is 1.1 ... 1.3 x
+        # faster (tools/probes/r5/conv_p3_probe.py, weights warm in the 256-MB Infinity Cache): in the step the 65 M weights come from HBM
+        # on every pass, and three bf16 planes are 6 bytes per element where the fp32 pack is 4 -- the optimiser and the transposing pack
+        # launch write 0.78 GB more, forward and data-gradient convs read 0.26 GB more, per step.  fp32 weights split in the kernel ARE
+        # the byte-optimal operand format for these weight-streaming GEMMs.  Default off; DESIGN.md section 3 "Round 5".
+        self.use_p3 = False
+        self._p3 = {}                # data_ptr of an fp32 activation / gradient of the ConditionalUnet1D -> its three bf16 planes (this pass)
+        self._p3_active = False      # inside unet_fwd / unet_bwd: the GroupNorm launches also write the planes of their outputs
         self._deferred = []
         self.split_deferred = False  # data parallel: backward_phase2 leaves the deferred weight gradients to run_deferred_wgrads()
         # debug export for the parity tests (None: off): when a dict, encode_fwd records the forward's DISCRETE decisions of each camera
@@ -238,6 +262,15 @@ class PolicyEngine:
                                 us=self.conv(f"{m}up_modules.{i}.2.conv.weight", f"{m}up_modules.{i}.2.conv.bias", transposed=True)))
         self.fin0 = self.conv(m + "final_conv.0.block.0.weight", m + "final_conv.0.block.0.bias")
         self.fin1 = self.conv(m + "final_conv.1.weight", m + "final_conv.1.bias")
+        # convs of the ConditionalUnet1D whose operands can arrive pre-split (channel counts in 32N, 64N output columns both ways)
+        for blk in [b for lvl in self.down for b in (lvl["r0"], lvl["r1"])] + list(self.mid) + [b for lvl in self.up for b in (lvl["r0"], lvl["r1"])]:
+            for cv in (blk["c0"], blk["c1"], blk["rc"]):
+                if cv is not None and cv.ci % 64 == 0 and cv.co % 64 == 0:
+                    cv.want_p3 = True
+        for lvl in self.down:
+            if lvl["ds"] is not None:
+                lvl["ds"].want_p3 = True
+        self.fin0.want_p3 = True
         # the 16 FiLM projections (cond_encoder = Mish -> Linear(G, 2*C), one per residual block) all read the same Mish(cond):
         # they run as ONE GEMM over concatenated weights (forward, weight gradient, data gradient), see unet_fwd / unet_bwd
         self.film = []
@@ -280,6 +313,19 @@ class PolicyEngine:
             return None
         self._tw, self._tw_tag = None, 0
         return tw
+
+    def _p3_mode(self):
+        """Pre-split operands are used in the fp32 three-plane conv mode only (the 16-bit MFMA modes have their twins, the exact mode no planes)."""
+        return self.use_p3 and ops.lib.v2a_get_precision() == 0 and ops.lib.v2a_get_f32_conv_mode() == 1
+
+    def _planes_of(self, t):
+        """The three bf16 planes a GroupNorm launch of this pass wrote next to the fp32 tensor `t`, or None."""
+        if t is None or not self._p3:
+            return None
+        ent = self._p3.get(t.data_ptr())
+        if ent is None or ent[1] != t.numel():
+            return None
+        return ent[0]
 
     # ------------------------------------------------------------------ weight gradients off the critical path
     def _wg(self, *a, **k):
@@ -403,6 +449,14 @@ class PolicyEngine:
         for c in self._convs.values():
             taps = c.kh * c.kw
             tw = c._pf_h.data_ptr() if (bf16 and c._pf_h is not None) else 0
+            if not bf16 and c._pf_p3 is not None and self._p3_mode():      # side copy = the three bf16 planes of the forward operand (format 2)
+                tw = c._pf_p3.data_ptr()
+                fmt = 2
+                if taps > 1:
+                    by_ptr[c.w.data_ptr()] = (c._pf.data_ptr(), c.ci, taps, 0, tw, fmt)
+                else:
+                    by_ptr[c.w.data_ptr()] = (0, c.w.numel(), 1, 0, tw, fmt)
+                continue
             if taps > 1:
                 by_ptr[c.w.data_ptr()] = (c._pf.data_ptr(), c.ci, taps, c._pw.data_ptr() if c.window else 0, tw, f16)
             elif tw:                                    # 1 x 1 / linear weights are their own fp32 operand: twin only
@@ -428,8 +482,10 @@ class PolicyEngine:
         bf16 kernel can take."""
         from ._lib import lib, check
         bf16 = lib.v2a_get_precision() == 1
-        if getattr(self, "_mp", None) is not None and (self._mp["bf16"] != bf16 or self._mp.get("half") is not ops.POLICY_HALF[0]):
-            self._mp = None                            # precision mode or 16-bit format changed: new twins
+        p3 = self._p3_mode()
+        if getattr(self, "_mp", None) is not None and (self._mp["bf16"] != bf16 or self._mp.get("half") is not ops.POLICY_HALF[0]
+                                                       or self._mp.get("p3") != p3):
+            self._mp = None                            # precision mode, 16-bit format or fp32 conv mode changed: new twins / planes
         if getattr(self, "_mp", None) is None:
             rows = []
             ch0, ch1 = {"enc": [], "unet": []}, {"enc": [], "unet": []}
@@ -444,8 +500,15 @@ class PolicyEngine:
                     c._pf = w
                 elif c._pf is None or c._pf.data_ptr() == w.data_ptr():
                     c._pf = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
-                if taps > 1 or bf16:                   # forward operand (1x1 weights are their own fp32 operand: twin only)
-                    rows.append([w.data_ptr(), c._pf.data_ptr() if taps > 1 else 0, c.co, c.ci, taps, 0, c._pf_h.data_ptr() if bf16 else 0])
+                cp3 = p3 and c.want_p3 and not bf16
+                if cp3 and c._pf_p3 is None:
+                    c._pf_p3 = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=self.device)
+                    c._pd_p3 = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=self.device)
+                if not cp3:
+                    c._pf_p3 = c._pd_p3 = None
+                if taps > 1 or bf16 or cp3:            # forward operand (1x1 weights are their own fp32 operand: twin / planes only)
+                    rows.append([w.data_ptr(), c._pf.data_ptr() if taps > 1 else 0, c.co, c.ci, taps, 256 if cp3 else 0,
+                                 c._pf_p3.data_ptr() if cp3 else (c._pf_h.data_ptr() if bf16 else 0)])
                     ch0[c.group] += [[len(rows) - 1, s0] for s0 in range(0, w.numel(), ce)]
                 if c.window:                           # RGB stem: the channel-window pack next to the plain one (mode 2 of the same launch)
                     if c._pw is None:
@@ -455,12 +518,16 @@ class PolicyEngine:
                 if not c.nmaj or bf16 or self.flip_dgrad:
                     if c._pd is None:
                         c._pd = torch.empty(w.numel(), dtype=torch.float32, device=self.device)
-                    rows.append([w.data_ptr(), c._pd.data_ptr(), c.co, c.ci, taps, 1, c._pd_h.data_ptr() if bf16 else 0])
+                    rows.append([w.data_ptr(), c._pd.data_ptr(), c.co, c.ci, taps, 1 | (256 if cp3 else 0),
+                                 c._pd_p3.data_ptr() if cp3 else (c._pd_h.data_ptr() if bf16 else 0)])
                     ntile = -(-c.co // 64) * -(-(c.ci * taps) // 64)
                     ch1[c.group] += [[len(rows) - 1, t] for t in range(ntile)]
                 if bf16:
                     ops.register_h_twin(c._pf, c._pf_h)
                     ops.register_h_twin(c._pd, c._pd_h)
+                if cp3:
+                    ops.register_p3(c._pf, c._pf_p3)
+                    ops.register_p3(c._pd, c._pd_p3)
             if self.batch_film:                        # (FiLM tables: ConditionalUnet1D operands)
                 f0, f1 = self._film_rows()
                 for row in f0:
@@ -472,7 +539,7 @@ class PolicyEngine:
             dev = self.device
             t = lambda a, dt: torch.tensor(a, dtype=dt).to(dev) if a else None
             self._mp_serial += 1
-            self._mp = dict(tab=t(rows, torch.int64), ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16, half=ops.POLICY_HALF[0],
+            self._mp = dict(tab=t(rows, torch.int64), ptrs=[c.w.data_ptr() for c in self._convs.values()], bf16=bf16, half=ops.POLICY_HALF[0], p3=p3,
                             ch0={g: t(v, torch.int32) for g, v in ch0.items()}, n0={g: len(v) for g, v in ch0.items()},
                             ch1={g: t(v, torch.int32) for g, v in ch1.items()}, n1={g: len(v) for g, v in ch1.items()})
         mp = self._mp
@@ -502,8 +569,12 @@ class PolicyEngine:
         x3 = x4.view(N, -1, C)
         r3 = residual.view(N, -1, C) if residual is not None else None
         tw = [] if (C % 64 == 0 and ops.lib.v2a_get_precision() == 1) else None      # bf16-MFMA mode: the consuming conv's operand twin
+        pl = [] if (self._p3_active and tw is None and C % 64 == 0) else None        # fp32 three-plane mode: its pre-split operand
         y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs,
-                                          twin_out=tw, post=None if post is None else post.view(N, -1, C), post_slabs=post_slabs)
+                                          twin_out=tw, post=None if post is None else post.view(N, -1, C), post_slabs=post_slabs,
+                                          planes_out=pl)
+        if pl:
+            self._p3[y.data_ptr()] = (pl[0], y.numel())
         self._set_tw(tw[0] if tw else None, y)       # taken by the caller right after (x_h of the next conv): no cast launch
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
@@ -520,6 +591,8 @@ class PolicyEngine:
         kw = dict(dout_slabs=dslabs, dout_sum=d3 if (dslabs is not None and keep_dout) else None)
         tw = [] if (want_twin and C % 64 == 0 and ops.lib.v2a_get_precision() == 1) else None
         kw["twin_out"] = tw
+        pl = [] if (self._p3_active and tw is None and C % 64 == 0) else None
+        kw["planes_out"] = pl
         chain = self._gn_chain
         if chain is None:            # outside a chain (stand-alone use): reduce this layer's parameter gradients right away
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
@@ -534,6 +607,8 @@ class PolicyEngine:
             dx, _, _, dres, dfilm = ops.groupnorm_bwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, d3, mean, rstd, act,
                                                       residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
                                                       dfilm_out=dfilm_out, colsum=cs, defer_params=True, **kw)
+        if pl:
+            self._p3[dx.data_ptr()] = (pl[0], dx.numel())
         self._set_tw(tw[0] if tw else None, dx)      # bf16 twin of dx (want_twin): operand of the data / weight gradients that follow
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
@@ -742,9 +817,16 @@ class PolicyEngine:
         """Conv1d on [B,T,C] (channels-last) via the (1 x k) view.  defer: returns (y, ops.Slabs | None), see ops.conv2d."""
         B, T, C = x.shape
         pad = k // 2 if pad is None else pad
+        x3, x23 = self._planes_of(x), self._planes_of(x2)
+        if x3 is not None and (x2 is None or x23 is not None):      # both sources arrive pre-split: the pure LDS-DMA kernel (ops.conv2d)
+            x3 = x3.view(3, B, 1, T, C)
+            x23 = None if x2 is None else x23.view(3, B, 1, T, -1)
+        else:
+            x3 = x23 = None
         y = ops.conv2d(x.view(B, 1, T, C), cv.pf(), cv.b, cv.co, 1, k, (1, stride), (0, pad),
                        x2=None if x2 is None else x2.view(B, 1, T, -1),
-                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h, defer=defer, x_h=x_h)
+                       residual=None if residual is None else residual.view(B, 1, -1, cv.co), keep_h=keep_h, defer=defer, x_h=x_h,
+                       x_p3=x3, x2_p3=x23)
         if defer:
             return y[0].view(B, -1, cv.co), y[1]
         return y.view(B, -1, cv.co)
@@ -870,6 +952,17 @@ class PolicyEngine:
         cfg = self.cfg
         B, T, Da = sample.shape
         ops.tstamp("unet_fwd begin")
+        self._p3 = {}
+        self._p3_active = self._p3_mode()
+        try:
+            return self._unet_fwd(sample, t_long, global_cond, save)
+        finally:
+            self._p3_active = False
+            self._p3 = {}
+
+    def _unet_fwd(self, sample, t_long, global_cond, save):
+        cfg = self.cfg
+        B, T, Da = sample.shape
         temb = ops.sincos_embed(t_long, cfg.dsed, 0)
         e1 = ops.linear(temb, self.step1.pf(), self.step1.b)
         m1 = ops.act_fwd(e1, "mish")
@@ -922,6 +1015,15 @@ class PolicyEngine:
 
     def unet_bwd(self, dpred, save, grads):
         """Returns d(global_cond) [B,G]."""
+        self._p3 = {}
+        self._p3_active = self._p3_mode()
+        try:
+            return self._unet_bwd(dpred, save, grads)
+        finally:
+            self._p3_active = False
+            self._p3 = {}
+
+    def _unet_bwd(self, dpred, save, grads):
         cfg = self.cfg
         k = cfg.kernel_size
         B, T, Da = dpred.shape
