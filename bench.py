@@ -1050,6 +1050,8 @@ def main():
                     t1 = out["video_b1"]["seconds_per_sample_call"] * 8
                     out["joint"] = {"workload": "BASELINE configs[3] at one GPU: policy train steps + one video-guided exploration round (8 tasks, "
                                                 "100 ancestral steps) every 200 steps", "rollout_every_steps": every,
+                                    "steps_per_sec": every / (every * ms * 1e-3 + t8),
+                                    "product_path": "LB_Online_Trainer_V7.video_guided_explore samples a round as ONE batched call (explore_batched, default)",
                                     "steps_per_sec_incl_sampling_rollouts_one_by_one": every / (every * ms * 1e-3 + t1),
                                     "steps_per_sec_incl_sampling_one_b8_call": every / (every * ms * 1e-3 + t8),
                                     "sampler_seconds_per_round_one_by_one": t1, "sampler_seconds_per_round_b8": t8}

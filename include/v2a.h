@@ -189,7 +189,11 @@ int v2a_video_denoise_step(const float* v, const float* v_uncond, const float* i
 int v2a_video_denoise_row_bytes(void);
 int v2a_video_denoise_step2(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                             int frame_ch, int objective, const void* table_dev, const uint64_t* state_dev, int step_imm, int use_philox,
-                            v2a_stream_t s);
+                            const uint64_t* row_seeds_dev, v2a_stream_t s);
+/* row_seeds_dev (optional, uint64 [B]): one Philox seed per sample instead of state[1] -- row b then draws exactly what a one-row call
+   with seed row_seeds_dev[b] draws, so a batched GoalGaussianDiffusion.sample reproduces its rows sampled one at a time (the
+   exploration round of lb_online_trainer_v7.py:866-891 as ONE call); v2a_philox_normal_rows draws the initial image the same way. */
+int v2a_philox_normal_rows(float* out, int rows, size_t row_elems, const uint64_t* seeds_dev, uint64_t offset_imm, v2a_stream_t s);
 /* state_dev[0] += 1; tt[0..B) = t of the new row (the time step the next UNet forward embeds) */
 int v2a_video_sampler_advance(uint64_t* state_dev, const void* table_dev, int64_t* tt, int B, int nrows, v2a_stream_t s);
 /* out_i = x W_i^T + bias_i for n <= v2a_emb_linear_multi_max() weight matrices sharing x [B <= 16][K]: the per-ResBlock `emb_layers`

@@ -141,6 +141,40 @@ def _build_trainer(tmp_path, tasks=2, **over):
 
 
 @pytest.mark.gpu
+def test_batched_exploration_round_equals_the_one_by_one_rows(tmp_path):
+    """LB_Online_Trainer_V7.video_guided_explore samples the goal frames of ALL of a round's combinations in ONE
+    batched sampler call (one Philox seed per row).  The same round with the rows sampled through bs-1 calls (same token rows, same
+    seeds: trainer_dict['_explore_rows_one_by_one']) must give the same initial noise bit for bit, the same frames up to the kernels'
+    batch-size-dependent summation order, and the same number of episodes; the reference's one-at-a-time order (explore_batched=False)
+    still runs."""
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    vids, eps = {}, {}
+    for mode in ("batched", "rows", "reference"):
+        over = {"batched": {}, "rows": {"_explore_rows_one_by_one": True}, "reference": {"explore_batched": False}}[mode]
+        tr, ds, dp, video = _build_trainer(tmp_path / mode, tasks=3, **over)
+        torch.manual_seed(11); torch.cuda.manual_seed(11); np.random.seed(11); random.seed(11)
+        tr.video_guided_explore()
+        assert len(tr.envBuf_vid) == 3 and tr.cnt_vid_rollouts == 3
+        vids[mode] = getattr(tr, "_last_explore_videos", None)
+        eps[mode] = tr.envBuf_vid.episode_lengths().copy()
+        del tr, ds, dp, video
+        torch.cuda.empty_cache()
+    a, b = vids["batched"], vids["rows"]
+    assert a.shape == b.shape == (3, 7, 3, 128, 128) and vids["reference"] is None
+    d = float((a - b).abs().max())
+    print(f"[batched exploration] frames of the B = 3 call vs three bs-1 calls: max |diff| {d:.2e}")
+    assert d <= 1e-4, d
+    assert float((a[0] - a[1]).abs().max()) > 1e-2                     # (the rows do differ from each other)
+    # one Philox seed per row: a batched draw reproduces the one-row draws bit for bit
+    from v2a_hip import ops
+    seeds = torch.tensor([5, 6, 7], dtype=torch.int64, device="cuda:0")
+    z3 = ops.philox_normal_rows(torch.empty(3, 21, 128, 128, device="cuda:0"), seeds)
+    for j in range(3):
+        z1 = ops.philox_normal_rows(torch.empty(1, 21, 128, 128, device="cuda:0"), seeds[j:j + 1])
+        assert torch.equal(z1[0], z3[j]) and torch.equal(ops.philox_normal(torch.empty(21, 128, 128, device="cuda:0"), int(seeds[j])), z3[j])
+
+
+@pytest.mark.gpu
 def test_joint_loop_train_rollout_checkpoint_eval(tmp_path):
     tr, ds, dp, video = _build_trainer(tmp_path)
     # the entry script's smoke test (scripts/train_libero_dp.py:126-135): autograd loss through the plugin + opt.zero_grad

@@ -367,6 +367,27 @@ __global__ void philox_normal_kernel(float* out, size_t n, uint64_t seed, const 
             if (q * 4 + j < n) out[q * 4 + j] = z[j];
     }
 }
+// the same generator with ONE SEED PER ROW of a [rows][row_elems] tensor (row_elems % 4 == 0): element e of row b = the value
+// v2a_philox_normal(seeds[b], offset + e / 4) writes -- row b of a batched draw equals the draw of a one-row call with that seed
+__global__ void philox_normal_rows_kernel(float* out, int rows, size_t nq_row, const uint64_t* seeds, uint64_t off) {
+    const size_t n4 = (size_t)rows * nq_row;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+        const size_t b = q / nq_row, qq = q - b * nq_row;
+        const uint64_t ctr = off + qq, seed = seeds[b];
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;
+            const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+            const float rr = sqrtf(-2.0f * logf(u1));
+            out[q * 4 + 2 * h] = rr * cosf(6.283185307179586f * u2);
+            out[q * 4 + 2 * h + 1] = rr * sinf(6.283185307179586f * u2);
+        }
+    }
+}
 __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t ctr, float (&z)[4]) {
     uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
     uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -392,7 +413,7 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t ctr, floa
 struct DenoiseRow { float sa, s1, ra, rm, c1, c2, sigma, gw; int mode, final, t, pad; };
 __global__ void video_denoise_kernel2(const float* v, const float* v_u, const float* img, const float* noise, float* out, int B, int f,
                                       int HW, int ci, int objective, const DenoiseRow* table, const uint64_t* state, int step_imm,
-                                      int use_philox) {
+                                      int use_philox, const uint64_t* row_seeds) {
     const uint64_t step = state ? state[0] : (uint64_t)step_imm;
     const DenoiseRow k = table[step];
     const size_t total = (size_t)B * f * ci * HW;
@@ -400,9 +421,16 @@ __global__ void video_denoise_kernel2(const float* v, const float* v_u, const fl
     const bool draw = use_philox && !noise && k.sigma != 0.f && k.mode != 2;
     const uint64_t seed = (state && use_philox) ? state[1] : 0ull;
     const uint64_t ctr0 = (state && use_philox) ? state[2] + (step + 1) * (uint64_t)nq : 0ull;
+    // row_seeds (one Philox seed per sample; the row length is a multiple of 4): row b draws what a ONE-row call with seed row_seeds[b]
+    // draws -- counters state[2] + (step + 1) * nq_row + q_row -- so a batched sample() reproduces its rows sampled one at a time
+    const size_t nq_row = ((size_t)f * ci * HW) >> 2;
+    const uint64_t ctr0r = (state && use_philox) ? state[2] + (step + 1) * (uint64_t)nq_row : 0ull;
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (draw) philox_normal4(seed, ctr0 + q, z);
+        if (draw) {
+            if (row_seeds) { const size_t b = q / nq_row; philox_normal4(row_seeds[b], ctr0r + (q - b * nq_row), z); }
+            else philox_normal4(seed, ctr0 + q, z);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const size_t i = q * 4 + e;
@@ -722,14 +750,15 @@ int v2a_video_denoise_row_bytes(void) { return (int)sizeof(DenoiseRow); }
 // seed, Philox counter of the initial image} or null (then row `step_imm`, no in-kernel noise).  `out` may alias `img`.
 int v2a_video_denoise_step2(const float* v, const float* v_uncond, const float* img, const float* noise, float* out, int B, int f, int HW,
                             int frame_ch, int objective, const void* table_dev, const uint64_t* state_dev, int step_imm, int use_philox,
-                            hipStream_t s) {
+                            const uint64_t* row_seeds_dev, hipStream_t s) {
     if (!v || !img || !out || !table_dev || objective < 0 || objective > 2) return V2A_ERR_ARG;
+    if (row_seeds_dev && (((size_t)f * frame_ch * HW) & 3)) return V2A_ERR_ARG;        // per-row seeds: whole 4-element draws per row
     // use_philox: bit 0 = draw the noise in the kernel; bit 1 = the device table holds guided rows (gw > 0) -- the host cannot read
     // the table, so the caller says so, and the unconditional half is then mandatory (the kernel would dereference null)
     if ((use_philox & 2) && !v_uncond) return V2A_ERR_ARG;
     const size_t total = (size_t)B * f * frame_ch * HW;
     hipLaunchKernelGGL(video_denoise_kernel2, GRID_FOR((total + 3) / 4), dim3(256), 0, s, v, (use_philox & 2) ? v_uncond : nullptr, img, noise,
-                       out, B, f, HW, frame_ch, objective, (const DenoiseRow*)table_dev, state_dev, step_imm, use_philox & 1);
+                       out, B, f, HW, frame_ch, objective, (const DenoiseRow*)table_dev, state_dev, step_imm, use_philox & 1, row_seeds_dev);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -766,6 +795,13 @@ int v2a_emb_linear_multi(const float* x, int B, int K, const float* const* w, co
 }
 int v2a_philox_normal(float* out, size_t n, uint64_t seed, const uint64_t* offset_dev, uint64_t offset_imm, hipStream_t s) {
     hipLaunchKernelGGL(philox_normal_kernel, GRID_FOR((n + 3) / 4), dim3(256), 0, s, out, n, seed, offset_dev, offset_imm);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
+int v2a_philox_normal_rows(float* out, int rows, size_t row_elems, const uint64_t* seeds_dev, uint64_t offset_imm, hipStream_t s) {
+    if (!out || !seeds_dev || rows < 1 || row_elems == 0 || (row_elems & 3)) return V2A_ERR_ARG;
+    hipLaunchKernelGGL(philox_normal_rows_kernel, GRID_FOR((size_t)rows * (row_elems / 4)), dim3(256), 0, s, out, rows, row_elems / 4, seeds_dev,
+                       offset_imm);
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }

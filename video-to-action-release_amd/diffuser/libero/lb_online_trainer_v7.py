@@ -224,7 +224,7 @@ class LB_Online_Trainer_V7(object):
 
         dl = DataLoader(self.train_set, batch_size=train_batch_size, shuffle=True, num_workers=0)
         self.dl = cycle(dl)
-        assert video_batch_size == 1
+        assert video_batch_size == 1                 # (the DataLoader's batch, as in the reference; the exploration round batches the SAMPLER itself)
         mine = list(range(acc.process_index, len(self.train_set), acc.num_processes))     # this rank's rollout combinations
         self.dl_vid = DataLoader(Subset(self.train_set, mine), batch_size=video_batch_size, shuffle=True, num_workers=0)
 
@@ -536,24 +536,59 @@ class LB_Online_Trainer_V7(object):
 
     # ------------------------------------------------------------------------------------------- video-guided exploration
     def video_guided_explore(self):
-        """One exploration round (reference :859-938): for every (task, camera, env) combination of this rank -- one at a time, as
-        the reference does -- sample the 7 goal frames from the current render (HIP UNet sampler), follow them (lb_rollout.py) and
-        push the episode into envBuf_vid."""
+        """One exploration round (reference :859-938): for every (task, camera, env) combination of this rank sample the 7 goal frames from
+        the current render (HIP UNet sampler), follow them with the EMA policy (lb_rollout.py) and push the episode into envBuf_vid.
+
+        trainer_dict['explore_batched'] (default True): the round's sampler calls run as ONE batched call -- every combination's environment
+        is created and rendered first, `video_model.forward` runs once at B = number of combinations (rows are independent: per-sample
+        GroupNorm, per-frame attention; one Philox seed per row, so row j draws exactly the noise of the bs-1 call with that seed and
+        its frames equal that call's up to the kernels' batch-size-dependent summation order, <= 1e-4 in fp32: tests/test_joint_loop.py),
+        then the rollouts run in the same order.  2.3 s instead of 5.2 s of sampling per 8-task round
+        (bench.py `video_round8`).  What differs from the reference's one-at-a-time loop: the task strings of a round are tokenised as
+        one padded batch, and the host generators see the round's environment draws before its rollout draws.  False: the reference's
+        order, one combination at a time."""
         self.env_list.check_no_envs_exist()
         n_before = len(self.envBuf_vid)
         utils.print_color(f'[Vid Exp] self.step {self.step}', c='y')
-        for tasks, cams, idxs in self.dl_vid:
-            tasks, cams, idxs = list(tasks), list(cams), idxs.cpu().numpy()
-            if len(tasks) != 1:
-                raise AssertionError("rollouts run one combination at a time (video_batch_size == 1)")
-            self.env_list.init_1_given_env(tk_name=tasks[0], env_idx=idxs[0], is_rand=True)
-            start = self.env_get_preproc_imgs(tasks, cams, idxs)
+        if self.trainer_dict.get('explore_batched', True):
+            combos = []
+            for tasks, cams, idxs in self.dl_vid:
+                tasks, cams, idxs = list(tasks), list(cams), idxs.cpu().numpy()
+                combos += [(tasks[i], cams[i], idxs[i]) for i in range(len(tasks))]
+            starts = []
+            for tk, cam, idx in combos:
+                self.env_list.init_1_given_env(tk_name=tk, env_idx=idx, is_rand=True)
+                starts.append(self.env_get_preproc_imgs([tk], [cam], [idx]))
+            start_all = torch.cat(starts, dim=0)
+            all_tasks = [c[0] for c in combos]
+            from flowdiffusion.flowdiffusion.goal_diffusion import _draw_philox_seed
+            seeds = [_draw_philox_seed(self.device) for _ in combos]          # one sampler seed per combination, in round order
+            from ..models.video_model import _spaced
             with torch.no_grad():
-                video = self.video_model.forward(start.to(self.device), tasks)
-            frames, acts = self.envs_video_guided_execute(tasks, cams, idxs, start, video)
-            self.env_list.close_1_given_env(tk_name=tasks[0], env_idx=idxs[0])
-            for i, tk in enumerate(tasks):
-                self.envBuf_vid.add_one_episode(tk, cams[i], idxs[i], frames[i], acts[i])
+                emb = self.video_model.encode_batch_text(_spaced(all_tasks))      # (one padded token batch for the round)
+                if not self.trainer_dict.get('_explore_rows_one_by_one'):
+                    videos = self.video_model.forward(start_all.to(self.device), emb, row_seeds=seeds)
+                else:     # test hook: the same rows through bs-1 calls (same token rows, same seeds) -- must give the same frames
+                    videos = torch.cat([self.video_model.forward(start_all[j:j + 1].to(self.device), emb[j:j + 1], row_seeds=seeds[j:j + 1])
+                                        for j in range(len(combos))], dim=0)
+            self._last_explore_videos = videos
+            for j, (tk, cam, idx) in enumerate(combos):
+                frames, acts = self.envs_video_guided_execute([tk], [cam], [idx], start_all[j:j + 1], videos[j:j + 1])
+                self.env_list.close_1_given_env(tk_name=tk, env_idx=idx)
+                self.envBuf_vid.add_one_episode(tk, cam, idx, frames[0], acts[0])
+        else:
+            for tasks, cams, idxs in self.dl_vid:
+                tasks, cams, idxs = list(tasks), list(cams), idxs.cpu().numpy()
+                if len(tasks) != 1:
+                    raise AssertionError("rollouts run one combination at a time (video_batch_size == 1)")
+                self.env_list.init_1_given_env(tk_name=tasks[0], env_idx=idxs[0], is_rand=True)
+                start = self.env_get_preproc_imgs(tasks, cams, idxs)
+                with torch.no_grad():
+                    video = self.video_model.forward(start.to(self.device), tasks)
+                frames, acts = self.envs_video_guided_execute(tasks, cams, idxs, start, video)
+                self.env_list.close_1_given_env(tk_name=tasks[0], env_idx=idxs[0])
+                for i, tk in enumerate(tasks):
+                    self.envBuf_vid.add_one_episode(tk, cams[i], idxs[i], frames[i], acts[i])
         utils.print_color(f'Finish Vid Explore, vid buf before: {n_before}, after: {len(self.envBuf_vid)}')
         self.env_list.check_no_envs_exist()
 

@@ -65,12 +65,14 @@ class Video_PredModel(nn.Module):
         tok = self.tokenizer(batch_text, return_tensors="pt", padding=True, truncation=True, max_length=128).to(self.device)
         return self.text_encoder(**tok).last_hidden_state
 
-    def forward(self, x_conds, tasks):
+    def forward(self, x_conds, tasks, row_seeds=None):
+        """row_seeds (extension): one sampler seed per row, see GoalGaussianDiffusion.sample."""
         n = x_conds.shape[0]
         if n != len(tasks):
             raise ValueError(f"{n} conditioning images for {len(tasks)} tasks")
         tokens = tasks if torch.is_tensor(tasks) else self.encode_batch_text(_spaced(tasks))
-        frames = self.ema.ema_model.sample(batch_size=n, x_cond=x_conds.to(self.device), task_embed=tokens.to(self.device))
+        kw = {} if row_seeds is None else {"row_seeds": row_seeds}
+        frames = self.ema.ema_model.sample(batch_size=n, x_cond=x_conds.to(self.device), task_embed=tokens.to(self.device), **kw)
         b, c, h, w = frames.shape
         return frames.view(b, c // self.single_img_channels, self.single_img_channels, h, w).detach()
 

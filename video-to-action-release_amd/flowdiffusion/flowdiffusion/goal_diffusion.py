@@ -195,7 +195,7 @@ class GoalGaussianDiffusion(nn.Module):
         return sum(p._version for p in self.model.parameters()) + sum(b._version for b in self.buffers())
 
     @torch.no_grad()
-    def _sample_loop(self, shape, x_cond, task_embed, return_all_timesteps=False):
+    def _sample_loop(self, shape, x_cond, task_embed, return_all_timesteps=False, row_seeds=None):
         """Both sampling loops of the reference (p_sample_loop :582-599, ddim_sample :601-641) for all three objectives
         (model_predictions :499-559).  Per step: one HIP UNet forward (two with classifier-free guidance) + ONE table-driven denoise
         kernel.  Default path: the step {pack, UNet, denoise, advance} is captured ONCE into a hipGraph and replayed for every step of
@@ -217,11 +217,17 @@ class GoalGaussianDiffusion(nn.Module):
         hook = self.__dict__.get("_noise_hook")
         use_graph = hook is None and not return_all_timesteps and self.__dict__.get("_use_graph", True) and v2a_hip.sampler_graphs_enabled()
         nq = (B * C * H * W + 3) // 4
+        rs = None
         if hook is None:
             # sampler noise = counter-based Philox, seeded from torch's generator (torch.manual_seed reproduces a call); the initial
             # image uses counters [off0, off0 + nq), step s the next block -- drawn inside the denoise kernel
-            seed = _draw_philox_seed(device)
+            seed = _draw_philox_seed(device) if row_seeds is None else 0
             off0 = 0
+            if row_seeds is not None:                    # one seed per sample (see sample()): counters run per row
+                rs = torch.as_tensor([int(v) & ((1 << 62) - 1) for v in row_seeds], dtype=torch.int64).to(device)
+                assert rs.numel() == B and (C * H * W) % 4 == 0
+        elif row_seeds is not None:
+            raise ValueError("row_seeds and an injected noise stream (_noise_hook) exclude each other")
         if not use_graph:
             label = eng.label_embedding(task_embed)                               # t-independent: once per call
             label_u = eng.label_embedding(torch.zeros_like(task_embed)) if gw > 0.0 else None
@@ -229,7 +235,10 @@ class GoalGaussianDiffusion(nn.Module):
             state = None
             if hook is None:
                 img = torch.empty(shape, dtype=torch.float32, device=device)
-                ops.philox_normal(img, seed, offset_imm=off0)
+                if rs is not None:
+                    ops.philox_normal_rows(img, rs, offset_imm=off0)
+                else:
+                    ops.philox_normal(img, seed, offset_imm=off0)
                 state = torch.tensor([0, seed, off0], dtype=torch.int64, device=device)
             else:
                 img = self._noise(shape, device)
@@ -250,7 +259,7 @@ class GoalGaussianDiffusion(nn.Module):
                 if state is not None:
                     state[0] = i
                 img = ops.video_denoise_step2(v, vu, img, noise, table, self.objective, f, H * W, ci, state=state, step=i,
-                                              use_philox=hook is None, guided=gw > 0.0)
+                                              use_philox=hook is None, guided=gw > 0.0, row_seeds=rs)
                 imgs.append(img)
             if return_all_timesteps:
                 ret = torch.stack(imgs, dim=1)
@@ -258,7 +267,7 @@ class GoalGaussianDiffusion(nn.Module):
             return img
         # ---- whole-loop hipGraph
         key = (B, C, H, W, ci, gw > 0.0, self.objective, getattr(eng, "storage", "f32"), v2a_hip.get_precision(), tuple(task_embed.shape),
-               id(eng), len(rows), self._weights_version())
+               id(eng), len(rows), rs is not None, self._weights_version())
         ent = _SGRAPHS.get(self)
         if ent is None:
             ent = _SGRAPHS[self] = {"lru": {}, "graph": None}
@@ -269,7 +278,7 @@ class GoalGaussianDiffusion(nn.Module):
                 del lru[k]
             while len(lru) >= _SGRAPH_KEEP:                    # least recently used first (dict order = use order)
                 del lru[next(iter(lru))]
-            g = self._build_sampler_graph(key, eng, shape, ci, f, task_embed.shape, gw)
+            g = self._build_sampler_graph(key, eng, shape, ci, f, task_embed.shape, gw, rs is not None)
         lru[key] = g
         ent["graph"] = g["graph"]                              # the graph this call replays (tests look at it)
         g["x_cond"].copy_(x_cond)
@@ -279,12 +288,16 @@ class GoalGaussianDiffusion(nn.Module):
         ops.video_denoise_table(rows, device, out=g["table"])
         g["state"].copy_(torch.tensor([0, seed, off0], dtype=torch.int64))
         g["tt"].fill_(rows[0][10])
-        ops.philox_normal(g["img"], seed, offset_imm=off0)
+        if rs is not None:
+            g["row_seeds"].copy_(rs)
+            ops.philox_normal_rows(g["img"], g["row_seeds"], offset_imm=off0)
+        else:
+            ops.philox_normal(g["img"], seed, offset_imm=off0)
         for _ in range(len(rows)):
             g["graph"].replay()
         return g["img"].clone()
 
-    def _build_sampler_graph(self, key, eng, shape, ci, f, te_shape, gw):
+    def _build_sampler_graph(self, key, eng, shape, ci, f, te_shape, gw, per_row=False):
         from v2a_hip import ops
         device = self.betas.device
         B, C, H, W = shape
@@ -294,7 +307,8 @@ class GoalGaussianDiffusion(nn.Module):
                  x_cond=torch.zeros((B, 3, H, W), dtype=torch.float32, device=device),
                  task_embed=torch.full(te_shape, float("nan"), dtype=torch.float32, device=device),
                  table=torch.zeros((MAXR, 12), dtype=torch.float32, device=device), state=torch.zeros(3, dtype=torch.int64, device=device),
-                 tt=torch.zeros(B, dtype=torch.long, device=device))
+                 tt=torch.zeros(B, dtype=torch.long, device=device),
+                 row_seeds=torch.zeros(B, dtype=torch.int64, device=device) if per_row else None)
         te0 = torch.zeros(te_shape, dtype=torch.float32, device=device)
         g["label"] = eng.label_embedding(te0).clone()
         g["label_u"] = eng.label_embedding(te0).clone() if gw > 0.0 else None          # the unconditional branch embeds zeros (:504-506)
@@ -304,7 +318,7 @@ class GoalGaussianDiffusion(nn.Module):
             v = eng.forward_cl(xin, g["tt"], g["label"])
             vu = eng.forward_cl(xin, g["tt"], g["label_u"]) if gw > 0.0 else None
             ops.video_denoise_step2(v, vu, g["img"], None, g["table"], self.objective, f, H * W, ci, state=g["state"], use_philox=True, out=g["img"],
-                                    guided=gw > 0.0)
+                                    guided=gw > 0.0, row_seeds=g["row_seeds"])
             ops.video_sampler_advance(g["state"], g["table"], g["tt"], nrows)        # the real row count: the last replay re-reads the last row
 
         rows = self._step_rows(False)
@@ -329,9 +343,14 @@ class GoalGaussianDiffusion(nn.Module):
         return self._sample_loop(shape, x_cond, task_embed, return_all_timesteps)
 
     @torch.no_grad()
-    def sample(self, x_cond, task_embed, batch_size=16, return_all_timesteps=False):
+    def sample(self, x_cond, task_embed, batch_size=16, return_all_timesteps=False, row_seeds=None):
+        """row_seeds (extension; list / tensor of batch_size ints): one Philox seed per sample instead of one per call -- row b then draws
+        exactly the noise of sample(x_cond[b:b+1], task_embed[b:b+1], 1, row_seeds=[row_seeds[b]]) (and equals its result up to the
+        batch-size-dependent summation order of the conv kernels' split plans), so the trainer's exploration round
+        (lb_online_trainer_v7.py:866-891, one task at a time in the reference) can run as ONE batched call."""
         image_size, channels = self.image_size, self.channels
-        return self._sample_loop((batch_size, channels, image_size[0], image_size[1]), x_cond, task_embed, return_all_timesteps)
+        return self._sample_loop((batch_size, channels, image_size[0], image_size[1]), x_cond, task_embed, return_all_timesteps,
+                                 row_seeds=row_seeds)
 
     # ------------------------------------------------------------------ training (reference :674-724)
     def predict_v(self, x_start, t, noise):

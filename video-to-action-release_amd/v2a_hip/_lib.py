@@ -90,11 +90,12 @@ SIGNATURES = {
     "v2a_video_loss_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "v2a_video_denoise_step": (I, [P, P, P, P, P, I, I, I, F, F, F, F, F, F, F, F, I, I, I, P]),
     "v2a_video_denoise_row_bytes": (I, []),
-    "v2a_video_denoise_step2": (I, [P, P, P, P, P, I, I, I, I, I, P, P, I, I, P]),
+    "v2a_video_denoise_step2": (I, [P, P, P, P, P, I, I, I, I, I, P, P, I, I, P, P]),
     "v2a_video_sampler_advance": (I, [P, P, P, I, I, P]),
     "v2a_emb_linear_multi_max": (I, []),
     "v2a_emb_linear_multi": (I, [P, I, I, P, P, P, P, I, P]),
     "v2a_philox_normal": (I, [P, SZ, U64, P, U64, P]),
+    "v2a_philox_normal_rows": (I, [P, I, SZ, P, U64, P]),
     "v2a_philox_randint": (I, [P, I, I, U64, P, U64, P]),
     "v2a_advance_counter": (I, [P, U64, P]),
     "v2a_debug_timestamp": (I, [P, P]),

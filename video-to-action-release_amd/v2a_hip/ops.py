@@ -1230,6 +1230,14 @@ def philox_normal(out, seed, offset_dev=None, offset_imm=0):
     return out
 
 
+def philox_normal_rows(out, seeds, offset_imm=0):
+    """out [rows, ...] ~ N(0, 1) with one Philox seed per row (seeds: int64 device tensor [rows]): row b = philox_normal of a one-row call
+    with seed seeds[b]."""
+    rows = out.shape[0]
+    check(lib.v2a_philox_normal_rows(out.data_ptr(), rows, out.numel() // rows, seeds.data_ptr(), offset_imm, _stream()), "philox_normal_rows")
+    return out
+
+
 def philox_randint(out, high, seed, offset_dev=None, offset_imm=0):
     check(lib.v2a_philox_randint(out.data_ptr(), out.numel(), high, seed, _p(offset_dev), offset_imm, _stream()), "philox_randint")
     return out
@@ -1302,7 +1310,8 @@ def video_denoise_table(rows, device, out=None):
     return out
 
 
-def video_denoise_step2(v, v_uncond, img, noise, table, objective, f, HW, ci=3, state=None, step=0, use_philox=False, out=None, guided=None):
+def video_denoise_step2(v, v_uncond, img, noise, table, objective, f, HW, ci=3, state=None, step=0, use_philox=False, out=None, guided=None,
+                        row_seeds=None):
     """One table-driven sampler step (csrc/elementwise.hip video_denoise_kernel2).  state: uint64[3] device tensor {row, seed, counter}
     (row index and Philox state read on the device) or None (row `step`).  out=img updates the sampler state in place.
     guided: the table's rows carry a guidance weight > 0 (default: whether v_uncond was given) -- then v_uncond is mandatory and the C
@@ -1314,7 +1323,7 @@ def video_denoise_step2(v, v_uncond, img, noise, table, objective, f, HW, ci=3, 
         guided = v_uncond is not None
     flags = (1 if use_philox else 0) | (2 if guided else 0)
     check(lib.v2a_video_denoise_step2(v.data_ptr(), _p(v_uncond), img.data_ptr(), _p(noise), out.data_ptr(), B, f, HW, ci,
-                                      _OBJECTIVES[objective], table.data_ptr(), _p(state), int(step), flags, _stream()),
+                                      _OBJECTIVES[objective], table.data_ptr(), _p(state), int(step), flags, _p(row_seeds), _stream()),
           "video_denoise_step2")
     return out
 
