@@ -573,8 +573,8 @@ class PolicyEngine:
         y, mean, rstd = ops.groupnorm_fwd(x3, self.P[pre + ".weight"], self.P[pre + ".bias"], G, act, residual=r3, film=film, slabs=slabs,
                                           twin_out=tw, post=None if post is None else post.view(N, -1, C), post_slabs=post_slabs,
                                           planes_out=pl)
-        if pl:
-            self._p3[y.data_ptr()] = (pl[0], y.numel())
+        if pl:      # (the entry keeps y alive until the pass ends: in an inference pass nothing else does, and a freed address would be handed
+            self._p3[y.data_ptr()] = (pl[0], y.numel(), y)      # to some other tensor that must not inherit these planes)
         self._set_tw(tw[0] if tw else None, y)       # taken by the caller right after (x_h of the next conv): no cast launch
         return y.view(x4.shape), (x3, mean, rstd, r3, film, pre, G, act)
 
@@ -608,7 +608,7 @@ class PolicyEngine:
                                                       residual=r3, film=film, want_dres=want_dres, want_dfilm=want_dfilm,
                                                       dfilm_out=dfilm_out, colsum=cs, defer_params=True, **kw)
         if pl:
-            self._p3[dx.data_ptr()] = (pl[0], dx.numel())
+            self._p3[dx.data_ptr()] = (pl[0], dx.numel(), dx)
         self._set_tw(tw[0] if tw else None, dx)      # bf16 twin of dx (want_twin): operand of the data / weight gradients that follow
         return dx.view(dout4.shape), (dres.view(dout4.shape) if dres is not None else None), dfilm
 
