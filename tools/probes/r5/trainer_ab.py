@@ -16,6 +16,9 @@ for v in vals * reps:
     store = bench.build_store(torch, "cuda:0", 64, seed=100)
     if where == "engine":
         setattr(pol.engine, attr, v)
+    if where == "ops":
+        from v2a_hip import ops
+        getattr(ops, attr)[0] = v
     tr = PolicyTrainer(pol, store, batch_size=64, seed=0, use_graph=True)
     if where == "trainer":
         setattr(tr, attr, v)
