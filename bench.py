@@ -129,7 +129,7 @@ def _emit(out):
     print(txt)
 
 
-def _graph_avg_us(kernel_prefix, csv_name="r04_policy_kernel_stats.csv"):
+def _graph_avg_us(kernel_prefix, csv_name="r05_policy_kernel_stats.csv"):
     """Average duration (us) of the launches whose name starts with kernel_prefix in the committed rocprofv3 --kernel-trace --stats summary
     of the captured step (profiles/): the figure INSIDE the replayed graph, next to the eager-pass figure this run measures."""
     import csv
