@@ -652,6 +652,7 @@ def main():
     ap.add_argument("--video-batch", type=int, default=16)
     ap.add_argument("--video-steps", type=int, default=50)
     ap.add_argument("--video-reps", type=int, default=3)
+    ap.add_argument("--watchdog", type=int, default=0, help="seconds after which every rank dumps its Python stacks to stderr and exits (0: off)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -666,6 +667,9 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))))
 
+    if args.watchdog > 0:                                  # in the ranks, not in the launcher above
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -736,41 +740,92 @@ def main():
 
     for _ in range(max(args.warmup, 3)):       # >= 3: two eager steps + the capture step
         tr.step()
+
+    # ---- which gradient exchange the timed steps run on (comm.algo).  The two slice all-reduces alone (nothing to hide under), blocking,
+    # 5 rounds, through the process group (RCCL on a node); if that moves the 349 MB below DIRECT_BELOW_GBPS of bus bandwidth -- a ring on
+    # the xGMI mesh is bound by ONE link per direction, ~153 GB/s peak, SURVEY.md section 5 -- the peer-pointer exchange (v2a_hip/dp.py
+    # algo="direct", csrc/dp.hip) is connected and measured the same way, and the faster of the two carries the timed steps.  Every number
+    # a decision hangs on is a max over ranks, so all ranks decide alike.
+    DIRECT_BELOW_GBPS = 200.0
+    choice = None
+
+    def iso_ms(launch_all):
+        ts = []
+        for _ in range(5):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch_all()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        tr.arena.zero_()
+        return max_over_ranks(_median(ts))
+
+    def busbw(ms_):
+        return tr.reducer.bytes_per_step() * 2.0 * (world - 1) / world / (ms_ * 1e-3) / 1e9
+
+    def pg_all():
+        import torch.distributed as dist
+        for lo, hi in tr.reducer.slices:
+            if hi > lo:
+                dist.all_reduce(tr.arena[lo:hi], op=dist.ReduceOp.SUM, group=pg)
+
+    def direct_all():
+        tr.reducer.launch(0)
+        tr.reducer.launch(1)
+        tr.reducer.finish(lambda scale: None)
+
+    iso_pg = iso_direct = None
+    if tr.dp:
+        iso_pg = iso_ms(pg_all)
+        if world > 1:
+            choice = {"threshold_busbw_GBps": DIRECT_BELOW_GBPS, "process_group_busbw_GBps": busbw(iso_pg), "picked": "rccl",
+                      "rule": "process group below the threshold -> connect the peer-pointer exchange, measure it alike, keep the faster"}
+            if busbw(iso_pg) < DIRECT_BELOW_GBPS:
+                try:
+                    tr.set_dp_algo("direct")                   # raises on every rank or on none
+                    for _ in range(2):
+                        tr.step()
+                    iso_direct = iso_ms(direct_all)
+                    torch.cuda.synchronize()
+                    tr.reducer.check()
+                    choice["direct_busbw_GBps"] = busbw(iso_direct)
+                    if iso_direct < iso_pg:
+                        choice["picked"] = "direct"
+                    else:
+                        tr.set_dp_algo("rccl")
+                except RuntimeError as e:
+                    choice["direct_error"] = str(e)[:400]
+                    if tr.reducer.algo != "rccl":
+                        tr.set_dp_algo("rccl")
     if tr.dp:
         tr.comm_events = []
     dt, med_ms = _timed_policy_steps(torch, tr, args.steps, barrier)
     dt = max_over_ranks(dt)
     comm = None
     if tr.dp:
-        import torch.distributed as dist
-        # exposed communication: how long the compute stream sat in its wait on the communicator, per step (HIP events recorded on
-        # the launch stream right before / after GradReducer.finish)
+        if tr.reducer.algo == "direct":
+            torch.cuda.synchronize()
+            tr.reducer.check()
+        # exposed communication: how long the compute stream sat in its wait on the exchange, per step (HIP events recorded on the launch
+        # stream right before / after GradReducer.finish; with the direct exchange the wait is the join with the side stream of slice 0)
         exposed = [a.elapsed_time(b) for a, b in tr.comm_events]
         tr.comm_events = None
-        # the two slice all-reduces alone (nothing to hide under): blocking, 5 rounds
-        iso = []
-        for _ in range(5):
-            barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for lo, hi in tr.reducer.slices:
-                if hi > lo:
-                    dist.all_reduce(tr.arena[lo:hi], op=dist.ReduceOp.SUM, group=pg)
-            e1.record()
-            torch.cuda.synchronize()
-            iso.append(e0.elapsed_time(e1))
-        tr.arena.zero_()
         nbytes = tr.reducer.bytes_per_step()
-        iso_ms = _median(iso)
-        comm = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else "gloo (ranks share a GPU: RCCL needs one device per rank)",
+        iso_used = iso_direct if tr.reducer.algo == "direct" else iso_pg
+        comm = {"algo": tr.reducer.algo,
+                "backend": ("peer pointers (hipIpc), csrc/dp.hip; handles exchanged through " + backend) if tr.reducer.algo == "direct"
+                else ("rccl (torch.distributed nccl)" if backend == "nccl" else "gloo (ranks share a GPU: RCCL needs one device per rank)"),
+                "choice": choice,
                 "rccl_ranks": world if backend == "nccl" else 0, "ranks": world, "physical_gpus": min(world, ndev),
                 "allreduce_bytes_per_step": nbytes, "slices": [hi - lo for lo, hi in tr.reducer.slices],
-                "allreduce_ms_isolated": iso_ms,
-                "allreduce_busbw_GBps": (nbytes * 2.0 * (world - 1) / max(world, 1) / (iso_ms * 1e-3) / 1e9) if world > 1 else None,
+                "allreduce_ms_isolated": iso_used,
+                "allreduce_busbw_GBps": busbw(iso_used) if world > 1 else None,
                 "exposed_comm_ms_per_step": sum(exposed) / max(len(exposed), 1),
-                "algo": _rccl_algo(rccl_log) if (backend == "nccl" and rccl_log) else None,
+                "rccl_algo": _rccl_algo(rccl_log) if (backend == "nccl" and rccl_log) else None,
                 "note": "slice 0 (ConditionalUnet1D gradients) is launched after backward phase 1 and travels under the image-encoder "
-                        "backward; exposed = compute-stream wait on the communicator, measured with HIP events inside the timed steps"}
+                        "backward; exposed = compute-stream wait on the exchange, measured with HIP events inside the timed steps"}
     loss = float(tr.loss.item())
 
     out = None

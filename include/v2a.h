@@ -454,6 +454,32 @@ int v2a_wgrad_multi_max(void);
 int v2a_wgrad_family(int variant);   /* kernel family of a described gradient (one family per v2a_conv2d_wgrad_multi launch): 0 exact 64x64 / twin-fed, 1 halo, 2 / 3 three-bf16-plane 64x64 / 128x128 */
 int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* tiles, int n, v2a_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------- direct gradient exchange (csrc/dp.hip)
+ * The second algorithm behind the data-parallel gradient all-reduce of the policy step (reference: torch DDP through accelerator.prepare,
+ * diffuser/libero/lb_online_trainer_v7.py:153-154; its hooks reduce inside accelerator.backward :604, before clip_grad_norm_ :608): a
+ * reduce-scatter + all-gather over hipIpc peer pointers in one stream-ordered launch per arena slice, for a node where RCCL would run the
+ * 349 MB message over a ring.  Sums are taken in rank order on the chunk's owner, so every rank ends with bit-identical gradients.
+ * Host side: v2a_hip/dp.py GradReducer(algo="direct"). */
+int v2a_dp_max_world(void);                        /* ranks one launch can connect (8: one xGMI node) */
+int v2a_dp_slots(void);                            /* independent flag sets = arena slices that may be in flight together */
+size_t v2a_dp_signal_bytes(void);
+int v2a_dp_arena_alloc(void** arena_out, size_t bytes);   /* a gradient arena as an allocation of its own (zeroed): the unit the peers map */
+int v2a_dp_arena_free(void* arena);
+int v2a_dp_signal_alloc(void** sig_out);           /* this rank's flag block: uncached device memory, zeroed */
+int v2a_dp_signal_free(void* sig);
+int v2a_dp_errword_alloc(int** word_out);          /* 16 pinned host ints the kernel raises: [0] 0 fine / 1 + p: peer p never arrived; [1] slot,
+                                                      [2] flag value awaited (3 * epoch + barrier), [3] workgroup, [4] flag value seen */
+int v2a_dp_errword_free(int* word);
+int v2a_dp_ipc_export(const void* ptr, void* handle64_out, uint64_t* offset_out, uint64_t* alloc_bytes_out);   /* handle of the allocation
+                                                      holding ptr, ptr's offset in it, the allocation's size */
+int v2a_dp_ipc_open(const void* handle64, void** base_out);                          /* map a peer's allocation (once per handle and process) */
+int v2a_dp_ipc_close(void* base);
+/* arenas / signals: HOST arrays of `world` device pointers valid in this process, same peer order on every rank; slot < v2a_dp_slots();
+   epoch = 1, 2, 3 ... per slot, equal on all ranks; blocks: workgroups of the launch (0 = default 64, <= 256), equal on all ranks.
+   Stream-ordered, no host wait. */
+int v2a_dp_allreduce_direct(float* const* arenas, uint32_t* const* signals, int world, int rank, size_t lo, size_t hi, int slot, uint32_t epoch,
+                            int* errword, int timeout_ms, int blocks, v2a_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- random-action episode file (csrc/h5read.hip)
  * Native reader for the HDF5 file of the reference's generator (environment/libero/lb_data/lb_randsam.py:84-104: groups
  * `{task}/{episode}` holding `agentview_image` uint8 [T+1,128,128,3], `action` float [T,7], `ee_poses` float [T+1,3]), replacing the

@@ -310,3 +310,15 @@ def test_world8_sampler_rows_and_exploration_tasks_partition_without_a_collectiv
         cover = sorted(i for r in range(w) for i in range(*shard_rows(16, w, r)))
         assert cover == list(range(16)), (w, cover)
         assert sorted(t for r in range(w) for t in shard_tasks(8, w, r)) == list(range(8))
+
+
+def test_direct_exchange_is_for_hbm_arenas_only():
+    """algo="direct" maps HBM between ranks: a CPU arena is refused at construction (no silent change of algorithm); alloc_arena on the
+    CPU is an ordinary zeroed tensor."""
+    from v2a_hip.dp import GradReducer, alloc_arena
+    a = alloc_arena(100, "cpu")
+    assert a.dtype == torch.float32 and a.numel() == 100 and float(a.abs().sum()) == 0.0
+    with pytest.raises(ValueError, match="HBM"):
+        GradReducer(a, [(0, 100)], None, 1, algo="direct")
+    with pytest.raises(ValueError):
+        GradReducer(a, [(0, 100)], None, 1, algo="ring")

@@ -1,0 +1,254 @@
+"""The direct gradient exchange (GradReducer(algo="direct"): reduce-scatter + all-gather over hipIpc peer pointers, csrc/dp.hip) against
+the torch.distributed all-reduce it stands in for (reference: DDP's gradient all-reduce inside accelerator.backward,
+diffuser/libero/lb_online_trainer_v7.py:153-154,604-608).  A one-GPU box has no second device for RCCL, so two PROCESSES share cuda:0: the
+handles, the mappings, the flag barriers and the kernel are the ones a node runs, only the wires are missing.  Bit-exact: the sum order is
+fixed (rank order on the chunk's owner) and for two ranks a + b has one order."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _init(rank, world, port):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "video-to-action-release_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    return dist
+
+
+def _arena_worker(rank, world, port, q):
+    """Ragged slices, an arena that does not start on a 16-byte boundary, several steps (the flag epochs), both slices in flight on two
+    streams; the expected value is gloo's all-reduce of the same numbers."""
+    try:
+        dist = _init(rank, world, port)
+        from v2a_hip.dp import GradReducer
+        out = []
+        for numel, cut, shift in ((1_000_003, 700_001, 0), (4_099, 5, 1), (87_219_143, 64_836_103, 0), (2_051, 2_051, 3)):
+            back = torch.zeros(numel + 8, dtype=torch.float32, device="cuda:0")
+            arena = back[shift:shift + numel]
+            slices = [(0, cut), (cut, numel)]
+            ref = GradReducer(torch.zeros(numel, dtype=torch.float32, device="cuda:0"), slices, dist.group.WORLD, world, algo="rccl")
+            red = GradReducer(arena, slices, dist.group.WORLD, world, algo="direct", timeout_ms=20000)
+            side = torch.cuda.Stream()
+            for step in range(3):
+                g = torch.Generator(device="cuda:0").manual_seed(1000 * rank + step)
+                x = torch.randn(numel, device="cuda:0", generator=g) * (10.0 ** (step - 1))
+                arena.copy_(x); ref.arena.copy_(x)
+                back[:shift].fill_(7.0); back[shift + numel:].fill_(7.0)          # the exchange must not touch its surroundings
+                torch.cuda.synchronize()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    red.launch(0)                                                 # like the trainer: slice 0 from the side stream
+                red.launch(1)
+                torch.cuda.current_stream().wait_stream(side)
+                red.finish()
+                ref.launch(0); ref.launch(1); ref.finish()
+                torch.cuda.synchronize()
+                red.check()
+                same = bool(torch.equal(arena, ref.arena))
+                untouched = bool((back[:shift] == 7.0).all() and (back[shift + numel:] == 7.0).all())
+                out.append((numel, step, same, untouched, float((arena - ref.arena).abs().max())))
+            red.close()
+        q.put((rank, out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                        # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def _run(worker, args=(), world=2, timeout=600):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 90
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[2] is None, r[2]
+    for p in procs:
+        assert p.exitcode == 0
+    return res
+
+
+def test_direct_exchange_equals_the_all_reduce_bitwise_two_ranks():
+    res = _run(_arena_worker)
+    for rank, out, _ in res:
+        assert len(out) == 12
+        for numel, step, same, untouched, err in out:
+            assert same, f"rank {rank}: arena of {numel} elements, step {step}: differs from the all-reduce by {err}"
+            assert untouched, f"rank {rank}: arena of {numel} elements, step {step}: wrote outside the arena"
+
+
+def _three_worker(rank, world, port, q):
+    """Three ranks: the sum has an order now.  Expected = ((g0 + g1) + g2) / 3 computed from every rank's inputs, identical on all ranks."""
+    try:
+        dist = _init(rank, world, port)
+        from v2a_hip.dp import GradReducer
+        numel = 300_007
+        arena = torch.zeros(numel, dtype=torch.float32, device="cuda:0")
+        red = GradReducer(arena, [(0, 100_001), (100_001, numel)], dist.group.WORLD, world, algo="direct", timeout_ms=20000)
+        ok = []
+        for step in range(2):
+            xs = [torch.randn(numel, generator=torch.Generator().manual_seed(50 * r + step)) * 3.0 for r in range(world)]
+            arena.copy_(xs[rank])
+            red.launch(0); red.launch(1); red.finish()
+            torch.cuda.synchronize()
+            red.check()
+            want = xs[0]
+            for r in range(1, world):
+                want = want + xs[r]
+            want = want * (1.0 / world)                      # finish() without a scale_fn averages in place
+            got = arena.cpu()
+            bad = (got != want).nonzero().flatten()
+            ok.append(True if bad.numel() == 0 else
+                      f"{bad.numel()} elements differ, first at {int(bad[0])}, last at {int(bad[-1])}, max |diff| {float((got - want).abs().max()):.3e}")
+        red.close()
+        q.put((rank, ok, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def test_direct_exchange_three_ranks_sum_in_rank_order():
+    res = _run(_three_worker, world=3)
+    for rank, ok, _ in res:
+        assert ok == [True, True], f"rank {rank}: {ok}"
+
+
+def _lost_rank_worker(rank, world, port, q):
+    """Rank 1 never launches: rank 0's kernel must give up after its budget, terminate, and the host must say which peer was missing."""
+    try:
+        dist = _init(rank, world, port)
+        from v2a_hip.dp import GradReducer
+        arena = torch.ones(10_000, dtype=torch.float32, device="cuda:0")
+        red = GradReducer(arena, [(0, 10_000)], dist.group.WORLD, world, algo="direct", timeout_ms=300)
+        msg = None
+        if rank == 0:
+            red.launch(0)
+            torch.cuda.synchronize()
+            try:
+                red.check()
+            except RuntimeError as e:
+                msg = str(e)
+        dist.barrier()
+        red.close()
+        q.put((rank, msg, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def test_direct_exchange_reports_a_missing_rank_instead_of_hanging():
+    res = _run(_lost_rank_worker)
+    assert res[0][1] is not None and "rank 1" in res[0][1] and "gave up" in res[0][1], res[0][1]
+
+
+def _unmappable_worker(rank, world, port, q):
+    """Rank 1's arena is a window of a 2.5 GiB allocation, which peers cannot map on this runtime (the call never returns: measured, see
+    v2a_hip/dp.py _ipc_export).  The constructor must refuse -- on BOTH ranks, with the reason -- instead of hanging, and an arena from
+    alloc_arena() must then connect."""
+    try:
+        dist = _init(rank, world, port)
+        from v2a_hip.dp import GradReducer, alloc_arena
+        numel = 1_000_000
+        big = torch.zeros((5 << 29) // 4 if rank == 1 else numel, dtype=torch.float32, device="cuda:0")
+        msg = None
+        try:
+            GradReducer(big[:numel], [(0, numel)], dist.group.WORLD, world, algo="direct")
+        except RuntimeError as e:
+            msg = str(e)
+        del big
+        arena = alloc_arena(numel, "cuda:0")
+        arena.fill_(float(rank + 1))
+        red = GradReducer(arena, [(0, numel)], dist.group.WORLD, world, algo="direct", timeout_ms=20000)
+        red.launch(0); red.finish()
+        torch.cuda.synchronize()
+        red.check()
+        q.put((rank, (msg, float(arena.min()), float(arena.max())), None))
+        red.close()
+        dist.destroy_process_group()
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def test_direct_exchange_refuses_an_arena_the_peers_cannot_map():
+    res = _run(_unmappable_worker)
+    for rank, (msg, lo, hi), _ in res:
+        assert msg is not None and "rank 1" in msg and "2 to 4 GiB" in msg, f"rank {rank}: {msg}"
+        assert lo == hi == 1.5, f"rank {rank}: {lo} {hi}"            # (1 + 2) / 2 after the refusal: the group is still usable
+
+
+def _trainer_worker(rank, world, port, q, algo):
+    try:
+        dist = _init(rank, world, port)
+        import random, sys, time
+        from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+        from v2a_hip.replay import ReplayStore
+        from v2a_hip.trainer import PolicyTrainer
+        torch.manual_seed(1)
+        pol = build_policy(DEFAULT_CONF).to("cuda:0")
+        store = ReplayStore(64, 200, 30, capacity_frames=40 * 12)
+        gen = torch.Generator().manual_seed(3 + rank)
+        for e in range(12):
+            n = 30 + e
+            store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
+                                  torch.rand(n - 1, 7, generator=gen) * 2 - 1)
+        np.random.seed(5 + rank); random.seed(5 + rank)
+        tr = PolicyTrainer(pol, store, batch_size=4, seed=11, use_graph=True, process_group=dist.group.WORLD, world_size=world, rank=rank,
+                           dp_algo="rccl" if algo == "switch" else algo)
+        losses = []
+        for i in range(6):                                   # 2 eager steps, capture, replays of the graphs around the exchange
+            if algo == "switch" and i == 3:
+                tr.set_dp_algo("direct")                     # between two replayed steps: nothing is re-captured
+            t0 = time.time()
+            losses.append(tr.step().item())
+            print(f"[{algo}] rank {rank} step {i}: {time.time() - t0:.3f} s (at {time.time() % 1000:.3f})", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        if tr.reducer.algo == "direct":
+            tr.reducer.check()
+        flat = torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu()
+        q.put((rank, (losses, float(flat.double().norm()), flat[::9973].numpy(), tr.reducer.algo, tr.reducer.launches), None))
+        dist.barrier()
+        tr.reducer.close()
+        dist.destroy_process_group()
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def test_policy_trainer_two_ranks_direct_exchange_equals_the_all_reduce_run():
+    """Six data-parallel steps of PolicyTrainer on two ranks, three times: gradients through torch.distributed, through the peer-pointer
+    exchange, and switching from one to the other after step 3.  Losses and parameters must agree to the bit, on both ranks."""
+    runs = {algo: _run(_trainer_worker, args=(algo,)) for algo in ("rccl", "direct", "switch")}
+    base = runs["rccl"]
+    assert base[0][1][3] == "rccl" and runs["direct"][0][1][3] == "direct" and runs["switch"][0][1][3] == "direct"
+    assert runs["direct"][0][1][4] == 12 and runs["switch"][0][1][4] == 6
+    for algo in ("direct", "switch"):
+        for r in range(2):
+            a, b = base[r][1], runs[algo][r][1]
+            assert a[0] == b[0], f"{algo}, rank {r}: losses {a[0]} vs {b[0]}"
+            assert a[1] == b[1] and np.array_equal(a[2], b[2]), f"{algo}, rank {r}: parameters differ"
+    for algo, res in runs.items():
+        assert np.array_equal(res[0][1][2], res[1][1][2]) and res[0][1][1] == res[1][1][1], f"{algo}: replicas diverged"
+        assert res[0][1][0] != res[1][1][0]

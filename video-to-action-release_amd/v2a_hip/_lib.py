@@ -68,6 +68,19 @@ SIGNATURES = {
     "v2a_groupnorm_takes_post": (I, [I, I, I]),
     "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, SZ, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, I, SZ, P, P, SZ, P]),
     "v2a_groupnorm_bwd_s": (I, [P] * 5 + [I] + [P] * 5 + [SZ] + [P] * 5 + [I, I, I, I, I, I, P, I, SZ, P, P, P, SZ, P]),
+    "v2a_dp_max_world": (I, []),
+    "v2a_dp_slots": (I, []),
+    "v2a_dp_signal_bytes": (SZ, []),
+    "v2a_dp_arena_alloc": (I, [P, SZ]),
+    "v2a_dp_arena_free": (I, [P]),
+    "v2a_dp_signal_alloc": (I, [P]),
+    "v2a_dp_signal_free": (I, [P]),
+    "v2a_dp_errword_alloc": (I, [P]),
+    "v2a_dp_errword_free": (I, [P]),
+    "v2a_dp_ipc_export": (I, [P, P, P, P]),
+    "v2a_dp_ipc_open": (I, [P, P]),
+    "v2a_dp_ipc_close": (I, [P]),
+    "v2a_dp_allreduce_direct": (I, [P, P, I, I, SZ, SZ, I, ctypes.c_uint32, P, I, I, P]),
     "v2a_h5_open": (I, [ctypes.c_char_p, P]),
     "v2a_h5_close": (None, [P]),
     "v2a_h5_last_error": (ctypes.c_char_p, [P]),

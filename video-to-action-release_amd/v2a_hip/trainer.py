@@ -17,19 +17,19 @@ import torch
 from . import ops
 from .optim import FusedAdamWEMA
 from .replay import ReplayStore, sample_indices, count_uniform_below
-from .dp import GradReducer
+from .dp import GradReducer, alloc_arena
 from ._lib import lib, check
 
 
 class PolicyTrainer:
     def __init__(self, policy, store: ReplayStore, batch_size=64, opt_params=None, ema_params=None, seed=0, use_graph=True,
                  process_group=None, world_size=1, rank=0, store_vid: ReplayStore = None, rand_prob=0.3, force_dp=False, dp_wire="fp32",
-                 loss_scale_init=65536.0, fuse_packs=True, presum=True):
+                 loss_scale_init=65536.0, fuse_packs=True, presum=True, dp_algo="rccl"):
         """`store_vid` (optional, same HBM pool as `store`: ReplayStore.pair) is the video-guided-rollout buffer; minibatches
         then follow sample_from_bufs' 'rand_prob' rule (lb_online_trainer_v7.py:787-851): all rows from `store` while `store_vid` is
         empty, otherwise n_rand = #(U[0,1) < rand_prob) rows from `store` first and the rest from `store_vid`.
         force_dp: the data-parallel step structure for a single rank too (exercises the RCCL path on a one-GPU box); dp_wire: "fp32" |
-        "bf16" wire format of the gradient all-reduce; loss_scale_init: initial dynamic loss scale of the fp16 mode (<= 0: no scaling);
+        "bf16" wire format of the gradient all-reduce; dp_algo: "rccl" | "direct" (peer-pointer exchange, v2a_hip/dp.py); loss_scale_init: initial dynamic loss scale of the fp16 mode (<= 0: no scaling);
         fuse_packs / presum: the optimiser's update kernel writes the forward conv operands / the ConditionalUnet1D slice's gradient-norm
         partial sums run ahead of the serial tail (both bit-equal to their separate-launch forms: tests/test_policy_gpu.py)."""
         self.policy = policy
@@ -64,7 +64,8 @@ class PolicyTrainer:
         P = dict(policy.named_parameters())
         EP = dict(self.ema_policy.named_parameters())
         total = sum(P[n].numel() for n in self.names)
-        self.arena = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # data parallel: the arena is an allocation of its own (the unit the peer-pointer exchange maps into the other ranks)
+        self.arena = alloc_arena(total, self.device) if self.dp else torch.zeros(total, dtype=torch.float32, device=self.device)
         gviews = self.eng.grad_views(self.arena, self.names)
         self.opt = FusedAdamWEMA([P[n].data for n in self.names], [gviews[n] for n in self.names], [EP[n].data for n in self.names],
                                  lr=opt_params["lr"], betas=tuple(opt_params["betas"]), eps=opt_params["eps"],
@@ -96,7 +97,8 @@ class PolicyTrainer:
         self._slices = self.eng.arena_slices(self.names)
         # the one collective of the path (v2a_hip/dp.py): slice 0 = ConditionalUnet1D gradients (final after phase 1), slice 1 = encoders
         # dp_wire="bf16": opt-in bf16 wire format (half the bytes per xGMI link; the sum is rounded to bf16 -- not the parity path)
-        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size, wire=dp_wire) if self.dp else None
+        self._dp_wire = dp_wire
+        self.reducer = GradReducer(self.arena, self._slices, process_group, world_size, wire=dp_wire, algo=dp_algo) if self.dp else None
         self.feed = None               # parity / test hook (eager mode): dict(rows=int64[B] pool offsets, noise=[B,T,Da], timesteps=int64[B])
         self.on_grads_ready = None     # diagnostics hook (eager mode): called with the arena right before the optimiser consumes it
         self.comm_events = None        # bench: [(before_wait, after_wait)] HIP event pairs bracketing the stream's wait on the communicator
@@ -201,6 +203,17 @@ class PolicyTrainer:
         imgs = {"img_obs_1": o0, "img_goal_1": o1}
         self._st = self.eng.backward_phase1(imgs, oa, self.noise, self.timesteps, names=self.names, arena=self.arena)
         ops.copy2d(self._st["loss"], self.loss, 1, 1, 1, 1)
+
+    def set_dp_algo(self, algo):
+        """Swap the gradient exchange ("rccl" | "direct") between two steps; collective (every rank calls it with the same value).  The
+        exchange launches sit between the captured graphs, so nothing is re-captured."""
+        if not self.dp:
+            raise RuntimeError("not a data-parallel trainer")
+        if algo == self.reducer.algo:
+            return
+        new = GradReducer(self.arena, self._slices, self.pg, self.world, wire=self._dp_wire, algo=algo)      # raises on every rank or on none
+        self.reducer.close()
+        self.reducer = new
 
     def _bwd_encoders(self):
         self.eng.backward_phase2(self._st)
