@@ -744,8 +744,10 @@ def main():
     # ---- which gradient exchange the timed steps run on (comm.algo).  The two slice all-reduces alone (nothing to hide under), blocking,
     # 5 rounds, through the process group (RCCL on a node); if that moves the 349 MB below DIRECT_BELOW_GBPS of bus bandwidth -- a ring on
     # the xGMI mesh is bound by ONE link per direction, ~153 GB/s peak, SURVEY.md section 5 -- the peer-pointer exchange (v2a_hip/dp.py
-    # algo="direct", csrc/dp.hip) is connected and measured the same way, and the faster of the two carries the timed steps.  Every number
-    # a decision hangs on is a max over ranks, so all ranks decide alike.
+    # algo="direct", csrc/dp.hip) is connected and measured the same way, and the faster of the two carries the timed steps.  Two ranks on
+    # two GPUs have ONE link between them whichever algorithm drives it: the direct exchange is tried from three ranks on (and when the
+    # ranks share a GPU, where the process group is gloo through the host).  Every number a decision hangs on is a max over ranks, so all
+    # ranks decide alike.
     DIRECT_BELOW_GBPS = 200.0
     choice = None
 
@@ -781,8 +783,9 @@ def main():
         iso_pg = iso_ms(pg_all)
         if world > 1:
             choice = {"threshold_busbw_GBps": DIRECT_BELOW_GBPS, "process_group_busbw_GBps": busbw(iso_pg), "picked": "rccl",
-                      "rule": "process group below the threshold -> connect the peer-pointer exchange, measure it alike, keep the faster"}
-            if busbw(iso_pg) < DIRECT_BELOW_GBPS:
+                      "rule": "process group below the threshold and (>= 3 ranks or ranks sharing a GPU) -> connect the peer-pointer exchange, "
+                              "measure it alike, keep the faster"}
+            if busbw(iso_pg) < DIRECT_BELOW_GBPS and (world >= 3 or backend == "gloo"):
                 try:
                     tr.set_dp_algo("direct")                   # raises on every rank or on none
                     for _ in range(2):
