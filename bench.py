@@ -954,21 +954,30 @@ def main():
                 raise KeyboardInterrupt
             from v2a_hip.inference import GraphedPredictAction
             polq = tr.ema_for_inference()
-            gp = GraphedPredictAction(polq, batch_size=1, use_ddim=True)
             obs1 = {k: torch.rand(1, 1, 3, 128, 128, device=device) for k in ("img_obs_1", "img_goal_1")}
-            for _ in range(3):
-                gp(obs1)
-            lat = []
-            for _ in range(50):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                gp(obs1)
-                e1.record()
-                torch.cuda.synchronize()
-                lat.append(e0.elapsed_time(e1))
-            out["predict_action"] = {"latency_ms": _median(lat), "batch": 1, "sampler": "ddim-8", "timing": "median of 50 HIP-event intervals",
-                                     "note": "encoders + 8 ConditionalUnet1D steps + unnormalise, one hipGraph replay per call; "
-                                             "reference CPU path 110 ms (SURVEY section 6)"}
+
+            def pa_latency(persistent):
+                gp = GraphedPredictAction(polq, batch_size=1, use_ddim=True, persistent=persistent)
+                for _ in range(3):
+                    gp(obs1)
+                lat = []
+                for _ in range(50):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    gp(obs1)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    lat.append(e0.elapsed_time(e1))
+                return _median(lat), gp
+
+            ms_p, gp_p = pa_latency(True)
+            ms_l, _ = pa_latency(False)
+            out["predict_action"] = {"latency_ms": ms_p, "batch": 1, "sampler": "ddim-8", "timing": "median of 50 HIP-event intervals",
+                                     "path": "persistent denoiser (default at batch 1): csrc/policy_persist.hip",
+                                     "layer_by_layer_ms": ms_l, "grid_barriers_per_call": gp_p.pp.n_barriers, "workgroups": gp_p.pp.nwg,
+                                     "note": "encoders + 8 ConditionalUnet1D steps + scheduler updates + unnormalise, one hipGraph replay per "
+                                             "call; the 8 steps are ONE persistent launch (exact fp32 FMA), layer_by_layer_ms = the same call on "
+                                             "the training path's kernels; reference CPU path 110 ms (SURVEY section 6)"}
         except KeyboardInterrupt:
             pass
         except Exception as e:                      # never let the secondary leg break the headline line

@@ -454,6 +454,18 @@ int v2a_wgrad_multi_max(void);
 int v2a_wgrad_family(int variant);   /* kernel family of a described gradient (one family per v2a_conv2d_wgrad_multi launch): 0 exact 64x64 / twin-fed, 1 halo, 2 / 3 three-bf16-plane 64x64 / 128x128 */
 int v2a_conv2d_wgrad_multi(const void* items, const int* variants, const int* tiles, int n, v2a_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------- persistent predict_action (csrc/policy_persist.hip)
+ * Every scheduler step of DiffusionUnetImagePolicy.conditional_sample (diffusion_policy/diffusion_unet_image_policy.py:88-133) over
+ * ConditionalUnet1D.forward (model/conditional_unet1d.py:186-246), the scheduler updates and the action un-normalisation (:139-201) as ONE
+ * persistent launch for batch <= 2 (the rollout loop calls predict_action at batch 1: diffuser/libero/lb_online_trainer_v7.py:1060-1122).
+ * The caller describes the network as an op list in device memory (struct PPOp / PPArgs in the .hip file; v2a_hip/policy_persist.py builds
+ * it from the live fp32 parameters, nothing is packed). */
+size_t v2a_policy_persist_op_bytes(void);          /* sizeof(PPOp) / sizeof(PPArgs): the host mirror checks itself against these */
+size_t v2a_policy_persist_args_bytes(void);
+int v2a_policy_persist_waves_per_wg(void);         /* the host picks how many waves share an output channel from this and nwg */
+size_t v2a_policy_persist_lds_bytes(int B, int Tin, int Tout, int Cin, int K, int stride, int pad, int type);   /* 0: the op cannot run */
+int v2a_policy_persist_launch(const void* args_host, int nwg, size_t lds_bytes, v2a_stream_t stream);   /* nwg workgroups, all resident (<= #CUs) */
+
 /* ---------------------------------------------------------------------------------------------- direct gradient exchange (csrc/dp.hip)
  * The second algorithm behind the data-parallel gradient all-reduce of the policy step (reference: torch DDP through accelerator.prepare,
  * diffuser/libero/lb_online_trainer_v7.py:153-154; its hooks reduce inside accelerator.backward :604, before clip_grad_norm_ :608): a

@@ -530,14 +530,17 @@ def test_data_parallel_two_ranks_on_one_gpu():
     assert res[0][1] != res[1][1] and all(np.isfinite(res[0][1] + res[1][1]))
 
 
-def test_graphed_predict_action_matches_eager(golden_dir):
-    """The hipGraph-replayed predict_action (v2a_hip.inference) against the golden DDIM-8 output (same injected noise)."""
+@pytest.mark.parametrize("persistent", [False, True])
+def test_graphed_predict_action_matches_eager(golden_dir, persistent):
+    """The hipGraph-replayed predict_action (v2a_hip.inference) against the golden DDIM-8 output (same injected noise): on the layer-by-layer
+    kernels and with the eight scheduler steps as one persistent launch (csrc/policy_persist.hip)."""
     from v2a_hip.inference import GraphedPredictAction
     g = np.load(f"{golden_dir}/policy.npz", allow_pickle=True)
     pol, _ = _policy()
     pol.eval()
     obs = {k: v.cuda() for k, v in _batch(g)["obs"].items()}
-    gp = GraphedPredictAction(pol, batch_size=2, use_ddim=True)
+    gp = GraphedPredictAction(pol, batch_size=2, use_ddim=True, persistent=persistent)
+    assert (gp.pp is not None) == persistent
     torch.manual_seed(70)
     init = torch.randn(2, 16, 7)
     for _ in range(3):                                   # first call captures, the others replay
@@ -546,6 +549,45 @@ def test_graphed_predict_action_matches_eager(golden_dir):
     assert rel(out["action"], g["ddim_action"]) <= TOL
     out2 = gp(obs)                                       # device Philox noise: different sample, finite, in range
     assert torch.isfinite(out2["action_pred"]).all() and float(out2["action_pred"].abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("batch,ddim", [(1, True), (1, False), (2, True)])
+def test_persistent_denoiser_equals_the_layer_by_layer_path(batch, ddim):
+    """predict_action at the rollout loop's batch (lb_online_trainer_v7.py:1060-1122): all scheduler steps in one persistent launch against
+    the same call on the training path's kernels -- same observation, same injected noises, DDIM-8 and the 100 ancestral steps (whose
+    per-step noises and sigma enter the in-kernel update).  Both are fp32-accurate; they differ by summation order only."""
+    from v2a_hip.inference import GraphedPredictAction
+    pol, _ = _policy()
+    pol.eval()
+    g = torch.Generator().manual_seed(5)
+    obs = {k: torch.rand(batch, 1, 3, 128, 128, generator=g).cuda() for k in pol._cfg.rgb_keys}
+    init = torch.randn(batch, 16, 7, generator=g).cuda()
+    noises = None if ddim else [torch.randn(batch, 16, 7, generator=g).cuda() for _ in range(100)]
+    ref = GraphedPredictAction(pol, batch, use_ddim=ddim, persistent=False)
+    per = GraphedPredictAction(pol, batch, use_ddim=ddim) if batch == 1 else GraphedPredictAction(pol, batch, use_ddim=ddim, persistent=True)
+    assert per.pp is not None and ref.pp is None            # (batch 1 takes the persistent path by default)
+    a = {k: v.clone() for k, v in ref(obs, init_noise=init, step_noises=noises).items()}        # (the outputs are static buffers)
+    for _ in range(3):                                       # eager warm-up, capture, replays: the noise buffer must survive a launch
+        b = per(obs, init_noise=init, step_noises=noises)
+    assert rel(b["action_pred"], a["action_pred"]) <= TOL
+    assert rel(b["action"], a["action"]) <= TOL
+    assert torch.equal(per.init, init)                       # the caller's initial noise is an input, not scratch
+    if batch == 1 and ddim:                                  # the weights change in place (an optimiser step): the next launch must see it
+        with torch.no_grad():
+            pol.model.final_conv[1].weight.mul_(1.5)
+            pol.model.down_modules[0][0].blocks[0].block[0].weight.add_(0.01)
+        pol.engine.refresh_packs()
+        a2 = ref(obs, init_noise=init)["action_pred"]
+        b2 = per(obs, init_noise=init)["action_pred"]
+        assert rel(a2, a["action_pred"]) > 1e-3 and rel(b2, a2) <= TOL
+
+
+def test_persistent_denoiser_refuses_what_does_not_fit():
+    from v2a_hip.inference import GraphedPredictAction
+    pol, _ = _policy()
+    with pytest.raises(ValueError, match="batch <= 2"):
+        GraphedPredictAction(pol, batch_size=4, use_ddim=True, persistent=True)
+    assert GraphedPredictAction(pol, batch_size=4, use_ddim=True).pp is None      # default: the layer path for larger batches
 
 
 def test_dp_step_structure_on_rccl_single_rank():

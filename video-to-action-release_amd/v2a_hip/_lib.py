@@ -68,6 +68,11 @@ SIGNATURES = {
     "v2a_groupnorm_takes_post": (I, [I, I, I]),
     "v2a_groupnorm_fwd_s": (I, [P, P, I, P, P, P, P, I, P, P, SZ, P, P, I, I, I, I, F, I, P, I, SZ, P, P, P, I, SZ, P, P, SZ, P]),
     "v2a_groupnorm_bwd_s": (I, [P] * 5 + [I] + [P] * 5 + [SZ] + [P] * 5 + [I, I, I, I, I, I, P, I, SZ, P, P, P, SZ, P]),
+    "v2a_policy_persist_op_bytes": (SZ, []),
+    "v2a_policy_persist_args_bytes": (SZ, []),
+    "v2a_policy_persist_waves_per_wg": (I, []),
+    "v2a_policy_persist_lds_bytes": (SZ, [I, I, I, I, I, I, I, I]),
+    "v2a_policy_persist_launch": (I, [P, I, SZ, P]),
     "v2a_dp_max_world": (I, []),
     "v2a_dp_slots": (I, []),
     "v2a_dp_signal_bytes": (SZ, []),

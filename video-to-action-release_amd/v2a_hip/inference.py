@@ -8,7 +8,11 @@ from .policy_sched import ddim_coeffs, ddpm_coeffs, ddim_timesteps
 
 
 class GraphedPredictAction:
-    def __init__(self, policy, batch_size=1, use_ddim=True, seed=0):
+    def __init__(self, policy, batch_size=1, use_ddim=True, seed=0, persistent=None):
+        """persistent: run all scheduler steps of the ConditionalUnet1D as ONE persistent launch (v2a_hip/policy_persist.py,
+        csrc/policy_persist.hip: plain fp32 FMA arithmetic, ~30 grid barriers per step instead of ~100 launches).  None = at batch 1 (the
+        rollout loop's batch, where it is the faster path: 3.9 against 5.0 ms for the eight steps; at batch 2 it also runs but is no
+        faster); False = the layer-by-layer kernels of the training path."""
         self.policy = policy
         self.eng = policy.engine
         dev = self.eng.device
@@ -24,10 +28,18 @@ class GraphedPredictAction:
         self.seed, self.counter = seed, torch.zeros(1, dtype=torch.int64, device=dev)
         self.out = None
         self.graph = None
+        from .policy_persist import PersistentDenoiser
+        if persistent is None:
+            persistent = batch_size == 1
+        self.pp = PersistentDenoiser(self.eng, batch_size, self.steps, use_ddim, policy.num_inference_steps_ddim, self.init,
+                                     self.step_noise) if persistent else None
 
     def _run(self):
         eng, pol = self.eng, self.policy
         gc = eng.global_cond(self.obs)
+        if self.pp is not None:
+            self.out = self.pp.launch(gc)             # every scheduler step, the scheduler updates and the un-normalisation: one launch
+            return
         traj = self.init
         for i, t in enumerate(self.steps):
             eps = eng.unet_fwd(traj, self.tt[i], gc)
