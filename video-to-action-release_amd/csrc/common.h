@@ -140,10 +140,20 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
     }
 }
 
+// Sum / max over the 64 lanes, result in every lane (all lanes must be active).  Butterflies inside the 16-lane rows are DPP permutes, the
+// four row totals meet through v_readlane: 47 ns per dependent sum against 180 ns for six ds_bpermute shuffles (tools/probes/r5/
+// wave_sum_bench.hip) -- a GroupNorm launch chains two to four of these.
+template <int CTRL> __device__ __forceinline__ float v2a_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += v2a_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += v2a_dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += v2a_dpp<0x141>(v);         // row_half_mirror
+    v += v2a_dpp<0x140>(v);         // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -151,9 +161,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, v2a_dpp<0xB1>(v));
+    v = fmaxf(v, v2a_dpp<0x4E>(v));
+    v = fmaxf(v, v2a_dpp<0x141>(v));
+    v = fmaxf(v, v2a_dpp<0x140>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Stateless dropout: element `idx` of random stream `stream` under `seed` is kept with probability 1 - p.  A splitmix64 finaliser of
