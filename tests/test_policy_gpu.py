@@ -582,6 +582,27 @@ def test_persistent_denoiser_equals_the_layer_by_layer_path(batch, ddim):
         assert rel(a2, a["action_pred"]) > 1e-3 and rel(b2, a2) <= TOL
 
 
+def test_persistent_denoiser_gives_up_instead_of_hanging():
+    """More workgroups than the device can hold at once: the ones that are resident wait at the first grid barrier for peers that cannot
+    start.  The kernel must abandon the wait (2 s), terminate, and the host must say so on its next look."""
+    from v2a_hip.policy_persist import PersistentDenoiser
+    from v2a_hip.policy_sched import ddim_timesteps
+    pol, _ = _policy()
+    init = torch.randn(1, 16, 7).cuda()
+    pd = PersistentDenoiser(pol.engine, 1, ddim_timesteps(100, 8), True, 8, init, nwg=1024)
+    pd.launch(torch.randn(1, pd.gcond.shape[1]).cuda())
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="abandoned"):
+        pd.check()
+    with pytest.raises(RuntimeError, match="abandoned"):
+        pd.launch(torch.randn(1, pd.gcond.shape[1]).cuda())
+    ok = PersistentDenoiser(pol.engine, 1, ddim_timesteps(100, 8), True, 8, init)          # the default geometry still runs
+    ok.launch(torch.randn(1, ok.gcond.shape[1]).cuda())
+    torch.cuda.synchronize()
+    ok.check()
+    assert torch.isfinite(ok.action).all()
+
+
 def test_persistent_denoiser_refuses_what_does_not_fit():
     from v2a_hip.inference import GraphedPredictAction
     pol, _ = _policy()

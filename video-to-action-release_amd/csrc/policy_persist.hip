@@ -28,6 +28,7 @@
 #define PP_WAVES 8
 #define PP_MAX_LDS (156 * 1024)
 #define PP_MAX_WG 1024
+#define PP_BARRIER_BUDGET 200000000ull      // 100 MHz ticks a workgroup waits at one barrier before it gives up (2 s)
 #define PP_U 8               // input-channel iterations (64 channels each) whose weights are loaded ahead
 
 enum { PP_SRC_NONE = 0, PP_SRC_PLAIN = 1, PP_SRC_MISH = 2, PP_SRC_GN_MISH = 3, PP_SRC_SINCOS = 4 };
@@ -64,22 +65,32 @@ struct PPArgs {
     float* action;         // [B][T][Da] un-normalised
     unsigned* barrier;     // PP_MAX_WG flags (zeroed by the launch entry point)
     const float* init;     // [B][T][Da]: the initial noise (read by the first scheduler step instead of `traj`; never written)
+    int* err;              // device-visible error word (pinned host memory): set when a barrier wait exceeds its budget; or NULL
     unsigned long long* trace;   // NULL, or [ops executed][4] 100 MHz ticks of workgroup 0: op start, loader done, product done, barrier passed
     int n_prologue, n_step, nsteps, mode, B, T, Da, pad0;
 };
 
 // Grid barrier: workgroup w publishes flags[w] = phase, wave 0 of every workgroup polls all flags (lane l reads flags l, l + 64, ...) until
 // none is behind.  No fences: see the note on the data path below.  Phases only grow within a launch; the host zeroes the flags before it.
-__device__ __forceinline__ void pp_grid_barrier(unsigned* flags, unsigned& phase) {
+__device__ __forceinline__ void pp_grid_barrier(unsigned* flags, unsigned& phase, int* err) {
     __syncthreads();                                                // (the caller has waited for its write-through stores: see the main loop)
     ++phase;
     if (threadIdx.x < 64) {
         if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int n = gridDim.x;
-        for (;;) {
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spins = 1;; ++spins) {
             unsigned behind = 0;                               // (no short circuit: a lane's loads are independent and in flight together)
             for (int i = threadIdx.x; i < n; i += 64) behind |= (unsigned)(__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase);
             if (__all(behind == 0)) break;
+            // A workgroup that never arrives (not resident: the launch asked for more workgroups than the device can hold next to what else
+            // is running) must not hang the GPU: after PP_BARRIER_BUDGET of wall clock the wait is abandoned, the error word raised and every
+            // later barrier of the launch falls through (the numbers are garbage; the host raises on its next look at the word).
+            if ((spins & 1023u) == 0 && err &&
+                (wall_clock64() - t0 > PP_BARRIER_BUDGET || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+                if (threadIdx.x == 0) __hip_atomic_store(err, (int)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
     }
     __syncthreads();
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(PP_THREADS) void policy_persist_kernel(PPArgs A) {
         __builtin_amdgcn_s_waitcnt(0);           // this wave's write-through stores have arrived -- BEFORE the prefetch below is issued, so
         asm volatile("" ::: "memory");            // that nothing at the barrier has to wait for the prefetched weights
         if (opn + 1 < total) pp_prefetch(opn + 1 < A.n_prologue ? A.prologue[opn + 1] : A.step_ops[ni], wpre);
-        if (op.barrier_after) pp_grid_barrier(A.barrier, target);
+        if (op.barrier_after) pp_grid_barrier(A.barrier, target, A.err);
         PP_TRACE(3)
         i = ni;
         s = ns;
@@ -782,6 +793,11 @@ int v2a_policy_persist_launch(const void* args_host, int nwg, size_t lds_bytes, 
             hipSuccess)
             return V2A_ERR_LAUNCH;
         attr_set = true;
+    }
+    if (A.err) {                                  // (a pinned host word from v2a_dp_errword_alloc: the kernel needs its device address)
+        int* dev = nullptr;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), A.err, 0) != hipSuccess) return V2A_ERR_ARG;
+        A.err = dev;
     }
     if (hipMemsetAsync(A.barrier, 0, PP_MAX_WG * sizeof(unsigned), stream) != hipSuccess) return V2A_ERR_LAUNCH;
     hipLaunchKernelGGL(policy_persist_kernel, dim3(nwg), dim3(PP_THREADS), lds_bytes, stream, A);

@@ -30,7 +30,7 @@ class PPOp(ctypes.Structure):
 
 class PPArgs(ctypes.Structure):
     _fields_ = [("prologue", P), ("step_ops", P), ("coef", P), ("noise", P), ("traj", P), ("amin", P), ("amax", P), ("action", P),
-                ("barrier", P), ("init", P), ("trace", P), ("n_prologue", I), ("n_step", I), ("nsteps", I), ("mode", I), ("B", I), ("T", I), ("Da", I), ("pad0", I)]
+                ("barrier", P), ("init", P), ("err", P), ("trace", P), ("n_prologue", I), ("n_step", I), ("nsteps", I), ("mode", I), ("B", I), ("T", I), ("Da", I), ("pad0", I)]
 
 
 def _ptr(t):
@@ -181,9 +181,12 @@ class PersistentDenoiser:
             self.lds = max(self.lds, need)
         self._pro_dev = self._upload(pro)
         self._st_dev = self._upload(st)
+        word = ctypes.c_void_p()
+        check(lib.v2a_dp_errword_alloc(ctypes.byref(word)), "errword_alloc")       # pinned host ints the kernel can raise (shared helper)
+        self._err = word.value
         lim = eng.act_limits
         self.args = PPArgs(prologue=_ptr(self._pro_dev), step_ops=_ptr(self._st_dev), coef=_ptr(self.coef), noise=_ptr(step_noise), traj=_ptr(traj),
-                           amin=_ptr(lim[0]) if lim else 0, amax=_ptr(lim[1]) if lim else 0, action=_ptr(self.action), barrier=_ptr(self.barrier), init=_ptr(init), trace=0,
+                           amin=_ptr(lim[0]) if lim else 0, amax=_ptr(lim[1]) if lim else 0, action=_ptr(self.action), barrier=_ptr(self.barrier), init=_ptr(init), err=self._err, trace=0,
                            n_prologue=len(pro), n_step=len(st), nsteps=self.nsteps, mode=self.mode, B=B, T=T, Da=self.Da)
         self.n_ops = (len(pro), len(st))
         self._pack_ptrs = {id(cv): cv.pf().data_ptr() for cv in self._convs}
@@ -248,9 +251,18 @@ class PersistentDenoiser:
         t = buf.cpu().double()
         return ((t - t[0, 0]) / 100.0).tolist()
 
+    def check(self):
+        """Raise if a launch abandoned a grid barrier (a workgroup never became resident within 2 s: the kernel terminates instead of hanging
+        the GPU, its results are garbage).  Read without synchronising; launch() looks at it before every launch."""
+        v = ctypes.c_int.from_address(self._err).value
+        if v:
+            raise RuntimeError(f"persistent denoiser: a grid barrier (phase {v}) was abandoned after 2 s -- {self.nwg} workgroups of 512 threads "
+                               f"with {self.lds} bytes of LDS were not all resident (another kernel holding the CUs?)")
+
     def launch(self, global_cond):
         """global_cond [B, G] (the image encoders' output).  Runs every scheduler step; afterwards self.traj holds the normalised sample and
         self.action the un-normalised one."""
+        self.check()
         for cv in self._convs:
             if cv.pf().data_ptr() != self._pack_ptrs[id(cv)]:
                 raise RuntimeError("a forward pack of the policy was re-allocated: build a new PersistentDenoiser")
