@@ -88,7 +88,7 @@ def joint_steps_per_sec(world: int, ms_per_step: float, seconds_per_rollout: flo
 
 class _OwnAllocation:
     """numel fp32 elements of HBM from the library's allocator (csrc/dp.hip v2a_dp_arena_alloc), seen by torch through
-    __cuda_array_interface__; freed when the last tensor over it is gone."""
+    __cuda_array_interface__; released (outside any graph capture) after the last tensor over it is gone."""
 
     def __init__(self, numel, device):
         from ._lib import lib, check
@@ -99,14 +99,26 @@ class _OwnAllocation:
         self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<f4", "data": (self.ptr, False), "version": 2, "strides": None}
 
     def __del__(self):
-        try:
-            from ._lib import lib
-            if self.ptr:
-                with torch.cuda.device(self.device):
-                    lib.v2a_dp_arena_free(self.ptr)
-                self.ptr = None
-        except Exception:                                          # noqa: BLE001 -- interpreter shutdown
-            pass
+        # Garbage collection can run at any moment -- also while some stream of the process is capturing a hipGraph, where hipFree is not
+        # allowed (it invalidates the capture; torch's allocator never frees during one either).  The pointer is parked and released by the
+        # next alloc_arena() / drain_arenas() call outside a capture.
+        if getattr(self, "ptr", None):
+            _PENDING_FREE.append((self.ptr, self.device))
+            self.ptr = None
+
+
+_PENDING_FREE = []
+
+
+def drain_arenas():
+    """Release the arenas whose tensors are gone (see _OwnAllocation.__del__).  A no-op while the current stream is capturing."""
+    if not _PENDING_FREE or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return
+    from ._lib import lib
+    while _PENDING_FREE:
+        ptr, device = _PENDING_FREE.pop()
+        with torch.cuda.device(device):
+            lib.v2a_dp_arena_free(ptr)
 
 
 def alloc_arena(numel, device):
@@ -115,6 +127,7 @@ def alloc_arena(numel, device):
     dev = torch.device(device)
     if dev.type != "cuda":
         return torch.zeros(int(numel), dtype=torch.float32, device=dev)
+    drain_arenas()
     own = _OwnAllocation(numel, dev)
     t = torch.as_tensor(own, device=dev)
     if t.data_ptr() != own.ptr:
