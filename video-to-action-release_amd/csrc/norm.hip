@@ -814,16 +814,19 @@ __device__ __forceinline__ void gn_wv_gather(const GnDesc& p, const float* dense
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < p.nslab; s0 += 4) {          // slab order, four slabs in flight (as gn_wave_gather)
-        f32x4 u[4][NJ];
+    // slab order; eight slabs in flight (<= 128 registers at NJ = 4): a launch is one wave per SIMD, every round of this loop is a full
+    // memory round trip, and the deep ResNet stages arrive in 8-13 slabs
+    constexpr int INFL = 8;
+    for (int s0 = 0; s0 < p.nslab; s0 += INFL) {
+        f32x4 u[INFL][NJ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < INFL; ++q)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 u[q][j] = (s0 + q < p.nslab) ? *reinterpret_cast<const f32x4*>(p.slabs + (size_t)(s0 + q) * p.slab_stride + off[j])
                                              : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < INFL; ++q)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) v[j] += u[q][j];
     }
