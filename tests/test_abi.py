@@ -74,3 +74,19 @@ def test_argument_validation_returns_error_codes_without_touching_the_device():
     assert lib.v2a_conv2d_wgrad_h_workspace_bytes(229376, 128, 1152) >= 128 * 1152 * 4 * 2
     assert lib.v2a_colsum_batched_workspace_bytes(2, 114688, 128) >= 2 * 128 * 8
     assert lib.v2a_video_loss_workspace_bytes(4) >= 4 * 8
+
+
+def test_persistent_denoiser_structs_match_the_library():
+    """v2a_hip/policy_persist.py mirrors the op / argument structs of csrc/policy_persist.hip with ctypes; the library reports their sizes."""
+    from v2a_hip.policy_persist import PPOp, PPArgs, PPSrc
+    from v2a_hip._lib import lib
+    assert ctypes.sizeof(PPOp) == lib.v2a_policy_persist_op_bytes()
+    assert ctypes.sizeof(PPArgs) == lib.v2a_policy_persist_args_bytes()
+    assert ctypes.sizeof(PPOp) == 2 * ctypes.sizeof(PPSrc) + 3 * 8 + 14 * 4
+    assert lib.v2a_policy_persist_waves_per_wg() in (4, 8, 16)
+    # shapes the kernel takes / refuses: (B, Tin, Tout, Cin, K, stride, pad, type)
+    assert lib.v2a_policy_persist_lds_bytes(1, 16, 16, 256, 5, 1, 2, 0) > 0
+    assert lib.v2a_policy_persist_lds_bytes(2, 4, 4, 2048, 5, 1, 2, 0) > 0           # the largest layer input at batch 2
+    assert lib.v2a_policy_persist_lds_bytes(4, 4, 4, 2048, 5, 1, 2, 0) == 0          # batch 4 does not fit the LDS
+    assert lib.v2a_policy_persist_lds_bytes(1, 16, 16, 256, 7, 1, 3, 0) == 0         # no 7-tap instance
+    assert lib.v2a_policy_persist_lds_bytes(1, 8, 16, 256, 4, 2, 1, 1) > 0           # Upsample1d

@@ -96,10 +96,11 @@ class PersistentDenoiser:
 
         layer(lambda lo, n: [dict(kind=SRC_SINCOS, C=dsed, tsteps=self.tsteps, rows_per_step=B, row0=lo)], eng.step1, e1, True)
         layer(lambda lo, n: [dict(kind=SRC_MISH, a=e1[lo:lo + n], C=4 * dsed)], eng.step3, e2, True)
+        film_of = {}                                          # residual block (by its parameter prefix) -> its FiLM rows [R, 2 * Cout]
         for j, r in enumerate(eng.film):
-            r["_pp_film"] = f(R, 2 * r["cout"])
+            film_of[r["pre"]] = f(R, 2 * r["cout"])
             layer(lambda lo, n: [dict(kind=SRC_MISH, a=e2[lo:lo + n], C=dsed), dict(kind=SRC_MISH, a=self.gcond, C=Gd, tmod=B)], r["ce"],
-                  r["_pp_film"], j == len(eng.film) - 1)
+                  film_of[r["pre"]], j == len(eng.film) - 1)
 
         # ---- one scheduler step
         st = []
@@ -133,7 +134,7 @@ class PersistentDenoiser:
                 assert len(xs) == 1 and xs[0]["C"] == co
                 res = xs[0]["plain"] if "raw" in xs[0] else xs[0]["t"]        # identity residual: the block's input as a plain tensor
             g0, g1 = r["pre"] + ".blocks.0.block.1", r["pre"] + ".blocks.1.block.1"
-            st.append(self._op([dict(kind=SRC_GN_MISH, a=raw0, gamma=eng.P[g0 + ".weight"], beta=eng.P[g0 + ".bias"], groups=G, film=r["_pp_film"],
+            st.append(self._op([dict(kind=SRC_GN_MISH, a=raw0, gamma=eng.P[g0 + ".weight"], beta=eng.P[g0 + ".bias"], groups=G, film=film_of[r["pre"]],
                                      C=co)], r["c1"], raw1, B, Tc, Tc, K=k, pad=k // 2, barrier=1))
             out = dict(raw=raw1, gamma=eng.P[g1 + ".weight"], beta=eng.P[g1 + ".bias"], addend=res, plain=f(B, Tc, co), C=co)
             self.named.update({r["pre"] + ".raw0": raw0, r["pre"] + ".raw1": raw1, r["pre"] + ".out": out["plain"]})
@@ -168,7 +169,7 @@ class PersistentDenoiser:
         st.append(self._op(as_sources([x], [True]), eng.fin0, rawf, B, Tc, Tc, K=k, pad=k // 2, barrier=1))
         gf = "model.final_conv.0.block.1"
         self.eps = f(B, Tc, self.Da)
-        self.named.update({"final.raw": rawf, "film": [r["_pp_film"] for r in eng.film], "e1": e1, "e2": e2})
+        self.named.update({"final.raw": rawf, "film": [film_of[r["pre"]] for r in eng.film], "e1": e1, "e2": e2})
         st.append(self._op([dict(kind=SRC_GN_MISH, a=rawf, gamma=eng.P[gf + ".weight"], beta=eng.P[gf + ".bias"], groups=G, C=eng.fin0.co)],
                            eng.fin1, self.eps, B, Tc, Tc, K=1, pad=0, barrier=1, sched=1))
         assert Tc == T
