@@ -106,7 +106,7 @@ template <bool F16> __device__ __forceinline__ unsigned int v2a_gn_act2(unsigned
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
-        case ACT_SILU: return x / (1.0f + expf(-x));
+        case ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));      // v_exp_f32 + v_rcp_f32, ~1 ulp each
         case ACT_RELU: return x > 0.f ? x : 0.f;
         case ACT_MISH: {
             // x * tanh(softplus(x)) with torch's softplus threshold 20.  tanh(log(1 + n)) = w / (w + 2) for n = e^x, w = n (n + 2): one
@@ -125,7 +125,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
 __device__ __forceinline__ float act_bwd(float x, int act) {
     switch (act) {
         case ACT_SILU: {
-            float s = 1.0f / (1.0f + expf(-x));
+            const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
             return s * (1.0f + x * (1.0f - s));
         }
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
