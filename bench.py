@@ -126,6 +126,18 @@ def _emit(out):
             return o
         line = shed(line)
         txt = json.dumps(line, separators=(",", ":"))
+    # the driver keeps the LAST 8 KB of stdout: a longer line would arrive cut.  Whole secondary legs go (least important first, named in
+    # `dropped_for_length`; the full record on stderr / bench_full_last.json keeps them) until the line fits with room to spare.
+    dropped = []
+    for leg in ("video_train", "video_c5_fp16", "video_c5", "video_bf16_ddpm100", "video_fp16", "video_exact", "policy_exact", "video_round8",
+                "dp_structure", "policy_b256", "video_b1"):
+        if len(txt) <= 7900:
+            break
+        if leg in line:
+            dropped.append(leg)
+            del line[leg]
+            line["dropped_for_length"] = dropped
+            txt = json.dumps(line, separators=(",", ":"))
     print(txt)
 
 
