@@ -800,6 +800,15 @@ def main():
             if busbw(iso_pg) < DIRECT_BELOW_GBPS and (world >= 3 or backend == "gloo"):
                 try:
                     tr.set_dp_algo("direct")                   # raises on every rank or on none
+                    # a known answer before anything is timed on it: every rank contributes rank + 1 everywhere, the sum is W (W + 1) / 2
+                    tr.arena.fill_(float(rank + 1))
+                    direct_all()
+                    torch.cuda.synchronize()
+                    tr.reducer.check()
+                    wrong = float((tr.arena != world * (world + 1) / 2.0).any().item())
+                    tr.arena.zero_()
+                    if max_over_ranks(wrong) != 0.0:
+                        raise RuntimeError("the peer-pointer exchange returned a wrong sum on this node (known-answer check)")
                     for _ in range(2):
                         tr.step()
                     iso_direct = iso_ms(direct_all)
