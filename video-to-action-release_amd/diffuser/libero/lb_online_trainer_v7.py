@@ -595,7 +595,10 @@ class LB_Online_Trainer_V7(object):
     def _predict(self, img_st, img_goal):
         """EMA policy, DDIM-8: `[1,3,H,W]` start / goal -> clamped actions [n_acts_per_pred, 7] on the host."""
         batch = self.to_batch_dict(img_st, img_goal, None)
-        if self.trainer_dict.get('graphed_rollout', False):
+        # default: one hipGraph replay per call with the eight scheduler steps as one persistent launch (v2a_hip.inference, 4.8 ms against
+        # ~3x that for the eager layer-by-layer call); the trajectory noise then comes from the device Philox stream.  graphed_rollout=False
+        # keeps the eager predict_action, whose noise is torch.randn's (the reference's call: diffusion_unet_image_policy.py:97-101)
+        if self.trainer_dict.get('graphed_rollout', True):
             from v2a_hip.inference import GraphedPredictAction
             ema = self.ema.ema_model                                   # refreshes the packed EMA weights if stale
             if self._graphed_predict is None:
