@@ -7,9 +7,12 @@
 // Why a persistent kernel.  At batch 1-2 a layer is a [<= 32 rows] x [5 * Cin] x [Cout] product: 16 FMAs per weight element, no reuse to
 // speak of -- the step is bound by streaming the 65 M fp32 parameters (260 MB, ~50 us at HBM speed) and by the ~100 dependent launches it
 // used to take (5-6 us each in a replayed graph: 0.6 ms per scheduler step, 5 ms per call).  Here a "launch" is a grid barrier (a few us)
-// and a layer's GroupNorm + Mish + FiLM + residual add live in the NEXT layer's loader, so a scheduler step is ~33 barriers.
+// and a layer's GroupNorm + Mish + FiLM + residual add live in the NEXT layer's loader, so a scheduler step is 35 ops and 30 barriers.
+// Measured (profiles/r05_predict_persistent.txt): 3.9 ms for the eight steps against 5.0 ms layer by layer; a phase costs ~14 us, most of
+// it dependent trips through the memory side, which is why this does not reach the weight-streaming floor.
 //
-// Execution model.  `nwg` workgroups of 256 threads, all resident (<= one per CU), walk the same op list; a grid barrier separates phases.
+// Execution model.  `nwg` workgroups of 512 threads (default 128: half the CUs), all resident, walk the same op list; a grid barrier
+// separates phases.
 // An op is a 1-D convolution over [B][T][C] (channels last) tensors:
 //   loader   every workgroup builds the op's WHOLE input in its LDS: up to two channel-concatenated sources, each
 //            plain | mish(x) | mish(groupnorm(x)) [* film_scale + film_shift] [+ addend] | sin/cos step embedding;
@@ -19,7 +22,7 @@
 //            [Cout][Cin][k] puts a lane's k taps 20 bytes apart and was measured at 1.4 TB/s on the 21 MB layers), the time window of the
 //            input held in registers (each LDS value feeds k FMAs), 4 / 8 / 16 output times per pass
 //   epilogue bias; the last op of a step applies the DDPM / DDIM update to the trajectory in place.
-// ConvTranspose1d (Upsample1d) has its weights as [Cin][Cout][4]: lanes over output channels there, input channels split over the four waves.
+// ConvTranspose1d (Upsample1d) reads torch's [Cin][Cout][4] directly: same wave-per-output-channel scheme, a lane's four taps are 16 bytes.
 // Arithmetic is plain fp32 FMA (exact products, fp32 sums) -- nothing is rounded to 16 bits on this path.
 #include "common.h"
 #include <string.h>
