@@ -303,6 +303,11 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
                            const float* residual, float* y, const void* zeros, int N, int H, int W, int C1, int C2, int Cout, int KH, int KW,
                            int sh, int sw, int ph, int pw, int ups, int idil, int OH, int OW, int rows_per_batch, float* stats,
                            void* workspace, size_t workspace_bytes, v2a_stream_t s);
+/* 1 when v2a_conv2d_fwd_dma_f32 runs this temporal (3 x 1, stride 1, pad (1, 0)) conv over x [B, F, HW, C] -- the `temporal_conv` of the
+   factorised Conv3d, guided_diffusion/nn.py:53-87 -- on the frame-stack three-plane kernel (csrc/igemm_x3t.hip conv_frames_x3: all F = 7
+   frames of 64 pixels x 128 output channels per workgroup, the operands split into bf16 planes once for the three taps; three-plane mode
+   only).  A pure function of the shape. */
+int v2a_conv2d_x3t_eligible(int B, int F, int HW, int C, int Cout, int rows_per_batch, int has_rowvec);
 /* "channel window" form for few-channel inputs (the RGB stem of the policy's ResNet-18 encoders: torchvision resnet18.conv1 7x7 / 2 behind
    diffuser/diffusion_policy/common/vision_nets.py:29-39): pixel (ih, iw) = the C floats at x + ((n * H + ih) * W + iw) * xpitch, xpitch <= C
    (overlapping windows); no padding (the buffer carries its zero border, v2a_nchw_to_nhwc4p); w_packed [Cout][KH][KW][C] (pack mode 2 of

@@ -1104,6 +1104,85 @@ def test_three_plane_halo_conv_vs_fp64(N, HW, Ci, Co, res):
     assert err < 5e-6, err
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Ci,Co,ups,res", [(1, 128, 128, 32, 64, False, False), (2, 24, 48, 96, 128, False, True), (1, 8, 16, 64, 64, False, False),
+                                                 (2, 16, 16, 64, 128, True, True), (1, 64, 64, 32, 64, True, False), (3, 12, 24, 160, 64, True, False),
+                                                 (4, 4, 4, 128, 64, True, False)])
+def test_three_plane_halo_conv_patches_and_upsample_vs_fp64(N, H, W, Ci, Co, ups, res):
+    """conv_halo_x3<0>: 8 x 16 pixel patches of maps that are not one of the square 4 ... 64 sizes (the video UNet's 128 x 128 level,
+    non-square maps, a map that is exactly one patch), and the nearest x2 upsample of unet.py:105-115 folded into the halo gather of every
+    instance (H, W are the SOURCE sizes when ups; the 4 x 4 source lands on the whole-row 8 x 8 instance).  Against fp64 torch."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    g = torch.Generator().manual_seed(N * H + W + Ci)
+    x = torch.randn(N, Ci, H, W, generator=g) * torch.rand(N, Ci, H, W, generator=g).mul(4).exp2()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    b = torch.randn(Co, generator=g)
+    OH, OW = (2 * H, 2 * W) if ups else (H, W)
+    r = torch.randn(N, Co, OH, OW, generator=g) if res else None
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if ups else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    wp = ops.pack_weight(w.to(dev()), 0)
+    y = ops.conv2d(nhwc(x), wp, b.to(dev()), Co, 3, 3, (1, 1), (1, 1), residual=nhwc(r) if res else None, ups=ups)
+    assert ops.last_kernel[0].startswith("conv_halo_x3"), ops.last_kernel[0]
+    assert y.shape == (N, OH, OW, Co)
+    err = (nchw(y).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 5e-6, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("epi", ["residual", "rowvec", "bias"])
+@pytest.mark.parametrize("B,HW,C,Co", [(16, 1024, 128, 128), (4, 4096, 96, 256), (30, 512, 32, 128), (18, 256, 160, 384)])
+def test_three_plane_temporal_frames_kernel_vs_fp64(B, HW, C, Co, epi):
+    """conv_frames_x3 (csrc/igemm_x3t.hip): the (3 x 1) temporal conv of the fp32 video UNet with all 7 frames of 64 pixels in one
+    workgroup and the reduction in 16-channel phases -- first / last frame borders (products against frames -1 and 7 are not issued),
+    several pixel tiles per sample and several tiles per persistent workgroup, 1 .. 5 channel chunks (2 .. 10 phases), bias + per-sample
+    row vector + fp32 residual, statistics in natural 64-row blocks.  Against fp64 torch at the fp32 budget of the three-plane products
+    (measured ~3e-7 of max |y|); bitwise repeatable."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    F = 7
+    g = torch.Generator().manual_seed(11 + B)
+    x = (torch.randn(B, F, HW, C, generator=g) * torch.rand(B, F, HW, C, generator=g).mul(4).exp2()).to(dev())
+    w = (torch.randn(Co, C, 3, 1, generator=g) * 0.08).to(dev())
+    b = torch.randn(Co, generator=g).to(dev())
+    rowvec = torch.randn(B, Co, generator=g).to(dev()) if epi != "bias" else None
+    res = torch.randn(B, F, HW, Co, generator=g).to(dev()) if epi == "residual" else None
+    wp = ops.pack_weight(w, 0)
+    y, st = ops.conv2d(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res, want_stats=True)
+    assert ops.last_kernel[0].startswith("conv_frames_x3") and st is not None, ops.last_kernel[0]
+    xin = x.permute(0, 3, 1, 2).cpu().double()
+    for n in (0, B // 2, B - 1):
+        ref = F_conv(xin[n:n + 1], w.cpu().double(), b.cpu().double()).permute(0, 2, 3, 1)[0]
+        if rowvec is not None:
+            ref = ref + rowvec[n].cpu().double()
+        if res is not None:
+            ref = ref + res[n].cpu().double()
+        err = (y[n].cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (n, err)
+    rows = y.view(-1, 64, Co)                                          # natural block numbering: rows / 64
+    assert torch.allclose(st[:, 0], rows.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[:, 1], (rows * rows).sum(1), rtol=1e-4, atol=1e-1)
+    y2, st2 = ops.conv2d(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=F * HW, residual=res, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(st, st2)                 # fixed summation order
+    # a row vector that is not one row per sample is outside the kernel's contract: the tap-by-tap kernel takes the launch
+    if epi == "rowvec":
+        rv2 = torch.randn(B * F, Co, generator=g).to(dev())
+        y3 = ops.conv2d(x, wp, b, Co, 3, 1, (1, 1), (1, 0), rowvec=rv2, rows_per_batch=HW)
+        assert not ops.last_kernel[0].startswith("conv_frames_x3")
+        ref = F_conv(xin[:1], w.cpu().double(), b.cpu().double()).permute(0, 2, 3, 1)[0] + rv2[:F].cpu().double()[:, None, :]
+        assert (y3[0].cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+
+
+def F_conv(x, w, b):
+    return F.conv2d(x, w, b, padding=(1, 0))
+
+
 def test_two_host_threads_two_streams_do_not_disturb_each_other():
     """SURVEY 8b / VERDICT r4 next #5: the C ABI is "thread-safe for distinct streams ... no hidden global state".  Two host threads, each
     on a stream and a scratch lane of its own, run DIFFERENT operands through the entry points that used to hand operands over in process

@@ -1,0 +1,6 @@
+// Internal (not part of the C ABI): launcher of conv_frames_x3 (csrc/igemm_x3t.hip), called from conv_dma_launch (csrc/igemm_h.hip).
+#pragma once
+#include "common.h"
+int conv_frames_x3_eligible(int B, int F, int HW, int C, int Cout, int rows_per_batch, bool has_rowvec);
+int conv_frames_x3_launch(const float* x, const float* w_packed, const float* bias, const float* rowvec, const float* residual, float* y,
+                          const void* zeros, int B, int F, int HW, int C, int Cout, int rows_per_batch, float* stats, hipStream_t stream);

@@ -205,11 +205,16 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
     wsb = lib.v2a_conv2d_dma_f32_workspace_bytes(M, Cout, K)
     ws = workspace(wsb, x.device) if wsb else None
     last_kernel[0] = _plan_name_h(M, Cout, K, 32, "float")
-    # mirrors conv_dma_launch (csrc/igemm_h.hip): 3x3 / stride 1 / pad 1 over square 4 ... 32-wide maps -> the three-plane halo kernel
-    if (lib.v2a_get_f32_conv_mode() == 1 and KH == 3 and KW == 3 and (sh, sw, ph, pw) == (1, 1, 1, 1) and not ups and idil == 1
-            and x2 is None and H == W and (OH, OW) == (H, W) and W in (4, 8, 16, 32, 64) and M % 128 == 0 and Cout % 64 == 0
-            and not want_stats):
-        last_kernel[0] = f"conv_halo_x3<{W}>"
+    # mirrors conv_dma_launch (csrc/igemm_h.hip): 3x3 / stride 1 / pad 1 (optionally behind the x2 upsample) -> the three-plane halo
+    # kernel: whole rows of square 4 ... 64-wide maps, 8 x 16 pixel patches of every other map with OH % 8 == 0, OW % 16 == 0
+    sq = OH == OW and OW in (4, 8, 16, 32, 64)
+    if (lib.v2a_get_f32_conv_mode() == 1 and KH == 3 and KW == 3 and (sh, sw, ph, pw) == (1, 1, 1, 1) and idil == 1
+            and x2 is None and (OH, OW) == ((2 * H, 2 * W) if ups else (H, W)) and (sq or (OH % 8 == 0 and OW % 16 == 0))
+            and M % 128 == 0 and Cout % 64 == 0 and not want_stats and N * H * W * C1 < 2 ** 31):
+        last_kernel[0] = f"conv_halo_x3<{OW}>" if sq else "conv_halo_x3<8x16>"
+    if (lib.v2a_get_f32_conv_mode() == 1 and (KH, KW, sh, sw, ph, pw) == (3, 1, 1, 1, 1, 0) and not ups and idil == 1 and x2 is None
+            and (OH, OW) == (H, W) and lib.v2a_conv2d_x3t_eligible(N, H, W, C1, Cout, rows_per_batch, 0 if rowvec is None else 1)):
+        last_kernel[0] = "conv_frames_x3<448x128>"
     if defer and wsb and rowvec is None:
         import ctypes
         ns = ctypes.c_int(0)
