@@ -308,6 +308,11 @@ int v2a_conv2d_fwd_dma_f32(const float* x, const float* x2, const float* w_packe
    frames of 64 pixels x 128 output channels per workgroup, the operands split into bf16 planes once for the three taps; three-plane mode
    only).  A pure function of the shape. */
 int v2a_conv2d_x3t_eligible(int B, int F, int HW, int C, int Cout, int rows_per_batch, int has_rowvec);
+/* 1 when v2a_conv2d_fwd_dma_f32 runs this 3 x 3 / stride 1 / pad 1 conv over an H x W map (H, W: the conv's map, i.e. twice the source's
+   behind an upsample) -- the `spatial_conv` of the factorised Conv3d -- on the phase-structured patch kernel (csrc/igemm_x3p.hip
+   conv_patch_x3: a 16 x 16 pixel patch x 128 output channels per persistent workgroup; three-plane mode, no row vector / statistics).
+   Depends on the shape and the device's CU count only. */
+int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
 /* "channel window" form for few-channel inputs (the RGB stem of the policy's ResNet-18 encoders: torchvision resnet18.conv1 7x7 / 2 behind
    diffuser/diffusion_policy/common/vision_nets.py:29-39): pixel (ih, iw) = the C floats at x + ((n * H + ih) * W + iw) * xpitch, xpitch <= C
    (overlapping windows); no padding (the buffer carries its zero border, v2a_nchw_to_nhwc4p); w_packed [Cout][KH][KW][C] (pack mode 2 of

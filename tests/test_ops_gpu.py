@@ -1179,6 +1179,40 @@ def test_three_plane_temporal_frames_kernel_vs_fp64(B, HW, C, Co, epi):
         assert (y3[0].cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Ci,Co,ups,res", [(7, 64, 64, 64, 256, False, False), (56, 32, 32, 32, 128, False, True), (28, 16, 16, 96, 256, True, False),
+                                                 (4, 48, 64, 160, 640, False, True), (7, 64, 64, 128, 128, True, False)])
+def test_three_plane_patch_conv_vs_fp64(N, H, W, Ci, Co, ups, res):
+    """conv_patch_x3 (csrc/igemm_x3p.hip): 3x3 / stride 1 / pad 1 on 16 x 16 pixel patches x 128 output channels per persistent
+    workgroup, reduction in (chunk, 16-channel half, filter row) phases -- one to five chunks, one and several output-channel tiles per
+    patch, image borders on every side of a patch, a non-square map, fewer tiles than workgroup slots and several tiles per workgroup,
+    the folded nearest x2 upsample (H, W = SOURCE sizes then), bias + fp32 residual.  Against fp64 torch; bitwise repeatable."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    g = torch.Generator().manual_seed(N * H + W + Ci)
+    x = torch.randn(N, Ci, H, W, generator=g) * torch.rand(N, Ci, H, W, generator=g).mul(4).exp2()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    b = torch.randn(Co, generator=g)
+    OH, OW = (2 * H, 2 * W) if ups else (H, W)
+    r = torch.randn(N, Co, OH, OW, generator=g) if res else None
+    wp = ops.pack_weight(w.to(dev()), 0)
+    xd, rd = nhwc(x), (nhwc(r) if res else None)
+    y = ops.conv2d(xd, wp, b.to(dev()), Co, 3, 3, (1, 1), (1, 1), residual=rd, ups=ups)
+    assert ops.last_kernel[0].startswith("conv_patch_x3"), ops.last_kernel[0]
+    assert y.shape == (N, OH, OW, Co)
+    for n in sorted({0, N // 2, N - 1}):
+        xin = F.interpolate(x[n:n + 1].double(), scale_factor=2, mode="nearest") if ups else x[n:n + 1].double()
+        ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+        if res:
+            ref = ref + r[n:n + 1].double()
+        err = (nchw(y[n:n + 1]).double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (n, err)
+    y2 = ops.conv2d(xd, wp, b.to(dev()), Co, 3, 3, (1, 1), (1, 1), residual=rd, ups=ups)
+    assert torch.equal(y, y2)
+
+
 def F_conv(x, w, b):
     return F.conv2d(x, w, b, padding=(1, 0))
 

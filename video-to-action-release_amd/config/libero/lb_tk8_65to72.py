@@ -1,7 +1,7 @@
 """Hyper-parameters of the released Libero 8-task run, grouped by what they steer (values as published in the reference's
 config/libero/lb_tk8_65to72.py:33-165).  `scripts/train_libero_dp.py --config <this file>` reads `base['diffusion']`."""
 from diffuser.libero.lb_constants import LB_GRASP_actdown_value_range_1
-from diffuser.libero._host_utils import LB_ACTION_MIN, LB_ACTION_MAX
+from diffuser.datasets import LB_ACTION_MIN, LB_ACTION_MAX
 
 ACTION_HORIZON = 16          # actions predicted per policy call (8 of them are executed)
 

@@ -1655,6 +1655,12 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
     }
     if constexpr (sizeof(T) == 4) {
         f32_conv_mode_init();
+        // 3x3 / stride 1 / pad 1 on maps of 16 x 16 patches with >= 128 output channels: the phase-structured patch kernel (csrc/igemm_x3p.hip)
+        if (g_f32x3 && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && idil == 1 && !x2 && C2 == 0 &&
+            (ups ? (OH == 2 * H && OW == 2 * W) : (OH == H && OW == W)) && !stats && !rowvec && y &&
+            v2a_conv2d_x3p_eligible(N, OH, OW, C1, Cout))
+            return conv_patch_x3_launch((const float*)x, (const float*)w_packed, bias, (const float*)residual, (float*)y, zeros, N, OH, OW, C1,
+                                        Cout, ups, stream);
         const bool hx_square = OH == OW && (OW == 4 || OW == 8 || OW == 16 || OW == 32 || OW == 64);
         const bool hx_patch = !hx_square && OH % 8 == 0 && OW % 16 == 0;
         if (g_f32x3 && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && idil == 1 &&

@@ -4,3 +4,7 @@
 int conv_frames_x3_eligible(int B, int F, int HW, int C, int Cout, int rows_per_batch, bool has_rowvec);
 int conv_frames_x3_launch(const float* x, const float* w_packed, const float* bias, const float* rowvec, const float* residual, float* y,
                           const void* zeros, int B, int F, int HW, int C, int Cout, int rows_per_batch, float* stats, hipStream_t stream);
+int conv_patch_x3_eligible(int N, int H, int W, int C, int Cout, int ncu);
+int conv_patch_x3_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, const void* zeros, int N,
+                         int H, int W, int C, int Cout, int ups, hipStream_t stream);
+extern "C" int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
