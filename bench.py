@@ -63,7 +63,7 @@ def _leg_traffic(leg, batch_scale=1.0):
 # The driver keeps the last 8 KB of stdout: the FULL record (every note, every conv variant) goes to bench_full_last.json + stderr, the
 # line on stdout is the same record with prose dropped, floats rounded to 5 significant digits and long strings cut -- so that the
 # bf16 leg, the sampler legs, predict_action and every cpu_baseline survive in the driver's copy.
-_DROP = {"note", "timing", "isolation", "traffic_source", "source", "settings", "all_conv_variants", "hbm_bytes_incl_setup_of_the_profiled_run",
+_DROP = {"note", "timing", "isolation", "traffic_source", "source", "settings", "all_conv_variants", "families", "hbm_bytes_incl_setup_of_the_profiled_run",
          "per", "cpu_model_detail", "image", "action"}
 _KEEP_STR = 110
 
@@ -100,9 +100,10 @@ def _emit(out):
         pass
     print("[bench full record] " + full, file=sys.stderr)
     line = _compact(out)
-    if isinstance(out.get("roofline"), dict) and "all_conv_variants" in out["roofline"]:      # the three largest families, by time
-        top = sorted(out["roofline"]["all_conv_variants"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
-        line["roofline"]["top_conv_variants"] = {k: _compact(v) for k, v in top}
+    if isinstance(out.get("roofline"), dict) and "families" in out["roofline"]:      # the three largest source-kernel families, by in-graph time
+        fams = out["roofline"]["families"]
+        top = sorted(fams.items(), key=lambda kv: -(kv[1].get("ms_per_step_in_graph") or 0.0))[:3]
+        line["roofline"]["top_families"] = {k: _compact(v) for k, v in top}
     for leg in ("policy_exact", "video_exact"):  # the strict-arithmetic legs: the numbers only (everything else is in the full record)
         if isinstance(line.get(leg), dict):
             line[leg] = {k: v for k, v in line[leg].items() if k in ("value", "unit", "ms_per_step", "seconds_per_sample_call", "f32_conv_mode",
@@ -139,6 +140,56 @@ def _emit(out):
             line["dropped_for_length"] = dropped
             txt = json.dumps(line, separators=(",", ":"))
     print(txt)
+
+
+def _family(name):
+    """Source-kernel family of a kernel name: 'void conv_igemm_f32x3<64, 64, 2, 2, 2, false>(ConvDescH)' and the launcher's plan name
+    'conv_igemm_f32x3<64,64>' -> 'conv_igemm_f32x3' (every instance of one template is one kernel: same source, same roofline)."""
+    n = name.replace("void ", "").strip()
+    for sep in ("<", "("):
+        i = n.find(sep)
+        if i > 0:
+            n = n[:i]
+    return n[:-len("_kernel")] if n.endswith("_kernel") else n
+
+
+def _live_kernel_stats(precision, batch, steps=10, warmup=3, timeout=420):
+    """Per-family launch statistics of the CAPTURED policy step, measured in THIS bench run: a child `rocprofv3 --kernel-trace --stats` of
+    this script (policy leg only, no secondary legs) in a scratch directory; returns ({family: [calls, total_ns]}, csv_path) or (None, why).
+    The same command as tools/profile_round.sh's first line, whose summary is committed under profiles/ per round."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="v2a_bench_prof_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "policy", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch), "--precision", precision, "--no-cpu-baseline", "--no-video",
+           "--no-bf16-extra", "--no-predict", "--no-roofline-pass", "--no-video-train"]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, f"rocprofv3 child rc {r.returncode}: {r.stderr[-300:]}"
+        fam = {}
+        for row in csv.DictReader(open(files[0])):
+            d = fam.setdefault(_family(row["Name"]), [0, 0.0])
+            d[0] += int(row["Calls"])
+            d[1] += float(row["TotalDurationNs"])
+        keep = os.path.join(ROOT, "gpurun_out", "bench_live_policy_kernel_stats.csv")      # scratch copy for the round's profiles/ commit
+        try:
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            shutil.copyfile(files[0], keep)
+        except Exception:
+            keep = files[0]
+        return fam, keep
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _graph_avg_us(kernel_prefix, csv_name="r05_policy_kernel_stats.csv"):
@@ -530,10 +581,14 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
     for name, fl, e0, e1 in recs:
         v = agg.setdefault(name, [0.0, 0.0, 0])
         v[0] += fl; v[1] += e0.elapsed_time(e1) * 1e-3; v[2] += 1
-    name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+    famv = {}                                     # source-kernel families (every instance of one template is one kernel)
+    for k, v in agg.items():
+        d = famv.setdefault(_family(k), [0.0, 0.0, 0])
+        d[0] += v[0]; d[1] += v[1]; d[2] += v[2]
+    name, (fl, sec, cnt) = max(famv.items(), key=lambda kv: kv[1][1])
     ach = fl / sec / 1e12
     std = batch == 16 and size == 128
-    x3 = "f32x3" in name                          # fp32 products from three bf16 planes: the kernel's peak is the bf16 matrix peak / 6
+    x3 = "x3" in name                             # fp32 products from three bf16 planes: the kernel's peak is the bf16 matrix peak / 6
     pk = (BF16_MFMA_PEAK_TFLOPS / 6.0) if x3 else FP32_MFMA_PEAK_TFLOPS
     res["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s",
                        "frac": ach / pk, "frac_of_f32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
@@ -544,6 +599,8 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
                        "traffic_vs_algorithmic": _leg_traffic(traffic_leg) if std else None, "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
                        "share_of_conv_time": sec / sum(v[1] for v in agg.values()),
                        "end_to_end_frac": flops / dt / 1e12 / pk,
+                       "frac_src": "HIP events around every launch of one eager UNet forward of this run (ms-scale launches: eager = in-graph)",
+                       "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]} for k, v in sorted(famv.items())},
                        "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_unet_fwd": v[1] * 1e3, "launches": v[2]}
                                              for k, v in sorted(agg.items())}}
     return res
@@ -913,31 +970,51 @@ def main():
         if not args.no_roofline_pass:
             agg = instrumented_pass(torch, tr, 3)
             tot = sum(v[1] for v in agg.values())
-            # kernel FAMILIES for the choice of the dominant kernel: the conv_halo_x3<OW> instances are one kernel (same source, same
-            # 128 x 64 tile, same roofline; OW only fixes the halo geometry) -- the per-instance figures stay in all_conv_variants
+            # Kernel FAMILIES = source kernels (every instance of one template: conv_igemm_f32x3<BM, BN, ...>, conv_halo_x3<OW> ...); the
+            # per-instance figures stay in all_conv_variants.  FLOPs per launch come from the instrumented eager pass (the launcher's
+            # shapes); the DURATIONS that price them are the in-graph ones of the captured step, measured by a rocprofv3 --kernel-trace
+            # --stats child of this very run (the eager figure stays on the line as avg_launch_us_eager).
             fam = {}
             for k, v in agg.items():
-                fk = "conv_halo_x3" if k.startswith("conv_halo_x3<") else k
-                d = fam.setdefault(fk, [0.0, 0.0, 0])
+                d = fam.setdefault(_family(k), [0.0, 0.0, 0])
                 d[0] += v[0]; d[1] += v[1]; d[2] += v[2]
-            name, (fl, sec, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
-            achieved = fl / sec / 1e12
+            live, live_src = _live_kernel_stats(args.precision, args.batch)
+            if live:
+                have = {k: v for k, v in fam.items() if k in live}
+                name = max(have, key=lambda k: live[k][1]) if have else max(fam, key=lambda k: fam[k][1])
+            else:
+                name = max(fam, key=lambda k: fam[k][1])
+            fl, sec, cnt = fam[name]
             x3 = "x3" in name                        # fp32 products from three bf16 planes: six bf16 MFMAs per product block
             peak = (BF16_MFMA_PEAK_TFLOPS / 6.0) if x3 else (FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS)
-            g_us = (_graph_avg_us(name.rstrip(">") + ",") or _graph_avg_us(name.rstrip(">") + ">") or _graph_avg_us(name + "_kernel")
-                    or _graph_avg_us(name + "<"))
+            eager_tf = fl / sec / 1e12
+            if live and name in live:
+                g_us = live[name][1] / live[name][0] / 1e3
+                frac_source = "in-graph launch durations: rocprofv3 --kernel-trace --stats child of this bench run"
+                conv_live = sum(v[1] for k, v in live.items() if k in fam)
+                share = live[name][1] / conv_live if conv_live else None
+            else:
+                g_us = (_graph_avg_us(name + "<") or _graph_avg_us(name + "_kernel") or _graph_avg_us(name))
+                frac_source = f"in-graph durations from the COMMITTED profiles/r05_policy_kernel_stats.csv ({live_src}); eager figure if absent"
+                share = sec / tot
+            achieved = ((fl / cnt) / (g_us * 1e-6) / 1e12) if g_us else eager_tf
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                               "frac": achieved / peak,
+                               "frac": achieved / peak, "frac_src": frac_source,
                                "peak_is": ("dense bf16 MFMA peak 2500 / 6 plane products per fp32 product (three-plane kernels)" if x3 else
                                            "dense MFMA peak of the dtype"),
                                "frac_of_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else None,
-                               "frac_in_graph": ((fl / cnt) / (g_us * 1e-6) / 1e12 / peak) if g_us else None,
-                               "avg_launch_us_in_graph": g_us,
-                               "traffic": _traffic("policy", name), "traffic_source": TRAFFIC_SOURCE,
+                               "frac_eager": eager_tf / peak, "avg_launch_us": g_us if g_us else sec / cnt * 1e6,
+                               "avg_launch_us_eager": sec / cnt * 1e6, "live_stats_csv": live_src if live else None,
+                               "traffic": _traffic("policy", name), "traffic_src": "committed profiles/roofline_traffic.json (PMC passes of a separate run)",
+                               "traffic_source": TRAFFIC_SOURCE,
                                "traffic_vs_algorithmic": _leg_traffic("policy") if (args.batch == 64 and args.precision == "fp32") else None,
-                               "launches": cnt, "avg_launch_us": sec / cnt * 1e6, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
-                               "share_of_conv_time": sec / tot, "whole_step_frac_of_mfma_floor": flops_step / (ms * 1e-3) / 1e12 / peak,
+                               "launches": cnt, "launches_per_step": cnt / 3, "algorithmic_gflop_per_launch": fl / cnt / 1e9,
+                               "share_of_conv_time": share, "whole_step_frac_of_mfma_floor": flops_step / (ms * 1e-3) / 1e12 / peak,
                                "whole_step_frac_of_f32_mfma_floor": flops_step / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                               "families": {k: {"tflops_eager": v[0] / v[1] / 1e12, "launches_per_step": v[2] / 3,
+                                                "tflops_in_graph": ((v[0] / v[2]) / (live[k][1] / live[k][0] * 1e-9) / 1e12) if (live and k in live) else None,
+                                                "ms_per_step_in_graph": (live[k][1] / live[k][0] * (v[2] / 3) * 1e-6) if (live and k in live) else None}
+                                            for k, v in sorted(fam.items())},
                                "all_conv_variants": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 3 * 1e3, "launches_per_step": v[2] / 3}
                                                      for k, v in sorted(agg.items())}}
         if cpu is not None:

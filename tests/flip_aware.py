@@ -58,4 +58,9 @@ def check_routing(rec, use, tag=""):
         worst = max(worst, g)
         assert g <= TIE, f"{tag}{name}: {k} decisions differ and the furthest is no tie ({g:.2e} of max |z|)"
     assert n_diff <= max(1, int(FRAC * n_tot)), f"{tag}{n_diff} of {n_tot} decisions differ"
+    try:
+        from conftest import parity_record
+        parity_record(f"{tag}routing: share of decisions differing", n_diff / max(n_tot, 1), FRAC, largest_tie_distance=worst, tie_bound=TIE)
+    except ImportError:
+        pass
     return n_diff, n_tot, worst

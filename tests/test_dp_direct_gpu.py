@@ -130,6 +130,15 @@ def test_direct_exchange_three_ranks_sum_in_rank_order():
         assert ok == [True, True], f"rank {rank}: {ok}"
 
 
+def test_direct_exchange_eight_ranks_share_one_gpu():
+    """The geometry of a full node: W = 8 chunking of both slices, seven peers mapped per rank, eight-way flag barriers,
+    sums in rank order ((((g0 + g1) + g2) + ...) + g7) / 8 on the chunk's owner -- bit-equal to the host's sum in that order, on every rank."""
+    res = _run(_three_worker, world=8, timeout=900)
+    assert len(res) == 8
+    for rank, ok, _ in res:
+        assert ok == [True, True], f"rank {rank}: {ok}"
+
+
 def _lost_rank_worker(rank, world, port, q):
     """Rank 1 never launches: rank 0's kernel must give up after its budget, terminate, and the host must say which peer was missing."""
     try:
@@ -252,3 +261,78 @@ def test_policy_trainer_two_ranks_direct_exchange_equals_the_all_reduce_run():
     for algo, res in runs.items():
         assert np.array_equal(res[0][1][2], res[1][1][2]) and res[0][1][1] == res[1][1][1], f"{algo}: replicas diverged"
         assert res[0][1][0] != res[1][1][0]
+
+
+def _eight_worker(rank, world, port, q):
+    """B = 8 rows of ONE 64-row batch per rank (same rows / noise / timesteps as the single-rank B = 64 step rank 0 also runs), two eager
+    steps over the direct exchange."""
+    try:
+        dist = _init(rank, world, port)
+        import random
+        from diffuser.diffusion_policy.get_dp import build_policy, DEFAULT_CONF
+        from v2a_hip.replay import ReplayStore, sample_indices
+        from v2a_hip.trainer import PolicyTrainer
+
+        def make(batch, pg, w, r):
+            torch.manual_seed(1)
+            pol = build_policy(DEFAULT_CONF).to("cuda:0")
+            store = ReplayStore(64, 200, 30, capacity_frames=40 * 12)
+            gen = torch.Generator().manual_seed(3)
+            for e in range(12):
+                n = 30 + e
+                store.add_one_episode("t", "agentview", e, torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=gen),
+                                      torch.rand(n - 1, 7, generator=gen) * 2 - 1)
+            tr = PolicyTrainer(pol, store, batch_size=batch, seed=11, use_graph=False, process_group=pg, world_size=w, rank=r,
+                               dp_algo="direct" if w > 1 else "rccl")
+            return pol, store, tr
+
+        pol, store, tr = make(8, dist.group.WORLD, world, rank)
+        np.random.seed(5); random.seed(5)
+        feeds = []
+        for step in range(2):
+            ep, st = sample_indices(store.episode_lengths(), 64, store.act_len)
+            g = torch.Generator().manual_seed(100 + step)
+            feeds.append({"rows": np.asarray(store.pool_rows(ep, st)), "noise": torch.randn(64, store.act_len, store.act_dim, generator=g),
+                          "timesteps": torch.randint(0, 100, (64,), generator=g)})
+        grads = []
+        tr.on_grads_ready = lambda arena: grads.append(arena.detach().clone())
+        for step in range(2):
+            f = feeds[step]
+            tr.feed = {"rows": f["rows"][8 * rank:8 * rank + 8], "noise": f["noise"][8 * rank:8 * rank + 8],
+                       "timesteps": f["timesteps"][8 * rank:8 * rank + 8]}
+            tr.step()
+        torch.cuda.synchronize()
+        tr.reducer.check()
+        flat = torch.cat([p.detach().flatten() for p in pol.parameters()])
+        res = {"algo": tr.reducer.algo, "pnorm": float(flat.double().norm()), "psample": flat[::9973].cpu().numpy(), "launches": tr.reducer.launches}
+        if rank == 0:                                             # the single-rank step over all 64 rows
+            pol1, _, tr1 = make(64, None, 1, 0)
+            g1 = []
+            tr1.on_grads_ready = lambda arena: g1.append(arena.detach().clone())
+            tr1.feed = feeds[0]
+            tr1.step()
+            torch.cuda.synchronize()
+            mean8 = grads[0] * (1.0 / world)                      # the exchange leaves the SUM; the optimiser's gradient scale carries 1 / W
+            res["err"] = float((mean8 - g1[0]).abs().max())
+            res["scale"] = float(g1[0].abs().max())
+            res["numel"] = int(g1[0].numel())
+        q.put((rank, res, None))
+        dist.barrier()
+        tr.reducer.close()
+        dist.destroy_process_group()
+    except Exception:                                             # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise
+
+
+def test_policy_trainer_eight_ranks_share_one_gpu():
+    """Eight PolicyTrainer ranks (B = 8 each) on one GPU over the direct exchange: the replicas stay identical over two steps, and the
+    averaged gradient of step 1 equals the B = 64 single-rank gradient of the same rows to 1e-6 of its largest entry (DDP's contract:
+    reference lb_online_trainer_v7.py:153-154,604-608)."""
+    res = _run(_eight_worker, world=8, timeout=1200)
+    r0 = res[0][1]
+    assert r0["algo"] == "direct" and r0["launches"] == 4
+    assert r0["numel"] == 87_219_143 and r0["err"] <= 1e-6 * r0["scale"], (r0["err"], r0["scale"])
+    for rank, r, _ in res[1:]:
+        assert r["pnorm"] == r0["pnorm"] and np.array_equal(r["psample"], r0["psample"]), f"replica {rank} diverged"

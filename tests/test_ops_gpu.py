@@ -19,6 +19,8 @@ def close(a, b, tol=1e-4, what=""):
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     scale = b.abs().max().item() + 1e-12
     err = (a - b).abs().max().item()
+    from conftest import parity_record
+    parity_record(what or "close", err / scale, tol)
     assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 

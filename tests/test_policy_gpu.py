@@ -24,8 +24,9 @@ def _batch(g):
 
 
 def rel(a, b):
+    from conftest import parity_record
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    return parity_record("rel", ((a - b).abs().max() / (b.abs().max() + 1e-30)).item())
 
 
 def test_compute_loss_and_grads_vs_golden_and_oracle(golden_dir):
@@ -75,6 +76,9 @@ def test_compute_loss_and_grads_vs_golden_and_oracle(golden_dir):
     worst = max(dist.values())
     print(f"[golden B=2] {nd} of {nt} encoder decisions differ from the CPU oracle's (largest tie distance {tie:.1e}); worst gradient tensor "
           f"vs the oracle routed through the HIP decisions {worst:.2e}")
+    from conftest import parity_record
+    parity_record("worst gradient tensor vs oracle routed through the HIP decisions", worst, TOL, decisions_differing=nd, decisions_total=nt,
+                  largest_tie_distance=tie, encoders_skipped_in_golden_comparison=len(flipped))
     assert worst <= TOL, {n: d for n, d in dist.items() if d > TOL}
 
 
@@ -102,6 +106,9 @@ def test_predict_action_vs_golden(golden_dir, use_ddim, seed, key):
     exact = OP.predict_action(sd64, {k: v.double() for k, v in _batch(g)["obs"].items()}, init, stepn, use_ddim=use_ddim)["action_pred"]
     ref_dev, err_exact = rel(g[key], exact), rel(out["action_pred"], exact)
     print(f"[predict_action {key}] HIP vs reference {err:.2e}; HIP vs fp64 {err_exact:.2e}; reference fp32 vs fp64 {ref_dev:.2e}")
+    from conftest import parity_record
+    parity_record(f"predict_action {key}: HIP vs reference", err, max(TOL, 4 * ref_dev), carried_by="1e-4" if err <= TOL else "4 x reference's own fp32-vs-fp64 distance",
+                  hip_vs_fp64=err_exact, reference_vs_fp64=ref_dev)
     assert err <= max(TOL, 4 * ref_dev), (err, ref_dev)
     if use_ddim:
         assert rel(out["action"], g["ddim_action"]) <= TOL

@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 def rel(a, b):
+    from conftest import parity_record
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    return parity_record("rel", ((a - b).abs().max() / (b.abs().max() + 1e-30)).item())
 
 
 def _sample_idx(n, k, seed):
