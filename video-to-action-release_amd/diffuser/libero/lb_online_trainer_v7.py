@@ -372,6 +372,7 @@ class LB_Online_Trainer_V7(object):
     _CKPT_SCALARS = ('step', 'num_steps_in_env', 'cnt_vid_rollouts', 'cnt_vid_rout_per_tk')
 
     def save(self, milestone):
+        self.ptrainer.verify_exchange()          # (every rank) a step whose gradient exchange gave up must not reach a checkpoint
         if not self.accelerator.is_local_main_process:
             return
         data = {k: getattr(self, k) for k in self._CKPT_SCALARS}
@@ -544,8 +545,9 @@ class LB_Online_Trainer_V7(object):
         GroupNorm, per-frame attention; one Philox seed per row, so row j draws exactly the noise of the bs-1 call with that seed and
         its frames equal that call's up to the kernels' batch-size-dependent summation order, <= 1e-4 in fp32: tests/test_joint_loop.py),
         then the rollouts run in the same order.  2.3 s instead of 5.2 s of sampling per 8-task round
-        (bench.py `video_round8`).  What differs from the reference's one-at-a-time loop: the task strings of a round are tokenised as
-        one padded batch, and the host generators see the round's environment draws before its rollout draws.  False: the reference's
+        (bench.py `video_round8`).  Every task string is still tokenised and encoded on its own (no padding: `Video_PredModel.encode_rows`),
+        so each row's conditioning is the one-at-a-time loop's; what differs from it: the host generators see the round's environment draws
+        before its rollout draws.  False: the reference's
         order, one combination at a time."""
         self.env_list.check_no_envs_exist()
         n_before = len(self.envBuf_vid)
@@ -565,11 +567,13 @@ class LB_Online_Trainer_V7(object):
             seeds = [_draw_philox_seed(self.device) for _ in combos]          # one sampler seed per combination, in round order
             from ..models.video_model import _spaced
             with torch.no_grad():
-                emb = self.video_model.encode_batch_text(_spaced(all_tasks))      # (one padded token batch for the round)
+                # every task string is tokenised and encoded ON ITS OWN (unpadded, as the reference's bs = 1 loop does); only the sampler
+                # call is batched -- a ragged list of token features (GoalGaussianDiffusion.sample embeds each row separately)
+                emb = self.video_model.encode_rows(_spaced(all_tasks))
                 if not self.trainer_dict.get('_explore_rows_one_by_one'):
                     videos = self.video_model.forward(start_all.to(self.device), emb, row_seeds=seeds)
-                else:     # test hook: the same rows through bs-1 calls (same token rows, same seeds) -- must give the same frames
-                    videos = torch.cat([self.video_model.forward(start_all[j:j + 1].to(self.device), emb[j:j + 1], row_seeds=seeds[j:j + 1])
+                else:     # test hook: the same rows through bs-1 calls of the plain [1, L, 512] form (the reference's call), same seeds
+                    videos = torch.cat([self.video_model.forward(start_all[j:j + 1].to(self.device), emb[j], row_seeds=seeds[j:j + 1])
                                         for j in range(len(combos))], dim=0)
             self._last_explore_videos = videos
             for j, (tk, cam, idx) in enumerate(combos):
@@ -602,7 +606,10 @@ class LB_Online_Trainer_V7(object):
             from v2a_hip.inference import GraphedPredictAction
             ema = self.ema.ema_model                                   # refreshes the packed EMA weights if stale
             if self._graphed_predict is None:
-                self._graphed_predict = GraphedPredictAction(ema, batch_size=1, use_ddim=True, seed=self.trainer_dict.get('seed', 0))
+                # per-rank noise stream (as PolicyTrainer's: seed + 7919 x rank), or every data-parallel rank would draw the same
+                # trajectory noise for its k-th call
+                self._graphed_predict = GraphedPredictAction(ema, batch_size=1, use_ddim=True,
+                                                             seed=self.trainer_dict.get('seed', 0) + 7919 * int(self.accelerator.process_index))
             act = self._graphed_predict(batch['obs'])['action'].cpu()
         else:
             act = self.ema.ema_model.predict_action(batch['obs'], use_ddim=True)['action'].cpu()

@@ -65,14 +65,25 @@ class Video_PredModel(nn.Module):
         tok = self.tokenizer(batch_text, return_tensors="pt", padding=True, truncation=True, max_length=128).to(self.device)
         return self.text_encoder(**tok).last_hidden_state
 
+    def encode_rows(self, batch_text):
+        """One tokeniser / text-encoder call PER string -> a list of [1, L_b, 512] features without padding: what the reference's bs = 1
+        exploration loop feeds the sampler for each task (the text branch of the UNet takes no attention mask, so the pad-token states of a
+        padded batch would leak into the shorter strings' conditioning)."""
+        return [self.encode_batch_text([t]) for t in batch_text]
+
     def forward(self, x_conds, tasks, row_seeds=None):
         """row_seeds (extension): one sampler seed per row, see GoalGaussianDiffusion.sample."""
         n = x_conds.shape[0]
         if n != len(tasks):
             raise ValueError(f"{n} conditioning images for {len(tasks)} tasks")
-        tokens = tasks if torch.is_tensor(tasks) else self.encode_batch_text(_spaced(tasks))
+        if torch.is_tensor(tasks):
+            tokens = tasks.to(self.device)
+        elif len(tasks) and torch.is_tensor(tasks[0]):
+            tokens = [t.to(self.device) for t in tasks]          # per-row token features of different lengths (encode_rows): never padded
+        else:
+            tokens = self.encode_batch_text(_spaced(tasks))
         kw = {} if row_seeds is None else {"row_seeds": row_seeds}
-        frames = self.ema.ema_model.sample(batch_size=n, x_cond=x_conds.to(self.device), task_embed=tokens.to(self.device), **kw)
+        frames = self.ema.ema_model.sample(batch_size=n, x_cond=x_conds.to(self.device), task_embed=tokens, **kw)
         b, c, h, w = frames.shape
         return frames.view(b, c // self.single_img_channels, self.single_img_channels, h, w).detach()
 

@@ -211,7 +211,26 @@ class GoalGaussianDiffusion(nn.Module):
         f = C // ci
         eng = self.model._engine()
         x_cond = x_cond.to(device).float().contiguous()
-        task_embed = task_embed.to(device).float().contiguous()
+        # task_embed: [B, L, D] token features, or (extension) a list of B per-row tensors [1, L_b, D] / [L_b, D] of DIFFERENT lengths: the text
+        # branch takes no attention mask, so rows of a padded batch would mix pad-token states into their conditioning -- a ragged batch
+        # embeds every row on its own, unpadded, exactly as the reference's one-at-a-time loop does (lb_online_trainer_v7.py:871-891)
+        te_rows = None
+        if isinstance(task_embed, (list, tuple)):
+            te_rows = [t.to(device).float().reshape(1, -1, t.shape[-1]).contiguous() for t in task_embed]
+            assert len(te_rows) == B, (len(te_rows), B)
+            lmax = max(t.shape[1] for t in te_rows)
+            task_embed = torch.zeros((B, lmax, te_rows[0].shape[-1]), dtype=torch.float32, device=device)      # identity of the batch: cache key only
+            for b, t in enumerate(te_rows):
+                task_embed[b, :t.shape[1]] = t[0]
+            te_lens = tuple(t.shape[1] for t in te_rows)
+        else:
+            task_embed = task_embed.to(device).float().contiguous()
+            te_lens = None
+
+        def embed(zeros=False):
+            if te_rows is None:
+                return eng.label_embedding(torch.zeros_like(task_embed) if zeros else task_embed)
+            return torch.cat([eng.label_embedding(torch.zeros_like(t) if zeros else t) for t in te_rows], dim=0)
         gw = float(self.guidance_weight)
         rows = self._step_rows(return_all_timesteps)
         hook = self.__dict__.get("_noise_hook")
@@ -229,8 +248,8 @@ class GoalGaussianDiffusion(nn.Module):
         elif row_seeds is not None:
             raise ValueError("row_seeds and an injected noise stream (_noise_hook) exclude each other")
         if not use_graph:
-            label = eng.label_embedding(task_embed)                               # t-independent: once per call
-            label_u = eng.label_embedding(torch.zeros_like(task_embed)) if gw > 0.0 else None
+            label = embed()                                                       # t-independent: once per call
+            label_u = embed(zeros=True) if gw > 0.0 else None
             table = ops.video_denoise_table(rows, device)
             state = None
             if hook is None:
@@ -267,7 +286,7 @@ class GoalGaussianDiffusion(nn.Module):
             return img
         # ---- whole-loop hipGraph
         key = (B, C, H, W, ci, gw > 0.0, self.objective, getattr(eng, "storage", "f32"), v2a_hip.get_precision(), tuple(task_embed.shape),
-               id(eng), len(rows), rs is not None, self._weights_version())
+               te_lens, id(eng), len(rows), rs is not None, self._weights_version())
         ent = _SGRAPHS.get(self)
         if ent is None:
             ent = _SGRAPHS[self] = {"lru": {}, "graph": None}
@@ -284,7 +303,9 @@ class GoalGaussianDiffusion(nn.Module):
         g["x_cond"].copy_(x_cond)
         if not torch.equal(g["task_embed"], task_embed):          # the text branch does not depend on t: recomputed only when it changes
             g["task_embed"].copy_(task_embed)
-            g["label"].copy_(eng.label_embedding(task_embed))
+            g["label"].copy_(embed())
+            if te_rows is not None and g["label_u"] is not None:  # (zeros of each row's own length; the dense form was embedded at capture)
+                g["label_u"].copy_(embed(zeros=True))
         ops.video_denoise_table(rows, device, out=g["table"])
         g["state"].copy_(torch.tensor([0, seed, off0], dtype=torch.int64))
         g["tt"].fill_(rows[0][10])
@@ -327,7 +348,7 @@ class GoalGaussianDiffusion(nn.Module):
         step()                                    # eager once: weight packs, workspaces, allocator warm
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, **ops.graph_capture_mode()):
             step()
         g["graph"] = graph
         return g

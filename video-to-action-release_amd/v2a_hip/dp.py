@@ -186,6 +186,7 @@ class GradReducer:
         self._works = []
         self._launched = set()
         self.launches = 0
+        self._last_evt = None                  # recorded by finish() behind the step's exchange launches (algo="direct"): check(sync=True)
         # a single rank with a live communicator still issues its collectives (V2A_FORCE_DP: the RCCL path on a one-GPU box)
         self.active = dist.is_available() and dist.is_initialized()
         self._agree_on_layout()
@@ -258,9 +259,13 @@ class GradReducer:
             raise RuntimeError('algo="direct": the peer table could not be built: ' + "; ".join(sorted(set(bad))))
         d["arenas"], d["signals"] = arenas, signals
 
-    def check(self):
+    def check(self, sync=False):
         """Raise if a direct launch gave up waiting for a peer (the kernel raises a pinned host word and terminates; results of that step
-        are garbage).  Read without synchronising: launch() and finish() call it, a caller that wants certainty synchronises first."""
+        are garbage).  Read without synchronising by launch() and finish() -- a give-up in step N is then seen at step N + 1's launch, AFTER
+        the optimiser consumed the garbage.  sync=True first waits for the event finish() recorded behind the step's last exchange launch:
+        call it before anything that must not see such a step (a checkpoint write, a logged loss): `PolicyTrainer.verify_exchange()`."""
+        if sync and self._last_evt is not None:
+            self._last_evt.synchronize()
         d = self._direct
         if d is not None and d.get("err"):
             w = (ctypes.c_int * 5).from_address(d["err"])
@@ -285,6 +290,7 @@ class GradReducer:
             _ipc_close(h)
         if d.get("sig"):
             lib.v2a_dp_signal_free(d["sig"])
+        drain_arenas()                     # arenas parked by dead trainers (349 MB each) go back now, not at the next alloc_arena()
         if d.get("err"):
             lib.v2a_dp_errword_free(d["err"])
 
@@ -346,6 +352,9 @@ class GradReducer:
             missing = sorted(set(range(len(self.slices))) - self._launched)
             raise RuntimeError(f"finish() before slices {missing} were launched: ranks would issue different collectives")
         self.check()                       # direct: the launches are stream-ordered, there is nothing to wait for on the host
+        if self.algo == "direct" and self.arena.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self._last_evt = torch.cuda.Event()
+            self._last_evt.record()
         for w, staged in self._works:
             w.wait()
             if staged is not None:

@@ -29,10 +29,25 @@ class GraphedPredictAction:
         self.out = None
         self.graph = None
         from .policy_persist import PersistentDenoiser
-        if persistent is None:
+        auto = persistent is None
+        if auto:
             persistent = batch_size == 1
-        self.pp = PersistentDenoiser(self.eng, batch_size, self.steps, use_ddim, policy.num_inference_steps_ddim, self.init,
-                                     self.step_noise) if persistent else None
+        self.pp = None
+        self.pp_fallback = None                           # why the automatic choice fell back to the layer-by-layer kernels, if it did
+        if persistent:
+            try:
+                # statistics area of the kernel: 2 floats per (sample, group), 64 floats in all
+                if batch_size * self.eng.cfg.n_groups * 2 > 64:
+                    raise ValueError(f"policy_persist: batch {batch_size} x {self.eng.cfg.n_groups} groups exceeds the kernel's statistics area")
+                self.pp = PersistentDenoiser(self.eng, batch_size, self.steps, use_ddim, policy.num_inference_steps_ddim, self.init,
+                                             self.step_noise)
+            except (ValueError, RuntimeError) as e:
+                # persistent=True is a demand: re-raise.  The automatic choice (None) covers the shapes the kernel was built for (horizon 16,
+                # kernel sizes 5 / 3, layers that fit the LDS); any other config takes the working layer-by-layer path, and says so
+                if not auto:
+                    raise
+                self.pp_fallback = f"{type(e).__name__}: {e}"
+                print(f"[GraphedPredictAction] persistent denoiser not used ({self.pp_fallback}); layer-by-layer kernels instead", flush=True)
 
     def _run(self):
         eng, pol = self.eng, self.policy
@@ -74,8 +89,14 @@ class GraphedPredictAction:
             self._run()                                   # warm-up (packs, workspace)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **ops.graph_capture_mode()):
                 self._run()
         self.graph.replay()
+        if self.pp is not None:
+            # Under replay no host code of launch() runs, so the abandoned-barrier word is read HERE.  It is written by the kernel before it
+            # terminates: synchronise first -- the caller is about to read the action on the host anyway (the rollout's .cpu()), and a garbage
+            # action must not reach the simulator or the replay buffer
+            torch.cuda.current_stream().synchronize()
+            self.pp.check()
         start = To - 1
         return {"action": self.out[:, start:start + self.policy.n_action_steps], "action_pred": self.out}

@@ -120,6 +120,19 @@ def _plan_name_h(M, Cout, K, ept, tname):
     return f"conv_igemm_h<128,{64 if Cout <= 64 else 128},{tname}>"
 
 
+def graph_capture_mode():
+    """Keyword arguments for `torch.cuda.graph(...)`: thread-local capture while a process group is live -- the communicator's watchdog
+    thread polls the events of earlier collectives during a capture, and in the default GLOBAL mode its hipEventQuery is an illegal call
+    that takes the process down (v2a_hip/trainer.py captures its step graphs the same way)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return {"capture_error_mode": "thread_local"}
+    except Exception:
+        pass
+    return {}
+
+
 _h_twin_regs = 0
 _h_twin = {}        # fp32 operand data_ptr -> bf16 twin of the same operand (registered by the engines that keep both fresh)
 

@@ -257,6 +257,7 @@ class PersistentDenoiser:
         the GPU, its results are garbage).  Read without synchronising; launch() looks at it before every launch."""
         v = ctypes.c_int.from_address(self._err).value
         if v:
+            ctypes.c_int.from_address(self._err).value = 0          # the instance stays usable: the NEXT abandoned barrier raises again
             raise RuntimeError(f"persistent denoiser: a grid barrier (phase {v}) was abandoned after 2 s -- {self.nwg} workgroups of 512 threads "
                                f"with {self.lds} bytes of LDS were not all resident (another kernel holding the CUs?)")
 

@@ -352,6 +352,22 @@ class PolicyTrainer:
                     pe[4].record()
                     self.phase_events.append(pe)
 
+    def verify_exchange(self):
+        """Data parallel over the direct exchange: wait for the last step's exchange launches and raise if one of them gave up on a peer
+        (GradReducer.check(sync=True)) -- call it before writing a checkpoint or logging a loss, so that a step whose gradients were garbage
+        is reported BEFORE its parameters are kept.  A no-op for a single rank and for the process-group all-reduce (which raises by itself)."""
+        red = getattr(self, "reducer", None)
+        if red is not None and red.algo == "direct":
+            red.check(sync=True)
+
+    def close(self):
+        """Release the data-parallel resources (peer mappings, signal block, parked arenas).  Collective when data parallel."""
+        red = getattr(self, "reducer", None)
+        if red is not None:
+            red.close()
+        from .dp import drain_arenas
+        drain_arenas()
+
     def ema_for_inference(self):
         """EMA weights are updated by the fused kernel behind torch's back: refresh its packed copies before use."""
         self.ema_policy.engine.refresh_packs()
