@@ -227,6 +227,31 @@ def test_attention(L, heads, ch, n):
     close(out.view(n, L, C).permute(0, 2, 1), ref, what="attention")
 
 
+@pytest.mark.parametrize("L,heads,n", [(256, 16, 14), (64, 20, 7), (32, 1, 1), (96, 3, 2)])
+def test_attention_three_plane_mfma_vs_fp64(L, heads, n):
+    """attn_mfma_x3_kernel (fp32 storage, head_ch 32, L <= 256): QK^T and PV as six bf16 plane products each on the matrix pipe, softmax
+    state in fp32.  Against an fp64 evaluation of QKVAttentionLegacy (unet.py:341-358) -- the fp32 budget of the plane products (~1e-6 of
+    max |out|) -- on inputs with a wide dynamic range (large logits: the softmax is close to one-hot for some queries); bitwise repeatable."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1:
+        pytest.skip("three-plane mode only")
+    ch = 32
+    g = torch.Generator().manual_seed(L * heads + n)
+    C = heads * ch
+    qkv = torch.randn(n, 3 * C, L, generator=g) * torch.rand(n, 3 * C, 1, generator=g).mul(2).exp2()
+    q, k, v = qkv.double().reshape(n * heads, 3 * ch, L).split(ch, dim=1)
+    s = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", w, v).reshape(n, C, L)
+    x = qkv.permute(0, 2, 1).contiguous().to(dev()).view(n * L, 3 * C)
+    out = ops.attention(x, n, L, heads, ch)
+    got = out.view(n, L, C).permute(0, 2, 1).cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    assert torch.equal(out, ops.attention(x, n, L, heads, ch))
+
+
 def test_maxpool_and_spatial_softmax():
     from v2a_hip import ops
     g = torch.Generator().manual_seed(21)

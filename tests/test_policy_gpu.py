@@ -601,8 +601,11 @@ def test_persistent_denoiser_gives_up_instead_of_hanging():
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="abandoned"):
         pd.check()
+    pd.check()                                   # raising cleared the word: the instance is not left in a permanent give-up state ...
+    pd.launch(torch.randn(1, pd.gcond.shape[1]).cuda())
+    torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="abandoned"):
-        pd.launch(torch.randn(1, pd.gcond.shape[1]).cuda())
+        pd.check()                               # ... and the same over-sized grid gives up again, and says so again
     ok = PersistentDenoiser(pol.engine, 1, ddim_timesteps(100, 8), True, 8, init)          # the default geometry still runs
     ok.launch(torch.randn(1, ok.gcond.shape[1]).cuda())
     torch.cuda.synchronize()

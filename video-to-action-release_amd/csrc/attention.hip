@@ -347,6 +347,164 @@ __global__ __launch_bounds__(256) void attn_mfma_h_kernel(const uint16_t* __rest
     }
 }
 
+// MFMA attention for the fp32 (parity) configuration, head_ch = 32, L <= 256 keys (the video UNet attends at 16 x 16 and 8 x 8):
+// attn_mfma_h_kernel's structure with every fp32 operand as three bf16 planes (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid))
+// and every product block as the six plane products of weight >= 2^-16, smallest first -- the arithmetic of the three-plane convs
+// (csrc/igemm_h.hip conv_igemm_f32x3; fp32-equivalent: each bf16 x bf16 product is exact in the MFMA's fp32 accumulation, the dropped
+// products are <= 2^-24 |a||b|).  K and V^T planes of the head live in LDS (split once while staged); Q is split in registers; the
+// probabilities P (fp32, softmax state in fp32 as before) are split in registers on their way into O^T += V^T P^T.  Scores are scaled by
+// ch^-1/2 after the product (the reference scales q and k by ch^-1/4 each, unet.py:349-353: one rounding apart).
+__global__ __launch_bounds__(256) void attn_mfma_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int heads) {
+    constexpr int CH = 32, LDK = 40;                          // K row stride in bf16 (80 B: conflict-free ds_read_b128)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    const int LDV = L + 4;                                     // V^T row stride in bf16 (2L + 8 B)
+    const int KP = L * LDK, VP = CH * LDV;                     // elements per plane
+    uint16_t* Ks = reinterpret_cast<uint16_t*>(sm_raw);        // [3][L][LDK]
+    uint16_t* Vt = Ks + 3 * (size_t)KP;                        // [3][CH][LDV]
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C3 = heads * 3 * CH, C = heads * CH;
+    const float* base = qkv + (size_t)n * L * C3 + (size_t)h * 3 * CH;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    // ---- stage K (row-major, padded) and V^T, split into planes
+    for (int i = tid; i < L * 4; i += blockDim.x) {           // 4 x 8-channel pieces per key row for K and for V
+        const int r = i >> 2, c = i & 3;
+        const float* src = base + (size_t)r * C3 + CH + c * 8;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(src), k1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + CH), v1 = *reinterpret_cast<const f32x4*>(src + CH + 4);
+        uint32_t kh[4], km[4], kl[4], vh[4], vm[4], vl[4];
+        v2a_split3x2(k0[0], k0[1], kh[0], km[0], kl[0]); v2a_split3x2(k0[2], k0[3], kh[1], km[1], kl[1]);
+        v2a_split3x2(k1[0], k1[1], kh[2], km[2], kl[2]); v2a_split3x2(k1[2], k1[3], kh[3], km[3], kl[3]);
+        v2a_split3x2(v0[0], v0[1], vh[0], vm[0], vl[0]); v2a_split3x2(v0[2], v0[3], vh[1], vm[1], vl[1]);
+        v2a_split3x2(v1[0], v1[1], vh[2], vm[2], vl[2]); v2a_split3x2(v1[2], v1[3], vh[3], vm[3], vl[3]);
+        uint16_t* kd = Ks + r * LDK + c * 8;
+        *reinterpret_cast<uint4*>(kd) = make_uint4(kh[0], kh[1], kh[2], kh[3]);
+        *reinterpret_cast<uint4*>(kd + KP) = make_uint4(km[0], km[1], km[2], km[3]);
+        *reinterpret_cast<uint4*>(kd + 2 * KP) = make_uint4(kl[0], kl[1], kl[2], kl[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint16_t* vd = Vt + (c * 8 + 2 * e) * LDV + r;
+            vd[0] = (uint16_t)(vh[e] & 0xffffu); vd[LDV] = (uint16_t)(vh[e] >> 16);
+            vd[VP] = (uint16_t)(vm[e] & 0xffffu); vd[VP + LDV] = (uint16_t)(vm[e] >> 16);
+            vd[2 * VP] = (uint16_t)(vl[e] & 0xffffu); vd[2 * VP + LDV] = (uint16_t)(vl[e] >> 16);
+        }
+    }
+    __syncthreads();
+
+    const float s2 = 1.0f / sqrtf((float)CH);                 // (ch^-1/4)^2
+#define V2A_X3A_SIX(ACC, A, B)                                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);   /* lo  * hi  */ \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);   /* hi  * lo  */ \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);   /* mid * mid */ \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);   /* mid * hi  */ \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);   /* hi  * mid */ \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);   /* hi  * hi  */
+    for (int q0 = wid * 64; q0 < L; q0 += (blockDim.x >> 6) * 64) {
+        // Q planes straight from HBM: B operand of S^T = K Q^T, lane -> (query q0 + t*32 + lr, d = kstep*16 + lk*8 .. +8)
+        bf16x8_a qf[2][2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int q = q0 + t * 32 + lr;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                if (q < L) {
+                    const float* qp = base + (size_t)q * C3 + ks * 16 + lk * 8;
+                    a = *reinterpret_cast<const f32x4*>(qp);
+                    b = *reinterpret_cast<const f32x4*>(qp + 4);
+                }
+                uint32_t hh[4], mm[4], ll[4];
+                v2a_split3x2(a[0], a[1], hh[0], mm[0], ll[0]); v2a_split3x2(a[2], a[3], hh[1], mm[1], ll[1]);
+                v2a_split3x2(b[0], b[1], hh[2], mm[2], ll[2]); v2a_split3x2(b[2], b[3], hh[3], mm[3], ll[3]);
+                uint4 uh = make_uint4(hh[0], hh[1], hh[2], hh[3]), um = make_uint4(mm[0], mm[1], mm[2], mm[3]), ul = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                qf[t][ks][0] = *reinterpret_cast<bf16x8_a*>(&uh);
+                qf[t][ks][1] = *reinterpret_cast<bf16x8_a*>(&um);
+                qf[t][ks][2] = *reinterpret_cast<bf16x8_a*>(&ul);
+            }
+        f32x16 o[2];
+        float m[2], l[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            m[t] = -INFINITY;
+            l[t] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+        }
+        for (int k0 = 0; k0 < L; k0 += 32) {
+            bf16x8_a kf[2][3], vf[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    kf[ks][p] = *reinterpret_cast<const bf16x8_a*>(Ks + p * KP + (k0 + lr) * LDK + ks * 16 + lk * 8);
+                    // V^T: A operand of O^T += V^T P^T, lane -> (d = lr, keys in the accumulator's row order)
+                    const uint16_t* vp = Vt + p * VP + lr * LDV + k0 + ks * 16 + lk * 4;
+                    const uint2 a = *reinterpret_cast<const uint2*>(vp);          // keys k0 + 16ks + 4lk + {0..3}
+                    const uint2 b = *reinterpret_cast<const uint2*>(vp + 8);      // keys k0 + 16ks + 4lk + 8 + {0..3}
+                    uint4 u = make_uint4(a.x, a.y, b.x, b.y);
+                    vf[ks][p] = *reinterpret_cast<bf16x8_a*>(&u);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                V2A_X3A_SIX(sacc, kf[0], qf[t][0])
+                V2A_X3A_SIX(sacc, kf[1], qf[t][1])
+                float cm = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] *= s2;
+                    cm = fmaxf(cm, sacc[r]);
+                }
+                cm = fmaxf(cm, __shfl_xor(cm, 32, 64));                      // the partner lane holds the other 16 keys of this query
+                const float mn = fmaxf(m[t], cm);
+                const float alpha = expf(m[t] - mn);
+                float ps = 0.f;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = expf(sacc[r] - mn);
+                    ps += pv[r];
+                }
+                ps += __shfl_xor(ps, 32, 64);
+                l[t] = l[t] * alpha + ps;
+                m[t] = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                bf16x8_a pf[2][3];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v2a_split3x2(pv[ks * 8 + 2 * e], pv[ks * 8 + 2 * e + 1], hh[e], mm[e], ll[e]);
+                    uint4 uh = make_uint4(hh[0], hh[1], hh[2], hh[3]), um = make_uint4(mm[0], mm[1], mm[2], mm[3]), ul = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                    pf[ks][0] = *reinterpret_cast<bf16x8_a*>(&uh);
+                    pf[ks][1] = *reinterpret_cast<bf16x8_a*>(&um);
+                    pf[ks][2] = *reinterpret_cast<bf16x8_a*>(&ul);
+                }
+                V2A_X3A_SIX(o[t], vf[0], pf[0])
+                V2A_X3A_SIX(o[t], vf[1], pf[1])
+            }
+        }
+        // O^T accumulator: lane -> query lr of tile t, channels d = (r & 3) + 8 (r >> 2) + 4 lk : four runs of 4 channels (16 B each)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = q0 + t * 32 + lr;
+            if (q >= L) continue;
+            const float inv = 1.0f / l[t];
+            float* dst = out + ((size_t)n * L + q) * C + (size_t)h * CH + 4 * lk;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+            }
+        }
+    }
+#undef V2A_X3A_SIX
+}
+
 // Generic small attention for the PerceiverResampler (reference imagen.py:283-319): q,k l2-normalised per head then
 // scaled elementwise by q_scale / k_scale, sim * 8, softmax, @ v.  q [B, Lq, H*D], kv [B, Lk, 2*H*D] (k | v),
 // out [B, Lq, H*D].  One workgroup per (b, head), one lane per query; runs once per sample() call (t-independent).
@@ -750,8 +908,21 @@ __global__ __launch_bounds__(64) void mha_bwd_kernel(const float* __restrict__ q
 
 extern "C" {
 
+int v2a_get_f32_conv_mode(void);
 int v2a_attention_fwd(const float* qkv, float* out, int n_frames, int L, int heads, int head_ch, hipStream_t s) {
     if (!qkv || !out) return V2A_ERR_ARG;
+    if (head_ch == 32 && L % 32 == 0 && L <= 256 && v2a_get_f32_conv_mode() == 1 && ((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0)) {
+        // three-plane mode (the default fp32 arithmetic of the convs around it): QK^T and PV on the matrix pipe
+        const size_t ldsx = (size_t)3 * L * 40 * 2 + (size_t)3 * 32 * (L + 4) * 2;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_mfma_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * 80 + 3 * 32 * 260 * 2);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_mfma_x3_kernel, dim3(n_frames * heads), dim3(256), ldsx, s, qkv, out, L, heads);
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
+    }
     const int threads = L >= 256 ? 256 : ((L + 63) / 64) * 64;
     const size_t lds = (size_t)2 * 256 * head_ch * sizeof(float);
     dim3 grid(n_frames * heads);
