@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libv2a_hip.so")
+# V2A_HIP_LIB: debug hook -- another build of the same library (csrc/Makefile `asan`); the product loads the in-tree .so
+LIB_PATH = os.environ.get("V2A_HIP_LIB") or os.path.join(_HERE, "libv2a_hip.so")
 
 P = ctypes.c_void_p
 I = ctypes.c_int
