@@ -856,12 +856,14 @@ def _flip_aware_rows(OP, sd, batch, noise, ts, names, hip_grads, eng_dec, tag):
     return _grad_distances(hip_grads, g32, g64, names), ref_loss
 
 
-RAGGED_CASES = [(1, 0), (3, 1), (5, 2), (6, 3), (7, 4), (6, 1)]      # (B, generator seed): NOT selected
+# (B, generator seed): NOT selected.  Round 6 keeps four of round 5's six pairs -- (5, 2) and (6, 1) repeat tile / split plans that (3, 1),
+# (6, 3) and (7, 4) already cover, and each pair costs ~18 s of fp64 CPU oracle: the GPU suite has a 600-s budget
+RAGGED_CASES = [(1, 0), (3, 1), (6, 3), (7, 4)]
 
 
 def test_ragged_batch_loss_and_grads_vs_oracle():
     """Batches that fill no tile evenly (1024 ... 7168 conv rows at the first ResNet stage, 16 ... 112 rows in the ConditionalUnet1D):
-    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin; six unselected
+    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin; four unselected
     (batch size, seed) pairs, the loss and EVERY gradient tensor.
 
     Round 3 found that two correct fp32 implementations of this step do not always agree to 1e-4 on the encoder gradients at B <= 7:
@@ -898,7 +900,9 @@ def test_ragged_batch_loss_and_grads_vs_oracle():
         worst_all = max(worst_all, worst_hip)
         del pol
         torch.cuda.empty_cache()
-    print(f"[ragged] largest per-tensor distance over the six batches: {worst_all:.2e}")
+    from conftest import parity_record
+    parity_record("largest per-tensor distance over the ragged batches (HIP vs fp64, HIP routing)", worst_all)
+    print(f"[ragged] largest per-tensor distance over the {len(RAGGED_CASES)} batches: {worst_all:.2e}")
 
 
 def test_c2_batch64_loss_and_grads_vs_oracle():

@@ -239,24 +239,25 @@ def test_ddpm_sampler_with_variance_temperature():
     gen = torch.Generator().manual_seed(99)
     x_cond, te = torch.rand(2, 3, 32, 32, generator=gen), torch.randn(2, 4, 512, generator=gen)
     nz = [torch.randn(2, 9, 32, 32, generator=gen) for _ in range(101)]
-    outs = {}
-    for vt in (0.6, 1.0):
-        d = GoalGaussianDiffusion(m, image_size=(32, 32), channels=9, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
-                                  beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0, var_temp=vt).to("cuda:0")
-        it = iter(nz)
-        d.__dict__["_noise_hook"] = lambda shape: next(it)
-        outs[vt] = d.sample(x_cond.cuda(), te.cuda(), batch_size=2).cpu()
-    ref = OG.sample(lambda x, t, e: VU.unet_libero_forward(sd, x, t, e, cfg), OG.cosine_tables(), nz, x_cond, te, guidance_weight=0.0,
-                    var_temp=0.6, sampling_timesteps=100)
-    err = rel(outs[0.6], ref)
+    d = GoalGaussianDiffusion(m, image_size=(32, 32), channels=9, timesteps=100, sampling_timesteps=100, loss_type="l2", objective="pred_v",
+                              beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0, var_temp=0.6).to("cuda:0")
+    it = iter(nz)
+    d.__dict__["_noise_hook"] = lambda shape: next(it)
+    out = d.sample(x_cond.cuda(), te.cuda(), batch_size=2).cpu()
+    model = lambda x, t, e: VU.unet_libero_forward(sd, x, t, e, cfg)      # noqa: E731
+    ref = OG.sample(model, OG.cosine_tables(), nz, x_cond, te, guidance_weight=0.0, var_temp=0.6, sampling_timesteps=100)
+    err = rel(out, ref)
     print(f"[sampler var_temp=0.6] HIP vs oracle {err:.2e}")
     assert err <= TOL, err
-    assert rel(outs[0.6], outs[1.0]) > 1e-2
+    # ... and the temperature matters: a sampler that ignored it would reproduce the var_temp = 1 trajectory instead (the oracle's own two
+    # runs differ by far more than the tolerance; round 5 ran the HIP sampler a second time for this -- 18 s of launches)
+    ref1 = OG.sample(model, OG.cosine_tables(), nz, x_cond, te, guidance_weight=0.0, var_temp=1.0, sampling_timesteps=100)
+    assert rel(ref, ref1) > 1e-2 and rel(out, ref1) > 1e-2
 
 
 def test_full_size_sampler_multi_step_and_batch_rows():
     """error accumulation over sequential FULL-SIZE UNet calls, and C3's batch of 16 inside the GPU suite.
-    (a) 5 DDIM steps of the 201 M-parameter Unet_Libero at B=2 against the CPU oracle on the same injected noise (1e-4);
+    (a) 4 DDIM steps of the 201 M-parameter Unet_Libero at B=2 against the CPU oracle on the same injected noise (1e-4);
     (b) the same two rows inside a B=16 call: rows of a batch are independent (per-sample GroupNorm, per-frame attention), so they
         must reproduce the B=2 result -- only tile / split-K plans change with the row count (fp32 reassociation, <= 1e-5)."""
     from flowdiffusion.flowdiffusion.unet import Unet_Libero
@@ -268,7 +269,7 @@ def test_full_size_sampler_multi_step_and_batch_rows():
     m = Unet_Libero()
     sd = fill_module(m, seed=12)
     m = m.to("cuda:0").eval()
-    steps = 5
+    steps = 4
     d = GoalGaussianDiffusion(m, image_size=(128, 128), channels=21, timesteps=100, sampling_timesteps=steps, loss_type="l2",
                               objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0).to("cuda:0")
     gen = torch.Generator().manual_seed(31)

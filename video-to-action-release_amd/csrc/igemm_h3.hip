@@ -620,16 +620,6 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
         float* st = reinterpret_cast<float*>(smem + istage * STAGE + ST_OFF);       // [2 (w)][F][4 (wn)][2][32]
         // ---- epilogue: sub-tile i of this wave = frame i, pixels p0 + w*32 .. +31 (staging rows private to the wave)
         const int n = n0 + wn + vcol;
-#ifndef V2A_T3_EXP
-#define V2A_T3_EXP 0
-#endif
-        if (V2A_T3_EXP == 2) {
-            // (measurement build: no epilogue at all -- one store per lane keeps the accumulators alive)
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < F; ++i) sacc += acc[i][0] + acc[i][15];
-            if (sacc == 12345.678f) p.y[lane] = 1;
-        } else
         if (!p.residual && (!p.rowvec || p.rows_per_batch == F * p.HW)) {
             // no residual, and the row vector is one table row for the whole tile: the register path (pack_subtile3)
             const int ncol = n0 + wn + lr;
@@ -656,7 +646,7 @@ __global__ __launch_bounds__(512, 1) void conv_frames_h3(const ConvDescT3 p) {
                     const uint4 u = *reinterpret_cast<const uint4*>(ph + ml * 16 + (lane % V) * 4);
                     *reinterpret_cast<uint4*>(p.y + (m0 + ml) * p.Cout + n) = u;
                 }
-                if (p.stats && V2A_T3_EXP != 1) {
+                if (p.stats) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         s2[k] += pair_swap3(s2[k]);
