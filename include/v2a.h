@@ -313,6 +313,17 @@ int v2a_conv2d_x3t_eligible(int B, int F, int HW, int C, int Cout, int rows_per_
    conv_patch_x3: a 16 x 16 pixel patch x 128 output channels per persistent workgroup; three-plane mode, no row vector / statistics).
    Depends on the shape and the device's CU count only. */
 int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
+/* GroupNorm32 + SiLU in front of a ResBlock conv (guided_diffusion/unet.py:181-197 in_layers / out_layers, nn.py:95-97) folded into that
+   conv in the fp32 configuration: v2a_groupnorm_stats_f32 turns the producing conv's per-64-row statistics blocks `stats`
+   [N * S/64][2][C] into mean / rstd [N][G] (the reduce + finalise launches of v2a_groupnorm_fwd_st, S % 64 == 0, workspace >= N*64*2*C*8
+   bytes); v2a_conv2d_fwd_x3p_gn is conv_patch_x3 reading act((x - mean) * rstd * gamma + beta) -- the arithmetic of the apply pass it
+   replaces, done on the halo in registers; x [N images, H, W, C], gn_frames images per GroupNorm sample, act 0 / 1 (SiLU).  3 x 3 /
+   stride 1 / pad 1, bias only; where v2a_conv2d_x3p_eligible(N, H, W, C, Cout) and (C / G) % 4 == 0. */
+int v2a_groupnorm_stats_f32(const float* stats, float* mean, float* rstd, int N, int S, int C, int G, float eps, void* workspace,
+                            size_t workspace_bytes, v2a_stream_t stream);
+int v2a_conv2d_fwd_x3p_gn(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int G, int gn_frames,
+                          int act, const float* w_packed, const float* bias, float* y, const void* zeros, int N, int H, int W, int C, int Cout,
+                          v2a_stream_t stream);
 /* "channel window" form for few-channel inputs (the RGB stem of the policy's ResNet-18 encoders: torchvision resnet18.conv1 7x7 / 2 behind
    diffuser/diffusion_policy/common/vision_nets.py:29-39): pixel (ih, iw) = the C floats at x + ((n * H + ih) * W + iw) * xpitch, xpitch <= C
    (overlapping windows); no padding (the buffer carries its zero border, v2a_nchw_to_nhwc4p); w_packed [Cout][KH][KW][C] (pack mode 2 of

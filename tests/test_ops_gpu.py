@@ -1240,6 +1240,48 @@ def test_three_plane_patch_conv_vs_fp64(N, H, W, Ci, Co, ups, res):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Fr,H,W,C,Co,act", [(4, 7, 32, 32, 128, 128, "silu"), (2, 7, 64, 64, 160, 256, "silu"), (32, 7, 16, 16, 128, 128, "none")])
+def test_three_plane_patch_conv_applies_groupnorm_in_its_loader(B, Fr, H, W, C, Co, act):
+    """GroupNorm32 + SiLU folded into conv_patch_x3 (v2a_groupnorm_stats_f32 -> v2a_conv2d_fwd_x3p_gn): statistics from the producing
+    conv's 64-row blocks, the affine + activation applied to the halo in registers, padding ring left at zero.  Against fp64
+    GroupNorm -> SiLU -> conv2d (the fp32 budget: the normalised values are fp32 before they are split into planes), and within fp32
+    round-off of the unfused pair (materialised GroupNorm, then the same conv kernel)."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    N, S = B * Fr, Fr * H * W
+    assert ops.conv2d_x3p_gn_ok(N, H, W, C, Co)
+    g = torch.Generator().manual_seed(B + C)
+    x = (torch.randn(B, S, C, generator=g) * 2 + torch.randn(1, 1, C, generator=g)).to(dev())
+    gamma, beta = torch.randn(C, generator=g).to(dev()), torch.randn(C, generator=g).to(dev())
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(Co, generator=g)
+    rows = x.view(-1, 64, C)
+    stats = torch.stack([rows.sum(1), (rows * rows).sum(1)], dim=1).contiguous()          # what a conv epilogue leaves: [M/64][2][C]
+    pg = ops.groupnorm_prep_f32(x, gamma, beta, 32, act, stats=stats)
+    assert pg is not None
+    wp = ops.pack_weight(w.to(dev()), 0)
+    y = ops.conv2d_x3p_gn(pg, x.view(N, H, W, C), wp, b.to(dev()), Co, Fr)
+    # unfused pair on the same kernels
+    y1 = ops.conv2d(pg.apply().view(N, H, W, C), wp, b.to(dev()), Co, 3, 3, (1, 1), (1, 1))
+    assert ops.last_kernel[0].startswith("conv_patch_x3")
+    d = (y - y1).abs().max().item() / y1.abs().max().item()
+    assert d < 2e-6, d
+    # fp64 reference on two samples
+    for n in (0, B - 1):
+        xs = x[n].double().cpu().view(Fr, H, W, C).permute(3, 0, 1, 2)[None]              # [1, C, F, H, W]: GroupNorm over (C/32, F, H, W)
+        a = F.group_norm(xs, 32, gamma.double().cpu(), beta.double().cpu(), 1e-5)
+        if act == "silu":
+            a = F.silu(a)
+        a = a[0].permute(1, 0, 2, 3)                                                       # [F, C, H, W]
+        ref = F.conv2d(a, w.double(), b.double(), padding=1)
+        got = y.view(B, Fr, H, W, Co)[n].permute(0, 3, 1, 2).double().cpu()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, (n, err)
+
+
 def F_conv(x, w, b):
     return F.conv2d(x, w, b, padding=(1, 0))
 

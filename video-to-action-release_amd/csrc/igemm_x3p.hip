@@ -32,6 +32,14 @@ struct ConvDescX3P {
     float* y;                // [N, H, W, Cout]
     const float* zeros;
     int N, H, W, C, Cout, K, tiles_x, tiles_img, ups;
+    // GN = true: the conv reads act(GroupNorm(x)) -- z = (x - mean[s, g]) * rstd[s, g] * gamma[c] + beta[c], the arithmetic of
+    // gn_apply_fwd_rows (csrc/norm.hip) -- applied to the halo in registers on its way into LDS (padding stays zero): the normalised
+    // tensor is never written (GroupNorm32 + SiLU in front of the ResBlock convs, guided_diffusion/unet.py:181-197, nn.py:95-97)
+    const float* mean;       // [N / fps][G]
+    const float* rstd;
+    const float* gamma;      // [C]
+    const float* beta;
+    int G, fps, act;         // groups; images (frames) per GroupNorm sample; ACT_SILU / ACT_NONE
 };
 
 __device__ __forceinline__ int xcd_remap_x3p(int bid, int nblk) {
@@ -48,6 +56,7 @@ __device__ __forceinline__ int patch16_perm_x3p(int m) {
     return ((__builtin_popcount(qd) & 1) << 4) | ((qd >> 1) << 2) | (m & 3);
 }
 
+template <bool GN>
 __global__ __launch_bounds__(512, 1) void conv_patch_x3(const ConvDescX3P p) {
     constexpr int BN = 128, NT = 512;
     constexpr int HWD = 18, HS = HWD * HWD;                  // halo: 18 x 18 slots of 64 B (32 channels, both halves)
@@ -83,9 +92,11 @@ __global__ __launch_bounds__(512, 1) void conv_patch_x3(const ConvDescX3P p) {
     // the halo stream being LOADED (one (chunk, half) period ahead of the one computed, across tile boundaries)
     int la_lin = lin, la_c = 0, la_h = 0;
     uint32_t a_off[AJ];                                      // element offset of the slot's pixel in x (+ float4 index), 0xffffffff: zero line
+    int la_ns = 0;                                           // GN: GroupNorm sample of the tile being loaded
     auto a_tile_setup = [&](int l) {
         const int tm = l / tiles_n;
         const int img = tm / p.tiles_img, rem = tm - img * p.tiles_img;
+        if (GN) la_ns = img / p.fps;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -97,15 +108,31 @@ __global__ __launch_bounds__(512, 1) void conv_patch_x3(const ConvDescX3P p) {
     };
     a_tile_setup(la_lin);
     f32x4 ra[AJ], rw[3];
+    // GN: scale / shift of this thread's four channels of the period in flight, and which of its slots carry image pixels
+    f32x4 gn_gm = {0.f, 0.f, 0.f, 0.f}, gn_bt = {0.f, 0.f, 0.f, 0.f};
+    float gn_mu = 0.f, gn_rs = 0.f;
+    int ra_ok = 0;
+    const int cg = GN ? p.C / p.G : 1;
     // (no branches around the loads: past the end of the stream and outside the image they read the zero line -- a conditional load makes
     // the compiler's wait-count bookkeeping fall back to vmcnt(0) everywhere)
     auto issue_a = [&]() {
         const bool live = la_lin < total;
         const float* xb = p.x + la_c * 32 + la_h * 16;
+        ra_ok = 0;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const float* g = (live && a_off[j] != 0xffffffffu) ? xb + a_off[j] : zsrc;
+            const bool ok = live && a_off[j] != 0xffffffffu;
+            const float* g = ok ? xb + a_off[j] : zsrc;
             ra[j] = *(const gf32x4_x3p*)(uint64_t)g;
+            ra_ok |= ok ? (1 << j) : 0;
+        }
+        if (GN) {
+            const int c0 = la_c * 32 + la_h * 16 + (tid & 3) * 4;
+            const int sg = (live ? la_ns : 0) * p.G + c0 / cg;
+            gn_gm = *(const gf32x4_x3p*)(uint64_t)(p.gamma + c0);
+            gn_bt = *(const gf32x4_x3p*)(uint64_t)(p.beta + c0);
+            gn_mu = p.mean[sg];
+            gn_rs = p.rstd[sg];
         }
         la_h ^= 1;
         if (la_h == 0 && ++la_c == nchunks) {
@@ -118,6 +145,13 @@ __global__ __launch_bounds__(512, 1) void conv_patch_x3(const ConvDescX3P p) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             if (a_dst[j] < 0) continue;
+            if (GN && ((ra_ok >> j) & 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = (ra[j][e] - gn_mu) * gn_rs * gn_gm[e] + gn_bt[e];
+                    ra[j][e] = act_fwd(z, p.act);
+                }
+            }
             uint32_t h0, m0, l0, h1, m1, l1;
             v2a_split3x2(ra[j][0], ra[j][1], h0, m0, l0);
             v2a_split3x2(ra[j][2], ra[j][3], h1, m1, l1);
@@ -303,8 +337,16 @@ static int x3p_ncu() {
     return ncu;
 }
 
+static int conv_patch_x3_launch_gn(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, const void* zeros,
+                                   int N, int H, int W, int C, int Cout, int ups, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, int G, int fps, int act, hipStream_t stream);
 int conv_patch_x3_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, const void* zeros, int N,
                          int H, int W, int C, int Cout, int ups, hipStream_t stream) {
+    return conv_patch_x3_launch_gn(x, w_packed, bias, residual, y, zeros, N, H, W, C, Cout, ups, nullptr, nullptr, nullptr, nullptr, 0, 1, 0, stream);
+}
+static int conv_patch_x3_launch_gn(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, const void* zeros,
+                                   int N, int H, int W, int C, int Cout, int ups, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, int G, int fps, int act, hipStream_t stream) {
     if (!x || !w_packed || !zeros || !y || N <= 0) return V2A_ERR_ARG;
     const int ncu = x3p_ncu();
     if (!conv_patch_x3_eligible(N, H, W, C, Cout, ncu)) return V2A_ERR_ARG;
@@ -316,7 +358,15 @@ int conv_patch_x3_launch(const float* x, const float* w_packed, const float* bia
     p.tiles_x = W / 16;
     p.tiles_img = (H / 16) * (W / 16);
     const int total = N * p.tiles_img * (Cout / 128);
-    hipLaunchKernelGGL(conv_patch_x3, dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);      // one persistent workgroup per CU
+    p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.G = G; p.fps = fps > 0 ? fps : 1; p.act = act;
+    if (mean) {
+        if (!rstd || !gamma || !beta || G <= 0 || C % G || (C / G) % 4 || N % p.fps || (act != ACT_NONE && act != ACT_SILU) ||
+            (((uintptr_t)gamma | (uintptr_t)beta) & 15))
+            return V2A_ERR_ARG;
+        hipLaunchKernelGGL(conv_patch_x3<true>, dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(conv_patch_x3<false>, dim3(total < ncu ? total : ncu), dim3(512), 0, stream, p);      // one persistent workgroup per CU
+    }
     V2A_CHECK_LAUNCH();
     return V2A_OK;
 }
@@ -324,4 +374,14 @@ int conv_patch_x3_launch(const float* x, const float* w_packed, const float* bia
 extern "C" {
 // 1 when v2a_conv2d_fwd_dma_f32 / _d run this 3 x 3 / stride 1 / pad 1 conv (H, W: the conv's map) on the patch kernel (three-plane mode)
 int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout) { return conv_patch_x3_eligible(N, H, W, C, Cout, x3p_ncu()); }
+
+// conv_patch_x3 over act(GroupNorm(x)) without materialising the normalised tensor: x [N, H, W, C] fp32 (N images = N / gn_frames GroupNorm
+// samples of gn_frames images each), mean / rstd [N / gn_frames][G] (v2a_groupnorm_stats_f32), gamma / beta [C], act 0 none / 1 SiLU.
+// 3 x 3 / stride 1 / pad 1, bias, no upsample; only where v2a_conv2d_x3p_eligible(N, H, W, C, Cout) says 1 and (C / G) % 4 == 0.
+int v2a_conv2d_fwd_x3p_gn(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int G, int gn_frames,
+                          int act, const float* w_packed, const float* bias, float* y, const void* zeros, int N, int H, int W, int C, int Cout,
+                          hipStream_t stream) {
+    if (!mean) return V2A_ERR_ARG;
+    return conv_patch_x3_launch_gn(x, w_packed, bias, nullptr, y, zeros, N, H, W, C, Cout, 0, mean, rstd, gamma, beta, G, gn_frames, act, stream);
+}
 }

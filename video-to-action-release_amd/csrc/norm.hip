@@ -1134,6 +1134,26 @@ int v2a_groupnorm_fwd_st(const float* x, const float* x2, int C1, const float* g
                        stats1, stats2, GnPost{}, workspace, workspace_bytes, stream);
 }
 }  // extern "C"
+// Statistics of a GroupNorm whose apply pass is folded into the consuming conv (v2a_conv2d_fwd_x3p_gn): mean / rstd [N][G] from the
+// producing conv's per-64-row (sum, sum of squares) blocks `stats` [N * S/64][2][C] -- the reduce + finalise launches of
+// v2a_groupnorm_fwd_st (same arithmetic, in double), without the pass over the tensor.  S % 64 == 0; workspace >= N * 64 * 2 * C * 8 B.
+extern "C" int v2a_groupnorm_stats_f32(const float* stats, float* mean, float* rstd, int N, int S, int C, int G, float eps, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+    if (!stats || !mean || !rstd || N <= 0 || G <= 0 || C % G || S % 64) return V2A_ERR_ARG;
+    GnDesc p = {};
+    p.N = N; p.S = S; p.C = C; p.G = G; p.eps = eps; p.mean = mean; p.rstd = rstd; p.C1 = C;
+    const int nb = S >> 6;
+    p.nchunk = nb < 64 ? nb : 64;
+    p.rows_per_chunk = (nb + p.nchunk - 1) / p.nchunk;
+    if ((size_t)N * p.nchunk * 2 * C * sizeof(double) > workspace_bytes) return V2A_ERR_WORKSPACE;
+    p.partial = (double*)workspace;
+    p.st1 = stats; p.st2 = nullptr;
+    hipLaunchKernelGGL(gn_reduce_blocks_f32, dim3(p.nchunk, N), dim3(256), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finalize<0>, dim3(N * G), dim3(256), 0, stream, p);
+    V2A_CHECK_LAUNCH();
+    return V2A_OK;
+}
 extern "C" int v2a_groupnorm_takes_post(int S, int C, int G) {
     if (G <= 0 || C % G != 0) return 0;
     GnDesc t = {};

@@ -903,6 +903,49 @@ def groupnorm_fwd(x, gamma, beta, G, act="none", residual=None, film=None, eps=1
     return y, mean, rstd
 
 
+class PendingGN32:
+    """fp32 GroupNorm (+ activation) whose apply pass is postponed: only mean / rstd exist (from the producing conv's statistics blocks).
+    conv2d_x3p_gn() normalises inside the conv kernel; apply() materialises the tensor for every other consumer."""
+
+    def __init__(self, x, gamma, beta, G, act, eps, stats, mean, rstd):
+        self.x, self.gamma, self.beta, self.G, self.act, self.eps, self.stats, self.mean, self.rstd = x, gamma, beta, G, act, eps, stats, mean, rstd
+
+    def apply(self):
+        y, _, _ = groupnorm_fwd(self.x, self.gamma, self.beta, self.G, self.act, eps=self.eps, stats=self.stats)
+        return y
+
+
+def groupnorm_prep_f32(x, gamma, beta, G, act="none", eps=1e-5, stats=None):
+    """Statistics only (v2a_groupnorm_stats_f32: mean / rstd from the conv epilogue's per-64-row blocks) -> PendingGN32, or None when
+    the shape is outside the fused form (no statistics blocks, S % 64, channel groups that are not whole float4s, exact-f32 mode)."""
+    N, S, C = x.shape
+    if stats is None or S % 64 or C % G or (C // G) % 4 or lib.v2a_get_f32_conv_mode() != 1 or act not in ("none", "silu"):
+        return None
+    mean = torch.empty(N * G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N * G, dtype=torch.float32, device=x.device)
+    wsb = N * 64 * 2 * C * 8
+    ws = workspace(wsb, x.device)
+    check(lib.v2a_groupnorm_stats_f32(stats.data_ptr(), mean.data_ptr(), rstd.data_ptr(), N, S, C, G, eps, ws.data_ptr(), wsb, _stream()),
+          "groupnorm_stats_f32")
+    return PendingGN32(x, gamma, beta, G, act, eps, stats, mean, rstd)
+
+
+def conv2d_x3p_gn_ok(N, H, W, C, Cout):
+    return bool(lib.v2a_conv2d_x3p_eligible(N, H, W, C, Cout)) and lib.v2a_get_f32_conv_mode() == 1 and lib.v2a_get_precision() == 0
+
+
+def conv2d_x3p_gn(pg, x4, w_packed, bias, Cout, frames_per_sample):
+    """3x3 / stride 1 / pad 1 conv over act(GroupNorm(x)) with the normalisation applied inside the kernel (csrc/igemm_x3p.hip
+    conv_patch_x3<GN>).  x4 = pg.x viewed as [N images, H, W, C]; frames_per_sample images form one GroupNorm sample."""
+    N, H, W, C = x4.shape
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x4.device)
+    last_kernel[0] = "conv_patch_x3_gn<256x128>"
+    check(lib.v2a_conv2d_fwd_x3p_gn(x4.data_ptr(), pg.mean.data_ptr(), pg.rstd.data_ptr(), pg.gamma.data_ptr(), pg.beta.data_ptr(), pg.G,
+                                    frames_per_sample, ACT[pg.act], w_packed.data_ptr(), _p(bias), y.data_ptr(), _zero_line(x4.device).data_ptr(),
+                                    N, H, W, C, Cout, _stream()), "conv2d_fwd_x3p_gn")
+    return y
+
+
 def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None, stats2=None):
     """bf16-storage GroupNorm + activation: x [N,S,C1] (+ x2 [N,S,C2] virtual concat) bf16 -> y [N,S,C] bf16.
     stats / stats2: the per-64-row statistic slabs conv2d_h(want_stats=True) returned with x / x2 (skips the statistics pass)."""

@@ -111,6 +111,18 @@ class _LazyGN:
         return self.pending.apply().view(self.shape)
 
 
+class _LazyGN32:
+    """fp32 counterpart of _LazyGN: GroupNorm + SiLU of a [B,F,H,W,C] fp32 tensor of which only the statistics ran (ops.PendingGN32).  The
+    3x3 ResBlock convs that run on conv_patch_x3 normalise their input in the kernel; every other consumer calls `materialize()`."""
+
+    def __init__(self, pending, shape):
+        self.pending, self.shape = pending, tuple(shape)
+        self.dtype = torch.float32
+
+    def materialize(self):
+        return self.pending.apply().view(self.shape)
+
+
 class UNetEngine:
     def __init__(self, cfg, params: dict, prefix="unet."):
         self.cfg = cfg
@@ -207,6 +219,20 @@ class UNetEngine:
             return self._conv3d_h(x, name, cout, stride, ups, x2, rowvec, residual, out_f32)
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
+        if isinstance(x, _LazyGN32):
+            if (k == 3 and stride == 1 and not ups and x2 is None and has_t and self.storage == "f32"
+                    and ops.conv2d_x3p_gn_ok(B * Fr, H, W, C, cout)):
+                # GroupNorm + SiLU applied inside the spatial conv (conv_patch_x3<GN>): the normalised tensor is never written
+                pg = x.pending
+                y = ops.conv2d_x3p_gn(pg, pg.x.view(B * Fr, H, W, C), self.w(name + ".spatial_conv.weight"), self.p(name + ".spatial_conv.bias"),
+                                      cout, Fr)
+                z, stats = ops.conv2d(y.view(B, Fr, H * W, cout), self.w(name + ".temporal_conv.weight"), self.p(name + ".temporal_conv.bias"),
+                                      cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * H * W,
+                                      residual=None if residual is None else residual.view(B, Fr, H * W, cout), want_stats=True)
+                out = z.view(B, Fr, H, W, cout)
+                out._gn_stats = stats
+                return out
+            x = x.materialize()
         x4 = x.view(B * Fr, H, W, C)
         x24 = None if x2 is None else x2.view(B * Fr, H, W, -1)
         if (self.storage != "f32" and has_t and cout % 128 == 0 and C < 32 and k == 3 and stride == 1 and x2 is None and not ups
@@ -273,6 +299,11 @@ class UNetEngine:
             return ops.groupnorm_fwd_h(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, x2=x23,
                                        stats=getattr(x, "_gn_stats", None),
                                        stats2=None if x2 is None else getattr(x2, "_gn_stats", None)).view(B, Fr, H, W, C)
+        if (lazy and x2 is None and not frames_separate and self.storage == "f32" and x.dtype == torch.float32
+                and getattr(x, "_gn_stats", None) is not None and S * (C // 32) > GN_SMALL_MAX):
+            pg = ops.groupnorm_prep_f32(x3, self.p(name + ".weight"), self.p(name + ".bias"), 32, act, stats=x._gn_stats)
+            if pg is not None:
+                return _LazyGN32(pg, (B, Fr, H, W, C))
         if x23 is not None and S * (C // 32) <= GN_SMALL_MAX:
             cat = torch.empty((N, S, C), dtype=torch.float32, device=x.device)      # tiny tensors: materialise the concat
             ops.copy2d(x3, cat, N * S, C1, C1, C)
