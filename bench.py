@@ -568,6 +568,17 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
     timed, timed_h = wrap(orig), wrap(orig_h)
     ops.conv2d = timed
     ops.conv2d_h = timed_h
+    orig_gn = ops.conv2d_x3p_gn                    # fp32 3x3 convs with GroupNorm folded into the loader: (pg, x4, w_packed, bias, Cout, fps)
+
+    def timed_gn(pg, x4, wp, bias, cout, fps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_gn(pg, x4, wp, bias, cout, fps)
+        e1.record()
+        recs.append((ops.last_kernel[0], 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * 9 * x4.shape[-1], e0, e1))
+        return y
+
+    ops.conv2d_x3p_gn = timed_gn
     try:
         eng = unet._engine()
         lab = eng.label_embedding(te)
@@ -577,6 +588,7 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
     finally:
         ops.conv2d = orig
         ops.conv2d_h = orig_h
+        ops.conv2d_x3p_gn = orig_gn
     agg = {}
     for name, fl, e0, e1 in recs:
         v = agg.setdefault(name, [0.0, 0.0, 0])

@@ -37,11 +37,25 @@ def wrap(fn):
     return f
 
 
-o1, o2 = ops.conv2d, ops.conv2d_h
-ops.conv2d, ops.conv2d_h = wrap(o1), wrap(o2)
+o1, o2, o3 = ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn
+
+
+def wrap_gn(fn):
+    def f(pg, x4, wp, bias, cout, fps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = fn(pg, x4, wp, bias, cout, fps)
+        e1.record()
+        M = y.shape[0] * y.shape[1] * y.shape[2]
+        recs.append(((M, x4.shape[-1], cout, 3, 3, ops.last_kernel[0]), 2.0 * M * cout * 9 * x4.shape[-1], e0, e1))
+        return y
+    return f
+
+
+ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn = wrap(o1), wrap(o2), wrap_gn(o3)
 m(x, t, task_embed=te)
 torch.cuda.synchronize()
-ops.conv2d, ops.conv2d_h = o1, o2
+ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn = o1, o2, o3
 agg = {}
 for key, fl, e0, e1 in recs:
     a = agg.setdefault(key, [0.0, 0.0, 0])

@@ -220,9 +220,12 @@ class UNetEngine:
         k = self.p(name + ".spatial_conv.weight").shape[-1]
         has_t = self.has(name + ".temporal_conv.weight")
         if isinstance(x, _LazyGN32):
-            if (k == 3 and stride == 1 and not ups and x2 is None and has_t and self.storage == "f32"
+            if (k == 3 and stride == 1 and not ups and x2 is None and has_t and self.storage == "f32" and cout <= 128
                     and ops.conv2d_x3p_gn_ok(B * Fr, H, W, C, cout)):
-                # GroupNorm + SiLU applied inside the spatial conv (conv_patch_x3<GN>): the normalised tensor is never written
+                # GroupNorm + SiLU applied inside the spatial conv (conv_patch_x3<GN>): the normalised tensor is never written.  Only
+                # where ONE 128-channel column tile covers the layer: every column tile normalises the halo again, and measured per
+                # layer (gpurun_out/r6m) the in-kernel arithmetic costs 6-7 % of the conv -- less than the apply pass it replaces at
+                # cout = 128 (-200 us per 128 x 128 layer), break-even at 256, a loss at 384 / 512
                 pg = x.pending
                 y = ops.conv2d_x3p_gn(pg, pg.x.view(B * Fr, H, W, C), self.w(name + ".spatial_conv.weight"), self.p(name + ".spatial_conv.bias"),
                                       cout, Fr)
