@@ -251,6 +251,46 @@ def g_c3_row():
     print("c3_row ok", out.shape, len(calls), float(out.double().abs().sum()))
 
 
+def g_c5_row():
+    """BASELINE configs[4]'s video half pinned on the REFERENCE at its full shape: 256 x 256, 1 conditioning + 15 predicted frames (45
+    channels), the 201 M-parameter Unet_Libero, 2 DDIM steps at batch 1 made by the imported reference's own GoalGaussianDiffusion.sample
+    (the attention layers see L = 1024 and 256 keys here).  ~4 minutes and ~12 GB on 8 cores.  Stored: every fourth pixel of every third
+    frame channel + sums of the whole sample."""
+    from flowdiffusion.flowdiffusion.goal_diffusion import GoalGaussianDiffusion
+    torch.manual_seed(0)
+    m = build_ref_unet(tiny=False).eval()
+    sd = fill_module(m, seed=12)
+    steps = 2
+    d = GoalGaussianDiffusion(m, image_size=(256, 256), channels=45, timesteps=100, sampling_timesteps=steps, loss_type="l2",
+                              objective="pred_v", beta_schedule="cosine", min_snr_loss_weight=True, guidance_weight=0)
+    gen = torch.Generator().manual_seed(43)
+    x_cond = torch.rand(1, 3, 256, 256, generator=gen)
+    te = torch.randn(1, 10, 512, generator=gen)
+    n0 = torch.randn(1, 45, 256, 256, generator=gen)
+    calls = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def fake_randn(*shape, **kw):
+        calls.append(1)
+        return n0.clone()
+
+    def fake_randn_like(t, **kw):                 # eta = 0: sigma = 0 multiplies every later draw
+        calls.append(1)
+        return torch.zeros_like(t)
+
+    torch.randn, torch.randn_like = fake_randn, fake_randn_like
+    try:
+        with torch.no_grad():
+            out = d.sample(x_cond, te, batch_size=1)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    assert out.shape == (1, 45, 256, 256), out.shape
+    np.savez_compressed(f"{OUT}/c5_row.npz", weights_abs_sum=wsum(sd), steps=steps, seed=43, n_noise_calls=len(calls),
+                        row0_sub=out[0, ::3, ::4, ::4].numpy().astype(np.float32), row0_sum=float(out.double().sum()),
+                        row0_abs_sum=float(out.double().abs().sum()), row0_sq_sum=float((out.double() ** 2).sum()))
+    print("c5_row ok", out.shape, len(calls), float(out.double().abs().sum()))
+
+
 def g_policy():
     torch.manual_seed(0)
     pol = build_ref_policy()
@@ -469,7 +509,7 @@ def g_wrappers():
     np.savez_compressed(f"{OUT}/wrappers.npz", **out)
 
 
-GROUPS = {"wrappers": g_wrappers, "tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer, "c3_row": g_c3_row}
+GROUPS = {"wrappers": g_wrappers, "tables": g_tables, "unet_tiny": g_unet_tiny, "unet_full": g_unet_full, "policy": g_policy, "replay": g_replay, "replay_mixed": g_replay_mixed, "policy_limits": g_policy_limits, "schedule": g_schedule, "video_train": g_video_train, "transformer": g_transformer, "c3_row": g_c3_row, "c5_row": g_c5_row}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GROUPS)
