@@ -244,6 +244,10 @@ int v2a_conv2d_fwd_p3(const void* x3, size_t x_plane_stride, const void* x2_3, s
                       int KH, int KW, int sh, int sw, int ph, int pw, int OH, int OW, int* nslab_out, void* workspace, size_t workspace_bytes,
                       v2a_stream_t stream);
 int v2a_split3_f32(const float* x, void* y3, size_t n, size_t plane_stride, v2a_stream_t stream);   /* fp32 [n] -> three bf16 planes (n % 4 == 0) */
+/* measurement / test hook: 0 = a zero-interleaved input (idil = 2: data gradient of a stride-2 conv, transposed conv) multiplies every
+   filter tap as in round 5; 1 (default) = class-major tile rows whose K loop walks the live taps only (2.25 of 9 for a 3 x 3 filter).
+   Returns the old value.  Process-wide. */
+int v2a_debug_set_parity_classes(int on);
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
 int v2a_get_f32_conv_mode(void);
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */

@@ -1282,6 +1282,44 @@ def test_three_plane_patch_conv_applies_groupnorm_in_its_loader(B, Fr, H, W, C, 
         assert err < 1e-5, (n, err)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Ci,Co,H,k,res", [(64, 128, 64, 16, 3, True), (64, 256, 128, 8, 3, False), (64, 512, 256, 4, 3, True), (64, 128, 64, 16, 1, False),
+                                             (8, 96, 64, 12, 3, False)])
+def test_stride2_data_gradient_walks_live_taps_only(N, Ci, Co, H, k, res):
+    """Data gradient of a stride-2 conv = a conv over the zero-interleaved output gradient (idil = 2).  Round 6: tile rows are numbered
+    by parity class of the output pixel and a tile's K loop visits only the taps that meet stored pixels (1 / 2 / 2 / 4 of 9; 1 / 0 / 0 / 0
+    for the 1 x 1 downsample) -- against torch's conv_transpose2d in fp64, and against the all-taps form of round 5 (the skipped products
+    are exact zeros: equal to fp32 reassociation across the different split-K partitions).  dy [N, H, H, Ci] -> dx [N, 2H, 2H, Co]."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    g = torch.Generator().manual_seed(N + Ci + k)
+    pad = k // 2
+    w = torch.randn(Ci, Co, k, k, generator=g) * 0.05                    # forward conv: Co -> Ci channels, stride 2 (torch layout [out, in, kh, kw])
+    dy = torch.randn(N, Ci, H, H, generator=g)
+    r = torch.randn(N, Co, 2 * H, 2 * H, generator=g) if res else None
+    ref = F.conv_transpose2d(dy.double(), w.double(), stride=2, padding=pad, output_padding=2 * H - ((H - 1) * 2 - 2 * pad + k))
+    if res:
+        ref = ref + r.double()
+    # the data-gradient operand: flipped taps, in / out channels swapped -> an ordinary forward pack [Co][k][k][Ci]
+    wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    wp = ops.pack_weight(wd.to(dev()), 0) if k > 1 else wd.reshape(Co, Ci).contiguous().to(dev())
+    outs = {}
+    for on in (1, 0):
+        old = lib.v2a_debug_set_parity_classes(on)
+        try:
+            y = ops.conv2d(nhwc(dy), wp, None, Co, k, k, (1, 1), (k - 1 - pad, k - 1 - pad), idil=2, out_hw=(2 * H, 2 * H),
+                           residual=nhwc(r) if res else None)
+        finally:
+            lib.v2a_debug_set_parity_classes(old)
+        outs[on] = y
+        err = (nchw(y).double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (on, err)
+    d = (outs[1] - outs[0]).abs().max().item() / outs[0].abs().max().item()
+    assert d < 2e-6, d
+
+
 def F_conv(x, w, b):
     return F.conv2d(x, w, b, padding=(1, 0))
 

@@ -72,6 +72,13 @@ struct ConvDescH {
     size_t xps, x2ps, wps;    // conv_p3 (pre-split operands): elements between the hi / mid / lo bf16 planes of x, x2, w
     int xp1;                  // element pitch between consecutive pixels of source 1 (= C1; < C1: overlapping channel windows,
                               // v2a_conv2d_fwd_window_f32)                                      [conv_igemm_f32x3, non-GEN path only]
+    // Parity classes of a zero-interleaved input (idil = 2: the data gradient of a stride-2 conv, a transposed conv).  Logical input
+    // position (oh - ph + kh, ow - pw + kw) is a stored pixel only when both coordinates are even, i.e. for the taps kh = (ph + oh) mod 2
+    // (mod 2), kw likewise: a 3 x 3 filter has 1 / 2 / 2 / 4 live taps for the four (oh & 1, ow & 1) classes -- 2.25 of 9 on average.
+    // pcls = 1: tile rows are numbered class-major (class c = rows [c * cls_R, (c + 1) * cls_R), inside a class (image, oh / nch, ow / ncw)),
+    // so that a tile's rows share ONE class and its K loop walks the live taps only; the epilogue maps rows back to NHWC order.
+    int pcls, nch, ncw, chh, cwh, cls_R;                                                         // [conv_igemm_f32x3<GEN>]
+    FastDivH fd_cw, fd_chw;
 };
 
 __device__ __forceinline__ int xcd_remap_h(int bid, int nblk) {
@@ -424,6 +431,29 @@ struct RowsPatch16H {
     __device__ __forceinline__ int operator()(int r) const {
         const int q = (r & ~31) | patch16_perm_h(r & 31);
         return base + (q >> 4) * W + (q & 15);
+    }
+};
+// (class-major tile rows of a zero-interleaved input, ConvDescH::pcls: row m' = cls * R + (img, a, b) -> NHWC row of pixel
+// (a * nch + cph, b * ncw + cpw))
+__device__ __forceinline__ int parity_row_h(const ConvDescH& p, int mp, int cls, int cph, int cpw, int& oh, int& ow, int& img) {
+    const uint32_t r = (uint32_t)(mp - cls * p.cls_R);
+    const uint32_t im = fdivh(r, p.fd_chw);
+    const uint32_t rem = r - im * (uint32_t)(p.chh * p.cwh);
+    const uint32_t a = fdivh(rem, p.fd_cw);
+    const uint32_t b = rem - a * (uint32_t)p.cwh;
+    img = (int)im;
+    oh = (int)a * p.nch + cph;
+    ow = (int)b * p.ncw + cpw;
+    return (img * p.OH + oh) * p.OW + ow;
+}
+struct RowsParityH {
+    const ConvDescH* p;
+    int m0, cls, cph, cpw;
+    __device__ __forceinline__ int operator()(int r) const {
+        const int mp = m0 + r;
+        if (mp >= p->M) return p->M;
+        int oh, ow, img;
+        return parity_row_h(*p, mp, cls, cph, cpw, oh, ow, img);
     }
 };
 template <int BM, int BN, int WVM = 2, int WVN = 2, typename RM = RowsLinearH>
@@ -797,9 +827,25 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     }
     const int m0 = tm * BM;
     const int Cin = p.C1 + p.C2;
-    const int nkt = p.K / EPT;
-    const int kt_begin = split * p.ktiles_per_split;
-    const int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    // parity classes (GEN, p.pcls): this tile's class and the live taps kh0, kh0 + khs, ... / kw0, kw0 + kws, ...
+    int cls = 0, cph = 0, cpw = 0, kh0 = 0, khs = 1, kw0 = 0, kws = 1, ntw = p.KW;
+    int nkt = p.K / EPT;
+    int kt_begin = split * p.ktiles_per_split;
+    int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    if constexpr (GEN) {
+        if (p.pcls) {
+            cls = m0 / p.cls_R;
+            cph = p.ncw == 2 ? (cls >> 1) : cls;
+            cpw = p.ncw == 2 ? (cls & 1) : 0;
+            if (p.nch == 1) { cph = 0; cpw = cls; }
+            int nth = p.KH;
+            if (p.nch == 2) { kh0 = (p.ph + cph) & 1; khs = 2; nth = (p.KH - kh0 + 1) >> 1; }
+            if (p.ncw == 2) { kw0 = (p.pw + cpw) & 1; kws = 2; ntw = (p.KW - kw0 + 1) >> 1; }
+            nkt = nth * ntw * (Cin / EPT);
+            kt_begin = (int)(((long)split * nkt) / p.splitk);           // the class's own k tiles, spread evenly over the slices
+            kt_end = (int)(((long)(split + 1) * nkt) / p.splitk);
+        }
+    }
     const float* wsel = reinterpret_cast<const float*>(p.w);
     const float* bias_sel = p.bias;
 
@@ -811,10 +857,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
         const int m = m0 + j * RP + lrow;
         const bool ok = m < p.M;
         const uint32_t mm = ok ? (uint32_t)m : 0u;
-        const uint32_t t = fdivh(mm, p.fd_ow);
-        const int ow = (int)(mm - t * p.OW);
-        const uint32_t img = fdivh(t, p.fd_oh);
-        const int oh = (int)(t - img * p.OH);
+        int ow, oh, img;
+        if (GEN && p.pcls) {
+            parity_row_h(p, ok ? m : m0, cls, cph, cpw, oh, ow, img);
+        } else {
+            const uint32_t t = fdivh(mm, p.fd_ow);
+            ow = (int)(mm - t * p.OW);
+            const uint32_t im = fdivh(t, p.fd_oh);
+            oh = (int)(t - im * p.OH);
+            img = (int)im;
+        }
         a_imgh[j] = (int)img * p.H;
         a_ihb[j] = ok ? oh * p.sh - p.ph : -(1 << 28);
         a_iwb[j] = ow * p.sw - p.pw;
@@ -833,10 +885,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     }
     const int shift = (p.ups || p.idil == 2) ? 1 : 0;
     const int pmask = (p.idil == 2) ? 1 : 0;
-    int ik0 = kt_begin * EPT;
-    int itap = ik0 / Cin;
-    int ic0 = ik0 - itap * Cin;
-    int ikh = itap / p.KW, ikw = itap - ikh * p.KW;
+    // position of the next k tile: the itap-th LIVE tap (all taps without parity classes) and the channel offset inside it
+    const int itap = (kt_begin * EPT) / Cin;
+    int ic0 = kt_begin * EPT - itap * Cin;
+    const int ntw1 = ntw > 0 ? ntw : 1;                         // (a class without live taps has no k tiles: its outputs are bias + residual)
+    int ikh = kh0 + (itap / ntw1) * khs, ikw = kw0 + (itap % ntw1) * kws;
+    int ik0 = (ikh * p.KW + ikw) * Cin + ic0;
     int it = kt_begin;
 
     // request the next k tile (16-B loads into the given register set; past the slice's end: the zero line) and advance the position
@@ -873,14 +927,14 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
             rb[j] = *reinterpret_cast<const gf32x4_t*>(gi);
         }
         ++it;
-        ik0 += EPT;
         ic0 += EPT;
         const bool wrap = ic0 >= Cin;
         ic0 = wrap ? 0 : ic0;
-        const int kw1 = ikw + (wrap ? 1 : 0);
-        const bool wrap2 = kw1 == p.KW;
-        ikw = wrap2 ? 0 : kw1;
-        ikh += wrap2 ? 1 : 0;
+        const int kw1 = ikw + (wrap ? kws : 0);
+        const bool wrap2 = kw1 >= p.KW;
+        ikw = wrap2 ? kw0 : kw1;
+        ikh += wrap2 ? khs : 0;
+        ik0 = (ikh * p.KW + ikw) * Cin + ic0;
     };
     // LDS position of this thread's 8-B piece (4 bf16) of plane row r: 16-B chunk (c4 >> 1) ^ ((r >> 2) & 3), half c4 & 1
     int w_off[AL > BL ? AL : BL];
@@ -1006,6 +1060,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     }
     // (every wave passed the loop's last barrier after its last LDS access; the trailing register loads hit the zero line)
     static_assert(WVM * WVN * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
+    if constexpr (GEN) {
+        if (p.pcls) {
+            conv_f32_epilogue_rm<BM, BN, WVM, WVN, RowsParityH>(p, acc, smem, RowsParityH{&p, m0, cls, cph, cpw}, n0, split, bias_sel);
+            return;
+        }
+    }
     conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, bias_sel);
 }
 
@@ -1524,6 +1584,7 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
 }
 
 static void f32_conv_mode_init();
+static int g_pcls_on = 1;     // parity-class tiles for zero-interleaved inputs (v2a_debug_set_parity_classes: A/B hook of the tests)
 static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact / v2a_set_f32_conv_mode(0) select the exact-f32 MFMA kernels
 // Tile / split plan shared by the LDS-DMA conv families.  128-row tiles (64 output columns for 64-wide layers); problems that 128-row
 // tiles cannot spread over the chip (< 128 tiles) take 64 x 64 tiles; K is split so that one round of about 512 workgroups covers the
@@ -1609,6 +1670,7 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
         return V2A_ERR_ARG;
     if ((double)N * H * W * (C1 > C2 ? C1 : C2) >= 4294967296.0) return V2A_ERR_ARG;      // the gather uses 32-bit element offsets
     ConvDescH p;
+    p.pcls = 0;
     p.x = x; p.x2 = x2; p.w = w_packed;
     p.bias = bias; p.rowvec = rowvec; p.residual = residual; p.residual_f = residual_f32; p.idil = idil;
     p.y = y; p.yf = y_f32; p.partial = (float*)workspace; p.zeros = zeros;
@@ -1687,6 +1749,18 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
             // the wider the tile, the fewer fp32 -> plane conversions and LDS bytes per MFMA
             const bool gen = ups || idil == 2;
             p.split_xcd = (s >= 8 && s % 8 == 0 && p.frame_tiles == 0) ? s / 8 : 0;
+            // zero-interleaved input (data gradient of a stride-2 conv, transposed conv): class-major tile rows, live taps only
+            p.pcls = 0;
+            if (idil == 2 && !x2 && C2 == 0 && (OH == 1 || OH % 2 == 0) && OW % 2 == 0 && !stats && g_pcls_on) {
+                const int nch = OH > 1 ? 2 : 1, ncw = 2;
+                const long R = (long)N * (OH / nch) * (OW / ncw);
+                const int bm_eff = (bm == 64) ? 64 : ((bn == 64 && cdiv(p.M, 256) * cdiv(Cout, 64) >= 200 && p.M % 256 == 0) ? 256 : 128);
+                if (R % bm_eff == 0 && R < 2147483647L) {
+                    p.pcls = 1; p.nch = nch; p.ncw = ncw; p.chh = OH / nch; p.cwh = OW / ncw; p.cls_R = (int)R;
+                    p.fd_cw = make_fastdiv_h((uint32_t)p.cwh);
+                    p.fd_chw = make_fastdiv_h((uint32_t)(p.chh * p.cwh));
+                }
+            }
 #define V2A_X3_LAUNCH(BM_, BN_, WM_, WN_, G_)                                                                                            \
     do {                                                                                                                                   \
         const dim3 grid_ = p.split_xcd > 0 ? dim3((G_) * s, 1) : dim3(G_, s);                                                              \
@@ -1755,6 +1829,11 @@ static void f32_conv_mode_init() {
         const char* e = getenv("V2A_F32_CONV");
         g_f32x3 = (e && e[0] == 'e') ? 0 : 1;
     }
+}
+int v2a_debug_set_parity_classes(int on) {      // returns the old value; 0: every tap of a zero-interleaved input is multiplied (round-5 form)
+    const int old = g_pcls_on;
+    g_pcls_on = on ? 1 : 0;
+    return old;
 }
 int v2a_set_f32_conv_mode(int x3) {
     f32_conv_mode_init();
