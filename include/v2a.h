@@ -317,6 +317,15 @@ int v2a_conv2d_x3t_eligible(int B, int F, int HW, int C, int Cout, int rows_per_
    conv_patch_x3: a 16 x 16 pixel patch x 128 output channels per persistent workgroup; three-plane mode, no row vector / statistics).
    Depends on the shape and the device's CU count only. */
 int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
+/* Upsample (nearest x2, guided_diffusion/unet.py:105-115) + 3 x 3 conv in the fp32 configuration as FOUR 2 x 2 convs over the source map, one
+   per parity class of the output pixel: two of the three filter rows / columns read the same source pixel, so their weights are summed
+   once (v2a_pack_weight_ups4: forward pack [Cout][3][3][C] -> [4][Cout][2][2][C]) and every output needs 4 of the 9 products
+   (conv_patch_x3<.., 2>, csrc/igemm_x3p.hip).  v2a_conv2d_fwd_x3p_ups4: x = the SOURCE [N, H/2, W/2, C], y [N, H, W, Cout], bias only;
+   where v2a_conv2d_x3p_ups4_eligible(N, H, W, C, Cout) (H, W the OUTPUT map, multiples of 32). */
+int v2a_conv2d_x3p_ups4_eligible(int N, int H, int W, int C, int Cout);
+int v2a_pack_weight_ups4(const float* w_packed, float* out, int Cout, int C, v2a_stream_t stream);
+int v2a_conv2d_fwd_x3p_ups4(const float* x, const float* w_ups4, const float* bias, float* y, const void* zeros, int N, int H, int W, int C,
+                            int Cout, v2a_stream_t stream);
 /* GroupNorm32 + SiLU in front of a ResBlock conv (guided_diffusion/unet.py:181-197 in_layers / out_layers, nn.py:95-97) folded into that
    conv in the fp32 configuration: v2a_groupnorm_stats_f32 turns the producing conv's per-64-row statistics blocks `stats`
    [N * S/64][2][C] into mean / rstd [N][G] (the reduce + finalise launches of v2a_groupnorm_fwd_st, S % 64 == 0, workspace >= N*64*2*C*8

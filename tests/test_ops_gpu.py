@@ -1320,6 +1320,40 @@ def test_stride2_data_gradient_walks_live_taps_only(N, Ci, Co, H, k, res):
     assert d < 2e-6, d
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Ci,Co", [(7, 64, 64, 64, 128), (28, 16, 16, 96, 256), (10, 32, 48, 32, 128)])
+def test_upsample_conv_as_four_class_convs_vs_fp64(N, H, W, Ci, Co):
+    """Upsample (nearest x2) + 3x3 conv as four 2x2 convs over the source map (conv_patch_x3<.., 2>, v2a_pack_weight_ups4): the filter
+    taps that read the same source pixel are summed in advance, every output pixel of parity class (oh & 1, ow & 1) gets its own 2 x 2
+    filter and window origin.  Borders on every side (the up-sampled map's zero padding falls on source pixels outside the map),
+    several tiles per workgroup, a non-square map; against fp64 interpolate -> conv2d and against the gather form (H, W = source sizes)."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    assert ops.conv2d_x3p_ups4_ok(N, 2 * H, 2 * W, Ci, Co)
+    g = torch.Generator().manual_seed(N * H + W + Ci)
+    x = torch.randn(N, Ci, H, W, generator=g) * torch.rand(N, Ci, H, W, generator=g).mul(4).exp2()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    b = torch.randn(Co, generator=g)
+    wp = ops.pack_weight(w.to(dev()), 0)
+    w4 = ops.pack_weight_ups4(wp, Co, Ci)
+    # the class filters are sums of the 3x3 taps: class (1, 0), tap (0, 1) = w[kh 0..1][kw 1..2] summed
+    want = (w[:, :, 0:2, 1:3].double().sum((2, 3))).float()
+    assert torch.allclose(w4[2, :, 0, 1, :].cpu(), want, rtol=1e-6, atol=1e-6)
+    xd = nhwc(x)
+    y = ops.conv2d_x3p_ups4(xd, w4, b.to(dev()), Co)
+    assert y.shape == (N, 2 * H, 2 * W, Co)
+    y1 = ops.conv2d(xd, wp, b.to(dev()), Co, 3, 3, (1, 1), (1, 1), ups=True)
+    d = (y - y1).abs().max().item() / y1.abs().max().item()
+    assert d < 3e-6, d
+    for n in sorted({0, N - 1}):
+        ref = F.conv2d(F.interpolate(x[n:n + 1].double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+        err = (nchw(y[n:n + 1]).double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (n, err)
+    assert torch.equal(y, ops.conv2d_x3p_ups4(xd, w4, b.to(dev()), Co))
+
+
 def F_conv(x, w, b):
     return F.conv2d(x, w, b, padding=(1, 0))
 

@@ -8,3 +8,4 @@ int conv_patch_x3_eligible(int N, int H, int W, int C, int Cout, int ncu);
 int conv_patch_x3_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, const void* zeros, int N,
                          int H, int W, int C, int Cout, int ups, hipStream_t stream);
 extern "C" int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
+int conv_patch_x3_ups4_eligible(int N, int H, int W, int C, int Cout, int ncu);

@@ -161,6 +161,9 @@ SIGNATURES = {
     "v2a_conv2d_t3_eligible": (I, [I] * 13),
     "v2a_conv2d_x3t_eligible": (I, [I] * 7),
     "v2a_conv2d_x3p_eligible": (I, [I] * 5),
+    "v2a_conv2d_x3p_ups4_eligible": (I, [I] * 5),
+    "v2a_pack_weight_ups4": (I, [P, P, I, I, P]),
+    "v2a_conv2d_fwd_x3p_ups4": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "v2a_conv2d_fwd_x3p_gn": (I, [P, P, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, P]),
     "v2a_groupnorm_stats_f32": (I, [P, P, P, I, I, I, I, F, P, SZ, P]),
     "v2a_groupnorm_prep_h": (I, [P, P, I, P, P, P, P, P, P, I, I, I, I, F, P, P, SZ, P]),

@@ -946,6 +946,29 @@ def conv2d_x3p_gn(pg, x4, w_packed, bias, Cout, frames_per_sample):
     return y
 
 
+def pack_weight_ups4(w_packed, Cout, C, out=None):
+    """Forward pack [Cout][3][3][C] of an Upsample + 3x3 conv -> the four class filters [4][Cout][2][2][C] (v2a_pack_weight_ups4)."""
+    if out is None:
+        out = torch.empty((4, Cout, 2, 2, C), dtype=torch.float32, device=w_packed.device)
+    check(lib.v2a_pack_weight_ups4(w_packed.data_ptr(), out.data_ptr(), Cout, C, _stream()), "pack_weight_ups4")
+    return out
+
+
+def conv2d_x3p_ups4_ok(N, OH, OW, C, Cout):
+    return (bool(lib.v2a_conv2d_x3p_ups4_eligible(N, OH, OW, C, Cout)) and lib.v2a_get_f32_conv_mode() == 1
+            and lib.v2a_get_precision() == 0)
+
+
+def conv2d_x3p_ups4(x, w_ups4, bias, Cout):
+    """Upsample (nearest x2) + 3x3 / pad 1 conv of x [N, H, W, C] -> [N, 2H, 2W, Cout] as four 2x2 class convs over x (4 / 9 of the MACs)."""
+    N, H, W, C = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
+    last_kernel[0] = "conv_patch_x3_ups4<256x128>"
+    check(lib.v2a_conv2d_fwd_x3p_ups4(x.data_ptr(), w_ups4.data_ptr(), _p(bias), y.data_ptr(), _zero_line(x.device).data_ptr(), N, 2 * H, 2 * W,
+                                      C, Cout, _stream()), "conv2d_fwd_x3p_ups4")
+    return y
+
+
 def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None, stats2=None):
     """bf16-storage GroupNorm + activation: x [N,S,C1] (+ x2 [N,S,C2] virtual concat) bf16 -> y [N,S,C] bf16.
     stats / stats2: the per-64-row statistic slabs conv2d_h(want_stats=True) returned with x / x2 (skips the statistics pass)."""

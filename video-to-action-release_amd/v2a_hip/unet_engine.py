@@ -71,6 +71,18 @@ class _Packs:
         self.P = P
         self._c = {}
 
+    def get_ups4(self, name):
+        """The four class filters of an Upsample + 3x3 conv (ops.pack_weight_ups4), refreshed with the weight like every other pack."""
+        w = self.P[name]
+        key = (w.data_ptr(), w._version)
+        ck = (name, "ups4", 0)
+        ent = self._c.get(ck)
+        if ent is None or ent[0] != key:
+            pk = ops.pack_weight_ups4(self.get(name), w.shape[0], w.shape[1], None if ent is None else ent[1])
+            ent = (key, pk)
+            self._c[ck] = ent
+        return ent[1]
+
     def get(self, name, half=False, pad_cin=0):
         """half: False (fp32 pack) or the 16-bit dtype of the pack (torch.bfloat16 / torch.float16).
         pad_cin: 16-bit pack with the input-channel axis zero-padded to `pad_cin` (the 6-channel stem on the 32-channel-chunk kernels)."""
@@ -251,6 +263,17 @@ class UNetEngine:
                                     rows_per_batch=Fr * H * W, residual=None if residual is None else residual.view(B, Fr, H * W, cout),
                                     want_stats=True)
             out = z.view(B, Fr, H, W, cout)
+            out._gn_stats = stats
+            return out
+        if (ups and k == 3 and stride == 1 and x2 is None and has_t and self.storage == "f32"
+                and ops.conv2d_x3p_ups4_ok(B * Fr, 2 * H, 2 * W, C, cout)):
+            # Upsample + 3x3 as four 2x2 class convs over the source map: 4 of the 9 products per output (conv_patch_x3<.., 2>)
+            y = ops.conv2d_x3p_ups4(x4, self.packs.get_ups4(self.pre + name + ".spatial_conv.weight"), self.p(name + ".spatial_conv.bias"), cout)
+            OH, OW = 2 * H, 2 * W
+            z, stats = ops.conv2d(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight"), self.p(name + ".temporal_conv.bias"),
+                                  cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec, rows_per_batch=Fr * OH * OW,
+                                  residual=None if residual is None else residual.view(B, Fr, OH * OW, cout), want_stats=True)
+            out = z.view(B, Fr, OH, OW, cout)
             out._gn_stats = stats
             return out
         wsp = self.w(name + ".spatial_conv.weight")
