@@ -52,10 +52,25 @@ def wrap_gn(fn):
     return f
 
 
-ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn = wrap(o1), wrap(o2), wrap_gn(o3)
+o4 = ops.conv2d_x3p_ups4
+
+
+def wrap_ups4(fn):                 # (x, w_ups4, bias, Cout): algorithmic FLOPs = the reference's nine taps per output
+    def f(xs, w4, bias, cout):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = fn(xs, w4, bias, cout)
+        e1.record()
+        M = y.shape[0] * y.shape[1] * y.shape[2]
+        recs.append(((M, xs.shape[-1], cout, 3, 3, ops.last_kernel[0]), 2.0 * M * cout * 9 * xs.shape[-1], e0, e1))
+        return y
+    return f
+
+
+ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn, ops.conv2d_x3p_ups4 = wrap(o1), wrap(o2), wrap_gn(o3), wrap_ups4(o4)
 m(x, t, task_embed=te)
 torch.cuda.synchronize()
-ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn = o1, o2, o3
+ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn, ops.conv2d_x3p_ups4 = o1, o2, o3, o4
 agg = {}
 for key, fl, e0, e1 in recs:
     a = agg.setdefault(key, [0.0, 0.0, 0])
