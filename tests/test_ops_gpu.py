@@ -1354,6 +1354,45 @@ def test_upsample_conv_as_four_class_convs_vs_fp64(N, H, W, Ci, Co):
     assert torch.equal(y, ops.conv2d_x3p_ups4(xd, w4, b.to(dev()), Co))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,Ci,Co,k,two", [(64, 4, 1024, 1024, 5, False), (64, 8, 512, 512, 5, False), (64, 16, 256, 256, 5, True), (128, 4, 64, 128, 3, False)])
+def test_short_conv1d_skips_the_taps_that_meet_the_padding(B, T, Ci, Co, k, two):
+    """ConditionalUnet1D Conv1d (k = 5, pad 2 over T = 4 / 8 / 16 positions; conv1d_components.py:23-40) on conv_igemm_f32x3 with one row
+    class per output position: a tile's K loop visits only the taps that land inside the sequence (3, 4, 4, 3 of 5 at T = 4).  The skipped
+    products were exact zeros: against fp64 conv1d, and against the all-taps form up to the different split-K partitions; deferred
+    split-K slabs (summed here by hand) and a two-source (concat) input included."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    g = torch.Generator().manual_seed(B + T + Ci)
+    x = torch.randn(B, Ci, T, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) * 0.03
+    b = torch.randn(Co, generator=g)
+    ref = F.conv1d(x.double(), w.double(), b.double(), padding=k // 2).permute(0, 2, 1)          # [B, T, Co]
+    xd = x.permute(0, 2, 1).contiguous().to(dev())                                               # [B, T, Ci]
+    wp = ops.pack_weight(w.view(Co, Ci, 1, k).to(dev()), 0)
+    C1 = Ci // 2 if two else Ci
+    xa = xd[..., :C1].contiguous().view(B, 1, T, C1)
+    xb = xd[..., C1:].contiguous().view(B, 1, T, Ci - C1) if two else None
+    outs = {}
+    for on in (1, 0):
+        old = lib.v2a_debug_set_parity_classes(on)
+        try:
+            y = ops.conv2d(xa, wp, b.to(dev()), Co, 1, k, (1, 1), (0, k // 2), x2=xb)
+            yd, sl = ops.conv2d(xa, wp, b.to(dev()), Co, 1, k, (1, 1), (0, k // 2), x2=xb, defer=True)
+        finally:
+            lib.v2a_debug_set_parity_classes(old)
+        if sl is not None:                                    # unreduced slabs: their sum + bias is the tensor
+            yd = sl.ws.view(torch.float32)[:sl.n * sl.stride].view(sl.n, -1).sum(0).view(B, 1, T, Co) + b.to(dev())
+        outs[on] = y
+        for name, t in (("finished", y), ("deferred", yd)):
+            err = (t.view(B, T, Co).cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 5e-6, (on, name, err)
+    d = (outs[1] - outs[0]).abs().max().item() / outs[0].abs().max().item()
+    assert d < 2e-6, d
+
+
 def F_conv(x, w, b):
     return F.conv2d(x, w, b, padding=(1, 0))
 

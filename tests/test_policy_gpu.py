@@ -327,6 +327,10 @@ def test_presplit_operand_convs_equal_the_register_split_path_bitwise(B):
         seen.append(1)
         return orig(*a, **k)
     out = {}
+    from v2a_hip._lib import lib
+    # (round 6: the register-splitting kernel numbers its rows by output position / parity and skips dead taps -- another split-K partition
+    # than conv_p3's, which has no such mode: the bit-for-bit comparison is made on the all-taps form both kernels share)
+    old_cls = lib.v2a_debug_set_parity_classes(0)
     for use in (True, False):
         eng.use_p3 = use
         eng.refresh_packs()
@@ -336,6 +340,8 @@ def test_presplit_operand_convs_equal_the_register_split_path_bitwise(B):
             l_inf, _, _ = eng.loss_fwd_bwd(imgs, act, noise, ts, need_grad=False)
         finally:
             ops.conv2d_p3 = orig
+            if not use:
+                lib.v2a_debug_set_parity_classes(old_cls)
         torch.cuda.synchronize()
         out[use] = (loss.clone(), arena.clone(), l_inf.clone(), len(seen))
         seen.clear()

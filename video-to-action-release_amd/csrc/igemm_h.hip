@@ -442,8 +442,13 @@ __device__ __forceinline__ int parity_row_h(const ConvDescH& p, int mp, int cls,
     const uint32_t a = fdivh(rem, p.fd_cw);
     const uint32_t b = rem - a * (uint32_t)p.cwh;
     img = (int)im;
-    oh = (int)a * p.nch + cph;
-    ow = (int)b * p.ncw + cpw;
+    if (p.pcls == 2) {          // position classes: chh = OH, cwh = 1 -> a = oh, b = 0; the class IS the output column
+        oh = (int)a;
+        ow = cpw;
+    } else {
+        oh = (int)a * p.nch + cph;
+        ow = (int)b * p.ncw + cpw;
+    }
     return (img * p.OH + oh) * p.OW + ow;
 }
 struct RowsParityH {
@@ -832,19 +837,26 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     int nkt = p.K / EPT;
     int kt_begin = split * p.ktiles_per_split;
     int kt_end = min(nkt, kt_begin + p.ktiles_per_split);
-    if constexpr (GEN) {
-        if (p.pcls) {
-            cls = m0 / p.cls_R;
+    if (p.pcls) {
+        cls = m0 / p.cls_R;
+        int nth = p.KH;
+        if (p.pcls == 2) {
+            // position classes of a short same-size 1-d conv (ncw = OW classes, one per output column ow = cls): the taps that fall into
+            // the zero padding are skipped -- kw in [pw - ow, W - 1 + pw - ow] clipped to the filter
+            cph = 0; cpw = cls;
+            kw0 = max(0, p.pw - cls);
+            const int kw1 = min(p.KW - 1, p.W - 1 + p.pw - cls);
+            ntw = kw1 - kw0 + 1;
+        } else {
             cph = p.ncw == 2 ? (cls >> 1) : cls;
             cpw = p.ncw == 2 ? (cls & 1) : 0;
             if (p.nch == 1) { cph = 0; cpw = cls; }
-            int nth = p.KH;
             if (p.nch == 2) { kh0 = (p.ph + cph) & 1; khs = 2; nth = (p.KH - kh0 + 1) >> 1; }
             if (p.ncw == 2) { kw0 = (p.pw + cpw) & 1; kws = 2; ntw = (p.KW - kw0 + 1) >> 1; }
-            nkt = nth * ntw * (Cin / EPT);
-            kt_begin = (int)(((long)split * nkt) / p.splitk);           // the class's own k tiles, spread evenly over the slices
-            kt_end = (int)(((long)(split + 1) * nkt) / p.splitk);
         }
+        nkt = nth * ntw * (Cin / EPT);
+        kt_begin = (int)(((long)split * nkt) / p.splitk);           // the class's own k tiles, spread evenly over the slices
+        kt_end = (int)(((long)(split + 1) * nkt) / p.splitk);
     }
     const float* wsel = reinterpret_cast<const float*>(p.w);
     const float* bias_sel = p.bias;
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
         const bool ok = m < p.M;
         const uint32_t mm = ok ? (uint32_t)m : 0u;
         int ow, oh, img;
-        if (GEN && p.pcls) {
+        if (p.pcls) {
             parity_row_h(p, ok ? m : m0, cls, cph, cpw, oh, ow, img);
         } else {
             const uint32_t t = fdivh(mm, p.fd_ow);
@@ -1060,11 +1072,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, MINW) void conv_igemm_f32x3(const C
     }
     // (every wave passed the loop's last barrier after its last LDS access; the trailing register loads hit the zero line)
     static_assert(WVM * WVN * 32 * WN * 4 <= S * STAGE, "epilogue staging exceeds the operand buffers");
-    if constexpr (GEN) {
-        if (p.pcls) {
-            conv_f32_epilogue_rm<BM, BN, WVM, WVN, RowsParityH>(p, acc, smem, RowsParityH{&p, m0, cls, cph, cpw}, n0, split, bias_sel);
-            return;
-        }
+    if (p.pcls) {
+        conv_f32_epilogue_rm<BM, BN, WVM, WVN, RowsParityH>(p, acc, smem, RowsParityH{&p, m0, cls, cph, cpw}, n0, split, bias_sel);
+        return;
     }
     conv_f32_epilogue<BM, BN, WVM, WVN>(p, acc, smem, m0, n0, split, bias_sel);
 }
@@ -1759,6 +1769,18 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
                     p.pcls = 1; p.nch = nch; p.ncw = ncw; p.chh = OH / nch; p.cwh = OW / ncw; p.cls_R = (int)R;
                     p.fd_cw = make_fastdiv_h((uint32_t)p.cwh);
                     p.fd_chw = make_fastdiv_h((uint32_t)(p.chh * p.cwh));
+                }
+            }
+            // short same-size 1-d convs (ConditionalUnet1D: k = 5 over T = 4 / 8 / 16 with pad 2): 30 / 15 / 7.5 % of the tap x position
+            // products meet the zero padding -- one class per output column, live taps only
+            if (!p.pcls && !gen && g_pcls_on && KH == 1 && KW >= 3 && sh == 1 && sw == 1 && ph == 0 && pw > 0 && OH == 1 && H == 1 && OW == W &&
+                OW <= 16 && !stats && xpitch == 0 && p.frame_tiles == 0) {
+                const long R = (long)N;
+                const int bm_eff = (bm == 64) ? 64 : ((bn == 64 && cdiv(p.M, 256) * cdiv(Cout, 64) >= 200 && p.M % 256 == 0) ? 256 : 128);
+                if (R % bm_eff == 0) {
+                    p.pcls = 2; p.nch = 1; p.ncw = OW; p.chh = 1; p.cwh = 1; p.cls_R = (int)R;
+                    p.fd_cw = make_fastdiv_h(1u);
+                    p.fd_chw = make_fastdiv_h(1u);
                 }
             }
 #define V2A_X3_LAUNCH(BM_, BN_, WM_, WN_, G_)                                                                                            \
