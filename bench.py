@@ -251,7 +251,10 @@ def instrumented_pass(torch, trainer, steps):
         y = y[0] if isinstance(y, tuple) else y          # conv2d(..., defer=True) returns (y, slabs)
         m = y.shape[0] * y.shape[1] * y.shape[2]
         K = kh * kw * (x.shape[-1] + c2)
-        return (ops.last_kernel[0], 2.0 * m * cout * K, (m, cout, K, kh, kw, int(k.get("bmode", 0) or 0)))     # name: the launcher's plan
+        # a conv over a zero-interleaved input (idil = 2: data gradient of a stride-2 conv, transposed conv) has 1 / 4 (2-d) or 1 / 2 (1-d) of
+        # its tap x pixel products on stored pixels: only those are algorithmic work (the kernels skip the rest since round 6)
+        live = 1.0 if int(k.get("idil", 1) or 1) != 2 else (0.25 if y.shape[1] > 1 else 0.5)
+        return (ops.last_kernel[0], 2.0 * m * cout * K * live, (m, cout, K, kh, kw, int(k.get("bmode", 0) or 0)))     # name: the launcher's plan
 
     def f_wg(a, k, out):
         x, dy, kh, kw = a[0], a[1], a[3], a[4]
