@@ -68,6 +68,8 @@ def pytest_sessionfinish(session, exitstatus):
         old.update(_LEDGER)
         summary = {k: {"max": max(r["value"] for r in v), "n": len(v)} for k, v in old.items()}
         with open(path, "w") as f:
-            json.dump({"unit": "as computed by the test (mostly max |a - b| / max |b|)", "summary": summary, "tests": old}, f, indent=0, sort_keys=True)
+            json.dump({"unit": "as computed by the test (mostly max |a - b| / max |b|); the helpers are also used for 'must differ' checks (a changed "
+                               "weight must change the output: values >> 1e-2 are those), so read a value next to its test's assertion",
+                       "summary": summary, "tests": old}, f, indent=0, sort_keys=True)
     except Exception as e:                          # never fail a session over the ledger
         print(f"[parity ledger] not written: {e}")
