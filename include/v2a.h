@@ -323,6 +323,13 @@ int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
    (conv_patch_x3<.., 2>, csrc/igemm_x3p.hip).  v2a_conv2d_fwd_x3p_ups4: x = the SOURCE [N, H/2, W/2, C], y [N, H, W, Cout], bias only;
    where v2a_conv2d_x3p_ups4_eligible(N, H, W, C, Cout) (H, W the OUTPUT map, multiples of 32). */
 int v2a_conv2d_x3p_ups4_eligible(int N, int H, int W, int C, int Cout);
+/* the same decomposition for the 16-bit video UNet (csrc/igemm_hp.hip conv_patch_h_ups4: 32 x 16 class pixels x 128 channels per persistent
+   workgroup, register-staged operands; format = v2a_set_half_format of the calling thread): x = the SOURCE [N, H/2, W/2, C] 16-bit,
+   w_ups4 = [4][Cout][2][2][C] 16-bit (v2a_pack_weight_ups4 of the fp32 pack, then v2a_cast_f32_h), y [N, H, W, Cout] 16-bit, bias fp32;
+   where v2a_conv2d_hp_ups4_eligible(N, H, W, C, Cout) (H % 64 == 0, W % 32 == 0: the OUTPUT map). */
+int v2a_conv2d_hp_ups4_eligible(int N, int H, int W, int C, int Cout);
+int v2a_conv2d_fwd_hp_ups4(const void* x, const void* w_ups4, const float* bias, void* y, const void* zeros, int N, int H, int W, int C,
+                           int Cout, v2a_stream_t stream);
 int v2a_pack_weight_ups4(const float* w_packed, float* out, int Cout, int C, v2a_stream_t stream);
 int v2a_conv2d_fwd_x3p_ups4(const float* x, const float* w_ups4, const float* bias, float* y, const void* zeros, int N, int H, int W, int C,
                             int Cout, v2a_stream_t stream);

@@ -1393,6 +1393,42 @@ def test_short_conv1d_skips_the_taps_that_meet_the_padding(B, T, Ci, Co, k, two)
     assert d < 2e-6, d
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Ci,Co", [(14, 64, 64, 64, 128), (28, 32, 32, 96, 256), (20, 32, 48, 32, 128)])
+def test_16bit_upsample_conv_as_four_class_convs(N, H, W, Ci, Co, dt):
+    """conv_patch_h_ups4 (csrc/igemm_hp.hip): Upsample + 3x3 of the 16-bit video UNet as four 2x2 class convs over the source map.  Against
+    an fp64 conv of the same rounded inputs with the PRE-SUMMED, rounded class filters (what the kernel multiplies: within one 16-bit ulp
+    of the stored result), and against the nine-tap gather form on conv_halo_h3 (differs by the second rounding of the summed weights:
+    a few 16-bit ulps); borders on every side, several tiles per workgroup, a non-square map, both 16-bit formats; bitwise repeatable."""
+    from v2a_hip import ops
+    assert ops.conv2d_hp_ups4_ok(N, 2 * H, 2 * W, Ci, Co)
+    g = torch.Generator().manual_seed(N * H + W + Ci)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dt).to(dev())
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    b = torch.randn(Co, generator=g).to(dev())
+    wp = ops.pack_weight(w.to(dev()), 0)
+    w4 = ops.cast_h(ops.pack_weight_ups4(wp, Co, Ci), dt)
+    y = ops.conv2d_hp_ups4(x, w4, b, Co)
+    assert y.shape == (N, 2 * H, 2 * W, Co) and y.dtype == dt
+    assert torch.equal(y, ops.conv2d_hp_ups4(x, w4, b, Co))
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    # reference per class from the rounded class filters
+    w4d = w4.float().cpu().double()                                     # [4, Co, 2, 2, Ci]
+    for n in sorted({0, N - 1}):
+        xs = x[n].float().cpu().double().permute(2, 0, 1)[None]        # [1, Ci, H, W]
+        got = y[n].float().cpu().double()                               # [2H, 2W, Co]
+        for cls in range(4):
+            ph, pw = cls >> 1, cls & 1
+            xp = F.pad(xs, (1 - pw, pw, 1 - ph, ph))                    # window origin (a - 1 + ph, b - 1 + pw)
+            ref = F.conv2d(xp, w4d[cls].permute(0, 3, 1, 2).contiguous(), b.cpu().double())[0].permute(1, 2, 0)      # [H, W, Co]
+            err = (got[ph::2, pw::2] - ref).abs()
+            assert (err <= ref.abs() * eps + 2e-5 * ref.abs().max()).all(), (n, cls, float(err.max()))
+    yh = ops.conv2d_h(x, ops.pack_weight_h(w.to(dev()), dtype=dt), b, Co, 3, 3, (1, 1), (1, 1), ups=True)
+    d = (y.float() - yh.float()).abs()
+    assert float(d.max()) <= 16 * eps * float(yh.float().abs().max()), float(d.max())
+
+
 def F_conv(x, w, b):
     return F.conv2d(x, w, b, padding=(1, 0))
 

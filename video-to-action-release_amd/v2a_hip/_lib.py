@@ -162,6 +162,8 @@ SIGNATURES = {
     "v2a_conv2d_x3t_eligible": (I, [I] * 7),
     "v2a_conv2d_x3p_eligible": (I, [I] * 5),
     "v2a_conv2d_x3p_ups4_eligible": (I, [I] * 5),
+    "v2a_conv2d_hp_ups4_eligible": (I, [I] * 5),
+    "v2a_conv2d_fwd_hp_ups4": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "v2a_pack_weight_ups4": (I, [P, P, I, I, P]),
     "v2a_conv2d_fwd_x3p_ups4": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "v2a_conv2d_fwd_x3p_gn": (I, [P, P, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, P]),

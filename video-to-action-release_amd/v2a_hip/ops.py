@@ -969,6 +969,24 @@ def conv2d_x3p_ups4(x, w_ups4, bias, Cout):
     return y
 
 
+def conv2d_hp_ups4_ok(N, OH, OW, C, Cout):
+    return bool(lib.v2a_conv2d_hp_ups4_eligible(N, OH, OW, C, Cout))
+
+
+def conv2d_hp_ups4(x, w_ups4, bias, Cout):
+    """16-bit Upsample (nearest x2) + 3x3 / pad 1 conv of x [N, H, W, C] -> [N, 2H, 2W, Cout] as four 2x2 class convs over x
+    (csrc/igemm_hp.hip); w_ups4 = the pre-summed class filters [4, Cout, 2, 2, C] in x's dtype."""
+    _chk_h(x, "x")
+    _set_fmt(x.dtype)
+    N, H, W, C = x.shape
+    assert w_ups4.dtype == x.dtype
+    y = torch.empty((N, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+    last_kernel[0] = "conv_patch_h_ups4<512x128>"
+    check(lib.v2a_conv2d_fwd_hp_ups4(x.data_ptr(), w_ups4.data_ptr(), _p(bias), y.data_ptr(), _zero_line(x.device).data_ptr(), N, 2 * H, 2 * W,
+                                     C, Cout, _stream()), "conv2d_fwd_hp_ups4")
+    return y
+
+
 def groupnorm_fwd_h(x, gamma, beta, G, act="none", eps=1e-5, x2=None, stats=None, stats2=None):
     """bf16-storage GroupNorm + activation: x [N,S,C1] (+ x2 [N,S,C2] virtual concat) bf16 -> y [N,S,C] bf16.
     stats / stats2: the per-64-row statistic slabs conv2d_h(want_stats=True) returned with x / x2 (skips the statistics pass)."""

@@ -71,14 +71,17 @@ class _Packs:
         self.P = P
         self._c = {}
 
-    def get_ups4(self, name):
-        """The four class filters of an Upsample + 3x3 conv (ops.pack_weight_ups4), refreshed with the weight like every other pack."""
+    def get_ups4(self, name, half=False):
+        """The four class filters of an Upsample + 3x3 conv (ops.pack_weight_ups4: sums of the fp32 taps), refreshed with the weight like
+        every other pack.  half: the 16-bit dtype of the copy the 16-bit kernel takes (rounded once, from the fp32 sums)."""
         w = self.P[name]
         key = (w.data_ptr(), w._version)
-        ck = (name, "ups4", 0)
+        ck = (name, "ups4", half)
         ent = self._c.get(ck)
         if ent is None or ent[0] != key:
-            pk = ops.pack_weight_ups4(self.get(name), w.shape[0], w.shape[1], None if ent is None else ent[1])
+            pk = ops.pack_weight_ups4(self.get(name), w.shape[0], w.shape[1], None if (ent is None or half) else ent[1])
+            if half:
+                pk = ops.cast_h(pk, half)
             ent = (key, pk)
             self._c[ck] = ent
         return ent[1]
@@ -181,6 +184,22 @@ class UNetEngine:
         has_t = self.has(name + ".temporal_conv.weight")
         t_half = has_t and cout % 64 == 0
         sp_f32 = (has_t and not t_half) or (out_f32 and not has_t)
+        if (ups and k == 3 and stride == 1 and x2 is None and t_half and not isinstance(x, _LazyGN) and not sp_f32
+                and ops.conv2d_hp_ups4_ok(B * Fr, 2 * H, 2 * W, C, cout)):
+            # Upsample + 3x3 as four 2x2 class convs over the source map: 4 of the 9 products per output (csrc/igemm_hp.hip)
+            y = ops.conv2d_hp_ups4(x.view(B * Fr, H, W, C), self.packs.get_ups4(self.pre + name + ".spatial_conv.weight", half=self.hdt),
+                                   self.p(name + ".spatial_conv.bias"), cout)
+            OH, OW = 2 * H, 2 * W
+            z = ops.conv2d_h(y.view(B, Fr, OH * OW, cout), self.w(name + ".temporal_conv.weight", half=True),
+                             self.p(name + ".temporal_conv.bias"), cout, 3, 1, (1, 1), (1, 0), rowvec=rowvec,
+                             rows_per_batch=Fr * OH * OW, residual=None if residual is None else residual.view(B, Fr, OH * OW, cout),
+                             out_f32=out_f32, want_stats=not out_f32)
+            stats = None
+            if not out_f32:
+                z, stats = z
+            out = z.view(B, Fr, OH, OW, cout)
+            out._gn_stats = stats
+            return out
         pre_gn = None
         if isinstance(x, _LazyGN):
             assert x2 is None
