@@ -593,6 +593,17 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
         return y
 
     ops.conv2d_x3p_ups4 = timed_u4
+    orig_u4h = ops.conv2d_hp_ups4
+
+    def timed_u4h(xs, w4, bias, cout):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_u4h(xs, w4, bias, cout)
+        e1.record()
+        recs.append((ops.last_kernel[0], 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * 9 * xs.shape[-1], e0, e1))
+        return y
+
+    ops.conv2d_hp_ups4 = timed_u4h
     try:
         eng = unet._engine()
         lab = eng.label_embedding(te)
@@ -604,6 +615,7 @@ def video_leg(torch, device, batch=16, sampling_steps=50, traffic_leg="video", s
         ops.conv2d_h = orig_h
         ops.conv2d_x3p_gn = orig_gn
         ops.conv2d_x3p_ups4 = orig_u4
+        ops.conv2d_hp_ups4 = orig_u4h
     agg = {}
     for name, fl, e0, e1 in recs:
         v = agg.setdefault(name, [0.0, 0.0, 0])

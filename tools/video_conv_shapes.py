@@ -67,10 +67,11 @@ def wrap_ups4(fn):                 # (x, w_ups4, bias, Cout): algorithmic FLOPs 
     return f
 
 
-ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn, ops.conv2d_x3p_ups4 = wrap(o1), wrap(o2), wrap_gn(o3), wrap_ups4(o4)
+o5 = ops.conv2d_hp_ups4
+ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn, ops.conv2d_x3p_ups4, ops.conv2d_hp_ups4 = wrap(o1), wrap(o2), wrap_gn(o3), wrap_ups4(o4), wrap_ups4(o5)
 m(x, t, task_embed=te)
 torch.cuda.synchronize()
-ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn, ops.conv2d_x3p_ups4 = o1, o2, o3, o4
+ops.conv2d, ops.conv2d_h, ops.conv2d_x3p_gn, ops.conv2d_x3p_ups4, ops.conv2d_hp_ups4 = o1, o2, o3, o4, o5
 agg = {}
 for key, fl, e0, e1 in recs:
     a = agg.setdefault(key, [0.0, 0.0, 0])
