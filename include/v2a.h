@@ -248,6 +248,12 @@ int v2a_split3_f32(const float* x, void* y3, size_t n, size_t plane_stride, v2a_
    filter tap as in round 5; 1 (default) = class-major tile rows whose K loop walks the live taps only (2.25 of 9 for a 3 x 3 filter).
    Returns the old value.  Process-wide. */
 int v2a_debug_set_parity_classes(int on);
+/* 3 x 3 / stride 1 / pad 1 convs over small square maps (32 / 16 / 8 / 4: the policy's ResNet-18 encoders, torchvision BasicBlock as built by
+   diffusion_policy/model/vision/model_getter.py + multi_image_obs_encoder.py): 1 when v2a_conv2d_fwd_dma_f32 / _d run the problem on
+   conv_maps_x3 (256-row tiles, phases of 36 MFMAs; csrc/igemm_x3m.hip).  v2a_debug_set_maps_kernel(0) keeps them on conv_halo_x3 (the
+   round-5 form; measurement / test hook, returns the old value, process-wide). */
+int v2a_conv2d_x3m_eligible(int N, int S, int C, int Cout);
+int v2a_debug_set_maps_kernel(int on);
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */
 int v2a_get_f32_conv_mode(void);
 int v2a_debug_timestamp(uint64_t* dst, v2a_stream_t s);   /* measurement aid: *dst = constant-rate wall clock (100 MHz) when the stream gets here */

@@ -1132,6 +1132,46 @@ def test_three_plane_halo_conv_vs_fp64(N, HW, Ci, Co, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,HW,Ci,Co,res", [(64, 32, 64, 64, True), (64, 16, 128, 128, False), (64, 8, 256, 256, True), (64, 4, 512, 512, False),
+                                             (48, 32, 64, 64, False), (64, 8, 96, 256, True), (128, 4, 160, 512, True), (192, 16, 32, 64, False)])
+def test_three_plane_small_map_conv_vs_fp64(N, HW, Ci, Co, res):
+    """conv_maps_x3 (csrc/igemm_x3m.hip): the 3x3 / stride 1 / pad 1 convs of the policy's ResNet-18 encoders at batch 64 (64 ch x 32^2,
+    128 x 16^2, 256 x 8^2, 512 x 4^2: 1 / 2 / 4 / 8 slabs over 32-channel chunks), plus an uneven slab count (5 chunks in 3 slabs), one chunk
+    per workgroup, a single-chunk layer and a tile count that is not a power of two.  Against fp64 torch at the fp32 budget of the path, and
+    against conv_halo_x3 on the same inputs (same six plane products per block; the reduction is cut differently)."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_f32_conv_mode() != 1 or lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 three-plane mode only")
+    assert lib.v2a_conv2d_x3m_eligible(N, HW, Ci, Co) == 1
+    g = torch.Generator().manual_seed(N * HW + Ci)
+    x = torch.randn(N, Ci, HW, HW, generator=g) * torch.rand(N, Ci, HW, HW, generator=g).mul(4).exp2()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    r = torch.randn(N, Co, HW, HW, generator=g) if res else None
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    wp = ops.pack_weight(w.to(dev()), 0)
+    xd, rd, bd = nhwc(x), (nhwc(r) if res else None), b.to(dev())
+    y = ops.conv2d(xd, wp, bd, Co, 3, 3, (1, 1), (1, 1), residual=rd)
+    assert ops.last_kernel[0] == f"conv_maps_x3<{HW}>", ops.last_kernel[0]
+    err = (nchw(y).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 5e-6, err
+    old = lib.v2a_debug_set_maps_kernel(0)
+    try:
+        y0 = ops.conv2d(xd, wp, bd, Co, 3, 3, (1, 1), (1, 1), residual=rd)
+        assert ops.last_kernel[0].startswith("conv_halo_x3"), ops.last_kernel[0]
+    finally:
+        lib.v2a_debug_set_maps_kernel(old)
+    d = (y.double() - y0.double()).abs().max().item() / ref.abs().max().item()
+    assert d < 2e-6, d
+    from conftest import parity_record
+    parity_record(f"conv_maps_x3 {N}x{HW}x{HW} {Ci}->{Co} vs fp64", err, 5e-6)
+    parity_record("conv_maps_x3 vs conv_halo_x3", d, 2e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,H,W,Ci,Co,ups,res", [(1, 128, 128, 32, 64, False, False), (2, 24, 48, 96, 128, False, True), (1, 8, 16, 64, 64, False, False),
                                                  (2, 16, 16, 64, 128, True, True), (1, 64, 64, 32, 64, True, False), (3, 12, 24, 160, 64, True, False),
                                                  (4, 4, 4, 128, 64, True, False)])

@@ -1594,6 +1594,7 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ x, float* __re
 }
 
 static void f32_conv_mode_init();
+static int g_maps_on = 1;     // conv_maps_x3 for the small square maps (v2a_debug_set_maps_kernel: A/B hook)
 static int g_pcls_on = 1;     // parity-class tiles for zero-interleaved inputs (v2a_debug_set_parity_classes: A/B hook of the tests)
 static int g_f32x3 = -1;      // fp32 convs by three bf16 planes (conv_igemm_f32x3): V2A_F32_CONV=exact / v2a_set_f32_conv_mode(0) select the exact-f32 MFMA kernels
 // Tile / split plan shared by the LDS-DMA conv families.  128-row tiles (64 output columns for 64-wide layers); problems that 128-row
@@ -1658,6 +1659,10 @@ size_t v2a_conv2d_dma_f32_workspace_bytes(int M, int Cout, int K) {
     if (K % 9 == 0 && (K / 9) % 32 == 0 && M % 128 == 0 && Cout % 64 == 0) {      // the halo kernel may take it (geometry permitting)
         const int sh = conv_halo_x3_split(M, Cout, K / 9);
         if (sh > s) s = sh;
+        if (M % 256 == 0) {                                                          // ... or conv_maps_x3 (csrc/igemm_x3m.hip)
+            const int sm = conv_maps_x3_split(M, Cout, K / 9);
+            if (sm > s) s = sm;
+        }
     }
     return s > 1 ? (size_t)s * M * Cout * sizeof(float) : 0;
 }
@@ -1733,6 +1738,19 @@ static int conv_dma_launch(const void* x, const void* x2, const void* w_packed, 
             v2a_conv2d_x3p_eligible(N, OH, OW, C1, Cout))
             return conv_patch_x3_launch((const float*)x, (const float*)w_packed, bias, (const float*)residual, (float*)y, zeros, N, OH, OW, C1,
                                         Cout, ups, stream);
+        // ... on small square maps (the policy's ResNet-18 encoders at batch 64): 256-row tiles, phases of 36 MFMAs (csrc/igemm_x3m.hip)
+        if (g_f32x3 && g_maps_on && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && idil == 1 && !x2 && C2 == 0 &&
+            !ups && OH == H && OW == W && OH == OW && !stats && !rowvec && y && conv_maps_x3_eligible(N, OW, C1, Cout)) {
+            s = conv_maps_x3_split(p.M, Cout, C1);
+            if (s > 1 && (size_t)s * p.M * Cout * sizeof(float) > workspace_bytes) return V2A_ERR_WORKSPACE;
+            p.splitk = s;
+            p.ktiles_per_split = cdiv(C1 / 32, s);
+            p.frame_tiles = 0;
+            const int rc = conv_maps_x3_launch((const float*)x, (const float*)w_packed, bias, (const float*)residual, (float*)y, p.partial, zeros,
+                                               N, OW, C1, Cout, s, stream);
+            if (rc != V2A_OK) return rc;
+            goto launched;
+        }
         const bool hx_square = OH == OW && (OW == 4 || OW == 8 || OW == 16 || OW == 32 || OW == 64);
         const bool hx_patch = !hx_square && OH % 8 == 0 && OW % 16 == 0;
         if (g_f32x3 && xpitch == 0 && KH == 3 && KW == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && idil == 1 &&
@@ -1851,6 +1869,13 @@ static void f32_conv_mode_init() {
         const char* e = getenv("V2A_F32_CONV");
         g_f32x3 = (e && e[0] == 'e') ? 0 : 1;
     }
+}
+// 1 when v2a_conv2d_fwd_dma_f32 / _d run this 3 x 3 / stride 1 / pad 1 conv over N square S x S maps on conv_maps_x3 (three-plane mode)
+int v2a_conv2d_x3m_eligible(int N, int S, int C, int Cout) { return g_maps_on ? conv_maps_x3_eligible(N, S, C, Cout) : 0; }
+int v2a_debug_set_maps_kernel(int on) {         // returns the old value; 0: the small square maps stay on conv_halo_x3 (round-5 form)
+    const int old = g_maps_on;
+    g_maps_on = on ? 1 : 0;
+    return old;
 }
 int v2a_debug_set_parity_classes(int on) {      // returns the old value; 0: every tap of a zero-interleaved input is multiplied (round-5 form)
     const int old = g_pcls_on;

@@ -9,3 +9,8 @@ int conv_patch_x3_launch(const float* x, const float* w_packed, const float* bia
                          int H, int W, int C, int Cout, int ups, hipStream_t stream);
 extern "C" int v2a_conv2d_x3p_eligible(int N, int H, int W, int C, int Cout);
 int conv_patch_x3_ups4_eligible(int N, int H, int W, int C, int Cout, int ncu);
+// conv_maps_x3 (csrc/igemm_x3m.hip): 3 x 3 / stride 1 / pad 1 over N square maps of S = 32 / 16 / 8 / 4, split over 32-channel chunks
+int conv_maps_x3_eligible(int N, int S, int C, int Cout);
+int conv_maps_x3_split(int M, int Cout, int C);
+int conv_maps_x3_launch(const float* x, const float* w_packed, const float* bias, const float* residual, float* y, float* partial,
+                        const void* zeros, int N, int S, int C, int Cout, int splitk, hipStream_t stream);

@@ -225,6 +225,8 @@ def _conv2d_dma_f32(x, w_packed, bias, Cout, KH, KW, stride, pad, x2, rowvec, ro
             and x2 is None and (OH, OW) == ((2 * H, 2 * W) if ups else (H, W)) and (sq or (OH % 8 == 0 and OW % 16 == 0))
             and M % 128 == 0 and Cout % 64 == 0 and not want_stats and N * H * W * C1 < 2 ** 31):
         last_kernel[0] = f"conv_halo_x3<{OW}>" if sq else "conv_halo_x3<8x16>"
+        if sq and not ups and rowvec is None and lib.v2a_conv2d_x3m_eligible(N, OW, C1, Cout):
+            last_kernel[0] = f"conv_maps_x3<{OW}>"
         if rowvec is None and lib.v2a_conv2d_x3p_eligible(N, OH, OW, C1, Cout):
             last_kernel[0] = "conv_patch_x3<256x128>"
     if (lib.v2a_get_f32_conv_mode() == 1 and (KH, KW, sh, sw, ph, pw) == (3, 1, 1, 1, 1, 0) and not ups and idil == 1 and x2 is None
