@@ -48,7 +48,8 @@ struct MX3 {
     static constexpr int P = OWC == 32 ? 34 : OWC == 16 ? 18 : OWC == 8 ? 12 : 6;      // slot pitch of a halo row
     static constexpr int HS = (PH + 2) * P + (OWC == 4 ? 4 : 0);         // slots per map
     static constexpr int NS = SP * HS;                                   // 340 / 324 / 480 / 640
-    static constexpr int PHB = NS * 64;                                  // bytes of one plane of the halo image
+    static constexpr int PHB = (NS + 1) * 64;                            // bytes of one plane of the halo image (+ a dump slot: threads without a
+                                                                         // pixel store there, never read -- no branches in the phase body)
     static constexpr int TAPB = BN * 32, PWB = 3 * TAPB, WST = 3 * PWB;  // weight stage: [plane][tap kw][64 rows x 32 B]
     static constexpr int W_OFF = 3 * PHB;
     static constexpr int SMEM = W_OFF + 2 * WST;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv_maps_x3(const ConvDescX3M p) {
     const int img0 = m0 / G::PIX, row0 = (m0 % G::PIX) / OWC;            // (row0 = 0 when the tile holds whole maps)
 
     // ---- halo loader: item q = j * 512 + tid -> slot q >> 2, float4 q & 3 of the half's 16 channels
-    int a_dst[AJ];                                           // LDS byte offset for half 0 (half 1: ^ 32); -1: no such slot / pad slot
+    int a_dst[AJ];                                           // LDS byte offset for half 0 (half 1: ^ 32); no such slot / pad slot: the dump slot
     uint32_t a_off[AJ];                                      // element offset of the slot's pixel in x (+ float4 index); ~0: zero line
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
@@ -103,11 +104,11 @@ __global__ __launch_bounds__(512, 1) void conv_maps_x3(const ConvDescX3M p) {
         const bool valid = slot < NS && hy < G::PH + 2 && hx < OWC + 2;
         const int ih = row0 + hy - 1, iw = hx - 1;
         const bool ok = valid && (unsigned)ih < (unsigned)OWC && (unsigned)iw < (unsigned)OWC;
-        a_dst[j] = valid ? slot * 64 + ((((c4 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c4 & 1) << 3)) : -1;
+        a_dst[j] = valid ? slot * 64 + ((((c4 >> 1) ^ ((slot >> 2) & 3)) << 4) | ((c4 & 1) << 3)) : NS * 64;
         a_off[j] = ok ? ((uint32_t)((img0 + sp) * OWC + ih) * (uint32_t)OWC + (uint32_t)iw) * (uint32_t)p.C + (uint32_t)(c4 * 4) : 0xffffffffu;
     }
     int la_c = ck_begin, la_h = 0;                           // the (chunk, half) being LOADED: one period ahead of the one computed
-    f32x4 ra[AJ], rw0[2], rw1[2], rw2[2];                 // three weight sets: phase g + 3 is requested while g + 1 is split, g + 2 in flight
+    f32x4 ra[AJ];
     // (no branches around the loads: past the end of the slice and outside the map they read the zero line -- a conditional load makes
     // the compiler's wait-count bookkeeping fall back to vmcnt(0) everywhere)
     auto issue_a = [&]() {
@@ -121,10 +122,10 @@ __global__ __launch_bounds__(512, 1) void conv_maps_x3(const ConvDescX3M p) {
         la_h ^= 1;
         la_c += la_h == 0 ? 1 : 0;
     };
-    auto store_a = [&](int hd) {
+    auto store_a = [&](int hd, int j0, int j1) {            // items [j0, j1) of the thread (the conversion work is spread over two phases)
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            if (a_dst[j] < 0) continue;
+            if (j < j0 || j >= j1) continue;
             uint32_t h0, m0_, l0, h1, m1, l1;
             v2a_split3x2(ra[j][0], ra[j][1], h0, m0_, l0);
             v2a_split3x2(ra[j][2], ra[j][3], h1, m1, l1);
@@ -134,41 +135,50 @@ __global__ __launch_bounds__(512, 1) void conv_maps_x3(const ConvDescX3M p) {
             *reinterpret_cast<uint2*>(d + 2 * PHB) = uint2{l0, l1};
         }
     };
-    // ---- weight loader of a phase (c, h, kh): item k = j * 512 + tid (k < 768): tap kw = k >> 8, row (k & 255) >> 2, float4 k & 3 of its
-    // 16 channels.  LDS: 32-B rows in pairs, the pair's four 16-B pieces XOR-ed with (n >> 3) & 3 (conv_patch_x3's layout)
+    // ---- weight loader of a phase (c, h, kh), 3 taps x 64 rows x 16 channels over 512 threads without a branch: a float4 of tap tid >> 8
+    // (row (tid & 255) >> 2, channels 4 (tid & 3) ..) and a float2 of tap 2 (row tid >> 3, channels 2 (tid & 7) ..).  LDS: 32-B rows in pairs,
+    // the pair's four 16-B pieces XOR-ed with (n >> 3) & 3 (conv_patch_x3's layout)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_x3m;
+    typedef __attribute__((address_space(1))) f32x2_x3m gf32x2_x3m;
     const int wr_ld = (tid & 255) >> 2, wc4 = tid & 3;
-    const bool w2_on = tid < 256;                            // the thread's second item (tap 2) exists
+    const int w_tap0 = tid >> 8;
     const uint32_t w_src = (uint32_t)(n0 + wr_ld) * (uint32_t)p.K + (uint32_t)wc4 * 4u;
-    const int w_dst = (wr_ld >> 1) * 64 + ((((((wr_ld & 1) << 1) | (wc4 >> 1)) ^ ((wr_ld >> 3) & 3)) << 4) | ((wc4 & 1) << 3));
-    const int w_tap0 = tid >> 8;                             // tap of the first item (0 or 1); the second item is tap 2
+    const int w_dst = w_tap0 * TAPB + (wr_ld >> 1) * 64 + ((((((wr_ld & 1) << 1) | (wc4 >> 1)) ^ ((wr_ld >> 3) & 3)) << 4) | ((wc4 & 1) << 3));
+    const int wr2 = tid >> 3, we2 = tid & 7;
+    const uint32_t w_src2 = (uint32_t)(n0 + wr2) * (uint32_t)p.K + (uint32_t)we2 * 2u;
+    const int w_dst2 = 2 * TAPB + (wr2 >> 1) * 64 + ((((((wr2 & 1) << 1) | (we2 >> 2)) ^ ((wr2 >> 3) & 3)) << 4) | ((we2 & 3) << 2));
+    struct WSet { f32x4 a; f32x2_x3m b; };
     int lw_c = ck_begin, lw_h = 0, lw_kh = 0;
-    auto issue_w = [&](f32x4 (&r)[2]) {
+    auto issue_w = [&](WSet& r) {
         const bool live = lw_c < ck_end;
-        const float* wb = p.w + w_src + (size_t)(lw_kh * 3) * p.C + lw_c * 32 + lw_h * 16;
-        const float* g0 = live ? wb + (size_t)w_tap0 * p.C : zsrc;
-        const float* g1 = (live && w2_on) ? wb + (size_t)2 * p.C : zsrc;
-        r[0] = *(const gf32x4_x3m*)(uint64_t)g0;
-        r[1] = *(const gf32x4_x3m*)(uint64_t)g1;
+        const float* wb = p.w + (size_t)(lw_kh * 3) * p.C + lw_c * 32 + lw_h * 16;
+        const float* g0 = live ? wb + w_src + (size_t)w_tap0 * p.C : zsrc;
+        const float* g1 = live ? wb + w_src2 + (size_t)2 * p.C : zsrc;
+        r.a = *(const gf32x4_x3m*)(uint64_t)g0;
+        r.b = *(const gf32x2_x3m*)(uint64_t)g1;
         if (++lw_kh == 3) {
             lw_kh = 0;
             lw_h ^= 1;
             lw_c += lw_h == 0 ? 1 : 0;
         }
     };
-    auto store_w = [&](const f32x4 (&r)[2], int stage) {
-        unsigned char* wbs = smem + W_OFF + stage * WST + w_dst;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t == 1 && !w2_on) break;
-            uint32_t h0, m0_, l0, h1, m1, l1;
-            v2a_split3x2(r[t][0], r[t][1], h0, m0_, l0);
-            v2a_split3x2(r[t][2], r[t][3], h1, m1, l1);
-            unsigned char* d = wbs + (t == 0 ? w_tap0 : 2) * TAPB;
-            *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
-            *reinterpret_cast<uint2*>(d + PWB) = uint2{m0_, m1};
-            *reinterpret_cast<uint2*>(d + 2 * PWB) = uint2{l0, l1};
-        }
+    auto store_w = [&](const WSet& r, int stage) {
+        unsigned char* wbs = smem + W_OFF + stage * WST;
+        uint32_t h0, m0_, l0, h1, m1, l1, h2, m2, l2;
+        v2a_split3x2(r.a[0], r.a[1], h0, m0_, l0);
+        v2a_split3x2(r.a[2], r.a[3], h1, m1, l1);
+        v2a_split3x2(r.b[0], r.b[1], h2, m2, l2);
+        unsigned char* d = wbs + w_dst;
+        *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(d + PWB) = uint2{m0_, m1};
+        *reinterpret_cast<uint2*>(d + 2 * PWB) = uint2{l0, l1};
+        unsigned char* d2 = wbs + w_dst2;
+        *reinterpret_cast<uint32_t*>(d2) = h2;
+        *reinterpret_cast<uint32_t*>(d2 + PWB) = m2;
+        *reinterpret_cast<uint32_t*>(d2 + 2 * PWB) = l2;
     };
+
+    WSet rw0, rw1, rw2;                                      // three weight sets: phase g + 3 is requested while g + 1 is split, g + 2 in flight
 
     // ---- compute mapping: wave = (64-row group wm, 32-channel group wn); sub-tile i = 32 rows x 32 channels
     const int wm = wid >> 1, wn = (wid & 1) * 32;
@@ -206,7 +216,6 @@ __global__ __launch_bounds__(512, 1) void conv_maps_x3(const ConvDescX3M p) {
         for (int q = 0; q < 3; ++q) f.b[q] = *reinterpret_cast<const bfx8_x3m*>(wb + q * PWB);
     };
     auto frag_mfma = [&](const Frag& f) {
-        asm volatile("" ::: "memory");
 #define V2A_X3M_PROD(QA, QB)                                                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                   \
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][QA], f.b[QB], acc[i], 0, 0, 0);
@@ -220,49 +229,63 @@ __global__ __launch_bounds__(512, 1) void conv_maps_x3(const ConvDescX3M p) {
     };
     Frag f0, f1;
 
-    // ---- prologue: halo (first chunk, half 0) and weight phases 0, 1, 2 requested together; phase 0 into LDS
+    // ---- prologue: halo (first chunk, half 0) and weight phases 0, 1, 2 requested together; phase 0 into LDS, its first tap requested
     issue_a();
     issue_w(rw0);
     issue_w(rw1);
     issue_w(rw2);
-    store_a(0);
+    store_a(0, 0, AJ);
     store_w(rw0, 0);
     __syncthreads();
+    frag_load(f0, 0, 0, 0, 0);
 
-    // The two waves of a SIMD (w and w + 4) run the phase in different orders: waves 4-7 split the next phase's operands BEFORE their
-    // MFMAs, waves 0-3 between their second and third tap -- the conversion VALU of one wave executes under the MFMAs of the other
-    // (in step, the eight waves alternate between "everyone converts" and "everyone multiplies": measured 0.85 + 1.2 us per phase)
-    const bool early = wid >= 4;
+    // A phase's barrier sits between its second and third tap: the operands of phase + 1 (stored behind the first tap) are visible from
+    // there on, so the first tap of phase + 1 is requested before the MFMAs of this phase's third tap -- every fragment request has a tap
+    // of MFMAs to land.  (All reads of this phase's weight stage / halo half are complete at that barrier (lgkmcnt(0) in front of it):
+    // the stores of phase + 1, which re-use the stage, come after it.)  Fragment sets alternate: on entry X holds tap 0 of the phase.
+    constexpr int AJ1 = (AJ + 1) / 2;                        // halo items converted in the group's second phase (the rest in its third)
+    constexpr int AV1 = (22 * AJ1 + 11) / 12, AV2 = (22 * (AJ - AJ1) + 11) / 12;
     for (int c = ck_begin; c < ck_end; ++c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(slot0[i]));
+    // (the 12 MFMAs of a tap with NV_ VALU instructions behind each -- conversions run in the MFMAs' issue shadow, at most five
+    // single-issue instructions fit per 32-cycle MFMA: MI355X_MICROARCH.md -- then the NW_ LDS stores)
+#define V2A_X3M_MIX(NV_, NW_)                                                                                                   \
+    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV_, 0);                                                                    \
+    }                                                                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x200, NW_, 0);
 #define V2A_X3M_SET(I_) ((I_) % 3 == 0 ? rw0 : (I_) % 3 == 1 ? rw1 : rw2)
-#define V2A_X3M_PHASE(H_, KH_)                                                                                                  \
+#define V2A_X3M_PHASE(H_, KH_, X_, Y_)                                                                                          \
     {                                                                                                                           \
         constexpr int idx_ = (H_) * 3 + (KH_);          /* six phases per chunk: stage = idx & 1, register set = idx % 3 */          \
         constexpr int stage_ = idx_ & 1;                                                                                        \
-        frag_load(f0, H_, stage_, KH_, 0);                                                                                      \
-        frag_load(f1, H_, stage_, KH_, 1);                                                                                      \
+        constexpr int nh_ = (KH_) == 2 ? ((H_) ^ 1) : (H_), nkh_ = (KH_) == 2 ? 0 : (KH_) + 1;   /* the next phase */                 \
+        frag_load(Y_, H_, stage_, KH_, 1);                                                                                      \
         issue_w(V2A_X3M_SET(idx_));                      /* phase + 3 into the set whose phase went into LDS one phase ago */       \
         if ((KH_) == 0) issue_a();                       /* the halo of the next (chunk, half) ... */                             \
-        if (early) {                                                                                                            \
-            store_w(V2A_X3M_SET(idx_ + 1), stage_ ^ 1);  /* phase + 1: its stage's readers passed the last barrier */               \
-            if ((KH_) == 2) store_a((H_) ^ 1);           /* ... into the half whose readers passed the barriers of the last (c, h) */ \
-        }                                                                                                                       \
-        frag_mfma(f0);                                                                                                          \
-        frag_load(f0, H_, stage_, KH_, 2);                                                                                      \
-        frag_mfma(f1);                                                                                                          \
-        if (!early) {                                                                                                           \
-            store_w(V2A_X3M_SET(idx_ + 1), stage_ ^ 1);                                                                         \
-            if ((KH_) == 2) store_a((H_) ^ 1);                                                                                  \
-        }                                                                                                                       \
-        frag_mfma(f0);                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);               /* (requests stay in front of the MFMAs they hide under) */                \
+        frag_mfma(X_);                                                                                                          \
+        store_w(V2A_X3M_SET(idx_ + 1), stage_ ^ 1);      /* phase + 1: its stage's readers finished before the last barrier */       \
+        V2A_X3M_MIX(3, 9)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        frag_load(X_, H_, stage_, KH_, 2);                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        frag_mfma(Y_);                                                                                                          \
+        /* ... into the half whose readers finished two barriers ago, the conversions spread over the group's last two phases */  \
+        if ((KH_) == 1) { store_a((H_) ^ 1, 0, AJ1); V2A_X3M_MIX(AV1, 3 * AJ1) }                                                    \
+        if ((KH_) == 2) { store_a((H_) ^ 1, AJ1, AJ); V2A_X3M_MIX(AV2, 3 * (AJ - AJ1)) }                                            \
         __syncthreads();                                                                                                        \
+        frag_load(Y_, nh_, stage_ ^ 1, nkh_, 0);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        frag_mfma(X_);                                                                                                          \
     }
-        V2A_X3M_PHASE(0, 0) V2A_X3M_PHASE(0, 1) V2A_X3M_PHASE(0, 2)
-        V2A_X3M_PHASE(1, 0) V2A_X3M_PHASE(1, 1) V2A_X3M_PHASE(1, 2)
+        V2A_X3M_PHASE(0, 0, f0, f1) V2A_X3M_PHASE(0, 1, f1, f0) V2A_X3M_PHASE(0, 2, f0, f1)
+        V2A_X3M_PHASE(1, 0, f1, f0) V2A_X3M_PHASE(1, 1, f0, f1) V2A_X3M_PHASE(1, 2, f1, f0)
 #undef V2A_X3M_PHASE
 #undef V2A_X3M_SET
+#undef V2A_X3M_MIX
     }
 
     // ---- epilogue: lane = output column n0 + wn + lr; register r = row (r & 3) + 8 (r >> 2) + 4 lk of sub-tile i
