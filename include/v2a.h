@@ -252,6 +252,10 @@ int v2a_debug_set_parity_classes(int on);
    diffusion_policy/model/vision/model_getter.py + multi_image_obs_encoder.py): 1 when v2a_conv2d_fwd_dma_f32 / _d run the problem on
    conv_maps_x3 (256-row tiles, phases of 36 MFMAs; csrc/igemm_x3m.hip).  v2a_debug_set_maps_kernel(0) keeps them on conv_halo_x3 (the
    round-5 form; measurement / test hook, returns the old value, process-wide). */
+/* v2a_conv2d_fwd runs reductions of at most 64 values that its vector loader cannot take (ConditionalUnet1D's layers over the 7 action
+   channels: model/conditional_unet1d.py:137-160,198-201) on a direct kernel (conv_smallk, csrc/igemm.hip).  v2a_debug_set_smallk(0) sends
+   them back to the tile kernels (measurement / test hook; returns the old value, a negative argument only queries; process-wide). */
+int v2a_debug_set_smallk(int on);
 int v2a_conv2d_x3m_eligible(int N, int S, int C, int Cout);
 int v2a_debug_set_maps_kernel(int on);
 int v2a_set_f32_conv_mode(int x3);   /* fp32 convs: 1 = three-bf16-plane products (fp32-equivalent accuracy, default), 0 = exact-f32 MFMA; returns the old value */

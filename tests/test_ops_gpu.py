@@ -1132,6 +1132,45 @@ def test_three_plane_halo_conv_vs_fp64(N, HW, Ci, Co, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Ci,Co,kh,kw,st,pad,res", [(64, 1, 16, 7, 256, 1, 5, (1, 1), (0, 2), False), (64, 1, 16, 7, 256, 1, 1, (1, 1), (0, 0), True),
+                                                          (3, 1, 16, 7, 300, 1, 5, (1, 1), (0, 2), True), (2, 9, 11, 3, 40, 3, 3, (2, 1), (1, 1), False),
+                                                          (1, 5, 5, 1, 8, 5, 5, (1, 1), (2, 2), False), (5, 1, 8, 12, 16, 1, 5, (1, 2), (0, 2), True)])
+def test_direct_small_reduction_conv_vs_fp64(N, H, W, Ci, Co, kh, kw, st, pad, res):
+    """conv_smallk (csrc/igemm.hip): reductions of at most 64 values whose channel count the vector loaders cannot take -- the
+    ConditionalUnet1D layers over the 7 action channels (Conv1d k = 5 -> K = 35, 1 x 1 residual conv and the final conv's data gradient ->
+    K = 7) at batch 64, a ragged channel count above one 256-thread block, a strided 2-d case, a single input channel, K = 60.  Exact fp32 FMA
+    chains: against fp64 torch at 1e-6 of max |y|, and against the tile kernel on the same inputs."""
+    from v2a_hip import ops
+    from v2a_hip._lib import lib
+    if lib.v2a_get_precision() != 0:
+        pytest.skip("fp32 mode only")
+    g = torch.Generator().manual_seed(N * W + Ci)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, kh, kw, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pad)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    wp = ops.pack_weight(w.to(dev()), 0)
+    xd, rd, bd = nhwc(x), (nhwc(r) if res else None), b.to(dev())
+    y = ops.conv2d(xd, wp, bd, Co, kh, kw, st, pad, residual=rd)
+    assert ops.last_kernel[0].startswith("conv_smallk"), ops.last_kernel[0]
+    err = (nchw(y).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-6, err
+    old = lib.v2a_debug_set_smallk(0)
+    try:
+        y0 = ops.conv2d(xd, wp, bd, Co, kh, kw, st, pad, residual=rd)
+        assert not ops.last_kernel[0].startswith("conv_smallk"), ops.last_kernel[0]
+    finally:
+        lib.v2a_debug_set_smallk(old)
+    d = (y.double() - y0.double()).abs().max().item() / ref.abs().max().item()
+    assert d < 1e-6, d
+    from conftest import parity_record
+    parity_record(f"conv_smallk {N}x{H}x{W} {Ci}->{Co} k{kh}x{kw} vs fp64", err, 1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,HW,Ci,Co,res", [(64, 32, 64, 64, True), (64, 16, 128, 128, False), (64, 8, 256, 256, True), (64, 4, 512, 512, False),
                                              (48, 32, 64, 64, False), (64, 8, 96, 256, True), (128, 4, 160, 512, True), (192, 16, 32, 64, False)])
 def test_three_plane_small_map_conv_vs_fp64(N, HW, Ci, Co, res):

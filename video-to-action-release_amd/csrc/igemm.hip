@@ -2306,6 +2306,51 @@ static void wgrad_plan(int M, int Cout, int K, int* bm, int* bn, int* tiles, int
 extern "C" int v2a_get_f32_conv_mode(void);
 static int g_wgrad_dma = -1;  // fp32 weight gradients with 128-row output tiles on the LDS-DMA kernel (V2A_WGRAD_DMA=0 / v2a_debug_wgrad_dma)
 
+// Direct convolution for reductions of at most 64 values (ConditionalUnet1D's first layers over the 7 action channels: Conv1d k = 5 -> K = 35,
+// the 1 x 1 residual conv -> K = 7, the data gradient of the final 256 -> 7 conv -> K = 7; model/conditional_unet1d.py:137-160,198-201).
+// The tile kernels gather such operands scalar by scalar (33-47 us per launch for 9 MFLOP, on the critical path of the captured step);
+// here a workgroup stages the windows of `rows` output rows in LDS, a thread owns one output channel with its K weights in registers:
+// exact fp32 FMA chains in k order, bias / row vector / residual as the tile kernels' epilogue.
+static int g_smallk_on = 1;
+template <int KMAX>
+__global__ __launch_bounds__(256) void conv_smallk_kernel(const ConvDesc p, int rows) {
+    __shared__ float xs[8][KMAX];
+    const int co = blockIdx.y * 256 + threadIdx.x;
+    const int m0 = blockIdx.x * rows;
+    for (int i = threadIdx.x; i < rows * KMAX; i += 256) {
+        const int r = i / KMAX, k = i - r * KMAX, m = m0 + r;
+        float v = 0.f;
+        if (m < p.M && k < p.K) {
+            const int ci = k % p.C1, t = k / p.C1;
+            const int kw = t % p.KW, kh = t / p.KW;
+            const int ow = m % p.OW, t2 = m / p.OW;
+            const int oh = t2 % p.OH, n = t2 / p.OH;
+            const int ih = oh * p.sh - p.ph + kh, iw = ow * p.sw - p.pw + kw;
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) v = p.x[((size_t)(n * p.H + ih) * p.W + iw) * p.C1 + ci];
+        }
+        xs[r][k] = v;
+    }
+    float w[KMAX];
+    const bool live = co < p.Cout;
+    const float* wr = p.w + (size_t)(live ? co : 0) * p.K;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) w[k] = (k < p.K) ? wr[k] : 0.f;
+    __syncthreads();
+    if (!live) return;
+    const float b = p.bias ? p.bias[co] : 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const int m = m0 + r;
+        if (m >= p.M) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc = fmaf(xs[r][k], w[k], acc);     // (k >= K: both factors are zero)
+        float v = acc + b;
+        const size_t o = (size_t)m * p.Cout + co;
+        if (p.rowvec) v += p.rowvec[(size_t)(m / p.rows_per_batch) * p.Cout + co];
+        if (p.residual) v += p.residual[o];
+        p.y[o] = v;
+    }
+}
 extern "C" {
 
 // process-wide MFMA precision of the contraction kernels (0 = f32 exact, 1 = bf16 inputs / f32 accumulate); returns the old value
@@ -2365,6 +2410,12 @@ size_t v2a_conv2d_workspace_bytes(int M, int Cout, int K) {
 
 // Generic NHWC conv forward (also data-gradient / transposed conv via idil, upsample via ups, concat via x2).
 // replaces: torch Conv2d/Conv1d/Linear/ConvTranspose1d calls of the reference hot path (see file header).
+int v2a_debug_set_smallk(int on) {       // returns the old value; 0: the tile kernels take these layers (round-5 form; A/B hook); < 0: query only
+    const int old = g_smallk_on;
+    if (on >= 0) g_smallk_on = on ? 1 : 0;
+    return old;
+}
+
 int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const float* bias, const float* rowvec,
                    const float* residual, float* y, float* y2, int csplit, int N, int H, int W, int C1, int C2, int OH,
                    int OW, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int idil, int ups,
@@ -2387,6 +2438,14 @@ int v2a_conv2d_fwd(const float* x, const float* x2, const float* w_packed, const
                      (((uintptr_t)w_packed & 15) == 0);
     // the N-major (data-gradient) loader needs whole 16-wide k tiles inside one tap and float4 columns
     if (bmode && !(vec && Cout % 4 == 0)) return V2A_ERR_ARG;
+    if (g_smallk_on && !vec && !bmode && !x2 && C2 == 0 && !y2 && p.idil == 1 && !ups && p.K <= 64 && p.M <= (1 << 20)) {
+        const int rows = p.M >= 2048 ? 8 : 4;
+        const dim3 grid(cdiv(p.M, rows), cdiv(Cout, 256));
+        if (p.K <= 8) hipLaunchKernelGGL((conv_smallk_kernel<8>), grid, dim3(256), 0, stream, p, rows);
+        else hipLaunchKernelGGL((conv_smallk_kernel<64>), grid, dim3(256), 0, stream, p, rows);
+        V2A_CHECK_LAUNCH();
+        return V2A_OK;
+    }
     int bm, bn, tiles, s;
     conv_plan(p.M, Cout, p.K, &bm, &bn, &tiles, &s);
     // 32-deep tiles (full 128-B lines per row segment, half the barriers) pay off on the smaller tiles; the 128x128 tile keeps

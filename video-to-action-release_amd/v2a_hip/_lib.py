@@ -28,6 +28,7 @@ SIGNATURES = {
     "v2a_get_policy_half": (I, []),
     "v2a_debug_force_tile": (I, [I, I]),
     "v2a_debug_set_parity_classes": (I, [I]),
+    "v2a_debug_set_smallk": (I, [I]),
     "v2a_conv2d_x3m_eligible": (I, [I, I, I, I]),
     "v2a_debug_set_maps_kernel": (I, [I]),
     "v2a_debug_force_wgrad_plan": (I, [I, I, I]),

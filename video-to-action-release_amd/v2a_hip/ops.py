@@ -323,6 +323,11 @@ def conv2d(x, w_packed, bias, Cout, KH, KW, stride=(1, 1), pad=(0, 0), x2=None, 
                              _p(y2), csplit, N, H, W, C1, C2, OH, OW, Cout, KH, KW, sh, sw, ph, pw, idil, 1 if ups else 0,
                              rows_per_batch, bmode, _p(ws), wsb, _stream()), "conv2d_fwd")
     last_kernel[0] = _plan_name(lib.v2a_conv2d_plan, "conv_igemm_bf16" if lib.v2a_get_precision() == 1 else "conv_igemm_f32", M, Cout, K)
+    # mirrors v2a_conv2d_fwd (csrc/igemm.hip): reductions of <= 64 values the vector loader cannot take -> the direct kernel
+    vec = (C1 + C2) % 16 == 0 and C1 % 4 == 0 and x.data_ptr() % 16 == 0 and w_packed.data_ptr() % 16 == 0
+    if (not vec and not bmode and x2 is None and y2 is None and idil == 1 and not ups and K <= 64 and M <= (1 << 20)
+            and lib.v2a_debug_set_smallk(-1) == 1):
+        last_kernel[0] = "conv_smallk<8>" if K <= 8 else "conv_smallk<64>"
     return y
 
 
