@@ -862,14 +862,14 @@ def _flip_aware_rows(OP, sd, batch, noise, ts, names, hip_grads, eng_dec, tag):
     return _grad_distances(hip_grads, g32, g64, names), ref_loss
 
 
-# (B, generator seed): NOT selected.  Round 6 keeps four of round 5's six pairs -- (5, 2) and (6, 1) repeat tile / split plans that (3, 1),
-# (6, 3) and (7, 4) already cover, and each pair costs ~18 s of fp64 CPU oracle: the GPU suite has a 600-s budget
-RAGGED_CASES = [(1, 0), (3, 1), (6, 3), (7, 4)]
+# (B, generator seed): NOT selected.  Round 6 keeps three of round 5's six pairs -- (5, 2), (6, 1) and (6, 3) repeat tile / split plans that
+# (3, 1) and (7, 4) already cover, and each pair costs 18-36 s of fp64 CPU oracle depending on the box's host: the GPU suite has a 600-s budget
+RAGGED_CASES = [(1, 0), (3, 1), (7, 4)]
 
 
 def test_ragged_batch_loss_and_grads_vs_oracle():
     """Batches that fill no tile evenly (1024 ... 7168 conv rows at the first ResNet stage, 16 ... 112 rows in the ConditionalUnet1D):
-    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin; four unselected
+    partial row tiles, split-K plans and GroupNorm launches other than the B = 8 / 64 ones the fixtures pin; three unselected
     (batch size, seed) pairs, the loss and EVERY gradient tensor.
 
     Round 3 found that two correct fp32 implementations of this step do not always agree to 1e-4 on the encoder gradients at B <= 7:
