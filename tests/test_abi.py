@@ -90,3 +90,30 @@ def test_persistent_denoiser_structs_match_the_library():
     assert lib.v2a_policy_persist_lds_bytes(4, 4, 4, 2048, 5, 1, 2, 0) == 0          # batch 4 does not fit the LDS
     assert lib.v2a_policy_persist_lds_bytes(1, 16, 16, 256, 7, 1, 3, 0) == 0         # no 7-tap instance
     assert lib.v2a_policy_persist_lds_bytes(1, 8, 16, 256, 4, 2, 1, 1) > 0           # Upsample1d
+
+
+def test_small_map_conv_routing_is_decided_on_the_host():
+    """conv_maps_x3's eligibility and slab plan are host logic (csrc/igemm_x3m.hip conv_maps_x3_eligible / _split): the four ResNet-18 layer
+    shapes of the policy's encoders at batch 64 go to it, each with 256 workgroups (1 / 2 / 4 / 8 slabs over 32-channel chunks), and the
+    workspace v2a_conv2d_dma_f32_workspace_bytes reports covers those slabs; launches too small to fill the chip, maps that are not
+    32 / 16 / 8 / 4 wide, channel counts off the 32 / 64 grid and row counts off the 256-row tile stay on the older kernels; the debug
+    switch turns the route off and back on."""
+    from v2a_hip._lib import lib
+    for N, S, C, slabs in ((64, 32, 64, 1), (64, 16, 128, 2), (64, 8, 256, 4), (64, 4, 512, 8)):
+        assert lib.v2a_conv2d_x3m_eligible(N, S, C, C) == 1, (N, S, C)
+        M = N * S * S
+        need = slabs * M * C * 4 if slabs > 1 else 0
+        assert lib.v2a_conv2d_dma_f32_workspace_bytes(M, C, 9 * C) >= need, (N, S, C)
+    assert lib.v2a_conv2d_x3m_eligible(256, 32, 64, 64) == 1            # B = 256: 1024 tiles, one slab
+    assert lib.v2a_conv2d_x3m_eligible(8, 32, 64, 64) == 0              # 32 tiles x 2 chunks: 64 workgroups
+    assert lib.v2a_conv2d_x3m_eligible(64, 64, 64, 64) == 0             # 64-wide maps: the patch kernels
+    assert lib.v2a_conv2d_x3m_eligible(64, 16, 120, 128) == 0 and lib.v2a_conv2d_x3m_eligible(64, 16, 128, 96) == 0
+    assert lib.v2a_conv2d_x3m_eligible(3, 8, 256, 256) == 0             # 192 rows: no whole tile
+    old = lib.v2a_debug_set_maps_kernel(0)
+    try:
+        assert lib.v2a_conv2d_x3m_eligible(64, 32, 64, 64) == 0
+    finally:
+        lib.v2a_debug_set_maps_kernel(old)
+    assert lib.v2a_conv2d_x3m_eligible(64, 32, 64, 64) == 1
+    assert lib.v2a_debug_set_smallk(-1) in (0, 1)                       # query form: no change
+    assert lib.v2a_debug_set_smallk(-1) == lib.v2a_debug_set_smallk(-1)
